@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of BASELINE.json: Gelements/s of fused Q->DQ, BFP[8|8]{16}(SN) ("BFP16,
+group 16"), on a 4096x4096 bf16 tensor, and % of the MI355X HBM roofline.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N)
+
+One "step" = one pass of the hot path (`dmxq_bfp_qdq`, one kernel launch through the C ABI) over one
+4096x4096 bf16 tensor already resident in HBM.  Steps rotate over NBUF distinct input/output buffer pairs whose
+total footprint (>= 1.25 GiB) exceeds the 256 MiB Infinity Cache, so every step streams from/to HBM.
+Each rank (one process per GPU) works on its own tensors: the path shards with no data-path collective
+ -> weak scaling; RCCL is used only for the barrier and the max-over-ranks of the timing.
+
+The JSON line carries
+  roofline     : algorithmic bytes (4 B/element: 2 read + 2 written) / average launch duration measured with
+                 HIP events on the launch stream over the timed region, vs 8.0 TB/s peak HBM.
+  cpu_baseline : the reference's own compiled CPU kernel (oracle/_ref/quant_cpu.so, built from the reference
+                 sources) driven by a restatement of the reference's Format.cast loop, timed on this box's host
+                 cores (rank 0, N = 1 only, bounded sample).  Falls back to the C oracle port if _ref is absent.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+ROWS = COLS = 4096
+BLOCK, PRECISION = 16, 8
+PEAK_HBM = 8.0e12  # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_PER_ELEM = 4  # bf16 in + bf16 out (CastTo contract, numerical/cast.py:262,306)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--nbuf", type=int, default=20, help="distinct in/out buffer pairs (20 x 64 MiB = 1.25 GiB)")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--resident", action="store_true", help="also report the cache-resident (single buffer) rate")
+    return ap.parse_args()
+
+
+def synth(seed, device):
+    """N(0,1) * exp(2 * N(0,1)) in bf16: per-block exponent spread, generated on the device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    a = torch.randn(ROWS, COLS, generator=g, device=device)
+    b = torch.randn(ROWS, COLS, generator=g, device=device)
+    return (a * torch.exp(2.0 * b)).to(torch.bfloat16)
+
+
+def cpu_baseline(seconds):
+    """Times the reference CPU path on the host cores for the same 4096x4096 bf16 workload."""
+    import numpy as np  # noqa: F401
+
+    x = (torch.randn(ROWS, COLS, generator=torch.Generator().manual_seed(0))).to(torch.bfloat16)
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    kind, fn = None, None
+    try:
+        sys.path.insert(0, ref_dir)
+        import quant_cpu  # the reference's C++ extension, compiled from its own sources by oracle/Makefile
+
+        def fn():
+            # restatement of numerical/format.py:322-341 + cast.py:306 around the reference's native call
+            xf = x.float()
+            chunks = torch.split(xf.reshape(-1, COLS), BLOCK, dim=-1)
+            out = torch.cat([quant_cpu.block_quantize_nearest(c.contiguous(), PRECISION, 0, True) for c in chunks], dim=-1)
+            return out.reshape(ROWS, COLS).to(torch.bfloat16)
+
+        kind = "reference"
+    except Exception:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O
+
+        def fn():
+            return O.bfp_cast(x, PRECISION, BLOCK).to(torch.bfloat16)
+
+        kind = "port"
+    fn()  # cold call (page-in, allocator)
+    best, n, t_end = float("inf"), 0, time.perf_counter() + seconds
+    while n < 2 or (time.perf_counter() < t_end and n < 50):
+        t0 = time.perf_counter()
+        fn()
+        best = min(best, time.perf_counter() - t0)
+        n += 1
+    return {
+        "value": round(ROWS * COLS / best / 1e9, 5), "unit": "Gelements/s", "cores": torch.get_num_threads(),
+        "kind": kind,
+        "sample": f"{n} full passes over one 4096x4096 bf16 tensor (min time {best * 1e3:.1f} ms), "
+                  + ("reference quant_cpu.block_quantize_nearest per [4096,16] chunk inside the reference's split/cat loop"
+                     if kind == "reference" else "oracle/oracle.c OpenMP port, whole tensor"),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    import dmx_compressor_amd as d
+    from dmx_compressor_amd import _lib
+
+    L = _lib.lib()  # raises if libdmxq.so is missing: no fallback
+    ins = [synth(1000 * rank + i, dev) for i in range(args.nbuf)]
+    outs = [torch.empty_like(t) for t in ins]
+    numel = ROWS * COLS
+    bf16 = _lib.BF16
+
+    def launch(i, stream_ptr):
+        rc = L.dmxq_bfp_qdq(ctypes.c_void_p(ins[i].data_ptr()), ctypes.c_void_p(outs[i].data_ptr()), bf16, bf16,
+                            ROWS, COLS, 1, BLOCK, PRECISION, _lib.ROUND_NEAREST, 1, 0, stream_ptr)
+        if rc != 0:
+            raise RuntimeError(f"dmxq_bfp_qdq failed: {rc}")
+
+    stream = torch.cuda.Stream(device=dev)
+    sp = ctypes.c_void_p(stream.cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        for i in range(args.warmup):
+            launch(i % args.nbuf, sp)
+        graph = None
+        if not args.no_graph:
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                for i in range(args.steps):
+                    launch(i % args.nbuf, sp)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        e0.record(stream)
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(args.steps):
+                launch(i % args.nbuf, sp)
+        e1.record(stream)
+        barrier()
+        wall = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)
+
+    t = torch.tensor([wall, ev_ms / 1e3], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max, ev_max = float(t[0]), float(t[1])
+
+    resident = None
+    if args.resident:
+        with torch.cuda.stream(stream):
+            for _ in range(50):
+                launch(0, sp)
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            r0.record(stream)
+            for _ in range(500):
+                launch(0, sp)
+            r1.record(stream)
+            torch.cuda.synchronize(dev)
+        resident = numel / (r0.elapsed_time(r1) / 500 * 1e-3) / 1e9
+
+    # sanity: the timed launches really produced the quantised tensors (spot-check one pair against the module API)
+    chk = d.CastTo(format="BFP[8|8]{16}(SN)")(ins[0])
+    assert torch.equal(chk, outs[0]), "bench output differs from CastTo output"
+
+    if rank == 0:
+        ms_per_step = wall_max * 1e3 / args.steps
+        value = numel * world / (wall_max / args.steps) / 1e9
+        launch_s = ev_max / args.steps
+        achieved = BYTES_PER_ELEM * numel / launch_s
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Gelements/s fused Q->DQ (BFP16, group=16) on 4096x4096 bf16",
+            "value": round(value, 2), "unit": "Gelements/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BFP[8|8]{16}(SN) fused Q->DQ, 4096x4096 bf16 -> bf16, block_dim=-1, RNE "
+                                   "(BASELINE.json configs[1])",
+                       "buffers": f"{args.nbuf} rotating in/out pairs = {args.nbuf * 2 * numel * 2 / 2**30:.2f} GiB (> 256 MiB Infinity Cache)",
+                       "launch": "eager C-ABI calls" if args.no_graph else "hipGraph replay of the K C-ABI launches",
+                       "per_gpu_elements_per_step": numel},
+            "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                         "frac": round(achieved / PEAK_HBM, 4), "traffic": traffic,
+                         "kernel": "dmxq::bfp_rows_kernel<bf16,bf16,nearest,sym>",
+                         "algorithmic_bytes_per_launch": BYTES_PER_ELEM * numel,
+                         "avg_launch_us": round(launch_s * 1e6, 3)},
+        }
+        if resident is not None:
+            line["cache_resident_value"] = round(resident, 2)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,54 @@
+"""dmx_compressor_amd — MI355X (gfx950) native fake-quantisation / sparsity operator library.
+
+A drop-in for the hot path of d-matrix-ai/dmx-compressor (CastTo -> Format.cast -> {block,float,fixed}_quantize,
+the N:M mask, SmoothQuant scaling, the exact-function approximator slot): same vocabulary, hand-written HIP
+kernels behind the C ABI of include/dmxq.h.  There is no CPU fallback: ops raise without libdmxq.so / a GPU.
+"""
+from types import SimpleNamespace
+
+from . import ops, quant
+from ._lib import DmxqError, LIB_PATH
+from .cast import CastTo, CastToDict, CastToFormat
+from .format import (ROUNDING_MODE, BlockFloatingPoint, FixedPoint, FloatingPoint, Format, MXFP, MXINT, Same,
+                     ScaledBlockFloatingPoint)
+from .observer import DummyObserver, HistogramObserver, MinMaxObserver
+from .sparse import Bernoulli, BlockTopK, Dense, Sparseness, Sparsify, TopK
+
+__version__ = "0.1.0"
+
+
+def _format_aliases():
+    """Alias vocabulary of the reference (src/dmx/compressor/__init__.py:20-97), generated rather than listed.
+    `BFPnn` means an (nn-8)-bit mantissa + 8-bit shared exponent.  Reference quirk kept:
+    BFP16A_16 is defined with a 6-bit mantissa there."""
+    a = dict(
+        SAME="SAME", FLOAT32="FP[1|8|23,127](_N)", FLOAT16="FP[1|5|10,15](FN)", BFLOAT16="FP[1|8|7,127](FN)",
+        AFLOAT8="FP[1|4|3,7](_N)", BFLOAT8="FP[1|5|2,15](_N)", INT8="XP[8,0](CSN)", INT4="XP[4,0](CSN)",
+        BFP32_1="BFP[24|8]{1}(SN)",
+    )
+    for b in (64, 32, 16):
+        a[f"BFP24_{b}"] = f"BFP[16|8]{{{b}}}(SN)"
+    for total, man in ((16, 8), (14, 6), (12, 4)):
+        for b in (128, 64, 32, 16):
+            a[f"BFP{total}_{b}"] = f"BFP[{man}|8]{{{b}}}(SN)"
+            a[f"BFP{total}A_{b}"] = f"BFP[{man}|8]{{{b}}}(_N)"
+    a["BFP16A_16"] = "BFP[6|8]{16}(_N)"
+    a["SBFP12_16"] = "SBFP<XP[4,0](CSN)><FP[0|4|4,7](FN)>{16}"
+    for bias in range(4, 19):
+        a[f"SBFP12_16_{bias}"] = f"SBFP<XP[4,0](CSN)><FP[0|4|4,{bias}](FN)>{{16}}"
+    for p, e, m in ((8, 4, 3), (8, 5, 2), (6, 2, 3), (6, 3, 2), (4, 2, 1)):
+        for b in (128, 64, 32):
+            a[f"MXFP{p}_E{e}M{m}K{b}"] = f"MXFP{p}[E{e}M{m}]{{{b}}}"
+    for p in (8, 6, 4):
+        for b in (128, 64, 32):
+            a[f"MXINT{p}_K{b}"] = f"MXINT{p}{{{b}}}"
+    return SimpleNamespace(**{k: Format.from_shorthand(v) for k, v in a.items()})
+
+
+format = _format_aliases()
+
+# sparseness aliases (reference __init__.py:100-105): LD = last dim, FD = dim 1
+sparseness = SimpleNamespace(**{
+    f"BTK8_{k}_{tag}": Sparseness.from_shorthand(f"BTOPK{{{k}:8,{dim}}}(U)")
+    for k in (4, 2) for tag, dim in (("LD", -1), ("FD", 1))
+})

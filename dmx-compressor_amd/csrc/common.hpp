@@ -1,0 +1,185 @@
+// csrc/common.hpp — shared device helpers for the gfx950 (CDNA4, wave64) kernels of libdmxq.
+//
+// Everything here is bit-level fp32 arithmetic that must match the reference's CPU path exactly
+// (quant/quant_cpu/quant_cpu.cpp, bit_helper.cpp, sim_helper.cpp of d-matrix-ai/dmx-compressor), so the
+// library is built with -fno-fast-math -ffp-contract=off and keeps fp32 denormals on (gfx950 default).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dmxq.h"
+
+namespace dmxq {
+
+constexpr int kWave = 64;        // CDNA4 wavefront width
+constexpr int kThreads = 256;    // workgroup size: 4 waves, one per SIMD
+constexpr int kMaxBlocks = 256 * 8;  // memory-bound grid cap: 256 CUs x 8 workgroups, grid-stride beyond
+
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// splitmix64(seed, linear element index): the same counter-based stream as oracle/oracle.c rnd_bits, so the
+// stochastic modes are reproducible and kernel-vs-oracle bit-exact (the reference's RNG is an unseeded
+// global mt19937, quant_cpu.cpp:32-34: only statistical parity is possible against it).
+__device__ __forceinline__ uint32_t rnd_bits(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+
+// quant_cpu.cpp:211-237 round_bitwise: keep `man_bits` (0..22) mantissa bits of an fp32 bit pattern.
+// nearest == round-half-to-even on the bit pattern, written as the branch-free (half-1)+lsb form:
+// dropped > half carries, dropped < half does not, dropped == half carries iff the kept LSB is odd.
+// RND is a compile-time DMXQ_ROUND_NEAREST on the hot instantiations, or kRuntimeRounding, in which case the
+// (wave-uniform) `rounding` argument selects the mode.
+constexpr int kRuntimeRounding = -1;
+template <int RND>
+__device__ __forceinline__ uint32_t round_bitwise(uint32_t t, int man_bits, int rounding, uint32_t rnd) {
+  const int sh = 23 - man_bits;
+  const uint32_t mask = (1u << sh) - 1u;
+  const int r = (RND == kRuntimeRounding) ? rounding : RND;
+  uint32_t add;
+  if (r == DMXQ_ROUND_NEAREST) add = (mask >> 1) + ((t >> sh) & 1u);
+  else if (r == DMXQ_ROUND_DOWN) add = 0u;
+  else if (r == DMXQ_ROUND_UP) add = 1u << sh;
+  else add = rnd & mask;
+  return (t + add) & ~mask;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 16-byte vector I/O.  One lane always moves 16 B of input per step (global_load_dwordx4): 8 x bf16/fp16 or
+// 4 x fp32.  Elements are widened to fp32 (exact) for the arithmetic and narrowed with a true RNE convert
+// (what `.to(physical_dtype)` does in numerical/cast.py:306).
+template <int DT> struct Elem;
+template <> struct Elem<DMXQ_F32> { static constexpr int bytes = 4; };
+template <> struct Elem<DMXQ_F16> { static constexpr int bytes = 2; };
+template <> struct Elem<DMXQ_BF16> { static constexpr int bytes = 2; };
+
+template <int DT>
+__device__ __forceinline__ float load1(const void* p, int64_t i) {
+  if (DT == DMXQ_F32) return ((const float*)p)[i];
+  if (DT == DMXQ_F16) return (float)((const _Float16*)p)[i];
+  return u2f((uint32_t)((const uint16_t*)p)[i] << 16);
+}
+
+template <int DT>
+__device__ __forceinline__ void store1(void* p, int64_t i, float v) {
+  if (DT == DMXQ_F32) ((float*)p)[i] = v;
+  else if (DT == DMXQ_F16) ((_Float16*)p)[i] = (_Float16)v;
+  else ((__bf16*)p)[i] = (__bf16)v;  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+}
+
+// runtime-dtype scalar access (cold paths: wave-uniform switch)
+__device__ __forceinline__ float load_rt(const void* p, int dt, int64_t i) {
+  if (dt == DMXQ_F32) return load1<DMXQ_F32>(p, i);
+  if (dt == DMXQ_F16) return load1<DMXQ_F16>(p, i);
+  return load1<DMXQ_BF16>(p, i);
+}
+__device__ __forceinline__ void store_rt(void* p, int dt, int64_t i, float v) {
+  if (dt == DMXQ_F32) store1<DMXQ_F32>(p, i, v);
+  else if (dt == DMXQ_F16) store1<DMXQ_F16>(p, i, v);
+  else store1<DMXQ_BF16>(p, i, v);
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// N fp32 values <- N consecutive elements starting at element index i (N*bytes must be 16 or 32 aligned as used)
+template <int DT, int N>
+__device__ __forceinline__ void load_vec(const void* p, int64_t i, float (&x)[N]) {
+  if (DT == DMXQ_F32) {
+#pragma unroll
+    for (int k = 0; k < N; k += 4) {
+      f32x4 v = *(const f32x4*)((const float*)p + i + k);
+      x[k] = v.x; x[k + 1] = v.y; x[k + 2] = v.z; x[k + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; k += 8) {
+      u32x4 v = *(const u32x4*)((const uint16_t*)p + i + k);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (DT == DMXQ_BF16) {
+          x[k + 2 * j] = u2f(v[j] << 16);
+          x[k + 2 * j + 1] = u2f(v[j] & 0xFFFF0000u);
+        } else {
+          f16x2 h = __builtin_bit_cast(f16x2, v[j]);
+          x[k + 2 * j] = (float)h.x;
+          x[k + 2 * j + 1] = (float)h.y;
+        }
+      }
+    }
+  }
+}
+
+template <int DT>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  if (DT == DMXQ_BF16) {
+    bf16x2 h; h.x = (__bf16)a; h.y = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, h);
+  } else {
+    f16x2 h; h.x = (_Float16)a; h.y = (_Float16)b;
+    return __builtin_bit_cast(uint32_t, h);
+  }
+}
+
+template <int DT, int N, bool NT = false>
+__device__ __forceinline__ void store_vec(void* p, int64_t i, const float (&y)[N]) {
+  if (DT == DMXQ_F32) {
+#pragma unroll
+    for (int k = 0; k < N; k += 4) {
+      f32x4 v = {y[k], y[k + 1], y[k + 2], y[k + 3]};
+      f32x4* dst = (f32x4*)((float*)p + i + k);
+      if (NT) __builtin_nontemporal_store(v, dst); else *dst = v;
+    }
+  } else if (N % 8 == 0) {
+#pragma unroll
+    for (int k = 0; k < N; k += 8) {
+      u32x4 v = {pack2<DT>(y[k], y[k + 1]), pack2<DT>(y[k + 2], y[k + 3]), pack2<DT>(y[k + 4], y[k + 5]),
+                 pack2<DT>(y[k + 6], y[k + 7])};
+      u32x4* dst = (u32x4*)((uint16_t*)p + i + k);
+      if (NT) __builtin_nontemporal_store(v, dst); else *dst = v;
+    }
+  } else {  // N == 4 sixteen-bit outputs: one 8-byte store
+    u32x2 v = {pack2<DT>(y[0], y[1]), pack2<DT>(y[2], y[3])};
+    u32x2* dst = (u32x2*)((uint16_t*)p + i);
+    if (NT) __builtin_nontemporal_store(v, dst); else *dst = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// max over aligned groups of LANES adjacent lanes, using DPP only (no LDS traffic):
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror give xor-1/2/4/8 partners once the
+// smaller groups are already uniform; 32 and 64 lanes fall back to ds_swizzle / readlane-style shuffles.
+// `lanes` is wave-uniform (a kernel argument), so these are scalar branches.
+__device__ __forceinline__ float group_max(float m, int lanes) {
+  const int LANES = lanes;
+  if (LANES >= 2) m = fmaxf(m, u2f(__builtin_amdgcn_update_dpp(0, f2u(m), 0xB1, 0xF, 0xF, false)));   // quad_perm 1,0,3,2
+  if (LANES >= 4) m = fmaxf(m, u2f(__builtin_amdgcn_update_dpp(0, f2u(m), 0x4E, 0xF, 0xF, false)));   // quad_perm 2,3,0,1
+  if (LANES >= 8) m = fmaxf(m, u2f(__builtin_amdgcn_update_dpp(0, f2u(m), 0x141, 0xF, 0xF, false)));  // row_half_mirror
+  if (LANES >= 16) m = fmaxf(m, u2f(__builtin_amdgcn_update_dpp(0, f2u(m), 0x140, 0xF, 0xF, false))); // row_mirror
+  if (LANES >= 32) m = fmaxf(m, __shfl_xor(m, 16));
+  if (LANES >= 64) m = fmaxf(m, __shfl_xor(m, 32));
+  return m;
+}
+
+inline int grid_for(int64_t work_items_of_one_thread) {
+  int64_t b = (work_items_of_one_thread + kThreads - 1) / kThreads;
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return (int)b;
+}
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? DMXQ_OK : DMXQ_ERR_LAUNCH; }
+
+inline bool valid_dtype(int d) { return d == DMXQ_F32 || d == DMXQ_F16 || d == DMXQ_BF16; }
+inline bool valid_rounding(int r) { return r >= 0 && r <= 3; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// dtype / rounding dispatch: calls f(std::integral_constant...) style via macros kept local to each .hip file
+}  // namespace dmxq

@@ -1,0 +1,182 @@
+// csrc/reduce.hip — calibration-side reductions for gfx950:
+//   * per-group min/max over slabs of channels   (numerical/cast.py:179-226 + numerical/observer.py:173-193)
+//   * (min,max) -> (scale, zero_point)            (numerical/observer.py:59-115)
+//   * per-channel max|x|                          (numerical/smoothquant.py:285-299)
+//   * SmoothQuant scale                           (numerical/smoothquant.py:301-321)
+// The reference builds one observer nn.Module per group in a Python loop and runs two ATen reductions per
+// group; here one launch covers all groups.  Partial results are combined with integer atomics on the float
+// bit patterns (order-preserving for non-NaN values), so the outputs are exact and order-independent.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace dmxq {
+
+// float atomic min/max through integer atomics: non-negative floats order like signed ints, negative floats
+// order inversely like unsigned ints.
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  if (!(v < 0.0f) && !(f2u(v) >> 31)) atomicMax((int*)addr, (int)f2u(v));
+  else atomicMin((unsigned int*)addr, f2u(v));
+}
+__device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
+  if (!(v < 0.0f) && !(f2u(v) >> 31)) atomicMin((int*)addr, (int)f2u(v));
+  else atomicMax((unsigned int*)addr, f2u(v));
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__global__ void fill2_kernel(float* a, float va, float* b, float vb, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    a[i] = va;
+    if (b) b[i] = vb;
+  }
+}
+
+// grid = (splits, G).  Group g owns, for every o, the contiguous run [(o*C + g*gs) * inner, +len_g*inner).
+__global__ __launch_bounds__(kThreads) void group_minmax_kernel(const void* __restrict__ in, int dt, int64_t outer,
+                                                               int64_t C, int64_t inner, int64_t gs, float* mn,
+                                                               float* mx) {
+  const int64_t g = blockIdx.y;
+  const int64_t c0 = g * gs;
+  const int64_t len = ((C - c0 < gs) ? (C - c0) : gs) * inner;  // run length per o
+  const int64_t total = outer * len;
+  float lo = INFINITY, hi = -INFINITY;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < total; t += stride) {
+    const int64_t o = t / len, r = t % len;
+    const float v = load_rt(in, dt, (o * C + c0) * inner + r);
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  }
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  __shared__ float s_lo[kThreads / kWave], s_hi[kThreads / kWave];
+  const int w = threadIdx.x / kWave;
+  if ((threadIdx.x & (kWave - 1)) == 0) { s_lo[w] = lo; s_hi[w] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 1; i < kThreads / kWave; i++) { lo = fminf(lo, s_lo[i]); hi = fmaxf(hi, s_hi[i]); }
+    if (lo <= hi) {  // at least one element seen
+      atomic_min_f32(&mn[g], lo);
+      atomic_max_f32(&mx[g], hi);
+    }
+  }
+}
+
+__global__ void qparams_kernel(const float* mn, const float* mx, int64_t G, int qmin, int qmax, int sym, float* scale,
+                               int64_t* zp) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const float eps = 1.1920928955078125e-07f;  // torch.finfo(torch.float32).eps (observer.py:37)
+  const float min_neg = fminf(mn[g], 0.0f);
+  const float max_pos = fmaxf(mx[g], 0.0f);
+  if (sym) {
+    const float m = fmaxf(-min_neg, max_pos);
+    scale[g] = fmaxf(m / ((float)(qmax - qmin) / 2.0f), eps);
+    zp[g] = 0;
+  } else {
+    const float s = fmaxf((max_pos - min_neg) / (float)(qmax - qmin), eps);
+    float z = (float)qmin - rintf(min_neg / s);
+    z = fminf(fmaxf(z, (float)qmin), (float)qmax);
+    scale[g] = s;
+    zp[g] = (int64_t)z;
+  }
+}
+
+// grid = (ceil(C*inner / 256), splits over outer).  Lanes run along the contiguous (c, i) plane.
+__global__ __launch_bounds__(kThreads) void channel_maxabs_kernel(const void* __restrict__ in, int dt, int64_t outer,
+                                                                 int64_t C, int64_t inner, float* out) {
+  const int64_t col = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const int64_t plane = C * inner;
+  if (col >= plane) return;
+  float m = 0.0f;
+  for (int64_t o = blockIdx.y; o < outer; o += gridDim.y) m = fmaxf(m, fabsf(load_rt(in, dt, o * plane + col)));
+  atomicMax((int*)&out[col / inner], (int)f2u(m));  // m >= 0: int order == float order
+}
+
+__global__ void smoothquant_scale_kernel(const float* a, const float* b, int64_t C, float alpha, float smin,
+                                         float* scale) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float bb = fmaxf(b[c], smin);
+  const float s = powf(a[c], alpha) / powf(bb, 1.0f - alpha);
+  scale[c] = fmaxf(s, smin);
+}
+
+}  // namespace dmxq
+
+using namespace dmxq;
+
+extern "C" int dmxq_group_minmax(const void* in, int dtype_in, int64_t outer, int64_t C, int64_t inner,
+                                 int64_t group_size, float* mn, float* mx, void* stream) {
+  if (!valid_dtype(dtype_in) || outer < 0 || C < 0 || inner < 0 || group_size < 1) return DMXQ_ERR_BAD_ARG;
+  if (C == 0) return DMXQ_OK;
+  if (!mn || !mx) return DMXQ_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t G = (C + group_size - 1) / group_size;
+  if (G > 65535) return DMXQ_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(fill2_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, mn, INFINITY, mx, -INFINITY, G);
+  if (outer * inner > 0) {
+    if (!in) return DMXQ_ERR_BAD_ARG;
+    const int64_t per_group = outer * group_size * inner;
+    int64_t splits = (per_group + kThreads * 16 - 1) / (kThreads * 16);
+    const int64_t cap = (kMaxBlocks + G - 1) / G;
+    if (splits > cap) splits = cap;
+    if (splits < 1) splits = 1;
+    hipLaunchKernelGGL(group_minmax_kernel, dim3((unsigned)splits, (unsigned)G), dim3(kThreads), 0, s, in, dtype_in,
+                       outer, C, inner, group_size, mn, mx);
+  }
+  return launch_status();
+}
+
+extern "C" int dmxq_qparams(const float* mn, const float* mx, int64_t n_groups, int qmin, int qmax,
+                            int symmetric_qscheme, float* scale, int64_t* zero_point, void* stream) {
+  if (n_groups < 0 || qmax <= qmin) return DMXQ_ERR_BAD_ARG;
+  if (n_groups == 0) return DMXQ_OK;
+  if (!mn || !mx || !scale || !zero_point) return DMXQ_ERR_BAD_ARG;
+  hipLaunchKernelGGL(qparams_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mn,
+                     mx, n_groups, qmin, qmax, symmetric_qscheme, scale, zero_point);
+  return launch_status();
+}
+
+extern "C" int dmxq_channel_maxabs(const void* in, int dtype_in, int64_t outer, int64_t C, int64_t inner, float* out,
+                                   void* stream) {
+  if (!valid_dtype(dtype_in) || outer < 0 || C < 0 || inner < 0) return DMXQ_ERR_BAD_ARG;
+  if (C == 0) return DMXQ_OK;
+  if (!out) return DMXQ_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(fill2_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, out, 0.0f, (float*)nullptr, 0.0f, C);
+  const int64_t plane = C * inner;
+  if (outer * plane > 0) {
+    if (!in) return DMXQ_ERR_BAD_ARG;
+    const int64_t gx = (plane + kThreads - 1) / kThreads;
+    int64_t gy = kMaxBlocks / gx;
+    if (gy < 1) gy = 1;
+    if (gy > outer) gy = outer;
+    if (gy > 65535) gy = 65535;
+    hipLaunchKernelGGL(channel_maxabs_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, s, in, dtype_in,
+                       outer, C, inner, out);
+  }
+  return launch_status();
+}
+
+extern "C" int dmxq_smoothquant_scale(const float* a_maxabs, const float* b_maxabs, int64_t C, float alpha,
+                                      float scale_min, float* scale, void* stream) {
+  if (C < 0) return DMXQ_ERR_BAD_ARG;
+  if (C == 0) return DMXQ_OK;
+  if (!a_maxabs || !b_maxabs || !scale) return DMXQ_ERR_BAD_ARG;
+  hipLaunchKernelGGL(smoothquant_scale_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     a_maxabs, b_maxabs, C, alpha, scale_min, scale);
+  return launch_status();
+}

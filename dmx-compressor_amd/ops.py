@@ -1,0 +1,222 @@
+"""Tensor-level front ends of the libdmxq C ABI (include/dmxq.h): each function is ONE kernel launch on
+torch's current HIP stream, allocating its output like the reference's native functions do (`zeros_like` +
+return, quant/quant_cuda/quant_cuda.cpp:116-139 — here `empty`, every element is written).
+
+No CPU path: a non-GPU tensor or a missing libdmxq.so raises `DmxqError`.
+"""
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
+
+__all__ = [
+    "bfp_qdq", "float_qdq", "fixed_qdq", "nm_mask", "nm_sparsify", "group_minmax", "qparams", "channel_maxabs",
+    "smoothquant_scale", "scale_channels", "gelu", "softmax", "layernorm",
+]
+
+_SEED_COUNTER = [0x5EED]
+
+
+def _next_seed() -> int:
+    """Stochastic rounding draws from a counter-based stream keyed by (seed, element index); a fresh seed per
+    call, derived from torch's generator state so `torch.manual_seed` makes runs reproducible."""
+    _SEED_COUNTER[0] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _SEED_COUNTER[0]) & 0xFFFFFFFFFFFFFFFF
+
+
+def _prep(x: torch.Tensor, what: str) -> torch.Tensor:
+    require_gpu(x, what)
+    dtype_code(x.dtype)
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def bfp_qdq(x, precision: int, block_size: int, block_dim: int = -1, symmetric: bool = True,
+            rounding: str = "nearest", out_dtype: Optional[torch.dtype] = None, seed: Optional[int] = None):
+    """BlockFloatingPoint Q->DQ of a whole tensor in one launch (numerical/format.py:304-343 semantics).
+    Blocks run along `block_dim`; output has x's shape, contiguous, dtype `out_dtype` (default x.dtype)."""
+    xc = _prep(x, "bfp_qdq")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    if xc.dim() == 0:
+        outer, L, inner = 1, 1, 1
+    else:
+        outer, L, inner = split3(xc.shape, block_dim)
+    seed = _next_seed() if (seed is None and rounding == "stochastic") else (seed or 0)
+    check(lib().dmxq_bfp_qdq(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), outer, L, inner,
+                             block_size, precision, _lib.ROUNDING_CODE[rounding], int(symmetric), seed, stream_of(xc)),
+          "dmxq_bfp_qdq")
+    return out
+
+
+def float_qdq(x, man: int, exp: int, bias: int, flush_subnormal: bool, unsigned: bool = False,
+              rounding: str = "nearest", out_dtype: Optional[torch.dtype] = None, seed: Optional[int] = None):
+    """Low-bit float Q->DQ (quant/quant_function.py:120-152 semantics), one launch."""
+    xc = _prep(x, "float_qdq")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    seed = _next_seed() if (seed is None and rounding == "stochastic") else (seed or 0)
+    check(lib().dmxq_float_qdq(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), xc.numel(), man, exp,
+                               bias, int(flush_subnormal), int(unsigned), _lib.ROUNDING_CODE[rounding], seed,
+                               stream_of(xc)), "dmxq_float_qdq")
+    return out
+
+
+def fixed_qdq(x, precision: int, fraction: int, clamp: bool = True, symmetric: bool = True, rounding: str = "nearest",
+              scale: Optional[torch.Tensor] = None, zero_point: Optional[torch.Tensor] = None,
+              ch_axis: Optional[int] = None, group_size: Optional[int] = None,
+              out_dtype: Optional[torch.dtype] = None, seed: Optional[int] = None):
+    """Fixed-point Q->DQ with the affine wrapper of numerical/cast.py:278-296 fused in, one launch.
+    scale None: bare FixedPoint.cast.  ch_axis None: per-tensor scale; else per-channel (group_size None) or
+    per-group slabs of `group_size` channels."""
+    xc = _prep(x, "fixed_qdq")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    sc = zp = None
+    outer, C, inner, gs = 1, 1, xc.numel(), 1
+    if scale is not None:
+        sc = scale.detach().to(device=xc.device, dtype=torch.float32).contiguous()
+        zp = zero_point.detach().to(device=xc.device, dtype=torch.int64).contiguous()
+        if ch_axis is not None and xc.dim() > 0:
+            outer, C, inner = split3(xc.shape, ch_axis)
+            gs = group_size or 1
+            need = -(-C // gs)
+        else:
+            need = 1
+        if sc.numel() < need or zp.numel() < need:
+            raise ValueError(f"fixed_qdq: need {need} scale/zero_point entries, got {sc.numel()}/{zp.numel()}")
+    seed = _next_seed() if (seed is None and rounding == "stochastic") else (seed or 0)
+    check(lib().dmxq_fixed_qdq(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), outer, C, inner,
+                               precision, fraction, int(clamp), int(symmetric), _lib.ROUNDING_CODE[rounding],
+                               ptr(sc), ptr(zp), gs, seed, stream_of(xc)), "dmxq_fixed_qdq")
+    return out
+
+
+def _nm(score, x, K, M, block_dim, want_mask, want_y, mask_dtype, y_dtype):
+    sc = _prep(score, "nm_mask")
+    if sc.dim() == 0 or sc.shape[block_dim] % M != 0:
+        # sparse.py:166-168
+        raise AssertionError(
+            f"score has size {tuple(sc.shape)} at dimension {block_dim}, not a multiple of block size {M}")
+    outer, L, inner = split3(sc.shape, block_dim)
+    xc = None
+    if want_y:
+        xc = _prep(x, "nm_sparsify")
+        if xc.shape != sc.shape:
+            xc = xc.expand(sc.shape).contiguous()
+    mask = torch.empty(sc.shape, dtype=mask_dtype or sc.dtype, device=sc.device) if want_mask else None
+    y = torch.empty(sc.shape, dtype=y_dtype, device=sc.device) if want_y else None
+    check(lib().dmxq_nm_mask(ptr(sc), dtype_code(sc.dtype), ptr(xc), dtype_code(xc.dtype) if want_y else 0,
+                             ptr(mask), dtype_code(mask.dtype) if want_mask else 0,
+                             ptr(y), dtype_code(y.dtype) if want_y else 0, outer, L, inner, K, M, stream_of(sc)),
+          "dmxq_nm_mask")
+    return mask, y
+
+
+def nm_mask(score, K: int, M: int, block_dim: int = -1, mask_dtype: Optional[torch.dtype] = None):
+    """N:M mask (sparse.py:163-180): float mask in the score's dtype."""
+    return _nm(score, None, K, M, block_dim, True, False, mask_dtype, None)[0]
+
+
+def nm_sparsify(x, score, K: int, M: int, block_dim: int = -1, out_dtype: Optional[torch.dtype] = None,
+                return_mask: bool = False):
+    """Fused mask + apply: y = x * mask(score) (sparse.py:287-301); out dtype defaults to torch's promotion of
+    (x.dtype, score.dtype), i.e. what `x * mask` yields in the reference."""
+    yd = out_dtype or torch.promote_types(x.dtype, score.dtype)
+    mask, y = _nm(score, x, K, M, block_dim, return_mask, True, None, yd)
+    return (y, mask) if return_mask else y
+
+
+def group_minmax(x, ch_axis: int, group_size: int):
+    """Per-group (slabs of `group_size` channels along ch_axis) min and max: two float32 [G] tensors."""
+    xc = _prep(x, "group_minmax")
+    outer, C, inner = split3(xc.shape, ch_axis)
+    G = -(-C // group_size)
+    mn = torch.empty(G, dtype=torch.float32, device=xc.device)
+    mx = torch.empty(G, dtype=torch.float32, device=xc.device)
+    check(lib().dmxq_group_minmax(ptr(xc), dtype_code(xc.dtype), outer, C, inner, group_size, ptr(mn), ptr(mx),
+                                  stream_of(xc)), "dmxq_group_minmax")
+    return mn, mx
+
+
+def qparams(mn, mx, qmin: int, qmax: int, symmetric_qscheme: bool):
+    """(min,max) -> (scale fp32, zero_point int64), numerical/observer.py:59-115."""
+    require_gpu(mn, "qparams")
+    mn = mn.to(torch.float32).contiguous()
+    mx = mx.to(torch.float32).contiguous()
+    scale = torch.empty_like(mn)
+    zp = torch.empty(mn.shape, dtype=torch.int64, device=mn.device)
+    check(lib().dmxq_qparams(ptr(mn), ptr(mx), mn.numel(), qmin, qmax, int(symmetric_qscheme), ptr(scale), ptr(zp),
+                             stream_of(mn)), "dmxq_qparams")
+    return scale, zp
+
+
+def channel_maxabs(x, ch_axis: int):
+    """max|x| per channel along ch_axis (numerical/smoothquant.py:285-299): float32 [C]."""
+    xc = _prep(x, "channel_maxabs")
+    outer, C, inner = split3(xc.shape, ch_axis)
+    out = torch.empty(C, dtype=torch.float32, device=xc.device)
+    check(lib().dmxq_channel_maxabs(ptr(xc), dtype_code(xc.dtype), outer, C, inner, ptr(out), stream_of(xc)),
+          "dmxq_channel_maxabs")
+    return out
+
+
+def smoothquant_scale(a_maxabs, b_maxabs, alpha: float, scale_min: float = 1e-5):
+    require_gpu(a_maxabs, "smoothquant_scale")
+    a = a_maxabs.to(torch.float32).contiguous()
+    b = b_maxabs.to(device=a.device, dtype=torch.float32).contiguous()
+    out = torch.empty_like(a)
+    check(lib().dmxq_smoothquant_scale(ptr(a), ptr(b), a.numel(), float(alpha), float(scale_min), ptr(out),
+                                       stream_of(a)), "dmxq_smoothquant_scale")
+    return out
+
+
+def scale_channels(x, scale, ch_axis: int, divide: bool, out_dtype: Optional[torch.dtype] = None):
+    xc = _prep(x, "scale_channels")
+    outer, C, inner = split3(xc.shape, ch_axis)
+    sc = scale.detach().to(device=xc.device, dtype=torch.float32).contiguous()
+    if sc.numel() != C:
+        raise ValueError(f"scale_channels: scale has {sc.numel()} entries for {C} channels")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    check(lib().dmxq_scale_channels(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), outer, C, inner,
+                                    ptr(sc), int(divide), stream_of(xc)), "dmxq_scale_channels")
+    return out
+
+
+def gelu(x, approximate: str = "none", out_dtype: Optional[torch.dtype] = None):
+    xc = _prep(x, "gelu")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    check(lib().dmxq_gelu(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), xc.numel(),
+                          int(approximate == "tanh"), stream_of(xc)), "dmxq_gelu")
+    return out
+
+
+def softmax(x, dim: int = -1, input_clamp: Optional[float] = None, out_dtype: Optional[torch.dtype] = None):
+    require_gpu(x, "softmax")
+    d = dim % x.dim()
+    xt = x if d == x.dim() - 1 else x.transpose(d, -1)
+    xc = xt.contiguous()
+    cols = xc.shape[-1]
+    rows = xc.numel() // max(cols, 1)
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    check(lib().dmxq_softmax(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), rows, cols,
+                             float(input_clamp) if input_clamp is not None else -math.inf, stream_of(xc)),
+          "dmxq_softmax")
+    return out if d == x.dim() - 1 else out.transpose(d, -1)
+
+
+def layernorm(x, normalized_shape, weight=None, bias=None, eps: float = 1e-5,
+              out_dtype: Optional[torch.dtype] = None):
+    xc = _prep(x, "layernorm")
+    cols = 1
+    for s in (normalized_shape if not isinstance(normalized_shape, int) else (normalized_shape,)):
+        cols *= s
+    rows = xc.numel() // max(cols, 1)
+    w = weight.detach().contiguous() if weight is not None else None
+    b = bias.detach().contiguous() if bias is not None else None
+    if w is not None and b is not None and w.dtype != b.dtype:
+        b = b.to(w.dtype)
+    wb_dtype = dtype_code((w if w is not None else b).dtype) if (w is not None or b is not None) else 0
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    check(lib().dmxq_layernorm(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), rows, cols, ptr(w),
+                               ptr(b), wb_dtype, float(eps), stream_of(xc)), "dmxq_layernorm")
+    return out

@@ -1,0 +1,223 @@
+"""Weight sparsity — mirror of the reference's `sparse.py` (Sparseness shorthands, Sparsify module).
+
+Hot path: `BlockTopK` (N:M structured sparsity, sparse.py:140-198) and `Sparsify.forward` (sparse.py:287-301).
+The reference builds the mask with argsort (int64 indices, 8 B/elem) + ones + scatter and then multiplies;
+here mask and `x * mask` come out of ONE kernel in which each lane ranks its M-group in registers.
+`TopK` (global, needs a full sort/select) and `Bernoulli` are vocabulary-only ("next"/out of scope).
+"""
+import re
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+__all__ = ["Sparseness", "Dense", "TopK", "BlockTopK", "Bernoulli", "Sparsify"]
+
+
+class Sparseness:
+    blocked: bool = False
+    density: Optional[float] = None
+
+    def __init__(self, mask_gradient=False):
+        self.mask_gradient = bool(mask_gradient)
+
+    def get_mask(self, score):
+        raise NotImplementedError
+
+    @classmethod
+    def from_shorthand(cls, sh: str):
+        if isinstance(sh, Sparseness):
+            return sh
+        for prefix, klass in (("DENSE", Dense), ("TOPK", TopK), ("BTOPK", BlockTopK), ("BERN", Bernoulli)):
+            if sh.startswith(prefix):
+                return klass.from_shorthand(sh)
+        raise ValueError(f"unrecognized sparseness shorthand: {sh}")
+
+
+class Dense(Sparseness):
+    def __init__(self, mask_gradient=False):
+        super().__init__(mask_gradient)
+        self.density = 1.0
+
+    def get_mask(self, score):
+        return None
+
+    @classmethod
+    def from_shorthand(cls, sh: str):
+        return cls()
+
+    def __str__(self):
+        return "Dummy sparseness: no pruning"
+
+    def __repr__(self):
+        return "DENSE"
+
+
+class TopK(Sparseness):
+    """Global top-K (sparse.py:95-137): vocabulary only — a whole-tensor selection, not part of the N:M hot path."""
+
+    def __init__(self, density=0.5, mask_gradient=False):
+        super().__init__(mask_gradient)
+        assert 0 <= density <= 1.0, "density has to be between 0 and 1"
+        self.density = density
+
+    def get_mask(self, score):
+        raise NotImplementedError("TOPK (global unstructured top-K) is outside the accelerated N:M path (SURVEY §2 row 8)")
+
+    @classmethod
+    def from_shorthand(cls, sh: str):
+        m = re.fullmatch(r"TOPK\{([-+]?\d*\.?\d+(?:[eE][-+]?\d+)?)\}\(([MU])\)", sh)
+        if m is None:
+            raise ValueError(f"unrecognized sparseness shorthand: {sh}")
+        return cls(density=float(m[1]), mask_gradient=m[2] == "M")
+
+    def __str__(self):
+        return f"Global TopK sparseness: density = {self.density}"
+
+    def __repr__(self):
+        return f"TOPK{{{self.density}}}({'M' if self.mask_gradient else 'U'})"
+
+
+class _NMMask(Function):
+    """mask = N:M(score); identity gradient to the score (sparse.py:182-184)."""
+
+    @staticmethod
+    def forward(ctx, score, K, M, block_dim):
+        return ops.nm_mask(score, K, M, block_dim)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None, None
+
+
+class _NMSparsify(Function):
+    """y = x * N:M(score), fused.  Backward of the product: dx = g * mask (STE passes weight gradients through the
+    multiply exactly as autograd would for `x * mask` in the reference), dscore = g * x when requested."""
+
+    @staticmethod
+    def forward(ctx, x, score, K, M, block_dim, need_mask_grad):
+        y, mask = ops.nm_sparsify(x, score, K, M, block_dim, return_mask=True)
+        ctx.save_for_backward(mask, x if need_mask_grad else None)
+        ctx.x_dtype, ctx.s_dtype = x.dtype, score.dtype
+        return y, mask
+
+    @staticmethod
+    def backward(ctx, gy, gmask):
+        mask, x = ctx.saved_tensors
+        gx = (gy * mask).to(ctx.x_dtype) if gy is not None and ctx.needs_input_grad[0] else None
+        gs = None
+        if ctx.needs_input_grad[1]:
+            gs = (gy * x).to(ctx.s_dtype) if (gy is not None and x is not None) else None
+            if gmask is not None:
+                gs = gmask if gs is None else gs + gmask
+        return gx, gs, None, None, None, None
+
+
+class BlockTopK(Sparseness):
+    """K non-zeros out of every `block_size` consecutive elements along `block_dim` (sparse.py:140-198)."""
+
+    blocked = True
+
+    def __init__(self, K=4, block_size=8, block_dim=-1, mask_gradient=False):
+        super().__init__(mask_gradient)
+        assert 0 < K <= block_size, "N and M must be positive and N no greater than M"
+        self.K, self.block_size, self.block_dim = K, block_size, block_dim
+        self.density = K / block_size
+
+    def get_mask(self, score):
+        return _NMMask.apply(score, self.K, self.block_size, self.block_dim)
+
+    @classmethod
+    def from_shorthand(cls, sh: str):
+        m = re.fullmatch(r"BTOPK\{(\d+):(\d+),(-?\d+)\}\(([MU])\)", sh)
+        if m is None:
+            raise ValueError(f"unrecognized sparseness shorthand: {sh}")
+        return cls(K=int(m[1]), block_size=int(m[2]), block_dim=int(m[3]), mask_gradient=m[4] == "M")
+
+    def __str__(self):
+        return f"Block TopK sparseness: pattern = {self.K}:{self.block_size}, block dimension = {self.block_dim}"
+
+    def __repr__(self):
+        return f"BTOPK{{{self.K}:{self.block_size},{self.block_dim}}}({'M' if self.mask_gradient else 'U'})"
+
+
+class Bernoulli(Sparseness):
+    """Bernoulli supermask sampler (sparse.py:201-242): vocabulary only (random, no parity to pin)."""
+
+    def get_mask(self, score):
+        raise NotImplementedError("BERN sampling is outside the accelerated N:M path")
+
+    @classmethod
+    def from_shorthand(cls, sh: str):
+        return cls()
+
+    def __str__(self):
+        return "Bernoulli sparseness"
+
+    def __repr__(self):
+        return "BERN"
+
+
+class Sparsify(torch.nn.Module):
+    """Sparsification module (sparse.py:245-320): holds a `score` Parameter (uniform random init), recomputes the
+    mask on every forward and multiplies.  Reference quirk kept: a `score_func` result
+    is used for exactly one forward and never written back to `self.score`."""
+
+    def __init__(self, tensor_shape, sparseness="DENSE", backward_mode="STE", score_func=None):
+        super().__init__()
+        self.score = torch.nn.Parameter(torch.rand(tensor_shape), requires_grad=True)
+        self.mask = None
+        self.configure(sparseness, backward_mode, score_func)
+        self.plastic = False
+
+    def configure(self, sparseness=None, backward_mode=None, score_func=None):
+        if sparseness is not None:
+            sparseness = Sparseness.from_shorthand(sparseness)
+            if not hasattr(self, "sparseness") or repr(sparseness) != repr(self.sparseness):
+                self.sparseness = sparseness
+        if backward_mode is not None:
+            self.backward_mode = backward_mode
+            self.enable_weight_gradient = backward_mode.lower() in {"ste", "joint"}
+            self.enable_mask_gradient = backward_mode.lower() in {"supermask", "joint"}
+        if score_func is not None:
+            self.score_func = score_func
+            self.plastic = True  # rewire on the next forward()
+
+    def update_mask(self, score):
+        self.mask = self.sparseness.get_mask(score)
+
+    def forward(self, x):
+        if isinstance(self.sparseness, Dense):
+            return x
+        if self.plastic:
+            score = self.score_func(self.score, x)
+            self.plastic = False
+        else:
+            score = self.score
+        if not isinstance(self.sparseness, BlockTopK):
+            self.update_mask(score)
+            return x * self.mask
+        sp = self.sparseness
+        if score.device != x.device:
+            score = score.to(x.device)
+        if self.training:
+            xin = x if self.enable_weight_gradient else x.detach()
+            sin = score if self.enable_mask_gradient else score.detach()
+        else:
+            xin, sin = x, score
+        y, mask = _NMSparsify.apply(xin, sin, sp.K, sp.block_size, sp.block_dim,
+                                    bool(self.training and self.enable_mask_gradient))
+        self.mask = mask
+        return y
+
+    @property
+    def density(self) -> float:
+        if self.sparseness.density is not None:
+            return self.sparseness.density
+        self.update_mask(self.score)
+        return self.mask.data.sum() / self.mask.numel()
+
+    def extra_repr(self):
+        return f"sparseness = {self.sparseness.__repr__()}, backward_mode = {self.backward_mode}"

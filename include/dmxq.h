@@ -1,0 +1,117 @@
+/* include/dmxq.h — C ABI of libdmxq.so, the MI355X (gfx950) fake-quantisation / sparsity operator library.
+ *
+ * This is the drop-in boundary for the hot path of d-matrix-ai/dmx-compressor (reference paths below are
+ * relative to /root/reference/src/dmx/compressor/).  The reference's native seam is a pair of pybind
+ * modules, `quant_cpu` / `quant_cuda`, picked per call by quant/quant_function.py:38-43; each entry point
+ * here replaces one family of those pybind functions *and* the Python loop that drives it, so that one call
+ * (= one kernel launch) handles a whole tensor.
+ *
+ * Conventions (all entry points):
+ *   - plain C: raw DEVICE pointers + explicit 64-bit sizes, no torch types, no global state, never throws;
+ *   - caller-allocated outputs (the reference allocates with zeros_like and returns a new tensor,
+ *     quant_cuda.cpp:116-139 — the host mirror keeps that ownership contract above this ABI);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are asynchronous;
+ *   - return value: DMXQ_OK, or an error code (see dmxq_status_string); nothing is launched on error;
+ *   - tensors are described as a contiguous [outer, L, inner] (or [outer, C, inner]) view: `L`/`C` is the
+ *     extent of the blocked / channel dimension, `inner` the product of the dimensions after it
+ *     (block_dim=-1  <=>  inner = 1).  in and out may alias exactly (in-place) but must not partially overlap.
+ */
+#ifndef DMXQ_H
+#define DMXQ_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { DMXQ_F32 = 0, DMXQ_F16 = 1, DMXQ_BF16 = 2 } dmxq_dtype;
+
+/* Rounding modes, numbered like the reference's `enum Mode` (quant/quant_cpu/quant_cpu.cpp:9-15). */
+typedef enum { DMXQ_ROUND_UP = 0, DMXQ_ROUND_DOWN = 1, DMXQ_ROUND_NEAREST = 2, DMXQ_ROUND_STOCHASTIC = 3 } dmxq_rounding;
+
+typedef enum {
+  DMXQ_OK = 0,
+  DMXQ_ERR_BAD_ARG = 1,     /* null pointer, negative size, misaligned/invalid enum ... */
+  DMXQ_ERR_UNSUPPORTED = 2, /* parameter outside what the reference defines (e.g. mantissa bits = 23: UB there) */
+  DMXQ_ERR_LAUNCH = 3       /* hipGetLastError() != hipSuccess after the launch */
+} dmxq_status;
+
+const char* dmxq_status_string(int status);
+/* ABI version: bumped on any signature change. */
+int dmxq_abi_version(void);
+
+/* Block floating point Q->DQ ("BFP[p|8]{B}", MXINT).
+ * Replaces: numerical/format.py:304-343 BlockFloatingPoint.cast (split / per-chunk / cat loop)
+ *           -> quant/quant_function.py:87-117 block_quantize -> quant_cpu.cpp:239-311 / quant_cuda/quant.cu:14-112
+ *           + format.py:349-372 make_mantissa_asymmetric (symmetric = 0)
+ *           + the `.float()` / `.to(physical_dtype)` round trip of numerical/cast.py:262,306 (dtype_in/dtype_out).
+ * Blocks are `block_size` consecutive indices along L (stride `inner`); a ragged last block is allowed
+ * (torch.split semantics).  block_size == 1 takes the reference's float_quantize detour (format.py:312-320).
+ * precision = total mantissa bits incl. sign ("8" in BFP[8|8]); 2 <= precision <= 22 when block_size > 1. */
+int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L, int64_t inner,
+                 int64_t block_size, int precision, int rounding, int symmetric, uint64_t seed, void* stream);
+
+/* Low-bit floating point Q->DQ ("FP[s|e|m,bias](F|_ N|S)").
+ * Replaces: numerical/format.py:208-233 FloatingPoint.cast -> quant_function.py:120-152 float_quantize
+ *           -> quant_cpu.cpp:359-402 / quant_cuda/float_kernel.cu.  0 <= man_bits <= 22 (23 is UB in the
+ *           reference; the host mirror treats FP32 as the identity), 1 <= exp_bits <= 8.
+ * unsigned_abs != 0 applies the final `.abs()` of sign-less formats (format.py:233). */
+int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int man_bits, int exp_bits,
+                   int exp_bias, int flush_subnormal, int unsigned_abs, int rounding, uint64_t seed, void* stream);
+
+/* Fixed point Q->DQ ("XP[p,f](C|_ S|_ R)") with the optional affine wrapper fused in.
+ * Replaces: numerical/format.py:134-142 FixedPoint.cast -> quant_function.py:47-84 fixed_point_quantize
+ *           -> quant_cpu.cpp:127-209 (CPU rounding: half-to-even through sim_helper.cpp:14-21), and
+ *           numerical/cast.py:278-296:  x/sc + zp -> cast -> (x - zp)*sc.
+ * The tensor is [outer, C, inner]; channel c uses scale[c / group_size], zero_point[c / group_size]
+ * (cast.py:281-292 repeat_interleave).  scale == NULL: no affine.  per-tensor: C = 1, group_size = 1. */
+int dmxq_fixed_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t C, int64_t inner,
+                   int precision, int fraction, int clamp, int symmetric, int rounding, const float* scale,
+                   const int64_t* zero_point, int64_t group_size, uint64_t seed, void* stream);
+
+/* N:M structured-sparsity mask ("BTOPK{K:M,dim}") and its application.
+ * Replaces: sparse.py:163-180 BlockTopK.forward (argsort + scatter) and sparse.py:300 `x * mask`.
+ * Groups are M consecutive indices along L (stride inner); L % M == 0 required (sparse.py:166-168).
+ * Rule: within a group, rank_i = #{j : s_j < s_i or (s_j == s_i and j < i)}, NaN ranks highest;
+ * mask_i = 1 iff rank_i >= M-K (stable ascending argsort, first M-K zeroed).
+ * mask_out (dtype_mask, float mask of 0/1) and/or y_out = x * mask (dtype_y) may be NULL.  M <= 64. */
+int dmxq_nm_mask(const void* score, int dtype_score, const void* x, int dtype_x, void* mask_out, int dtype_mask,
+                 void* y_out, int dtype_y, int64_t outer, int64_t L, int64_t inner, int K, int M, void* stream);
+
+/* Per-group min/max over slabs of `group_size` channels (MinMaxObserver on torch.split slabs).
+ * Replaces: numerical/cast.py:179-226 _observer_step + numerical/observer.py:173-193.
+ * mn/mx: float[ceil(C/group_size)] device buffers (fully overwritten). */
+int dmxq_group_minmax(const void* in, int dtype_in, int64_t outer, int64_t C, int64_t inner, int64_t group_size,
+                      float* mn, float* mx, void* stream);
+
+/* (min,max) -> (scale, zero_point).  Replaces numerical/observer.py:59-115 _calculate_qparams. */
+int dmxq_qparams(const float* mn, const float* mx, int64_t n_groups, int qmin, int qmax, int symmetric_qscheme,
+                 float* scale, int64_t* zero_point, void* stream);
+
+/* Per-channel max|x| (SmoothQuant).  Replaces numerical/smoothquant.py:285-299 _maxabs. out: float[C]. */
+int dmxq_channel_maxabs(const void* in, int dtype_in, int64_t outer, int64_t C, int64_t inner, float* out, void* stream);
+
+/* SmoothQuant scale = clamp(a^alpha / clamp(b, min)^(1-alpha), min).  Replaces smoothquant.py:301-321. */
+int dmxq_smoothquant_scale(const float* a_maxabs, const float* b_maxabs, int64_t C, float alpha, float scale_min,
+                           float* scale, void* stream);
+
+/* y = x * s[c] (divide = 0) or x / s[c] (divide = 1) along the channel dim of [outer, C, inner], computed in
+ * fp32 and rounded once to dtype_out.  Replaces smoothquant.py:255-283 scale_a / scale_b. */
+int dmxq_scale_channels(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t C,
+                        int64_t inner, const float* scale, int divide, void* stream);
+
+/* Approximator-slot ops.  The reference evaluates the exact torch.nn.functional op and then overwrites it with a
+ * vsimd approximation that lives in a private package (functional/approximate.py:9-14, 300-327); with vsimd
+ * absent (the public reference) the exact function is the result, and that is what these compute, in fp32.
+ * Replaces: ApproximationMixin.approx_forward for GELU (torch_modules.py GELU), Softmax (torch_modules.py:
+ * 989-998, `input_clamp` wrapper argument = input_clamp_min, -INFINITY disables) and LayerNorm (:1062-1082).
+ * softmax / layernorm act on the contiguous last dim of a [rows, cols] view. weight/bias may be NULL. */
+int dmxq_gelu(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int tanh_form, void* stream);
+int dmxq_softmax(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
+                 float input_clamp_min, void* stream);
+int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
+                   const void* weight, const void* bias, int dtype_wb, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMXQ_H */

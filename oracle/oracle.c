@@ -1,0 +1,326 @@
+/* oracle/oracle.c — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C restatement of the reference's (d-matrix-ai/dmx-compressor v0.1.11) CPU algorithms for the
+ * fake-quantisation hot path.  It exists so that the HIP kernels can be checked bit-for-bit on the GPU box,
+ * where /root/reference does not exist.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load it; the product package (dmx-compressor_amd/) never does.
+ *
+ * PINNING: this file is validated bit-exactly against (a) the reference's own compiled C++ extension
+ * (oracle/_ref/quant_cpu.so, built from the reference sources in place by oracle/Makefile), (b) the
+ * reference's Python path (numerical/format.py, cast.py, sparse.py imported through oracle/ref_shim.py) by
+ * oracle/gen_golden.py, and (c) the committed fixtures in tests/golden/ (which include the reference's own
+ * known-answer values, tests/test_bfp.py:26-65 and tests/test_group_quant.py:49-63).
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/src/dmx/compressor/).  The code is a restatement, not a copy: whole-tensor, layout-explicit,
+ * ATen-free, with 64-bit sizes.
+ *
+ * Build: gcc -O2 -fPIC -shared -fopenmp -ffp-contract=off -fno-fast-math  (see oracle/Makefile)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+/* rounding codes shared with include/dmxq.h (order of the reference's `enum Mode`, quant/quant_cpu/quant_cpu.cpp:9-15) */
+enum { R_UP = 0, R_DOWN = 1, R_NEAREST = 2, R_STOCHASTIC = 3 };
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* Counter-based random bits for the stochastic mode.  The reference uses an UNSEEDED global mt19937
+ * (quant_cpu.cpp:32-34), so its stochastic results are not reproducible; parity there is statistical only.
+ * The HIP kernels use the same splitmix64(seed, linear index) stream, so kernel-vs-oracle is still bit-exact. */
+static inline uint32_t rnd_bits(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+
+/* quant_cpu.cpp:211-237 round_bitwise: keep `man_bits` mantissa bits of an fp32 bit pattern.
+ * nearest = round-half-to-even on the bit pattern; the carry may ripple into the exponent (intended).
+ * Valid for 0 <= man_bits <= 22 (the reference shifts by a negative count at 23: undefined behaviour). */
+static inline uint32_t round_bitwise(uint32_t target, int man_bits, int rounding, uint32_t rnd) {
+  const uint32_t mask = (1u << (23 - man_bits)) - 1u;
+  uint32_t add;
+  if (rounding == R_STOCHASTIC) {
+    add = rnd & mask;
+  } else if (rounding == R_NEAREST) {
+    add = 1u << (22 - man_bits);
+    if ((target & mask) == add && ((target >> (23 - man_bits)) & 1u) == 0u) add = 0u; /* tie, kept LSB even */
+  } else if (rounding == R_DOWN) {
+    add = 0u;
+  } else {
+    add = 1u << (23 - man_bits);
+  }
+  return (target + add) & ~mask;
+}
+
+/* quant_cpu/bit_helper.cpp:4-22 clip_exponent: saturate to the largest finite value of the simulated format.
+ * No exponent code is reserved for inf/nan: max stored exponent = 2^(exp_bits-1) + 127. */
+static inline uint32_t clip_exponent(int exp_bits, int man_bits, uint32_t old_num, uint32_t q) {
+  if (q == 0u) return q;
+  const int qe = (int)((q & 0x7FFFFFFFu) >> 23);
+  const int max_e = (1 << (exp_bits - 1)) + 127;
+  if (qe > max_e) {
+    const uint32_t max_man = (0x007FFFFFu >> (23 - man_bits)) << (23 - man_bits);
+    q = (old_num & 0x80000000u) | ((uint32_t)max_e << 23) | max_man;
+  }
+  return q;
+}
+
+/* quant_cpu/bit_helper.cpp:24-37 clip_max_exponent */
+static inline uint32_t clip_max_exponent(int man_bits, uint32_t max_exponent, uint32_t q) {
+  const uint32_t qe = q & 0x7F800000u;
+  if (qe > max_exponent) {
+    const uint32_t max_man = (0x007FFFFFu >> (23 - man_bits)) << (23 - man_bits);
+    q = (q & 0x80000000u) | max_exponent | max_man;
+  }
+  return q;
+}
+
+/* ------------------------------------------------------------------------------------------- low-bit float
+ * quant_cpu.cpp:359-402 float_quantize (one element). */
+static inline float float_q1(float a, int man, int exp_bits, int bias, int flush, int rounding, uint32_t rnd) {
+  uint32_t target = f2u(a);
+  const int target_exp = (int)((target & 0x7FFFFFFFu) >> 23) - 127;
+  const int min_exp = -(bias - 1);
+  if (target_exp < min_exp) {
+    if (flush) return 0.0f;
+    const uint32_t shift_bits = ((uint32_t)(127 + min_exp) << 23) | (target & 0x80000000u);
+    const float shift = u2f(shift_bits);
+    const float val = a + shift;
+    const uint32_t qb = round_bitwise(f2u(val), man, rounding, rnd);
+    return u2f(qb) - shift;
+  }
+  uint32_t qb = round_bitwise(target, man, rounding, rnd);
+  qb = clip_exponent(exp_bits, man, target, qb);
+  return u2f(qb);
+}
+
+/* returns 0 ok, 1 bad argument (man outside 0..22: the reference's behaviour at man=23 is undefined) */
+int oracle_float_qdq(const float* in, float* out, int64_t n, int man, int exp_bits, int bias, int flush,
+                     int rounding, uint64_t seed) {
+  if (man < 0 || man > 22 || exp_bits < 1 || exp_bits > 8) return 1;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++)
+    out[i] = float_q1(in[i], man, exp_bits, bias, flush, rounding, rounding == R_STOCHASTIC ? rnd_bits(seed, (uint64_t)i) : 0u);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- block floating point
+ * quant_cpu.cpp:239-275 block_quantize_helper for one element, given the block's max|x| (symmetric=true path,
+ * the only one the Python layer ever requests: numerical/format.py:332). */
+static inline float bfp_q1(float x, float maxabs, int wl, int rounding, uint32_t rnd) {
+  const uint32_t max_exp = f2u(maxabs) & 0x7F800000u; /* (max_num << 1 >> 24 << 23) */
+  const float base = u2f(max_exp) * 6.0f;
+  const float t = x + base;                           /* fp32 RNE add: deliberate first rounding */
+  const uint32_t qb = round_bitwise(f2u(t), wl, rounding, rnd);
+  const float q = u2f(qb) - base;
+  return u2f(clip_max_exponent(wl - 2, max_exp, f2u(q)));
+}
+
+/* numerical/format.py:349-372 make_mantissa_asymmetric, restated literally for one block of `len` elements
+ * (q = symmetric result, x = original).  The reference runs it on a whole [N,B] chunk; rows are independent,
+ * and its "no edge -> return unchanged" early-out yields the same values as the rebuild (ldexp of the
+ * integer mantissas reproduces q exactly). */
+static void bfp_asym_block(float* q, const float* x, int64_t len, int n) {
+  int max_e = -200;
+  int e_i[1]; (void)e_i;
+  for (int64_t i = 0; i < len; i++) {
+    int e; float m = frexpf(q[i], &e);
+    if (e == 0 && m == 0.0f) e = -200;
+    if (e > max_e) max_e = e;
+  }
+  const int scale_e = max_e - n + 1;
+  const int edge = -((1 << (n - 1)) - 1);
+  for (int64_t i = 0; i < len; i++) {
+    int e; float m = frexpf(q[i], &e);
+    if (e == 0 && m == 0.0f) e = -200;
+    int im = (int)(m * powf(2.0f, (float)(e - scale_e)));
+    if (im == edge) {
+      const float old_err = q[i] - x[i];
+      const float cand_err = old_err - powf(2.0f, (float)scale_e);
+      if (fabsf(cand_err) <= fabsf(old_err)) im -= 1;
+      q[i] = ldexpf((float)im, scale_e);
+    }
+  }
+}
+
+/* numerical/format.py:304-343 BlockFloatingPoint.cast on a contiguous fp32 [rows, L] matrix with blocks of B
+ * along the last dim; ragged last block = torch.split semantics (:324-326).  B==1 is routed to float_quantize
+ * with man = wl-2, exp=8, bias=127, no flush (:312-320).
+ * returns 0 ok, 1 bad argument. */
+int oracle_bfp_qdq(const float* in, float* out, int64_t rows, int64_t L, int64_t B, int wl, int rounding,
+                   int symmetric, uint64_t seed) {
+  if (B < 1 || wl < 2) return 1;
+  if (B == 1) return oracle_float_qdq(in, out, rows * L, wl - 2, 8, 127, 0, rounding, seed);
+  if (wl > 22) return 1; /* reference shifts by a negative count: undefined */
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < rows; r++) {
+    const float* xi = in + r * L;
+    float* yo = out + r * L;
+    for (int64_t b0 = 0; b0 < L; b0 += B) {
+      const int64_t len = (L - b0 < B) ? (L - b0) : B;
+      float m = 0.0f;
+      for (int64_t i = 0; i < len; i++) { float a = fabsf(xi[b0 + i]); if (a > m) m = a; } /* quant_cpu.cpp:277-297 */
+      for (int64_t i = 0; i < len; i++)
+        yo[b0 + i] = bfp_q1(xi[b0 + i], m, wl, rounding,
+                            rounding == R_STOCHASTIC ? rnd_bits(seed, (uint64_t)(r * L + b0 + i)) : 0u);
+      if (!symmetric) bfp_asym_block(yo + b0, xi + b0, len, wl);
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- fixed point
+ * quant_cpu/sim_helper.cpp:5-12 fixed_min_max */
+static void fixed_min_max(int wl, int fl, int symmetric, float* t_min, float* t_max) {
+  const int sigma = -fl;
+  *t_min = (float)(-ldexp(1.0, wl - fl - 1));
+  *t_max = (float)(-(double)*t_min - ldexp(1.0, sigma));
+  if (symmetric) *t_min = (float)((double)*t_min + ldexp(1.0, sigma));
+}
+
+/* quant_cpu/sim_helper.cpp:14-21 round(a, r, sigma): `a + r` is a float add (r is a float parameter),
+ * `- 0.5` promotes to double, nearbyint(double) rounds half-to-even, result narrows to float.
+ * sim_helper.cpp:24-38 up_round / down_round use ceil / floor. */
+static inline float fixed_q1(float a, int sigma, int rounding, float r) {
+  a = ldexpf(a, -sigma);
+  if (rounding == R_UP) a = ceilf(a);
+  else if (rounding == R_DOWN) a = floorf(a);
+  else a = (float)nearbyint((double)(float)(a + r) - 0.5);
+  return ldexpf(a, sigma);
+}
+
+static inline float clampf(float a, float lo, float hi) { return a > hi ? hi : (a < lo ? lo : a); }
+
+static inline float rnd_unit(uint64_t seed, uint64_t idx) { /* [0,1) with 24 random bits, like rand_like */
+  return (float)(rnd_bits(seed, idx) >> 8) * (1.0f / 16777216.0f);
+}
+
+/* quant_cpu.cpp:148-167 (+ :127-146, 169-209 for the other modes), fused with the affine wrapper of
+ * numerical/cast.py:278-296:  v = x/sc + zp ; q = fixed_point_quantize(v) ; y = (q - zp) * sc, all fp32.
+ * x is viewed as [outer, C, inner] (C = size along ch_axis); channel c uses scale[c / group_size]
+ * (repeat_interleave(sc, group_size)[:C], cast.py:281-292).  scale == NULL -> no affine (bare Format.cast).
+ * Per-tensor: C = 1 (outer*inner = numel), group_size = 1, one scale.  Per-channel: group_size = 1. */
+int oracle_fixed_qdq(const float* in, float* out, int64_t outer, int64_t C, int64_t inner, int wl, int fl,
+                     int clamp, int symmetric, int rounding, const float* scale, const int64_t* zp,
+                     int64_t group_size, uint64_t seed) {
+  if (wl < 1 || group_size < 1) return 1;
+  float t_min, t_max;
+  fixed_min_max(wl, fl, symmetric, &t_min, &t_max);
+  const int sigma = -fl;
+  const int64_t n = outer * C * inner;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t c = (i / inner) % C;
+    float v = in[i], sc = 1.0f, z = 0.0f;
+    if (scale) {
+      sc = scale[c / group_size];
+      z = (float)zp[c / group_size];
+      v = v / sc + z;
+    }
+    float r = 0.5f;
+    if (rounding == R_STOCHASTIC) r = rnd_unit(seed, (uint64_t)i);
+    float q = fixed_q1(v, sigma, rounding, r);
+    if (clamp) q = clampf(q, t_min, t_max);
+    if (scale) q = (q - z) * sc;
+    out[i] = q;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- N:M mask
+ * sparse.py:163-180 BlockTopK.forward on contiguous groups of M: idx = argsort(score)[:, :M-K]; mask =
+ * ones.scatter_(idx, 0).  torch.argsort on CPU behaves as a STABLE ascending sort (pinned by the golden
+ * vectors): ties keep index order, NaN sorts last.  sparse.py:300: y = x * mask (a multiply, so a masked
+ * negative keeps its sign bit: -1 * 0 = -0.0).  Either of mask/y may be NULL. */
+static inline int key_lt(float a, float b) { /* a sorts strictly before b */
+  if (isnan(a)) return 0;
+  if (isnan(b)) return 1;
+  return a < b;
+}
+int oracle_nm_mask(const float* score, const float* x, float* mask, float* y, int64_t n_groups, int M, int K) {
+  if (M < 1 || M > 64 || K < 1 || K > M) return 1;
+#pragma omp parallel for schedule(static)
+  for (int64_t g = 0; g < n_groups; g++) {
+    const float* s = score + g * M;
+    int order[64];
+    for (int i = 0; i < M; i++) order[i] = i;
+    for (int i = 1; i < M; i++) { /* stable insertion sort, ascending */
+      int oi = order[i], j = i - 1;
+      while (j >= 0 && key_lt(s[oi], s[order[j]])) { order[j + 1] = order[j]; j--; }
+      order[j + 1] = oi;
+    }
+    float mk[64];
+    for (int i = 0; i < M; i++) mk[i] = 1.0f;
+    for (int i = 0; i < M - K; i++) mk[order[i]] = 0.0f;
+    for (int i = 0; i < M; i++) {
+      if (mask) mask[g * M + i] = mk[i];
+      if (y) y[g * M + i] = x[g * M + i] * mk[i];
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- reductions
+ * numerical/observer.py:173-193 MinMaxObserver.forward (one call, no running state) on slabs: x viewed as
+ * [outer, C, inner]; group g covers channels [g*group_size, min((g+1)*group_size, C)) (torch.split along
+ * ch_axis, cast.py:200-204).  Writes min/max per group. */
+int oracle_group_minmax(const float* in, int64_t outer, int64_t C, int64_t inner, int64_t group_size,
+                        float* mn, float* mx) {
+  if (group_size < 1) return 1;
+  const int64_t G = (C + group_size - 1) / group_size;
+  for (int64_t g = 0; g < G; g++) { mn[g] = INFINITY; mx[g] = -INFINITY; }
+  for (int64_t o = 0; o < outer; o++)
+    for (int64_t c = 0; c < C; c++) {
+      const int64_t g = c / group_size;
+      const float* p = in + (o * C + c) * inner;
+      for (int64_t i = 0; i < inner; i++) {
+        if (p[i] < mn[g]) mn[g] = p[i];
+        if (p[i] > mx[g]) mx[g] = p[i];
+      }
+    }
+  return 0;
+}
+
+/* numerical/observer.py:59-115 DMXObserverBase._calculate_qparams for FixedPoint formats.
+ * qmin/qmax from observer.py:13-21: symmetric format -> [-(2^(p-1)-1), 2^(p-1)-1], else [-2^(p-1), 2^(p-1)-1].
+ * symmetric qscheme: scale = max(-min_neg, max_pos) / ((qmax-qmin)/2), clamped >= eps, zp = 0.
+ * affine qscheme:    scale = (max_pos - min_neg) / (qmax-qmin), clamped >= eps,
+ *                    zp = clamp(qmin - round(min_neg/scale), qmin, qmax)  (torch.round = half-to-even). */
+int oracle_qparams(const float* mn, const float* mx, int64_t G, int qmin, int qmax, int symmetric_qscheme,
+                   float* scale, int64_t* zp) {
+  const float eps = 1.1920928955078125e-07f; /* torch.finfo(torch.float32).eps */
+  for (int64_t g = 0; g < G; g++) {
+    const float min_neg = mn[g] < 0.0f ? mn[g] : 0.0f;
+    const float max_pos = mx[g] > 0.0f ? mx[g] : 0.0f;
+    if (symmetric_qscheme) {
+      float m = (-min_neg > max_pos) ? -min_neg : max_pos;
+      float s = m / ((float)(qmax - qmin) / 2.0f);
+      scale[g] = s > eps ? s : eps;
+      zp[g] = 0;
+    } else {
+      float s = (max_pos - min_neg) / (float)(qmax - qmin);
+      s = s > eps ? s : eps;
+      float z = (float)qmin - nearbyintf(min_neg / s);
+      z = z < (float)qmin ? (float)qmin : (z > (float)qmax ? (float)qmax : z);
+      scale[g] = s;
+      zp[g] = (int64_t)z;
+    }
+  }
+  return 0;
+}
+
+/* numerical/smoothquant.py:285-299 _maxabs: per-channel max|x| of x viewed as [outer, C, inner]. */
+int oracle_channel_maxabs(const float* in, int64_t outer, int64_t C, int64_t inner, float* out) {
+  for (int64_t c = 0; c < C; c++) out[c] = 0.0f;
+  for (int64_t o = 0; o < outer; o++)
+    for (int64_t c = 0; c < C; c++) {
+      const float* p = in + (o * C + c) * inner;
+      for (int64_t i = 0; i < inner; i++) { float a = fabsf(p[i]); if (a > out[c] || isnan(a)) out[c] = a; }
+    }
+  return 0;
+}

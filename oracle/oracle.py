@@ -1,0 +1,189 @@
+"""oracle/oracle.py — ctypes front-end of the CPU oracle (oracle/oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this module; the product
+package (dmx-compressor_amd/) never does and fails loudly without its HIP library instead.
+
+The C file restates the reference's per-element arithmetic; this module restates the reference's *Python*
+orchestration around it (layout handling and dtype round-trips), citing numerical/format.py and
+numerical/cast.py of /root/reference/src/dmx/compressor.  CPU torch tensors are used only as typed
+containers (bf16/fp16 <-> fp32 conversion, transposes); all quantisation arithmetic happens in oracle.c.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+R_UP, R_DOWN, R_NEAREST, R_STOCHASTIC = 0, 1, 2, 3
+ROUNDING = {"up": R_UP, "down": R_DOWN, "nearest": R_NEAREST, "stochastic": R_STOCHASTIC}
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        fp, i64, i32, u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64
+        L.oracle_float_qdq.argtypes = [fp, fp, i64, i32, i32, i32, i32, i32, u64]
+        L.oracle_bfp_qdq.argtypes = [fp, fp, i64, i64, i64, i32, i32, i32, u64]
+        L.oracle_fixed_qdq.argtypes = [fp, fp, i64, i64, i64, i32, i32, i32, i32, i32, fp, fp, i64, u64]
+        L.oracle_nm_mask.argtypes = [fp, fp, fp, fp, i64, i32, i32]
+        L.oracle_group_minmax.argtypes = [fp, i64, i64, i64, i64, fp, fp]
+        L.oracle_qparams.argtypes = [fp, fp, i64, i32, i32, i32, fp, fp]
+        L.oracle_channel_maxabs.argtypes = [fp, i64, i64, i64, fp]
+        for f in ("oracle_float_qdq", "oracle_bfp_qdq", "oracle_fixed_qdq", "oracle_nm_mask",
+                  "oracle_group_minmax", "oracle_qparams", "oracle_channel_maxabs"):
+            getattr(L, f).restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _f32c(x: torch.Tensor) -> torch.Tensor:
+    assert not x.is_cuda, "the oracle is CPU-only"
+    return x.detach().to(torch.float32).contiguous()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise ValueError(f"oracle {what}: bad argument (rc={rc})")
+
+
+# ------------------------------------------------------------------------------------------------ formats
+def float_quantize(x, man, exp, bias, flush_subnormal, rounding="nearest", seed=0):
+    """quant/quant_function.py:120-152 -> quant_cpu.cpp:359-402.  fp32 in -> fp32 out."""
+    xi = _f32c(x)
+    out = torch.empty_like(xi)
+    _check(lib().oracle_float_qdq(_ptr(xi), _ptr(out), xi.numel(), man, exp, bias, int(flush_subnormal),
+                                  ROUNDING[rounding], seed), "float_qdq")
+    return out
+
+
+def floating_point_cast(x, man, exp, bias, flush_subnormal, unsigned=False, rounding="nearest", seed=0):
+    """numerical/format.py:208-233 FloatingPoint.cast (returns fp32, or x itself for the two native bypasses)."""
+    rep = f"FP[{'0' if unsigned else '1'}|{exp}|{man},{bias}]({'F' if flush_subnormal else '_'}{'N' if rounding=='nearest' else 'S'})"
+    if (x.dtype == torch.float32 and rep == "FP[1|8|23,127](_N)") or (x.dtype == torch.float16 and rep == "FP[1|5|10,15](_N)"):
+        y = x
+    else:
+        y = float_quantize(x, man, exp, bias, flush_subnormal, rounding, seed)
+    if rep == "FP[1|5|10,15](FN)":  # format.py:222-232 extra fp16 subnormal flush
+        y = torch.where(y.abs() < 2.0 ** -14, torch.zeros((), dtype=y.dtype), y)
+    return y.abs() if unsigned else y
+
+
+def bfp_cast(x, precision, block_size, block_dim=-1, symmetric=True, rounding="nearest", seed=0):
+    """numerical/format.py:304-343 BlockFloatingPoint.cast: fp32 result, same shape, with the reference's
+    transposed-view strides when block_dim != -1 (values are what the tests compare)."""
+    xf = x.detach().to(torch.float32)
+    if block_size == 1:
+        return float_quantize(xf, precision - 2, 8, 127, False, rounding, seed)
+    xt = xf.transpose(block_dim, -1)
+    shp = xt.shape
+    x2 = xt.reshape(-1, shp[-1]).contiguous()
+    out = torch.empty_like(x2)
+    _check(lib().oracle_bfp_qdq(_ptr(x2), _ptr(out), x2.shape[0], x2.shape[1], block_size, precision,
+                                ROUNDING[rounding], int(symmetric), seed), "bfp_qdq")
+    return out.reshape(shp).transpose_(block_dim, -1)
+
+
+def fixed_point_cast(x, precision, fraction, clamp=True, symmetric=True, rounding="nearest", seed=0):
+    """numerical/format.py:134-142 FixedPoint.cast -> quant_cpu.cpp:148-167."""
+    xi = _f32c(x)
+    out = torch.empty_like(xi)
+    _check(lib().oracle_fixed_qdq(_ptr(xi), _ptr(out), 1, 1, xi.numel(), precision, fraction, int(clamp),
+                                  int(symmetric), ROUNDING[rounding], None, None, 1, seed), "fixed_qdq")
+    return out
+
+
+def fixed_point_affine_cast(x, precision, fraction, clamp, symmetric, scale, zero_point, ch_axis=None,
+                            group_size=None, rounding="nearest", seed=0):
+    """numerical/cast.py:278-296: x/sc + zp -> FixedPoint.cast -> (x - zp)*sc, fp32 result.
+    ch_axis None = per-tensor (scale has one element); group_size None with ch_axis = per-channel."""
+    xi = _f32c(x)
+    out = torch.empty_like(xi)
+    sc = scale.detach().to(torch.float32).contiguous()
+    zp = zero_point.detach().to(torch.int64).contiguous()
+    if ch_axis is None:
+        outer, C, inner, gs = 1, 1, xi.numel(), 1
+    else:
+        ax = ch_axis % xi.dim()
+        C = xi.shape[ax]
+        outer = int(np.prod(xi.shape[:ax], dtype=np.int64))
+        inner = int(np.prod(xi.shape[ax + 1:], dtype=np.int64))
+        gs = group_size or 1
+    _check(lib().oracle_fixed_qdq(_ptr(xi), _ptr(out), outer, C, inner, precision, fraction, int(clamp),
+                                  int(symmetric), ROUNDING[rounding], _ptr(sc), _ptr(zp), gs, seed), "fixed_qdq")
+    return out
+
+
+def cast_to(x, cast_fn):
+    """numerical/cast.py:261-306 CastTo.forward dtype contract: remember physical dtype, cast in fp32,
+    `.to(physical_dtype)` (torch CPU RNE narrowing)."""
+    return cast_fn(x).to(x.dtype)
+
+
+# ------------------------------------------------------------------------------------------------ sparsity
+def nm_mask(score, K, M, block_dim=-1):
+    """sparse.py:163-180 BlockTopK.forward: float mask in score's dtype."""
+    assert score.shape[block_dim] % M == 0
+    st = score.detach().transpose(block_dim, -1)
+    shp = st.shape
+    s2 = st.reshape(-1, M).to(torch.float32).contiguous()
+    mask = torch.empty_like(s2)
+    _check(lib().oracle_nm_mask(_ptr(s2), None, _ptr(mask), None, s2.shape[0], M, K), "nm_mask")
+    return mask.reshape(shp).transpose_(block_dim, -1).to(score.dtype)
+
+
+def sparsify(x, score, K, M, block_dim=-1):
+    """sparse.py:287-301 Sparsify.forward: x * mask (type promotion as torch does)."""
+    return x * nm_mask(score, K, M, block_dim)
+
+
+# ------------------------------------------------------------------------------------------------ calibration
+def group_minmax(x, ch_axis, group_size):
+    xi = _f32c(x)
+    ax = ch_axis % xi.dim()
+    C = xi.shape[ax]
+    outer = int(np.prod(xi.shape[:ax], dtype=np.int64))
+    inner = int(np.prod(xi.shape[ax + 1:], dtype=np.int64))
+    G = (C + group_size - 1) // group_size
+    mn, mx = torch.empty(G), torch.empty(G)
+    _check(lib().oracle_group_minmax(_ptr(xi), outer, C, inner, group_size, _ptr(mn), _ptr(mx)), "group_minmax")
+    return mn, mx
+
+
+def qparams(mn, mx, precision, fmt_symmetric, qscheme_symmetric):
+    qmin = -(2 ** (precision - 1)) + (1 if fmt_symmetric else 0)
+    qmax = 2 ** (precision - 1) - 1
+    mn, mx = _f32c(mn), _f32c(mx)
+    sc = torch.empty(mn.numel())
+    zp = torch.empty(mn.numel(), dtype=torch.int64)
+    _check(lib().oracle_qparams(_ptr(mn), _ptr(mx), mn.numel(), qmin, qmax, int(qscheme_symmetric), _ptr(sc), _ptr(zp)), "qparams")
+    return sc, zp
+
+
+def channel_maxabs(x, ch_axis):
+    xi = _f32c(x)
+    ax = ch_axis % xi.dim()
+    C = xi.shape[ax]
+    outer = int(np.prod(xi.shape[:ax], dtype=np.int64))
+    inner = int(np.prod(xi.shape[ax + 1:], dtype=np.int64))
+    out = torch.empty(C)
+    _check(lib().oracle_channel_maxabs(_ptr(xi), outer, C, inner, _ptr(out)), "channel_maxabs")
+    return out

@@ -1,0 +1,64 @@
+"""Portable synthetic inputs: a counter-based generator (splitmix64 on the linear index -> Box-Muller in fp64)
+so the build container and the GPU box produce identical bits without shipping tensors."""
+import numpy as np
+import torch
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(idx, seed):
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (idx.astype(np.uint64) + np.uint64(1)))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform(n, seed):
+    """float64 in (0, 1)"""
+    r = splitmix64(np.arange(n, dtype=np.uint64), seed)
+    return ((r >> np.uint64(11)).astype(np.float64) + 0.5) / float(1 << 53)
+
+
+def normal(n, seed):
+    u1, u2 = uniform(n, seed), uniform(n, seed ^ 0xABCDEF1234567)
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def make(kind, shape, seed=0, dtype=torch.float32, block=16):
+    """kinds: normal | heavy (exponent spread) | outlier (one 2^10 outlier per block) | ties (half-quantum
+    lattice: every value is a multiple of 2^-8 with |x| < 2) | zeros | denormal | mixed (all of them, by rows)"""
+    n = int(np.prod(shape))
+    if kind == "normal":
+        v = normal(n, seed)
+    elif kind == "heavy":
+        v = normal(n, seed) * np.exp(4.0 * normal(n, seed + 1))
+    elif kind == "outlier":
+        v = normal(n, seed)
+        pos = np.arange(0, n, block) + (splitmix64(np.arange(0, n, block, dtype=np.uint64), seed + 7) % np.uint64(block)).astype(np.int64)
+        pos = pos[pos < n]
+        v[pos] *= 1024.0
+    elif kind == "ties":
+        k = (splitmix64(np.arange(n, dtype=np.uint64), seed) % np.uint64(1023)).astype(np.int64) - 511
+        v = k.astype(np.float64) / 256.0
+    elif kind == "zeros":
+        v = np.zeros(n)
+    elif kind == "denormal":
+        v = normal(n, seed) * 1e-40
+    elif kind == "mixed":
+        parts = [make(k, (n,), seed + i, torch.float32, block).double().numpy()
+                 for i, k in enumerate(("normal", "heavy", "outlier", "ties", "zeros", "denormal"))]
+        sel = (np.arange(n) // max(block * 4, 1)) % len(parts)
+        v = np.choose(sel, parts)
+    else:
+        raise ValueError(kind)
+    t = torch.from_numpy(v.astype(np.float32)).reshape(shape)
+    return t.to(dtype)
+
+
+def bits_equal(a: torch.Tensor, b: torch.Tensor) -> int:
+    """number of elements whose bit patterns differ (NaN-safe, distinguishes -0.0 from +0.0)"""
+    assert a.shape == b.shape and a.dtype == b.dtype, (a.shape, b.shape, a.dtype, b.dtype)
+    a, b = a.detach().cpu().contiguous(), b.detach().cpu().contiguous()
+    it = {4: torch.int32, 2: torch.int16, 8: torch.int64}[a.element_size()]
+    return int((a.view(it) != b.view(it)).sum())

@@ -1,0 +1,142 @@
+"""CPU-side tests (-m "not gpu"): the C-ABI library loads and exports exactly what include/dmxq.h declares,
+argument validation never needs a GPU, and the host-side vocabulary (shorthands, aliases) round-trips."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "dmxq.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(dmxq_\w+)\s*\(", src))
+
+
+def test_library_exports_every_declared_symbol(dmx):
+    L = dmx._lib.lib()
+    declared = _header_functions()
+    assert declared, "no declarations parsed from include/dmxq.h"
+    for name in declared:
+        assert hasattr(L, name), f"libdmxq.so does not export {name}"
+    # the ctypes table covers the whole header (minus the two helpers bound separately)
+    assert declared - {"dmxq_status_string", "dmxq_abi_version"} == set(dmx._lib.SIGNATURES)
+    assert L.dmxq_abi_version() == 1
+    assert L.dmxq_status_string(0) == b"ok" and b"bad" in L.dmxq_status_string(1)
+
+
+def test_argument_validation_without_gpu(dmx):
+    """Bad arguments are rejected before anything is launched (no GPU needed); n == 0 is a successful no-op."""
+    L = dmx._lib.lib()
+    lib = dmx._lib
+    null = ctypes.c_void_p(None)
+    one = ctypes.c_void_p(16)
+    assert L.dmxq_bfp_qdq(null, null, lib.BF16, lib.BF16, 0, 16, 1, 16, 8, lib.ROUND_NEAREST, 1, 0, null) == lib.OK
+    assert L.dmxq_bfp_qdq(null, null, lib.BF16, lib.BF16, 4, 16, 1, 16, 8, lib.ROUND_NEAREST, 1, 0, null) == lib.ERR_BAD_ARG
+    assert L.dmxq_bfp_qdq(one, one, 7, lib.BF16, 4, 16, 1, 16, 8, lib.ROUND_NEAREST, 1, 0, null) == lib.ERR_BAD_ARG
+    assert L.dmxq_bfp_qdq(one, one, lib.BF16, lib.BF16, 4, 16, 1, 0, 8, lib.ROUND_NEAREST, 1, 0, null) == lib.ERR_BAD_ARG
+    assert L.dmxq_bfp_qdq(one, one, lib.BF16, lib.BF16, 4, 16, 1, 16, 8, 9, 1, 0, null) == lib.ERR_BAD_ARG
+    assert L.dmxq_bfp_qdq(one, one, lib.BF16, lib.BF16, 4, 16, 1, 16, 23, lib.ROUND_NEAREST, 1, 0, null) == lib.ERR_UNSUPPORTED
+    assert L.dmxq_float_qdq(one, one, lib.F32, lib.F32, 8, 23, 8, 127, 0, 0, lib.ROUND_NEAREST, 0, null) == lib.ERR_UNSUPPORTED
+    assert L.dmxq_float_qdq(one, one, lib.F32, lib.F32, 8, 3, 9, 7, 0, 0, lib.ROUND_NEAREST, 0, null) == lib.ERR_BAD_ARG
+    assert L.dmxq_fixed_qdq(one, one, lib.F32, lib.F32, 1, 1, 8, 8, 0, 1, 1, lib.ROUND_NEAREST, one, null, 1, 0, null) == lib.ERR_BAD_ARG
+    assert L.dmxq_nm_mask(one, lib.F32, null, 0, one, lib.F32, null, 0, 1, 6, 1, 2, 4, null) == lib.ERR_BAD_ARG  # L % M
+    assert L.dmxq_nm_mask(one, lib.F32, null, 0, one, lib.F32, null, 0, 1, 8, 1, 5, 4, null) == lib.ERR_BAD_ARG  # K > M
+    assert L.dmxq_nm_mask(one, lib.F32, null, 0, null, 0, null, 0, 1, 8, 1, 2, 4, null) == lib.ERR_BAD_ARG      # no output
+
+
+def test_no_cpu_fallback(dmx):
+    x = torch.randn(4, 16)
+    for call in (lambda: dmx.ops.bfp_qdq(x, 8, 16), lambda: dmx.ops.float_qdq(x, 10, 5, 15, True),
+                 lambda: dmx.ops.fixed_qdq(x, 8, 0), lambda: dmx.ops.nm_mask(x, 2, 4),
+                 lambda: dmx.CastTo(format="BFP[8|8]{16}(SN)")(x), lambda: dmx.ops.gelu(x)):
+        with pytest.raises(dmx.DmxqError):
+            call()
+
+
+SHORTHANDS = ["SAME", "XP[8,0](CSN)", "XP[4,0](CSN)", "XP[8,+4](C_N)", "XP[16,-2](_SS)", "FP[1|5|10,15](FN)",
+              "FP[1|8|7,127](FN)", "FP[1|4|3,7](_N)", "FP[0|4|4,7](FN)", "FP[1|5|2,15](_S)", "BFP[8|8]{16}(SN)",
+              "BFP[8|8]{64}(_N)", "BFP[24|8]{1}(SN)", "BFP[4|8]{128}(SU)", "SBFP<XP[4,0](CSN)><FP[0|4|4,7](FN)>{16}",
+              "MXFP8[E4M3]{32}", "MXFP4[E2M1]{128}", "MXINT8{32}", "MXINT4{64}"]
+
+
+@pytest.mark.parametrize("sh", SHORTHANDS)
+def test_format_shorthand_roundtrip(dmx, sh):
+    f = dmx.Format.from_shorthand(sh)
+    assert repr(f) == sh
+    assert repr(dmx.Format.from_shorthand(repr(f))) == sh
+    str(f)
+
+
+def test_format_validation_and_properties(dmx):
+    with pytest.raises(ValueError):
+        dmx.Format.from_shorthand("BFP[8|8]{16,1}(SN)")          # legacy form is not the current grammar
+    fmt, dim = dmx.BlockFloatingPoint.parse_legacy("BFP[8|8]{64,1}(SN)")
+    assert repr(fmt) == "BFP[8|8]{64}(SN)" and dim == 1
+    with pytest.raises(ValueError):
+        dmx.Format.from_shorthand("INT8")
+    with pytest.raises(AssertionError):
+        dmx.FixedPoint(25, 0)
+    with pytest.raises(AssertionError):
+        dmx.FloatingPoint(mantissa=3, exponent=4, bias=-200)
+    with pytest.raises(AssertionError):
+        dmx.BlockFloatingPoint(precision=1)
+    assert dmx.format.BFP16_16.bytes_per_elem == (8 + 8 / 16) / 8
+    assert dmx.format.BFP16_16.bit_precision == 8.5
+    assert dmx.format.INT4.bytes_per_elem == 0.5
+    assert dmx.format.FLOAT16.bit_precision == 16.0
+    assert dmx.format.AFLOAT8.largest_representable_power_of_two == 256
+    assert dmx.format.SBFP12_16.man_scaling == 7
+    assert repr(dmx.format.BFP16A_16) == "BFP[6|8]{16}(_N)"     # reference alias quirk kept
+    assert repr(dmx.format.MXINT8_K32) == "MXINT8{32}" and isinstance(dmx.format.MXINT8_K32, dmx.BlockFloatingPoint)
+    assert len(vars(dmx.format)) == 76
+
+
+def test_sparseness_shorthands(dmx):
+    for sh in ["DENSE", "TOPK{0.5}(U)", "BTOPK{2:4,-1}(U)", "BTOPK{4:8,1}(M)", "BERN"]:
+        assert repr(dmx.Sparseness.from_shorthand(sh)) == sh
+    assert dmx.sparseness.BTK8_2_LD.density == 0.25 and dmx.sparseness.BTK8_4_FD.block_dim == 1
+    with pytest.raises(AssertionError):
+        dmx.BlockTopK(K=5, block_size=4)
+    with pytest.raises(ValueError):
+        dmx.Sparseness.from_shorthand("NM{2:4}")
+
+
+def test_quant_seam_signatures(dmx):
+    q = dmx.quant.quant_hip
+    for fam in ("block_quantize", "float_quantize", "fixed_point_quantize"):
+        for r in ("nearest", "stochastic", "down", "up"):
+            assert callable(getattr(q, f"{fam}_{r}"))
+    with pytest.raises(AssertionError):
+        dmx.quant.float_quantize(torch.zeros(2), 5, 10, rounding="up")   # quant_function.py:138-140
+    with pytest.raises(AssertionError):
+        dmx.quant.block_quantize(torch.zeros(2), 8, rounding="bogus")
+    with pytest.raises(dmx.DmxqError):
+        dmx.quant.block_quantize(torch.zeros(2, 16), 8, 0, True, "nearest")
+
+
+def test_castto_configuration_surface(dmx):
+    c = dmx.CastTo()
+    assert repr(c.format) == "SAME" and c.block_dim == -1 and c.group_size is None
+    c.set_format("BFP[8|8]{64}(SN)")
+    assert isinstance(c.format, dmx.BlockFloatingPoint) and c.get_precision() == 8.125
+    c.set_pre_transform({"format": "FP[1|5|10,15](FN)", "shaping": [("view", (-1, 4))]})
+    assert isinstance(c.pre_transform["format"], dmx.FloatingPoint)
+    x = torch.arange(24.0).reshape(2, 3, 4)
+    y, inv = dmx.CastTo.apply_shaping_seq(x, [("permute", (2, 0, 1)), ("flatten", (0, 1)), ("view", (4, 6))])
+    z, _ = dmx.CastTo.apply_shaping_seq(y, inv)
+    assert torch.equal(z, x)
+    with pytest.raises(AssertionError):
+        dmx.CastTo(format="XP[8,0](CSN)", group_size=4, qscheme=torch.per_channel_symmetric)
+    d = dmx.CastToDict({"input_cast": dmx.CastTo(), "other_cast": dmx.CastTo()})
+    d.set_format(["BFP[8|8]{16}(SN)", None])
+    assert repr(d["input_cast"].format) == "BFP[8|8]{16}(SN)" and repr(d["other_cast"].format) == "SAME"
+    with pytest.raises(RuntimeError):
+        d.set_format({"nope": "SAME", "x": "SAME"})
+    # SAME format on CPU tensors is a clone and needs no GPU
+    t = torch.randn(3)
+    out = dmx.CastTo()(t)
+    assert torch.equal(out, t) and out.data_ptr() != t.data_ptr()

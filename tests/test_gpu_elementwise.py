@@ -1,0 +1,140 @@
+"""-m gpu parity tests: low-bit float and fixed-point (+affine / group-quant) Q->DQ vs the CPU oracle, bit-exact.
+
+Reference: quant_cpu.cpp:359-402 (float), :127-209 + sim_helper.cpp (fixed), numerical/cast.py:278-296 (affine).
+"""
+import pytest
+import torch
+
+from _data import bits_equal, make
+
+pytestmark = pytest.mark.gpu
+
+# (man, exp, bias, flush): FP16-FN, FP16 no-flush, BF16-FN, E4M3, E5M2, FP[0|8|0] scaler, BFP32_1 path, E2M1, E3M2
+FLOAT_FORMATS = [(10, 5, 15, True), (10, 5, 15, False), (7, 8, 127, True), (3, 4, 7, False), (2, 5, 15, False),
+                 (0, 8, 127, False), (22, 8, 127, False), (1, 2, 1, False), (2, 3, 3, False), (4, 4, 7, True)]
+
+
+def _special(dtype):
+    v = torch.tensor([0.0, -0.0, 65504.0, 65520.0, 3e38, -3e38, 1e-40, -1e-40, 6.0e-5, 6.1035e-5, 6.2e-5, 5.9e-8,
+                      448.0, 464.0, 480.0, 1e-3, -1.5, 2.0 ** -14, 2.0 ** -15, 2.0 ** -24, 2.0 ** -25])
+    return v.to(dtype)
+
+
+@pytest.mark.parametrize("fmt", FLOAT_FORMATS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_float_qdq_nearest(dmx, cuda, oracle, fmt, dtype):
+    man, exp, bias, flush = fmt
+    x = torch.cat([make("heavy", (50003,), seed=man + exp, dtype=dtype), _special(dtype)])
+    got = dmx.ops.float_qdq(x.to(cuda), man, exp, bias, flush)
+    want = oracle.float_quantize(x, man, exp, bias, flush).to(dtype)
+    assert bits_equal(got, want) == 0
+    got32 = dmx.ops.float_qdq(x.to(cuda), man, exp, bias, flush, out_dtype=torch.float32)
+    assert bits_equal(got32, oracle.float_quantize(x, man, exp, bias, flush)) == 0
+
+
+@pytest.mark.parametrize("rounding", ["stochastic"])
+def test_float_qdq_stochastic_matches_oracle_stream(dmx, cuda, oracle, rounding):
+    x = make("heavy", (4099,), seed=4)
+    got = dmx.ops.float_qdq(x.to(cuda), 3, 4, 7, False, rounding=rounding, seed=42)
+    assert bits_equal(got, oracle.float_quantize(x, 3, 4, 7, False, rounding, 42)) == 0
+
+
+def test_float_unsigned_and_bypass(dmx, cuda, oracle):
+    x = make("normal", (1000,), seed=1)
+    f = dmx.Format.from_shorthand("FP[0|4|4,7](FN)")
+    got = f.cast(x.to(cuda))
+    want = oracle.floating_point_cast(x, 4, 4, 7, True, unsigned=True)
+    assert bits_equal(got, want) == 0
+    xg = x.to(cuda)
+    assert dmx.format.FLOAT32.cast(xg) is xg                                   # format.py:209-212 pass-through
+    h = xg.half()
+    assert dmx.Format.from_shorthand("FP[1|5|10,15](_N)").cast(h) is h
+    with pytest.raises(NotImplementedError):
+        dmx.ops.float_qdq(xg, 23, 8, 127, False)                               # reference UB (shift by -1)
+
+
+def test_fp16_format_matches_torch_half_roundtrip(dmx, cuda):
+    """FLOAT16 = FP[1|5|10,15](FN) on in-range values is IEEE fp16 rounding with subnormals flushed."""
+    x = make("normal", (100000,), seed=8).to(cuda)
+    got = dmx.format.FLOAT16.cast(x)
+    ref = x.half().float()
+    ref = torch.where(ref.abs() < 2.0 ** -14, torch.zeros_like(ref), ref)
+    assert torch.equal(got, ref)
+
+
+FIXED_FORMATS = [(8, 0, True, True), (8, 0, True, False), (4, 0, True, True), (8, 4, True, True), (8, -2, True, False),
+                 (16, 8, False, True), (4, 2, True, False), (24, 0, True, True)]
+
+
+@pytest.mark.parametrize("fmt", FIXED_FORMATS)
+@pytest.mark.parametrize("rounding", ["nearest", "down", "up", "stochastic"])
+def test_fixed_qdq(dmx, cuda, oracle, fmt, rounding):
+    wl, fl, clamp, sym = fmt
+    edge = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 0.5 + 2.0 ** -24, 126.5, 127.5, -127.5, 128.5, 1e9, -1e9, 0.0, -0.0])
+    x = torch.cat([make("heavy", (50001,), seed=wl + fl), make("normal", (50000,), seed=3) * 40, edge])
+    got = dmx.ops.fixed_qdq(x.to(cuda), wl, fl, clamp, sym, rounding, seed=11)
+    want = oracle.fixed_point_cast(x, wl, fl, clamp, sym, rounding, seed=11)
+    assert bits_equal(got, want) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_fixed_affine_per_tensor_channel_group(dmx, cuda, oracle, dtype):
+    x = make("normal", (37, 50, 3), seed=21, dtype=dtype)
+    g = torch.Generator().manual_seed(1)
+    # per tensor
+    sc, zp = torch.tensor([0.0173]), torch.tensor([3])
+    got = dmx.ops.fixed_qdq(x.to(cuda), 8, 0, True, False, scale=sc, zero_point=zp)
+    want = oracle.fixed_point_affine_cast(x, 8, 0, True, False, sc, zp).to(dtype)
+    assert bits_equal(got, want) == 0
+    for ax in (0, 1, 2, -1):
+        C = x.shape[ax]
+        sc = torch.rand(C, generator=g) * 0.05 + 1e-3
+        zp = torch.randint(-5, 6, (C,), generator=g)
+        got = dmx.ops.fixed_qdq(x.to(cuda), 8, 0, True, True, scale=sc, zero_point=zp, ch_axis=ax)
+        want = oracle.fixed_point_affine_cast(x, 8, 0, True, True, sc, zp, ch_axis=ax).to(dtype)
+        assert bits_equal(got, want) == 0, ax
+        for gs in (1, 2, 7, C, C + 3):  # ragged last group, one group, group larger than C
+            G = -(-C // gs)
+            got = dmx.ops.fixed_qdq(x.to(cuda), 4, 0, True, True, scale=sc[:G], zero_point=zp[:G], ch_axis=ax, group_size=gs)
+            want = oracle.fixed_point_affine_cast(x, 4, 0, True, True, sc[:G], zp[:G], ch_axis=ax, group_size=gs).to(dtype)
+            assert bits_equal(got, want) == 0, (ax, gs)
+
+
+def test_reference_known_answers_group_quant(dmx, cuda):
+    """tests/test_group_quant.py:49-63 of the reference: INT4, group_size 2 along dim 0, MinMax symmetric."""
+    x = torch.tensor([[0, 1], [3, 7], [5.1, 8], [10, 14], [0.1, 0.7]])
+    y = torch.tensor([[0, 1], [3, 7], [6, 8], [10, 14], [0.1, 0.7]])
+    cast = dmx.CastTo(format=dmx.format.INT4, observer=dmx.MinMaxObserver, group_size=2,
+                      qscheme=torch.per_tensor_symmetric, ch_axis=0)
+    cast.enable_observer()
+    out = cast(x.to(cuda))
+    assert torch.allclose(out.cpu(), y, rtol=0.0, atol=1e-6)
+
+
+def test_reference_known_answers_bfp_block1(dmx, cuda):
+    """tests/test_bfp.py:26-65 of the reference (block size 1 -> float_quantize path)."""
+    x = torch.tensor([1.0, 1.0 + 2 ** -7, 1.0 + 2 ** -6, 1.0 + 2 ** -6 + 2 ** -7]).to(cuda)
+    y = torch.tensor([1.0, 1.0, 1.015625, 1.03125]).to(cuda)
+    c = dmx.CastTo(format="BFP[8|8]{1}(SN)")
+    assert torch.all(c(x) == y) and torch.all(c(-x) == -y)
+    x = torch.tensor([1.0, 1.0 + 2 ** -3, 1.0 + 2 ** -2, 1.0 + 2 ** -2 + 2 ** -3]).to(cuda)
+    y = torch.tensor([1.0, 1.0, 1.25, 1.5]).to(cuda)
+    c = dmx.CastTo(format="BFP[4|8]{1}(SN)")
+    assert torch.all(c(x) == y) and torch.all(c(-x) == -y)
+    # test_bfp.py:11-23
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((1, 1000), generator=g)
+    x *= 0.5 / x.abs().max()
+    x += 1.0
+    x = x.to(cuda)
+    assert torch.allclose(dmx.CastTo(format="BFP[8|8]{1}(SN)")(x), x, rtol=0.0, atol=2 ** -7)
+
+
+def test_scale_channels(dmx, cuda):
+    x = make("normal", (6, 40, 9), seed=2, dtype=torch.bfloat16)
+    s = (torch.rand(40) + 0.5)
+    got = dmx.ops.scale_channels(x.to(cuda), s, 1, divide=True)
+    want = (x.float() / s.view(1, 40, 1)).to(torch.bfloat16)
+    assert bits_equal(got, want) == 0
+    got = dmx.ops.scale_channels(x.to(cuda), s, 1, divide=False, out_dtype=torch.float32)
+    assert bits_equal(got, x.float() * s.view(1, 40, 1)) == 0

@@ -1,0 +1,198 @@
+"""-m gpu parity tests: N:M mask (bit-exact), calibration reductions (exact), SmoothQuant scale and the
+approximator-slot ops (floating point: tolerance stated per test)."""
+import math
+
+import pytest
+import torch
+
+from _data import bits_equal, make
+
+pytestmark = pytest.mark.gpu
+
+
+def _scores(kind, shape, seed):
+    if kind == "random":
+        return make("normal", shape, seed)
+    if kind == "tied":       # few distinct values -> many ties inside every group
+        g = torch.Generator().manual_seed(seed)
+        return torch.randint(0, 3, shape, generator=g).float()
+    if kind == "equal":
+        return torch.ones(shape)
+    if kind == "zeros_signed":
+        g = torch.Generator().manual_seed(seed)
+        return torch.where(torch.rand(shape, generator=g) < 0.5, torch.tensor(0.0), torch.tensor(-0.0))
+    if kind == "nan":
+        s = make("normal", shape, seed)
+        g = torch.Generator().manual_seed(seed)
+        s[torch.rand(shape, generator=g) < 0.2] = float("nan")
+        return s
+    if kind == "absbf16":
+        return make("normal", shape, seed, torch.bfloat16).abs()
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("KM", [(2, 4), (4, 8), (2, 8), (1, 4), (3, 4), (1, 2), (5, 16), (3, 12), (8, 32)])
+@pytest.mark.parametrize("kind", ["random", "tied", "equal", "zeros_signed", "nan", "absbf16"])
+def test_nm_mask_bit_exact(dmx, cuda, oracle, KM, kind):
+    K, M = KM
+    s = _scores(kind, (64, 6 * M * 4), seed=K * 10 + M)
+    got = dmx.ops.nm_mask(s.to(cuda), K, M)
+    want = oracle.nm_mask(s, K, M)
+    assert got.dtype == s.dtype and bits_equal(got, want) == 0
+    assert torch.all(got.reshape(-1, M).float().sum(1) == K)                 # exactly K kept per group
+
+
+@pytest.mark.parametrize("dim", [1, 0, -2])
+def test_nm_mask_block_dim(dmx, cuda, oracle, dim):
+    s = _scores("tied", (8, 16, 24), seed=dim + 5)
+    assert bits_equal(dmx.ops.nm_mask(s.to(cuda), 4, 8, dim), oracle.nm_mask(s, 4, 8, dim).contiguous()) == 0
+
+
+@pytest.mark.parametrize("xd,sd", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
+                                   (torch.bfloat16, torch.bfloat16), (torch.float16, torch.float32)])
+def test_nm_sparsify_fused_apply(dmx, cuda, oracle, xd, sd):
+    x = make("normal", (128, 256), seed=1, dtype=xd)
+    s = make("normal", (128, 256), seed=2, dtype=sd)
+    got = dmx.ops.nm_sparsify(x.to(cuda), s.to(cuda), 2, 4)
+    want = oracle.sparsify(x, s, 2, 4)                                       # torch promotion of x * mask
+    assert got.dtype == want.dtype and bits_equal(got, want) == 0
+    assert bool((got.cpu() == 0).any()) and bool(torch.signbit(got.cpu()[got.cpu() == 0]).any())  # -0.0 kept
+
+
+def test_sparsify_module_semantics(dmx, cuda):
+    """sparse.py:287-301: score_func result used once, then the stored (random) score; mask recomputed per call."""
+    torch.manual_seed(0)
+    w = make("normal", (32, 64), seed=3).to(cuda)
+    sp = dmx.Sparsify(w.shape, sparseness="BTOPK{2:4,-1}(U)").to(cuda)
+    sp.eval()
+    y_rand = sp(w)
+    assert torch.all((y_rand != 0).reshape(-1, 4).sum(1) <= 2)
+    sp.configure(score_func=lambda score, x: x.abs())
+    y_mag = sp(w)   # plastic: magnitude pruning, once
+    keep = w.abs().reshape(-1, 4).argsort(dim=1, stable=True)[:, 2:]
+    ref = torch.zeros_like(w).reshape(-1, 4).scatter(1, keep, w.reshape(-1, 4).gather(1, keep)).reshape(w.shape)
+    assert torch.equal(y_mag, ref)
+    assert torch.equal(sp(w), y_rand)  # falls back to the stored score
+    with pytest.raises(AssertionError):
+        dmx.ops.nm_mask(torch.zeros(4, 6, device=cuda), 2, 4)                # sparse.py:166-168
+
+
+def test_sparsify_gradients(dmx, cuda):
+    """Structural check like the reference's tests/test_sparse.py: which gradients exist, and dx = g * mask."""
+    w = make("normal", (16, 32), seed=4).to(cuda).requires_grad_()
+    sp = dmx.Sparsify(w.shape, sparseness="BTOPK{4:8,-1}(U)", backward_mode="STE").to(cuda).train()
+    y = sp(w)
+    y.sum().backward()
+    assert w.grad is not None and torch.equal(w.grad, sp.mask) and sp.score.grad is None
+    sp2 = dmx.Sparsify(w.shape, sparseness="BTOPK{4:8,-1}(U)", backward_mode="joint").to(cuda).train()
+    w.grad = None
+    sp2(w).sum().backward()
+    assert w.grad is not None and sp2.score.grad is not None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_group_minmax_and_qparams(dmx, cuda, oracle, dtype):
+    x = make("heavy", (13, 50, 7), seed=6, dtype=dtype)
+    for ax in (0, 1, 2):
+        for gs in (1, 2, 5, x.shape[ax], 64):
+            mn, mx = dmx.ops.group_minmax(x.to(cuda), ax, gs)
+            omn, omx = oracle.group_minmax(x, ax, gs)
+            assert torch.equal(mn.cpu(), omn) and torch.equal(mx.cpu(), omx), (ax, gs)
+            for fmt_sym in (True, False):
+                for q_sym in (True, False):
+                    qmin = -(2 ** 7) + (1 if fmt_sym else 0)
+                    sc, zp = dmx.ops.qparams(mn, mx, qmin, 127, q_sym)
+                    osc, ozp = oracle.qparams(omn, omx, 8, fmt_sym, q_sym)
+                    assert bits_equal(sc, osc) == 0 and torch.equal(zp.cpu(), ozp)
+
+
+def test_group_minmax_large_single_group(dmx, cuda):
+    x = make("normal", (2048, 4096), seed=7, dtype=torch.bfloat16).to(cuda)
+    mn, mx = dmx.ops.group_minmax(x.reshape(1, -1), 0, 1)
+    assert float(mn) == float(x.min()) and float(mx) == float(x.max())
+    mn, mx = dmx.ops.group_minmax(x, 0, 128)
+    xr = x.float().reshape(16, -1)
+    assert torch.equal(mn, xr.amin(1)) and torch.equal(mx, xr.amax(1))
+
+
+def test_castto_calibration_flow_group_quant(dmx, cuda, oracle):
+    """numerical/cast.py:308-340 + 179-226: calibrate (observe only) then fake-quantise with per-group scales.
+    Pinned against the oracle: scale[g] = amax|W[g-th slab]| / 127, zp = 0, output = fused affine INT8."""
+    W = make("normal", (48, 40), seed=8)
+    c = dmx.CastTo(format=dmx.format.INT8, ch_axis=0)
+    c.enable_calibration(True, dmx.MinMaxObserver, torch.per_tensor_symmetric, group_size=16, ch_axis=0)
+    out = c(W.to(cuda))
+    assert torch.equal(out.cpu(), W)                                         # observe-only pass is the identity
+    c.enable_calibration(False)
+    omn, omx = oracle.group_minmax(W, 0, 16)
+    osc, ozp = oracle.qparams(omn, omx, 8, True, True)
+    assert bits_equal(c.scale, osc) == 0 and torch.equal(c.zero_point.cpu(), ozp)
+    got = c(W.to(cuda))
+    want = oracle.fixed_point_affine_cast(W, 8, 0, True, True, osc, ozp, ch_axis=0, group_size=16)
+    assert bits_equal(got, want) == 0
+    # equivalences the reference tests (tests/test_group_quant.py:144-369): g = C <=> per-tensor, g = 1 <=> per-channel
+    c1 = dmx.CastTo(format=dmx.format.INT8, ch_axis=0)
+    c1.enable_calibration(True, dmx.MinMaxObserver, torch.per_tensor_symmetric, group_size=48, ch_axis=0)
+    c1(W.to(cuda)); c1.enable_calibration(False)
+    c2 = dmx.CastTo(format=dmx.format.INT8)
+    c2.enable_calibration(True, dmx.MinMaxObserver, torch.per_tensor_symmetric)
+    c2(W.to(cuda)); c2.enable_calibration(False)
+    assert bits_equal(c1(W.to(cuda)), c2(W.to(cuda))) == 0
+    c3 = dmx.CastTo(format=dmx.format.INT8, ch_axis=0)
+    c3.enable_calibration(True, dmx.MinMaxObserver, torch.per_tensor_symmetric, group_size=1, ch_axis=0)
+    c3(W.to(cuda)); c3.enable_calibration(False)
+    c4 = dmx.CastTo(format=dmx.format.INT8, ch_axis=0)
+    c4.enable_calibration(True, dmx.MinMaxObserver, torch.per_channel_symmetric, ch_axis=0)
+    c4(W.to(cuda)); c4.enable_calibration(False)
+    assert bits_equal(c3(W.to(cuda)), c4(W.to(cuda))) == 0
+
+
+def test_channel_maxabs_and_smoothquant_scale(dmx, cuda, oracle):
+    a = make("heavy", (4, 33, 96), seed=9, dtype=torch.bfloat16)
+    w = make("normal", (80, 96), seed=10)
+    am = dmx.ops.channel_maxabs(a.to(cuda), -1)
+    wm = dmx.ops.channel_maxabs(w.to(cuda), -1)
+    assert torch.equal(am.cpu(), oracle.channel_maxabs(a, -1)) and torch.equal(wm.cpu(), oracle.channel_maxabs(w, -1))
+    assert torch.equal(dmx.ops.channel_maxabs(w.to(cuda), 0).cpu(), w.abs().amax(1))
+    for alpha in (0.0, 0.5, 0.25, 1.0):
+        got = dmx.ops.smoothquant_scale(am, wm, alpha, 1e-5).cpu()
+        b = wm.cpu().clamp(min=1e-5)
+        ref = ((am.cpu() ** alpha) / (b ** (1.0 - alpha))).clamp(min=1e-5)   # smoothquant.py:309-320 (CPU torch)
+        # floating point (pow): within 2 ulp of fp32
+        assert torch.allclose(got, ref, rtol=2.4e-7, atol=0.0), (alpha, (got - ref).abs().max())
+    z = dmx.ops.smoothquant_scale(torch.zeros(4, device=cuda), torch.zeros(4, device=cuda), 0.5, 1e-5)
+    assert torch.all(z == 1e-5)                                              # clamp at scale_min
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_gelu_softmax_layernorm_exact_function_parity(dmx, cuda, dtype):
+    """Approximator slot = exact torch.nn.functional result (vsimd absent).  Tolerance: 1 ULP of the output
+    format around the fp32-computed CPU reference (north_star: 'within 1 ULP of the stated format')."""
+    F = torch.nn.functional
+    eps = torch.finfo(dtype).eps
+
+    def close(got, ref32):
+        ref = ref32.to(dtype).float()
+        tol = eps * ref.abs().clamp(min=float(torch.finfo(dtype).tiny)) + 1e-30
+        # + 1e-6 absolute: 0.5*x*(1+erf(..)) cancels for x << 0, where fp32 libm differences dominate
+        bad = ((got.cpu().float() - ref).abs() > tol + 1e-6)
+        return int(bad.sum())
+
+    x = (make("normal", (64, 1500), seed=11) * 3).to(dtype)
+    assert close(dmx.ops.gelu(x.to(cuda)), F.gelu(x.float())) == 0
+    assert close(dmx.ops.gelu(x.to(cuda), "tanh"), F.gelu(x.float(), approximate="tanh")) == 0
+    assert close(dmx.ops.softmax(x.to(cuda), -1), F.softmax(x.float(), -1)) == 0
+    xc = x.float().clamp(min=-1.0)
+    assert close(dmx.ops.softmax(x.to(cuda), -1, input_clamp=-1.0), F.softmax(xc, -1)) == 0
+    x3 = x.reshape(8, 8, 1500)
+    assert close(dmx.ops.softmax(x3.to(cuda), 1), F.softmax(x3.float(), 1)) == 0
+    w = (make("normal", (1500,), seed=12) * 0.1 + 1).to(dtype)
+    b = (make("normal", (1500,), seed=13) * 0.1).to(dtype)
+    got = dmx.ops.layernorm(x.to(cuda), (1500,), w.to(cuda), b.to(cuda), 1e-5)
+    ref = F.layer_norm(x.float(), (1500,), w.float(), b.float(), 1e-5)
+    # layernorm: two fp32 reductions in a different order than torch's -> allow 2 ulp of the output format
+    ref_d = ref.to(dtype).float()
+    tol = 2 * eps * ref_d.abs() + 4e-6
+    assert int(((got.cpu().float() - ref_d).abs() > tol).sum()) == 0
+    big = (make("normal", (3, 20000), seed=14)).to(dtype)                     # longer than the LDS row buffer
+    assert close(dmx.ops.softmax(big.to(cuda), -1), F.softmax(big.float(), -1)) == 0
