@@ -212,7 +212,7 @@ def main():
                        "per_gpu_elements_per_step": numel},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                          "frac": round(achieved / PEAK_HBM, 4), "traffic": traffic,
-                         "kernel": "dmxq::bfp_rows_kernel<bf16,bf16,nearest,sym>",
+                         "kernel": "dmxq::bfp_rows_kernel<bf16,bf16,nearest,sym,U16,nt,T512,fast2>",
                          "algorithmic_bytes_per_launch": BYTES_PER_ELEM * numel,
                          "avg_launch_us": round(launch_s * 1e6, 3)},
         }

@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    hdrs = [os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "dmxq.h"), os.path.abspath(__file__)]
+    hdrs = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "bfp_math.hpp"), os.path.join(CSRC, "bfp_rows.hpp"), os.path.join(HERE, "..", "include", "dmxq.h"), os.path.abspath(__file__)]
     hipcc = _hipcc()
 
     def compile_one(src):

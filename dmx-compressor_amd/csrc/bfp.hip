@@ -24,88 +24,13 @@
 //   bfp_lds_rows_kernel inner == 1, any L / B (ragged tails, odd row pitch): a workgroup stages a span of whole
 //                     blocks in LDS with coalesced loads, lanes then own blocks inside LDS.
 //   bfp_generic_kernel  everything else: one lane per block, strided two-pass (correct for any layout).
-#include "common.hpp"
+#include "bfp_rows.hpp"
 
 namespace dmxq {
 
-struct BfpBlockParams {
-  float base;    // 6 * 2^e
-  float maxv;    // largest representable magnitude, 2^(e+1) - quantum
-  float thr;     // asymmetric threshold  -(2^(e+1) - quantum/2)
-  float neg_lim; // -2^(e+1)
-};
-
-template <bool ASYM>
-__device__ __forceinline__ BfpBlockParams bfp_block_params(float maxabs, int wl) {
-  BfpBlockParams p;
-  const uint32_t E = f2u(maxabs) & 0x7F800000u;
-  p.base = u2f(E) * 6.0f;
-  const uint32_t max_man = (0x007FFFFFu >> (25 - wl)) << (25 - wl);
-  p.maxv = u2f(E | max_man);
-  if (ASYM) {
-    const uint32_t thr_man = (0x007FFFFFu >> (24 - wl)) << (24 - wl);
-    p.thr = u2f(0x80000000u | E | thr_man);
-    p.neg_lim = u2f(0x80000000u | (E + 0x00800000u));
-  }
-  return p;
-}
-
-template <int RND, bool ASYM>
-__device__ __forceinline__ float bfp_q1(float x, const BfpBlockParams& p, int wl, int rounding, uint32_t rnd) {
-  const float t = x + p.base;
-  const uint32_t tb = round_bitwise<RND>(f2u(t), wl, rounding, rnd);
-  float q = u2f(tb) - p.base;
-  q = __builtin_amdgcn_fmed3f(q, -p.maxv, p.maxv);
-  if (ASYM) q = (x <= p.thr) ? p.neg_lim : q;
-  return q;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Row blocks, flat stream.  n_vec = number of 16-byte input vectors (= numel / EPL).
-template <int DTI, int DTO, int RND, bool ASYM, int UNROLL, bool NT>
-__global__ __launch_bounds__(kThreads) void bfp_rows_kernel(const void* __restrict__ in, void* __restrict__ out,
-                                                           int64_t n_vec, int lpb /*lanes per block*/, int wl,
-                                                           int rounding, uint64_t seed) {
-  const bool stoch = (RND == kRuntimeRounding) && rounding == DMXQ_ROUND_STOCHASTIC;
-  constexpr int EPL = 16 / Elem<DTI>::bytes;
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-
-  // main body: UNROLL independent 16-byte loads in flight per lane before any arithmetic
-  for (; v + (UNROLL - 1) * stride < n_vec; v += UNROLL * stride) {
-    float x[UNROLL][EPL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; u++) load_vec<DTI, EPL>(in, (v + u * stride) * EPL, x[u]);
-#pragma unroll
-    for (int u = 0; u < UNROLL; u++) {
-      float m = 0.0f;
-#pragma unroll
-      for (int k = 0; k < EPL; k++) m = fmaxf(m, fabsf(x[u][k]));
-      m = group_max(m, lpb);
-      const BfpBlockParams p = bfp_block_params<ASYM>(m, wl);
-      float y[EPL];
-      const int64_t e0 = (v + u * stride) * EPL;
-#pragma unroll
-      for (int k = 0; k < EPL; k++)
-        y[k] = bfp_q1<RND, ASYM>(x[u][k], p, wl, rounding, stoch ? rnd_bits(seed, (uint64_t)(e0 + k)) : 0u);
-      store_vec<DTO, EPL, NT>(out, e0, y);
-    }
-  }
-  for (; v < n_vec; v += stride) {
-    float x[EPL];
-    load_vec<DTI, EPL>(in, v * EPL, x);
-    float m = 0.0f;
-#pragma unroll
-    for (int k = 0; k < EPL; k++) m = fmaxf(m, fabsf(x[k]));
-    m = group_max(m, lpb);
-    const BfpBlockParams p = bfp_block_params<ASYM>(m, wl);
-    float y[EPL];
-#pragma unroll
-    for (int k = 0; k < EPL; k++)
-      y[k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, stoch ? rnd_bits(seed, (uint64_t)(v * EPL + k)) : 0u);
-    store_vec<DTO, EPL, NT>(out, v * EPL, y);
-  }
-}
+// 16-byte vectors in flight per lane on big tensors; 8 when the output vector is 32 B (16-bit in -> fp32 out)
+template <int DTI, int DTO> struct RowsUnroll { static constexpr int big = (Elem<DTO>::bytes > Elem<DTI>::bytes) ? 8 : 16; };
+constexpr int kRowsMaxGrid = 1 << 20;
 
 // ---------------------------------------------------------------------------------------------------------
 // Generic fallback: one lane per block; two strided passes.  Correct for every (outer, L, inner, B) incl.
@@ -125,9 +50,9 @@ __global__ __launch_bounds__(kThreads) void bfp_generic_kernel(const void* __res
     const int64_t l0 = k * B;
     const int64_t len = (L - l0 < B) ? (L - l0) : B;
     const int64_t e0 = (o * L + l0) * inner + j;
-    float m = 0.0f;
-    for (int64_t i = 0; i < len; i++) m = fmaxf(m, fabsf(load1<DTI>(in, e0 + i * inner)));
-    const BfpBlockParams p = bfp_block_params<ASYM>(m, wl);
+    uint32_t mb = 0u;
+    for (int64_t i = 0; i < len; i++) mb = max(mb, f2u(load1<DTI>(in, e0 + i * inner)) & 0x7FFFFFFFu);
+    const BfpBlockParams p = bfp_block_params<ASYM>(mb, wl);
     for (int64_t i = 0; i < len; i++) {
       const int64_t e = e0 + i * inner;
       // the oracle numbers random draws by the element's position in the transposed [rows, L] matrix
@@ -148,11 +73,35 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
   // (stochastic draws are numbered by flat element index in the rows kernel, which equals the oracle's
   //  numbering because inner == 1 on this path)
   if (inner == 1 && L % B == 0 && pow2 && B >= EPL && B <= 64 * EPL && aligned16(in) && aligned16(out)) {
-    constexpr int UNROLL = 4;
+    // Geometry (tools/tune_bfp, profiles/): workgroup-contiguous tiles of THREADS*UNROLL 16-byte vectors,
+    // non-temporal loads and stores, every load of a tile in flight before the arithmetic starts, stores in
+    // one burst.  Big tensors: 512 x 16 (128 KiB of bf16 per workgroup; 4096x4096 bf16 = 256 tiles = one per
+    // CU); smaller ones trade bytes in flight for enough workgroups to cover the 256 CUs.
+    constexpr int MODE = kRowsNtLoad | kRowsNtStore;
+    constexpr int UB = RowsUnroll<DTI, DTO>::big;
     const int64_t n_vec = n / EPL;
-    const int grid = grid_for((n_vec + UNROLL - 1) / UNROLL);
-    hipLaunchKernelGGL((bfp_rows_kernel<DTI, DTO, RND, ASYM, UNROLL, false>), dim3(grid), dim3(kThreads), 0, s, in,
-                       out, n_vec, (int)(B / EPL), wl, rounding, seed);
+    const int lpb = (int)(B / EPL);
+    // nearest-even: the magic-add path (bfp_math.hpp (2)); single rounding where the input dtype allows it
+    const int fast = (RND == DMXQ_ROUND_NEAREST && wl <= 20) ? (bfp_single_rounding_ok<DTI>(wl) ? 2 : 1) : 0;
+#define DMXQ_ROWS(T_, U_, F_)                                                                                    \
+  do {                                                                                                           \
+    const int64_t tiles = (n_vec + (int64_t)(T_) * (U_) - 1) / ((int64_t)(T_) * (U_));                           \
+    const int grid = (int)(tiles < kRowsMaxGrid ? tiles : kRowsMaxGrid);                                         \
+    hipLaunchKernelGGL((bfp_rows_kernel<DTI, DTO, RND, ASYM, U_, MODE, T_, F_>), dim3(grid), dim3(T_), 0, s, in, \
+                       out, n_vec, lpb, wl, rounding, seed);                                                     \
+  } while (0)
+#define DMXQ_ROWS_GEOM(F_)                                                     \
+  do {                                                                         \
+    if (n_vec >= (int64_t)256 * 512 * UB) DMXQ_ROWS(512, UB, F_);              \
+    else if (n_vec >= (int64_t)512 * 256 * 4) DMXQ_ROWS(256, 4, F_);           \
+    else DMXQ_ROWS(256, 1, F_);                                                \
+  } while (0)
+    constexpr bool in16 = Elem<DTI>::bytes == 2;
+    if (RND == DMXQ_ROUND_NEAREST && fast == 2 && in16) DMXQ_ROWS_GEOM(2);
+    else if (RND == DMXQ_ROUND_NEAREST && fast != 0) DMXQ_ROWS_GEOM(1);
+    else DMXQ_ROWS_GEOM(0);
+#undef DMXQ_ROWS_GEOM
+#undef DMXQ_ROWS
     return launch_status();
   }
   const int64_t nblk = (L + B - 1) / B;

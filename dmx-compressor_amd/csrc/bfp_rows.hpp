@@ -1,0 +1,121 @@
+// csrc/bfp_rows.hpp — the hot kernel: BFP Q->DQ over a flat stream of row blocks (block_dim = -1, L % B == 0).
+// Shared by bfp.hip (product) and tools/tune_bfp.hip (variant A/B harness).
+//
+// Layout: the tensor is n_vec 16-byte input vectors; one lane owns one vector per step (8 x bf16/fp16 or
+// 4 x fp32), a block of B elements spans lpb = B/EPL adjacent lanes of one wave, and the block max is an
+// integer max over abs bit patterns reduced with DPP moves — no LDS, no second pass, each element is read
+// once and written once (2 + 2 B/element for 16-bit I/O: HBM-bound).
+//
+// Work decomposition: workgroup-contiguous TILES of THREADS*UNROLL vectors (64 KiB of bf16 at 256 x 16).  A full
+// tile issues all UNROLL loads unconditionally and back to back (256 B in flight per lane), then converts and
+// stores vector by vector behind counted vmcnt waits; only the last, partial tile takes the predicated path.
+// MODE bits: 1 = non-temporal loads, 2 = non-temporal stores (tools/tune_bfp: both help on a streaming pass).
+#pragma once
+#include "bfp_math.hpp"
+
+namespace dmxq {
+
+constexpr int kRowsNtLoad = 1, kRowsNtStore = 2;
+
+// one 16-byte input vector -> its packed outputs, given the block's max bits.  PATH_FAST selects the magic-add
+// arithmetic (nearest-even only); `vi` = index of the input vector (numbers the random draws).
+template <int DTI, int DTO, int RND, bool ASYM, int FAST, bool PATH_FAST>
+__device__ __forceinline__ OutVec<DTO, 16 / Elem<DTI>::bytes> bfp_rows_vector(const u32x4& raw, uint32_t mb, int64_t vi,
+                                                                            int wl, int rounding, bool stoch,
+                                                                            uint64_t seed) {
+  constexpr int EPL = 16 / Elem<DTI>::bytes;
+  const BfpBlockParams p = bfp_block_params<ASYM, PATH_FAST>(mb, wl);
+  float x[EPL], y[EPL];
+  widen<DTI, EPL>(raw, x);
+  if (PATH_FAST) {
+#pragma unroll
+    for (int k = 0; k < EPL; k++) y[k] = bfp_q1_fast<FAST == 2, ASYM>(x[k], p);
+  } else {
+    const int64_t e0 = vi * EPL;
+#pragma unroll
+    for (int k = 0; k < EPL; k++)
+      y[k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, stoch ? rnd_bits(seed, (uint64_t)(e0 + k)) : 0u);
+  }
+  return pack_vec<DTO, EPL>(y);
+}
+
+// FAST: 0 = literal bit path only; 1 = magic-add path, double rounding; 2 = magic-add path, single rounding
+// (valid only for RND == nearest; the dispatcher picks 2 when bfp_single_rounding_ok<DTI>(wl)).
+// UNROLL vectors are in flight per lane; they are converted and stored in groups of GROUP: wait for the group's
+// loads, quantise all of them into registers, then issue the group's stores back to back (read bursts and write
+// bursts instead of a read/write interleave; tools/tune_bfp picks UNROLL and GROUP).
+template <int DTI, int DTO, int RND, bool ASYM, int UNROLL, int MODE, int THREADS, int FAST = 0, int GROUP = UNROLL>
+__global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restrict__ in, void* __restrict__ out,
+                                                          int64_t n_vec, int lpb_arg /*lanes per block*/, int wl,
+                                                          int rounding, uint64_t seed) {
+  static_assert(UNROLL % GROUP == 0, "GROUP must divide UNROLL");
+  constexpr bool NTL = (MODE & kRowsNtLoad) != 0, NTS = (MODE & kRowsNtStore) != 0;
+  constexpr int64_t TILE = (int64_t)THREADS * UNROLL;
+  constexpr int EPL = 16 / Elem<DTI>::bytes;
+  constexpr int OVB = EPL * Elem<DTO>::bytes;  // output bytes per input vector
+  const bool stoch = (RND == kRuntimeRounding) && rounding == DMXQ_ROUND_STOCHASTIC;
+  const int lpb = __builtin_amdgcn_readfirstlane(lpb_arg);
+  const int64_t n_tiles = (n_vec + TILE - 1) / TILE;
+  const uint32_t lane_in = threadIdx.x * 16u, lane_out = threadIdx.x * (uint32_t)OVB;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // workgroup-uniform tile bases + 32-bit lane offsets
+    const char* src = (const char*)in + tile * (TILE * 16);
+    char* dst = (char*)out + tile * (TILE * OVB);
+    const int64_t v0 = tile * TILE + threadIdx.x;
+    if ((tile + 1) * TILE <= n_vec) {  // full tile (workgroup-uniform): no predicates
+      u32x4 raw[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) raw[u] = load_raw16<NTL>(src + u * (THREADS * 16), lane_in);
+      __builtin_amdgcn_sched_barrier(0);  // every load is issued before any arithmetic: 16 B x UNROLL in flight per lane
+#pragma unroll
+      for (int g = 0; g < UNROLL; g += GROUP) {
+        // block maxima of the whole group first; the fast/literal choice is made once per group, wave-uniformly
+        // (every active lane's block must admit the magic-add path, see bfp_math.hpp)
+        uint32_t mb[GROUP];
+        bool all_fast = FAST != 0 && RND == DMXQ_ROUND_NEAREST;
+#pragma unroll
+        for (int u = 0; u < GROUP; u++) {
+          mb[u] = group_max_u32(absmax_bits<DTI>(raw[g + u]), lpb);
+          if (FAST != 0) all_fast = all_fast && bfp_fast_ok(mb[u], wl);
+        }
+        OutVec<DTO, EPL> o[GROUP];
+        constexpr bool kFast = FAST != 0 && RND == DMXQ_ROUND_NEAREST;
+#pragma unroll
+        for (int u = 0; u < GROUP; u++) {
+          o[u] = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, kFast>(raw[g + u], mb[u], v0 + (int64_t)(g + u) * THREADS, wl,
+                                                                   rounding, stoch, seed);
+          __builtin_amdgcn_sched_barrier(0);  // vector by vector: short live ranges (4 workgroups per CU need <= 128 VGPRs)
+        }
+        if (kFast && __builtin_amdgcn_ballot_w64(!all_fast) != 0ull) {
+          // rare: some block of this wave cannot take the magic-add path (bfp_fast_ok).  Redo the group with the
+          // literal bit path from a fresh read of the inputs (still unmodified: this tile's stores come later),
+          // instead of keeping every raw vector alive across a two-sided branch.  (Unrolled: a runtime-indexed
+          // o[u] would live in scratch.)
+#pragma unroll
+          for (int u = 0; u < GROUP; u++) {
+            const u32x4 r = load_raw16<false>(src + (g + u) * (THREADS * 16), lane_in);
+            const uint32_t m = group_max_u32(absmax_bits<DTI>(r), lpb);
+            o[u] = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, false>(r, m, v0 + (int64_t)(g + u) * THREADS, wl, rounding,
+                                                                     stoch, seed);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // ... and the group's stores go out as one burst
+#pragma unroll
+        for (int u = 0; u < GROUP; u++) store_out<DTO, EPL, NTS>(dst + (g + u) * (THREADS * OVB) + lane_out, o[u]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {  // last, partial tile: a block never straddles the predicate (n_vec % lpb == 0, lpb | THREADS)
+      for (int u = 0; u < UNROLL; u++) {
+        const int64_t vi = v0 + (int64_t)u * THREADS;
+        if (vi < n_vec) {
+          const u32x4 raw = load_raw16<NTL>(src + u * (THREADS * 16), lane_in);
+          const uint32_t mb = group_max_u32(absmax_bits<DTI>(raw), lpb);
+          const OutVec<DTO, EPL> o = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, false>(raw, mb, vi, wl, rounding, stoch, seed);
+          store_out<DTO, EPL, NTS>(dst + u * (THREADS * OVB) + lane_out, o);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace dmxq

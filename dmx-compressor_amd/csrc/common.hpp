@@ -57,17 +57,18 @@ template <> struct Elem<DMXQ_F32> { static constexpr int bytes = 4; };
 template <> struct Elem<DMXQ_F16> { static constexpr int bytes = 2; };
 template <> struct Elem<DMXQ_BF16> { static constexpr int bytes = 2; };
 
+__device__ __forceinline__ float opaque(float v);
 template <int DT>
 __device__ __forceinline__ float load1(const void* p, int64_t i) {
   if (DT == DMXQ_F32) return ((const float*)p)[i];
-  if (DT == DMXQ_F16) return (float)((const _Float16*)p)[i];
+  if (DT == DMXQ_F16) return opaque((float)((const _Float16*)p)[i]);
   return u2f((uint32_t)((const uint16_t*)p)[i] << 16);
 }
 
 template <int DT>
 __device__ __forceinline__ void store1(void* p, int64_t i, float v) {
   if (DT == DMXQ_F32) ((float*)p)[i] = v;
-  else if (DT == DMXQ_F16) ((_Float16*)p)[i] = (_Float16)v;
+  else if (DT == DMXQ_F16) ((_Float16*)p)[i] = (_Float16)opaque(v);
   else ((__bf16*)p)[i] = (__bf16)v;  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
 }
 
@@ -89,6 +90,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+// fp16 halves of a dword -> fp32 (explicit shifts: bit_cast of an ext-vector element to a 2 x f16 vector
+// was observed to read element 0 for every index under hipcc 7.2)
+// opaque(): keeps hipcc from folding an fp16<->fp32 conversion into a neighbouring multiply as v_fma_mix*(a, b, +0):
+// that form adds +0.0 and turns a -0.0 product into +0.0 (observed: `(q - zp) * sc` stored as fp16).
+__device__ __forceinline__ float opaque(float v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ float half_lo(uint32_t w) { return opaque((float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu))); }
+__device__ __forceinline__ float half_hi(uint32_t w) { return opaque((float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16))); }
+
 // N fp32 values <- N consecutive elements starting at element index i (N*bytes must be 16 or 32 aligned as used)
 template <int DT, int N>
 __device__ __forceinline__ void load_vec(const void* p, int64_t i, float (&x)[N]) {
@@ -108,9 +117,8 @@ __device__ __forceinline__ void load_vec(const void* p, int64_t i, float (&x)[N]
           x[k + 2 * j] = u2f(v[j] << 16);
           x[k + 2 * j + 1] = u2f(v[j] & 0xFFFF0000u);
         } else {
-          f16x2 h = __builtin_bit_cast(f16x2, v[j]);
-          x[k + 2 * j] = (float)h.x;
-          x[k + 2 * j + 1] = (float)h.y;
+          x[k + 2 * j] = half_lo(v[j]);
+          x[k + 2 * j + 1] = half_hi(v[j]);
         }
       }
     }
@@ -123,7 +131,7 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
     bf16x2 h; h.x = (__bf16)a; h.y = (__bf16)b;
     return __builtin_bit_cast(uint32_t, h);
   } else {
-    f16x2 h; h.x = (_Float16)a; h.y = (_Float16)b;
+    f16x2 h; h.x = (_Float16)opaque(a); h.y = (_Float16)opaque(b);
     return __builtin_bit_cast(uint32_t, h);
   }
 }
@@ -152,6 +160,42 @@ __device__ __forceinline__ void store_vec(void* p, int64_t i, const float (&y)[N
   }
 }
 
+// packed output vector: N elements of dtype DT held in registers until the store burst
+template <int DT, int N>
+struct OutVec {
+  static constexpr int kWords = N * Elem<DT>::bytes / 4;
+  uint32_t w[kWords];
+};
+
+template <int DT, int N>
+__device__ __forceinline__ OutVec<DT, N> pack_vec(const float (&y)[N]) {
+  OutVec<DT, N> o;
+  if (DT == DMXQ_F32) {
+#pragma unroll
+    for (int k = 0; k < N; k++) o.w[k] = f2u(y[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) o.w[k] = pack2<DT>(y[2 * k], y[2 * k + 1]);
+  }
+  return o;
+}
+
+template <int DT, int N, bool NT>
+__device__ __forceinline__ void store_out(void* p, const OutVec<DT, N>& o) {
+  constexpr int W = OutVec<DT, N>::kWords;
+  if (W % 4 == 0) {
+#pragma unroll
+    for (int k = 0; k < W; k += 4) {
+      u32x4 v = {o.w[k], o.w[k + 1], o.w[k + 2], o.w[k + 3]};
+      u32x4* dst = (u32x4*)p + k / 4;
+      if (NT) __builtin_nontemporal_store(v, dst); else *dst = v;
+    }
+  } else {  // 2 words: 4 sixteen-bit outputs
+    u32x2 v = {o.w[0], o.w[1]};
+    if (NT) __builtin_nontemporal_store(v, (u32x2*)p); else *(u32x2*)p = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // max over aligned groups of LANES adjacent lanes, using DPP only (no LDS traffic):
 // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror give xor-1/2/4/8 partners once the
@@ -166,6 +210,65 @@ __device__ __forceinline__ float group_max(float m, int lanes) {
   if (LANES >= 32) m = fmaxf(m, __shfl_xor(m, 16));
   if (LANES >= 64) m = fmaxf(m, __shfl_xor(m, 32));
   return m;
+}
+
+// same reduction on unsigned integers (abs-value bit patterns order like the magnitudes they encode, and a
+// NaN pattern is the largest of all, which reproduces torch.max's NaN propagation in get_max_entry)
+__device__ __forceinline__ uint32_t group_max_u32(uint32_t m, int lanes) {
+  if (lanes >= 2) m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, m, 0xB1, 0xF, 0xF, false));
+  if (lanes >= 4) m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, m, 0x4E, 0xF, 0xF, false));
+  if (lanes >= 8) m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, m, 0x141, 0xF, 0xF, false));
+  if (lanes >= 16) m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, m, 0x140, 0xF, 0xF, false));
+  if (lanes >= 32) m = max(m, (uint32_t)__shfl_xor((int)m, 16));
+  if (lanes >= 64) m = max(m, (uint32_t)__shfl_xor((int)m, 32));
+  return m;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// raw 16-byte input vector: load once, then (a) widen to fp32 and (b) take max|x| on the raw bit patterns.
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+
+template <bool NT, typename OFF = int64_t>
+__device__ __forceinline__ u32x4 load_raw16(const void* p, OFF byte_off) {
+  const u32x4* src = (const u32x4*)((const char*)p + byte_off);
+  return NT ? __builtin_nontemporal_load(src) : *src;
+}
+
+template <int DT, int EPL>
+__device__ __forceinline__ void widen(const u32x4& v, float (&x)[EPL]) {
+  if (DT == DMXQ_F32) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) x[j] = u2f(v[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (DT == DMXQ_BF16) {
+        x[2 * j] = u2f(v[j] << 16);
+        x[2 * j + 1] = u2f(v[j] & 0xFFFF0000u);
+      } else {
+        x[2 * j] = half_lo(v[j]);
+        x[2 * j + 1] = half_hi(v[j]);
+      }
+    }
+  }
+}
+
+// fp32 bit pattern of max|x| over the 16-byte vector (exact: widening is monotone)
+template <int DT>
+__device__ __forceinline__ uint32_t absmax_bits(const u32x4& v) {
+  if (DT == DMXQ_F32) {
+    const uint32_t a = max(v[0] & 0x7FFFFFFFu, v[1] & 0x7FFFFFFFu);
+    const uint32_t b = max(v[2] & 0x7FFFFFFFu, v[3] & 0x7FFFFFFFu);
+    return max(a, b);
+  }
+  // packed 16-bit: clear both sign bits, v_pk_max_u16 tree, then fold the two halves
+  const u16x2 a0 = __builtin_bit_cast(u16x2, v[0] & 0x7FFF7FFFu), a1 = __builtin_bit_cast(u16x2, v[1] & 0x7FFF7FFFu);
+  const u16x2 a2 = __builtin_bit_cast(u16x2, v[2] & 0x7FFF7FFFu), a3 = __builtin_bit_cast(u16x2, v[3] & 0x7FFF7FFFu);
+  const u16x2 m2 = __builtin_elementwise_max(__builtin_elementwise_max(a0, a1), __builtin_elementwise_max(a2, a3));
+  const uint32_t w = __builtin_bit_cast(uint32_t, m2);
+  const uint32_t h = max(w & 0xFFFFu, w >> 16);
+  if (DT == DMXQ_BF16) return h << 16;
+  return f2u((float)__builtin_bit_cast(_Float16, (uint16_t)h));
 }
 
 inline int grid_for(int64_t work_items_of_one_thread) {

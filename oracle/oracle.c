@@ -127,7 +127,6 @@ static inline float bfp_q1(float x, float maxabs, int wl, int rounding, uint32_t
  * integer mantissas reproduces q exactly). */
 static void bfp_asym_block(float* q, const float* x, int64_t len, int n) {
   int max_e = -200;
-  int e_i[1]; (void)e_i;
   for (int64_t i = 0; i < len; i++) {
     int e; float m = frexpf(q[i], &e);
     if (e == 0 && m == 0.0f) e = -200;
@@ -164,11 +163,15 @@ int oracle_bfp_qdq(const float* in, float* out, int64_t rows, int64_t L, int64_t
     for (int64_t b0 = 0; b0 < L; b0 += B) {
       const int64_t len = (L - b0 < B) ? (L - b0) : B;
       float m = 0.0f;
-      for (int64_t i = 0; i < len; i++) { float a = fabsf(xi[b0 + i]); if (a > m) m = a; } /* quant_cpu.cpp:277-297 */
+      /* quant_cpu.cpp:277-297 get_max_entry: torch's abs().max() PROPAGATES NaN, so a NaN (or Inf) element
+       * makes the block's exponent field 0xFF, base = inf and every element of the block NaN. */
+      for (int64_t i = 0; i < len; i++) { float a = fabsf(xi[b0 + i]); if (a > m || isnan(a)) m = a; }
       for (int64_t i = 0; i < len; i++)
         yo[b0 + i] = bfp_q1(xi[b0 + i], m, wl, rounding,
                             rounding == R_STOCHASTIC ? rnd_bits(seed, (uint64_t)(r * L + b0 + i)) : 0u);
-      if (!symmetric) bfp_asym_block(yo + b0, xi + b0, len, wl);
+      /* NaN/Inf maximum, or a maximum >= 2^126 whose base 6*2^e overflows: the symmetric pass already turned the
+       * whole block into NaN and the reference's post-pass is garbage-in/garbage-out there -> the block stays NaN */
+      if (!symmetric && isfinite(m) && isfinite(u2f(f2u(m) & 0x7F800000u) * 6.0f)) bfp_asym_block(yo + b0, xi + b0, len, wl);
     }
   }
   return 0;

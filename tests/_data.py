@@ -53,7 +53,17 @@ def make(kind, shape, seed=0, dtype=torch.float32, block=16):
     else:
         raise ValueError(kind)
     t = torch.from_numpy(v.astype(np.float32)).reshape(shape)
+    if dtype == torch.float16:  # keep inputs finite: Inf/NaN blocks are covered by their own test
+        t = t.clamp(-65504.0, 65504.0)
     return t.to(dtype)
+
+
+def mismatches_nan_aware(a: torch.Tensor, b: torch.Tensor) -> int:
+    """like bits_equal, but any NaN matches any NaN (payload/sign of a generated NaN is platform-defined)"""
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    both_nan = torch.isnan(a) & torch.isnan(b)
+    diff = (a.view(torch.int32) != b.view(torch.int32)) & ~both_nan
+    return int(diff.sum())
 
 
 def bits_equal(a: torch.Tensor, b: torch.Tensor) -> int:

@@ -6,7 +6,7 @@ CastTo's dtype contract numerical/cast.py:262,306.  Tolerance: NONE (bit pattern
 import pytest
 import torch
 
-from _data import bits_equal, make
+from _data import bits_equal, make, mismatches_nan_aware
 
 pytestmark = pytest.mark.gpu
 
@@ -86,6 +86,68 @@ def test_fp32_double_rounding_class(dmx, cuda, oracle):
     assert _run(dmx, cuda, oracle, x, 8, B) == 0
 
 
+def _all_patterns(dtype):
+    """every finite 16-bit pattern of the dtype, as a tensor"""
+    bits = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16)
+    v = bits.view(dtype)
+    return v[torch.isfinite(v.float())]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("wl", [2, 4, 6, 8, 11, 12, 14, 15, 16, 20, 21, 22])
+def test_exhaustive_16bit_inputs_against_every_block_exponent_class(dmx, cuda, oracle, dtype, wl):
+    """The nearest-even kernel replaces the reference's bit-level mantissa rounding by fp32 magic-constant adds
+    (bfp_math.hpp (2)), collapsing the two roundings into one where the input dtype allows it.  Check EVERY
+    finite 16-bit input value against block maxima of every kind: ordinary, denormal, tiny-normal, near the top
+    of the range (where the kernel must fall back to the literal bit path) and a block maximum equal to x itself."""
+    vals = _all_patterns(dtype)
+    fin = vals.float().abs()
+    tops = [1.0, 1.99, 3.5e-3, 2.0 ** -126, 1.2e-38, 3e-39, 1e-41, 2.0 ** 100, 2.0 ** 110, 2.0 ** 112, 3e38] if dtype == torch.bfloat16 \
+        else [1.0, 1.99, 6.1e-5, 5.96e-8, 3e-6, 1000.0, 65504.0, 0.33]
+    B = 16
+    for top in tops:
+        t = torch.tensor(top).to(dtype)
+        keep = vals[fin <= float(t.float())]
+        n = (keep.numel() + B - 2) // (B - 1)
+        blk = torch.zeros(n, B, dtype=dtype)
+        blk[:, 0] = t
+        flat = torch.zeros(n * (B - 1), dtype=dtype)
+        flat[: keep.numel()] = keep
+        blk[:, 1:] = flat.reshape(n, B - 1)
+        for sym in (True, False):
+            got = dmx.ops.bfp_qdq(blk.to(cuda), wl, B, -1, sym)
+            want = oracle.bfp_cast(blk, wl, B, -1, sym).to(dtype)
+            assert mismatches_nan_aware(got, want) == 0, (top, sym)
+    # self-maximum blocks: each value alone with zeros
+    solo = torch.zeros(vals.numel(), B, dtype=dtype)
+    solo[:, 3] = vals
+    assert mismatches_nan_aware(dmx.ops.bfp_qdq(solo.to(cuda), wl, B), oracle.bfp_cast(solo, wl, B).to(dtype)) == 0
+
+
+@pytest.mark.parametrize("wl", [4, 8, 12, 16, 20, 22])
+def test_fp32_inputs_near_every_tie(dmx, cuda, oracle, wl):
+    """fp32 inputs: the double-rounding form.  Values at, just below and just above every rounding tie of the
+    second rounding, at several magnitudes of the block max, plus random mantissas."""
+    g = torch.Generator().manual_seed(wl)
+    B = 32
+    rows = []
+    for e in (-126, -120, -60, -1, 0, 7, 60, 100, 120):
+        quantum = 2.0 ** (e + 2 - wl)
+        k = torch.randint(-(2 ** (wl - 1)) + 1, 2 ** (wl - 1) - 1, (512, B), generator=g).double()
+        nud = torch.randint(-2, 3, (512, B), generator=g).double() * 2.0 ** (e - 22)   # around 1 ulp of x + 6*2^e
+        x = ((k + 0.5) * quantum + nud)
+        x[:, 0] = 1.5 * 2.0 ** e      # block max with exponent e
+        x = x.clamp(-1.99 * 2.0 ** e, 1.99 * 2.0 ** e)
+        rows.append(x.float())
+        r = (torch.rand(256, B, generator=g).double() * 4 - 2) * 2.0 ** e
+        r[:, 0] = 1.999 * 2.0 ** e
+        rows.append(r.float())
+    x = torch.cat(rows)
+    for sym in (True, False):
+        got = dmx.ops.bfp_qdq(x.to(cuda), wl, B, -1, sym)
+        assert mismatches_nan_aware(got, oracle.bfp_cast(x, wl, B, -1, sym)) == 0, sym
+
+
 def test_full_size_headline_config(dmx, cuda, oracle):
     """BASELINE.json config 2: 4096x4096 bf16, BFP[8|8]{16}(SN)."""
     x = make("heavy", (4096, 4096), seed=0, dtype=torch.bfloat16)
@@ -108,6 +170,22 @@ def test_properties_at_full_size(dmx, cuda):
     quantum = torch.where(m > 0, torch.exp2(torch.floor(torch.log2(m)) - 6), torch.ones_like(m))
     codes = qb / quantum
     assert torch.all(codes == codes.round()) and float(codes.abs().max()) <= 127
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_inf_nan_poison_the_block_like_the_reference(dmx, cuda, oracle, dtype):
+    """Unspecified by the reference's docs but observable: a block whose max|x| is Inf/NaN (torch.max propagates
+    NaN, quant_cpu.cpp:277-297) gets base = inf and every element of THAT block becomes NaN; others are untouched."""
+    x = make("normal", (16, 256), seed=12, dtype=dtype)
+    x[1, 5] = float("inf")
+    x[2, 40] = float("-inf")
+    x[3, 100] = float("nan")
+    x[4, 255] = float("nan"); x[4, 254] = float("inf")
+    for B in (16, 64, 24):
+        got = dmx.ops.bfp_qdq(x.to(cuda), 8, B)
+        want = oracle.bfp_cast(x, 8, B).to(dtype)
+        assert mismatches_nan_aware(got, want) == 0, B
+        assert int(torch.isnan(got).sum()) == (4 * B if B != 24 else int(torch.isnan(want).sum()))
 
 
 def test_inplace_and_noncontiguous(dmx, cuda, oracle):

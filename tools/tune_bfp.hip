@@ -1,0 +1,86 @@
+// tools/tune_bfp.hip — on-GPU A/B harness for the hot kernel (not part of the product library).
+// Interleaved rounds in ONE process (cdna_hip_programming.md §5.4 rule 24), rotating over NBUF buffer pairs
+// (> 256 MiB Infinity Cache) so every launch streams HBM; a plain 16-byte copy kernel of the same launch
+// geometry is the measured ceiling on the same box (rule 10).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-fast-math -ffp-contract=off tools/tune_bfp.hip -o /tmp/tune_bfp
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../dmx-compressor_amd/csrc/bfp_rows.hpp"
+
+using namespace dmxq;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+template <int UNROLL, int MODE, int THREADS>
+__global__ __launch_bounds__(THREADS) void copy_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t n_vec) {
+  constexpr bool NTL = (MODE & 1) != 0, NTS = (MODE & 2) != 0, CONTIG = (MODE & 4) != 0, WCONTIG = (MODE & 8) != 0;
+  const int64_t step = WCONTIG ? 64 : (CONTIG ? (int64_t)THREADS : (int64_t)gridDim.x * THREADS);
+  const int64_t sweep = (int64_t)gridDim.x * THREADS * UNROLL;
+  int64_t v = WCONTIG ? (int64_t)blockIdx.x * THREADS * UNROLL + (int64_t)(threadIdx.x / 64) * 64 * UNROLL + (threadIdx.x & 63)
+              : (CONTIG ? (int64_t)blockIdx.x * THREADS * UNROLL + threadIdx.x : (int64_t)blockIdx.x * THREADS + threadIdx.x);
+  for (; v < n_vec; v += sweep) {
+    u32x4 raw[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) if (v + u * step < n_vec) raw[u] = load_raw16<NTL>(in, (v + u * step) * 16);
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) if (v + u * step < n_vec) {
+      u32x4* dst = (u32x4*)((char*)out + (v + u * step) * 16);
+      if (NTS) __builtin_nontemporal_store(raw[u], dst); else *dst = raw[u];
+    }
+  }
+}
+
+struct Variant { std::string name; std::function<void(const void*, void*, hipStream_t)> run; std::vector<float> us; };
+
+int main(int argc, char** argv) {
+  const int64_t rows = 4096, cols = 4096, n = rows * cols, n_vec = n / 8;
+  const int NBUF = 20, LAUNCHES = 100, ROUNDS = argc > 1 ? atoi(argv[1]) : 7;
+  std::vector<void*> in(NBUF), out(NBUF);
+  std::vector<uint16_t> h(n);
+  uint64_t s = 88172645463325252ull;
+  for (int64_t i = 0; i < n; i++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = (uint16_t)(((s >> 20) & 0x8FFF) | 0x3000) ^ (uint16_t)((s >> 40) & 0x0F00); }
+  for (int b = 0; b < NBUF; b++) { CK(hipMalloc(&in[b], n * 2)); CK(hipMalloc(&out[b], n * 2)); CK(hipMemcpy(in[b], h.data(), n * 2, hipMemcpyHostToDevice)); }
+  hipStream_t st; CK(hipStreamCreate(&st));
+  std::vector<Variant> vs;
+#define ADD_BFPG(U, M, T, GRID, F, GR) vs.push_back({"bfp  U" #U " M" #M " T" #T " G" #GRID " F" #F " grp" #GR, [=](const void* i, void* o, hipStream_t q) { \
+    int g = (GRID) > 0 ? (GRID) : (int)((n_vec + (int64_t)T * U - 1) / ((int64_t)T * U)); \
+    hipLaunchKernelGGL((bfp_rows_kernel<DMXQ_BF16, DMXQ_BF16, DMXQ_ROUND_NEAREST, false, U, M, T, F, GR>), dim3(g), dim3(T), 0, q, i, o, n_vec, 2, 8, 2, 0ull); }, {}})
+#define ADD_BFPF(U, M, T, GRID, F) ADD_BFPG(U, M, T, GRID, F, U)
+#define ADD_BFP(U, M, T, GRID) ADD_BFPF(U, M, T, GRID, 0)
+#define ADD_COPY(U, M, T, GRID) vs.push_back({"copy U" #U " M" #M " T" #T " G" #GRID, [=](const void* i, void* o, hipStream_t q) { \
+    int g = (GRID) > 0 ? (GRID) : (int)((n_vec + (int64_t)T * U - 1) / ((int64_t)T * U)); \
+    hipLaunchKernelGGL((copy_kernel<U, M, T>), dim3(g), dim3(T), 0, q, i, o, n_vec); }, {}})
+  // G0 = exact grid.  M bits: 1 nt-load, 2 nt-store (copy: 4 = workgroup-contiguous tiles; bfp is always tiled)
+  ADD_COPY(8, 7, 256, 0); ADD_COPY(16, 7, 256, 0); ADD_COPY(16, 7, 512, 0);
+  ADD_BFPG(16, 3, 256, 0, 2, 16); ADD_BFPG(16, 3, 256, 0, 2, 8); ADD_BFPG(16, 3, 256, 0, 2, 4); ADD_BFPG(16, 3, 256, 0, 2, 2); ADD_BFPG(16, 3, 256, 0, 2, 1);
+  ADD_BFPG(16, 3, 256, 0, 0, 16); ADD_BFPG(16, 3, 256, 0, 1, 16); ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPG(16, 3, 512, 0, 2, 8);
+  ADD_BFPG(8, 3, 256, 0, 2, 8); ADD_BFPG(8, 3, 256, 0, 2, 4); ADD_BFPG(8, 3, 512, 0, 2, 8); 
+  ADD_BFPG(12, 3, 256, 0, 2, 12); ADD_BFPG(16, 0, 256, 0, 2, 16); ADD_BFPG(16, 1, 256, 0, 2, 16); ADD_BFPG(16, 2, 256, 0, 2, 16);
+  ADD_BFPG(4, 3, 256, 0, 2, 4); ADD_BFPG(8, 3, 256, 1024, 2, 8); ADD_BFPG(16, 3, 256, 512, 2, 16);
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (auto& v : vs) for (int i = 0; i < 10; i++) v.run(in[i % NBUF], out[i % NBUF], st);
+  CK(hipStreamSynchronize(st));
+  for (int r = 0; r < ROUNDS; r++)
+    for (auto& v : vs) {
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < LAUNCHES; i++) v.run(in[i % NBUF], out[i % NBUF], st);
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      v.us.push_back(ms * 1e3f / LAUNCHES);
+    }
+  printf("%-28s %9s %9s %9s %8s\n", "variant", "min_us", "med_us", "TB/s(med)", "%8TB/s");
+  for (auto& v : vs) {
+    std::sort(v.us.begin(), v.us.end());
+    float med = v.us[v.us.size() / 2], mn = v.us[0];
+    double tbs = 4.0 * n / (med * 1e-6) / 1e12;
+    printf("%-28s %9.2f %9.2f %9.3f %7.1f%%\n", v.name.c_str(), mn, med, tbs, 100.0 * tbs / 8.0);
+  }
+  return 0;
+}
