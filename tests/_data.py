@@ -27,7 +27,8 @@ def normal(n, seed):
 
 def make(kind, shape, seed=0, dtype=torch.float32, block=16):
     """kinds: normal | heavy (exponent spread) | outlier (one 2^10 outlier per block) | ties (half-quantum
-    lattice: every value is a multiple of 2^-8 with |x| < 2) | zeros | denormal | mixed (all of them, by rows)"""
+    lattice: every value is a multiple of 2^-8 with |x| < 2) | zeros | denormal | mixed (all of them, by rows) |
+    mixed_nd (mixed without the denormal rows)"""
     n = int(np.prod(shape))
     if kind == "normal":
         v = normal(n, seed)
@@ -45,9 +46,9 @@ def make(kind, shape, seed=0, dtype=torch.float32, block=16):
         v = np.zeros(n)
     elif kind == "denormal":
         v = normal(n, seed) * 1e-40
-    elif kind == "mixed":
-        parts = [make(k, (n,), seed + i, torch.float32, block).double().numpy()
-                 for i, k in enumerate(("normal", "heavy", "outlier", "ties", "zeros", "denormal"))]
+    elif kind in ("mixed", "mixed_nd"):  # mixed_nd: no denormal-maximum blocks
+        kinds = ("normal", "heavy", "outlier", "ties", "zeros") + (("denormal",) if kind == "mixed" else ())
+        parts = [make(k, (n,), seed + i, torch.float32, block).double().numpy() for i, k in enumerate(kinds)]
         sel = (np.arange(n) // max(block * 4, 1)) % len(parts)
         v = np.choose(sel, parts)
     else:

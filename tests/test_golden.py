@@ -1,0 +1,229 @@
+"""Golden-vector tests.  tests/golden/*.npz hold inputs and the outputs of the REAL reference (generated in the
+build container by oracle/gen_golden.py, which runs d-matrix-ai/dmx-compressor's own CastTo / Sparsify /
+observer / SmoothQuant code).  Two consumers:
+  * -m "not gpu": the CPU oracle must reproduce every stored output bit for bit  -> the oracle is pinned;
+  * -m gpu      : the HIP kernels (through the C ABI) must reproduce them too     -> parity with the reference.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+T_BITS = {torch.float32: torch.int32, torch.bfloat16: torch.int16, torch.float16: torch.int16}
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def tensor(arr, dtype):
+    a = np.ascontiguousarray(arr)
+    t = torch.from_numpy(a.view(np.int32 if a.dtype == np.uint32 else np.int16))
+    return t.view(dtype)
+
+
+def mism(got, want_bits, dtype):
+    """bit mismatches, any NaN == any NaN"""
+    want = tensor(want_bits, dtype)
+    got = got.detach().cpu().contiguous()
+    assert got.dtype == dtype and got.shape == want.shape, (got.dtype, got.shape, want.shape)
+    both_nan = torch.isnan(got.float()) & torch.isnan(want.float())
+    return int(((got.view(T_BITS[dtype]) != want.view(T_BITS[dtype])) & ~both_nan).sum())
+
+
+class OracleBackend:
+    """runs a case on the CPU oracle"""
+
+    def __init__(self, O):
+        self.O = O
+        self.dev = torch.device("cpu")
+
+    def bfp(self, x, wl, B, dim, sym, out_dtype):
+        return self.O.bfp_cast(x, wl, B, dim, sym).to(out_dtype).contiguous()
+
+    def fmt(self, x, sh, out_dtype):
+        import dmx_compressor_amd as d
+        f = d.Format.from_shorthand(sh)
+        if isinstance(f, d.BlockFloatingPoint):
+            y = self.O.bfp_cast(x, f.precision, f.block_size)
+        elif isinstance(f, d.FloatingPoint):
+            y = self.O.floating_point_cast(x, f.mantissa, f.exponent, f.bias, f.flush_subnormal, f.unsigned)
+        else:
+            y = self.O.fixed_point_cast(x, f.precision, f.fraction, f.clamp, f.symmetric)
+        return y.to(out_dtype)
+
+    def affine(self, x, f, sc, zp, ch_axis, gs):
+        return self.O.fixed_point_affine_cast(x, f.precision, f.fraction, f.clamp, f.symmetric, sc, zp, ch_axis=ch_axis, group_size=gs)
+
+    def nm(self, s, K, M, dim):
+        return self.O.nm_mask(s, K, M, dim).contiguous()
+
+    def sparsify(self, x, s, K, M):
+        return self.O.sparsify(x, s, K, M)
+
+    def maxabs(self, x, ax):
+        return self.O.channel_maxabs(x, ax)
+
+    def minmax_qparams(self, x, ax, gs, per_channel, f, sym_q):
+        if gs:
+            mn, mx = self.O.group_minmax(x, ax, gs)
+        elif per_channel:
+            mn, mx = self.O.group_minmax(x, ax, 1)
+        else:
+            mn, mx = self.O.group_minmax(x.reshape(1, -1), 0, 1)
+        return self.O.qparams(mn, mx, f.precision, f.symmetric, sym_q)
+
+
+class HipBackend:
+    """runs a case on the GPU through the host mirror -> ctypes -> C ABI"""
+
+    def __init__(self, d, dev):
+        self.d, self.dev = d, dev
+
+    def bfp(self, x, wl, B, dim, sym, out_dtype):
+        return self.d.ops.bfp_qdq(x.to(self.dev), wl, B, dim, sym, out_dtype=out_dtype)
+
+    def fmt(self, x, sh, out_dtype):
+        return self.d.CastTo(format=sh)(x.to(self.dev))
+
+    def affine(self, x, f, sc, zp, ch_axis, gs):
+        return self.d.ops.fixed_qdq(x.to(self.dev), f.precision, f.fraction, f.clamp, f.symmetric, scale=sc, zero_point=zp,
+                                    ch_axis=ch_axis, group_size=gs)
+
+    def nm(self, s, K, M, dim):
+        return self.d.ops.nm_mask(s.to(self.dev), K, M, dim)
+
+    def sparsify(self, x, s, K, M):
+        return self.d.ops.nm_sparsify(x.to(self.dev), s.to(self.dev), K, M)
+
+    def maxabs(self, x, ax):
+        return self.d.ops.channel_maxabs(x.to(self.dev), ax)
+
+    def minmax_qparams(self, x, ax, gs, per_channel, f, sym_q):
+        obs = self.d.MinMaxObserver(dtype=f, qscheme={(True, True): torch.per_channel_symmetric, (True, False): torch.per_channel_affine,
+                                                     (False, True): torch.per_tensor_symmetric, (False, False): torch.per_tensor_affine}[(per_channel, sym_q)],
+                                    ch_axis=ax)
+        obs(x.to(self.dev), gs)
+        return obs.calculate_qparams()
+
+
+def backends():
+    return [pytest.param("oracle", id="oracle"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture
+def backend(request, oracle, dmx):
+    if request.param == "oracle":
+        return OracleBackend(oracle)
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return HipBackend(dmx, torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("backend", backends(), indirect=True)
+def test_bfp_fixtures(backend):
+    g = load("bfp.npz")
+    n = 0
+    for key in g.files:
+        if not key.startswith("y_"):
+            continue
+        _, dt, wl, B, sym = key.split("_")
+        x = tensor(g[("x_" if sym == "S" else "xa_") + dt], DT[dt])
+        got = backend.bfp(x, int(wl), int(B), -1, sym == "S", DT[dt])
+        assert mism(got, g[key], DT[dt]) == 0, key
+        n += 1
+    assert n == 3 * 4 * (5 * 2 - 1)
+    xr = tensor(g["ragged_x"], torch.float32)
+    for B in (16, 24, 64):
+        assert mism(backend.bfp(xr, 8, B, -1, True, torch.float32), g[f"ragged_y_{B}"], torch.float32) == 0, B
+    xc = tensor(g["conv_x"], torch.bfloat16)
+    for dim in (-1, -2, 1, 0):
+        for B in (16, 64):
+            assert mism(backend.bfp(xc, 8, B, dim, True, torch.bfloat16), g[f"conv_y_{dim}_{B}"], torch.bfloat16) == 0, (dim, B)
+    adv = tensor(g["adv_x"], torch.float32)
+    assert mism(backend.bfp(adv, 8, 16, -1, True, torch.float32), g["adv_y_S"], torch.float32) == 0
+    assert mism(backend.bfp(adv, 8, 16, -1, False, torch.float32), g["adv_y_A"], torch.float32) == 0
+
+
+@pytest.mark.parametrize("backend", backends(), indirect=True)
+def test_float_and_fixed_fixtures(backend, dmx):
+    g = load("elementwise.npz")
+    for i, sh in enumerate([str(s) for s in g["float_sh"]]):
+        for tag in ("f32", "bf16"):
+            x = tensor(g[f"x_{tag}"], DT[tag])
+            assert mism(backend.fmt(x, sh, DT[tag]), g[f"float{i}_{tag}"], DT[tag]) == 0, (sh, tag)
+    x = tensor(g["x_f32"], torch.float32)
+    for i, sh in enumerate([str(s) for s in g["fixed_sh"]]):
+        assert mism(backend.fmt(x, sh, torch.float32), g[f"fixed{i}_f32"], torch.float32) == 0, sh
+    # reference KAT (tests/test_group_quant.py:49-63) as stored by the generator
+    xk, yk = tensor(g["kat_group_x"], torch.float32), tensor(g["kat_group_y"], torch.float32)
+    assert torch.allclose(yk, torch.tensor([[0, 1], [3, 7], [6, 8], [10, 14], [0.1, 0.7]]), rtol=0.0, atol=1e-6)
+    f = dmx.format.INT4
+    sc, zp = backend.minmax_qparams(xk, 0, 2, False, f, True)
+    assert mism(backend.affine(xk, f, sc, zp, 0, 2), g["kat_group_y"], torch.float32) == 0
+
+
+AFFINE = [("tensor_sym", False, True, -1, None), ("tensor_aff", False, False, -1, None), ("chan0_sym", True, True, 0, None),
+          ("chan1_aff", True, False, 1, None), ("group16_sym", False, True, 0, 16), ("group7_sym_ragged", False, True, 0, 7),
+          ("group5_aff_axis1", False, False, 1, 5)]
+
+
+@pytest.mark.parametrize("backend", backends(), indirect=True)
+def test_affine_group_quant_fixtures(backend, dmx):
+    """MinMax observer -> (scale, zero_point) -> fused affine fixed-point cast, all three stages vs the reference."""
+    g = load("elementwise.npz")
+    W = tensor(g["aff_w"], torch.float32)
+    for sh in ("XP[8,0](CSN)", "XP[4,0](CSN)", "XP[8,0](C_N)"):
+        f = dmx.Format.from_shorthand(sh)
+        for name, per_channel, sym_q, ax, gs in AFFINE:
+            key = f"aff_{sh}_{name}"
+            sc, zp = backend.minmax_qparams(W, ax, gs, per_channel, f, sym_q)
+            assert mism(sc.reshape(-1), g[key + "_scale"], torch.float32) == 0, key
+            assert np.array_equal(zp.cpu().numpy().reshape(-1), g[key + "_zp"]), key
+            got = backend.affine(W, f, sc, zp, ax if (gs or per_channel) else None, gs)
+            assert mism(got, g[key + "_y"], torch.float32) == 0, key
+
+
+@pytest.mark.parametrize("backend", backends(), indirect=True)
+def test_nm_mask_fixtures(backend):
+    g = load("nm_mask.npz")
+    n = 0
+    for key in g.files:
+        if not key.startswith("m_"):
+            continue
+        body, K, M, dim = key[2:].rsplit("_", 3)
+        sdt = torch.bfloat16 if body == "absbf16" else torch.float32
+        s = tensor(g[f"s_{body}"], sdt)
+        assert mism(backend.nm(s, int(K), int(M), int(dim)), g[key], sdt) == 0, key
+        n += 1
+    assert n == 6 * 6 * 2
+    x, s = tensor(g["sp_x"], torch.bfloat16), tensor(g["s_random"], torch.float32)
+    assert mism(backend.sparsify(x, s, 2, 4), g["sp_y"], torch.float32) == 0
+
+
+@pytest.mark.parametrize("backend", backends(), indirect=True)
+def test_smoothquant_fixtures(backend, dmx):
+    g = load("smoothquant.npz")
+    a, w = tensor(g["a"], torch.float32), tensor(g["w"], torch.float32)
+    am, wm = backend.maxabs(a, -1), backend.maxabs(w, -1)
+    assert mism(am, g["a_maxabs"], torch.float32) == 0 and mism(wm, g["w_maxabs"], torch.float32) == 0
+    if isinstance(backend, HipBackend):
+        for alpha in (0.0, 0.25, 0.5, 1.0):
+            got = dmx.ops.smoothquant_scale(am, wm, alpha, 1e-5).cpu()
+            want = tensor(g[f"scale_{alpha}"], torch.float32)
+            # floating point (two powf + a divide on different libms): within 4 ulp of fp32
+            assert torch.allclose(got, want, rtol=4.8e-7, atol=0.0), alpha
+
+
+def test_vocabulary_matches_reference(dmx):
+    g = load("vocabulary.npz")
+    names, reprs = [str(s) for s in g["format_names"]], [str(s) for s in g["format_reprs"]]
+    mine = vars(dmx.format)
+    assert sorted(mine) == names
+    for n, r in zip(names, reprs):
+        assert repr(mine[n]) == r, n
+    for n, r in zip([str(s) for s in g["sparse_names"]], [str(s) for s in g["sparse_reprs"]]):
+        assert repr(getattr(dmx.sparseness, n)) == r, n
