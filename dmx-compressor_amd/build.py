@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libdmxq.so")
-SOURCES = ["bfp.hip", "elementwise.hip", "nm_mask.hip", "reduce.hip", "approx.hip"]
+SOURCES = ["bfp.hip", "bfp_cols.hip", "elementwise.hip", "nm_mask.hip", "reduce.hip", "approx.hip"]
 # bit-exact fp32: no fast-math, no fma contraction; fp32 denormals stay on (gfx950 default)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
          "-fgpu-flush-denormals-to-zero" if False else "-fno-gpu-flush-denormals-to-zero"]
@@ -36,7 +36,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    hdrs = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "bfp_math.hpp"), os.path.join(CSRC, "bfp_rows.hpp"), os.path.join(HERE, "..", "include", "dmxq.h"), os.path.abspath(__file__)]
+    hdrs = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "bfp_math.hpp"), os.path.join(CSRC, "bfp_rows.hpp"), os.path.join(CSRC, "stream.hpp"), os.path.join(HERE, "..", "include", "dmxq.h"), os.path.abspath(__file__)]
     hipcc = _hipcc()
 
     def compile_one(src):

@@ -7,7 +7,7 @@
 // implement that exact-function contract in fp32 (one read, one write per element); approximation
 // arithmetic is PARITY-UNPINNED and is not invented here.
 //
-//   gelu       elementwise, erf or tanh form                       (torch.nn.functional.gelu)
+//   gelu       elementwise, erf or tanh form (GeluOp in elementwise.hip)  (torch.nn.functional.gelu)
 //   softmax    over the contiguous last dim, optional input clamp  (modeling/nn/torch_modules.py:989-994)
 //   layernorm  over the contiguous last dim, affine optional       (modeling/nn/torch_modules.py:1062-1082)
 // Row kernels: one workgroup per row, the row is staged ONCE in LDS as fp32 (gfx950 has 160 KiB per CU), the
@@ -43,22 +43,6 @@ __device__ __forceinline__ float block_allreduce(float v, float* scratch) {
 #pragma unroll
   for (int i = 1; i < kThreads / kWave; i++) r = IS_MAX ? fmaxf(r, scratch[i]) : r + scratch[i];
   return r;
-}
-
-__global__ __launch_bounds__(kThreads) void gelu_kernel(const void* __restrict__ in, void* __restrict__ out, int dti,
-                                                       int dto, int64_t n, int tanh_form) {
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += stride) {
-    const float x = load_rt(in, dti, e);
-    float y;
-    if (tanh_form) {
-      const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-      y = 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));
-    } else {
-      y = 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
-    }
-    store_rt(out, dto, e, y);
-  }
 }
 
 template <bool LDS_ROW>
@@ -131,16 +115,6 @@ __global__ __launch_bounds__(kThreads) void layernorm_rows_kernel(const void* __
 }  // namespace dmxq
 
 using namespace dmxq;
-
-extern "C" int dmxq_gelu(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int tanh_form,
-                         void* stream) {
-  if (!valid_dtype(dtype_in) || !valid_dtype(dtype_out) || n < 0) return DMXQ_ERR_BAD_ARG;
-  if (n == 0) return DMXQ_OK;
-  if (!in || !out) return DMXQ_ERR_BAD_ARG;
-  hipLaunchKernelGGL(gelu_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, in, out, dtype_in,
-                     dtype_out, n, tanh_form);
-  return launch_status();
-}
 
 static inline int row_grid(int64_t rows) { return (int)(rows < 256 * 16 ? (rows < 1 ? 1 : rows) : 256 * 16); }
 

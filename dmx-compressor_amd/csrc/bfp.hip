@@ -96,10 +96,18 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
     else if (n_vec >= (int64_t)512 * 256 * 4) DMXQ_ROWS(256, 4, F_);           \
     else DMXQ_ROWS(256, 1, F_);                                                \
   } while (0)
+    // instantiate only what can run (see bfp_cols.hip): literal path for the runtime-rounding build, magic-add for
+    // nearest-even; nearest with wl > 20 is routed to the runtime-rounding build by dispatch_mode
     constexpr bool in16 = Elem<DTI>::bytes == 2;
-    if (RND == DMXQ_ROUND_NEAREST && fast == 2 && in16) DMXQ_ROWS_GEOM(2);
-    else if (RND == DMXQ_ROUND_NEAREST && fast != 0) DMXQ_ROWS_GEOM(1);
-    else DMXQ_ROWS_GEOM(0);
+    if constexpr (RND == kRuntimeRounding) {
+      DMXQ_ROWS_GEOM(0);
+    } else {
+      if (in16 && fast == 2) {
+        if constexpr (in16) DMXQ_ROWS_GEOM(2);
+      } else {
+        DMXQ_ROWS_GEOM(1);
+      }
+    }
 #undef DMXQ_ROWS_GEOM
 #undef DMXQ_ROWS
     return launch_status();
@@ -114,7 +122,7 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
 template <int DTI, int DTO>
 static int dispatch_mode(const void* in, void* out, int64_t outer, int64_t L, int64_t inner, int64_t B, int wl,
                          int rounding, bool asym, uint64_t seed, hipStream_t s) {
-  if (rounding == DMXQ_ROUND_NEAREST)
+  if (rounding == DMXQ_ROUND_NEAREST && wl <= 20)
     return asym ? launch_bfp<DTI, DTO, DMXQ_ROUND_NEAREST, true>(in, out, outer, L, inner, B, wl, rounding, seed, s)
                 : launch_bfp<DTI, DTO, DMXQ_ROUND_NEAREST, false>(in, out, outer, L, inner, B, wl, rounding, seed, s);
   return asym ? launch_bfp<DTI, DTO, kRuntimeRounding, true>(in, out, outer, L, inner, B, wl, rounding, seed, s)
@@ -126,6 +134,10 @@ static int dispatch_mode(const void* in, void* out, int64_t outer, int64_t L, in
 extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int man_bits,
                               int exp_bits, int exp_bias, int flush_subnormal, int unsigned_abs, int rounding,
                               uint64_t seed, void* stream);
+// bfp_cols.hip: register-tiled kernel for blocks along a non-contiguous dimension; DMXQ_ERR_UNSUPPORTED = not applicable
+extern "C" int dmxq_internal_bfp_cols(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L,
+                                      int64_t inner, int64_t B, int wl, int rounding, int symmetric, uint64_t seed,
+                                      void* stream);
 
 extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L,
                             int64_t inner, int64_t block_size, int precision, int rounding, int symmetric,
@@ -139,6 +151,11 @@ extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_o
   if (block_size == 1)  // numerical/format.py:312-320: BFP with block size 1 borrows float_quantize
     return dmxq_float_qdq(in, out, dtype_in, dtype_out, n, precision - 2, 8, 127, 0, 0, rounding, seed, stream);
   if (precision > 22) return DMXQ_ERR_UNSUPPORTED;  // reference shifts by a negative count (UB) beyond this
+  if (inner > 1) {
+    const int rc = dmxq_internal_bfp_cols(in, out, dtype_in, dtype_out, outer, L, inner, block_size, precision, rounding,
+                                          symmetric, seed, stream);
+    if (rc != DMXQ_ERR_UNSUPPORTED) return rc;
+  }
   hipStream_t s = (hipStream_t)stream;
   const bool asym = !symmetric;
 #define DMXQ_DT(I_, O_)                                                                                        \

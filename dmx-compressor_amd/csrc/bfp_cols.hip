@@ -1,0 +1,200 @@
+// csrc/bfp_cols.hip — BFP Q->DQ for blocks that run along a NON-contiguous dimension (inner > 1):
+// block_dim = -2 (attention K/V multipliers, modeling/nn/torch_modules.py:197-204), conv activations/weights
+// blocked along dim 1 (:582-585), i.e. the [outer, L, inner] view with inner > 1.
+//
+// The reference transposes the tensor so that the block dimension becomes last, runs its row algorithm and
+// transposes back (numerical/format.py:322-341).  Here nothing is transposed: lanes run along the CONTIGUOUS
+// inner dimension (16 B per lane, so a wave reads whole 1 KiB / 512 B / 256 B row segments), and each lane walks
+// down the B rows of its block keeping the column tile in REGISTERS: one pass, every element read once and
+// written once, all B row-loads of a lane in flight at once.
+//   RPL = rows per lane (<= 32: 128 data VGPRs), RS = row split: the B = RPL*RS rows of a block are shared by RS
+//   lane groups of 64/RS lanes (B = 64 -> two half-waves of 32 rows each); per-column maxima are combined across
+//   the groups with lane permutes.  Every COLUMN is its own block, so a lane carries EPL block maxima.
+// Arithmetic is bfp_math.hpp (magic-add nearest-even with the literal path as wave-uniform fallback).
+#include "bfp_math.hpp"
+
+namespace dmxq {
+
+template <int RS>
+__device__ __forceinline__ uint32_t split_max_u32(uint32_t m) {
+  if (RS >= 2) m = max(m, (uint32_t)__shfl_xor((int)m, 32));
+  if (RS >= 4) m = max(m, (uint32_t)__shfl_xor((int)m, 16));
+  return m;
+}
+
+// per-element abs bit patterns (as fp32 bits) of one raw vector, max-accumulated into mb[EPL]
+template <int DTI, int EPL>
+__device__ __forceinline__ void accumulate_absmax(const u32x4& v, uint32_t (&mb)[EPL]) {
+  if (DTI == DMXQ_F32) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) mb[j] = max(mb[j], v[j] & 0x7FFFFFFFu);
+  } else if (DTI == DMXQ_BF16) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      mb[2 * j] = max(mb[2 * j], (v[j] << 16) & 0x7FFF0000u);
+      mb[2 * j + 1] = max(mb[2 * j + 1], v[j] & 0x7FFF0000u);
+    }
+  } else {  // fp16: half bit patterns order like magnitudes; widened after the reduction
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      mb[2 * j] = max(mb[2 * j], v[j] & 0x7FFFu);
+      mb[2 * j + 1] = max(mb[2 * j + 1], (v[j] >> 16) & 0x7FFFu);
+    }
+  }
+}
+
+template <int DTI, int DTO, int RND, bool ASYM, int RPL, int RS, int FAST>
+__global__ __launch_bounds__(kThreads) void bfp_cols_kernel(const void* __restrict__ in, void* __restrict__ out,
+                                                           int64_t outer, int64_t L, int64_t inner, int wl,
+                                                           int rounding, uint64_t seed) {
+  constexpr int EPL = 16 / Elem<DTI>::bytes;
+  constexpr int B = RPL * RS;
+  constexpr int LPR = kWave / RS;  // lanes per row segment
+  constexpr int OVB = EPL * Elem<DTO>::bytes;
+  constexpr bool kFast = FAST != 0 && RND == DMXQ_ROUND_NEAREST;
+  const bool stoch = (RND == kRuntimeRounding) && rounding == DMXQ_ROUND_STOCHASTIC;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int grp = lane / LPR, lig = lane % LPR;  // row group, lane in group
+  const int64_t nblk = (L + B - 1) / B;
+  const int64_t cvec = inner / EPL;                       // 16-byte vectors per row (inner % EPL == 0)
+  const int64_t ctiles = (cvec + LPR - 1) / LPR;
+  const int64_t units = outer * nblk * ctiles;            // one unit = one wave's [B rows x LPR vectors] tile
+  const int64_t wave_id = (int64_t)blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave;
+  const int64_t n_waves = (int64_t)gridDim.x * (kThreads / kWave);
+  for (int64_t unit = wave_id; unit < units; unit += n_waves) {
+    const int64_t ct = unit % ctiles;
+    const int64_t blk = (unit / ctiles) % nblk;
+    const int64_t o = unit / (ctiles * nblk);
+    const int64_t cv = ct * LPR + lig;                    // this lane's column vector
+    const bool col_ok = cv < cvec;
+    const int64_t row0 = blk * B + grp * RPL;             // first row of this lane's share of the block
+    const int64_t base_e = (o * L + row0) * inner + cv * EPL;
+    u32x4 raw[RPL];
+    uint32_t mb[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; k++) mb[k] = 0u;
+#pragma unroll
+    for (int r = 0; r < RPL; r++) {                        // all row loads in flight
+      const bool ok = col_ok && row0 + r < L;              // ragged last block: rows beyond L count as absent
+      raw[r] = ok ? load_raw16<true>(in, (base_e + r * inner) * Elem<DTI>::bytes) : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int r = 0; r < RPL; r++) accumulate_absmax<DTI, EPL>(raw[r], mb);
+    uint32_t mfin[EPL];
+    bool all_fast = kFast;
+#pragma unroll
+    for (int k = 0; k < EPL; k++) {
+      uint32_t m = split_max_u32<RS>(mb[k]);
+      if (DTI == DMXQ_F16) m = f2u((float)__builtin_bit_cast(_Float16, (uint16_t)m));
+      if (kFast) all_fast = all_fast && bfp_fast_ok(m, wl);
+      mfin[k] = m;
+    }
+    char* const obase = (char*)out + base_e / EPL * OVB;
+    const int64_t ostride = inner / EPL * OVB;
+    if (kFast && __builtin_amdgcn_ballot_w64(!all_fast) == 0ull) {  // wave-uniform
+      BfpBlockParams p[EPL];
+#pragma unroll
+      for (int k = 0; k < EPL; k++) p[k] = bfp_block_params<ASYM, true>(mfin[k], wl);
+#pragma unroll
+      for (int r = 0; r < RPL; r++) {
+        float x[EPL], y[EPL];
+        widen<DTI, EPL>(raw[r], x);
+#pragma unroll
+        for (int k = 0; k < EPL; k++) y[k] = bfp_q1_fast<FAST == 2, ASYM>(x[k], p[k]);
+        if (col_ok && row0 + r < L) store_out<DTO, EPL, true>(obase + r * ostride, pack_vec<DTO, EPL>(y));
+      }
+    } else {
+      BfpBlockParams p[EPL];
+#pragma unroll
+      for (int k = 0; k < EPL; k++) p[k] = bfp_block_params<ASYM, false>(mfin[k], wl);
+#pragma unroll
+      for (int r = 0; r < RPL; r++) {
+        float x[EPL], y[EPL];
+        widen<DTI, EPL>(raw[r], x);
+#pragma unroll
+        for (int k = 0; k < EPL; k++) {
+          // the oracle numbers random draws by position in the transposed [outer*inner, L] matrix
+          const uint64_t ridx = (uint64_t)((o * inner + cv * EPL + k) * L + row0 + r);
+          y[k] = bfp_q1<RND, ASYM>(x[k], p[k], wl, rounding, stoch ? rnd_bits(seed, ridx) : 0u);
+        }
+        if (col_ok && row0 + r < L) store_out<DTO, EPL, true>(obase + r * ostride, pack_vec<DTO, EPL>(y));
+      }
+    }
+  }
+}
+
+template <int DTI, int DTO, int RND, bool ASYM, int RPL, int RS>
+static int launch_cols_geom(const void* in, void* out, int64_t outer, int64_t L, int64_t inner, int wl, int rounding,
+                            uint64_t seed, hipStream_t s) {
+  constexpr int EPL = 16 / Elem<DTI>::bytes;
+  constexpr int B = RPL * RS, LPR = kWave / RS;
+  const int64_t nblk = (L + B - 1) / B, cvec = inner / EPL, ctiles = (cvec + LPR - 1) / LPR;
+  const int64_t units = outer * nblk * ctiles;
+  int64_t grid = (units + 3) / 4;
+  if (grid < 1) grid = 1;
+  if (grid > (1 << 20)) grid = 1 << 20;
+  const int fast = (RND == DMXQ_ROUND_NEAREST && wl <= 20) ? (bfp_single_rounding_ok<DTI>(wl) ? 2 : 1) : 0;
+#define DMXQ_COLS(F_)                                                                                             \
+  hipLaunchKernelGGL((bfp_cols_kernel<DTI, DTO, RND, ASYM, RPL, RS, F_>), dim3((unsigned)grid), dim3(kThreads), 0, s, \
+                     in, out, outer, L, inner, wl, rounding, seed)
+  // instantiate only what can run: the literal path for the runtime-rounding build; magic-add (double / single
+  // rounding) for nearest-even.  (nearest with wl > 20 is routed to the runtime-rounding build by the caller.)
+  constexpr bool in16 = Elem<DTI>::bytes == 2;
+  if constexpr (RND == kRuntimeRounding) {
+    DMXQ_COLS(0);
+  } else {
+    if (in16 && fast == 2) {
+      if constexpr (in16) DMXQ_COLS(2);
+    } else {
+      DMXQ_COLS(1);
+    }
+  }
+#undef DMXQ_COLS
+  return launch_status();
+}
+
+template <int DTI, int DTO, int RND, bool ASYM>
+static int launch_cols(const void* in, void* out, int64_t outer, int64_t L, int64_t inner, int64_t B, int wl,
+                       int rounding, uint64_t seed, hipStream_t s) {
+#define DMXQ_G(RPL_, RS_) return launch_cols_geom<DTI, DTO, RND, ASYM, RPL_, RS_>(in, out, outer, L, inner, wl, rounding, seed, s)
+  switch (B) {
+    case 8: DMXQ_G(8, 1);
+    case 16: DMXQ_G(16, 1);
+    case 32: DMXQ_G(32, 1);
+    case 64: DMXQ_G(32, 2);
+    case 128: DMXQ_G(32, 4);
+  }
+#undef DMXQ_G
+  return DMXQ_ERR_UNSUPPORTED;
+}
+
+}  // namespace dmxq
+
+using namespace dmxq;
+
+// internal entry used by dmxq_bfp_qdq (bfp.hip): returns DMXQ_ERR_UNSUPPORTED when this path does not apply, in
+// which case the caller falls back to the generic kernel.
+extern "C" int dmxq_internal_bfp_cols(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L,
+                                      int64_t inner, int64_t B, int wl, int rounding, int symmetric, uint64_t seed,
+                                      void* stream) {
+  const int epl = dtype_in == DMXQ_F32 ? 4 : 8;
+  if (inner % epl != 0 || !aligned16(in) || !aligned16(out) || wl > 22) return DMXQ_ERR_UNSUPPORTED;
+  if (!(B == 8 || B == 16 || B == 32 || B == 64 || B == 128)) return DMXQ_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const bool asym = !symmetric;
+#define DMXQ_DT(I_, O_)                                                                                           \
+  if (dtype_in == I_ && dtype_out == O_) {                                                                        \
+    if (rounding == DMXQ_ROUND_NEAREST && wl <= 20)                                                               \
+      return asym ? launch_cols<I_, O_, DMXQ_ROUND_NEAREST, true>(in, out, outer, L, inner, B, wl, rounding, seed, s)  \
+                  : launch_cols<I_, O_, DMXQ_ROUND_NEAREST, false>(in, out, outer, L, inner, B, wl, rounding, seed, s); \
+    return asym ? launch_cols<I_, O_, kRuntimeRounding, true>(in, out, outer, L, inner, B, wl, rounding, seed, s)     \
+                : launch_cols<I_, O_, kRuntimeRounding, false>(in, out, outer, L, inner, B, wl, rounding, seed, s);   \
+  }
+  DMXQ_DT(DMXQ_BF16, DMXQ_BF16)
+  DMXQ_DT(DMXQ_F16, DMXQ_F16)
+  DMXQ_DT(DMXQ_F32, DMXQ_F32)
+  DMXQ_DT(DMXQ_BF16, DMXQ_F32)
+  DMXQ_DT(DMXQ_F16, DMXQ_F32)
+#undef DMXQ_DT
+  return DMXQ_ERR_UNSUPPORTED;
+}

@@ -93,15 +93,16 @@ __device__ __forceinline__ float bfp_q1(float x, const BfpBlockParams& p, int wl
 // nearest-even fast path, see (2); only for blocks that pass bfp_fast_ok (normal finite maximum, or all zero)
 template <bool SINGLE, bool ASYM>
 __device__ __forceinline__ float bfp_q1_fast(float x, const BfpBlockParams& p) {
-  float q;
   if (SINGLE) {
-    q = (x + p.K) - p.K;
-  } else {
-    const float t = x + p.base;
-    q = (t + p.M) - p.K;
+    const float q = (x + p.K) - p.K;
+    // single rounding: q == -2^(e+1) exactly when x <= thr (x < -(2^(wl-1) - 1/2) quanta rounds to the code
+    // -2^(wl-1), and the tie itself goes to that even code), so the asymmetric format is just an asymmetric clamp
+    return __builtin_amdgcn_fmed3f(q, ASYM ? p.neg_lim : -p.maxv, p.maxv);
   }
+  const float t = x + p.base;
+  float q = (t + p.M) - p.K;
   q = __builtin_amdgcn_fmed3f(q, -p.maxv, p.maxv);
-  if (ASYM) q = (x <= p.thr) ? p.neg_lim : q;
+  if (ASYM) q = (x <= p.thr) ? p.neg_lim : q;  // the first rounding may cross thr: compare the original x
   return q;
 }
 

@@ -94,7 +94,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // was observed to read element 0 for every index under hipcc 7.2)
 // opaque(): keeps hipcc from folding an fp16<->fp32 conversion into a neighbouring multiply as v_fma_mix*(a, b, +0):
 // that form adds +0.0 and turns a -0.0 product into +0.0 (observed: `(q - zp) * sc` stored as fp16).
-__device__ __forceinline__ float opaque(float v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ float opaque(float v) { asm("" : "+v"(v)); return v; }  // not volatile: free to schedule
 __device__ __forceinline__ float half_lo(uint32_t w) { return opaque((float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu))); }
 __device__ __forceinline__ float half_hi(uint32_t w) { return opaque((float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16))); }
 

@@ -5,7 +5,7 @@
 //   * per-channel scaling      (numerical/smoothquant.py:255-283)
 // All share one skeleton: each lane moves 16 B of input per step (global_load_dwordx4), UNROLL steps in flight,
 // fp32 arithmetic, one RNE narrowing to the output dtype, 16-byte stores.  HBM-bound: 2+2 B/elem for 16-bit I/O.
-#include "common.hpp"
+#include "stream.hpp"
 
 namespace dmxq {
 
@@ -53,14 +53,25 @@ struct FixedFmt {
   uint64_t seed;
 };
 
-// sim_helper.cpp:14-21 round(a, 0.5, sigma): ldexp, (float)(a + 0.5f) - 0.5 in double, nearbyint (half-even),
-// narrow to float, ldexp.  The double step is kept literally (v_add_f64 + v_rndne_f64): it is what makes
-// e.g. 0.5 + 2^-24 round to 0.  sim_helper.cpp:24-38 for up (ceil) / down (floor).
+// sim_helper.cpp:14-21 round(a, r, sigma): ldexp; a1 = (float)(a + r); nearbyint((double)a1 - 0.5) (half-even);
+// narrow to float; ldexp.  The fp32 add comes first — that is what makes 0.5 + 2^-24 round to 0 — and the
+// double subtraction is exact.  It is reproduced in fp32 only (no f64 VALU, half rate on gfx950):
+//   |a1| <  2^23 : a1 - 0.5f is exactly representable, rintf of it is the same integer;
+//   |a1| >= 2^23 : a1 is an integer, a1 - 0.5 is an exact tie between a1-1 and a1 -> the even one: a1 unless it
+//                  is odd (only possible below 2^24, where the mantissa LSB is the units bit), then a1 - 1.
+// sim_helper.cpp:24-38 for up (ceil) / down (floor).
+__device__ __forceinline__ float rne_minus_half(float a1) {
+  const float mag = fabsf(a1);
+  const float small = rintf(a1 - 0.5f);
+  const bool odd = (f2u(a1) & 1u) != 0u && mag < 16777216.0f;
+  const float big = odd ? a1 - 1.0f : a1;
+  return mag >= 8388608.0f ? big : small;
+}
 __device__ __forceinline__ float fixed_q1(float a, const FixedFmt& f, float r) {
   a = ldexpf(a, -f.sigma);
   if (f.rounding == DMXQ_ROUND_UP) a = ceilf(a);
   else if (f.rounding == DMXQ_ROUND_DOWN) a = floorf(a);
-  else a = (float)__builtin_rint((double)(a + r) - 0.5);
+  else a = rne_minus_half(a + r);
   a = ldexpf(a, f.sigma);
   if (f.clamp) a = a > f.t_max ? f.t_max : (a < f.t_min ? f.t_min : a);
   return a;
@@ -70,122 +81,151 @@ __device__ __forceinline__ float rnd_unit(uint64_t seed, uint64_t idx) {
   return (float)(rnd_bits(seed, idx) >> 8) * (1.0f / 16777216.0f);
 }
 
-// ------------------------------------------------------------------------------------------------- skeleton
-// OP::apply(x, flat element index) -> y.   n_vec 16-byte input vectors + scalar tail handled by the caller.
-template <int DTI, int DTO, int UNROLL, class OP>
-__global__ __launch_bounds__(kThreads) void ew_vec_kernel(const void* __restrict__ in, void* __restrict__ out,
-                                                         int64_t n, OP op) {
-  constexpr int EPL = 16 / Elem<DTI>::bytes;
-  const int64_t n_vec = n / EPL;
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  const int64_t tid = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  int64_t v = tid;
-  for (; v + (UNROLL - 1) * stride < n_vec; v += UNROLL * stride) {
-    float x[UNROLL][EPL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; u++) load_vec<DTI, EPL>(in, (v + u * stride) * EPL, x[u]);
-#pragma unroll
-    for (int u = 0; u < UNROLL; u++) {
-      float y[EPL];
-      const int64_t e0 = (v + u * stride) * EPL;
-#pragma unroll
-      for (int k = 0; k < EPL; k++) y[k] = op.apply(x[u][k], e0 + k);
-      store_vec<DTO, EPL>(out, e0, y);
-    }
-  }
-  for (; v < n_vec; v += stride) {
-    float x[EPL], y[EPL];
-    load_vec<DTI, EPL>(in, v * EPL, x);
-#pragma unroll
-    for (int k = 0; k < EPL; k++) y[k] = op.apply(x[k], v * EPL + k);
-    store_vec<DTO, EPL>(out, v * EPL, y);
-  }
-  // scalar tail (n % EPL elements)
-  const int64_t e = n_vec * EPL + tid;
-  if (e < n) store1<DTO>(out, e, op.apply(load1<DTI>(in, e), e));
-}
-
-// unaligned pointers: scalar accesses
-template <int DTI, int DTO, class OP>
-__global__ __launch_bounds__(kThreads) void ew_scalar_kernel(const void* __restrict__ in, void* __restrict__ out,
-                                                            int64_t n, OP op) {
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += stride)
-    store1<DTO>(out, e, op.apply(load1<DTI>(in, e), e));
-}
-
+// ------------------------------------------------------------------------------------------------- ops
+// (streaming skeleton, geometry and the channel walker: stream.hpp)
 template <int RND>
 struct FloatOp {
+  static constexpr bool kHeavy = true;  // ~15-25 VALU ops per element: stagger workgroups (stream.hpp)
   FloatFmt f;
-  __device__ __forceinline__ float apply(float x, int64_t e) const {
+  __device__ __forceinline__ void apply_one(float x, float& y, int64_t e) const {
     const bool stoch = (RND == kRuntimeRounding) && f.rounding == DMXQ_ROUND_STOCHASTIC;
-    return float_q1<RND>(x, f, stoch ? rnd_bits(f.seed, (uint64_t)e) : 0u);
+    y = float_q1<RND>(x, f, stoch ? rnd_bits(f.seed, (uint64_t)e) : 0u);
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
+#pragma unroll
+    for (int k = 0; k < N; k++) apply_one(x[k], y[k], e0 + k);
   }
 };
 
-// channel lookup for [outer, C, inner]: c = (e / inner) % C ; group = c / group_size
-struct ChannelMap {
-  int64_t C, inner, group_size;
-  __device__ __forceinline__ int64_t group(int64_t e) const { return ((e / inner) % C) / group_size; }
-};
+// How scale / zero_point are looked up for the N elements of one vector (chosen on the host, see pick_mode):
+//   kNone    no affine
+//   kTensor  one scale for everything (C == 1)
+//   kUniform inner % N == 0: the whole vector lies in ONE channel -> one (32-bit when possible) division pair
+//   kLast    inner == 1, group_size == 1, C % N == 0: channel = element index mod C, N consecutive scales
+//   kWalk    anything else: ChanIter carries per element
+enum ChanMode { kNone = 0, kTensor = 1, kUniform = 2, kLast = 3, kWalk = 4 };
 
-template <bool AFFINE>
+static inline int pick_mode(int64_t C, int64_t inner, int64_t group_size, int epl) {
+  if (C <= 1) return kTensor;
+  if (inner % epl == 0) return kUniform;
+  if (inner == 1 && group_size == 1 && C % epl == 0) return kLast;
+  return kWalk;
+}
+
+template <int MODE>
 struct FixedOp {
+  static constexpr bool kHeavy = true;
   FixedFmt f;
   ChannelMap cm;
   const float* scale;
   const int64_t* zp;
-  __device__ __forceinline__ float apply(float x, int64_t e) const {
-    float sc = 1.0f, z = 0.0f;
-    if (AFFINE) {
-      const int64_t g = cm.group(e);
-      sc = scale[g];
-      z = (float)zp[g];
-      x = x / sc + z;  // IEEE division, as torch CPU (cast.py:293)
-    }
+  __device__ __forceinline__ float q(float x, float sc, float z, int64_t e) const {
+    if (MODE != kNone) x = x / sc + z;  // IEEE division, as torch CPU (cast.py:293)
     const float r = (f.rounding == DMXQ_ROUND_STOCHASTIC) ? rnd_unit(f.seed, (uint64_t)e) : 0.5f;
-    float q = fixed_q1(x, f, r);
-    if (AFFINE) q = (q - z) * sc;
-    return q;
+    float v = fixed_q1(x, f, r);
+    if (MODE != kNone) v = (v - z) * sc;
+    return v;
+  }
+  __device__ __forceinline__ void apply_one(float x, float& y, int64_t e) const {
+    float sc = 1.0f, z = 0.0f;
+    if (MODE != kNone) {
+      ChanIter it;
+      it.start(cm, e);
+      sc = scale[it.g];
+      z = (float)zp[it.g];
+    }
+    y = q(x, sc, z, e);
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
+    if (MODE == kNone || MODE == kTensor || MODE == kUniform) {
+      float sc = 1.0f, z = 0.0f;
+      if (MODE == kTensor) { sc = scale[0]; z = (float)zp[0]; }
+      if (MODE == kUniform) {
+        ChanIter it;
+        it.start(cm, e0);
+        sc = scale[it.g];
+        z = (float)zp[it.g];
+      }
+#pragma unroll
+      for (int k = 0; k < N; k++) y[k] = q(x[k], sc, z, e0 + k);
+    } else if (MODE == kLast) {
+      const int64_t c0 = cm.small ? (int64_t)((uint32_t)e0 % (uint32_t)cm.C) : e0 % cm.C;
+#pragma unroll
+      for (int k = 0; k < N; k++) y[k] = q(x[k], scale[c0 + k], (float)zp[c0 + k], e0 + k);
+    } else {
+      ChanIter it;
+      it.start(cm, e0);
+      float sc = scale[it.g], z = (float)zp[it.g];
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+        y[k] = q(x[k], sc, z, e0 + k);
+        if (k + 1 < N && it.next(cm)) {  // group boundary inside the vector: reload
+          sc = scale[it.g];
+          z = (float)zp[it.g];
+        }
+      }
+    }
   }
 };
 
-template <bool DIVIDE>
+template <bool DIVIDE, int MODE>
 struct ScaleOp {
   ChannelMap cm;
   const float* scale;
-  __device__ __forceinline__ float apply(float x, int64_t e) const {
-    const float s = scale[cm.group(e)];
-    return DIVIDE ? x / s : x * s;
+  __device__ __forceinline__ void apply_one(float x, float& y, int64_t e) const {
+    ChanIter it;
+    it.start(cm, e);
+    const float s = scale[it.g];
+    y = DIVIDE ? x / s : x * s;
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
+    if (MODE == kTensor || MODE == kUniform) {
+      ChanIter it;
+      it.start(cm, e0);
+      const float s = scale[it.g];
+#pragma unroll
+      for (int k = 0; k < N; k++) y[k] = DIVIDE ? x[k] / s : x[k] * s;
+    } else if (MODE == kLast) {
+      const int64_t c0 = cm.small ? (int64_t)((uint32_t)e0 % (uint32_t)cm.C) : e0 % cm.C;
+#pragma unroll
+      for (int k = 0; k < N; k++) y[k] = DIVIDE ? x[k] / scale[c0 + k] : x[k] * scale[c0 + k];
+    } else {
+      ChanIter it;
+      it.start(cm, e0);
+      float s = scale[it.g];
+#pragma unroll
+      for (int k = 0; k < N; k++) {
+        y[k] = DIVIDE ? x[k] / s : x[k] * s;
+        if (k + 1 < N && it.next(cm)) s = scale[it.g];
+      }
+    }
   }
 };
 
-template <int DTI, int DTO, class OP>
-static int launch_ew(const void* in, void* out, int64_t n, const OP& op, hipStream_t s) {
-  constexpr int EPL = 16 / Elem<DTI>::bytes;
-  constexpr int UNROLL = 4;
-  if (aligned16(in) && aligned16(out)) {
-    const int grid = grid_for((n / EPL + UNROLL - 1) / UNROLL + 1);
-    hipLaunchKernelGGL((ew_vec_kernel<DTI, DTO, UNROLL, OP>), dim3(grid), dim3(kThreads), 0, s, in, out, n, op);
-  } else {
-    hipLaunchKernelGGL((ew_scalar_kernel<DTI, DTO, OP>), dim3(grid_for(n)), dim3(kThreads), 0, s, in, out, n, op);
+// torch.nn.functional.gelu, erf and tanh forms (approximator slot, see approx.hip)
+struct GeluOp {
+  static constexpr bool kHeavy = true;
+  int tanh_form;
+  __device__ __forceinline__ void apply_one(float x, float& y, int64_t) const {
+    if (tanh_form) {
+      const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+      y = 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));
+    } else {
+      y = 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+    }
   }
-  return launch_status();
-}
+  template <int N>
+  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
+#pragma unroll
+    for (int k = 0; k < N; k++) apply_one(x[k], y[k], e0 + k);
+  }
+};
 
-template <class OP>
-static int dispatch_dtypes(const void* in, void* out, int dti, int dto, int64_t n, const OP& op, hipStream_t s) {
-#define DMXQ_DT(I_, O_) \
-  if (dti == I_ && dto == O_) return launch_ew<I_, O_, OP>(in, out, n, op, s);
-  DMXQ_DT(DMXQ_BF16, DMXQ_BF16)
-  DMXQ_DT(DMXQ_F16, DMXQ_F16)
-  DMXQ_DT(DMXQ_F32, DMXQ_F32)
-  DMXQ_DT(DMXQ_BF16, DMXQ_F32)
-  DMXQ_DT(DMXQ_F16, DMXQ_F32)
-  DMXQ_DT(DMXQ_F32, DMXQ_BF16)
-  DMXQ_DT(DMXQ_F32, DMXQ_F16)
-#undef DMXQ_DT
-  return DMXQ_ERR_BAD_ARG;
+static inline ChannelMap make_channel_map(int64_t C, int64_t inner, int64_t group_size, int64_t n) {
+  return ChannelMap{C < 1 ? 1 : C, inner < 1 ? 1 : inner, group_size, n < (int64_t)1 << 31 ? 1 : 0};
 }
 
 }  // namespace dmxq
@@ -202,8 +242,8 @@ extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype
   if (!in || !out) return DMXQ_ERR_BAD_ARG;
   const FloatFmt f{man_bits, exp_bits, exp_bias, flush_subnormal ? 1 : 0, unsigned_abs ? 1 : 0, rounding, seed};
   hipStream_t s = (hipStream_t)stream;
-  if (rounding == DMXQ_ROUND_NEAREST) return dispatch_dtypes(in, out, dtype_in, dtype_out, n, FloatOp<DMXQ_ROUND_NEAREST>{f}, s);
-  return dispatch_dtypes(in, out, dtype_in, dtype_out, n, FloatOp<kRuntimeRounding>{f}, s);
+  if (rounding == DMXQ_ROUND_NEAREST) return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<DMXQ_ROUND_NEAREST>{f}, s);
+  return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<kRuntimeRounding>{f}, s);
 }
 
 extern "C" int dmxq_fixed_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t C,
@@ -222,10 +262,15 @@ extern "C" int dmxq_fixed_qdq(const void* in, void* out, int dtype_in, int dtype
   const float t_max = (float)(-(double)t_min - ldexp(1.0, sigma));
   if (symmetric) t_min = (float)((double)t_min + ldexp(1.0, sigma));
   const FixedFmt f{sigma, clamp ? 1 : 0, rounding, t_min, t_max, seed};
-  const ChannelMap cm{C, inner, group_size};
+  const ChannelMap cm = make_channel_map(C, inner, group_size, n);
   hipStream_t s = (hipStream_t)stream;
-  if (scale) return dispatch_dtypes(in, out, dtype_in, dtype_out, n, FixedOp<true>{f, cm, scale, zero_point}, s);
-  return dispatch_dtypes(in, out, dtype_in, dtype_out, n, FixedOp<false>{f, cm, nullptr, nullptr}, s);
+  if (!scale) return dispatch_stream(in, out, dtype_in, dtype_out, n, FixedOp<kNone>{f, cm, nullptr, nullptr}, s);
+  switch (pick_mode(C, inner, group_size, dtype_in == DMXQ_F32 ? 4 : 8)) {
+    case kTensor: return dispatch_stream(in, out, dtype_in, dtype_out, n, FixedOp<kTensor>{f, cm, scale, zero_point}, s);
+    case kUniform: return dispatch_stream(in, out, dtype_in, dtype_out, n, FixedOp<kUniform>{f, cm, scale, zero_point}, s);
+    case kLast: return dispatch_stream(in, out, dtype_in, dtype_out, n, FixedOp<kLast>{f, cm, scale, zero_point}, s);
+    default: return dispatch_stream(in, out, dtype_in, dtype_out, n, FixedOp<kWalk>{f, cm, scale, zero_point}, s);
+  }
 }
 
 extern "C" int dmxq_scale_channels(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t C,
@@ -234,10 +279,27 @@ extern "C" int dmxq_scale_channels(const void* in, void* out, int dtype_in, int 
   const int64_t n = outer * C * inner;
   if (n == 0) return DMXQ_OK;
   if (!in || !out || !scale) return DMXQ_ERR_BAD_ARG;
-  const ChannelMap cm{C, inner, 1};
+  const ChannelMap cm = make_channel_map(C, inner, 1, n);
   hipStream_t s = (hipStream_t)stream;
-  if (divide) return dispatch_dtypes(in, out, dtype_in, dtype_out, n, ScaleOp<true>{cm, scale}, s);
-  return dispatch_dtypes(in, out, dtype_in, dtype_out, n, ScaleOp<false>{cm, scale}, s);
+  const int mode = pick_mode(C, inner, 1, dtype_in == DMXQ_F32 ? 4 : 8);
+#define DMXQ_SCALE(D_, M_) return dispatch_stream(in, out, dtype_in, dtype_out, n, ScaleOp<D_, M_>{cm, scale}, s)
+  if (divide) {
+    if (mode == kTensor || mode == kUniform) DMXQ_SCALE(true, kUniform);
+    if (mode == kLast) DMXQ_SCALE(true, kLast);
+    DMXQ_SCALE(true, kWalk);
+  }
+  if (mode == kTensor || mode == kUniform) DMXQ_SCALE(false, kUniform);
+  if (mode == kLast) DMXQ_SCALE(false, kLast);
+  DMXQ_SCALE(false, kWalk);
+#undef DMXQ_SCALE
+}
+
+extern "C" int dmxq_gelu(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int tanh_form,
+                         void* stream) {
+  if (!valid_dtype(dtype_in) || !valid_dtype(dtype_out) || n < 0) return DMXQ_ERR_BAD_ARG;
+  if (n == 0) return DMXQ_OK;
+  if (!in || !out) return DMXQ_ERR_BAD_ARG;
+  return dispatch_stream(in, out, dtype_in, dtype_out, n, GeluOp{tanh_form}, (hipStream_t)stream);
 }
 
 extern "C" const char* dmxq_status_string(int status) {

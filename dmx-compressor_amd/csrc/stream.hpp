@@ -1,0 +1,160 @@
+// csrc/stream.hpp — the streaming skeleton shared by the per-element kernels (float / fixed / scale / gelu).
+//
+// Same memory schedule as the BFP rows kernel (bfp_rows.hpp, tuned in tools/tune_bfp): a workgroup owns a
+// CONTIGUOUS tile of THREADS*UNROLL 16-byte input vectors; all UNROLL non-temporal loads of a full tile are
+// issued back to back, then every vector is converted into registers, then all stores go out as one burst.
+// OP::apply_vec(x[EPL], y[EPL], e0) maps EPL consecutive elements (flat index e0..) to their outputs in fp32.
+#pragma once
+#include "common.hpp"
+
+namespace dmxq {
+
+template <int DTI, int DTO, int UNROLL, int THREADS, class OP>
+__global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict__ in, void* __restrict__ out,
+                                                        int64_t n, OP op) {
+  constexpr int EPL = 16 / Elem<DTI>::bytes;
+  constexpr int OVB = EPL * Elem<DTO>::bytes;
+  constexpr int64_t TILE = (int64_t)THREADS * UNROLL;
+  const int64_t n_vec = n / EPL;
+  const int64_t n_tiles = (n_vec + TILE - 1) / TILE;
+  const uint32_t lane_in = threadIdx.x * 16u, lane_out = threadIdx.x * (uint32_t)OVB;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const char* src = (const char*)in + tile * (TILE * 16);
+    char* dst = (char*)out + tile * (TILE * OVB);
+    const int64_t v0 = tile * TILE + threadIdx.x;
+    if ((tile + 1) * TILE <= n_vec) {
+      u32x4 raw[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) raw[u] = load_raw16<true>(src + u * (THREADS * 16), lane_in);
+      __builtin_amdgcn_sched_barrier(0);
+      OutVec<DTO, EPL> o[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) {
+        float x[EPL], y[EPL];
+        widen<DTI, EPL>(raw[u], x);
+        op.apply_vec(x, y, (v0 + (int64_t)u * THREADS) * EPL);
+        o[u] = pack_vec<DTO, EPL>(y);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) store_out<DTO, EPL, true>(dst + u * (THREADS * OVB) + lane_out, o[u]);
+    } else {
+      for (int u = 0; u < UNROLL; u++) {
+        const int64_t vi = v0 + (int64_t)u * THREADS;
+        if (vi < n_vec) {
+          const u32x4 raw = load_raw16<true>(src + u * (THREADS * 16), lane_in);
+          float x[EPL], y[EPL];
+          widen<DTI, EPL>(raw, x);
+          op.apply_vec(x, y, vi * EPL);
+          store_out<DTO, EPL, true>(dst + u * (THREADS * OVB) + lane_out, pack_vec<DTO, EPL>(y));
+        }
+      }
+    }
+  }
+  // scalar tail: the n % EPL elements after the last whole vector
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n_vec * EPL)) {
+    const int64_t e = n_vec * EPL + threadIdx.x;
+    float x1[1] = {load1<DTI>(in, e)}, y1[1];
+    op.apply_one(x1[0], y1[0], e);
+    store1<DTO>(out, e, y1[0]);
+  }
+}
+
+// pointers not 16-byte aligned: scalar accesses
+template <int DTI, int DTO, class OP>
+__global__ __launch_bounds__(kThreads) void stream_scalar_kernel(const void* __restrict__ in, void* __restrict__ out,
+                                                                int64_t n, OP op) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += stride) {
+    float y;
+    op.apply_one(load1<DTI>(in, e), y, e);
+    store1<DTO>(out, e, y);
+  }
+}
+
+// geometry as in bfp.hip: 512 x 16 tiles for big tensors (8 when the output vector is 32 B), 256 x 4, 256 x 1.
+// The big tile puts ONE workgroup on each CU, all in the same phase (load / compute / store): right for ops whose
+// arithmetic is a small fraction of the memory time.  VALU-heavy ops (OP::kHeavy: erf, divisions) use 256 x 4
+// tiles instead, so that several workgroups per CU interleave their compute with each other's memory phases.
+template <class OP, class = void> struct OpHeavy { static constexpr bool value = false; };
+template <class OP> struct OpHeavy<OP, decltype((void)OP::kHeavy)> { static constexpr bool value = OP::kHeavy; };
+
+template <int DTI, int DTO, class OP>
+static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hipStream_t s) {
+  constexpr int EPL = 16 / Elem<DTI>::bytes;
+  constexpr int UB = (Elem<DTO>::bytes > Elem<DTI>::bytes) ? 8 : 16;
+  if (!aligned16(in) || !aligned16(out)) {
+    hipLaunchKernelGGL((stream_scalar_kernel<DTI, DTO, OP>), dim3(grid_for(n)), dim3(kThreads), 0, s, in, out, n, op);
+    return launch_status();
+  }
+  const int64_t n_vec = n / EPL;
+#define DMXQ_STREAM(T_, U_)                                                                                       \
+  do {                                                                                                            \
+    int64_t tiles = (n_vec + (int64_t)(T_) * (U_) - 1) / ((int64_t)(T_) * (U_));                                  \
+    if (tiles < 1) tiles = 1;                                                                                     \
+    if (tiles > (1 << 20)) tiles = 1 << 20;                                                                       \
+    hipLaunchKernelGGL((stream_kernel<DTI, DTO, U_, T_, OP>), dim3((unsigned)tiles), dim3(T_), 0, s, in, out, n, op); \
+  } while (0)
+  if (!OpHeavy<OP>::value && n_vec >= (int64_t)256 * 512 * UB) DMXQ_STREAM(512, UB);
+  else if (n_vec >= (int64_t)512 * 256 * 4) DMXQ_STREAM(256, 4);
+  else DMXQ_STREAM(256, 1);
+#undef DMXQ_STREAM
+  return launch_status();
+}
+
+template <class OP>
+static int dispatch_stream(const void* in, void* out, int dti, int dto, int64_t n, const OP& op, hipStream_t s) {
+#define DMXQ_DT(I_, O_) \
+  if (dti == I_ && dto == O_) return launch_stream<I_, O_, OP>(in, out, n, op, s);
+  DMXQ_DT(DMXQ_BF16, DMXQ_BF16)
+  DMXQ_DT(DMXQ_F16, DMXQ_F16)
+  DMXQ_DT(DMXQ_F32, DMXQ_F32)
+  DMXQ_DT(DMXQ_BF16, DMXQ_F32)
+  DMXQ_DT(DMXQ_F16, DMXQ_F32)
+  DMXQ_DT(DMXQ_F32, DMXQ_BF16)
+  DMXQ_DT(DMXQ_F32, DMXQ_F16)
+#undef DMXQ_DT
+  return DMXQ_ERR_BAD_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Channel / group walker for tensors viewed as [outer, C, inner]: group(e) = ((e / inner) % C) / group_size.
+// One division per VECTOR (32-bit when the tensor is small enough), then incremental carries per element.
+struct ChannelMap {
+  int64_t C, inner, group_size;
+  int small;  // 1: n < 2^31, 32-bit index arithmetic
+};
+
+struct ChanIter {
+  int64_t c, i, g, r;
+  __device__ __forceinline__ void start(const ChannelMap& m, int64_t e) {
+    if (m.small) {
+      const uint32_t q = (uint32_t)e / (uint32_t)m.inner;
+      i = (uint32_t)e - q * (uint32_t)m.inner;
+      c = q % (uint32_t)m.C;
+      g = (uint32_t)c / (uint32_t)m.group_size;
+      r = (uint32_t)c - (uint32_t)g * (uint32_t)m.group_size;
+    } else {
+      const int64_t q = e / m.inner;
+      i = e - q * m.inner;
+      c = q % m.C;
+      g = c / m.group_size;
+      r = c - g * m.group_size;
+    }
+  }
+  // advance to the next element; returns true when the group index changed
+  __device__ __forceinline__ bool next(const ChannelMap& m) {
+    if (++i < m.inner) return false;
+    i = 0;
+    if (++c == m.C) {
+      c = 0; r = 0;
+      const bool ch = g != 0;
+      g = 0;
+      return ch;
+    }
+    if (++r == m.group_size) { r = 0; ++g; return true; }
+    return false;
+  }
+};
+
+}  // namespace dmxq

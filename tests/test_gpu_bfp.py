@@ -65,6 +65,25 @@ def test_block_dim_layouts(dmx, cuda, oracle, dim, B):
         assert _run(dmx, cuda, oracle, x.float(), 6, B, dim=dim, sym=False) == 0, (shape, dim, B)
 
 
+@pytest.mark.parametrize("B", [8, 16, 32, 64, 128])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_column_block_kernel(dmx, cuda, oracle, B, dtype):
+    """Blocks along a non-contiguous dim with inner % (16 B) == 0: the register-tiled kernel of bfp_cols.hip
+    (row split across half / quarter waves for B = 64 / 128), incl. ragged last block and column tails."""
+    for shape, dim in (((3, 128, 64), 1), ((2, 200, 520), -2), ((1, 64, 8), 1), ((260, 1032), 0), ((2, 3, 96, 40), 2)):
+        x = make("mixed", shape, seed=B + len(shape), dtype=dtype, block=8)
+        assert _run(dmx, cuda, oracle, x, 8, B, dim=dim) == 0, (shape, dim)
+        xa = make("mixed_nd", shape, seed=B, dtype=dtype, block=8)
+        assert _run(dmx, cuda, oracle, xa, 6, B, dim=dim, sym=False) == 0, (shape, dim)
+    x = make("heavy", (2, 128, 64), seed=1, dtype=dtype)
+    for rounding in ("down", "up", "stochastic"):
+        assert _run(dmx, cuda, oracle, x, 8, B, dim=1, rounding=rounding, seed=77) == 0, rounding
+    assert _run(dmx, cuda, oracle, x, 22, B, dim=1) == 0                            # wl > 20: literal path
+    if dtype != torch.float32:
+        assert _run(dmx, cuda, oracle, x, 8, B, dim=1, out_dtype=torch.float32) == 0
+        assert _run(dmx, cuda, oracle, x, 16, B, dim=1) == 0                         # double-rounding form on 16-bit input
+
+
 @pytest.mark.parametrize("rounding", ["down", "up", "stochastic"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_other_rounding_modes(dmx, cuda, oracle, rounding, dtype):

@@ -100,6 +100,49 @@ def test_fixed_affine_per_tensor_channel_group(dmx, cuda, oracle, dtype):
             assert bits_equal(got, want) == 0, (ax, gs)
 
 
+def test_fixed_rounding_fp32_only_form_matches_the_double_step(dmx, cuda, oracle):
+    """The kernel evaluates nearbyint((double)(float)(a + 0.5f) - 0.5) without f64 instructions; check the regions
+    where the argument is not representable in fp32: |a| around 2^22 .. 2^25, odd/even integers, halves, +-inf, nan."""
+    g = torch.Generator().manual_seed(0)
+    parts = [torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, 0.5 + 2.0 ** -24, 0.49999997, 4194303.5, 4194304.5, 8388607.0, 8388607.5,
+                           8388608.0, 8388609.0, 8388610.0, 16777215.0, 16777216.0, 16777218.0, 3e9, -3e9, float("inf"),
+                           float("-inf"), float("nan"), 1e30, -1e30])]
+    for lo, hi in ((21, 22), (22, 23), (23, 24), (24, 25), (0, 3)):
+        m = torch.rand(20000, generator=g) * (2.0 ** hi - 2.0 ** lo) + 2.0 ** lo
+        parts += [m, -m, torch.floor(m), -torch.floor(m), torch.floor(m) + 0.5, -(torch.floor(m) + 0.5)]
+    x = torch.cat(parts)
+    for wl, fl, clamp, sym in ((24, 0, False, False), (24, 0, True, True), (16, -8, False, True), (20, 4, False, False), (8, -20, False, True)):
+        for rounding in ("nearest", "stochastic"):
+            got = dmx.ops.fixed_qdq(x.to(cuda), wl, fl, clamp, sym, rounding, seed=5)
+            want = oracle.fixed_point_cast(x, wl, fl, clamp, sym, rounding, seed=5)
+            both_nan = torch.isnan(got.cpu()) & torch.isnan(want)
+            assert int(((got.cpu().view(torch.int32) != want.view(torch.int32)) & ~both_nan).sum()) == 0, (wl, fl, rounding)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fixed_affine_scale_lookup_modes(dmx, cuda, oracle, dtype):
+    """One case per scale-lookup mode of the kernel (elementwise.hip ChanMode): vector inside one channel
+    (weights, ch_axis 0), N consecutive channels (per-channel along the last dim), and the carrying walker."""
+    g = torch.Generator().manual_seed(2)
+    for shape, ax, gs in (((48, 64), 0, None), ((48, 64), 0, 16), ((48, 64), 0, 7), ((32, 64), -1, None), ((6, 32, 64), -1, None),
+                          ((6, 32, 64), 1, None), ((6, 32, 64), 1, 5), ((5, 24, 12), 1, 4), ((33, 40), -1, 8), ((9, 7, 3), 2, None)):
+        x = make("normal", shape, seed=len(shape) + (gs or 0), dtype=dtype)
+        C = shape[ax]
+        G = -(-C // (gs or 1))
+        sc = torch.rand(G, generator=g) * 0.05 + 1e-3
+        zp = torch.randint(-5, 6, (G,), generator=g)
+        got = dmx.ops.fixed_qdq(x.to(cuda), 8, 0, True, False, scale=sc, zero_point=zp, ch_axis=ax, group_size=gs)
+        want = oracle.fixed_point_affine_cast(x, 8, 0, True, False, sc, zp, ch_axis=ax, group_size=gs).to(dtype)
+        assert bits_equal(got, want) == 0, (shape, ax, gs)
+        s = torch.rand(C, generator=g) + 0.5
+        sh = [1] * len(shape)
+        sh[ax] = C
+        got = dmx.ops.scale_channels(x.to(cuda), s, ax, divide=True)
+        assert bits_equal(got, (x.float() / s.view(sh)).to(dtype)) == 0, (shape, ax)
+        got = dmx.ops.scale_channels(x.to(cuda), s, ax, divide=False)
+        assert bits_equal(got, (x.float() * s.view(sh)).to(dtype)) == 0, (shape, ax)
+
+
 def test_reference_known_answers_group_quant(dmx, cuda):
     """tests/test_group_quant.py:49-63 of the reference: INT4, group_size 2 along dim 0, MinMax symmetric."""
     x = torch.tensor([[0, 1], [3, 7], [5.1, 8], [10, 14], [0.1, 0.7]])

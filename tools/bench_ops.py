@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""tools/bench_ops.py — per-op HBM roofline table for every libdmxq entry point (GPU box).
+
+For each op: direct C-ABI launches (ctypes, preallocated outputs) on one stream, rotating over enough buffer
+sets to exceed the 256 MiB Infinity Cache, HIP-event timing; reports us/launch, algorithmic GB/s, % of 8 TB/s.
+    python tools/bench_ops.py [--rows 4096 --cols 4096] [--json out.json]
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import dmx_compressor_amd as d  # noqa: E402
+from dmx_compressor_amd import _lib  # noqa: E402
+
+PEAK = 8.0e12
+DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+vp = ctypes.c_void_p
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=4096)
+    ap.add_argument("--cols", type=int, default=4096)
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    R, C = args.rows, args.cols
+    n = R * C
+    stream = torch.cuda.Stream()
+    sp = vp(stream.cuda_stream)
+    results = []
+
+    def bufs(dtype, count, shape=(R, C), gen=None):
+        out = []
+        for i in range(count):
+            g = torch.Generator(device=dev).manual_seed(i)
+            t = torch.randn(*shape, generator=g, device=dev) * torch.exp(2 * torch.randn(*shape, generator=g, device=dev))
+            out.append(t.to(dtype))
+        return out
+
+    def run(name, launch, nbuf, bytes_per_launch, check=None):
+        with torch.cuda.stream(stream):
+            for i in range(20):
+                launch(i % nbuf)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for i in range(args.iters):
+                launch(i % nbuf)
+            e1.record(stream)
+            torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        gbs = bytes_per_launch / (us * 1e-6) / 1e9
+        results.append({"op": name, "us": round(us, 2), "GB/s": round(gbs, 1), "frac": round(gbs * 1e9 / PEAK, 4),
+                        "bytes": bytes_per_launch})
+        print(f"{name:58s} {us:9.2f} us {gbs:9.1f} GB/s {100 * gbs * 1e9 / PEAK:6.1f}%", flush=True)
+
+    def nb(per_set_bytes):  # buffer sets needed to exceed 512 MiB total
+        return max(2, min(24, math.ceil(512 * 2 ** 20 / per_set_bytes)))
+
+    # ---------------------------------------------------------------- BFP, rows
+    for din, dout in ((torch.bfloat16, torch.bfloat16), (torch.float16, torch.float16), (torch.float32, torch.float32),
+                      (torch.bfloat16, torch.float32), (torch.float32, torch.bfloat16)):
+        byt = n * (din.itemsize + dout.itemsize)
+        k = nb(byt)
+        xs = bufs(din, k)
+        ys = [torch.empty(R, C, dtype=dout, device=dev) for _ in range(k)]
+        for B, wl, sym, rnd in ((16, 8, 1, 2), (64, 8, 1, 2), (128, 8, 1, 2), (64, 8, 0, 2), (16, 16, 1, 2), (16, 8, 1, 3), (64, 8, 1, 1)):
+            if din != torch.bfloat16 and (B, wl, sym, rnd) not in ((16, 8, 1, 2), (64, 8, 1, 2)):
+                continue
+            run(f"bfp_qdq {str(din)[6:]}->{str(dout)[6:]} B={B} wl={wl} {'sym' if sym else 'asym'} rnd={rnd}",
+                lambda i: L.dmxq_bfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), DT[din], DT[dout], R, C, 1, B, wl, rnd, sym, 7, sp),
+                k, byt)
+        del xs, ys
+    # ---------------------------------------------------------------- BFP, column blocks and ragged
+    k = nb(n * 4)
+    xs = bufs(torch.bfloat16, k)
+    ys = [torch.empty_like(x) for x in xs]
+    run("bfp_qdq bf16 block_dim=-2 B=64 ([R,C] blocks along R)",
+        lambda i: L.dmxq_bfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, 1, R, C, 64, 8, 2, 1, 0, sp), k, n * 4)
+    run("bfp_qdq bf16 block_dim=1 of [R/64,64,C] B=16",
+        lambda i: L.dmxq_bfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, R // 64, 64, C, 16, 8, 2, 1, 0, sp), k, n * 4)
+    run("bfp_qdq bf16 rows ragged L=C-8 B=64 (generic path)",
+        lambda i: L.dmxq_bfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, R, C - 8, 1, 64, 8, 2, 1, 0, sp), k, R * (C - 8) * 4)
+    # ---------------------------------------------------------------- float / fixed / scale / gelu
+    run("float_qdq bf16 FP16(FN) [BASIC activation cast]",
+        lambda i: L.dmxq_float_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, n, 10, 5, 15, 1, 0, 2, 0, sp), k, n * 4)
+    run("float_qdq bf16 E4M3 (AFLOAT8)",
+        lambda i: L.dmxq_float_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, n, 3, 4, 7, 0, 0, 2, 0, sp), k, n * 4)
+    run("fixed_qdq bf16 INT8 no affine",
+        lambda i: L.dmxq_fixed_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, 1, 1, n, 8, 0, 1, 1, 2, None, None, 1, 0, sp), k, n * 4)
+    G = R // 128
+    sc = (torch.rand(G, device=dev) * 0.05 + 0.01)
+    zp = torch.zeros(G, dtype=torch.int64, device=dev)
+    run("fixed_qdq bf16 INT8 group_size=128 along dim0 (opt-125m style)",
+        lambda i: L.dmxq_fixed_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, 1, R, C, 8, 0, 1, 1, 2, vp(sc.data_ptr()), vp(zp.data_ptr()), 128, 0, sp), k, n * 4)
+    scc = (torch.rand(C, device=dev) + 0.5)
+    zpc = torch.zeros(C, dtype=torch.int64, device=dev)
+    run("fixed_qdq bf16 INT8 per-channel along last dim",
+        lambda i: L.dmxq_fixed_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, R, C, 1, 8, 0, 1, 1, 2, vp(scc.data_ptr()), vp(zpc.data_ptr()), 1, 0, sp), k, n * 4)
+    run("scale_channels bf16 divide along last dim (SmoothQuant input)",
+        lambda i: L.dmxq_scale_channels(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, R, C, 1, vp(scc.data_ptr()), 1, sp), k, n * 4)
+    run("gelu bf16 (erf)", lambda i: L.dmxq_gelu(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, n, 0, sp), k, n * 4)
+    # ---------------------------------------------------------------- N:M
+    ss = bufs(torch.float32, max(2, k // 2))
+    k2 = len(ss)
+    yf = [torch.empty(R, C, dtype=torch.float32, device=dev) for _ in range(k2)]
+    for K_, M_ in ((2, 4), (4, 8)):
+        run(f"nm_mask {K_}:{M_} fp32 score -> fp32 mask",
+            lambda i: L.dmxq_nm_mask(vp(ss[i].data_ptr()), _lib.F32, None, 0, vp(yf[i].data_ptr()), _lib.F32, None, 0, R, C, 1, K_, M_, sp), k2, n * 8)
+        run(f"nm_sparsify {K_}:{M_} fp32 score, bf16 x -> bf16 y (fused apply)",
+            lambda i: L.dmxq_nm_mask(vp(ss[i].data_ptr()), _lib.F32, vp(xs[i].data_ptr()), _lib.BF16, None, 0, vp(ys[i].data_ptr()), _lib.BF16, R, C, 1, K_, M_, sp), k2, n * 8)
+    run("nm_sparsify 2:4 bf16 score(|w|) -> bf16 y",
+        lambda i: L.dmxq_nm_mask(vp(xs[i].data_ptr()), _lib.BF16, vp(xs[i].data_ptr()), _lib.BF16, None, 0, vp(ys[i].data_ptr()), _lib.BF16, R, C, 1, 2, 4, sp), k, n * 4)
+    # ---------------------------------------------------------------- reductions
+    mn = torch.empty(R, device=dev)
+    mx = torch.empty(R, device=dev)
+    run("group_minmax bf16 group_size=128 along dim0",
+        lambda i: L.dmxq_group_minmax(vp(xs[i].data_ptr()), _lib.BF16, 1, R, C, 128, vp(mn.data_ptr()), vp(mx.data_ptr()), sp), k, n * 2)
+    run("group_minmax bf16 per-tensor",
+        lambda i: L.dmxq_group_minmax(vp(xs[i].data_ptr()), _lib.BF16, 1, 1, n, 1, vp(mn.data_ptr()), vp(mx.data_ptr()), sp), k, n * 2)
+    ma = torch.empty(C, device=dev)
+    run("channel_maxabs bf16 along last dim (reduce over rows)",
+        lambda i: L.dmxq_channel_maxabs(vp(xs[i].data_ptr()), _lib.BF16, R, C, 1, vp(ma.data_ptr()), sp), k, n * 2)
+    # ---------------------------------------------------------------- row ops (Whisper shapes)
+    rows, cols = 12 * 1500, 1500
+    xr = [torch.randn(rows, cols, device=dev).to(torch.bfloat16) for _ in range(10)]
+    yr = [torch.empty_like(t) for t in xr]
+    run("softmax bf16 rows of 1500 (12 heads x 1500)",
+        lambda i: L.dmxq_softmax(vp(xr[i].data_ptr()), vp(yr[i].data_ptr()), _lib.BF16, _lib.BF16, rows, cols, ctypes.c_float(-math.inf), sp), 10, rows * cols * 4)
+    rows2, cols2 = 16 * 1500, 768
+    xl = [torch.randn(rows2, cols2, device=dev).to(torch.bfloat16) for _ in range(14)]
+    yl = [torch.empty_like(t) for t in xl]
+    w = torch.ones(cols2, device=dev, dtype=torch.bfloat16)
+    run("layernorm bf16 rows of 768",
+        lambda i: L.dmxq_layernorm(vp(xl[i].data_ptr()), vp(yl[i].data_ptr()), _lib.BF16, _lib.BF16, rows2, cols2, vp(w.data_ptr()), vp(w.data_ptr()), _lib.BF16, ctypes.c_float(1e-5), sp), 14, rows2 * cols2 * 4)
+    if args.json:
+        json.dump(results, open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
