@@ -11,7 +11,11 @@ from ._lib import DmxqError, LIB_PATH
 from .cast import CastTo, CastToDict, CastToFormat
 from .format import (ROUNDING_MODE, BlockFloatingPoint, FixedPoint, FloatingPoint, Format, MXFP, MXINT, Same,
                      ScaledBlockFloatingPoint)
+from . import nn
+from .approximate import Approximate, ApproximationFunction, NoApproximation, TorchFunctionApproximation
+from .nn import DmxConfigRule, DmxModule, configure_model
 from .observer import DummyObserver, HistogramObserver, MinMaxObserver
+from .smoothquant import ActivationWeightSmoothQuant
 from .sparse import Bernoulli, BlockTopK, Dense, Sparseness, Sparsify, TopK
 
 __version__ = "0.1.0"
@@ -52,3 +56,51 @@ sparseness = SimpleNamespace(**{
     f"BTK8_{k}_{tag}": Sparseness.from_shorthand(f"BTOPK{{{k}:8,{dim}}}(U)")
     for k in (4, 2) for tag, dim in (("LD", -1), ("FD", 1))
 })
+
+
+# default approximation functions (reference __init__.py:108-139).  The reference's defaults name the private "vsimd"
+# algorithm and collapse to NONE when it is absent — the state of the public repository, mirrored here.
+default_approx = SimpleNamespace(**{k: ApproximationFunction.from_shorthand("NONE") for k in (
+    "RELU", "RELU6", "SILU", "SOFTMAX", "GELU", "QUICK_GELU", "TANH", "BATCH_NORM_2D", "LAYER_NORM", "RMS_NORM",
+    "GROUP_NORM", "EXP", "APPLY_LLAMA_ROPE", "NONE")})
+
+
+def _rule_sets():
+    """config_rules.{BASELINE, BASIC, FP8, SBFP_WEIGHT_STORAGE} (reference __init__.py:142-483) for the module types of
+    `dmx_compressor_amd.nn`.  Each row: module types -> (input formats, weight, bias, output formats)."""
+    f = format
+    S, F16, B64 = f.SAME, f.FLOAT16, f.BFP16_64
+    conv_like = (nn.Conv1d, nn.Conv2d)
+    act_like = (nn.Softmax, nn.LayerNorm, nn.GELU, nn.ReLU)
+    pools = (nn.MaxPool2d, nn.AvgPool2d)
+
+    def wb(inp, w, b, out):
+        return dict(input_formats=[inp], weight_format=w, bias_format=b, output_formats=[out])
+
+    def io(n_in, inp, out, approx=None):
+        d = dict(input_formats=[inp] * n_in, output_formats=[out])
+        if approx is not None:
+            d["approximation_function"] = approx
+        return d
+
+    def build(lin, mm_in, elt):
+        return [
+            DmxConfigRule(module_types=(nn.Linear,), module_config=wb(*lin)),
+            DmxConfigRule(module_types=conv_like, module_config=wb(*lin)),
+            DmxConfigRule(module_types=(nn.ResAdd,), module_config=io(2, elt, elt)),
+            DmxConfigRule(module_types=(nn.ActActMatMul,), module_config=io(2, mm_in, elt)),
+            DmxConfigRule(module_types=(nn.Embedding,), module_config=dict(output_formats=[elt])),
+            DmxConfigRule(module_types=pools, module_config=io(1, elt, elt)),
+            DmxConfigRule(module_types=act_like, module_config=io(1, elt, elt, default_approx.NONE)),
+        ]
+
+    return SimpleNamespace(
+        BASELINE=build((S, S, S, S), S, S),
+        BASIC=build((B64, B64, f.BFP32_1, F16), B64, F16),
+        FP8=build((f.AFLOAT8, f.AFLOAT8, f.FLOAT32, F16), f.AFLOAT8, F16),
+        SBFP_WEIGHT_STORAGE=[DmxConfigRule(module_types=(nn.Linear,) + conv_like,
+                                           module_config=dict(weight_storage_format=f.SBFP12_16))],
+    )
+
+
+config_rules = _rule_sets()

@@ -1,0 +1,115 @@
+"""Approximator slot — mirror of the reference's `functional/approximate.py` containers.
+
+`FUNC[algorithm]{wrapper_kwargs}(extra_kwargs)` shorthands are parsed like the reference
+(approximate.py:128-132).  The reference's only algorithm is "vsimd", a private package that is absent from the
+public repository, where every default therefore collapses to NONE.  This mirror registers ONE algorithm,
+"dmxq": the exact torch.nn.functional contract evaluated by libdmxq's HIP kernels (GELU / SOFTMAX / LAYER_NORM).
+Approximation arithmetic itself is parity-unpinned and is not invented here.
+"""
+import re
+from typing import Any, Dict, Union
+
+import torch
+
+from . import ops
+
+__all__ = ["ApproximationFunction", "NoApproximation", "TorchFunctionApproximation", "Approximate"]
+
+_FUNCS = ("GELU", "SILU", "RMS_NORM", "LAYER_NORM", "SOFTMAX", "EXP", "QUICK_GELU", "APPLY_LLAMA_ROPE")
+
+
+def _parse_kwargs(s: str) -> Dict[str, Any]:
+    out = {}
+    for item in filter(None, (t.strip() for t in s.split(","))):
+        k, v = item.split("=")
+        try:
+            out[k.strip()] = eval(v, {"__builtins__": {}}, {"True": True, "False": False, "None": None})
+        except Exception:
+            out[k.strip()] = v.strip()
+    return out
+
+
+def _kwargs_str(d: Dict[str, Any]) -> str:
+    return ",".join(f"{k}={v}" for k, v in d.items())
+
+
+class ApproximationFunction:
+    def execute(self, *args, **kwargs):
+        raise NotImplementedError
+
+    @staticmethod
+    def from_shorthand(sh: str):
+        if isinstance(sh, ApproximationFunction):
+            return sh
+        if sh.startswith("NONE"):
+            return NoApproximation()
+        if sh.startswith(_FUNCS):
+            return TorchFunctionApproximation.from_shorthand(sh)
+        raise ValueError(f"unrecognized approximation function shorthand: {sh}")
+
+
+class NoApproximation(ApproximationFunction):
+    wrapper_params: Dict[str, Any] = {}
+
+    def execute(self, *args, **kwargs):
+        raise RuntimeError("NoApproximation is not supposed to be executed")
+
+    def __str__(self):
+        return "Dummy approximation function: no approximation"
+
+    def __repr__(self):
+        return "NONE"
+
+
+class TorchFunctionApproximation(ApproximationFunction):
+    def __init__(self, func_id: str, algorithm: str = "dmxq", wrapper_params=None, extra_params=None):
+        self.func_id, self.algorithm = func_id, algorithm
+        self.wrapper_params, self.extra_params = dict(wrapper_params or {}), dict(extra_params or {})
+
+    def execute(self, *args, **kwargs):
+        if self.algorithm != "dmxq":
+            raise NotImplementedError(
+                f"approximation algorithm {self.algorithm!r}: only 'dmxq' (exact function on the HIP kernels) exists here; "
+                "the reference's 'vsimd' arithmetic lives in a private package (parity unpinned)")
+        kw = {**kwargs, **self.extra_params}
+        if self.func_id == "GELU":
+            return ops.gelu(args[0], approximate=kw.get("approximate", "none"))
+        if self.func_id == "SOFTMAX":
+            return ops.softmax(args[0], dim=kw.get("dim", -1))
+        if self.func_id == "LAYER_NORM":
+            x, normalized_shape = args[0], args[1]
+            w = args[2] if len(args) > 2 else kw.get("weight")
+            b = args[3] if len(args) > 3 else kw.get("bias")
+            eps = args[4] if len(args) > 4 else kw.get("eps", 1e-5)
+            return ops.layernorm(x, normalized_shape, w, b, eps)
+        raise NotImplementedError(f"{self.func_id}: no HIP kernel in the accelerated path")
+
+    @classmethod
+    def from_shorthand(cls, sh: str):
+        m = re.fullmatch(r"(\w+)\[(\w+)\]\{(.*)\}\((.*)\)", sh)
+        if m is None:
+            raise ValueError(f"unrecognized approximation function shorthand: {sh}")
+        return cls(m[1], m[2], _parse_kwargs(m[3]), _parse_kwargs(m[4]))
+
+    def __str__(self):
+        return f"Approximated version of {self.func_id}: algorithm = {self.algorithm}, with extra_params = {self.extra_params}"
+
+    def __repr__(self):
+        return f"{self.func_id}[{self.algorithm}]{{{_kwargs_str(self.wrapper_params)}}}({_kwargs_str(self.extra_params)})"
+
+
+class Approximate(torch.nn.Module):
+    """approximation operator container (approximate.py:229-247)"""
+
+    def __init__(self, function=None):
+        super().__init__()
+        self.set_function(function or NoApproximation())
+
+    def set_function(self, function: Union[str, ApproximationFunction]) -> None:
+        self.function = ApproximationFunction.from_shorthand(function)
+
+    def forward(self, input, *args, **kwargs):
+        return self.function.execute(input, *args, **kwargs)
+
+    def extra_repr(self):
+        return f"function = {self.function!r}"

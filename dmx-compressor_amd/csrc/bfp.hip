@@ -134,6 +134,9 @@ static int dispatch_mode(const void* in, void* out, int64_t outer, int64_t L, in
 extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int man_bits,
                               int exp_bits, int exp_bias, int flush_subnormal, int unsigned_abs, int rounding,
                               uint64_t seed, void* stream);
+// bfp_ragged.hip: LDS-staged kernel for ragged / unaligned rows; DMXQ_ERR_UNSUPPORTED = not applicable
+extern "C" int dmxq_internal_bfp_ragged(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t L,
+                                        int64_t B, int wl, int rounding, int symmetric, uint64_t seed, void* stream);
 // bfp_cols.hip: register-tiled kernel for blocks along a non-contiguous dimension; DMXQ_ERR_UNSUPPORTED = not applicable
 extern "C" int dmxq_internal_bfp_cols(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L,
                                       int64_t inner, int64_t B, int wl, int rounding, int symmetric, uint64_t seed,
@@ -151,6 +154,17 @@ extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_o
   if (block_size == 1)  // numerical/format.py:312-320: BFP with block size 1 borrows float_quantize
     return dmxq_float_qdq(in, out, dtype_in, dtype_out, n, precision - 2, 8, 127, 0, 0, rounding, seed, stream);
   if (precision > 22) return DMXQ_ERR_UNSUPPORTED;  // reference shifts by a negative count (UB) beyond this
+  if (inner == 1) {
+    // flat-stream kernel (launch_bfp) when rows are whole blocks and 16-byte aligned; otherwise LDS re-alignment
+    const int epl = dtype_in == DMXQ_F32 ? 4 : 8;
+    const bool pow2 = (block_size & (block_size - 1)) == 0;
+    const bool rows_ok = L % block_size == 0 && pow2 && block_size >= epl && block_size <= 64 * epl && aligned16(in) && aligned16(out);
+    if (!rows_ok) {
+      const int rc = dmxq_internal_bfp_ragged(in, out, dtype_in, dtype_out, outer, L, block_size, precision, rounding,
+                                              symmetric, seed, stream);
+      if (rc != DMXQ_ERR_UNSUPPORTED) return rc;
+    }
+  }
   if (inner > 1) {
     const int rc = dmxq_internal_bfp_cols(in, out, dtype_in, dtype_out, outer, L, inner, block_size, precision, rounding,
                                           symmetric, seed, stream);

@@ -64,6 +64,108 @@ __global__ __launch_bounds__(kThreads) void nm_mask_kernel(NmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Vectorised path: inner == 1 (groups along the contiguous dim), M in {2,4,8,16}, 16-byte aligned streams.
+// A lane owns U = 8 (M <= 8) or 16 consecutive elements = U/M whole groups, moved with 16-byte accesses
+// (one per 16-bit stream, two or four per fp32 stream); UNROLL units per lane are loaded before the ranking.
+template <int U>
+__device__ __forceinline__ void load_elems(const void* p, int dt, int64_t e0, float (&v)[U]) {
+  if (dt == DMXQ_F32) {
+#pragma unroll
+    for (int k = 0; k < U; k += 4) {
+      const f32x4 t = *(const f32x4*)((const float*)p + e0 + k);
+      v[k] = t.x; v[k + 1] = t.y; v[k + 2] = t.z; v[k + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < U; k += 8) {
+      const u32x4 t = *(const u32x4*)((const uint16_t*)p + e0 + k);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (dt == DMXQ_BF16) {
+          v[k + 2 * j] = u2f(t[j] << 16);
+          v[k + 2 * j + 1] = u2f(t[j] & 0xFFFF0000u);
+        } else {
+          v[k + 2 * j] = half_lo(t[j]);
+          v[k + 2 * j + 1] = half_hi(t[j]);
+        }
+      }
+    }
+  }
+}
+
+template <int U>
+__device__ __forceinline__ void store_elems(void* p, int dt, int64_t e0, const float (&v)[U]) {
+  if (dt == DMXQ_F32) {
+#pragma unroll
+    for (int k = 0; k < U; k += 4) *(f32x4*)((float*)p + e0 + k) = f32x4{v[k], v[k + 1], v[k + 2], v[k + 3]};
+  } else {
+#pragma unroll
+    for (int k = 0; k < U; k += 8) {
+      u32x4 t;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        t[j] = dt == DMXQ_BF16 ? pack2<DMXQ_BF16>(v[k + 2 * j], v[k + 2 * j + 1]) : pack2<DMXQ_F16>(v[k + 2 * j], v[k + 2 * j + 1]);
+      *(u32x4*)((uint16_t*)p + e0 + k) = t;
+    }
+  }
+}
+
+template <int M, int UNROLL>
+__global__ __launch_bounds__(kThreads) void nm_mask_vec_kernel(NmArgs a, int64_t n_units) {
+  constexpr int U = M <= 8 ? 8 : 16;
+  const int64_t stride = (int64_t)gridDim.x * kThreads * UNROLL;
+  for (int64_t u0 = ((int64_t)blockIdx.x * UNROLL) * kThreads + threadIdx.x; u0 < n_units; u0 += stride) {
+    float s[UNROLL][U], x[UNROLL][U];
+#pragma unroll
+    for (int r = 0; r < UNROLL; r++) {
+      const int64_t u = u0 + (int64_t)r * kThreads;
+      if (u < n_units) {
+        load_elems<U>(a.score, a.dts, u * U, s[r]);
+        if (a.y) load_elems<U>(a.x, a.dtx, u * U, x[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < UNROLL; r++) {
+      const int64_t u = u0 + (int64_t)r * kThreads;
+      if (u >= n_units) continue;
+      float mk[U];
+#pragma unroll
+      for (int g = 0; g < U; g += M) {
+        int32_t key[M];
+        int rank[M];
+#pragma unroll
+        for (int i = 0; i < M; i++) { key[i] = sort_key(s[r][g + i]); rank[i] = 0; }
+#pragma unroll
+        for (int i = 0; i < M; i++)
+#pragma unroll
+          for (int jj = 0; jj < i; jj++) {
+            const bool jj_first = key[jj] <= key[i];  // equal keys: the lower index sorts first
+            rank[i] += jj_first ? 1 : 0;
+            rank[jj] += jj_first ? 0 : 1;
+          }
+#pragma unroll
+        for (int i = 0; i < M; i++) mk[g + i] = rank[i] >= M - a.K ? 1.0f : 0.0f;
+      }
+      if (a.mask) store_elems<U>(a.mask, a.dtm, u * U, mk);
+      if (a.y) {
+        float y[U];
+#pragma unroll
+        for (int i = 0; i < U; i++) y[i] = x[r][i] * mk[i];
+        store_elems<U>(a.y, a.dty, u * U, y);
+      }
+    }
+  }
+}
+
+template <int M>
+static void launch_nm_vec(const NmArgs& a, int64_t n, hipStream_t s) {
+  constexpr int U = M <= 8 ? 8 : 16, UNROLL = 2;
+  const int64_t n_units = n / U;
+  hipLaunchKernelGGL((nm_mask_vec_kernel<M, UNROLL>), dim3(grid_for((n_units + UNROLL - 1) / UNROLL)), dim3(kThreads), 0, s,
+                     a, n_units);
+}
+
 // any M <= 64: same rule with runtime loops (scores re-read instead of kept in registers)
 __global__ __launch_bounds__(kThreads) void nm_mask_anyM_kernel(NmArgs a, int M) {
   const int64_t ngrp = a.L / M;
@@ -106,6 +208,17 @@ extern "C" int dmxq_nm_mask(const void* score, int dtype_score, const void* x, i
   if (!score) return DMXQ_ERR_BAD_ARG;
   NmArgs a{score, x, mask_out, y_out, dtype_score, dtype_x, dtype_mask, dtype_y, outer, L, inner, K};
   hipStream_t s = (hipStream_t)stream;
+  const bool vec_ok = inner == 1 && (M == 2 || M == 4 || M == 8 || M == 16) && n % 16 == 0 && aligned16(score) &&
+                      (!x || aligned16(x)) && (!mask_out || aligned16(mask_out)) && (!y_out || aligned16(y_out));
+  if (vec_ok) {
+    switch (M) {
+      case 2: launch_nm_vec<2>(a, n, s); break;
+      case 4: launch_nm_vec<4>(a, n, s); break;
+      case 8: launch_nm_vec<8>(a, n, s); break;
+      default: launch_nm_vec<16>(a, n, s); break;
+    }
+    return launch_status();
+  }
   const int grid = grid_for(n / M);
   switch (M) {
     case 2: hipLaunchKernelGGL(nm_mask_kernel<2>, dim3(grid), dim3(kThreads), 0, s, a); break;

@@ -1,0 +1,386 @@
+"""DmxModule mirror — the Python CALLER of the hot path (reference: modeling/nn/core.py, torch_modules.py).
+
+Only what the parity harness of SURVEY.md §8 (rows a11 / a13) needs: the base class with the reference's order
+of operations, and the module types BASELINE.json's configs touch (Linear, Conv1d/2d, ResAdd, ActActMatMul,
+Softmax, LayerNorm, GELU, ReLU, MaxPool2d, Embedding).  The dense math stays `torch.nn.functional` (rocBLAS /
+MIOpen — not ours); every cast / mask / scale around it is a libdmxq kernel.
+
+Order of operations reproduced (core.py:178-264):
+  weight hypernet : weight_sparsifier -> smoothquant.scale_weight -> weight_storage_cast -> weight_cast   (:184-196)
+  forward         : smoothquant.scale_input -> input_casts -> _forward(_weight, _bias) -> output_casts -> .to(input dtype)
+  fold            : bias cast, effective weight, smoothquant fuse, storage cast, weight cast become permanent (:146-176)
+"""
+import re
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from .approximate import Approximate, NoApproximation
+from .cast import CastTo, CastToDict
+from .format import Same
+from .smoothquant import ActivationWeightSmoothQuant
+from .sparse import Dense, Sparsify
+
+__all__ = ["DmxModule", "Linear", "Conv1d", "Conv2d", "ResAdd", "ActActMatMul", "Softmax", "LayerNorm", "GELU", "ReLU",
+           "MaxPool2d", "AvgPool2d", "Embedding", "DmxConfigRule", "configure_model"]
+
+
+class _LazySparsify(Sparsify):
+    """score materialised at first use with the weight's shape (reference: sparse.py:323-344 LazySparsify)"""
+
+    def __init__(self, sparseness="DENSE", backward_mode="STE", score_func=None):
+        super().__init__(torch.Size([0]), sparseness, backward_mode, score_func)
+
+    def forward(self, x):
+        if not isinstance(self.sparseness, Dense) and self.score.shape != x.shape:
+            self.score = torch.nn.Parameter(torch.rand(x.shape, device=x.device), requires_grad=True)
+        return super().forward(x)
+
+
+class DmxModule(torch.nn.Module):
+    """Mixin base: call `_dmx_init()` after the torch module's own __init__ (see the concrete classes)."""
+
+    functional_forward = None
+    ch_axis = win_ch_axis = wout_ch_axis = None
+    has_accum = False
+
+    def _dmx_init(self, n_inputs: int = 1, input_names=("input_cast",), sparsifiable: bool = False):
+        pnames = [n for n, _ in self.named_parameters(recurse=False)]
+        self.align_boundary_dtype = True
+        self.input_casts = CastToDict(OrderedDict((n, CastTo(ch_axis=self.ch_axis if self.ch_axis is not None else -1))
+                                                  for n in input_names))
+        self.output_casts = CastToDict(OrderedDict({"output_cast": CastTo()}))
+        self.accum_cast = CastTo() if self.has_accum else None
+        wax = self.wout_ch_axis if self.wout_ch_axis is not None else -1
+        self.weight_storage_cast = CastTo(ch_axis=wax) if "weight" in pnames else None
+        self.weight_cast = CastTo(ch_axis=wax) if "weight" in pnames else None
+        self.bias_cast = CastTo() if "bias" in pnames else None
+        self.smoothquant = (ActivationWeightSmoothQuant(self.ch_axis, self.win_ch_axis)
+                            if self.ch_axis is not None and self.win_ch_axis is not None else None)
+        self.weight_sparsifier = _LazySparsify() if sparsifiable else None
+        self.approximator = Approximate()
+        self.approximation_error = None
+
+    # ------------------------------------------------------------------ configuration (core.py:65-108)
+    def configure(self, config) -> None:
+        if "input_formats" in config:
+            self.input_casts.set_format(config["input_formats"])
+        if "pre_input_transform" in config:
+            self.input_casts.set_pre_transform(config["pre_input_transform"])
+        if "output_formats" in config:
+            self.output_casts.set_format(config["output_formats"])
+        if "pre_output_transform" in config:
+            self.output_casts.set_pre_transform(config["pre_output_transform"])
+        if self.accum_cast is not None and "accum_format" in config:
+            self.accum_cast.set_format(config["accum_format"])
+        if self.weight_storage_cast is not None and "weight_storage_format" in config:
+            self.weight_storage_cast.set_format(config["weight_storage_format"])
+        if self.weight_cast is not None and "weight_format" in config:
+            self.weight_cast.set_format(config["weight_format"])
+        if self.weight_cast is not None and "pre_weight_transform" in config:
+            self.weight_cast.set_pre_transform(config["pre_weight_transform"])
+        if self.bias_cast is not None and "bias_format" in config:
+            self.bias_cast.set_format(config["bias_format"])
+        if self.smoothquant is not None and "smoothquant_scale_format" in config:
+            self.smoothquant.set_scale_format(config["smoothquant_scale_format"])
+        if self.weight_sparsifier is not None and "weight_sparseness" in config:
+            self.weight_sparsifier.configure(sparseness=config["weight_sparseness"])
+        if "approximation_function" in config:
+            self.approximator.set_function(config["approximation_function"])
+
+    transform = configure
+
+    # ------------------------------------------------------------------ views used by the harness
+    @property
+    def input_formats(self):
+        return [c.format for c in self.input_casts.values()]
+
+    @property
+    def output_formats(self):
+        return [c.format for c in self.output_casts.values()]
+
+    @property
+    def accum_format(self):
+        return self.accum_cast.format if self.accum_cast is not None else None
+
+    @property
+    def weight_format(self):
+        return self.weight_cast.format if self.weight_cast is not None else None
+
+    @property
+    def bias_format(self):
+        return self.bias_cast.format if self.bias_cast is not None else None
+
+    @property
+    def weight_sparseness(self):
+        return self.weight_sparsifier.sparseness if self.weight_sparsifier is not None else None
+
+    # ------------------------------------------------------------------ weight path (core.py:178-213)
+    @property
+    def weight_hypernet(self):
+        def _weight_hypernet(_w):
+            if self.weight_sparsifier is not None:
+                _w = self.weight_sparsifier(_w)
+            if self.smoothquant is not None and self.smoothquant.fused_to_weight[0] == 0:
+                _w = self.smoothquant.scale_weight(_w)
+            if self.weight_storage_cast is not None:
+                _w = self.weight_storage_cast(_w)
+            if self.weight_cast is not None:
+                _w = self.weight_cast(_w)
+            return _w
+
+        return _weight_hypernet
+
+    @property
+    def _weight(self):
+        return self.weight_hypernet(self.weight)
+
+    @property
+    def _bias(self):
+        return self.bias_cast(self.bias) if (self.bias_cast is not None and self.bias is not None) else None
+
+    @property
+    def effective_weight(self):
+        return self.weight_sparsifier(self.weight) if self.weight_sparsifier is not None else self.weight
+
+    def fold_weight_and_bias(self) -> None:
+        with torch.no_grad():
+            if self.bias_cast is not None and not isinstance(self.bias_format, Same) and self.bias is not None:
+                self.bias.data = self.bias_cast(self.bias.data)
+                self.bias_cast = CastTo(format=Same())
+            if self.weight_sparsifier is not None and not isinstance(self.weight_sparseness, Dense):
+                self.weight.data = self.effective_weight
+                self.weight_sparsifier = _LazySparsify(sparseness=Dense())
+            if self.smoothquant is not None and self.smoothquant.fused_to_weight[0] == 0:
+                self.smoothquant.fuse_to_weight(self.weight)
+            if self.weight_storage_cast is not None and not isinstance(self.weight_storage_cast.format, Same):
+                self.weight.data = self.weight_storage_cast(self.weight.data)
+                self.weight_storage_cast = CastTo(format=Same())
+            if self.weight_cast is not None and not isinstance(self.weight_cast.format, Same):
+                self.weight.data = self.weight_cast(self.weight.data)
+                self.weight_cast = CastTo(format=Same())
+
+    # ------------------------------------------------------------------ forward (core.py:215-264)
+    def update_smoothquant_scale(self, input):
+        if self.smoothquant is not None:  # layer_reconstruction.py:32-34: calibrates against the MASKED weight
+            self.smoothquant(input, self.effective_weight)
+
+    def enable_smoothquant_calib(self, state: bool, migration_strength: float = 0.5, fuse_to_weight: bool = False):
+        """layer_reconstruction.py:57-68"""
+        if self.smoothquant is not None:
+            if self.smoothquant.fused_to_weight[0] == 1:
+                raise RuntimeError("SmoothQuant cannot be calibrated because it has been fused to weight already")
+            self.smoothquant.set_migration_strength(migration_strength)
+            self.smoothquant.set_dynamic(False)
+            self.smoothquant.enable(not state)
+            self.smoothquant.calibrating = state
+            if not state and fuse_to_weight:
+                self.smoothquant.fuse_to_weight(self.weight)
+
+    def forward(self, input, *args, **kwargs):
+        _dtype = input.dtype
+        if self.smoothquant is not None:
+            if self.smoothquant.dynamic[0] == 1 or self.smoothquant.calibrating:
+                self.update_smoothquant_scale(input)
+            input = self.smoothquant.scale_input(input)
+        _input, args, kwargs = self.input_casts(input, *args, **kwargs)
+        _output = self._forward(_input, *args, **kwargs)
+        output = self.output_casts(_output, output=True)
+        if self.align_boundary_dtype:
+            output = (type(output)(a.to(_dtype) for a in output) if isinstance(output, (tuple, list)) else output.to(_dtype))
+        return output
+
+    # approximator slot (functional/approximate.py:300-327): exact function first, then overwritten by the approximation
+    def approximator_wrapper(self, inputs, approx_args, approx_kwargs, **wrapper_kwargs):
+        return self.approximator(*inputs, *approx_args, **approx_kwargs)
+
+    def approx_forward(self, inputs, *args, **kwargs):
+        _output = self.functional_forward(*inputs, *args, **kwargs)
+        if not isinstance(self.approximator.function, NoApproximation):
+            with torch.no_grad():
+                _approx = self.approximator_wrapper(inputs, args, kwargs, **self.approximator.function.wrapper_params)
+                self.approximation_error = _approx - _output.data
+                _output.data = _approx.to(_output.dtype)
+        return _output
+
+
+# ---------------------------------------------------------------------------------------------------- modules
+class Linear(DmxModule, torch.nn.Linear):
+    ch_axis, win_ch_axis, wout_ch_axis, has_accum = -1, -1, 0, True
+
+    def __init__(self, in_features, out_features, bias=True, **kw):
+        torch.nn.Linear.__init__(self, in_features, out_features, bias=bias, **kw)
+        self._dmx_init(sparsifiable=True)
+        self.input_casts.input_cast.block_dim = -1
+        self.weight_cast.block_dim = -1
+        if self.bias_cast is not None:
+            self.bias_cast.block_dim = -1
+
+    def _forward(self, _input):
+        if isinstance(self.accum_format, Same):  # torch_modules.py:346-350
+            _weight = self._weight.to(_input.dtype)
+            _bias = None if self._bias is None else self._bias.to(_input.dtype)
+            return F.linear(_input, _weight, _bias)
+        _weight = self._weight
+        _product = self.accum_cast(torch.matmul(_input.to(_weight.dtype), _weight.t()))
+        return torch.add(_product, self._bias) if self.bias is not None else _product
+
+    @classmethod
+    def from_raw(cls, raw):
+        m = cls(raw.in_features, raw.out_features, bias=raw.bias is not None)
+        m.weight, m.bias = raw.weight, raw.bias
+        return m.to(raw.weight.device, raw.weight.dtype)
+
+
+class _ConvNd(DmxModule):
+    ch_axis, win_ch_axis, wout_ch_axis, has_accum = 1, 1, 0, True
+
+    def _conv_init(self):
+        self._dmx_init(sparsifiable=True)
+        self.input_casts.input_cast.block_dim = 1   # torch_modules.py:582-585, 674-677
+        self.weight_cast.block_dim = 1
+        if self.bias_cast is not None:
+            self.bias_cast.block_dim = -1
+
+    def _forward(self, _input):  # torch_modules.py:677-686 (Conv2d), 585-594 (Conv1d)
+        _weight = self._weight
+        _convolution = self.accum_cast(self._conv_forward(_input.to(_weight.dtype), _weight, None))
+        if self.bias is not None:
+            _b = self._bias
+            for _ in range(_convolution.dim() - 2):
+                _b = _b.unsqueeze(-1)
+            return torch.add(_convolution, _b)
+        return _convolution
+
+
+class Conv2d(_ConvNd, torch.nn.Conv2d):
+    def __init__(self, *a, **kw):
+        torch.nn.Conv2d.__init__(self, *a, **kw)
+        self._conv_init()
+
+
+class Conv1d(_ConvNd, torch.nn.Conv1d):
+    def __init__(self, *a, **kw):
+        torch.nn.Conv1d.__init__(self, *a, **kw)
+        self._conv_init()
+
+
+class ResAdd(DmxModule):
+    def __init__(self):
+        torch.nn.Module.__init__(self)
+        self._dmx_init(input_names=("input_cast", "residual_cast"))
+
+    def _forward(self, _input, residual):
+        return _input + residual
+
+
+class ActActMatMul(DmxModule):
+    def __init__(self):
+        torch.nn.Module.__init__(self)
+        self._dmx_init(input_names=("input_cast", "multiplier_cast"))
+        self.input_casts.input_cast.block_dim = -1      # torch_modules.py:197-204
+        self.input_casts.multiplier_cast.block_dim = -2
+
+    def _forward(self, _input, multiplier):
+        return torch.matmul(_input, multiplier)
+
+
+class Softmax(DmxModule, torch.nn.Softmax):
+    def __init__(self, dim: int = -1):
+        torch.nn.Softmax.__init__(self, dim=dim)
+        self._dmx_init()
+        self.functional_forward = F.softmax
+
+    def approximator_wrapper(self, inputs, approx_args, approx_kwargs, **wrapper_kwargs):
+        if "input_clamp" in wrapper_kwargs:  # torch_modules.py:989-994
+            inputs = [torch.clamp(x, min=wrapper_kwargs["input_clamp"]) for x in inputs]
+        return self.approximator(*inputs, *approx_args, **approx_kwargs)
+
+    def _forward(self, _input):
+        return self.approx_forward((_input,), dim=self.dim)
+
+
+class LayerNorm(DmxModule, torch.nn.LayerNorm):
+    def __init__(self, normalized_shape, eps: float = 1e-5, elementwise_affine: bool = True):
+        torch.nn.LayerNorm.__init__(self, normalized_shape, eps=eps, elementwise_affine=elementwise_affine)
+        self._dmx_init()
+        self.functional_forward = F.layer_norm
+
+    def _forward(self, _input):
+        return self.approx_forward((_input,), self.normalized_shape, self._weight, self._bias, self.eps)
+
+
+class GELU(DmxModule, torch.nn.GELU):
+    def __init__(self, approximate: str = "none"):
+        torch.nn.GELU.__init__(self, approximate=approximate)
+        self._dmx_init()
+        self.functional_forward = F.gelu
+
+    def _forward(self, _input):
+        return self.approx_forward((_input,), approximate=self.approximate)
+
+
+class ReLU(DmxModule, torch.nn.ReLU):
+    def __init__(self, inplace: bool = False):
+        torch.nn.ReLU.__init__(self, inplace=False)
+        self._dmx_init()
+
+    def _forward(self, _input):
+        return F.relu(_input)
+
+
+class MaxPool2d(DmxModule, torch.nn.MaxPool2d):
+    def __init__(self, *a, **kw):
+        torch.nn.MaxPool2d.__init__(self, *a, **kw)
+        self._dmx_init()
+
+    def _forward(self, _input):
+        return torch.nn.MaxPool2d.forward(self, _input)
+
+
+class AvgPool2d(DmxModule, torch.nn.AvgPool2d):
+    def __init__(self, *a, **kw):
+        torch.nn.AvgPool2d.__init__(self, *a, **kw)
+        self._dmx_init()
+
+    def _forward(self, _input):
+        return torch.nn.AvgPool2d.forward(self, _input)
+
+
+class Embedding(DmxModule, torch.nn.Embedding):
+    def __init__(self, *a, **kw):
+        torch.nn.Embedding.__init__(self, *a, **kw)
+        self._dmx_init(sparsifiable=True)
+
+    def forward(self, input):  # integer indices: no input cast, no dtype alignment (reference Embedding)
+        _output = F.embedding(input, self._weight, self.padding_idx, self.max_norm, self.norm_type,
+                              self.scale_grad_by_freq, self.sparse)
+        return self.output_casts(_output, output=True)
+
+
+# ---------------------------------------------------------------------------------------------------- rules
+class DmxConfigRule:
+    """(module types, name regex) -> module config  (modeling/model.py:721-792)"""
+
+    def __init__(self, module_types=(), name_re: str = "", module_config: Optional[dict] = None):
+        assert all(issubclass(mt, DmxModule) for mt in module_types)
+        self.module_types = tuple(module_types)
+        self.name_rule = re.compile(name_re)
+        self.module_config = dict(module_config or {})
+
+    def names_in(self, model: torch.nn.Module):
+        return [n for n, m in model.named_modules() if isinstance(m, self.module_types) and self.name_rule.match(n)]
+
+    def apply_to(self, model: torch.nn.Module):
+        for n, m in model.named_modules():
+            if isinstance(m, DmxModule) and isinstance(m, self.module_types) and self.name_rule.match(n):
+                m.configure(self.module_config)
+
+
+def configure_model(model: torch.nn.Module, *rules: DmxConfigRule):
+    """DmxModel.configure(None, *rules) for a model already built from these modules (model.py:61-78)"""
+    for r in rules:
+        r.apply_to(model)
+    return model

@@ -1,0 +1,89 @@
+"""SmoothQuant — mirror of the reference's `numerical/smoothquant.py` ActivationWeightSmoothQuant.
+
+scale[c] = clamp( amax|inp[.., c]|^alpha / clamp(amax|w[:, c]|, scale_min)^(1-alpha), scale_min ), cast through the
+scale format; the input is divided and the weight multiplied along their channel axes
+(smoothquant.py:255-321).  The two per-channel reductions, the scale and the scaling are one kernel launch each
+(dmxq_channel_maxabs / dmxq_smoothquant_scale / dmxq_scale_channels) instead of abs + amax + pow + div chains.
+
+Reference quirk kept: the derived class stores `weight_maxabs` / `input_maxabs` but its
+"exists" checks read the base class's `b_maxabs` / `a_maxabs` (smoothquant.py:455-473, 527-535), so BOTH maxima
+are recomputed on every calibration call and the scale reflects the LAST batch only, not a running maximum.
+"""
+from typing import Union
+
+import torch
+
+from . import ops
+from .cast import CastTo
+from .format import Format
+
+__all__ = ["ActivationWeightSmoothQuant"]
+
+
+class ActivationWeightSmoothQuant(torch.nn.Module):
+    def __init__(self, ch_axis: int, win_ch_axis: int, migration_strength: float = 0.5,
+                 scale_format: Union[str, Format] = "SAME", dynamic: bool = False, scale_min: float = 1e-5):
+        super().__init__()
+        assert 0 <= migration_strength <= 1, "migration strength should be between 0 and 1"
+        self.ch_axis, self.win_ch_axis = ch_axis, win_ch_axis
+        self.register_buffer("migration_strength", torch.tensor(float(migration_strength)))
+        self.register_buffer("scale_min", torch.tensor(float(scale_min)))
+        self.register_buffer("scale", torch.ones(1))
+        self.register_buffer("enabled", torch.tensor([0], dtype=torch.long))
+        self.register_buffer("dynamic", torch.tensor([1 if dynamic else 0], dtype=torch.long))
+        self.register_buffer("fused_to_weight", torch.tensor([0], dtype=torch.long))
+        self.scale_cast = CastTo(format=scale_format)
+        self.calibrating = False
+        self.input_maxabs = self.weight_maxabs = None
+
+    # -------------------------------------------------------------- switches
+    def enable(self, enabled: bool = True):
+        self.enabled[0] = 1 if enabled else 0
+
+    def disable(self):
+        self.enable(False)
+
+    def set_dynamic(self, dynamic: bool = True):
+        if dynamic and self.fused_to_weight[0] == 1:
+            raise RuntimeError("SmoothQuant cannot be dynamic as scale has been fused to weight already")
+        self.dynamic[0] = 1 if dynamic else 0
+
+    def set_scale_format(self, format: Union[str, Format]):
+        self.scale_cast.set_format(format)
+
+    def set_migration_strength(self, migration_strength: float):
+        assert 0 <= migration_strength <= 1, "migration strength should be between 0 and 1"
+        self.migration_strength.fill_(float(migration_strength))
+
+    # -------------------------------------------------------------- calibration
+    def compute_scale(self, inp_maxabs: torch.Tensor, wgt_maxabs: torch.Tensor) -> None:
+        s = ops.smoothquant_scale(inp_maxabs, wgt_maxabs, float(self.migration_strength), float(self.scale_min))
+        self.scale = self.scale_cast(s)
+
+    def forward(self, inp: torch.Tensor, wgt: torch.Tensor) -> None:
+        """smoothquant.py:518-535 (with the quirk above: both maxima from this call only)."""
+        with torch.no_grad():
+            self.weight_maxabs = ops.channel_maxabs(wgt.detach(), self.win_ch_axis)
+            self.input_maxabs = ops.channel_maxabs(inp.detach(), self.ch_axis)
+            self.compute_scale(self.input_maxabs, self.weight_maxabs)
+
+    # -------------------------------------------------------------- application
+    def scale_input(self, inp: torch.Tensor) -> torch.Tensor:
+        if self.enabled[0] == 1:
+            # reference: a / scale.view(...) -> torch promotion of (input dtype, fp32 scale)
+            return ops.scale_channels(inp, self.scale, self.ch_axis, divide=True,
+                                      out_dtype=torch.promote_types(inp.dtype, torch.float32))
+        return inp
+
+    def scale_weight(self, wgt: torch.Tensor) -> torch.Tensor:
+        if self.enabled[0] == 1:
+            return ops.scale_channels(wgt, self.scale, self.win_ch_axis, divide=False, out_dtype=wgt.dtype)  # .to(wgt.dtype)
+        return wgt
+
+    def fuse_to_weight(self, wgt: torch.Tensor) -> None:
+        wgt.data = self.scale_weight(wgt.data)
+        self.fused_to_weight[0] = 1
+
+    def extra_repr(self) -> str:
+        return (f"migration_strength = {self.migration_strength.item()}, ch_axis = {self.ch_axis}, win_ch_axis = "
+                f"{self.win_ch_axis}, scale_format = {self.scale_cast.format}, dynamic = {bool(self.dynamic.item())}")

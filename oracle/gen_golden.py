@@ -273,6 +273,77 @@ def smoothquant_cases():
     np.savez_compressed(os.path.join(GOLD, "smoothquant.npz"), **store)
 
 
+# ------------------------------------------------------------------------------------------------ module level
+def module_cases():
+    """the reference's DmxModule order of operations, captured stage by stage.
+    dmxnn.Linear(64, 32) and LeNet-5 (tests/test_fold_weights_and_biases.py:21-48 topology) under BASIC rules, plus a
+    Linear with 2:4 weight sparsity + SmoothQuant.  Stored per module: input, input after input_cast, _weight, _bias,
+    output before output_cast, final output."""
+    from dmx.compressor.modeling import nn as rnn
+    store = {}
+
+    def configure(mods, rules):
+        for m in mods:
+            for r in rules:
+                if isinstance(m, r.module_types):
+                    m.configure(r.module_config)
+
+    def capture(tag, m, x, *extra):
+        with torch.no_grad():
+            xin = x
+            if m.smoothquant is not None:
+                xin = m.smoothquant.scale_input(x)
+            cin, a, k = m.input_casts(xin, *extra)
+            pre = m._forward(cin, *a, **k)
+            y = m(x, *extra)
+        store[f"{tag}_x"], store[f"{tag}_cin"] = bits(x), bits(cin.contiguous())
+        store[f"{tag}_pre"], store[f"{tag}_y"] = bits(pre.contiguous()), bits(y.contiguous())
+        if getattr(m, "weight", None) is not None and m.weight_cast is not None:
+            store[f"{tag}_w"], store[f"{tag}_wq"] = bits(m.weight.detach()), bits(m._weight.detach().contiguous())
+        if getattr(m, "bias", None) is not None and m.bias_cast is not None:
+            store[f"{tag}_b"], store[f"{tag}_bq"] = bits(m.bias.detach()), bits(m._bias.detach().contiguous())
+        return y
+
+    torch.manual_seed(0)
+    for dt in (torch.float32, torch.bfloat16):
+        lin = rnn.Linear(64, 32).to(dt)
+        lin.weight.data = make("normal", (32, 64), seed=61, dtype=dt) * 0.2
+        lin.bias.data = make("normal", (32,), seed=62, dtype=dt) * 0.1
+        configure([lin], ref.config_rules.BASIC)
+        capture(f"lin_{DT_NAME[dt]}", lin, make("heavy", (8, 64), seed=63, dtype=dt).clamp(-100, 100))
+    # LeNet-5, fp32, BASIC: conv1 C_in = 1 -> blocks of 1 along dim 1; conv2 C_in = 6; fc 400 = 6*64+16, 120, 84
+    layers = [("conv1", rnn.Conv2d(1, 6, 5)), ("relu1", rnn.ReLU()), ("pool1", rnn.MaxPool2d(2)),
+              ("conv2", rnn.Conv2d(6, 16, 5)), ("relu2", rnn.ReLU()), ("pool2", rnn.MaxPool2d(2)),
+              ("fc1", rnn.Linear(400, 120)), ("relu3", rnn.ReLU()), ("fc2", rnn.Linear(120, 84)), ("relu4", rnn.ReLU()),
+              ("fc3", rnn.Linear(84, 10))]
+    for i, (n, m) in enumerate(layers):
+        if getattr(m, "weight", None) is not None:
+            m.weight.data = make("normal", tuple(m.weight.shape), seed=70 + i) * 0.15
+            m.bias.data = make("normal", tuple(m.bias.shape), seed=90 + i) * 0.05
+    configure([m for _, m in layers], ref.config_rules.BASIC)
+    h = make("normal", (2, 1, 32, 32), seed=69)
+    for n, m in layers:
+        if n == "fc1":
+            h = h.flatten(1)
+        h = capture(f"lenet_{n}", m, h)
+    # weight hypernet with sparsity + SmoothQuant (core.py:184-196): Linear(64, 48), BTOPK{2:4,-1}, alpha = 0.5
+    sq = rnn.Linear(64, 48)
+    sq.weight.data = make("normal", (48, 64), seed=81) * 0.2
+    sq.bias.data = make("normal", (48,), seed=82) * 0.1
+    configure([sq], ref.config_rules.BASIC)
+    sq.configure(dict(weight_sparseness="BTOPK{2:4,-1}(U)"))
+    xs = make("heavy", (16, 64), seed=83).clamp(-50, 50)
+    sq(xs)                                                       # materialises the lazy score
+    sq.weight_sparsifier.score.data = make("normal", (48, 64), seed=84).abs()
+    sq.smoothquant.calibrating = True
+    sq(xs)                                                       # calibration pass: computes the scale
+    sq.smoothquant.calibrating = False
+    sq.smoothquant.enable()
+    store["sq_score"], store["sq_scale"] = bits(sq.weight_sparsifier.score.detach()), bits(sq.smoothquant.scale.detach().float())
+    capture("sq", sq, xs)
+    np.savez_compressed(os.path.join(GOLD, "modules.npz"), **store)
+
+
 # ------------------------------------------------------------------------------------------------ vocabulary
 def vocabulary():
     """alias name -> repr() of the reference's format / sparseness tables (config identity strings)."""
@@ -288,6 +359,7 @@ if __name__ == "__main__":
     elementwise_cases()
     nm_cases()
     smoothquant_cases()
+    module_cases()
     vocabulary()
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD)) if f.endswith(".npz")}
     print(f"oracle == reference on {checked} comparisons; fixtures: {sizes}")

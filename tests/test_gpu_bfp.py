@@ -65,6 +65,32 @@ def test_block_dim_layouts(dmx, cuda, oracle, dim, B):
         assert _run(dmx, cuda, oracle, x.float(), 6, B, dim=dim, sym=False) == 0, (shape, dim, B)
 
 
+@pytest.mark.parametrize("B", [8, 16, 64, 256])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ragged_and_unaligned_rows_lds_kernel(dmx, cuda, oracle, B, dtype):
+    """Row lengths that are not whole blocks and/or not 16-byte aligned: the LDS-staged kernel (bfp_ragged.hip),
+    every copy width (16/8/4/2 bytes), rows longer than one LDS segment, a view that starts mid-buffer."""
+    for shape in ((7, 400), (33, 1500), (5, 84), (3, 1001), (2, 9001), (1, 13), (64, 120), (3, 5, 2, 50)):
+        x = make("mixed", shape, seed=B + shape[-1], dtype=dtype, block=8)
+        assert _run(dmx, cuda, oracle, x, 8, B) == 0, shape
+        xa = make("mixed_nd", shape, seed=B, dtype=dtype, block=8)
+        assert _run(dmx, cuda, oracle, xa, 4, B, sym=False) == 0, shape
+    x = make("heavy", (9, 1500), seed=3, dtype=dtype)
+    for rounding in ("down", "up", "stochastic"):
+        assert _run(dmx, cuda, oracle, x, 8, B, rounding=rounding, seed=5) == 0, rounding
+    assert _run(dmx, cuda, oracle, x, 22, B) == 0
+    # misaligned base pointer: a contiguous slice that starts 2 bytes (16-bit) / 4 bytes (fp32) into the allocation
+    flat = make("normal", (1 + 6 * 200,), seed=9, dtype=dtype).to(cuda)
+    xv = flat[1:].view(6, 200)
+    got = dmx.ops.bfp_qdq(xv, 8, B)
+    want = oracle.bfp_cast(xv.cpu(), 8, B).to(dtype)
+    assert bits_equal(got, want) == 0
+    if dtype != torch.float32:
+        assert _run(dmx, cuda, oracle, x, 8, B, out_dtype=torch.float32) == 0
+    else:
+        assert _run(dmx, cuda, oracle, x, 8, B, out_dtype=torch.bfloat16) == 0
+
+
 @pytest.mark.parametrize("B", [8, 16, 32, 64, 128])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_column_block_kernel(dmx, cuda, oracle, B, dtype):
