@@ -16,6 +16,7 @@ from .approximate import Approximate, ApproximationFunction, NoApproximation, To
 from .nn import DmxConfigRule, DmxModule, configure_model
 from .observer import DummyObserver, HistogramObserver, MinMaxObserver
 from .smoothquant import ActivationWeightSmoothQuant
+from .config import apply_legacy_config, load_legacy_config
 from .sparse import Bernoulli, BlockTopK, Dense, Sparseness, Sparsify, TopK
 
 __version__ = "0.1.0"

@@ -140,3 +140,91 @@ def test_castto_configuration_surface(dmx):
     t = torch.randn(3)
     out = dmx.CastTo()(t)
     assert torch.equal(out, t) and out.data_ptr() != t.data_ptr()
+
+
+LEGACY_YAML = """
+conv1:
+  accum_format: SAME
+  approximation_function: NONE
+  bias_format: SAME
+  input_format: BFP[8|8]{64,1}(SN)
+  instance: Conv2d
+  output_format: FP[1|5|10,15](FN)
+  weight_format: BFP[8|8]{64,1}(SN)
+  weight_sparseness: DENSE
+fc1:
+  bias_format: SAME
+  input_format: BFP[8|8]{64,-1}(SN)
+  instance: Linear
+  output_format: FP[1|5|10,15](FN)
+  weight_format: BFP[8|8]{64,-1}(SN)
+mp1:
+  input_format: SAME
+  instance: MaxPool2d
+  output_format: FP[1|5|10,15](FN)
+"""
+
+
+def _tiny_net(dmx):
+    nn = dmx.nn
+    return torch.nn.Sequential(__import__("collections").OrderedDict(
+        conv1=nn.Conv2d(1, 6, 5), relu=nn.ReLU(), mp1=nn.MaxPool2d(2), flat=torch.nn.Flatten(1), fc1=nn.Linear(6 * 14 * 14, 10)))
+
+
+def test_config1_baseline_rules_on_cpu_equal_the_raw_model(dmx):
+    """BASELINE.json config 1 (LeNet-5 + legacy yaml + BASELINE rules, CPU torch): under the reference's current code
+    the yaml is a silent no-op and BASELINE = all-SAME casts, so the output is the raw torch model's, bit for bit.
+    SAME casts are clones and need no GPU."""
+    torch.manual_seed(0)
+    net = _tiny_net(dmx)
+    dmx.configure_model(net, *dmx.config_rules.BASELINE)
+    for m in net.modules():
+        if isinstance(m, dmx.DmxModule):
+            assert all(repr(f) == "SAME" for f in m.input_formats + m.output_formats)
+    raw = torch.nn.Sequential(torch.nn.Conv2d(1, 6, 5), torch.nn.ReLU(), torch.nn.MaxPool2d(2), torch.nn.Flatten(1), torch.nn.Linear(6 * 14 * 14, 10))
+    raw[0].load_state_dict({k: v for k, v in net.conv1.state_dict().items() if k in ("weight", "bias")})
+    raw[4].load_state_dict({k: v for k, v in net.fc1.state_dict().items() if k in ("weight", "bias")})
+    x = torch.randn(3, 1, 32, 32)
+    assert torch.equal(net(x), raw(x))
+    net.fc1.fold_weight_and_bias()
+    assert torch.equal(net(x), raw(x))
+
+
+def test_legacy_yaml_intent_loader(dmx):
+    cfg = dmx.load_legacy_config(LEGACY_YAML)
+    assert set(cfg) == {"conv1", "fc1", "mp1"}
+    assert repr(cfg["conv1"]["config"]["input_formats"][0]) == "BFP[8|8]{64}(SN)" and cfg["conv1"]["block_dims"] == {"input_cast": 1, "weight_cast": 1}
+    assert cfg["fc1"]["block_dims"] == {"input_cast": -1, "weight_cast": -1}
+    net = _tiny_net(dmx)
+    assert dmx.apply_legacy_config(net, LEGACY_YAML) == 3
+    assert repr(net.conv1.weight_format) == "BFP[8|8]{64}(SN)" and net.conv1.weight_cast.block_dim == 1
+    assert repr(net.conv1.output_formats[0]) == "FP[1|5|10,15](FN)" and repr(net.conv1.bias_format) == "SAME"
+    assert repr(net.mp1.output_formats[0]) == "FP[1|5|10,15](FN)" and repr(net.mp1.input_formats[0]) == "SAME"
+    with pytest.raises(TypeError):
+        dmx.apply_legacy_config(net, LEGACY_YAML.replace("instance: Linear", "instance: Conv2d"))
+
+
+def test_rule_sets_and_module_surface(dmx):
+    nn, rules = dmx.nn, dmx.config_rules
+    lin, conv, mm, add = nn.Linear(16, 8), nn.Conv2d(3, 4, 3), nn.ActActMatMul(), nn.ResAdd()
+    net = torch.nn.ModuleDict(dict(a=lin, b=conv, c=mm, d=add, e=nn.Softmax(), f=nn.GELU(), g=nn.LayerNorm(8)))
+    dmx.configure_model(net, *rules.BASIC)
+    assert [repr(f) for f in lin.input_formats] == ["BFP[8|8]{64}(SN)"] and repr(lin.weight_format) == "BFP[8|8]{64}(SN)"
+    assert repr(lin.bias_format) == "BFP[24|8]{1}(SN)" and repr(lin.output_formats[0]) == "FP[1|5|10,15](FN)"
+    assert conv.input_casts.input_cast.block_dim == 1 and conv.weight_cast.block_dim == 1 and lin.weight_cast.block_dim == -1
+    assert [repr(f) for f in mm.input_formats] == ["BFP[8|8]{64}(SN)"] * 2 and mm.input_casts.multiplier_cast.block_dim == -2
+    assert [repr(f) for f in add.input_formats] == ["FP[1|5|10,15](FN)"] * 2
+    assert repr(net["e"].approximator.function) == "NONE" and repr(net["f"].input_formats[0]) == "FP[1|5|10,15](FN)"
+    dmx.configure_model(net, *rules.FP8)
+    assert repr(lin.weight_format) == "FP[1|4|3,7](_N)" and repr(lin.bias_format) == "FP[1|8|23,127](_N)"
+    dmx.configure_model(net, *rules.SBFP_WEIGHT_STORAGE)
+    assert repr(lin.weight_storage_cast.format) == "SBFP<XP[4,0](CSN)><FP[0|4|4,7](FN)>{16}"
+    r = dmx.DmxConfigRule(module_types=(nn.Linear,), name_re="a", module_config=dict(weight_sparseness="BTOPK{2:4,-1}(U)"))
+    assert r.names_in(net) == ["a"]
+    r.apply_to(net)
+    assert repr(lin.weight_sparseness) == "BTOPK{2:4,-1}(U)" and lin.ch_axis == -1 and lin.wout_ch_axis == 0 and conv.win_ch_axis == 1
+    assert lin.smoothquant is not None and mm.smoothquant is None and mm.weight_cast is None
+    f = dmx.ApproximationFunction.from_shorthand("SOFTMAX[dmxq]{input_clamp=-100}(max_adjust=0.1141)")
+    assert f.wrapper_params == {"input_clamp": -100} and f.extra_params == {"max_adjust": 0.1141} and repr(f).startswith("SOFTMAX[dmxq]")
+    with pytest.raises(ValueError):
+        dmx.ApproximationFunction.from_shorthand("FOO[x]{}()")
