@@ -1,0 +1,182 @@
+// csrc/blockfmt.hip — composite block formats as single kernels:
+//   SBFP  numerical/format.py:453-479  per block: s = max|x| / (2^(p-1)-1); fixed(x/s) * |float(s)|
+//   MXFP  numerical/format.py:545-564  per block: scale = 2^floor(log2 max|x|) / 2^(2^(e-1)); float(x/scale) * scale
+// The reference composes each from 6+ ATen passes per CHUNK inside a Python loop; here: one read, one write.
+//   rows kernel     inner == 1, L % B == 0, B = 2^k covering whole 16-byte vectors: one vector per lane, block max
+//                   across B/EPL lanes by DPP (same layout idea as bfp_rows.hpp), 4 vectors in flight per lane
+//   generic kernel  any [outer, L, inner], ragged tails: one lane per block, two strided passes
+#include <math.h>
+
+#include "common.hpp"
+
+namespace dmxq {
+
+// per-element pieces shared with elementwise.hip (kept local: tiny, and it avoids a header for three functions)
+__device__ __forceinline__ uint32_t rne_bits(uint32_t t, int man_bits) {  // quant_cpu.cpp:211-237, nearest
+  const int sh = 23 - man_bits;
+  const uint32_t mask = (1u << sh) - 1u;
+  return (t + (mask >> 1) + ((t >> sh) & 1u)) & ~mask;
+}
+__device__ __forceinline__ float float_q_nearest(float a, int man, int exp_bits, int bias, int flush) {  // quant_cpu.cpp:359-402
+  const uint32_t target = f2u(a);
+  const int target_exp = (int)((target & 0x7FFFFFFFu) >> 23) - 127;
+  const int min_exp = -(bias - 1);
+  if (target_exp < min_exp) {
+    if (flush) return 0.0f;
+    const float shift = u2f(((uint32_t)(127 + min_exp) << 23) | (target & 0x80000000u));
+    return u2f(rne_bits(f2u(a + shift), man)) - shift;
+  }
+  uint32_t qb = rne_bits(target, man);
+  const int max_e = (1 << (exp_bits - 1)) + 127;
+  if (qb != 0u && (int)((qb & 0x7FFFFFFFu) >> 23) > max_e)
+    qb = (target & 0x80000000u) | ((uint32_t)max_e << 23) | ((0x007FFFFFu >> (23 - man)) << (23 - man));
+  return u2f(qb);
+}
+__device__ __forceinline__ float fixed_rne(float a) {  // sim_helper.cpp:14-21 with sigma = 0 (see elementwise.hip)
+  const float a1 = a + 0.5f;
+  const float mag = fabsf(a1);
+  const bool odd = (f2u(a1) & 1u) != 0u && mag < 16777216.0f;
+  return mag >= 8388608.0f ? (odd ? a1 - 1.0f : a1) : rintf(a1 - 0.5f);
+}
+
+struct SbfpFmt { int p, clamp; float t_min, t_max, man_scaling; int man, exp_bits, bias, flush; };
+struct MxfpFmt { int man, exp_bits, bias; float big; };
+
+struct SbfpBlock {
+  float s, sc;
+  __device__ __forceinline__ void setup(uint32_t maxbits, const SbfpFmt& f) {
+    s = u2f(maxbits) / f.man_scaling;
+    sc = fabsf(float_q_nearest(s, f.man, f.exp_bits, f.bias, f.flush));
+  }
+  __device__ __forceinline__ float apply(float x, const SbfpFmt& f) const {
+    if (!(s > 0.0f)) return x;  // zero (or NaN) block: passed through (format.py:467-474 torch.where)
+    float q = fixed_rne(x / s);
+    if (f.clamp) q = q > f.t_max ? f.t_max : (q < f.t_min ? f.t_min : q);
+    return q * sc;
+  }
+};
+struct MxfpBlock {
+  float scale;
+  bool zero;
+  __device__ __forceinline__ void setup(uint32_t maxbits, const MxfpFmt& f) {
+    const float m = u2f(maxbits);
+    zero = m == 0.0f;
+    scale = exp2f(floorf(log2f(m))) / f.big;  // the reference evaluates exactly this in fp32 (format.py:551-555)
+  }
+  __device__ __forceinline__ float apply(float x, const MxfpFmt& f) const {
+    if (zero) return x * 0.0f;
+    return float_q_nearest(x / scale, f.man, f.exp_bits, f.bias, 0) * scale;
+  }
+};
+
+template <int DTI, int DTO, class FMT, class BLK>
+__global__ __launch_bounds__(kThreads) void blockfmt_rows_kernel(const void* __restrict__ in, void* __restrict__ out,
+                                                                int64_t n_vec, int lpb_arg, FMT f) {
+  constexpr int EPL = 16 / Elem<DTI>::bytes, UNROLL = 4;
+  const int lpb = __builtin_amdgcn_readfirstlane(lpb_arg);
+  const int64_t sweep = (int64_t)gridDim.x * kThreads * UNROLL;
+  for (int64_t v0 = (int64_t)blockIdx.x * kThreads * UNROLL + threadIdx.x; v0 < n_vec; v0 += sweep) {
+    u32x4 raw[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++)
+      if (v0 + (int64_t)u * kThreads < n_vec) raw[u] = load_raw16<true>(in, (v0 + (int64_t)u * kThreads) * 16);
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int64_t vi = v0 + (int64_t)u * kThreads;
+      if (vi < n_vec) {  // a block never straddles this predicate (n_vec % lpb == 0, lpb | kThreads)
+        BLK b;
+        b.setup(group_max_u32(absmax_bits<DTI>(raw[u]), lpb), f);
+        float x[EPL], y[EPL];
+        widen<DTI, EPL>(raw[u], x);
+#pragma unroll
+        for (int k = 0; k < EPL; k++) y[k] = b.apply(x[k], f);
+        store_vec<DTO, EPL, true>(out, vi * EPL, y);
+      }
+    }
+  }
+}
+
+template <int DTI, int DTO, class FMT, class BLK>
+__global__ __launch_bounds__(kThreads) void blockfmt_generic_kernel(const void* __restrict__ in, void* __restrict__ out,
+                                                                   int64_t outer, int64_t L, int64_t inner, int64_t B,
+                                                                   FMT f) {
+  const int64_t nblk = (L + B - 1) / B;
+  const int64_t total = outer * nblk * inner;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < total; t += stride) {
+    const int64_t j = t % inner, k = (t / inner) % nblk, o = t / (inner * nblk);
+    const int64_t l0 = k * B, len = (L - l0 < B) ? (L - l0) : B;
+    const int64_t e0 = (o * L + l0) * inner + j;
+    uint32_t mb = 0u;
+    for (int64_t i = 0; i < len; i++) mb = max(mb, f2u(load1<DTI>(in, e0 + i * inner)) & 0x7FFFFFFFu);
+    BLK b;
+    b.setup(mb, f);
+    for (int64_t i = 0; i < len; i++) store1<DTO>(out, e0 + i * inner, b.apply(load1<DTI>(in, e0 + i * inner), f));
+  }
+}
+
+template <int DTI, int DTO, class FMT, class BLK>
+static int launch_blockfmt(const void* in, void* out, int64_t outer, int64_t L, int64_t inner, int64_t B, const FMT& f,
+                           hipStream_t s) {
+  constexpr int EPL = 16 / Elem<DTI>::bytes;
+  const int64_t n = outer * L * inner;
+  const bool pow2 = (B & (B - 1)) == 0;
+  if (inner == 1 && L % B == 0 && pow2 && B >= EPL && B <= 64 * EPL && aligned16(in) && aligned16(out)) {
+    const int64_t n_vec = n / EPL;
+    hipLaunchKernelGGL((blockfmt_rows_kernel<DTI, DTO, FMT, BLK>), dim3(grid_for((n_vec + 3) / 4)), dim3(kThreads), 0, s, in,
+                       out, n_vec, (int)(B / EPL), f);
+  } else {
+    const int64_t nblk = (L + B - 1) / B;
+    hipLaunchKernelGGL((blockfmt_generic_kernel<DTI, DTO, FMT, BLK>), dim3(grid_for(outer * nblk * inner)), dim3(kThreads), 0,
+                       s, in, out, outer, L, inner, B, f);
+  }
+  return launch_status();
+}
+
+template <class FMT, class BLK>
+static int dispatch_blockfmt(const void* in, void* out, int dti, int dto, int64_t outer, int64_t L, int64_t inner,
+                             int64_t B, const FMT& f, hipStream_t s) {
+#define DMXQ_DT(I_, O_) \
+  if (dti == I_ && dto == O_) return launch_blockfmt<I_, O_, FMT, BLK>(in, out, outer, L, inner, B, f, s);
+  DMXQ_DT(DMXQ_BF16, DMXQ_BF16)
+  DMXQ_DT(DMXQ_F16, DMXQ_F16)
+  DMXQ_DT(DMXQ_F32, DMXQ_F32)
+  DMXQ_DT(DMXQ_BF16, DMXQ_F32)
+  DMXQ_DT(DMXQ_F16, DMXQ_F32)
+  DMXQ_DT(DMXQ_F32, DMXQ_BF16)
+  DMXQ_DT(DMXQ_F32, DMXQ_F16)
+#undef DMXQ_DT
+  return DMXQ_ERR_BAD_ARG;
+}
+
+}  // namespace dmxq
+
+using namespace dmxq;
+
+extern "C" int dmxq_sbfp_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L,
+                             int64_t inner, int64_t block_size, int precision, int clamp, int symmetric,
+                             int scaler_man_bits, int scaler_exp_bits, int scaler_exp_bias, int scaler_flush_subnormal,
+                             void* stream) {
+  if (!valid_dtype(dtype_in) || !valid_dtype(dtype_out) || outer < 0 || L < 0 || inner < 0 || block_size < 1) return DMXQ_ERR_BAD_ARG;
+  if (precision < 2 || precision > 24 || scaler_exp_bits < 1 || scaler_exp_bits > 8 || scaler_man_bits < 0) return DMXQ_ERR_BAD_ARG;
+  if (scaler_man_bits > 22) return DMXQ_ERR_UNSUPPORTED;
+  if (outer * L * inner == 0) return DMXQ_OK;
+  if (!in || !out) return DMXQ_ERR_BAD_ARG;
+  float t_min = (float)(-ldexp(1.0, precision - 1));            // sim_helper.cpp:5-12 with fl = 0
+  const float t_max = (float)(-(double)t_min - 1.0);
+  if (symmetric) t_min = (float)((double)t_min + 1.0);
+  const SbfpFmt f{precision, clamp ? 1 : 0, t_min, t_max, (float)((1 << (precision - 1)) - 1), scaler_man_bits,
+                  scaler_exp_bits, scaler_exp_bias, scaler_flush_subnormal ? 1 : 0};
+  return dispatch_blockfmt<SbfpFmt, SbfpBlock>(in, out, dtype_in, dtype_out, outer, L, inner, block_size, f, (hipStream_t)stream);
+}
+
+extern "C" int dmxq_mxfp_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L,
+                             int64_t inner, int64_t block_size, int man_bits, int exp_bits, void* stream) {
+  if (!valid_dtype(dtype_in) || !valid_dtype(dtype_out) || outer < 0 || L < 0 || inner < 0 || block_size < 1) return DMXQ_ERR_BAD_ARG;
+  if (exp_bits < 1 || exp_bits > 8 || man_bits < 0) return DMXQ_ERR_BAD_ARG;
+  if (man_bits > 22) return DMXQ_ERR_UNSUPPORTED;
+  if (outer * L * inner == 0) return DMXQ_OK;
+  if (!in || !out) return DMXQ_ERR_BAD_ARG;
+  const MxfpFmt f{man_bits, exp_bits, (1 << (exp_bits - 1)) - 1, (float)ldexp(1.0, 1 << (exp_bits - 1))};
+  return dispatch_blockfmt<MxfpFmt, MxfpBlock>(in, out, dtype_in, dtype_out, outer, L, inner, block_size, f, (hipStream_t)stream);
+}

@@ -262,7 +262,7 @@ class MXINT(BlockFloatingPoint):
 
 class ScaledBlockFloatingPoint(Format):
     """SBFP<XP..><FP..>{B}: integer block elements times a low-bit float scaler (format.py:400-511).
-    Vocabulary only for now: the fused kernel is SURVEY.md §8(f) item 2 ("next")."""
+    One fused kernel (csrc/blockfmt.hip)."""
 
     blocked = True
 
@@ -276,7 +276,11 @@ class ScaledBlockFloatingPoint(Format):
         self.man_scaling = 2 ** (block_format.precision - 1) - 1
 
     def cast(self, x, block_dim: int = -1, out_dtype=torch.float32):
-        raise NotImplementedError("SBFP cast: composite block format kernels are the next scope row (SURVEY §8f-2)")
+        bf, sf = self.block_format, self.scaler_format
+        if bf.rounding != "nearest" or sf.rounding != "nearest":
+            raise NotImplementedError("SBFP: only nearest rounding (every SBFP alias of the reference) has a fused kernel")
+        return ops.sbfp_qdq(x, bf.precision, self.block_size, sf.mantissa, sf.exponent, sf.bias, sf.flush_subnormal,
+                            bf.clamp, bf.symmetric, block_dim, out_dtype=out_dtype)
 
     @property
     def bytes_per_elem(self):
@@ -301,7 +305,8 @@ class ScaledBlockFloatingPoint(Format):
 
 class MXFP(Format):
     """MXFP{p}[E{e}M{m}]{B}: low-bit float elements with a power-of-two (E8M0) block scale (format.py:514-609).
-    Vocabulary only for now."""
+    One fused kernel (csrc/blockfmt.hip); blocks run along `block_dim` as for BFP (the reference's
+    `cat(dim=block_dim)` slip is not reproduced) and an all-zero block stays zero (reference: NaN via log2(0))."""
 
     blocked = True
 
@@ -313,7 +318,8 @@ class MXFP(Format):
         self.block_size = block_size
 
     def cast(self, x, block_dim: int = -1, out_dtype=torch.float32):
-        raise NotImplementedError("MXFP cast: composite block format kernels are the next scope row (SURVEY §8f-2)")
+        ef = self.element_format
+        return ops.mxfp_qdq(x, ef.mantissa, ef.exponent, self.block_size, block_dim, out_dtype=out_dtype)
 
     @property
     def bytes_per_elem(self):

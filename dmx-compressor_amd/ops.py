@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
 
 __all__ = [
-    "bfp_qdq", "float_qdq", "fixed_qdq", "nm_mask", "nm_sparsify", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "nm_mask", "nm_sparsify", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "softmax", "layernorm",
 ]
 
@@ -47,6 +47,29 @@ def bfp_qdq(x, precision: int, block_size: int, block_dim: int = -1, symmetric: 
     check(lib().dmxq_bfp_qdq(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), outer, L, inner,
                              block_size, precision, _lib.ROUNDING_CODE[rounding], int(symmetric), seed, stream_of(xc)),
           "dmxq_bfp_qdq")
+    return out
+
+
+def sbfp_qdq(x, precision: int, block_size: int, scaler_man: int, scaler_exp: int, scaler_bias: int,
+             scaler_flush: bool = True, clamp: bool = True, symmetric: bool = True, block_dim: int = -1,
+             out_dtype: Optional[torch.dtype] = None):
+    """ScaledBlockFloatingPoint Q->DQ (numerical/format.py:453-479), one launch."""
+    xc = _prep(x, "sbfp_qdq")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    outer, L, inner = split3(xc.shape, block_dim) if xc.dim() else (1, 1, 1)
+    check(lib().dmxq_sbfp_qdq(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), outer, L, inner, block_size,
+                              precision, int(clamp), int(symmetric), scaler_man, scaler_exp, scaler_bias,
+                              int(scaler_flush), stream_of(xc)), "dmxq_sbfp_qdq")
+    return out
+
+
+def mxfp_qdq(x, man: int, exp: int, block_size: int, block_dim: int = -1, out_dtype: Optional[torch.dtype] = None):
+    """MXFP Q->DQ (numerical/format.py:545-564), one launch."""
+    xc = _prep(x, "mxfp_qdq")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    outer, L, inner = split3(xc.shape, block_dim) if xc.dim() else (1, 1, 1)
+    check(lib().dmxq_mxfp_qdq(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), outer, L, inner, block_size,
+                              man, exp, stream_of(xc)), "dmxq_mxfp_qdq")
     return out
 
 

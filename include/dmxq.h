@@ -50,6 +50,22 @@ int dmxq_abi_version(void);
 int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L, int64_t inner,
                  int64_t block_size, int precision, int rounding, int symmetric, uint64_t seed, void* stream);
 
+/* Scaled block floating point Q->DQ ("SBFP<XP[p,0](CSN)><FP[0|e|m,bias](FN)>{B}", e.g. SBFP12_16 weight storage).
+ * Replaces: numerical/format.py:453-479 ScaledBlockFloatingPoint.cast.  Per block: s = max|x| / (2^(p-1)-1);
+ * y = fixed(x / s; p, 0, clamp, symmetric, nearest) * |float(s; man, exp, bias, flush)| where s > 0, else x.
+ * Same [outer, L, inner] / ragged-tail conventions as dmxq_bfp_qdq. */
+int dmxq_sbfp_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L, int64_t inner,
+                  int64_t block_size, int precision, int clamp, int symmetric, int scaler_man_bits, int scaler_exp_bits,
+                  int scaler_exp_bias, int scaler_flush_subnormal, void* stream);
+
+/* MX floating point Q->DQ ("MXFP8[E4M3]{32}", ...): low-bit float elements with a power-of-two (E8M0) block scale.
+ * Replaces: numerical/format.py:545-564 MXFP.cast.  Per block: scale = 2^floor(log2 max|x|) / 2^(2^(e-1));
+ * y = float(x / scale; man, exp, bias = 2^(e-1)-1, no flush, nearest) * scale.  Blocks run along L as in
+ * dmxq_bfp_qdq (the reference's `cat(dim=block_dim)` slip is not reproduced); an all-zero block stays zero (the
+ * reference produces NaN through log2(0)). */
+int dmxq_mxfp_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L, int64_t inner,
+                  int64_t block_size, int man_bits, int exp_bits, void* stream);
+
 /* Low-bit floating point Q->DQ ("FP[s|e|m,bias](F|_ N|S)").
  * Replaces: numerical/format.py:208-233 FloatingPoint.cast -> quant_function.py:120-152 float_quantize
  *           -> quant_cpu.cpp:359-402 / quant_cuda/float_kernel.cu.  0 <= man_bits <= 22 (23 is UB in the

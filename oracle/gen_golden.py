@@ -273,6 +273,60 @@ def smoothquant_cases():
     np.savez_compressed(os.path.join(GOLD, "smoothquant.npz"), **store)
 
 
+# ------------------------------------------------------------------------------------------------ SBFP / MXFP
+SBFP_SH = ["SBFP<XP[4,0](CSN)><FP[0|4|4,7](FN)>{16}", "SBFP<XP[4,0](CSN)><FP[0|4|4,4](FN)>{16}",
+           "SBFP<XP[4,0](CSN)><FP[0|4|4,18](FN)>{16}", "SBFP<XP[8,0](CSN)><FP[0|5|2,15](FN)>{64}"]
+MXFP_SH = ["MXFP8[E4M3]{32}", "MXFP8[E5M2]{64}", "MXFP6[E2M3]{32}", "MXFP6[E3M2]{128}", "MXFP4[E2M1]{32}"]
+
+
+def composite_cases():
+    store = {"sbfp_sh": np.array(SBFP_SH), "mxfp_sh": np.array(MXFP_SH)}
+    xs = {"f32": make("mixed_nd", (16, 256), seed=91, dtype=torch.float32, block=16),
+          "bf16": make("mixed_nd", (16, 256), seed=92, dtype=torch.bfloat16, block=16)}
+    xz = xs["f32"].clone()
+    xz[3, 32:48] = 0.0                                           # an all-zero block: SBFP passes it through
+    xs["f32z"] = xz
+    # MXFP: no all-zero blocks (the reference turns them into NaN through log2(0); documented divergence)
+    xm = {"f32": make("heavy", (16, 256), seed=93, dtype=torch.float32), "bf16": make("normal", (16, 256), seed=94, dtype=torch.bfloat16)}
+    for k, v in xs.items():
+        store[f"sx_{k}"] = bits(v)
+    for k, v in xm.items():
+        store[f"mx_{k}"] = bits(v)
+    for i, sh in enumerate(SBFP_SH):
+        f = rnum.Format.from_shorthand(sh)
+        bf, sf = f.block_format, f.scaler_format
+        for k, x in xs.items():
+            y = rnum.CastTo(format=sh)(x)
+            o = O.cast_to(x, lambda t: O.sbfp_cast(t, bf.precision, f.block_size, sf.mantissa, sf.exponent, sf.bias,
+                                                   sf.flush_subnormal, bf.clamp, bf.symmetric))
+            check(y, o, f"{sh} {k}")
+            store[f"sbfp{i}_{k}"] = bits(y)
+    xr = make("normal", (5, 40), seed=95)                        # ragged last block + block_dim 0
+    store["sx_ragged"] = bits(xr)
+    y = rnum.CastTo(format=SBFP_SH[0])(xr)
+    check(y, O.sbfp_cast(xr, 4, 16, 4, 4, 7), "sbfp ragged")
+    store["sbfp_ragged"] = bits(y)
+    y = rnum.CastTo(format=SBFP_SH[0], block_dim=0)(xs["f32"]).contiguous()
+    check(y, O.sbfp_cast(xs["f32"], 4, 16, 4, 4, 7, block_dim=0).contiguous(), "sbfp block_dim 0")
+    store["sbfp_dim0"] = bits(y)
+    for i, sh in enumerate(MXFP_SH):
+        f = rnum.Format.from_shorthand(sh)
+        ef = f.element_format
+        for k, x in xm.items():
+            y = rnum.CastTo(format=sh)(x)
+            o = O.cast_to(x, lambda t: O.mxfp_cast(t, ef.mantissa, ef.exponent, f.block_size))
+            check(y, o, f"{sh} {k}")
+            store[f"mxfp{i}_{k}"] = bits(y)
+    np.savez_compressed(os.path.join(GOLD, "composite.npz"), **store)
+    # validation only: larger sweep
+    for seed in (1, 2, 3):
+        x = make("heavy", (64, 512), seed=seed)
+        check(rnum.CastTo(format=SBFP_SH[0])(x), O.sbfp_cast(x, 4, 16, 4, 4, 7), "sbfp sweep")
+        for sh in MXFP_SH[:3]:
+            f = rnum.Format.from_shorthand(sh)
+            check(rnum.CastTo(format=sh)(x), O.mxfp_cast(x, f.element_format.mantissa, f.element_format.exponent, f.block_size), f"{sh} sweep")
+
+
 # ------------------------------------------------------------------------------------------------ module level
 def module_cases():
     """the reference's DmxModule order of operations, captured stage by stage.
@@ -359,6 +413,7 @@ if __name__ == "__main__":
     elementwise_cases()
     nm_cases()
     smoothquant_cases()
+    composite_cases()
     module_cases()
     vocabulary()
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD)) if f.endswith(".npz")}

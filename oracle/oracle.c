@@ -235,6 +235,66 @@ int oracle_fixed_qdq(const float* in, float* out, int64_t outer, int64_t C, int6
   return 0;
 }
 
+static void fixed_min_max(int wl, int fl, int symmetric, float* t_min, float* t_max);
+static inline float fixed_q1(float a, int sigma, int rounding, float r);
+static inline float clampf(float a, float lo, float hi);
+/* ------------------------------------------------------------------------------------------- composite block formats
+ * numerical/format.py:453-479 ScaledBlockFloatingPoint.cast on a contiguous fp32 [rows, L] matrix, blocks of B along
+ * the last dim (ragged tail = torch.split).  Per block: s = max|x| / (2^(p-1)-1);  where s > 0:
+ *   y = fixed_point_quantize(x / s, wl=p, fl=0, clamp, symmetric, nearest) * |float_quantize(s, man, exp, bias, flush)|
+ * else y = x.  All fp32 (torch CPU): two IEEE divisions, the CPU fixed rounding, one product. */
+int oracle_sbfp_qdq(const float* in, float* out, int64_t rows, int64_t L, int64_t B, int p, int clamp, int symmetric,
+                    int man, int exp_bits, int bias, int flush) {
+  if (B < 1 || p < 1 || man < 0 || man > 22) return 1;
+  float t_min, t_max;
+  fixed_min_max(p, 0, symmetric, &t_min, &t_max);
+  const float man_scaling = (float)((1 << (p - 1)) - 1);
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < rows; r++)
+    for (int64_t b0 = 0; b0 < L; b0 += B) {
+      const int64_t len = (L - b0 < B) ? (L - b0) : B;
+      const float* x = in + r * L + b0;
+      float* y = out + r * L + b0;
+      float m = 0.0f;
+      for (int64_t i = 0; i < len; i++) { float a = fabsf(x[i]); if (a > m || isnan(a)) m = a; }
+      const float s = m / man_scaling;
+      if (s > 0.0f) {
+        const float sc = fabsf(float_q1(s, man, exp_bits, bias, flush, R_NEAREST, 0u));
+        for (int64_t i = 0; i < len; i++) {
+          float q = fixed_q1(x[i] / s, 0, R_NEAREST, 0.5f);
+          if (clamp) q = clampf(q, t_min, t_max);
+          y[i] = q * sc;
+        }
+      } else {
+        for (int64_t i = 0; i < len; i++) y[i] = x[i];
+      }
+    }
+  return 0;
+}
+
+/* numerical/format.py:545-564 MXFP.cast (intended layout: blocks along the last dim; the reference's
+ * cat(dim=block_dim) slip is not reproduced).  Per block: scale = 2^floor(log2(max|x|)) / 2^(2^(e-1));
+ * y = float_quantize(x / scale, man, exp, bias = 2^(e-1)-1, no flush) * scale.
+ * An all-zero block gives log2(0) = -inf, scale 0 and NaN in the reference; here it stays zero (documented). */
+int oracle_mxfp_qdq(const float* in, float* out, int64_t rows, int64_t L, int64_t B, int man, int exp_bits) {
+  if (B < 1 || man < 0 || man > 22 || exp_bits < 1 || exp_bits > 8) return 1;
+  const int bias = (1 << (exp_bits - 1)) - 1;
+  const float big = ldexpf(1.0f, 1 << (exp_bits - 1));
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < rows; r++)
+    for (int64_t b0 = 0; b0 < L; b0 += B) {
+      const int64_t len = (L - b0 < B) ? (L - b0) : B;
+      const float* x = in + r * L + b0;
+      float* y = out + r * L + b0;
+      float m = 0.0f;
+      for (int64_t i = 0; i < len; i++) { float a = fabsf(x[i]); if (a > m || isnan(a)) m = a; }
+      if (m == 0.0f) { for (int64_t i = 0; i < len; i++) y[i] = x[i] * 0.0f; continue; }
+      const float scale = powf(2.0f, floorf(log2f(m))) / big;
+      for (int64_t i = 0; i < len; i++) y[i] = float_q1(x[i] / scale, man, exp_bits, bias, 0, R_NEAREST, 0u) * scale;
+    }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------- N:M mask
  * sparse.py:163-180 BlockTopK.forward on contiguous groups of M: idx = argsort(score)[:, :M-K]; mask =
  * ones.scatter_(idx, 0).  torch.argsort on CPU behaves as a STABLE ascending sort (pinned by the golden

@@ -41,10 +41,12 @@ def lib():
         L.oracle_bfp_qdq.argtypes = [fp, fp, i64, i64, i64, i32, i32, i32, u64]
         L.oracle_fixed_qdq.argtypes = [fp, fp, i64, i64, i64, i32, i32, i32, i32, i32, fp, fp, i64, u64]
         L.oracle_nm_mask.argtypes = [fp, fp, fp, fp, i64, i32, i32]
+        L.oracle_sbfp_qdq.argtypes = [fp, fp, i64, i64, i64, i32, i32, i32, i32, i32, i32, i32]
+        L.oracle_mxfp_qdq.argtypes = [fp, fp, i64, i64, i64, i32, i32]
         L.oracle_group_minmax.argtypes = [fp, i64, i64, i64, i64, fp, fp]
         L.oracle_qparams.argtypes = [fp, fp, i64, i32, i32, i32, fp, fp]
         L.oracle_channel_maxabs.argtypes = [fp, i64, i64, i64, fp]
-        for f in ("oracle_float_qdq", "oracle_bfp_qdq", "oracle_fixed_qdq", "oracle_nm_mask",
+        for f in ("oracle_sbfp_qdq", "oracle_mxfp_qdq", "oracle_float_qdq", "oracle_bfp_qdq", "oracle_fixed_qdq", "oracle_nm_mask",
                   "oracle_group_minmax", "oracle_qparams", "oracle_channel_maxabs"):
             getattr(L, f).restype = ctypes.c_int
         _lib = L
@@ -130,6 +132,29 @@ def fixed_point_affine_cast(x, precision, fraction, clamp, symmetric, scale, zer
     _check(lib().oracle_fixed_qdq(_ptr(xi), _ptr(out), outer, C, inner, precision, fraction, int(clamp),
                                   int(symmetric), ROUNDING[rounding], _ptr(sc), _ptr(zp), gs, seed), "fixed_qdq")
     return out
+
+
+def _blocked(x, block_dim, fn):
+    """transpose block_dim to the end, flatten to [rows, L], run fn(in2d, out2d), restore (format.py:455-479 pattern)"""
+    xt = x.detach().to(torch.float32).transpose(block_dim, -1)
+    shp = xt.shape
+    x2 = xt.reshape(-1, shp[-1]).contiguous()
+    out = torch.empty_like(x2)
+    fn(x2, out)
+    return out.reshape(shp).transpose_(block_dim, -1)
+
+
+def sbfp_cast(x, precision, block_size, man, exp, bias, flush_subnormal=True, clamp=True, symmetric=True, block_dim=-1):
+    """numerical/format.py:453-479 ScaledBlockFloatingPoint.cast (fp32 result)."""
+    return _blocked(x, block_dim, lambda a, o: _check(lib().oracle_sbfp_qdq(
+        _ptr(a), _ptr(o), a.shape[0], a.shape[1], block_size, precision, int(clamp), int(symmetric), man, exp, bias,
+        int(flush_subnormal)), "sbfp_qdq"))
+
+
+def mxfp_cast(x, man, exp, block_size, block_dim=-1):
+    """numerical/format.py:545-564 MXFP.cast (fp32 result; intended block layout, zero blocks stay zero)."""
+    return _blocked(x, block_dim, lambda a, o: _check(lib().oracle_mxfp_qdq(
+        _ptr(a), _ptr(o), a.shape[0], a.shape[1], block_size, man, exp), "mxfp_qdq"))
 
 
 def cast_to(x, cast_fn):

@@ -188,6 +188,35 @@ def test_affine_group_quant_fixtures(backend, dmx):
 
 
 @pytest.mark.parametrize("backend", backends(), indirect=True)
+def test_composite_block_format_fixtures(backend, dmx, oracle):
+    """SBFP (weight-storage format) and MXFP through the reference's CastTo: format.py:453-479, 545-564."""
+    g = load("composite.npz")
+    hip = isinstance(backend, HipBackend)
+
+    def run(sh, x, dim=-1):
+        f = dmx.Format.from_shorthand(sh)
+        if hip:
+            return dmx.CastTo(format=f, block_dim=dim)(x.to(backend.dev))
+        if isinstance(f, dmx.ScaledBlockFloatingPoint):
+            bf, sf = f.block_format, f.scaler_format
+            y = oracle.sbfp_cast(x, bf.precision, f.block_size, sf.mantissa, sf.exponent, sf.bias, sf.flush_subnormal,
+                                 bf.clamp, bf.symmetric, dim)
+        else:
+            y = oracle.mxfp_cast(x, f.element_format.mantissa, f.element_format.exponent, f.block_size, dim)
+        return y.to(x.dtype).contiguous()
+
+    for i, sh in enumerate([str(s) for s in g["sbfp_sh"]]):
+        for k, dt in (("f32", torch.float32), ("bf16", torch.bfloat16), ("f32z", torch.float32)):
+            assert mism(run(sh, tensor(g[f"sx_{k}"], dt)), g[f"sbfp{i}_{k}"], dt) == 0, (sh, k)
+    sh0 = str(g["sbfp_sh"][0])
+    assert mism(run(sh0, tensor(g["sx_ragged"], torch.float32)), g["sbfp_ragged"], torch.float32) == 0
+    assert mism(run(sh0, tensor(g["sx_f32"], torch.float32), 0), g["sbfp_dim0"], torch.float32) == 0
+    for i, sh in enumerate([str(s) for s in g["mxfp_sh"]]):
+        for k, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            assert mism(run(sh, tensor(g[f"mx_{k}"], dt)), g[f"mxfp{i}_{k}"], dt) == 0, (sh, k)
+
+
+@pytest.mark.parametrize("backend", backends(), indirect=True)
 def test_nm_mask_fixtures(backend):
     g = load("nm_mask.npz")
     n = 0
