@@ -29,7 +29,7 @@
 namespace dmxq {
 
 // 16-byte vectors in flight per lane on big tensors; 8 when the output vector is 32 B (16-bit in -> fp32 out)
-template <int DTI, int DTO> struct RowsUnroll { static constexpr int big = (Elem<DTO>::bytes > Elem<DTI>::bytes) ? 8 : 16; };
+template <int DTI, int DTO> struct RowsUnroll { static constexpr int big = 16; };
 constexpr int kRowsMaxGrid = 1 << 20;
 
 // ---------------------------------------------------------------------------------------------------------
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kThreads) void bfp_generic_kernel(const void* __res
       const int64_t e = e0 + i * inner;
       // the oracle numbers random draws by the element's position in the transposed [rows, L] matrix
       const uint64_t ridx = (uint64_t)(((o * inner + j) * L) + l0 + i);
-      store1<DTO>(out, e, bfp_q1<RND, ASYM>(load1<DTI>(in, e), p, wl, rounding, stoch ? rnd_bits(seed, ridx) : 0u));
+      store1<DTO>(out, e, bfp_q1<RND, ASYM>(load1<DTI>(in, e), p, wl, rounding, rnd_if(stoch, seed, ridx)));
     }
   }
 }
@@ -67,7 +67,9 @@ __global__ __launch_bounds__(kThreads) void bfp_generic_kernel(const void* __res
 template <int DTI, int DTO, int RND, bool ASYM>
 static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64_t inner, int64_t B, int wl,
                       int rounding, uint64_t seed, hipStream_t s) {
-  constexpr int EPL = 16 / Elem<DTI>::bytes;
+  // lane-vector: 16 B of input, or 8 B when the output is wider than the input (bfp_rows.hpp IVB)
+  constexpr int IVB = (Elem<DTO>::bytes > Elem<DTI>::bytes) ? 8 : 16;
+  constexpr int EPL = IVB / Elem<DTI>::bytes;
   const int64_t n = outer * L * inner;
   const bool pow2 = (B & (B - 1)) == 0;
   // (stochastic draws are numbered by flat element index in the rows kernel, which equals the oracle's
@@ -87,7 +89,7 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
   do {                                                                                                           \
     const int64_t tiles = (n_vec + (int64_t)(T_) * (U_) - 1) / ((int64_t)(T_) * (U_));                           \
     const int grid = (int)(tiles < kRowsMaxGrid ? tiles : kRowsMaxGrid);                                         \
-    hipLaunchKernelGGL((bfp_rows_kernel<DTI, DTO, RND, ASYM, U_, MODE, T_, F_>), dim3(grid), dim3(T_), 0, s, in, \
+    hipLaunchKernelGGL((bfp_rows_kernel<DTI, DTO, RND, ASYM, U_, MODE, T_, F_, U_, IVB>), dim3(grid), dim3(T_), 0, s, in, \
                        out, n_vec, lpb, wl, rounding, seed);                                                     \
   } while (0)
 #define DMXQ_ROWS_GEOM(F_)                                                     \
@@ -156,7 +158,8 @@ extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_o
   if (precision > 22) return DMXQ_ERR_UNSUPPORTED;  // reference shifts by a negative count (UB) beyond this
   if (inner == 1) {
     // flat-stream kernel (launch_bfp) when rows are whole blocks and 16-byte aligned; otherwise LDS re-alignment
-    const int epl = dtype_in == DMXQ_F32 ? 4 : 8;
+    const bool widening = dtype_in != DMXQ_F32 && dtype_out == DMXQ_F32;  // lane-vector of 8 B, see launch_bfp
+    const int epl = (dtype_in == DMXQ_F32 || widening) ? 4 : 8;
     const bool pow2 = (block_size & (block_size - 1)) == 0;
     const bool rows_ok = L % block_size == 0 && pow2 && block_size >= epl && block_size <= 64 * epl && aligned16(in) && aligned16(out);
     if (!rows_ok) {

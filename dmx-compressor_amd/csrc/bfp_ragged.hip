@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void bfp_lds_rows_kernel(const void* __re
         const int64_t e0 = row * L + sg * seg + pos;                 // flat element index (numbers the random draws)
 #pragma unroll
         for (int k = 0; k < EPL; k++)
-          y[k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, stoch ? rnd_bits(seed, (uint64_t)(e0 + k)) : 0u);
+          y[k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, rnd_if(stoch, seed, (uint64_t)(e0 + k)));
       }
       store_out<DTO, EPL, false>(lds_out + v * OVB, pack_vec<DTO, EPL>(y));
     }

@@ -19,14 +19,16 @@ constexpr int kRowsNtLoad = 1, kRowsNtStore = 2;
 
 // one 16-byte input vector -> its packed outputs, given the block's max bits.  PATH_FAST selects the magic-add
 // arithmetic (nearest-even only); `vi` = index of the input vector (numbers the random draws).
-template <int DTI, int DTO, int RND, bool ASYM, int FAST, bool PATH_FAST>
-__device__ __forceinline__ OutVec<DTO, 16 / Elem<DTI>::bytes> bfp_rows_vector(const u32x4& raw, uint32_t mb, int64_t vi,
-                                                                            int wl, int rounding, bool stoch,
-                                                                            uint64_t seed) {
-  constexpr int EPL = 16 / Elem<DTI>::bytes;
+// EPLV = elements per lane-vector: 16 / sizeof(in), or half of that when the lane loads 8 bytes (see IVB below)
+template <int DTI, int DTO, int RND, bool ASYM, int FAST, bool PATH_FAST, int EPLV = 16 / Elem<DTI>::bytes>
+__device__ __forceinline__ OutVec<DTO, EPLV> bfp_rows_vector(const u32x4& raw, uint32_t mb, int64_t vi, int wl,
+                                                             int rounding, bool stoch, uint64_t seed) {
+  constexpr int EPL = EPLV;
   const BfpBlockParams p = bfp_block_params<ASYM, PATH_FAST>(mb, wl);
-  float x[EPL], y[EPL];
-  widen<DTI, EPL>(raw, x);
+  float xw[16 / Elem<DTI>::bytes], x[EPL], y[EPL];
+  widen<DTI, 16 / Elem<DTI>::bytes>(raw, xw);
+#pragma unroll
+  for (int k = 0; k < EPL; k++) x[k] = xw[k];
   if (PATH_FAST) {
 #pragma unroll
     for (int k = 0; k < EPL; k++) y[k] = bfp_q1_fast<FAST == 2, ASYM>(x[k], p);
@@ -34,9 +36,11 @@ __device__ __forceinline__ OutVec<DTO, 16 / Elem<DTI>::bytes> bfp_rows_vector(co
     const int64_t e0 = vi * EPL;
 #pragma unroll
     for (int k = 0; k < EPL; k++)
-      y[k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, stoch ? rnd_bits(seed, (uint64_t)(e0 + k)) : 0u);
+      y[k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, rnd_if(stoch, seed, (uint64_t)(e0 + k)));
   }
-  return pack_vec<DTO, EPL>(y);
+  // single-rounding fast path on a 16-bit input with the same 16-bit output: results are exactly representable
+  // (not for asymmetric formats: their extra code -2^(e+1) overflows fp16 at e = 15 and must round to -inf)
+  return pack_vec<DTO, EPL, PATH_FAST && FAST == 2 && DTO == DTI && !ASYM>(y);
 }
 
 // FAST: 0 = literal bit path only; 1 = magic-add path, double rounding; 2 = magic-add path, single rounding
@@ -44,28 +48,39 @@ __device__ __forceinline__ OutVec<DTO, 16 / Elem<DTI>::bytes> bfp_rows_vector(co
 // UNROLL vectors are in flight per lane; they are converted and stored in groups of GROUP: wait for the group's
 // loads, quantise all of them into registers, then issue the group's stores back to back (read bursts and write
 // bursts instead of a read/write interleave; tools/tune_bfp picks UNROLL and GROUP).
-template <int DTI, int DTO, int RND, bool ASYM, int UNROLL, int MODE, int THREADS, int FAST = 0, int GROUP = UNROLL>
+// IVB = input bytes per lane-vector: 16, or 8 when the output dtype is wider than the input (16-bit -> fp32): the
+// lane then owns 4 elements, loads 8 B and still STORES 16 contiguous bytes, so every store instruction of a wave
+// covers one contiguous KiB (32-B-per-lane outputs written as two strided 16-B halves cost ~40 % of the bandwidth).
+template <int IVB>
+__device__ __forceinline__ u32x4 load_rawv(const void* p, uint32_t off) {
+  if (IVB == 16) return load_raw16<true>(p, off);
+  const u32x2 t = __builtin_nontemporal_load((const u32x2*)((const char*)p + off));
+  return u32x4{t.x, t.y, 0u, 0u};
+}
+
+template <int DTI, int DTO, int RND, bool ASYM, int UNROLL, int MODE, int THREADS, int FAST = 0, int GROUP = UNROLL,
+          int IVB = 16>
 __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                           int64_t n_vec, int lpb_arg /*lanes per block*/, int wl,
                                                           int rounding, uint64_t seed) {
   static_assert(UNROLL % GROUP == 0, "GROUP must divide UNROLL");
   constexpr bool NTL = (MODE & kRowsNtLoad) != 0, NTS = (MODE & kRowsNtStore) != 0;
   constexpr int64_t TILE = (int64_t)THREADS * UNROLL;
-  constexpr int EPL = 16 / Elem<DTI>::bytes;
+  constexpr int EPL = IVB / Elem<DTI>::bytes;
   constexpr int OVB = EPL * Elem<DTO>::bytes;  // output bytes per input vector
   const bool stoch = (RND == kRuntimeRounding) && rounding == DMXQ_ROUND_STOCHASTIC;
   const int lpb = __builtin_amdgcn_readfirstlane(lpb_arg);
   const int64_t n_tiles = (n_vec + TILE - 1) / TILE;
-  const uint32_t lane_in = threadIdx.x * 16u, lane_out = threadIdx.x * (uint32_t)OVB;
+  const uint32_t lane_in = threadIdx.x * (uint32_t)IVB, lane_out = threadIdx.x * (uint32_t)OVB;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     // workgroup-uniform tile bases + 32-bit lane offsets
-    const char* src = (const char*)in + tile * (TILE * 16);
+    const char* src = (const char*)in + tile * (TILE * IVB);
     char* dst = (char*)out + tile * (TILE * OVB);
     const int64_t v0 = tile * TILE + threadIdx.x;
     if ((tile + 1) * TILE <= n_vec) {  // full tile (workgroup-uniform): no predicates
       u32x4 raw[UNROLL];
 #pragma unroll
-      for (int u = 0; u < UNROLL; u++) raw[u] = load_raw16<NTL>(src + u * (THREADS * 16), lane_in);
+      for (int u = 0; u < UNROLL; u++) raw[u] = load_rawv<IVB>(src + u * (THREADS * IVB), lane_in);
       __builtin_amdgcn_sched_barrier(0);  // every load is issued before any arithmetic: 16 B x UNROLL in flight per lane
 #pragma unroll
       for (int g = 0; g < UNROLL; g += GROUP) {
@@ -82,7 +97,7 @@ __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restric
         constexpr bool kFast = FAST != 0 && RND == DMXQ_ROUND_NEAREST;
 #pragma unroll
         for (int u = 0; u < GROUP; u++) {
-          o[u] = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, kFast>(raw[g + u], mb[u], v0 + (int64_t)(g + u) * THREADS, wl,
+          o[u] = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, kFast, EPL>(raw[g + u], mb[u], v0 + (int64_t)(g + u) * THREADS, wl,
                                                                    rounding, stoch, seed);
           __builtin_amdgcn_sched_barrier(0);  // vector by vector: short live ranges (4 workgroups per CU need <= 128 VGPRs)
         }
@@ -93,9 +108,9 @@ __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restric
           // o[u] would live in scratch.)
 #pragma unroll
           for (int u = 0; u < GROUP; u++) {
-            const u32x4 r = load_raw16<false>(src + (g + u) * (THREADS * 16), lane_in);
+            const u32x4 r = load_rawv<IVB>(src + (g + u) * (THREADS * IVB), lane_in);
             const uint32_t m = group_max_u32(absmax_bits<DTI>(r), lpb);
-            o[u] = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, false>(r, m, v0 + (int64_t)(g + u) * THREADS, wl, rounding,
+            o[u] = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, false, EPL>(r, m, v0 + (int64_t)(g + u) * THREADS, wl, rounding,
                                                                      stoch, seed);
           }
         }
@@ -108,9 +123,9 @@ __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restric
       for (int u = 0; u < UNROLL; u++) {
         const int64_t vi = v0 + (int64_t)u * THREADS;
         if (vi < n_vec) {
-          const u32x4 raw = load_raw16<NTL>(src + u * (THREADS * 16), lane_in);
+          const u32x4 raw = load_rawv<IVB>(src + u * (THREADS * IVB), lane_in);
           const uint32_t mb = group_max_u32(absmax_bits<DTI>(raw), lpb);
-          const OutVec<DTO, EPL> o = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, false>(raw, mb, vi, wl, rounding, stoch, seed);
+          const OutVec<DTO, EPL> o = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, false, EPL>(raw, mb, vi, wl, rounding, stoch, seed);
           store_out<DTO, EPL, NTS>(dst + u * (THREADS * OVB) + lane_out, o);
         }
       }

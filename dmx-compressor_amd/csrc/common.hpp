@@ -29,6 +29,17 @@ __device__ __forceinline__ uint32_t rnd_bits(uint64_t seed, uint64_t idx) {
   return (uint32_t)(z >> 32);
 }
 
+// random bits only when the (wave-uniform) mode is stochastic: the empty asm keeps the optimiser from turning the
+// branch into an unconditional evaluation + select (the 64-bit hash is ~25 VALU ops)
+__device__ __forceinline__ uint32_t rnd_if(bool stoch, uint64_t seed, uint64_t idx) {
+  uint32_t r = 0u;
+  if (stoch) {
+    r = rnd_bits(seed, idx);
+    asm volatile("" : "+v"(r));
+  }
+  return r;
+}
+
 // quant_cpu.cpp:211-237 round_bitwise: keep `man_bits` (0..22) mantissa bits of an fp32 bit pattern.
 // nearest == round-half-to-even on the bit pattern, written as the branch-free (half-1)+lsb form:
 // dropped > half carries, dropped < half does not, dropped == half carries iff the kept LSB is odd.
@@ -167,12 +178,17 @@ struct OutVec {
   uint32_t w[kWords];
 };
 
-template <int DT, int N>
+// EXACT16: the caller guarantees every value is exactly representable in the 16-bit output dtype (BFP results of
+// 16-bit inputs): fp16 then packs with v_cvt_pkrtz_f16_f32 (one instruction per pair; truncation == RNE when exact)
+template <int DT, int N, bool EXACT16 = false>
 __device__ __forceinline__ OutVec<DT, N> pack_vec(const float (&y)[N]) {
   OutVec<DT, N> o;
   if (DT == DMXQ_F32) {
 #pragma unroll
     for (int k = 0; k < N; k++) o.w[k] = f2u(y[k]);
+  } else if (DT == DMXQ_F16 && EXACT16) {
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) o.w[k] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y[2 * k], y[2 * k + 1]));
   } else {
 #pragma unroll
     for (int k = 0; k < N / 2; k++) o.w[k] = pack2<DT>(y[2 * k], y[2 * k + 1]);
@@ -234,7 +250,9 @@ __device__ __forceinline__ u32x4 load_raw16(const void* p, OFF byte_off) {
   return NT ? __builtin_nontemporal_load(src) : *src;
 }
 
-template <int DT, int EPL>
+// GUARD: wrap fp16 conversions in opaque().  Keep it on: besides the fma_mix issue (see opaque()), hipcc 7.2 was
+// observed to mis-select the half of the dword when it is free to fold these conversions (wrong elements).
+template <int DT, int EPL, bool GUARD = true>
 __device__ __forceinline__ void widen(const u32x4& v, float (&x)[EPL]) {
   if (DT == DMXQ_F32) {
 #pragma unroll
@@ -245,9 +263,12 @@ __device__ __forceinline__ void widen(const u32x4& v, float (&x)[EPL]) {
       if (DT == DMXQ_BF16) {
         x[2 * j] = u2f(v[j] << 16);
         x[2 * j + 1] = u2f(v[j] & 0xFFFF0000u);
-      } else {
+      } else if (GUARD) {
         x[2 * j] = half_lo(v[j]);
         x[2 * j + 1] = half_hi(v[j]);
+      } else {
+        x[2 * j] = (float)__builtin_bit_cast(_Float16, (uint16_t)(v[j] & 0xFFFFu));
+        x[2 * j + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(v[j] >> 16));
       }
     }
   }
