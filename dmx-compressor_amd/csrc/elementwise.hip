@@ -113,7 +113,11 @@ static inline int pick_mode(int64_t C, int64_t inner, int64_t group_size, int ep
   return kWalk;
 }
 
-template <int MODE>
+// SIMPLE: the integer formats of the alias tables (INT8 / INT4: fraction 0, clamped, nearest).  Then ldexp is the
+// identity, and the |a1| >= 2^23 branch of rne_minus_half cannot influence the result (such values are clamped to
+// t_min / t_max whatever they round to; +-inf likewise; NaN stays NaN through both forms), so the per-element work is
+// add, sub, rndne and the clamp.
+template <int MODE, bool SIMPLE = false>
 struct FixedOp {
   static constexpr bool kHeavy = true;
   FixedFmt f;
@@ -122,8 +126,14 @@ struct FixedOp {
   const int64_t* zp;
   __device__ __forceinline__ float q(float x, float sc, float z, int64_t e) const {
     if (MODE != kNone) x = x / sc + z;  // IEEE division, as torch CPU (cast.py:293)
-    const float r = (f.rounding == DMXQ_ROUND_STOCHASTIC) ? rnd_unit(f.seed, (uint64_t)e) : 0.5f;
-    float v = fixed_q1(x, f, r);
+    float v;
+    if (SIMPLE) {
+      v = rintf((x + 0.5f) - 0.5f);
+      v = v > f.t_max ? f.t_max : (v < f.t_min ? f.t_min : v);
+    } else {
+      const float r = (f.rounding == DMXQ_ROUND_STOCHASTIC) ? rnd_unit(f.seed, (uint64_t)e) : 0.5f;
+      v = fixed_q1(x, f, r);
+    }
     if (MODE != kNone) v = (v - z) * sc;
     return v;
   }
@@ -264,13 +274,27 @@ extern "C" int dmxq_fixed_qdq(const void* in, void* out, int dtype_in, int dtype
   const FixedFmt f{sigma, clamp ? 1 : 0, rounding, t_min, t_max, seed};
   const ChannelMap cm = make_channel_map(C, inner, group_size, n);
   hipStream_t s = (hipStream_t)stream;
-  if (!scale) return dispatch_stream(in, out, dtype_in, dtype_out, n, FixedOp<kNone>{f, cm, nullptr, nullptr}, s);
-  switch (pick_mode(C, inner, group_size, dtype_in == DMXQ_F32 ? 4 : 8)) {
-    case kTensor: return dispatch_stream(in, out, dtype_in, dtype_out, n, FixedOp<kTensor>{f, cm, scale, zero_point}, s);
-    case kUniform: return dispatch_stream(in, out, dtype_in, dtype_out, n, FixedOp<kUniform>{f, cm, scale, zero_point}, s);
-    case kLast: return dispatch_stream(in, out, dtype_in, dtype_out, n, FixedOp<kLast>{f, cm, scale, zero_point}, s);
-    default: return dispatch_stream(in, out, dtype_in, dtype_out, n, FixedOp<kWalk>{f, cm, scale, zero_point}, s);
+  const bool simple = fraction == 0 && clamp && rounding == DMXQ_ROUND_NEAREST && precision <= 22;  // |t| <= 2^21
+  const int mode = scale ? pick_mode(C, inner, group_size, dtype_in == DMXQ_F32 ? 4 : 8) : kNone;
+  const float* sc_ = scale;
+  const int64_t* zp_ = zero_point;
+#define DMXQ_FIX(M_, S_) return dispatch_stream(in, out, dtype_in, dtype_out, n, FixedOp<M_, S_>{f, cm, sc_, zp_}, s)
+  if (simple) {
+    switch (mode) {
+      case kNone: DMXQ_FIX(kNone, true);
+      case kTensor: DMXQ_FIX(kTensor, true);
+      case kUniform: DMXQ_FIX(kUniform, true);
+      default: break;  // the rarer lookup modes share the general build
+    }
   }
+  switch (mode) {
+    case kNone: DMXQ_FIX(kNone, false);
+    case kTensor: DMXQ_FIX(kTensor, false);
+    case kUniform: DMXQ_FIX(kUniform, false);
+    case kLast: DMXQ_FIX(kLast, false);
+    default: DMXQ_FIX(kWalk, false);
+  }
+#undef DMXQ_FIX
 }
 
 extern "C" int dmxq_scale_channels(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t C,
