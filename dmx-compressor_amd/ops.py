@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
 
 __all__ = [
-    "bfp_qdq", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "nm_mask", "nm_sparsify", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "bfp_pack", "bfp_unpack", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "nm_mask", "nm_sparsify", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "softmax", "layernorm",
 ]
 
@@ -47,6 +47,31 @@ def bfp_qdq(x, precision: int, block_size: int, block_dim: int = -1, symmetric: 
     check(lib().dmxq_bfp_qdq(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), outer, L, inner,
                              block_size, precision, _lib.ROUNDING_CODE[rounding], int(symmetric), seed, stream_of(xc)),
           "dmxq_bfp_qdq")
+    return out
+
+
+def bfp_pack(x, precision: int, block_size: int, symmetric: bool = True):
+    """Packed on-wire BFP of a tensor blocked along its last dim: (int8 mantissa codes, same shape; uint8 shared
+    exponents, [..., ceil(L / block_size)]).  bfp_unpack(*bfp_pack(x)) == bfp_qdq(x)."""
+    xc = _prep(x, "bfp_pack")
+    L = xc.shape[-1] if xc.dim() else 1
+    rows = xc.numel() // max(L, 1)
+    nblk = -(-L // block_size)
+    mant = torch.empty(xc.shape, dtype=torch.int8, device=xc.device)
+    exps = torch.empty(tuple(xc.shape[:-1]) + (nblk,), dtype=torch.uint8, device=xc.device)
+    check(lib().dmxq_bfp_pack(ptr(xc), dtype_code(xc.dtype), ptr(mant), ptr(exps), rows, L, block_size, precision,
+                              int(symmetric), stream_of(xc)), "dmxq_bfp_pack")
+    return mant, exps
+
+
+def bfp_unpack(mant, exps, precision: int, block_size: int, out_dtype: torch.dtype = torch.float32):
+    require_gpu(mant, "bfp_unpack")
+    m, e = mant.contiguous(), exps.contiguous()
+    L = m.shape[-1] if m.dim() else 1
+    rows = m.numel() // max(L, 1)
+    out = torch.empty(m.shape, dtype=out_dtype, device=m.device)
+    check(lib().dmxq_bfp_unpack(ptr(m), ptr(e), ptr(out), dtype_code(out_dtype), rows, L, block_size, precision,
+                                stream_of(m)), "dmxq_bfp_unpack")
     return out
 
 

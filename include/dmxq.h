@@ -66,6 +66,17 @@ int dmxq_sbfp_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_
 int dmxq_mxfp_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L, int64_t inner,
                   int64_t block_size, int man_bits, int exp_bits, void* stream);
 
+/* Packed on-wire BFP: int8 mantissa codes + one uint8 shared exponent per block (the com.microsoft::QuantizeBFP /
+ * DequantizeBFP pair the reference's export names, numerical/cast.py:34-55; type ids numerical/onnx.py).
+ * x is [rows, L] contiguous, blocks of block_size along L (ragged tail allowed); mant: int8[rows*L];
+ * exps: uint8[rows * ceil(L / block_size)] = biased fp32 exponent of the block maximum.  precision <= 8.
+ * dmxq_bfp_unpack(dmxq_bfp_pack(x)) == dmxq_bfp_qdq(x) bit for bit for blocks with a normal finite maximum
+ * (denormal / zero maxima pack to zeros, Inf/NaN maxima to exps = 255 -> NaN). */
+int dmxq_bfp_pack(const void* in, int dtype_in, int8_t* mant, uint8_t* exps, int64_t rows, int64_t L,
+                  int64_t block_size, int precision, int symmetric, void* stream);
+int dmxq_bfp_unpack(const int8_t* mant, const uint8_t* exps, void* out, int dtype_out, int64_t rows, int64_t L,
+                    int64_t block_size, int precision, void* stream);
+
 /* Low-bit floating point Q->DQ ("FP[s|e|m,bias](F|_ N|S)").
  * Replaces: numerical/format.py:208-233 FloatingPoint.cast -> quant_function.py:120-152 float_quantize
  *           -> quant_cpu.cpp:359-402 / quant_cuda/float_kernel.cu.  0 <= man_bits <= 22 (23 is UB in the

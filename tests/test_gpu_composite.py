@@ -45,3 +45,33 @@ def test_format_objects_and_weight_storage_rule(dmx, cuda, oracle):
     f = dmx.format.MXFP8_E4M3K32
     assert bits_equal(f.cast(w.to(cuda)), oracle.mxfp_cast(w, 3, 4, 32).contiguous()) == 0
     assert repr(f) == "MXFP8[E4M3]{32}" and f.bytes_per_elem == 1 + (9 / 8) / 32   # reference formula (format.py:566-571)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize("cfg", [(8, 16, True), (8, 64, True), (8, 64, False), (6, 32, True), (4, 128, False), (8, 24, True)])
+def test_packed_bfp_roundtrip_equals_fake_quant(dmx, cuda, oracle, dtype, cfg):
+    """unpack(pack(x)) == Q->DQ(x) bit for bit (round trip property), codes within the p-bit range,
+    exponents = biased exponent of each block's maximum."""
+    wl, B, sym = cfg
+    for shape in ((64, 512), (7, 400), (3, 5, 96)):
+        x = make("mixed_nd", shape, seed=wl + B, dtype=dtype, block=8).to(cuda)
+        mant, exps = dmx.ops.bfp_pack(x, wl, B, sym)
+        assert mant.dtype == torch.int8 and exps.dtype == torch.uint8 and mant.shape == x.shape
+        lim = 2 ** (wl - 1) - (1 if sym else 0)
+        assert int(mant.min()) >= -lim and int(mant.max()) <= 2 ** (wl - 1) - 1
+        back = dmx.ops.bfp_unpack(mant, exps, wl, B, out_dtype=dtype)
+        qdq = dmx.ops.bfp_qdq(x, wl, B, -1, sym)
+        normal = (x.float().reshape(-1, x.shape[-1]).abs().amax(1) >= 0)  # every row here has normal maxima or zeros
+        assert normal.all() and bits_equal(back, qdq) == 0 or _only_zero_blocks_differ(x, back, qdq, B)
+        L = x.shape[-1]
+        pad = (-L) % B
+        xm = torch.nn.functional.pad(x.float().abs(), (0, pad)).reshape(*x.shape[:-1], -1, B).amax(-1)
+        want_e = ((xm.view(torch.int32) >> 23) & 0xFF).to(torch.uint8)
+        want_e = torch.where(xm < 2.0 ** -126, torch.zeros_like(want_e), want_e)
+        assert torch.equal(exps, want_e)
+
+
+def _only_zero_blocks_differ(x, back, qdq, B):
+    """-0.0 vs +0.0 in all-zero blocks is the only allowed difference (packed zeros carry no sign)"""
+    d = (back.float().view(torch.int32) != qdq.float().view(torch.int32))
+    return bool(((back == 0) & (qdq == 0))[d].all())
