@@ -1,0 +1,156 @@
+// csrc/hypernet.hip — the fused weight hypernet.
+//
+// DmxModule.weight_hypernet (modeling/nn/core.py:178-198) runs, on EVERY forward until the weights are folded,
+//     w -> weight_sparsifier (N:M mask, x * mask) -> smoothquant.scale_weight (x * scale[c_in]) -> weight_storage_cast
+//       -> weight_cast (BFP)
+// as separate passes over the weight (score 4 B + w 2 B + y 4 B, then 4+4 B, then 4+4 B ... per element).  This kernel
+// does mask -> scale -> BFP Q->DQ in ONE pass for the Linear layout (everything along the contiguous last dim):
+// reads w (+ score, + the [C_in] scale vector), writes the quantised weight once.
+//
+// Bit-exactness with the unfused chain is kept by reproducing its dtype flow:
+//   T1 = promote(dtype(w), dtype(score)) after the mask multiply (exact: x or +-0);
+//   scale: fl32(x * s) rounded to T1 (ActivationWeightSmoothQuant.scale_weight's `.to(wgt.dtype)`);
+//   BFP nearest-even on the T1 value (bfp_math.hpp), result rounded to T1, then to dtype_out (`.to(input dtype)`).
+// Scope: inner == 1, L % B == 0, B = 2^k in [8, 512], L % 8 == 0, M in {0 (dense), 2, 4, 8}, nearest rounding.
+#include "bfp_math.hpp"
+
+namespace dmxq {
+
+__device__ __forceinline__ int32_t hn_sort_key(float s) {  // same order as nm_mask.hip sort_key
+  if (s != s) return 0x7FFFFFFF;
+  if (s == 0.0f) return 0;
+  const int32_t b = (int32_t)f2u(s);
+  return b >= 0 ? b : (int32_t)(0x80000000u - (uint32_t)b);
+}
+
+template <int DT>
+__device__ __forceinline__ void load8(const void* p, int64_t e, float (&v)[8]) {
+  if (DT == DMXQ_F32) {
+    const f32x4 a = *(const f32x4*)((const float*)p + e), b = *(const f32x4*)((const float*)p + e + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+    const u32x4 t = __builtin_nontemporal_load((const u32x4*)((const uint16_t*)p + e));
+    widen<DT, 8>(t, v);
+  }
+}
+
+template <int DT>
+__device__ __forceinline__ float round_to(float v) {  // RNE to DT and back (exact for fp32)
+  if (DT == DMXQ_BF16) return (float)(__bf16)v;
+  if (DT == DMXQ_F16) return (float)(_Float16)opaque(v);
+  return v;
+}
+
+struct HnArgs {
+  const void* w; const void* score; const float* scale; void* out;
+  int64_t n_units, L;
+  int K, lpb, wl, asym;
+};
+
+// DTW weight dtype, DTS score dtype (ignored when M == 0), DTO output dtype, M = 0 (no mask) / 2 / 4 / 8
+template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE>
+__global__ __launch_bounds__(kThreads) void hypernet_rows_kernel(HnArgs a) {
+  // T1: dtype after the mask multiply = torch promotion of (w, score); without a mask it stays the weight dtype
+  constexpr int T1 = (M == 0) ? DTW : ((DTW == DMXQ_F32 || DTS == DMXQ_F32 || DTW != DTS) ? DMXQ_F32 : DTW);
+  const int lpb = __builtin_amdgcn_readfirstlane(a.lpb);
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t u = (int64_t)blockIdx.x * kThreads + threadIdx.x; u < a.n_units; u += stride) {
+    const int64_t e0 = u * 8;
+    float x[8];
+    load8<DTW>(a.w, e0, x);
+    if (M != 0) {
+      float s[8];
+      load8<DTS>(a.score, e0, s);
+#pragma unroll
+      for (int g = 0; g < 8; g += (M ? M : 8)) {
+        int32_t key[M ? M : 1];
+        int rank[M ? M : 1];
+#pragma unroll
+        for (int i = 0; i < M; i++) { key[i] = hn_sort_key(s[g + i]); rank[i] = 0; }
+#pragma unroll
+        for (int i = 0; i < M; i++)
+#pragma unroll
+          for (int j = 0; j < i; j++) {
+            const bool j_first = key[j] <= key[i];
+            rank[i] += j_first ? 1 : 0;
+            rank[j] += j_first ? 0 : 1;
+          }
+#pragma unroll
+        for (int i = 0; i < M; i++) x[g + i] = x[g + i] * (rank[i] >= M - a.K ? 1.0f : 0.0f);  // a real multiply: -w * 0 = -0
+      }
+    }
+    if (HAS_SCALE) {
+      const int64_t c0 = e0 % a.L;
+      const f32x4 s0 = *(const f32x4*)(a.scale + c0), s1 = *(const f32x4*)(a.scale + c0 + 4);
+      const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+      for (int k = 0; k < 8; k++) x[k] = round_to<T1>(x[k] * sv[k]);
+    }
+    uint32_t mb = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) mb = max(mb, f2u(x[k]) & 0x7FFFFFFFu);
+    mb = group_max_u32(mb, lpb);
+    float y[8];
+    if (__builtin_amdgcn_ballot_w64(!bfp_fast_ok(mb, a.wl)) == 0ull) {
+      if (a.asym) { const BfpBlockParams p = bfp_block_params<true, true>(mb, a.wl);
+#pragma unroll
+        for (int k = 0; k < 8; k++) y[k] = bfp_q1_fast<false, true>(x[k], p); }
+      else { const BfpBlockParams p = bfp_block_params<false, true>(mb, a.wl);
+#pragma unroll
+        for (int k = 0; k < 8; k++) y[k] = bfp_q1_fast<false, false>(x[k], p); }
+    } else {
+      if (a.asym) { const BfpBlockParams p = bfp_block_params<true, false>(mb, a.wl);
+#pragma unroll
+        for (int k = 0; k < 8; k++) y[k] = bfp_q1<DMXQ_ROUND_NEAREST, true>(x[k], p, a.wl, DMXQ_ROUND_NEAREST, 0u); }
+      else { const BfpBlockParams p = bfp_block_params<false, false>(mb, a.wl);
+#pragma unroll
+        for (int k = 0; k < 8; k++) y[k] = bfp_q1<DMXQ_ROUND_NEAREST, false>(x[k], p, a.wl, DMXQ_ROUND_NEAREST, 0u); }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) y[k] = round_to<T1>(y[k]);   // CastTo's `.to(physical_dtype)`, then the caller's dtype
+    store_vec<DTO, 8, false>(a.out, e0, y);
+  }
+}
+
+template <int DTW, int DTS, int DTO>
+static int launch_hn(const HnArgs& a, int M, bool has_scale, hipStream_t s) {
+  const int grid = grid_for(a.n_units);
+#define DMXQ_HN(M_, S_) hipLaunchKernelGGL((hypernet_rows_kernel<DTW, DTS, DTO, M_, S_>), dim3(grid), dim3(kThreads), 0, s, a)
+  if (has_scale) { switch (M) { case 0: DMXQ_HN(0, true); break; case 2: DMXQ_HN(2, true); break; case 4: DMXQ_HN(4, true); break; default: DMXQ_HN(8, true); } }
+  else { switch (M) { case 0: DMXQ_HN(0, false); break; case 2: DMXQ_HN(2, false); break; case 4: DMXQ_HN(4, false); break; default: DMXQ_HN(8, false); } }
+#undef DMXQ_HN
+  return launch_status();
+}
+
+}  // namespace dmxq
+
+using namespace dmxq;
+
+extern "C" int dmxq_weight_hypernet(const void* w, int dtype_w, const void* score, int dtype_score, int K, int M,
+                                    const float* sq_scale, void* out, int dtype_out, int64_t rows, int64_t L,
+                                    int64_t block_size, int precision, int symmetric, void* stream) {
+  if (!valid_dtype(dtype_w) || !valid_dtype(dtype_out) || rows < 0 || L < 0 || block_size < 1) return DMXQ_ERR_BAD_ARG;
+  if (M != 0 && (!score || !valid_dtype(dtype_score) || K < 1 || K > M)) return DMXQ_ERR_BAD_ARG;
+  const int64_t B = block_size;
+  // fusable geometry; anything else is the caller's job to run unfused
+  if (!(M == 0 || M == 2 || M == 4 || M == 8) || (B & (B - 1)) != 0 || B < 8 || B > 512 || L % B != 0 || L % 8 != 0 ||
+      precision < 2 || precision > 20)
+    return DMXQ_ERR_UNSUPPORTED;
+  if (rows * L == 0) return DMXQ_OK;
+  if (!w || !out || !aligned16(w) || !aligned16(out) || (score && !aligned16(score)) || (sq_scale && !aligned16(sq_scale)))
+    return w && out ? DMXQ_ERR_UNSUPPORTED : DMXQ_ERR_BAD_ARG;
+  const HnArgs a{w, score, sq_scale, out, rows * L / 8, L, K, (int)(B / 8), precision, symmetric ? 0 : 1};
+  hipStream_t s = (hipStream_t)stream;
+  const int ds = M ? dtype_score : dtype_w;
+#define DMXQ_DT(W_, S_, O_) \
+  if (dtype_w == W_ && ds == S_ && dtype_out == O_) return launch_hn<W_, S_, O_>(a, M, sq_scale != nullptr, s);
+  DMXQ_DT(DMXQ_BF16, DMXQ_F32, DMXQ_BF16)   // bf16 weight, fp32 score Parameter, result straight to the matmul dtype
+  DMXQ_DT(DMXQ_BF16, DMXQ_F32, DMXQ_F32)    // ... or fp32, the reference's `_weight` dtype in this case
+  DMXQ_DT(DMXQ_BF16, DMXQ_BF16, DMXQ_BF16)  // dense / |w| score
+  DMXQ_DT(DMXQ_F16, DMXQ_F32, DMXQ_F16)
+  DMXQ_DT(DMXQ_F16, DMXQ_F32, DMXQ_F32)
+  DMXQ_DT(DMXQ_F16, DMXQ_F16, DMXQ_F16)
+  DMXQ_DT(DMXQ_F32, DMXQ_F32, DMXQ_F32)
+#undef DMXQ_DT
+  return DMXQ_ERR_UNSUPPORTED;
+}

@@ -118,9 +118,47 @@ class DmxModule(torch.nn.Module):
         return self.weight_sparsifier.sparseness if self.weight_sparsifier is not None else None
 
     # ------------------------------------------------------------------ weight path (core.py:178-213)
+    #: use the single-kernel weight path (csrc/hypernet.hip) when the configuration allows it; results are bit-identical
+    fuse_weight_hypernet = True
+
+    def _fused_weight(self, _w):
+        """mask -> SmoothQuant scale -> BFP in ONE launch, or None when this configuration must take the chain:
+        inference only (no autograd through the fused op), everything along the last dim (Linear layout),
+        BlockTopK or Dense sparseness, SAME storage format, plain BFP weight format with nearest rounding."""
+        from .format import BlockFloatingPoint
+        from .sparse import BlockTopK
+        if not self.fuse_weight_hypernet or self.weight_cast is None or torch.is_grad_enabled() and _w.requires_grad:
+            return None
+        wc, st = self.weight_cast, self.weight_storage_cast
+        fmt = wc.format
+        if (not isinstance(fmt, BlockFloatingPoint) or fmt.rounding != "nearest" or fmt.block_size < 8 or wc.pre_transform
+                or wc.block_dim not in (-1, _w.dim() - 1) or wc.fake_quant_enabled[0] != 1 or wc.observer_enabled[0] == 1):
+            return None
+        if st is not None and not (isinstance(st.format, Same) and not st.pre_transform):
+            return None
+        sp, score, K, M = self.weight_sparsifier, None, 0, 0
+        if sp is not None and not isinstance(sp.sparseness, Dense):
+            if not isinstance(sp.sparseness, BlockTopK) or sp.sparseness.block_dim not in (-1, _w.dim() - 1) or sp.plastic \
+                    or sp.score.shape != _w.shape or self.training:
+                return None
+            score, K, M = sp.score.detach(), sp.sparseness.K, sp.sparseness.block_size
+        sq = None
+        if self.smoothquant is not None and self.smoothquant.fused_to_weight[0] == 0 and self.smoothquant.enabled[0] == 1:
+            if self.smoothquant.win_ch_axis not in (-1, _w.dim() - 1):
+                return None
+            sq = self.smoothquant.scale
+        from . import ops
+        y = ops.weight_hypernet(_w.detach(), fmt.precision, fmt.block_size, fmt.symmetric, score, K, M, sq)
+        if y is not None and sp is not None and M:
+            sp.mask = None  # not materialised on the fused path
+        return y
+
     @property
     def weight_hypernet(self):
         def _weight_hypernet(_w):
+            fused = self._fused_weight(_w)
+            if fused is not None:
+                return fused
             if self.weight_sparsifier is not None:
                 _w = self.weight_sparsifier(_w)
             if self.smoothquant is not None and self.smoothquant.fused_to_weight[0] == 0:

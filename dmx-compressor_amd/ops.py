@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
 
 __all__ = [
-    "bfp_qdq", "bfp_pack", "bfp_unpack", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "nm_mask", "nm_sparsify", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "bfp_pack", "bfp_unpack", "weight_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "nm_mask", "nm_sparsify", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "softmax", "layernorm",
 ]
 
@@ -72,6 +72,31 @@ def bfp_unpack(mant, exps, precision: int, block_size: int, out_dtype: torch.dty
     out = torch.empty(m.shape, dtype=out_dtype, device=m.device)
     check(lib().dmxq_bfp_unpack(ptr(m), ptr(e), ptr(out), dtype_code(out_dtype), rows, L, block_size, precision,
                                 stream_of(m)), "dmxq_bfp_unpack")
+    return out
+
+
+def weight_hypernet(w, precision: int, block_size: int, symmetric: bool = True, score=None, K: int = 0, M: int = 0,
+                    sq_scale=None, out_dtype: Optional[torch.dtype] = None):
+    """Fused N:M mask -> SmoothQuant scale -> BFP Q->DQ over a weight blocked along its last dim (one launch).
+    Returns None when the geometry / dtype combination is not fusable (the caller runs the unfused chain)."""
+    wc = _prep(w, "weight_hypernet")
+    L = wc.shape[-1] if wc.dim() else 1
+    rows = wc.numel() // max(L, 1)
+    sc = _prep(score, "weight_hypernet") if (score is not None and M) else None
+    if sc is not None and sc.shape != wc.shape:
+        return None
+    t1 = torch.promote_types(wc.dtype, sc.dtype) if sc is not None else wc.dtype
+    od = out_dtype or t1
+    out = torch.empty(wc.shape, dtype=od, device=wc.device)
+    sq = sq_scale.detach().to(device=wc.device, dtype=torch.float32).contiguous() if sq_scale is not None else None
+    if sq is not None and sq.numel() != L:
+        return None
+    rc = lib().dmxq_weight_hypernet(ptr(wc), dtype_code(wc.dtype), ptr(sc), dtype_code(sc.dtype) if sc is not None else 0,
+                                    K, M if sc is not None else 0, ptr(sq), ptr(out), dtype_code(od), rows, L, block_size,
+                                    precision, int(symmetric), stream_of(wc))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    check(rc, "dmxq_weight_hypernet")
     return out
 
 

@@ -126,6 +126,18 @@ int dmxq_smoothquant_scale(const float* a_maxabs, const float* b_maxabs, int64_t
 int dmxq_scale_channels(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t C,
                         int64_t inner, const float* scale, int divide, void* stream);
 
+/* Fused weight hypernet: N:M mask -> SmoothQuant weight scale -> BFP Q->DQ in one pass over a [rows, L] weight.
+ * Replaces the chain of modeling/nn/core.py:178-198 (weight_sparsifier -> smoothquant.scale_weight ->
+ * weight_cast) that DmxModule re-runs on every forward, for the Linear layout (mask groups, scale channels and
+ * BFP blocks all along the contiguous last dim).  M = 0: no mask (score ignored); sq_scale = NULL: no scaling
+ * (else float[L], one per input channel).  Results are bit-identical to the unfused chain, whose intermediate
+ * dtypes are reproduced (see csrc/hypernet.hip).  Returns DMXQ_ERR_UNSUPPORTED for geometries it does not fuse
+ * (L % block_size != 0, block_size not a power of two in [8,512], M not in {0,2,4,8}, unaligned pointers,
+ * dtype combination outside {w,score,out}: the caller then runs the unfused ops). */
+int dmxq_weight_hypernet(const void* w, int dtype_w, const void* score, int dtype_score, int K, int M,
+                         const float* sq_scale, void* out, int dtype_out, int64_t rows, int64_t L, int64_t block_size,
+                         int precision, int symmetric, void* stream);
+
 /* Approximator-slot ops.  The reference evaluates the exact torch.nn.functional op and then overwrites it with a
  * vsimd approximation that lives in a private package (functional/approximate.py:9-14, 300-327); with vsimd
  * absent (the public reference) the exact function is the result, and that is what these compute, in fp32.

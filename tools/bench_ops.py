@@ -120,6 +120,14 @@ def main():
             lambda i: L.dmxq_nm_mask(vp(ss[i].data_ptr()), _lib.F32, vp(xs[i].data_ptr()), _lib.BF16, None, 0, vp(ys[i].data_ptr()), _lib.BF16, R, C, 1, K_, M_, sp), k2, n * 8)
     run("nm_sparsify 2:4 bf16 score(|w|) -> bf16 y",
         lambda i: L.dmxq_nm_mask(vp(xs[i].data_ptr()), _lib.BF16, vp(xs[i].data_ptr()), _lib.BF16, None, 0, vp(ys[i].data_ptr()), _lib.BF16, R, C, 1, 2, 4, sp), k, n * 4)
+    # ---------------------------------------------------------------- fused weight hypernet (mask -> scale -> BFP)
+    sq = (torch.rand(C, device=dev) + 0.5)
+    run("weight_hypernet 2:4 mask + BFP16_64, bf16 w, fp32 score -> bf16 (vs 3 unfused passes)",
+        lambda i: L.dmxq_weight_hypernet(vp(xs[i].data_ptr()), _lib.BF16, vp(ss[i % k2].data_ptr()), _lib.F32, 2, 4, None, vp(ys[i].data_ptr()), _lib.BF16, R, C, 64, 8, 1, sp), k2, n * 8)
+    run("weight_hypernet 2:4 mask + SmoothQuant scale + BFP16_64 -> bf16",
+        lambda i: L.dmxq_weight_hypernet(vp(xs[i].data_ptr()), _lib.BF16, vp(ss[i % k2].data_ptr()), _lib.F32, 2, 4, vp(sq.data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, R, C, 64, 8, 1, sp), k2, n * 8)
+    run("weight_hypernet dense + SmoothQuant scale + BFP16_64, bf16 -> bf16",
+        lambda i: L.dmxq_weight_hypernet(vp(xs[i].data_ptr()), _lib.BF16, None, 0, 0, 0, vp(sq.data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, R, C, 64, 8, 1, sp), k, n * 4)
     # ---------------------------------------------------------------- reductions
     mn = torch.empty(R, device=dev)
     mx = torch.empty(R, device=dev)
