@@ -14,22 +14,29 @@ namespace dmxq {
 constexpr int kRaggedLdsBytes = 32 * 1024;  // per workgroup: 4-5 workgroups per CU of the 160 KiB, phases of different workgroups overlap
 constexpr int64_t kRaggedSeg = 4096;        // elements per row segment (rows longer than this are cut at multiples of B)
 
-// all slots of a batch: item (row, segment) <-> LDS slot j; threads are spread over (slot, chunk) pairs
+// all slots of a batch: item (row, segment) <-> LDS slot j.  Threads form a (slot, chunk) grid whose chunk extent is
+// a power of two, so the mapping needs shifts only (no per-access division); nseg == 1 (rows that fit one segment,
+// the common case) skips the item -> (row, segment) division as well.
 template <int CW, bool TO_LDS>
 __device__ __forceinline__ void copy_slots_w(char* lds, char* glb, int eb, int64_t it0, int64_t nit, int64_t nseg,
                                              int64_t seg, int64_t segp, int64_t L) {
-  const int64_t cps = (seg * eb + CW - 1) / CW;  // chunks per full segment
-  for (int64_t idx = threadIdx.x; idx < nit * cps; idx += kThreads) {
-    const int64_t j = idx / cps, c = idx % cps;
-    const int64_t item = it0 + j, row = item / nseg, sg = item % nseg;
+  const uint32_t cps = (uint32_t)((seg * eb + CW - 1) / CW);  // chunks per full segment
+  uint32_t cp_log = 0;
+  while ((1u << cp_log) < cps && cp_log < 8) cp_log++;         // chunk lanes = 2^cp_log <= 256
+  const uint32_t tc = threadIdx.x & ((1u << cp_log) - 1u), tj = threadIdx.x >> cp_log, nj = kThreads >> cp_log;
+  for (int64_t j = tj; j < nit; j += nj) {
+    const int64_t item = it0 + j;
+    const int64_t row = nseg == 1 ? item : item / nseg, sg = nseg == 1 ? 0 : item % nseg;
     const int64_t len = (L - sg * seg < seg) ? (L - sg * seg) : seg;
-    if (c * CW < len * eb) {
-      char* l = lds + j * segp * eb + c * CW;
-      char* g = glb + (row * L + sg * seg) * eb + c * CW;
-      if (CW == 16) { if (TO_LDS) *(u32x4*)l = *(const u32x4*)g; else *(u32x4*)g = *(const u32x4*)l; }
-      else if (CW == 8) { if (TO_LDS) *(u32x2*)l = *(const u32x2*)g; else *(u32x2*)g = *(const u32x2*)l; }
-      else if (CW == 4) { if (TO_LDS) *(uint32_t*)l = *(const uint32_t*)g; else *(uint32_t*)g = *(const uint32_t*)l; }
-      else { if (TO_LDS) *(uint16_t*)l = *(const uint16_t*)g; else *(uint16_t*)g = *(const uint16_t*)l; }
+    const uint32_t nch = (uint32_t)((len * eb + CW - 1) / CW);
+    char* l = lds + j * segp * eb;
+    char* g = glb + (row * L + sg * seg) * eb;
+    for (uint32_t c = tc; c < nch; c += (1u << cp_log)) {
+      const uint32_t off = c * CW;
+      if (CW == 16) { if (TO_LDS) *(u32x4*)(l + off) = __builtin_nontemporal_load((const u32x4*)(g + off)); else __builtin_nontemporal_store(*(const u32x4*)(l + off), (u32x4*)(g + off)); }
+      else if (CW == 8) { if (TO_LDS) *(u32x2*)(l + off) = *(const u32x2*)(g + off); else *(u32x2*)(g + off) = *(const u32x2*)(l + off); }
+      else if (CW == 4) { if (TO_LDS) *(uint32_t*)(l + off) = *(const uint32_t*)(g + off); else *(uint32_t*)(g + off) = *(const uint32_t*)(l + off); }
+      else { if (TO_LDS) *(uint16_t*)(l + off) = *(const uint16_t*)(g + off); else *(uint16_t*)(g + off) = *(const uint16_t*)(l + off); }
     }
   }
 }
@@ -66,12 +73,15 @@ __global__ __launch_bounds__(kThreads) void bfp_lds_rows_kernel(const void* __re
     const int64_t nit = (items - it0 < R) ? (items - it0) : R;
     // 1. HBM -> LDS (threads spread over all slots of the batch), zero padding up to the slot pitch
     copy_slots<true>(cw_in, lds_in, (char*)in, IB, it0, nit, nseg, seg, segp, L);
-    {
-      for (int64_t idx = threadIdx.x; idx < nit * (int64_t)B; idx += kThreads) {  // at most B-1 real pad elements + short last segment
-        const int64_t j = idx / B, k = idx % B;
-        const int64_t item = it0 + j, sg = item % nseg;
+    {  // pad [len, segp) of every slot with zeros: at most B-1 elements, plus the shortfall of a row's last segment
+      uint32_t b_log = 0;
+      while ((1u << b_log) < (uint32_t)B) b_log++;               // B is a power of two <= 512
+      const uint32_t bl = b_log > 8 ? 8 : b_log;
+      const uint32_t tk = threadIdx.x & ((1u << bl) - 1u), tj = threadIdx.x >> bl, nj = kThreads >> bl;
+      for (int64_t j = tj; j < nit; j += nj) {
+        const int64_t sg = nseg == 1 ? 0 : (it0 + j) % nseg;
         const int64_t len = (L - sg * seg < seg) ? (L - sg * seg) : seg;
-        for (int64_t e = len + k; e < segp; e += B) {
+        for (int64_t e = len + tk; e < segp; e += (1u << bl)) {
           if (IB == 2) *(uint16_t*)(lds_in + (j * segp + e) * 2) = 0; else *(uint32_t*)(lds_in + (j * segp + e) * 4) = 0u;
         }
       }
