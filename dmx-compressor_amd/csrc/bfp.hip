@@ -77,8 +77,10 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
   if (inner == 1 && L % B == 0 && pow2 && B >= EPL && B <= 64 * EPL && aligned16(in) && aligned16(out)) {
     // Geometry (tools/tune_bfp, profiles/): workgroup-contiguous tiles of THREADS*UNROLL 16-byte vectors,
     // non-temporal loads and stores, every load of a tile in flight before the arithmetic starts, stores in
-    // one burst.  Big tensors: 512 x 16 (128 KiB of bf16 per workgroup; 4096x4096 bf16 = 256 tiles = one per
-    // CU); smaller ones trade bytes in flight for enough workgroups to cover the 256 CUs.
+    // one burst.  When the tensor is ONE round of 512 x 16 tiles (128 KiB of bf16 per workgroup; 4096x4096 bf16 =
+    // 256 tiles = one per CU) that shape wins (73 % of roofline); with several rounds per CU the rounds run in
+    // lockstep (read phase, compute, write phase), so bigger tensors take 256 x 4 tiles, whose many workgroups
+    // desynchronise and overlap reads with writes (77 %), and small ones 256 x 1 to cover the 256 CUs.
     constexpr int MODE = kRowsNtLoad | kRowsNtStore;
     constexpr int UB = RowsUnroll<DTI, DTO>::big;
     const int64_t n_vec = n / EPL;
@@ -92,11 +94,12 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
     hipLaunchKernelGGL((bfp_rows_kernel<DTI, DTO, RND, ASYM, U_, MODE, T_, F_, U_, IVB>), dim3(grid), dim3(T_), 0, s, in, \
                        out, n_vec, lpb, wl, rounding, seed);                                                     \
   } while (0)
-#define DMXQ_ROWS_GEOM(F_)                                                     \
-  do {                                                                         \
-    if (n_vec >= (int64_t)256 * 512 * UB) DMXQ_ROWS(512, UB, F_);              \
-    else if (n_vec >= (int64_t)512 * 256 * 4) DMXQ_ROWS(256, 4, F_);           \
-    else DMXQ_ROWS(256, 1, F_);                                                \
+#define DMXQ_ROWS_GEOM(F_)                                                                         \
+  do {                                                                                             \
+    const int64_t big_tiles = (n_vec + (int64_t)512 * UB - 1) / ((int64_t)512 * UB);               \
+    if (big_tiles <= 256 && big_tiles >= 224) DMXQ_ROWS(512, UB, F_); /* ONE full round, 1 WG per CU */ \
+    else if (n_vec >= (int64_t)256 * 256 * 4) DMXQ_ROWS(256, 4, F_);  /* many rounds: small tiles desynchronise */ \
+    else DMXQ_ROWS(256, 1, F_);                                                                    \
   } while (0)
     // instantiate only what can run (see bfp_cols.hip): literal path for the runtime-rounding build, magic-add for
     // nearest-even; nearest with wl > 20 is routed to the runtime-rounding build by dispatch_mode

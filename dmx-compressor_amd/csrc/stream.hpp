@@ -95,8 +95,9 @@ static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hip
     if (tiles > (1 << 20)) tiles = 1 << 20;                                                                       \
     hipLaunchKernelGGL((stream_kernel<DTI, DTO, U_, T_, OP>), dim3((unsigned)tiles), dim3(T_), 0, s, in, out, n, op); \
   } while (0)
-  if (!OpHeavy<OP>::value && n_vec >= (int64_t)256 * 512 * UB) DMXQ_STREAM(512, UB);
-  else if (n_vec >= (int64_t)512 * 256 * 4) DMXQ_STREAM(256, 4);
+  const int64_t big_tiles = (n_vec + (int64_t)512 * UB - 1) / ((int64_t)512 * UB);
+  if (!OpHeavy<OP>::value && big_tiles <= 256 && big_tiles >= 224) DMXQ_STREAM(512, UB);  // one full round (bfp.hip)
+  else if (n_vec >= (int64_t)256 * 256 * 4) DMXQ_STREAM(256, 4);
   else DMXQ_STREAM(256, 1);
 #undef DMXQ_STREAM
   return launch_status();

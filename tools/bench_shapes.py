@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""tools/bench_shapes.py — BFP16 Q->DQ (bf16 -> bf16) over the secondary shapes of SURVEY.md §8(d): Llama-3-8B and
+opt-125m weight shapes, activation shapes, B in {16, 64}.  Eager C-ABI launches (tiny tensors are therefore host-launch-bound: ~2 us per call) that rotate over enough buffers to exceed the Infinity Cache where the tensor allows it."""
+import ctypes
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from dmx_compressor_amd import _lib  # noqa: E402
+
+SHAPES = [(4096, 4096), (14336, 4096), (4096, 14336), (1024, 4096), (128256, 4096), (16384, 4096), (2048, 14336), (768, 768),
+          (3072, 768), (768, 3072), (50272, 768), (12 * 1500, 1500), (1500, 768), (64, 4096), (120, 400)]
+
+
+def main():
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    vp = ctypes.c_void_p
+    stream = torch.cuda.Stream()
+    sp = vp(stream.cuda_stream)
+    print(f"{'shape':>16s} {'B':>4s} {'us':>9s} {'GB/s':>9s} {'%8TB/s':>7s}  nbuf")
+    for R, C in SHAPES:
+        torch.cuda.empty_cache()
+        n = R * C
+        nbuf = max(2, min(16, math.ceil(600 * 2 ** 20 / (n * 4))))
+        xs = [(torch.randn(R, C, device=dev) * torch.exp(2 * torch.randn(R, C, device=dev))).to(torch.bfloat16) for _ in range(nbuf)]
+        ys = [torch.empty_like(x) for x in xs]
+        for B in (16, 64):
+            iters = 200
+            with torch.cuda.stream(stream):
+                def launch(i):
+                    rc = L.dmxq_bfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, R, C, 1, B, 8, 2, 1, 0, sp)
+                    assert rc == 0
+                for i in range(100):   # long warm-up: clocks and caches settle (10 launches read 10-30 % slow)
+                    launch(i % nbuf)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for i in range(iters):   # eager C-ABI launches (a hipGraph replay of big kernels measured ~30 % slower here)
+                    launch(i % nbuf)
+                e1.record(stream)
+                torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            gbs = n * 4 / (us * 1e-6) / 1e9
+            print(f"{R:>9d}x{C:<6d} {B:>4d} {us:9.2f} {gbs:9.1f} {100 * gbs / 8000:6.1f}%  {nbuf}", flush=True)
+        del xs, ys
+        torch.cuda.empty_cache()  # fresh allocations per shape: blocks carved out of a fragmented cache measured up to 50 % slower
+
+
+if __name__ == "__main__":
+    main()
