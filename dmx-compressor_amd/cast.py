@@ -185,8 +185,11 @@ class CastTo(torch.nn.Module):
         pt = self.pre_transform
         if "shaping" in pt:
             x, inverse_shaping = self.apply_shaping_seq(x, pt["shaping"])
-        if "noquant_shortcut" in pt:
-            shortcut = x[pt["noquant_shortcut"]].clone()
+        sc_idx = pt.get("noquant_shortcut")
+        if isinstance(sc_idx, list):  # the reference indexes with the list itself (a multi-dim index); spelled as a tuple
+            sc_idx = tuple(sc_idx)
+        if sc_idx is not None:
+            shortcut = x[sc_idx].clone()
         if "format" in pt:
             x = CastToFormat.apply(x, pt["format"], self.block_dim, torch.float32)
         if self.observer_enabled[0] == 1 and x is not None and not isinstance(self.format, Same):
@@ -199,7 +202,7 @@ class CastTo(torch.nn.Module):
                                 "not part of the accelerated hot path")
         if shortcut is not None:
             x = x.clone() if x.dtype == self.physical_dtype else x.to(self.physical_dtype)
-            x[pt["noquant_shortcut"]] = shortcut.to(x.dtype)
+            x[sc_idx] = shortcut.to(x.dtype)
         if inverse_shaping is not None:
             x, _ = self.apply_shaping_seq(x, inverse_shaping)
         return x.to(self.physical_dtype)

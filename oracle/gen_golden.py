@@ -395,6 +395,26 @@ def module_cases():
     sq.smoothquant.enable()
     store["sq_score"], store["sq_scale"] = bits(sq.weight_sparsifier.score.detach()), bits(sq.smoothquant.scale.detach().float())
     capture("sq", sq, xs)
+    # tests/test_flexible_quant.py:14-86 compositions: pre_weight_transform {format, shaping}, noquant_shortcut on ResAdd
+    flin = rnn.Linear(10, 20, bias=False)
+    flin.weight.data = make("normal", (20, 10), seed=101) * 0.3
+    xf = torch.from_numpy(np.random.RandomState(0).rand(5, 10).astype(np.float32))
+    store["flex_w"], store["flex_x"] = bits(flin.weight.detach()), bits(xf)
+    cfg1 = dict(input_formats=[ref.format.BFP16A_64], weight_format=ref.format.BFP16A_64, output_formats=[ref.format.FLOAT16],
+                pre_weight_transform={"format": ref.format.FLOAT16})
+    flin.configure(cfg1)
+    store["flex_wq1"] = bits(flin._weight.detach().contiguous())
+    cfg2 = dict(cfg1, pre_weight_transform={"format": ref.format.FLOAT16, "shaping": [("permute", (1, 0)), ("view", (10, 5, 4))]})
+    flin.configure(cfg2)
+    store["flex_wq2"] = bits(flin._weight.detach().contiguous())
+    radd = rnn.ResAdd()
+    radd.configure(dict(input_formats=[ref.format.INT8, ref.format.INT8], output_formats=[ref.format.INT8],
+                        pre_input_transform=[{"noquant_shortcut": [slice(0, 1)]}, {"noquant_shortcut": [slice(0, 1)]}],
+                        pre_output_transform=[{"noquant_shortcut": [slice(0, 1)]}]))
+    lhs = make("normal", (5, 20), seed=102) * 3
+    rhs = make("normal", (5, 20), seed=103) * 3
+    with torch.no_grad():
+        store["flex_lhs"], store["flex_rhs"], store["flex_add"] = bits(lhs), bits(rhs), bits(radd(lhs, rhs).contiguous())
     np.savez_compressed(os.path.join(GOLD, "modules.npz"), **store)
 
 
