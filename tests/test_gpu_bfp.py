@@ -254,3 +254,47 @@ def test_error_behaviour(dmx, cuda):
         dmx.ops.bfp_qdq(torch.randn(4, 16, device=cuda), 24, 16)            # reference UB region
     with pytest.raises(TypeError):
         dmx.ops.bfp_qdq(torch.zeros(4, 16, device=cuda, dtype=torch.int32), 8, 16)
+
+
+def test_inplace_through_the_c_abi(dmx, cuda, oracle):
+    """include/dmxq.h: `in` and `out` may alias exactly.  Every layout path (flat rows, column blocks, ragged/LDS,
+    generic) and the elementwise / mask kernels, called with out == in."""
+    import ctypes
+    from dmx_compressor_amd import _lib
+    L = _lib.lib()
+    vp = ctypes.c_void_p
+    s = vp(torch.cuda.current_stream().cuda_stream)
+    for shape, dim, B in (((64, 512), -1, 16), ((4, 64, 48), 1, 16), ((7, 400), -1, 64), ((5, 84), -1, 24)):
+        x = make("heavy", shape, seed=B, dtype=torch.bfloat16)
+        want = oracle.bfp_cast(x, 8, B, dim).to(torch.bfloat16).contiguous()
+        t = x.to(cuda).contiguous()
+        outer, Ld, inner = _lib.split3(t.shape, dim)
+        assert L.dmxq_bfp_qdq(vp(t.data_ptr()), vp(t.data_ptr()), _lib.BF16, _lib.BF16, outer, Ld, inner, B, 8, 2, 1, 0, s) == 0
+        assert bits_equal(t, want) == 0, (shape, dim, B)
+    x = make("heavy", (1000,), seed=1)
+    t = x.to(cuda)
+    assert L.dmxq_float_qdq(vp(t.data_ptr()), vp(t.data_ptr()), _lib.F32, _lib.F32, 1000, 3, 4, 7, 0, 0, 2, 0, s) == 0
+    assert bits_equal(t, oracle.float_quantize(x, 3, 4, 7, False)) == 0
+    sc = make("normal", (64, 64), seed=2)
+    t = sc.to(cuda)
+    assert L.dmxq_nm_mask(vp(t.data_ptr()), _lib.F32, vp(t.data_ptr()), _lib.F32, None, 0, vp(t.data_ptr()), _lib.F32, 64, 64, 1, 2, 4, s) == 0
+    assert bits_equal(t, oracle.sparsify(sc, sc, 2, 4)) == 0
+
+
+def test_more_than_2_to_the_31_elements(dmx, cuda):
+    """64-bit sizes (the reference's kernels take `int size`): a 2^31 + 2^20 element bf16 tensor; the rows beyond the
+    32-bit boundary must equal the same rows quantised on their own (shard invariance, no oracle needed)."""
+    free, _ = torch.cuda.mem_get_info()
+    n_rows = (1 << 19) + 256           # x 4096 columns = 2^31 + 2^20 elements, 4 GiB per tensor
+    if free < 3 * n_rows * 4096 * 2:
+        pytest.skip("not enough free device memory")
+    base = make("heavy", (256, 4096), seed=11, dtype=torch.bfloat16).to(cuda)
+    x = base.repeat(n_rows // 256, 1)
+    assert x.numel() > 2 ** 31
+    q = dmx.ops.bfp_qdq(x, 8, 16)
+    ref = dmx.ops.bfp_qdq(base, 8, 16)
+    assert torch.equal(q[-256:], ref) and torch.equal(q[:256], ref) and torch.equal(q[(1 << 19) - 256:(1 << 19)], ref)
+    f = dmx.ops.float_qdq(x, 10, 5, 15, True)
+    assert torch.equal(f[-256:], dmx.ops.float_qdq(base, 10, 5, 15, True))
+    del x, q, f
+    torch.cuda.empty_cache()
