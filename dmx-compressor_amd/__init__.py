@@ -14,7 +14,7 @@ from .format import (ROUNDING_MODE, BlockFloatingPoint, FixedPoint, FloatingPoin
 from . import nn
 from .approximate import Approximate, ApproximationFunction, NoApproximation, TorchFunctionApproximation
 from .nn import DmxConfigRule, DmxModule, configure_model
-from .observer import DummyObserver, HistogramObserver, MinMaxObserver
+from .observer import DummyObserver, HistogramObserver, MinMaxObserver, PercentileObserver
 from .smoothquant import ActivationWeightSmoothQuant
 from .config import apply_legacy_config, load_legacy_config
 from .sparse import Bernoulli, BlockTopK, Dense, Sparseness, Sparsify, TopK

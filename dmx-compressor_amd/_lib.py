@@ -33,6 +33,7 @@ SIGNATURES = {
     "dmxq_nm_mask": [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_group_minmax": [_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "dmxq_qparams": [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
+    "dmxq_histc": [_vp, _i32, _i64, _i64, _f32, _f32, _vp, _vp],
     "dmxq_channel_maxabs": [_vp, _i32, _i64, _i64, _i64, _vp, _vp],
     "dmxq_smoothquant_scale": [_vp, _vp, _i64, _f32, _f32, _vp, _vp],
     "dmxq_scale_channels": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _vp],

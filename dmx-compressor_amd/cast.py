@@ -15,7 +15,7 @@ from torch.autograd import Function
 
 from . import ops
 from .format import BlockFloatingPoint, FixedPoint, Format, Same
-from .observer import _PER_CHANNEL, DummyObserver, MinMaxObserver, ObserverBase
+from .observer import _PER_CHANNEL, DummyObserver, HistogramObserver, MinMaxObserver, ObserverBase
 
 __all__ = ["CastToFormat", "CastTo", "CastToDict"]
 
@@ -111,7 +111,7 @@ class CastTo(torch.nn.Module):
         if isinstance(self.pre_transform.get("format"), str):
             self.pre_transform["format"] = Format.from_shorthand(self.pre_transform["format"])
 
-    def enable_calibration(self, state: bool = True, observer_cls: ObserverBase = MinMaxObserver,
+    def enable_calibration(self, state: bool = True, observer_cls: ObserverBase = HistogramObserver,
                            qscheme_to_overload: Optional[torch.qscheme] = None, group_size: int = None,
                            ch_axis: int = None) -> None:
         """cast.py:308-340: install an observer and switch to observe-only, or back to fake-quant."""
@@ -125,6 +125,7 @@ class CastTo(torch.nn.Module):
             if self.group_size:
                 assert not self.is_per_channel, "group quantization is to be used with per tensor quantization"
             self.activation_post_process = observer_cls(dtype=self.format, qscheme=self.qscheme, ch_axis=self.ch_axis)
+            self._group_observers = []
             self.disable_fake_quant()
             self.enable_observer()
         else:
@@ -137,8 +138,23 @@ class CastTo(torch.nn.Module):
         obs = self.activation_post_process
         obs.ch_axis = self.ch_axis
         obs.qscheme = self.qscheme
-        obs(x.detach(), self.group_size) if isinstance(obs, MinMaxObserver) else obs(x.detach())
-        _scale, _zero_point = obs.calculate_qparams()
+        if self.group_size and not isinstance(obs, (MinMaxObserver, DummyObserver)):
+            # per-tensor-only observers (histogram): one instance per slab, as cast.py:185-213 does for every class
+            slabs = torch.split(x.detach(), self.group_size, dim=self.ch_axis)
+            if len(getattr(self, "_group_observers", ())) != len(slabs):
+                self._group_observers = [obs.__class__(dtype=self.format, qscheme=self.qscheme, ch_axis=self.ch_axis)
+                                         for _ in slabs]
+            qp = []
+            for o, slab in zip(self._group_observers, slabs):
+                o(slab)
+                qp.append(o.calculate_qparams())
+            _scale = torch.cat([s.reshape(1) for s, _ in qp])
+            _zero_point = torch.cat([z.reshape(1) for _, z in qp])
+            obs.min_val = torch.stack([o.min_val.reshape(()) for o in self._group_observers])
+            obs.max_val = torch.stack([o.max_val.reshape(()) for o in self._group_observers])
+        else:
+            obs(x.detach(), self.group_size) if isinstance(obs, MinMaxObserver) else obs(x.detach())
+            _scale, _zero_point = obs.calculate_qparams()
         _scale, _zero_point = _scale.to(x.device), _zero_point.to(x.device)
         if self.scale.shape != _scale.shape or self.scale.device != _scale.device:
             self.scale = torch.zeros_like(_scale)

@@ -3,6 +3,7 @@
 //   * (min,max) -> (scale, zero_point)            (numerical/observer.py:59-115)
 //   * per-channel max|x|                          (numerical/smoothquant.py:285-299)
 //   * SmoothQuant scale                           (numerical/smoothquant.py:301-321)
+//   * torch.histc for the HistogramObserver       (numerical/observer.py:453-510)
 // The reference builds one observer nn.Module per group in a Python loop and runs two ATen reductions per
 // group; here one launch covers all groups.  Partial results are combined with integer atomics on the float
 // bit patterns (order-preserving for non-NaN values), so the outputs are exact and order-independent.
@@ -229,6 +230,56 @@ __global__ void smoothquant_scale_kernel(const float* a, const float* b, int64_t
   scale[c] = fmaxf(s, smin);
 }
 
+
+// torch.histc (numerical/observer.py:470-472, 489-491): one pass, workgroup-private LDS histogram of integer
+// counts, flushed with one global atomic per non-empty bin per workgroup; the counts become fp32 in a second tiny
+// launch that reuses the output buffer.  The bin of an element is ATen's fp32 expression, evaluated with IEEE
+// multiply and divide: (int64)((x - lo) * bins / (hi - lo)), right edge into the last bin, out-of-range and NaN dropped.
+constexpr int kHistThreads = 1024;
+constexpr int kHistMaxBins = 8192;  // 32 KiB of LDS counters
+__device__ __forceinline__ void hist_add(uint32_t* s, float v, float lo, float hi, float fb, float width, int bins) {
+  if (v >= lo && v <= hi) {
+    int pos = (int)((v - lo) * fb / width);
+    pos = pos < bins ? pos : bins - 1;
+    atomicAdd(&s[pos], 1u);
+  }
+}
+__global__ __launch_bounds__(kHistThreads) void histc_kernel(const void* __restrict__ in, int dt, int64_t n, int bins,
+                                                             float lo, float hi, int vec, uint32_t* counts) {
+  extern __shared__ uint32_t s_hist[];
+  for (int b = threadIdx.x; b < bins; b += kHistThreads) s_hist[b] = 0;
+  __syncthreads();
+  const float fb = (float)bins, width = hi - lo;
+  const int64_t stride = (int64_t)gridDim.x * kHistThreads;
+  const int64_t t0 = (int64_t)blockIdx.x * kHistThreads + threadIdx.x;
+  if (vec) {
+    const int64_t nv = n / 8;
+    for (int64_t t = t0; t < nv; t += 2 * stride) {
+      float a[8], b[8];
+      const bool two = t + stride < nv;
+      load8_rt(in, dt, t * 8, a);
+      if (two) load8_rt(in, dt, (t + stride) * 8, b);
+#pragma unroll
+      for (int k = 0; k < 8; k++) hist_add(s_hist, a[k], lo, hi, fb, width, bins);
+      if (two) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) hist_add(s_hist, b[k], lo, hi, fb, width, bins);
+      }
+    }
+    for (int64_t e = nv * 8 + t0; e < n; e += stride) hist_add(s_hist, load_rt(in, dt, e), lo, hi, fb, width, bins);
+  } else {
+    for (int64_t e = t0; e < n; e += stride) hist_add(s_hist, load_rt(in, dt, e), lo, hi, fb, width, bins);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += kHistThreads) {
+    const uint32_t c = s_hist[b];
+    if (c) atomicAdd(&counts[b], c);
+  }
+}
+__global__ void hist_to_float_kernel(uint32_t* counts, int bins) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < bins) ((float*)counts)[b] = (float)counts[b];
+}
 }  // namespace dmxq
 
 using namespace dmxq;
@@ -313,5 +364,23 @@ extern "C" int dmxq_smoothquant_scale(const float* a_maxabs, const float* b_maxa
   if (!a_maxabs || !b_maxabs || !scale) return DMXQ_ERR_BAD_ARG;
   hipLaunchKernelGGL(smoothquant_scale_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      a_maxabs, b_maxabs, C, alpha, scale_min, scale);
+  return launch_status();
+}
+
+extern "C" int dmxq_histc(const void* in, int dtype_in, int64_t n, int64_t bins, float lo, float hi, float* hist,
+                          void* stream) {
+  if (!valid_dtype(dtype_in) || n < 0 || bins < 1 || !hist || !(lo < hi) || isinf(lo) || isinf(hi))
+    return DMXQ_ERR_BAD_ARG;
+  if (bins > kHistMaxBins) return DMXQ_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(hist, 0, (size_t)bins * sizeof(float), s) != hipSuccess) return DMXQ_ERR_LAUNCH;
+  if (n > 0) {
+    if (!in) return DMXQ_ERR_BAD_ARG;
+    int64_t blocks = (n + kHistThreads * 32 - 1) / (kHistThreads * 32);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(histc_kernel, dim3((unsigned)blocks), dim3(kHistThreads), (size_t)bins * sizeof(uint32_t), s, in,
+                       dtype_in, n, (int)bins, lo, hi, aligned16(in) ? 1 : 0, (uint32_t*)hist);
+    hipLaunchKernelGGL(hist_to_float_kernel, dim3((unsigned)((bins + 255) / 256)), dim3(256), 0, s, (uint32_t*)hist, (int)bins);
+  }
   return launch_status();
 }

@@ -3,8 +3,8 @@ path: MinMaxObserver (per-tensor / per-channel / per-group slabs) and `_calculat
 
 The reference creates one observer nn.Module per group in a Python loop (numerical/cast.py:185-213) and runs two
 ATen reductions per group; here ONE `dmxq_group_minmax` launch produces every group's min/max and one
-`dmxq_qparams` launch turns them into (scale, zero_point).  HistogramObserver's scalar search is host-side
-work outside the hot path and is not provided.
+`dmxq_qparams` launch turns them into (scale, zero_point).  HistogramObserver keeps its two passes over the
+tensor on the device (min/max + `dmxq_histc`) and its bins-long bookkeeping and scalar search on the host.
 """
 from typing import Optional, Tuple
 
@@ -97,7 +97,147 @@ class MinMaxObserver(ObserverBase):
 
 
 class HistogramObserver(ObserverBase):
-    def __init__(self, *a, **k):
-        raise NotImplementedError(
-            "HistogramObserver: the histogram/scalar search is host-side calibration outside the accelerated hot "
-            "path (SURVEY.md §2 row 6); use MinMaxObserver")
+    """Running histogram + L2-error range search (observer.py:213-583, itself adapted from torch.ao's observer).
+
+    Split by cost: the two passes over the observed tensor -- its min/max and `torch.histc` -- are device launches
+    (`dmxq_group_minmax`, `dmxq_histc`); everything that only touches the `bins`-long histogram (re-binning onto a
+    wider range, the quantile walk that picks the clipping range) is fp32 work on a host copy, with the same
+    operand types and order as the reference's tensor expressions so that the same bins win.  Per-tensor only.
+    Quirk kept: the histogram range is the observed min/max truncated toward zero by `int()`
+    (observer.py:470-472, 489-491), so the fractional tails fall outside and are not counted."""
+
+    def __init__(self, bins: int = 2048, upsample_rate: int = 128, dtype: Format = None,
+                 qscheme=torch.per_tensor_affine, ch_axis: int = -1, **kw):
+        if qscheme in _PER_CHANNEL:
+            raise NotImplementedError(
+                "HistogramObserver's qscheme only support torch.per_tensor_symmetric or torch.per_tensor_affine.")
+        super().__init__(dtype or Format.from_shorthand("XP[8,0](CSN)"), qscheme, ch_axis, **kw)
+        self.bins, self.upsample_rate = bins, upsample_rate
+        self.register_buffer("histogram", torch.zeros(bins))
+        self.register_buffer("min_val", torch.tensor(float("inf")))
+        self.register_buffer("max_val", torch.tensor(float("-inf")))
+        self._device = None
+
+    # ------------------------------------------------------------------ observation (device passes + host merge)
+    def _uninitialised(self):
+        return float(self.min_val) == float("inf") and float(self.max_val) == float("-inf")
+
+    def forward(self, x, group_size=None):
+        if x.numel() == 0:
+            return x
+        xd = x.detach()
+        self._device = xd.device
+        mn, mx = ops.group_minmax(xd.reshape(1, -1), 0, 1)
+        new_min, new_max = mn.reshape(()).cpu(), mx.reshape(()).cpu()
+        old_min, old_max = self.min_val.cpu(), self.max_val.cpu()
+        if self._uninitialised() or float(old_min) == float(old_max):
+            hist = ops.histc(xd, self.bins, int(new_min), int(new_max)).cpu()
+            lo, hi = new_min, new_max
+        else:
+            lo, hi = torch.min(new_min, old_min), torch.max(new_max, old_max)
+            # common fine grid (observer.py:400-423): the old bins are cut into upsample_rate pieces, the merged range
+            # is a whole number (`down`) of old bin widths per new bin; only the upper end is relaxed to make it fit
+            fine = (old_max - old_min) / (self.bins * self.upsample_rate)
+            down = int(torch.ceil((hi - lo) / (self.bins * fine)).item())
+            hi = hi + (down * (self.bins * fine) - (hi - lo))
+            start = int(torch.round((old_min - lo) / fine).item())
+            hist = ops.histc(xd, self.bins, int(lo), int(hi)).cpu()
+            old_hist = self.histogram.cpu()
+            if lo == old_min and hi == old_max:
+                hist = hist + old_hist
+            else:
+                hist = self._rebin_onto(hist, old_hist, down, start)
+        self.histogram = hist
+        self.min_val, self.max_val = lo.clone(), hi.clone()
+        return x
+
+    def _rebin_onto(self, hist, old_hist, down, start):
+        """observer.py:425-458: spread each old bin uniformly over its fine cells, place them at `start` on the
+        merged fine grid, and integrate `down` cells per new bin (running sum in fp64, differences back to fp32)."""
+        n, up = self.bins, self.upsample_rate
+        cells = torch.zeros(n * down)
+        cells[start:n * up + start] = old_hist.repeat_interleave(up)
+        upto = torch.cumsum(cells, 0, dtype=torch.double)[down - 1::down]
+        before = torch.zeros(n)
+        before[1:n] = upto[0:-1]
+        return hist + ((upto - before) / up).to(torch.float)
+
+    # ------------------------------------------------------------------ range search (host, bins-long vectors)
+    def _clip_error(self, hist, lo: float, hi: float, first: int, last: int) -> float:
+        """L2 error of quantising the histogram's mass with 2^precision uniform levels spanning bins
+        [first, last], each source bin treated as a uniform density (observer.py:277-329).  Three pieces per source
+        bin: from its start to the end of the level it starts in, the whole levels it spans, and from the start of
+        the level it ends in to its end; each piece is density * integral of x^2 = density * (b^3 - a^3) / 3."""
+        levels = 2 ** self.dtype.precision
+        width = (hi - lo) / self.bins
+        step = width * (last - first + 1) / levels
+        if step == 0.0:
+            return 0.0
+        cube3 = lambda a, b: (b * b * b - a * a * a) / 3
+        begin = (torch.arange(self.bins) - first) * width
+        end = begin + width
+        lvl_b = torch.clamp(torch.div(begin, step, rounding_mode="floor"), 0, levels - 1)
+        lvl_e = torch.clamp(torch.div(end, step, rounding_mode="floor"), 0, levels - 1)
+        density = hist / width
+        err = torch.zeros(self.bins)
+        err += density * cube3(begin - (lvl_b + 0.5) * step, torch.ones(self.bins) * (step / 2))
+        err += (lvl_e - lvl_b - 1) * (density * cube3(torch.tensor(-step / 2), torch.tensor(step / 2)))
+        err += density * cube3(torch.tensor(-step / 2), end - (lvl_e * step + step / 2))
+        return err.sum().item()
+
+    def _search_range(self):
+        """observer.py:331-397: shave 1e-5 quantile steps off whichever tail frees more bins while the L2 error
+        keeps falling.  The reference walks l / r bin by bin; the cumulative histogram is monotone, so the same
+        bins come out of a binary search."""
+        hist, min_val, max_val = self.histogram.cpu(), self.min_val.cpu(), self.max_val.cpu()
+        assert hist.numel() == self.bins, "bins mistmatch"
+        width = (max_val - min_val) / self.bins
+        total = torch.sum(hist).item()
+        csum = torch.cumsum(hist, dim=0)
+        step, lo_q, hi_q = 1e-5, 0.0, 1.0
+        first, last, best = 0, self.bins - 1, float("inf")
+        while lo_q < hi_q:
+            nlo, nhi = lo_q + step, hi_q - step
+            # first bin >= `first` whose cumulative count reaches the lower quantile / last bin <= `last` still
+            # within the upper quantile (thresholds compared in fp32, like tensor-vs-scalar comparisons)
+            l = int(torch.searchsorted(csum, torch.tensor(nlo * total, dtype=csum.dtype), right=False))
+            l = min(last, max(first, l))
+            r = int(torch.searchsorted(csum, torch.tensor(nhi * total, dtype=csum.dtype), right=True)) - 1
+            r = max(first, min(last, r))
+            nfirst, nlast = first, last
+            if (l - first) > (last - r):
+                nfirst, lo_q = l, nlo
+            else:
+                nlast, hi_q = r, nhi
+            if nfirst == first and nlast == last:
+                continue
+            err = self._clip_error(hist, min_val.item(), max_val.item(), nfirst, nlast)
+            if err > best:
+                break
+            best, first, last = err, nfirst, nlast
+        return min_val + width * first, min_val + width * (last + 1)
+
+    def calculate_qparams(self):
+        if self.quant_min is None:
+            raise ValueError(f"{self.dtype!r} has no integer range: qparams are defined for XP[p,0](C..) formats only")
+        if self._uninitialised() or self._device is None:
+            return torch.tensor([1.0]), torch.tensor([0])
+        assert self.bins == len(self.histogram), \
+            "The number of bins in histogram should be equal to the number of bins supplied while making this observer"
+        lo, hi = self._search_range()
+        return ops.qparams(lo.reshape(1).to(self._device), hi.reshape(1).to(self._device), self.quant_min,
+                           self.quant_max, self.qscheme in _SYMMETRIC)
+
+    def extra_repr(self):
+        return f"quant_min = {self.quant_min}, quant_max = {self.quant_max}, min_val = {self.min_val}, max_val = {self.max_val}"
+
+
+class PercentileObserver(HistogramObserver):
+    """observer.py:585-634: carries a `percentile` but computes its qparams exactly like HistogramObserver (the
+    percentile estimate is unimplemented upstream)."""
+
+    def __init__(self, percentile: float = 99.99, **kw):
+        if percentile < 0 or percentile > 100:
+            raise ValueError("Invalid percentile. Must be in range 0 <= percentile <= 100.")
+        self.percentile = percentile
+        super().__init__(**kw)

@@ -223,6 +223,25 @@ def qparams(mn, mx, qmin: int, qmax: int, symmetric_qscheme: bool):
     return scale, zp
 
 
+def histc(x, bins: int, lo: float = 0.0, hi: float = 0.0):
+    """torch.histc(x, bins, min=lo, max=hi) as the HistogramObserver uses it (numerical/observer.py:470-472,
+    489-491): float32 [bins] counts.  lo == hi selects the data's own range, widened by one either side when the
+    data is constant (torch.histc's convention)."""
+    xc = _prep(x, "histc").reshape(-1)
+    lo, hi = float(lo), float(hi)
+    if lo == hi and xc.numel():
+        mn, mx = group_minmax(xc.reshape(1, -1), 0, 1)
+        lo, hi = float(mn), float(mx)
+        if lo == hi:
+            lo, hi = lo - 1.0, hi + 1.0
+    out = torch.empty(int(bins), dtype=torch.float32, device=xc.device)
+    if xc.numel() == 0 and not lo < hi:
+        return out.zero_()
+    check(lib().dmxq_histc(ptr(xc), dtype_code(xc.dtype), xc.numel(), int(bins), lo, hi, ptr(out), stream_of(xc)),
+          "dmxq_histc")
+    return out
+
+
 def channel_maxabs(x, ch_axis: int):
     """max|x| per channel along ch_axis (numerical/smoothquant.py:285-299): float32 [C]."""
     xc = _prep(x, "channel_maxabs")

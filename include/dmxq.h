@@ -114,6 +114,13 @@ int dmxq_group_minmax(const void* in, int dtype_in, int64_t outer, int64_t C, in
 int dmxq_qparams(const float* mn, const float* mx, int64_t n_groups, int qmin, int qmax, int symmetric_qscheme,
                  float* scale, int64_t* zero_point, void* stream);
 
+/* torch.histc of a flat tensor: hist[b] = #{x : bin(x) == b}, bin(x) = (int64)((x - lo) * bins / (hi - lo)) in
+ * fp32, x == hi counted in the last bin, x outside [lo, hi] and NaN dropped (ATen's CPU histc, which the
+ * reference's HistogramObserver calls).  Replaces: numerical/observer.py:470-472 and :489-491.
+ * Requires finite lo < hi (the "lo == hi means the data's own range" convention of torch.histc is resolved by
+ * the caller) and bins <= 8192.  hist: float[bins] device buffer, fully overwritten. */
+int dmxq_histc(const void* in, int dtype_in, int64_t n, int64_t bins, float lo, float hi, float* hist, void* stream);
+
 /* Per-channel max|x| (SmoothQuant).  Replaces numerical/smoothquant.py:285-299 _maxabs. out: float[C]. */
 int dmxq_channel_maxabs(const void* in, int dtype_in, int64_t outer, int64_t C, int64_t inner, float* out, void* stream);
 

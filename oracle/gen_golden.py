@@ -418,6 +418,63 @@ def module_cases():
     np.savez_compressed(os.path.join(GOLD, "modules.npz"), **store)
 
 
+
+# ------------------------------------------------------------------------------------------------ histogram observer
+def histogram_cases():
+    """torch.histc (the reference's call, observer.py:470-472/489-491) and the HistogramObserver state after each
+    of a sequence of batches: histogram, running range, (scale, zero_point)."""
+    from dmx.compressor.numerical.observer import HistogramObserver as RefHist
+    store = {}
+    # 1. histc itself: integer ranges as the observer produces them, edge values planted, lo == hi conventions
+    cfgs = [(2048, -3, 4, 1.5), (2048, 0, 7, 3.0), (100, -5, 5, 2.0), (7, 0, 1, 0.5), (2048, -13, 27, 9.0),
+            (4096, -1, 1, 0.7), (1, -2, 2, 1.0), (2048, 0, 0, 0.3), (8192, -40, 33, 20.0)]
+    for i, (bins, lo, hi, sc) in enumerate(cfgs):
+        x = make("normal", (8000,), seed=900 + i) * sc
+        x[:4] = float(lo); x[4:8] = float(hi)
+        x[8] = float(np.nextafter(np.float32(lo), np.float32(-1e9))); x[9] = float(np.nextafter(np.float32(hi), np.float32(1e9)))
+        if i % 3 == 0:
+            x[100:3000] = x[100:3000].round()  # many values exactly on bin edges
+        want = torch.histc(x, bins, min=lo, max=hi)
+        check(want, O.histc(x, bins, lo, hi), f"histc {bins} [{lo},{hi}]")
+        store[f"histc{i}_x"], store[f"histc{i}_cfg"], store[f"histc{i}_out"] = bits(x), np.array([bins, lo, hi]), bits(want)
+    const = torch.full((100,), 3.0)
+    check(torch.histc(const, 8, min=0, max=0), O.histc(const, 8, 0, 0), "histc constant data")
+    store["n_histc"] = np.array(len(cfgs))
+    # 2. observer sequences (first batch, widening range, range already covered, one-sided data)
+    seqs = 0
+    for fmt in ("XP[8,0](CSN)", "XP[4,0](CSN)"):
+        for qs_name, qs in (("affine", torch.per_tensor_affine), ("symmetric", torch.per_tensor_symmetric)):
+            for kind in range(3 if fmt.startswith("XP[8") else 1):
+                obs = RefHist(dtype=ref.numerical.Format.from_shorthand(fmt), qscheme=qs)
+                tag = f"seq{seqs}"
+                store[f"{tag}_fmt"], store[f"{tag}_qs"] = np.array(fmt), np.array(qs_name)
+                for b, sc in enumerate((3.0, 7.0, 2.0, 11.0)):
+                    x = make("normal", (4096,), seed=950 + 10 * seqs + b) * sc + (kind - 1) * 1.5
+                    if kind == 2:
+                        x = x.abs()
+                    obs(x)
+                    scale, zp = obs.calculate_qparams()
+                    store[f"{tag}_x{b}"] = bits(x)
+                    store[f"{tag}_hist{b}"] = bits(obs.histogram.clone())
+                    store[f"{tag}_range{b}"] = bits(torch.stack([obs.min_val, obs.max_val]))
+                    store[f"{tag}_scale{b}"] = bits(scale.reshape(1).float())
+                    store[f"{tag}_zp{b}"] = zp.reshape(1).numpy().astype(np.int64)
+                seqs += 1
+    store["n_seq"], store["n_batch"] = np.array(seqs), np.array(4)
+    # 3. through CastTo: per-tensor and per-group calibration with the histogram observer (tests/test_group_quant.py:152)
+    w = make("normal", (32, 64), seed=990)
+    store["w"] = bits(w)
+    for name, kw in (("tensor", dict()), ("group16", dict(group_size=16, ch_axis=-1)), ("group64", dict(group_size=64, ch_axis=-1))):
+        c = rnum.CastTo(format="XP[8,0](CSN)")
+        c.enable_calibration(True, RefHist, torch.per_tensor_symmetric, **kw)
+        c(w)
+        c.enable_calibration(False)
+        store[f"cast_{name}_scale"] = bits(c.scale.detach().float().reshape(-1))
+        store[f"cast_{name}_zp"] = c.zero_point.detach().reshape(-1).numpy().astype(np.int64)
+        store[f"cast_{name}_out"] = bits(c(w).detach().float())
+    np.savez_compressed(os.path.join(GOLD, "histogram.npz"), **store)
+
+
 # ------------------------------------------------------------------------------------------------ vocabulary
 def vocabulary():
     """alias name -> repr() of the reference's format / sparseness tables (config identity strings)."""
@@ -435,6 +492,7 @@ if __name__ == "__main__":
     smoothquant_cases()
     composite_cases()
     module_cases()
+    histogram_cases()
     vocabulary()
     sizes = {f: os.path.getsize(os.path.join(GOLD, f)) for f in sorted(os.listdir(GOLD)) if f.endswith(".npz")}
     print(f"oracle == reference on {checked} comparisons; fixtures: {sizes}")

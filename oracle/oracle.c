@@ -387,3 +387,30 @@ int oracle_channel_maxabs(const float* in, int64_t outer, int64_t C, int64_t inn
     }
   return 0;
 }
+
+/* torch.histc as numerical/observer.py:470-472,489-491 calls it (ATen 2.10 CPU, aten/src/ATen/native/cpu/
+ * HistogramKernel.cpp, the LINEAR_INTERPOLATION binning used by histc -- a third-party dependency of the reference,
+ * restated from its behaviour and pinned against torch.histc itself in oracle/gen_golden.py): with lo < hi,
+ * elements outside [lo, hi] (and NaN) are dropped, bin = (int64)((x - lo) * bins / (hi - lo)) in fp32, and the
+ * right edge belongs to the last bin.  lo == hi means "use the data's own min/max" and, if those are equal too,
+ * [lo - 1, hi + 1].  Counts are accumulated in fp32 like ATen's (+1.0f per element). */
+int oracle_histc(const float* x, int64_t n, int64_t bins, float lo, float hi, float* hist) {
+  if (bins <= 0) return 1;
+  for (int64_t b = 0; b < bins; b++) hist[b] = 0.0f;
+  if (n == 0) return 0;
+  if (lo == hi) {
+    lo = hi = x[0];
+    for (int64_t i = 1; i < n; i++) { if (x[i] < lo) lo = x[i]; if (x[i] > hi) hi = x[i]; }
+    if (lo == hi) { lo -= 1.0f; hi += 1.0f; }
+  }
+  if (!(lo < hi)) return 1;
+  const float width = hi - lo, fb = (float)bins;
+  for (int64_t i = 0; i < n; i++) {
+    const float v = x[i];
+    if (!(v >= lo && v <= hi)) continue;
+    int64_t pos = (int64_t)((v - lo) * fb / width);
+    if (pos >= bins) pos = bins - 1;
+    hist[pos] += 1.0f;
+  }
+  return 0;
+}

@@ -46,8 +46,9 @@ def lib():
         L.oracle_group_minmax.argtypes = [fp, i64, i64, i64, i64, fp, fp]
         L.oracle_qparams.argtypes = [fp, fp, i64, i32, i32, i32, fp, fp]
         L.oracle_channel_maxabs.argtypes = [fp, i64, i64, i64, fp]
+        L.oracle_histc.argtypes = [fp, i64, i64, ctypes.c_float, ctypes.c_float, fp]
         for f in ("oracle_sbfp_qdq", "oracle_mxfp_qdq", "oracle_float_qdq", "oracle_bfp_qdq", "oracle_fixed_qdq", "oracle_nm_mask",
-                  "oracle_group_minmax", "oracle_qparams", "oracle_channel_maxabs"):
+                  "oracle_group_minmax", "oracle_qparams", "oracle_channel_maxabs", "oracle_histc"):
             getattr(L, f).restype = ctypes.c_int
         _lib = L
     return _lib
@@ -211,4 +212,11 @@ def channel_maxabs(x, ch_axis):
     inner = int(np.prod(xi.shape[ax + 1:], dtype=np.int64))
     out = torch.empty(C)
     _check(lib().oracle_channel_maxabs(_ptr(xi), outer, C, inner, _ptr(out)), "channel_maxabs")
+    return out
+
+
+def histc(x, bins, lo, hi):
+    xi = _f32c(x).reshape(-1)
+    out = torch.empty(bins)
+    _check(lib().oracle_histc(_ptr(xi), xi.numel(), bins, ctypes.c_float(lo), ctypes.c_float(hi), _ptr(out)), "histc")
     return out

@@ -247,6 +247,46 @@ def test_smoothquant_fixtures(backend, dmx):
             assert torch.allclose(got, want, rtol=4.8e-7, atol=0.0), alpha
 
 
+@pytest.mark.parametrize("backend", backends(), indirect=True)
+def test_histc_fixtures(backend, dmx, oracle):
+    """torch.histc outputs recorded from ATen (the reference's call, observer.py:470-472/489-491)."""
+    g = load("histogram.npz")
+    for i in range(int(g["n_histc"])):
+        x = tensor(g[f"histc{i}_x"], torch.float32)
+        bins, lo, hi = (int(v) for v in g[f"histc{i}_cfg"])
+        if isinstance(backend, HipBackend):
+            got = dmx.ops.histc(x.to(backend.dev), bins, lo, hi)
+        else:
+            got = oracle.histc(x, bins, lo, hi)
+        assert mism(got, g[f"histc{i}_out"], torch.float32) == 0, (i, bins, lo, hi)
+
+
+@pytest.mark.gpu
+def test_histogram_observer_fixtures(dmx, cuda):
+    """HistogramObserver state after each batch of a sequence (histogram, running range, scale, zero point) and
+    CastTo calibration through it, per tensor and per group -- recorded from the reference's own classes."""
+    g = load("histogram.npz")
+    qs = {"affine": torch.per_tensor_affine, "symmetric": torch.per_tensor_symmetric}
+    for s in range(int(g["n_seq"])):
+        obs = dmx.HistogramObserver(dtype=dmx.Format.from_shorthand(str(g[f"seq{s}_fmt"])), qscheme=qs[str(g[f"seq{s}_qs"])])
+        for b in range(int(g["n_batch"])):
+            obs(tensor(g[f"seq{s}_x{b}"], torch.float32).to(cuda))
+            assert mism(obs.histogram, g[f"seq{s}_hist{b}"], torch.float32) == 0, (s, b)
+            assert mism(torch.stack([obs.min_val, obs.max_val]), g[f"seq{s}_range{b}"], torch.float32) == 0, (s, b)
+            scale, zp = obs.calculate_qparams()
+            assert mism(scale.reshape(1), g[f"seq{s}_scale{b}"], torch.float32) == 0, (s, b)
+            assert int(zp.reshape(-1)[0]) == int(g[f"seq{s}_zp{b}"][0]), (s, b)
+    w = tensor(g["w"], torch.float32)
+    for name, kw in (("tensor", dict()), ("group16", dict(group_size=16, ch_axis=-1)), ("group64", dict(group_size=64, ch_axis=-1))):
+        c = dmx.CastTo(format="XP[8,0](CSN)")
+        c.enable_calibration(True, dmx.HistogramObserver, torch.per_tensor_symmetric, **kw)
+        c(w.to(cuda))
+        c.enable_calibration(False)
+        assert mism(c.scale.float().reshape(-1), g[f"cast_{name}_scale"], torch.float32) == 0, name
+        assert np.array_equal(c.zero_point.reshape(-1).cpu().numpy().astype(np.int64), g[f"cast_{name}_zp"]), name
+        assert mism(c(w.to(cuda)).float(), g[f"cast_{name}_out"], torch.float32) == 0, name
+
+
 def test_vocabulary_matches_reference(dmx):
     g = load("vocabulary.npz")
     names, reprs = [str(s) for s in g["format_names"]], [str(s) for s in g["format_reprs"]]

@@ -196,3 +196,41 @@ def test_gelu_softmax_layernorm_exact_function_parity(dmx, cuda, dtype):
     assert int(((got.cpu().float() - ref_d).abs() > tol).sum()) == 0
     big = (make("normal", (3, 20000), seed=14)).to(dtype)                     # longer than the LDS row buffer
     assert close(dmx.ops.softmax(big.to(cuda), -1), F.softmax(big.float(), -1)) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_histc_matches_oracle(dmx, cuda, oracle, dtype):
+    """dmxq_histc == the oracle's restatement of ATen's histc: ragged sizes (vector body + scalar tail, unaligned
+    views), every bins/range shape the observer produces, NaN / inf / out-of-range elements dropped."""
+    for i, (n, bins, lo, hi) in enumerate([(1, 2048, -1, 1), (7, 5, 0, 3), (4099, 2048, -3, 4), (100003, 2048, -9, 13),
+                                           (1 << 20, 2048, -4, 4), (65536, 8192, -2, 2), (5000, 1, -1, 1), (30000, 2048, 0, 0)]):
+        x = make("normal", (n,), seed=70 + i, dtype=dtype) * 3
+        if n > 100:
+            x[3] = float("nan"); x[5] = float("inf"); x[9] = float("-inf"); x[11] = lo; x[13] = hi
+        if lo == hi:
+            x = x.nan_to_num(0.0, 1.0, -1.0)
+        want = oracle.histc(x, bins, lo, hi)
+        assert bits_equal(dmx.ops.histc(x.to(cuda), bins, lo, hi), want) == 0, (n, bins, lo, hi)
+        if n > 16:  # a view that starts off the 16-byte grid
+            assert bits_equal(dmx.ops.histc(x.to(cuda)[1:], bins, lo - 1, hi + 1), oracle.histc(x[1:], bins, lo - 1, hi + 1)) == 0
+    const = torch.full((1000,), 2.5, dtype=dtype)
+    assert bits_equal(dmx.ops.histc(const.to(cuda), 16), oracle.histc(const, 16, 0, 0)) == 0
+    with pytest.raises(NotImplementedError):
+        dmx.ops.histc(const.to(cuda), 1 << 14, -1, 1)   # more bins than the LDS histogram holds
+    with pytest.raises(dmx.DmxqError):
+        dmx.ops.histc(const.to(cuda), 16, 3, 1)
+
+
+def test_histogram_observer_group_equals_tensor(dmx, cuda):
+    """tests/test_group_quant.py:152-188 (HistogramObserver leg): one group spanning the whole ch_axis == per tensor."""
+    W = make("normal", (24, 40), seed=5).to(cuda)
+    for fmt in ("XP[8,0](CSN)", "XP[4,0](CSN)"):
+        for qs in (torch.per_tensor_affine, torch.per_tensor_symmetric):
+            a, b = dmx.CastTo(format=fmt), dmx.CastTo(format=fmt)
+            a.enable_calibration(True, dmx.HistogramObserver, qs, group_size=W.shape[-1], ch_axis=-1)
+            b.enable_calibration(True, dmx.HistogramObserver, qs)
+            a(W); b(W)
+            a.enable_calibration(False); b.enable_calibration(False)
+            assert torch.allclose(a(W), b(W), rtol=0.0, atol=1e-8)
+    with pytest.raises(NotImplementedError):
+        dmx.HistogramObserver(qscheme=torch.per_channel_affine)

@@ -138,6 +138,9 @@ def main():
     ma = torch.empty(C, device=dev)
     run("channel_maxabs bf16 along last dim (reduce over rows)",
         lambda i: L.dmxq_channel_maxabs(vp(xs[i].data_ptr()), _lib.BF16, R, C, 1, vp(ma.data_ptr()), sp), k, n * 2)
+    hist = torch.empty(2048, device=dev)
+    run("histc bf16 2048 bins over [-4, 4] (HistogramObserver pass)",
+        lambda i: L.dmxq_histc(vp(xs[i].data_ptr()), _lib.BF16, n, 2048, -4.0, 4.0, vp(hist.data_ptr()), sp), k, n * 2)
     # ---------------------------------------------------------------- row ops (Whisper shapes)
     rows, cols = 12 * 1500, 1500
     xr = [torch.randn(rows, cols, device=dev).to(torch.bfloat16) for _ in range(10)]
