@@ -23,9 +23,9 @@
 //         q = fl(x + K) - K                                    ["single" form]
 //     E == 0 (denormal block max): base = 0 and the kept bits are the top wl of the 23-bit field, i.e.
 //     quantum = 2^(-126-wl); same formulas with that quantum.
-//     Blocks whose M would overflow (biased exponent of m > 229 + wl, incl. Inf/NaN maxima, which the reference
-//     turns into an all-NaN block) and blocks with a denormal maximum (sign of a zero result, see fast_ok) take
-//     the literal bit path; the choice is made per wave (uniform branch).
+//     Blocks whose M would overflow (finite maxima with biased exponent > 229 + wl) and blocks with a denormal
+//     maximum (sign of a zero result, see fast_ok) take the literal bit path; the choice is made per wave (uniform
+//     branch).  Inf/NaN maxima -- which the reference turns into an all-NaN block -- stay on the fast path: K = inf.
 // (3) Asymmetric formats ("(_N)", format.py:349-372) relax only the negative clip by one code; closed form:
 //         x <= -(2^(e+1) - quantum/2)  ->  y = -2^(e+1)        (tie goes to the even code -2^(wl-1)).
 #pragma once
@@ -51,17 +51,21 @@ __device__ __forceinline__ BfpBlockParams bfp_block_params(uint32_t maxabs_bits,
   const uint32_t E = maxabs_bits & 0x7F800000u;
   p.base = u2f(E) * 6.0f;
   const uint32_t max_man = (0x007FFFFFu >> (25 - wl)) << (25 - wl);
-  p.maxv = u2f(E | max_man);
+  // FAST, Inf/NaN maximum (E = 0xFF): base = K = inf, so every element becomes inf - inf = NaN as in the reference;
+  // the clamp limits are made NaN too, so that med3 (min3 when an operand is NaN) cannot turn the NaN into a limit
+  const uint32_t nan_lim = (FAST && E == 0x7F800000u) ? 0x00400000u : 0u;
+  p.maxv = u2f(E | max_man | nan_lim);
   p.E = E;
   if (ASYM) {
     const uint32_t thr_man = (0x007FFFFFu >> (24 - wl)) << (24 - wl);
     // a block poisoned to NaN (max >= 2^126 or Inf/NaN: base overflows) stays NaN: make the compare always false
     p.thr = E >= 0x7E800000u ? u2f(0x7FC00000u) : u2f(0x80000000u | E | thr_man);
-    p.neg_lim = u2f(0x80000000u | (E + 0x00800000u));
+    p.neg_lim = nan_lim ? u2f(0xFFC00000u) : u2f(0x80000000u | (E + 0x00800000u));
   }
   if (FAST) {
     const uint32_t eb = E >> 23;
-    const uint32_t mexp = eb ? eb + 25u - (uint32_t)wl : 24u - (uint32_t)wl;  // biased exponent of M
+    uint32_t mexp = eb ? eb + 25u - (uint32_t)wl : 24u - (uint32_t)wl;  // biased exponent of M
+    mexp = mexp < 254u ? mexp : 254u;                                    // (only E = 0xFF gets here with more)
     p.M = u2f((mexp << 23) | 0x00400000u);
     p.K = p.M + p.base;
   }
@@ -71,9 +75,11 @@ __device__ __forceinline__ BfpBlockParams bfp_block_params(uint32_t maxabs_bits,
 // may this block take the magic-add path?  M must be representable, and:
 // E == 0 with a non-zero (denormal) maximum: base = 0, so a negative x that rounds to zero keeps its sign in the
 // reference (-0.0) while the magic add yields +0.0 -> literal path.  All-zero blocks stay fast.
+// An Inf/NaN maximum (eb = 255; e.g. the -inf of an attention mask) is fine: the formulas produce the all-NaN block
+// by themselves, see bfp_block_params.
 __device__ __forceinline__ bool bfp_fast_ok(uint32_t maxabs_bits, int wl) {
   const uint32_t eb = (maxabs_bits & 0x7F800000u) >> 23;
-  return eb + 25u - (uint32_t)wl <= 254u && (eb != 0u || maxabs_bits == 0u);
+  return (eb + 25u - (uint32_t)wl <= 254u || eb == 255u) && (eb != 0u || maxabs_bits == 0u);
 }
 
 // literal bit path (every rounding mode)

@@ -102,16 +102,17 @@ __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restric
           __builtin_amdgcn_sched_barrier(0);  // vector by vector: short live ranges (4 workgroups per CU need <= 128 VGPRs)
         }
         if (kFast && __builtin_amdgcn_ballot_w64(!all_fast) != 0ull) {
-          // rare: some block of this wave cannot take the magic-add path (bfp_fast_ok).  Redo the group with the
-          // literal bit path from a fresh read of the inputs (still unmodified: this tile's stores come later),
-          // instead of keeping every raw vector alive across a two-sided branch.  (Unrolled: a runtime-indexed
-          // o[u] would live in scratch.)
+          // rare: some block of this wave cannot take the magic-add path (bfp_fast_ok).  Redo the affected vectors
+          // with the literal bit path from a fresh read of the inputs (still unmodified: this tile's stores come
+          // later), instead of keeping every raw vector alive across a two-sided branch.  (Unrolled: a
+          // runtime-indexed o[u] would live in scratch.)
 #pragma unroll
           for (int u = 0; u < GROUP; u++) {
             const u32x4 r = load_rawv<IVB>(src + (g + u) * (THREADS * IVB), lane_in);
             const uint32_t m = group_max_u32(absmax_bits<DTI>(r), lpb);
-            o[u] = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, false, EPL>(r, m, v0 + (int64_t)(g + u) * THREADS, wl, rounding,
-                                                                     stoch, seed);
+            if (__builtin_amdgcn_ballot_w64(!bfp_fast_ok(m, wl)) != 0ull)
+              o[u] = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, false, EPL>(r, m, v0 + (int64_t)(g + u) * THREADS, wl, rounding,
+                                                                       stoch, seed);
           }
         }
         __builtin_amdgcn_sched_barrier(0);  // ... and the group's stores go out as one burst

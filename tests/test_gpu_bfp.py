@@ -298,3 +298,26 @@ def test_more_than_2_to_the_31_elements(dmx, cuda):
     assert torch.equal(f[-256:], dmx.ops.float_qdq(base, 10, 5, 15, True))
     del x, q, f
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_masked_attention_scores(dmx, cuda, oracle, dtype):
+    """-inf above the diagonal (a causal mask already applied): every block that touches the mask becomes NaN in the
+    reference (base = inf, inf - inf), the others quantise normally.  These blocks stay on the magic-add path
+    (bfp_math.hpp), so this is also its NaN-propagation test: symmetric / asymmetric, wl = 2 (limit = 2^e, the case
+    where an un-poisoned clamp would return a finite limit), rows / columns / ragged layouts."""
+    S = 192
+    x = make("normal", (3, S, S), seed=21, dtype=dtype)
+    x = x.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+    x[1, 5, 2] = float("nan")
+    x[2, 7, 0] = float("inf")
+    for wl, B, dim, sym in ((8, 16, -1, True), (8, 64, -1, False), (2, 16, -1, True), (2, 16, -1, False), (16, 32, -1, True),
+                            (8, 16, -2, True), (8, 64, 1, False), (8, 24, -1, True), (4, 128, -1, True)):
+        want = oracle.bfp_cast(x, wl, B, dim, sym).to(dtype)
+        got = dmx.ops.bfp_qdq(x.to(cuda), wl, B, dim, sym)
+        assert mismatches_nan_aware(got, want) == 0, (wl, B, dim, sym)
+        assert int(torch.isnan(want.float()).sum()) > S * S  # the mask really poisons blocks
+    # the same through the fused weight path and a widening cast
+    w = x[0].contiguous()
+    want = oracle.bfp_cast(w, 8, 64, -1, True)
+    assert mismatches_nan_aware(dmx.ops.bfp_qdq(w.to(cuda), 8, 64, -1, True, out_dtype=torch.float32), want.float()) == 0
