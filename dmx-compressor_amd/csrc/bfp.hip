@@ -97,15 +97,17 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
 #define DMXQ_ROWS_GEOM(F_)                                                                         \
   do {                                                                                             \
     const int64_t big_tiles = (n_vec + (int64_t)512 * UB - 1) / ((int64_t)512 * UB);               \
-    if (big_tiles <= 256 && big_tiles >= 224) DMXQ_ROWS(512, UB, F_); /* ONE full round, 1 WG per CU */ \
-    else if (n_vec >= (int64_t)256 * 256 * 4) DMXQ_ROWS(256, 4, F_);  /* many rounds: small tiles desynchronise */ \
+    if constexpr ((F_) != 4) { /* (the any-rounding build would spill at 16 vectors per lane) */ \
+      if (big_tiles <= 256 && big_tiles >= 224) { DMXQ_ROWS(512, UB, F_); break; } /* ONE full round, 1 WG per CU */ \
+    }                                                                                              \
+    if (n_vec >= (int64_t)256 * 256 * 4) DMXQ_ROWS(256, 4, F_);  /* many rounds: small tiles desynchronise */ \
     else DMXQ_ROWS(256, 1, F_);                                                                    \
   } while (0)
     // instantiate only what can run (see bfp_cols.hip): literal path for the runtime-rounding build, magic-add for
     // nearest-even; nearest with wl > 20 is routed to the runtime-rounding build by dispatch_mode
     constexpr bool in16 = Elem<DTI>::bytes == 2;
     if constexpr (RND == kRuntimeRounding) {
-      DMXQ_ROWS_GEOM(0);
+      DMXQ_ROWS_GEOM(4);
     } else {
       if (in16 && fast == 2) {
         if constexpr (in16) DMXQ_ROWS_GEOM(2);

@@ -96,6 +96,23 @@ __device__ __forceinline__ float bfp_q1(float x, const BfpBlockParams& p, int wl
   return q;
 }
 
+// (5) the other rounding modes (down / up / stochastic act on t's bit pattern) keep the literal rounding and only
+//     replace the exponent-field clip by the clamp of (1): valid for a normal block maximum whose base is finite
+//     (biased exponent 1..252), and for an all-zero block unless the mode is "up" (which turns 0 into the smallest
+//     kept code, 2^(-126-wl), and at wl = 2 the clamp limit is 0).
+__device__ __forceinline__ bool bfp_bitfast_ok(uint32_t maxabs_bits, int rounding) {
+  const uint32_t eb = (maxabs_bits & 0x7F800000u) >> 23;
+  return (eb >= 1u && eb <= 252u) || (maxabs_bits == 0u && rounding != DMXQ_ROUND_UP);
+}
+template <int RND, bool ASYM>
+__device__ __forceinline__ float bfp_q1_bitfast(float x, const BfpBlockParams& p, int wl, int rounding, uint32_t rnd) {
+  const float t = x + p.base;
+  const uint32_t tb = round_bitwise<RND>(f2u(t), wl, rounding, rnd);
+  float q = __builtin_amdgcn_fmed3f(u2f(tb) - p.base, -p.maxv, p.maxv);
+  if (ASYM) q = (x <= p.thr) ? p.neg_lim : q;
+  return q;
+}
+
 // nearest-even fast path, see (2); only for blocks that pass bfp_fast_ok (normal finite maximum, or all zero)
 template <bool SINGLE, bool ASYM>
 __device__ __forceinline__ float bfp_q1_fast(float x, const BfpBlockParams& p) {

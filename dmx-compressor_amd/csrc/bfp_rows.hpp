@@ -24,12 +24,17 @@ template <int DTI, int DTO, int RND, bool ASYM, int FAST, bool PATH_FAST, int EP
 __device__ __forceinline__ OutVec<DTO, EPLV> bfp_rows_vector(const u32x4& raw, uint32_t mb, int64_t vi, int wl,
                                                              int rounding, bool stoch, uint64_t seed) {
   constexpr int EPL = EPLV;
-  const BfpBlockParams p = bfp_block_params<ASYM, PATH_FAST>(mb, wl);
+  const BfpBlockParams p = bfp_block_params<ASYM, PATH_FAST && FAST != 4>(mb, wl);
   float xw[16 / Elem<DTI>::bytes], x[EPL], y[EPL];
   widen<DTI, 16 / Elem<DTI>::bytes>(raw, xw);
 #pragma unroll
   for (int k = 0; k < EPL; k++) x[k] = xw[k];
-  if (PATH_FAST) {
+  if (PATH_FAST && FAST == 4) {  // any rounding mode: literal rounding, clamp instead of the exponent-field clip
+    const int64_t e0 = vi * EPL;
+#pragma unroll
+    for (int k = 0; k < EPL; k++)
+      y[k] = bfp_q1_bitfast<RND, ASYM>(x[k], p, wl, rounding, rnd_if(stoch, seed, (uint64_t)(e0 + k)));
+  } else if (PATH_FAST) {
 #pragma unroll
     for (int k = 0; k < EPL; k++) y[k] = bfp_q1_fast<FAST == 2, ASYM>(x[k], p);
   } else {
@@ -44,7 +49,8 @@ __device__ __forceinline__ OutVec<DTO, EPLV> bfp_rows_vector(const u32x4& raw, u
 }
 
 // FAST: 0 = literal bit path only; 1 = magic-add path, double rounding; 2 = magic-add path, single rounding
-// (valid only for RND == nearest; the dispatcher picks 2 when bfp_single_rounding_ok<DTI>(wl)).
+// (valid only for RND == nearest; the dispatcher picks 2 when bfp_single_rounding_ok<DTI>(wl)); 4 = literal rounding
+// in any mode + clamp (bfp_math.hpp (5); the runtime-rounding build).
 // UNROLL vectors are in flight per lane; they are converted and stored in groups of GROUP: wait for the group's
 // loads, quantise all of them into registers, then issue the group's stores back to back (read bursts and write
 // bursts instead of a read/write interleave; tools/tune_bfp picks UNROLL and GROUP).
@@ -87,14 +93,14 @@ __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restric
         // block maxima of the whole group first; the fast/literal choice is made once per group, wave-uniformly
         // (every active lane's block must admit the magic-add path, see bfp_math.hpp)
         uint32_t mb[GROUP];
-        bool all_fast = FAST != 0 && RND == DMXQ_ROUND_NEAREST;
+        constexpr bool kFast = FAST == 4 || (FAST != 0 && RND == DMXQ_ROUND_NEAREST);
+        bool all_fast = kFast;
 #pragma unroll
         for (int u = 0; u < GROUP; u++) {
           mb[u] = group_max_u32(absmax_bits<DTI>(raw[g + u]), lpb);
-          if (FAST != 0) all_fast = all_fast && bfp_fast_ok(mb[u], wl);
+          if (kFast) all_fast = all_fast && (FAST == 4 ? bfp_bitfast_ok(mb[u], rounding) : bfp_fast_ok(mb[u], wl));
         }
         OutVec<DTO, EPL> o[GROUP];
-        constexpr bool kFast = FAST != 0 && RND == DMXQ_ROUND_NEAREST;
 #pragma unroll
         for (int u = 0; u < GROUP; u++) {
           o[u] = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, kFast, EPL>(raw[g + u], mb[u], v0 + (int64_t)(g + u) * THREADS, wl,
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restric
           for (int u = 0; u < GROUP; u++) {
             const u32x4 r = load_rawv<IVB>(src + (g + u) * (THREADS * IVB), lane_in);
             const uint32_t m = group_max_u32(absmax_bits<DTI>(r), lpb);
-            if (__builtin_amdgcn_ballot_w64(!bfp_fast_ok(m, wl)) != 0ull)
+            if (__builtin_amdgcn_ballot_w64(!(FAST == 4 ? bfp_bitfast_ok(m, rounding) : bfp_fast_ok(m, wl))) != 0ull)
               o[u] = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, false, EPL>(r, m, v0 + (int64_t)(g + u) * THREADS, wl, rounding,
                                                                        stoch, seed);
           }

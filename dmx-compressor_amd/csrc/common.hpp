@@ -18,19 +18,22 @@ constexpr int kMaxBlocks = 256 * 8;  // memory-bound grid cap: 256 CUs x 8 workg
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 
-// splitmix64(seed, linear element index): the same counter-based stream as oracle/oracle.c rnd_bits, so the
+// hash32(seed, linear element index): the same counter-based stream as oracle/oracle.c rnd_bits, so the
 // stochastic modes are reproducible and kernel-vs-oracle bit-exact (the reference's RNG is an unseeded
-// global mt19937, quant_cpu.cpp:32-34: only statistical parity is possible against it).
+// global mt19937, quant_cpu.cpp:32-34: only statistical parity is possible against it).  32-bit avalanche hash of
+// the index's low half, keyed by the seed and the index's high half: two v_mul_lo_u32 per draw instead of the
+// twelve a 64-bit mixer needs.
 __device__ __forceinline__ uint32_t rnd_bits(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u) ^ ((uint32_t)(idx >> 32) * 0x85EBCA6Bu);
+  uint32_t x = (uint32_t)idx ^ key;
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15; x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
 }
 
 // random bits only when the (wave-uniform) mode is stochastic: the empty asm keeps the optimiser from turning the
-// branch into an unconditional evaluation + select (the 64-bit hash is ~25 VALU ops)
+// branch into an unconditional evaluation + select (the hash is ~10 VALU ops, two of them quarter-rate multiplies)
 __device__ __forceinline__ uint32_t rnd_if(bool stoch, uint64_t seed, uint64_t idx) {
   uint32_t r = 0u;
   if (stoch) {

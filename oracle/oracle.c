@@ -29,13 +29,16 @@ static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 /* Counter-based random bits for the stochastic mode.  The reference uses an UNSEEDED global mt19937
  * (quant_cpu.cpp:32-34), so its stochastic results are not reproducible; parity there is statistical only.
- * The HIP kernels use the same splitmix64(seed, linear index) stream, so kernel-vs-oracle is still bit-exact. */
+ * The HIP kernels use the same stream, so kernel-vs-oracle is still bit-exact: a 32-bit avalanche hash (two odd
+ * multiplies, three xor-shifts) of the low half of the linear element index, keyed by the seed and the high half of
+ * the index -- 32-bit on purpose, a 64-bit multiply costs a GPU lane four quarter-rate instructions. */
 static inline uint32_t rnd_bits(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u) ^ ((uint32_t)(idx >> 32) * 0x85EBCA6Bu);
+  uint32_t x = (uint32_t)idx ^ key;
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15; x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
 }
 
 /* quant_cpu.cpp:211-237 round_bitwise: keep `man_bits` mantissa bits of an fp32 bit pattern.
