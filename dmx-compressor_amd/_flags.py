@@ -1,0 +1,29 @@
+"""Host mirrors of the one-element switch buffers (`fake_quant_enabled`, `observer_enabled`, SmoothQuant's
+`enabled` / `dynamic` / `fused_to_weight`).
+
+The reference (and torch.ao's FakeQuantize it derives from) keeps these switches as registered buffers and reads
+them in every forward (`if self.fake_quant_enabled[0] == 1`, numerical/cast.py:268-277).  Once the module lives
+on the GPU each such read copies one byte back to the host and WAITS for the stream — two or three full
+pipeline drains per cast.  Here the buffers stay (same state_dict keys), but every write goes through
+`_set_flag`, which also records the value in the instance `__dict__`; forward paths read only the mirror.
+Code that pokes a buffer directly must call `refresh_flags()` afterwards; `load_state_dict` does it by itself.
+"""
+
+
+class HostFlags:
+    _flag_names = ()
+
+    def _set_flag(self, name: str, value) -> None:
+        getattr(self, name)[0] = 1 if value else 0
+        self.__dict__["_h_" + name] = 1 if value else 0
+
+    def _flag(self, name: str) -> int:
+        return self.__dict__["_h_" + name]
+
+    def refresh_flags(self) -> None:
+        for n in self._flag_names:
+            self.__dict__["_h_" + n] = int(getattr(self, n)[0])
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.refresh_flags()

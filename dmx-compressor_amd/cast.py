@@ -14,6 +14,7 @@ import torch
 from torch.autograd import Function
 
 from . import ops
+from ._flags import HostFlags
 from .format import BlockFloatingPoint, FixedPoint, Format, Same
 from .observer import _PER_CHANNEL, DummyObserver, HistogramObserver, MinMaxObserver, ObserverBase
 
@@ -53,10 +54,15 @@ class _FixedAffineCast(Function):
         return g, None, None, None, None, None, None
 
 
-class CastTo(torch.nn.Module):
+class CastTo(HostFlags, torch.nn.Module):
     """Simulated numerical cast to a target format (cast.py:136-162).  Buffers and switches follow
     torch.ao's FakeQuantize, which the reference subclasses: scale, zero_point, fake_quant_enabled,
-    observer_enabled, qscheme, ch_axis."""
+    observer_enabled, qscheme, ch_axis.  The two switches are read from host mirrors (_flags.py): forward never
+    waits for the device."""
+    _flag_names = ("fake_quant_enabled", "observer_enabled")
+    #: the reference returns a COPY from a SAME-format cast (numerical/format.py:89-90); here a no-op cast hands its
+    #: input back, as the un-wrapped torch module would.  Set to True for a fresh tensor per cast.
+    copy_on_same = False
 
     def __init__(self, format="SAME", observer=DummyObserver, group_size=None, block_dim=-1,
                  qscheme=torch.per_tensor_affine, ch_axis=-1, **observer_kwargs):
@@ -72,19 +78,20 @@ class CastTo(torch.nn.Module):
         self.register_buffer("zero_point", torch.tensor([0], dtype=torch.int64))
         self.register_buffer("fake_quant_enabled", torch.tensor([1], dtype=torch.uint8))
         self.register_buffer("observer_enabled", torch.tensor([0], dtype=torch.uint8))
+        self.refresh_flags()
         self.physical_dtype = None
         self.block_dim = block_dim
         self.pre_transform = {}
 
     # ------------------------------------------------------------------ switches (FakeQuantize API)
     def enable_fake_quant(self, enabled: bool = True):
-        self.fake_quant_enabled[0] = 1 if enabled else 0
+        self._set_flag("fake_quant_enabled", enabled)
 
     def disable_fake_quant(self):
         self.enable_fake_quant(False)
 
     def enable_observer(self, enabled: bool = True):
-        self.observer_enabled[0] = 1 if enabled else 0
+        self._set_flag("observer_enabled", enabled)
 
     def disable_observer(self):
         self.enable_observer(False)
@@ -183,6 +190,8 @@ class CastTo(torch.nn.Module):
 
     def _quantize(self, x, out_dtype):
         fmt = self.format
+        # the autograd wrappers only matter when a gradient will flow (straight-through estimator); inference skips them
+        ste = torch.is_grad_enabled() and x.requires_grad
         if isinstance(fmt, FixedPoint):
             # per-tensor: one scale; per-channel: scale[c]; per-group: scale[c // group_size] (cast.py:279-293)
             if self.group_size:
@@ -191,14 +200,32 @@ class CastTo(torch.nn.Module):
                 ch_axis, gs = self.ch_axis, None
             else:
                 ch_axis, gs = None, None
-            return _FixedAffineCast.apply(x, fmt, self.scale, self.zero_point, ch_axis, gs, out_dtype)
-        return CastToFormat.apply(x, fmt, self.block_dim, out_dtype)
+            if ste:
+                return _FixedAffineCast.apply(x, fmt, self.scale, self.zero_point, ch_axis, gs, out_dtype)
+            return ops.fixed_qdq(x, fmt.precision, fmt.fraction, fmt.clamp, fmt.symmetric, fmt.rounding, scale=self.scale,
+                                 zero_point=self.zero_point, ch_axis=ch_axis, group_size=gs, out_dtype=out_dtype)
+        if ste:
+            return CastToFormat.apply(x, fmt, self.block_dim, out_dtype)
+        return fmt.cast(x, self.block_dim, out_dtype=out_dtype)
 
     def forward(self, x):
-        self.physical_dtype = x.dtype
+        d = self.__dict__  # (plain attributes: nn.Module.__setattr__ costs several microseconds per assignment)
+        d["physical_dtype"] = x.dtype
+        fmt, pt = self.format, self.pre_transform
+        if not pt:  # the common case: no shaping / shortcut / pre-format
+            same = isinstance(fmt, Same)
+            if d["_h_observer_enabled"] and not same:
+                self._observer_step(x)
+            if not d["_h_fake_quant_enabled"]:
+                return x
+            if same:  # the reference's Same.cast is x.clone() (format.py:89-90): one full copy per no-op cast
+                return x.clone() if self.copy_on_same else x
+            if not isinstance(fmt, Format):
+                raise TypeError("CastTo with a torch.dtype format is torch.ao's stock FakeQuantize path, "
+                                "not part of the accelerated hot path")
+            return self._quantize(x, x.dtype)
         inverse_shaping = None
         shortcut = None
-        pt = self.pre_transform
         if "shaping" in pt:
             x, inverse_shaping = self.apply_shaping_seq(x, pt["shaping"])
         sc_idx = pt.get("noquant_shortcut")
@@ -208,10 +235,10 @@ class CastTo(torch.nn.Module):
             shortcut = x[sc_idx].clone()
         if "format" in pt:
             x = CastToFormat.apply(x, pt["format"], self.block_dim, torch.float32)
-        if self.observer_enabled[0] == 1 and x is not None and not isinstance(self.format, Same):
+        if d["_h_observer_enabled"] and x is not None and not isinstance(fmt, Same):
             self._observer_step(x)
-        if self.fake_quant_enabled[0] == 1:
-            if isinstance(self.format, Format):
+        if d["_h_fake_quant_enabled"]:
+            if isinstance(fmt, Format):
                 x = self._quantize(x, self.physical_dtype)
             else:
                 raise TypeError("CastTo with a torch.dtype format is torch.ao's stock FakeQuantize path, "

@@ -132,7 +132,7 @@ class DmxModule(torch.nn.Module):
         wc, st = self.weight_cast, self.weight_storage_cast
         fmt = wc.format
         if (not isinstance(fmt, BlockFloatingPoint) or fmt.rounding != "nearest" or fmt.block_size < 8 or wc.pre_transform
-                or wc.block_dim not in (-1, _w.dim() - 1) or wc.fake_quant_enabled[0] != 1 or wc.observer_enabled[0] == 1):
+                or wc.block_dim not in (-1, _w.dim() - 1) or not wc._flag("fake_quant_enabled") or wc._flag("observer_enabled")):
             return None
         if st is not None and not (isinstance(st.format, Same) and not st.pre_transform):
             return None
@@ -143,7 +143,7 @@ class DmxModule(torch.nn.Module):
                 return None
             score, K, M = sp.score.detach(), sp.sparseness.K, sp.sparseness.block_size
         sq = None
-        if self.smoothquant is not None and self.smoothquant.fused_to_weight[0] == 0 and self.smoothquant.enabled[0] == 1:
+        if self.smoothquant is not None and not self.smoothquant._flag("fused_to_weight") and self.smoothquant._flag("enabled"):
             if self.smoothquant.win_ch_axis not in (-1, _w.dim() - 1):
                 return None
             sq = self.smoothquant.scale
@@ -161,7 +161,7 @@ class DmxModule(torch.nn.Module):
                 return fused
             if self.weight_sparsifier is not None:
                 _w = self.weight_sparsifier(_w)
-            if self.smoothquant is not None and self.smoothquant.fused_to_weight[0] == 0:
+            if self.smoothquant is not None and not self.smoothquant._flag("fused_to_weight"):
                 _w = self.smoothquant.scale_weight(_w)
             if self.weight_storage_cast is not None:
                 _w = self.weight_storage_cast(_w)
@@ -191,7 +191,7 @@ class DmxModule(torch.nn.Module):
             if self.weight_sparsifier is not None and not isinstance(self.weight_sparseness, Dense):
                 self.weight.data = self.effective_weight
                 self.weight_sparsifier = _LazySparsify(sparseness=Dense())
-            if self.smoothquant is not None and self.smoothquant.fused_to_weight[0] == 0:
+            if self.smoothquant is not None and not self.smoothquant._flag("fused_to_weight"):
                 self.smoothquant.fuse_to_weight(self.weight)
             if self.weight_storage_cast is not None and not isinstance(self.weight_storage_cast.format, Same):
                 self.weight.data = self.weight_storage_cast(self.weight.data)
@@ -208,7 +208,7 @@ class DmxModule(torch.nn.Module):
     def enable_smoothquant_calib(self, state: bool, migration_strength: float = 0.5, fuse_to_weight: bool = False):
         """layer_reconstruction.py:57-68"""
         if self.smoothquant is not None:
-            if self.smoothquant.fused_to_weight[0] == 1:
+            if self.smoothquant._flag("fused_to_weight"):
                 raise RuntimeError("SmoothQuant cannot be calibrated because it has been fused to weight already")
             self.smoothquant.set_migration_strength(migration_strength)
             self.smoothquant.set_dynamic(False)
@@ -220,7 +220,7 @@ class DmxModule(torch.nn.Module):
     def forward(self, input, *args, **kwargs):
         _dtype = input.dtype
         if self.smoothquant is not None:
-            if self.smoothquant.dynamic[0] == 1 or self.smoothquant.calibrating:
+            if self.smoothquant._flag("dynamic") or self.smoothquant.calibrating:
                 self.update_smoothquant_scale(input)
             input = self.smoothquant.scale_input(input)
         _input, args, kwargs = self.input_casts(input, *args, **kwargs)

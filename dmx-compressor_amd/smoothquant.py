@@ -14,13 +14,16 @@ from typing import Union
 import torch
 
 from . import ops
+from ._flags import HostFlags
 from .cast import CastTo
 from .format import Format
 
 __all__ = ["ActivationWeightSmoothQuant"]
 
 
-class ActivationWeightSmoothQuant(torch.nn.Module):
+class ActivationWeightSmoothQuant(HostFlags, torch.nn.Module):
+    _flag_names = ("enabled", "dynamic", "fused_to_weight")
+
     def __init__(self, ch_axis: int, win_ch_axis: int, migration_strength: float = 0.5,
                  scale_format: Union[str, Format] = "SAME", dynamic: bool = False, scale_min: float = 1e-5):
         super().__init__()
@@ -32,21 +35,22 @@ class ActivationWeightSmoothQuant(torch.nn.Module):
         self.register_buffer("enabled", torch.tensor([0], dtype=torch.long))
         self.register_buffer("dynamic", torch.tensor([1 if dynamic else 0], dtype=torch.long))
         self.register_buffer("fused_to_weight", torch.tensor([0], dtype=torch.long))
+        self.refresh_flags()
         self.scale_cast = CastTo(format=scale_format)
         self.calibrating = False
         self.input_maxabs = self.weight_maxabs = None
 
     # -------------------------------------------------------------- switches
     def enable(self, enabled: bool = True):
-        self.enabled[0] = 1 if enabled else 0
+        self._set_flag("enabled", enabled)
 
     def disable(self):
         self.enable(False)
 
     def set_dynamic(self, dynamic: bool = True):
-        if dynamic and self.fused_to_weight[0] == 1:
+        if dynamic and self._flag("fused_to_weight"):
             raise RuntimeError("SmoothQuant cannot be dynamic as scale has been fused to weight already")
-        self.dynamic[0] = 1 if dynamic else 0
+        self._set_flag("dynamic", dynamic)
 
     def set_scale_format(self, format: Union[str, Format]):
         self.scale_cast.set_format(format)
@@ -69,20 +73,20 @@ class ActivationWeightSmoothQuant(torch.nn.Module):
 
     # -------------------------------------------------------------- application
     def scale_input(self, inp: torch.Tensor) -> torch.Tensor:
-        if self.enabled[0] == 1:
+        if self._flag("enabled"):
             # reference: a / scale.view(...) -> torch promotion of (input dtype, fp32 scale)
             return ops.scale_channels(inp, self.scale, self.ch_axis, divide=True,
                                       out_dtype=torch.promote_types(inp.dtype, torch.float32))
         return inp
 
     def scale_weight(self, wgt: torch.Tensor) -> torch.Tensor:
-        if self.enabled[0] == 1:
+        if self._flag("enabled"):
             return ops.scale_channels(wgt, self.scale, self.win_ch_axis, divide=False, out_dtype=wgt.dtype)  # .to(wgt.dtype)
         return wgt
 
     def fuse_to_weight(self, wgt: torch.Tensor) -> None:
         wgt.data = self.scale_weight(wgt.data)
-        self.fused_to_weight[0] = 1
+        self._set_flag("fused_to_weight", True)
 
     def extra_repr(self) -> str:
         return (f"migration_strength = {self.migration_strength.item()}, ch_axis = {self.ch_axis}, win_ch_axis = "

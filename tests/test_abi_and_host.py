@@ -136,10 +136,21 @@ def test_castto_configuration_surface(dmx):
     assert repr(d["input_cast"].format) == "BFP[8|8]{16}(SN)" and repr(d["other_cast"].format) == "SAME"
     with pytest.raises(RuntimeError):
         d.set_format({"nope": "SAME", "x": "SAME"})
-    # SAME format on CPU tensors is a clone and needs no GPU
+    # SAME format needs no GPU: the input itself by default, a clone (the reference's Same.cast) on request
     t = torch.randn(3)
-    out = dmx.CastTo()(t)
+    assert dmx.CastTo()(t) is t
+    c = dmx.CastTo()
+    c.copy_on_same = True
+    out = c(t)
     assert torch.equal(out, t) and out.data_ptr() != t.data_ptr()
+    # the two switches are mirrored on the host (forward never reads a device buffer) and survive a state_dict round trip
+    c.enable_calibration(True, dmx.DummyObserver)
+    assert c._flag("fake_quant_enabled") == 0 and c._flag("observer_enabled") == 1 and int(c.observer_enabled[0]) == 1
+    c2 = dmx.CastTo()
+    c2.load_state_dict(c.state_dict())
+    assert c2._flag("fake_quant_enabled") == 0 and c2._flag("observer_enabled") == 1
+    c.enable_calibration(False)
+    assert c._flag("fake_quant_enabled") == 1 and c._flag("observer_enabled") == 0
 
 
 LEGACY_YAML = """
