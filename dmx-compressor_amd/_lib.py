@@ -100,7 +100,8 @@ def ptr(t):
 
 def stream_of(x: torch.Tensor):
     """hipStream_t of torch's current stream on x's device (kernels are enqueued there, never on the null stream)."""
-    return ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    idx = x.device.index
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx))
 
 
 def split3(shape, dim):

@@ -104,12 +104,13 @@ struct FloatOp {
 //   kUniform inner % N == 0: the whole vector lies in ONE channel -> one (32-bit when possible) division pair
 //   kLast    inner == 1, group_size == 1, C % N == 0: channel = element index mod C, N consecutive scales
 //   kWalk    anything else: ChanIter carries per element
+typedef int64_t i64x2 __attribute__((ext_vector_type(2)));
 enum ChanMode { kNone = 0, kTensor = 1, kUniform = 2, kLast = 3, kWalk = 4 };
 
-static inline int pick_mode(int64_t C, int64_t inner, int64_t group_size, int epl) {
+static inline int pick_mode(int64_t C, int64_t inner, int64_t group_size, int epl, const void* scale, const void* zp) {
   if (C <= 1) return kTensor;
   if (inner % epl == 0) return kUniform;
-  if (inner == 1 && group_size == 1 && C % epl == 0) return kLast;
+  if (inner == 1 && group_size == 1 && C % epl == 0 && aligned16(scale) && aligned16(zp)) return kLast;
   return kWalk;
 }
 
@@ -161,9 +162,22 @@ struct FixedOp {
 #pragma unroll
       for (int k = 0; k < N; k++) y[k] = q(x[k], sc, z, e0 + k);
     } else if (MODE == kLast) {
+      // c0 is a multiple of N and the tables are 16-byte aligned (pick_mode): N scales = N/4 and N zero points = N/2
+      // 16-byte loads instead of 2N scalar ones
       const int64_t c0 = cm.small ? (int64_t)((uint32_t)e0 % (uint32_t)cm.C) : e0 % cm.C;
+      float sc[N], z[N];
 #pragma unroll
-      for (int k = 0; k < N; k++) y[k] = q(x[k], scale[c0 + k], (float)zp[c0 + k], e0 + k);
+      for (int k = 0; k < N; k += 4) {
+        const f32x4 t = *(const f32x4*)(scale + c0 + k);
+        sc[k] = t.x; sc[k + 1] = t.y; sc[k + 2] = t.z; sc[k + 3] = t.w;
+      }
+#pragma unroll
+      for (int k = 0; k < N; k += 2) {
+        const i64x2 t = *(const i64x2*)(zp + c0 + k);
+        z[k] = (float)t.x; z[k + 1] = (float)t.y;
+      }
+#pragma unroll
+      for (int k = 0; k < N; k++) y[k] = q(x[k], sc[k], z[k], e0 + k);
     } else {
       ChanIter it;
       it.start(cm, e0);
@@ -201,7 +215,13 @@ struct ScaleOp {
     } else if (MODE == kLast) {
       const int64_t c0 = cm.small ? (int64_t)((uint32_t)e0 % (uint32_t)cm.C) : e0 % cm.C;
 #pragma unroll
-      for (int k = 0; k < N; k++) y[k] = DIVIDE ? x[k] / scale[c0 + k] : x[k] * scale[c0 + k];
+      for (int k = 0; k < N; k += 4) {
+        const f32x4 t = *(const f32x4*)(scale + c0 + k);  // 16-byte aligned: c0 % N == 0, aligned table (pick_mode)
+        y[k] = DIVIDE ? x[k] / t.x : x[k] * t.x;
+        y[k + 1] = DIVIDE ? x[k + 1] / t.y : x[k + 1] * t.y;
+        y[k + 2] = DIVIDE ? x[k + 2] / t.z : x[k + 2] * t.z;
+        y[k + 3] = DIVIDE ? x[k + 3] / t.w : x[k + 3] * t.w;
+      }
     } else {
       ChanIter it;
       it.start(cm, e0);
@@ -275,7 +295,7 @@ extern "C" int dmxq_fixed_qdq(const void* in, void* out, int dtype_in, int dtype
   const ChannelMap cm = make_channel_map(C, inner, group_size, n);
   hipStream_t s = (hipStream_t)stream;
   const bool simple = fraction == 0 && clamp && rounding == DMXQ_ROUND_NEAREST && precision <= 22;  // |t| <= 2^21
-  const int mode = scale ? pick_mode(C, inner, group_size, dtype_in == DMXQ_F32 ? 4 : 8) : kNone;
+  const int mode = scale ? pick_mode(C, inner, group_size, dtype_in == DMXQ_F32 ? 4 : 8, scale, zero_point) : kNone;
   const float* sc_ = scale;
   const int64_t* zp_ = zero_point;
 #define DMXQ_FIX(M_, S_) return dispatch_stream(in, out, dtype_in, dtype_out, n, FixedOp<M_, S_>{f, cm, sc_, zp_}, s)
@@ -305,7 +325,7 @@ extern "C" int dmxq_scale_channels(const void* in, void* out, int dtype_in, int 
   if (!in || !out || !scale) return DMXQ_ERR_BAD_ARG;
   const ChannelMap cm = make_channel_map(C, inner, 1, n);
   hipStream_t s = (hipStream_t)stream;
-  const int mode = pick_mode(C, inner, 1, dtype_in == DMXQ_F32 ? 4 : 8);
+  const int mode = pick_mode(C, inner, 1, dtype_in == DMXQ_F32 ? 4 : 8, scale, nullptr);
 #define DMXQ_SCALE(D_, M_) return dispatch_stream(in, out, dtype_in, dtype_out, n, ScaleOp<D_, M_>{cm, scale}, s)
   if (divide) {
     if (mode == kTensor || mode == kUniform) DMXQ_SCALE(true, kUniform);

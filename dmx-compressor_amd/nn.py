@@ -259,8 +259,8 @@ class Linear(DmxModule, torch.nn.Linear):
     def _forward(self, _input):
         if isinstance(self.accum_format, Same):  # torch_modules.py:346-350
             _weight = self._weight.to(_input.dtype)
-            _bias = None if self._bias is None else self._bias.to(_input.dtype)
-            return F.linear(_input, _weight, _bias)
+            _bias = self._bias  # (a property: one cast launch per evaluation)
+            return F.linear(_input, _weight, None if _bias is None else _bias.to(_input.dtype))
         _weight = self._weight
         _product = self.accum_cast(torch.matmul(_input.to(_weight.dtype), _weight.t()))
         return torch.add(_product, self._bias) if self.bias is not None else _product
