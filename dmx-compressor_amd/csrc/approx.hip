@@ -10,9 +10,12 @@
 //   gelu       elementwise, erf or tanh form (GeluOp in elementwise.hip)  (torch.nn.functional.gelu)
 //   softmax    over the contiguous last dim, optional input clamp  (modeling/nn/torch_modules.py:989-994)
 //   layernorm  over the contiguous last dim, affine optional       (modeling/nn/torch_modules.py:1062-1082)
-// Row kernels: one workgroup per row, the row is staged ONCE in LDS as fp32 (gfx950 has 160 KiB per CU), the
-// reductions are wave shuffles + a 4-entry LDS exchange, and the result is written from LDS: 1 read + 1 write
-// of HBM per element.  Rows too long for LDS take a 3-pass global fallback.
+// Row kernels, 1 read + 1 write of HBM per element in every case:
+//   * register-resident (the product path: same dtype in and out, rows a multiple of the vector width): a row per
+//     64 or 32 lanes for up to 256 lane-vectors, a row per 256-thread workgroup beyond (LayerNorm); see below;
+//   * fallback for everything else (odd lengths, mixed dtypes): one workgroup per row, the row staged ONCE in LDS as
+//     fp32 (gfx950 has 160 KiB per CU), wave shuffles + a 4-entry LDS exchange; rows too long for LDS take a 3-pass
+//     global version.
 #include <math.h>
 
 #include "common.hpp"
@@ -113,138 +116,381 @@ __global__ __launch_bounds__(kThreads) void layernorm_rows_kernel(const void* __
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Wave-per-row versions for rows of up to 64 * 4 * VPL elements with cols % 4 == 0: the row lives in REGISTERS
-// (VPL 4-element vectors per lane, 8-byte accesses for 16-bit dtypes, 16-byte for fp32, a wave reads 512 B / 1 KiB
-// contiguous per step), reductions are wave shuffles only, no LDS and no workgroup barrier; 4 rows per workgroup.
-__device__ __forceinline__ void load4_rt(const void* p, int dt, int64_t e, float (&v)[4]) {
-  if (dt == DMXQ_F32) {
-    const f32x4 t = *(const f32x4*)((const float*)p + e);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  } else {
-    const u32x2 t = *(const u32x2*)((const uint16_t*)p + e);
-    if (dt == DMXQ_BF16) {
-      v[0] = u2f(t.x << 16); v[1] = u2f(t.x & 0xFFFF0000u); v[2] = u2f(t.y << 16); v[3] = u2f(t.y & 0xFFFF0000u);
-    } else {
-      v[0] = half_lo(t.x); v[1] = half_hi(t.x); v[2] = half_lo(t.y); v[3] = half_hi(t.y);
-    }
+// Register-resident row kernels (same dtype in and out, cols % EPL == 0).  A row is owned by LPR = 64 or 32 adjacent
+// lanes (32: two rows side by side in a wave, for rows whose vector count is an odd multiple of 32 -- 768 bf16
+// elements = 96 vectors = 3 per lane of a half wave, no idle lanes), as VPL lane-vectors of EPL elements (16-byte
+// accesses; 8-byte ones when a 16-bit row is only a multiple of 4 elements); RPW row slots are processed together.
+// Everything is compile-time typed, so the raw loads of all RPW x VPL vectors are issued back to back before the
+// first conversion (a runtime dtype switch around each load made the wave wait for every load in turn).  Lanes past
+// the row end and rows past the tensor end read a clamped in-bounds address instead of being predicated; such
+// duplicates cannot change a row maximum and are dropped from the sums with ONE select per vector.  Reductions are
+// wave shuffles within the LPR lanes: no LDS, no workgroup barrier.  These kernels were VALU-bound before they were
+// memory-bound (profiles/: 16 and 26 VALU instructions per element), hence the care about instruction counts.
+template <int DT, int EPL>
+struct RowVec {
+  static constexpr int kWords = EPL * Elem<DT>::bytes / 4;  // 2 (8 bytes) or 4 (16 bytes)
+  uint32_t w[kWords];
+};
+template <int DT, int EPL>
+__device__ __forceinline__ RowVec<DT, EPL> row_load(const void* p, int64_t e) {
+  RowVec<DT, EPL> r;
+  const char* a = (const char*)p + e * Elem<DT>::bytes;
+  if (RowVec<DT, EPL>::kWords == 4) { const u32x4 t = *(const u32x4*)a; r.w[0] = t.x; r.w[1] = t.y; r.w[2] = t.z; r.w[3] = t.w; }
+  else { const u32x2 t = *(const u32x2*)a; r.w[0] = t.x; r.w[1] = t.y; }
+  return r;
+}
+template <int DT, int EPL>
+__device__ __forceinline__ void row_widen(const RowVec<DT, EPL>& r, float (&x)[EPL]) {
+#pragma unroll
+  for (int j = 0; j < RowVec<DT, EPL>::kWords; j++) {
+    if (DT == DMXQ_F32) x[j] = u2f(r.w[j]);
+    else if (DT == DMXQ_BF16) { x[2 * j] = u2f(r.w[j] << 16); x[2 * j + 1] = u2f(r.w[j] & 0xFFFF0000u); }
+    else { x[2 * j] = half_lo(r.w[j]); x[2 * j + 1] = half_hi(r.w[j]); }
   }
 }
-__device__ __forceinline__ void store4_rt(void* p, int dt, int64_t e, const float (&v)[4]) {
-  if (dt == DMXQ_F32) {
-    *(f32x4*)((float*)p + e) = f32x4{v[0], v[1], v[2], v[3]};
-  } else if (dt == DMXQ_BF16) {
-    *(u32x2*)((uint16_t*)p + e) = u32x2{pack2<DMXQ_BF16>(v[0], v[1]), pack2<DMXQ_BF16>(v[2], v[3])};
-  } else {
-    *(u32x2*)((uint16_t*)p + e) = u32x2{pack2<DMXQ_F16>(v[0], v[1]), pack2<DMXQ_F16>(v[2], v[3])};
-  }
+template <int DT, int EPL>
+__device__ __forceinline__ void row_store(void* p, int64_t e, const float (&y)[EPL]) {
+  char* a = (char*)p + e * Elem<DT>::bytes;
+  if (DT == DMXQ_F32) *(f32x4*)a = f32x4{y[0], y[1], y[2], y[3]};
+  else if (EPL == 8) *(u32x4*)a = u32x4{pack2<DT>(y[0], y[1]), pack2<DT>(y[2], y[3]), pack2<DT>(y[4], y[5]), pack2<DT>(y[6], y[7])};
+  else *(u32x2*)a = u32x2{pack2<DT>(y[0], y[1]), pack2<DT>(y[2], y[3])};
 }
+template <int LPR>
+__device__ __forceinline__ float seg_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+template <int LPR>
+__device__ __forceinline__ float seg_max(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+// row slots per wave iteration: about 32 fp32 values per lane (occupancy beats bytes in flight per wave here: 64 was
+// 1-4 % slower on every shape of tools/bench_shapes)
+constexpr int rows_per_wave(int vpl, int epl) { return 32 / (vpl * epl) >= 4 ? 4 : (32 / (vpl * epl) >= 2 ? 2 : 1); }
 
-template <int VPL>
+// 16-bit outputs: exp(x - m) as v_exp_f32(fma(x, log2 e, -m log2 e)) and one reciprocal per row -- relative error
+// ~2^-21, far inside the output format's 2^-9 / 2^-12 half-ulp (the rounding of m log2 e scales numerator and
+// denominator alike and cancels); fp32 outputs keep expf and the per-element division.
+template <int DT, int EPL, int VPL, int LPR>
 __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __restrict__ in, void* __restrict__ out,
-                                                               int dti, int dto, int64_t rows, int64_t cols,
-                                                               float clamp_min) {
-  const int lane = threadIdx.x & (kWave - 1);
+                                                               int64_t rows, int64_t cols, float clamp_min) {
+  constexpr int SUB = kWave / LPR;  // rows side by side in one wave
+  constexpr int RPW = rows_per_wave(VPL, EPL);
+  constexpr bool FAST = DT != DMXQ_F32;
+  const int lane = threadIdx.x & (kWave - 1), sub = lane / LPR, sl = lane & (LPR - 1);
   const int64_t wave = (int64_t)blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave;
   const int64_t n_waves = (int64_t)gridDim.x * (kThreads / kWave);
-  for (int64_t r = wave; r < rows; r += n_waves) {
-    const int64_t base = r * cols;
-    float x[VPL][4];
-    float m = -INFINITY;
+  const int nv = (int)(cols / EPL);
+  const bool has_clamp = clamp_min > -INFINITY;  // torch.clamp(x, min=input_clamp) (torch_modules.py:989-994)
+  for (int64_t r0 = wave * (RPW * SUB); r0 < rows; r0 += n_waves * (RPW * SUB)) {
+    RowVec<DT, EPL> raw[RPW][VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; i++) {
-      const int64_t c = ((int64_t)i * kWave + lane) * 4;
-      if (c < cols) {
-        load4_rt(in, dti, base + c, x[i]);
+    for (int j = 0; j < RPW; j++) {
+      const int64_t r = r0 + j * SUB + sub;
+      const int64_t base = (r < rows ? r : rows - 1) * cols;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { x[i][k] = fmaxf(x[i][k], clamp_min); m = fmaxf(m, x[i][k]); }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) x[i][k] = -INFINITY;
+      for (int i = 0; i < VPL; i++) {
+        const int v = i * LPR + sl;
+        raw[j][i] = row_load<DT, EPL>(in, base + (int64_t)(v < nv ? v : nv - 1) * EPL);
       }
     }
-    m = wave_maxf(m);
-    float s = 0.0f;
+    float x[RPW][VPL][EPL], m[RPW], s[RPW];
 #pragma unroll
-    for (int i = 0; i < VPL; i++)
+    for (int j = 0; j < RPW; j++) {
+      m[j] = -INFINITY;
 #pragma unroll
-      for (int k = 0; k < 4; k++) { x[i][k] = expf(x[i][k] - m); s += x[i][k]; }  // exp(-inf) = 0 for padding
-    s = wave_sum(s);
+      for (int i = 0; i < VPL; i++) {
+        row_widen<DT, EPL>(raw[j][i], x[j][i]);
+        if (has_clamp) {
 #pragma unroll
-    for (int i = 0; i < VPL; i++) {
-      const int64_t c = ((int64_t)i * kWave + lane) * 4;
-      if (c < cols) {
-        float y[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) y[k] = x[i][k] / s;
-        store4_rt(out, dto, base + c, y);
-      }
-    }
-  }
-}
-
-template <int VPL>
-__global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __restrict__ in, void* __restrict__ out,
-                                                                 int dti, int dto, int64_t rows, int64_t cols,
-                                                                 const void* __restrict__ w,
-                                                                 const void* __restrict__ b, int dtw, float eps) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int64_t wave = (int64_t)blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave;
-  const int64_t n_waves = (int64_t)gridDim.x * (kThreads / kWave);
-  for (int64_t r = wave; r < rows; r += n_waves) {
-    const int64_t base = r * cols;
-    float x[VPL][4];
-    float s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < VPL; i++) {
-      const int64_t c = ((int64_t)i * kWave + lane) * 4;
-      if (c < cols) {
-        load4_rt(in, dti, base + c, x[i]);
-        s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) x[i][k] = 0.0f;
-      }
-    }
-    const float mean = wave_sum(s) / (float)cols;
-    float q = 0.0f;
-#pragma unroll
-    for (int i = 0; i < VPL; i++) {
-      const int64_t c = ((int64_t)i * kWave + lane) * 4;
-      if (c < cols) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const float d = x[i][k] - mean; q += d * d; }
-      }
-    }
-    const float var = wave_sum(q) / (float)cols;
-    const float rstd = 1.0f / sqrtf(var + eps);
-#pragma unroll
-    for (int i = 0; i < VPL; i++) {
-      const int64_t c = ((int64_t)i * kWave + lane) * 4;
-      if (c < cols) {
-        float y[4], ww[4], bb[4];
-        if (w) load4_rt(w, dtw, c, ww);
-        if (b) load4_rt(b, dtw, c, bb);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          y[k] = (x[i][k] - mean) * rstd;
-          if (w) y[k] *= ww[k];
-          if (b) y[k] += bb[k];
+          for (int k = 0; k < EPL; k++) x[j][i][k] = fmaxf(x[j][i][k], clamp_min);
         }
-        store4_rt(out, dto, base + c, y);
+#pragma unroll
+        for (int k = 0; k < EPL; k++) m[j] = fmaxf(m[j], x[j][i][k]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; j++) m[j] = seg_max<LPR>(m[j]);
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      const float mc = -m[j] * 1.4426950408889634f;
+      s[j] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < VPL; i++) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < EPL; k++) {
+          x[j][i][k] = FAST ? __builtin_amdgcn_exp2f(__builtin_fmaf(x[j][i][k], 1.4426950408889634f, mc)) : expf(x[j][i][k] - m[j]);
+          t += x[j][i][k];
+        }
+        s[j] += (i * LPR + sl < nv) ? t : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; j++) s[j] = seg_sum<LPR>(s[j]);
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      const int64_t r = r0 + j * SUB + sub;
+      if (r < rows) {
+        const float inv = 1.0f / s[j];
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+          const int v = i * LPR + sl;
+          if (v < nv) {
+            float y[EPL];
+#pragma unroll
+            for (int k = 0; k < EPL; k++) y[k] = FAST ? x[j][i][k] * inv : x[j][i][k] / s[j];
+            row_store<DT, EPL>(out, r * cols + (int64_t)v * EPL, y);
+          }
+        }
       }
     }
   }
 }
 
-// vector width 4 usable: cols % 4 == 0 and every base pointer aligned to 4 elements of its dtype
-static inline bool vec4_ok(const void* p, int dt, int64_t cols) {
-  const uintptr_t a = dt == DMXQ_F32 ? 16 : 8;
-  return cols % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0;
+// weight / bias (same dtype as the rows) are read ONCE per wave and kept across its rows: widened to fp32 for short
+// rows, packed for longer ones.  Per element: widen + add, subtract + fma, and (x - mean) * (rstd w) + b as
+// subtract + fma with rstd w formed once per (row, vector element).
+template <int DT, int EPL, int VPL, int LPR>
+__global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __restrict__ in, void* __restrict__ out,
+                                                                 int64_t rows, int64_t cols, const void* __restrict__ w,
+                                                                 const void* __restrict__ b, float eps) {
+  constexpr int SUB = kWave / LPR;
+  constexpr int RPW = rows_per_wave(VPL, EPL);
+  constexpr bool HOIST_F32 = VPL * EPL <= 24, HOIST_RAW = !HOIST_F32 && VPL <= 8;
+  const int lane = threadIdx.x & (kWave - 1), sub = lane / LPR, sl = lane & (LPR - 1);
+  const int64_t wave = (int64_t)blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave;
+  const int64_t n_waves = (int64_t)gridDim.x * (kThreads / kWave);
+  const int nv = (int)(cols / EPL);
+  const float inv_n = 1.0f / (float)cols;
+  float wf[HOIST_F32 ? VPL : 1][EPL], bf[HOIST_F32 ? VPL : 1][EPL];
+  RowVec<DT, EPL> wr[HOIST_RAW ? VPL : 1], br[HOIST_RAW ? VPL : 1];
+  if (HOIST_F32 || HOIST_RAW) {
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+      const int v = i * LPR + sl;
+      const int64_t c = (int64_t)(v < nv ? v : nv - 1) * EPL;
+      if (HOIST_F32) {
+        if (w) row_widen<DT, EPL>(row_load<DT, EPL>(w, c), wf[i]);
+        if (b) row_widen<DT, EPL>(row_load<DT, EPL>(b, c), bf[i]);
+      } else {
+        if (w) wr[i] = row_load<DT, EPL>(w, c);
+        if (b) br[i] = row_load<DT, EPL>(b, c);
+      }
+    }
+  }
+  for (int64_t r0 = wave * (RPW * SUB); r0 < rows; r0 += n_waves * (RPW * SUB)) {
+    RowVec<DT, EPL> raw[RPW][VPL];
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      const int64_t r = r0 + j * SUB + sub;
+      const int64_t base = (r < rows ? r : rows - 1) * cols;
+#pragma unroll
+      for (int i = 0; i < VPL; i++) {
+        const int v = i * LPR + sl;
+        raw[j][i] = row_load<DT, EPL>(in, base + (int64_t)(v < nv ? v : nv - 1) * EPL);
+      }
+    }
+    float x[RPW][VPL][EPL], mean[RPW], rstd[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < VPL; i++) {
+        row_widen<DT, EPL>(raw[j][i], x[j][i]);
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < EPL; k++) t += x[j][i][k];
+        s += (i * LPR + sl < nv) ? t : 0.0f;
+      }
+      mean[j] = s;
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; j++) mean[j] = seg_sum<LPR>(mean[j]) * inv_n;
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      float q = 0.0f;
+#pragma unroll
+      for (int i = 0; i < VPL; i++) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < EPL; k++) { const float d = x[j][i][k] - mean[j]; t = __builtin_fmaf(d, d, t); }
+        q += (i * LPR + sl < nv) ? t : 0.0f;
+      }
+      rstd[j] = q;
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; j++) rstd[j] = 1.0f / sqrtf(seg_sum<LPR>(rstd[j]) * inv_n + eps);  // biased variance, as F.layer_norm
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+      const int v = i * LPR + sl;
+      if (v < nv) {
+        float ww[EPL], bb[EPL];
+        if (!HOIST_F32) {
+          if (w) row_widen<DT, EPL>(HOIST_RAW ? wr[i] : row_load<DT, EPL>(w, (int64_t)v * EPL), ww);
+          if (b) row_widen<DT, EPL>(HOIST_RAW ? br[i] : row_load<DT, EPL>(b, (int64_t)v * EPL), bb);
+        }
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+          const int64_t r = r0 + j * SUB + sub;
+          if (r < rows) {
+            float y[EPL];
+#pragma unroll
+            for (int k = 0; k < EPL; k++) {
+              const float g = w ? rstd[j] * (HOIST_F32 ? wf[i][k] : ww[k]) : rstd[j];
+              const float d = x[j][i][k] - mean[j];
+              y[k] = b ? __builtin_fmaf(d, g, HOIST_F32 ? bf[i][k] : bb[k]) : d * g;
+            }
+            row_store<DT, EPL>(out, r * cols + (int64_t)v * EPL, y);
+          }
+        }
+      }
+    }
+  }
+}
+
+// Long rows (more than 256 lane-vectors): a 256-thread WORKGROUP per row, still register resident (VPL vectors per
+// thread), two workgroup reductions per row through a 4-entry LDS exchange, RPW rows per iteration to amortise the two
+// barriers, weight / bias hoisted (packed) out of the persistent row loop.  The wave kernel at this size would hold
+// 128+ values per lane and re-read weight and bias (as much data as the row itself) for every row.
+template <int DT, int EPL, int VPL>
+__global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* __restrict__ in, void* __restrict__ out,
+                                                                  int64_t rows, int64_t cols, const void* __restrict__ w,
+                                                                  const void* __restrict__ b, float eps) {
+  constexpr int RPW = VPL * EPL <= 32 ? 2 : 1;
+  constexpr int NW = kThreads / kWave;
+  __shared__ float red[2][RPW][NW];
+  const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
+  const int nv = (int)(cols / EPL);
+  const float inv_n = 1.0f / (float)cols;
+  RowVec<DT, EPL> wr[VPL], br[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; i++) {
+    const int v = i * kThreads + t;
+    const int64_t c = (int64_t)(v < nv ? v : nv - 1) * EPL;
+    if (w) wr[i] = row_load<DT, EPL>(w, c);
+    if (b) br[i] = row_load<DT, EPL>(b, c);
+  }
+  for (int64_t r0 = (int64_t)blockIdx.x * RPW; r0 < rows; r0 += (int64_t)gridDim.x * RPW) {
+    RowVec<DT, EPL> raw[RPW][VPL];
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      const int64_t base = (r0 + j < rows ? r0 + j : rows - 1) * cols;
+#pragma unroll
+      for (int i = 0; i < VPL; i++) {
+        const int v = i * kThreads + t;
+        raw[j][i] = row_load<DT, EPL>(in, base + (int64_t)(v < nv ? v : nv - 1) * EPL);
+      }
+    }
+    float x[RPW][VPL][EPL], mean[RPW], rstd[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < VPL; i++) {
+        row_widen<DT, EPL>(raw[j][i], x[j][i]);
+        float u = 0.0f;
+#pragma unroll
+        for (int k = 0; k < EPL; k++) u += x[j][i][k];
+        s += (i * kThreads + t < nv) ? u : 0.0f;
+      }
+      s = seg_sum<kWave>(s);
+      if (lane == 0) red[0][j][wv] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      float s = red[0][j][0];
+#pragma unroll
+      for (int k = 1; k < NW; k++) s += red[0][j][k];
+      mean[j] = s * inv_n;
+      float q = 0.0f;
+#pragma unroll
+      for (int i = 0; i < VPL; i++) {
+        float u = 0.0f;
+#pragma unroll
+        for (int k = 0; k < EPL; k++) { const float d = x[j][i][k] - mean[j]; u = __builtin_fmaf(d, d, u); }
+        q += (i * kThreads + t < nv) ? u : 0.0f;
+      }
+      q = seg_sum<kWave>(q);
+      if (lane == 0) red[1][j][wv] = q;
+    }
+    __syncthreads();  // (also orders this iteration's reads of red[0] before the next iteration's writes)
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      float q = red[1][j][0];
+#pragma unroll
+      for (int k = 1; k < NW; k++) q += red[1][j][k];
+      rstd[j] = 1.0f / sqrtf(q * inv_n + eps);  // biased variance, as F.layer_norm
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+      const int v = i * kThreads + t;
+      if (v < nv) {
+        float ww[EPL], bb[EPL];
+        if (w) row_widen<DT, EPL>(wr[i], ww);
+        if (b) row_widen<DT, EPL>(br[i], bb);
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+          if (r0 + j < rows) {
+            float y[EPL];
+#pragma unroll
+            for (int k = 0; k < EPL; k++) {
+              const float g = w ? rstd[j] * ww[k] : rstd[j];
+              const float d = x[j][i][k] - mean[j];
+              y[k] = b ? __builtin_fmaf(d, g, bb[k]) : d * g;
+            }
+            row_store<DT, EPL>(out, (r0 + j) * cols + (int64_t)v * EPL, y);
+          }
+        }
+      }
+    }
+  }
+}
+
+// lane-vector width for the wave kernels: 16 bytes when rows and bases allow it, else 8 bytes for 16-bit rows that are
+// a multiple of 4 elements; 0 = not applicable
+static inline int wave_epl(int dt, int64_t cols, const void* p0, const void* p1, const void* p2, const void* p3) {
+  const uintptr_t a = (uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2 | (uintptr_t)p3;
+  const int full = dt == DMXQ_F32 ? 4 : 8;
+  if (cols % full == 0 && (a & 15) == 0) return full;
+  if (dt != DMXQ_F32 && cols % 4 == 0 && (a & 7) == 0) return 4;
+  return 0;
+}
+
+// (lanes per row, vectors per lane) for a row of nv vectors: the instantiated shape with the fewest idle lane slots.
+// 64 lanes: VPL in {1,2,3,4,5,6,8,10,12,16}; 32 lanes: VPL in {1,3,5}.  vpl = 0: row too long for registers.
+static inline void wave_shape(int64_t nv, int* lpr, int* vpl) {
+  static const int v64[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16}, v32[] = {1, 3, 5};
+  int64_t best = 0;
+  *lpr = 64; *vpl = 0;
+  for (int v : v64)
+    if ((int64_t)v * 64 >= nv) { best = (int64_t)v * 64; *vpl = v; break; }
+  for (int v : v32)
+    if ((int64_t)v * 32 >= nv) { if (best == 0 || (int64_t)v * 32 < best) { *lpr = 32; *vpl = v; } break; }
 }
 
 }  // namespace dmxq
 
 using namespace dmxq;
+
+// persistent grid for the register-resident row kernels: as many workgroups as are resident at once (occupancy of
+// THIS kernel x number of CUs; queried once per kernel and cached), or fewer when the tensor is small
+template <typename K>
+static int resident_grid(K kernel, int64_t wanted) {
+  static int per_device = 0;  // one static per kernel instantiation
+  if (per_device == 0) {
+    int dev = 0, cus = 256, per_cu = 2;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    per_device = cus * per_cu;
+  }
+  return (int)(wanted < per_device ? (wanted < 1 ? 1 : wanted) : per_device);
+}
 
 static inline int row_grid(int64_t rows) { return (int)(rows < 256 * 16 ? (rows < 1 ? 1 : rows) : 256 * 16); }
 
@@ -254,11 +500,32 @@ extern "C" int dmxq_softmax(const void* in, void* out, int dtype_in, int dtype_o
   if (rows * cols == 0) return DMXQ_OK;
   if (!in || !out) return DMXQ_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (cols <= 64 * 4 * 16 && vec4_ok(in, dtype_in, cols) && vec4_ok(out, dtype_out, cols)) {
-    const int64_t vpl = (cols / 4 + kWave - 1) / kWave;
-    const int grid = (int)((rows + 3) / 4 < 256 * 32 ? (rows + 3) / 4 : 256 * 32);
-#define DMXQ_SM(V_) hipLaunchKernelGGL(softmax_wave_kernel<V_>, dim3(grid), dim3(kThreads), 0, s, in, out, dtype_in, dtype_out, rows, cols, input_clamp_min)
-    if (vpl <= 1) DMXQ_SM(1); else if (vpl <= 2) DMXQ_SM(2); else if (vpl <= 4) DMXQ_SM(4); else if (vpl <= 8) DMXQ_SM(8); else DMXQ_SM(16);
+  const int epl = dtype_in == dtype_out ? wave_epl(dtype_in, cols, in, out, nullptr, nullptr) : 0;
+  if (epl && cols <= (int64_t)64 * epl * 16) {
+    int lpr, vpl;
+    wave_shape(cols / epl, &lpr, &vpl);
+#define DMXQ_SM(D_, E_, V_, L_)                                                                                       \
+  do {                                                                                                                \
+    constexpr int per_wg = 4 * rows_per_wave(V_, E_) * (64 / (L_));                                                   \
+    hipLaunchKernelGGL((softmax_wave_kernel<D_, E_, V_, L_>),                                                         \
+                       dim3((unsigned)resident_grid(softmax_wave_kernel<D_, E_, V_, L_>, (rows + per_wg - 1) / per_wg)), \
+                       dim3(kThreads), 0, s, in, out, rows, cols, input_clamp_min);                                   \
+  } while (0)
+#define DMXQ_SM_V(D_, E_)                                                                            \
+  do {                                                                                               \
+    if (lpr == 32) { if (vpl == 1) DMXQ_SM(D_, E_, 1, 32); else if (vpl == 3) DMXQ_SM(D_, E_, 3, 32); else DMXQ_SM(D_, E_, 5, 32); } \
+    else switch (vpl) {                                                                              \
+      case 1: DMXQ_SM(D_, E_, 1, 64); break;   case 2: DMXQ_SM(D_, E_, 2, 64); break;                 \
+      case 3: DMXQ_SM(D_, E_, 3, 64); break;   case 4: DMXQ_SM(D_, E_, 4, 64); break;                 \
+      case 5: DMXQ_SM(D_, E_, 5, 64); break;   case 6: DMXQ_SM(D_, E_, 6, 64); break;                 \
+      case 8: DMXQ_SM(D_, E_, 8, 64); break;   case 10: DMXQ_SM(D_, E_, 10, 64); break;               \
+      case 12: DMXQ_SM(D_, E_, 12, 64); break; default: DMXQ_SM(D_, E_, 16, 64); break;               \
+    }                                                                                                \
+  } while (0)
+    if (dtype_in == DMXQ_F32) DMXQ_SM_V(DMXQ_F32, 4);
+    else if (dtype_in == DMXQ_BF16) { if (epl == 8) DMXQ_SM_V(DMXQ_BF16, 8); else DMXQ_SM_V(DMXQ_BF16, 4); }
+    else { if (epl == 8) DMXQ_SM_V(DMXQ_F16, 8); else DMXQ_SM_V(DMXQ_F16, 4); }
+#undef DMXQ_SM_V
 #undef DMXQ_SM
     return launch_status();
   }
@@ -279,12 +546,58 @@ extern "C" int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype
   if (rows * cols == 0) return DMXQ_OK;
   if (!in || !out) return DMXQ_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  if (cols <= 64 * 4 * 16 && vec4_ok(in, dtype_in, cols) && vec4_ok(out, dtype_out, cols) &&
-      (!weight || vec4_ok(weight, dtype_wb, cols)) && (!bias || vec4_ok(bias, dtype_wb, cols))) {
-    const int64_t vpl = (cols / 4 + kWave - 1) / kWave;
-    const int grid = (int)((rows + 3) / 4 < 256 * 32 ? (rows + 3) / 4 : 256 * 32);
-#define DMXQ_LN(V_) hipLaunchKernelGGL(layernorm_wave_kernel<V_>, dim3(grid), dim3(kThreads), 0, s, in, out, dtype_in, dtype_out, rows, cols, weight, bias, dtype_wb, eps)
-    if (vpl <= 1) DMXQ_LN(1); else if (vpl <= 2) DMXQ_LN(2); else if (vpl <= 4) DMXQ_LN(4); else if (vpl <= 8) DMXQ_LN(8); else DMXQ_LN(16);
+  const bool same = dtype_in == dtype_out && ((!weight && !bias) || dtype_wb == dtype_in);
+  const int epl = same ? wave_epl(dtype_in, cols, in, out, weight, bias) : 0;
+  const int full_epl = dtype_in == DMXQ_F32 ? 4 : 8;
+  if (epl == full_epl && cols / epl > 256 && cols / epl <= 8 * kThreads) {  // long rows: workgroup per row
+    const int64_t nv = cols / epl;
+    const int vpl = (int)((nv + kThreads - 1) / kThreads);
+#define DMXQ_LNB(D_, E_, V_)                                                                                          \
+  do {                                                                                                                \
+    constexpr int rpw = (V_) * (E_) <= 32 ? 2 : 1;                                                                    \
+    hipLaunchKernelGGL((layernorm_block_kernel<D_, E_, V_>),                                                          \
+                       dim3((unsigned)resident_grid(layernorm_block_kernel<D_, E_, V_>, (rows + rpw - 1) / rpw)),     \
+                       dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps);                                 \
+  } while (0)
+#define DMXQ_LNB_V(D_, E_)                                                                                            \
+  do {                                                                                                                \
+    switch (vpl) {                                                                                                    \
+      case 2: DMXQ_LNB(D_, E_, 2); break; case 3: DMXQ_LNB(D_, E_, 3); break; case 4: DMXQ_LNB(D_, E_, 4); break;      \
+      case 5: DMXQ_LNB(D_, E_, 5); break; case 6: DMXQ_LNB(D_, E_, 6); break; default: DMXQ_LNB(D_, E_, 8); break;     \
+    }                                                                                                                 \
+  } while (0)
+    if (dtype_in == DMXQ_F32) DMXQ_LNB_V(DMXQ_F32, 4);
+    else if (dtype_in == DMXQ_BF16) DMXQ_LNB_V(DMXQ_BF16, 8);
+    else DMXQ_LNB_V(DMXQ_F16, 8);
+#undef DMXQ_LNB_V
+#undef DMXQ_LNB
+    return launch_status();
+  }
+  if (epl && cols <= (int64_t)64 * epl * 16) {
+    int lpr, vpl;
+    wave_shape(cols / epl, &lpr, &vpl);
+#define DMXQ_LN(D_, E_, V_, L_)                                                                                       \
+  do {                                                                                                                \
+    constexpr int per_wg = 4 * rows_per_wave(V_, E_) * (64 / (L_));                                                   \
+    hipLaunchKernelGGL((layernorm_wave_kernel<D_, E_, V_, L_>),                                                       \
+                       dim3((unsigned)resident_grid(layernorm_wave_kernel<D_, E_, V_, L_>, (rows + per_wg - 1) / per_wg)), \
+                       dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps);                                 \
+  } while (0)
+#define DMXQ_LN_V(D_, E_)                                                                            \
+  do {                                                                                               \
+    if (lpr == 32) { if (vpl == 1) DMXQ_LN(D_, E_, 1, 32); else if (vpl == 3) DMXQ_LN(D_, E_, 3, 32); else DMXQ_LN(D_, E_, 5, 32); } \
+    else switch (vpl) {                                                                              \
+      case 1: DMXQ_LN(D_, E_, 1, 64); break;   case 2: DMXQ_LN(D_, E_, 2, 64); break;                 \
+      case 3: DMXQ_LN(D_, E_, 3, 64); break;   case 4: DMXQ_LN(D_, E_, 4, 64); break;                 \
+      case 5: DMXQ_LN(D_, E_, 5, 64); break;   case 6: DMXQ_LN(D_, E_, 6, 64); break;                 \
+      case 8: DMXQ_LN(D_, E_, 8, 64); break;   case 10: DMXQ_LN(D_, E_, 10, 64); break;               \
+      case 12: DMXQ_LN(D_, E_, 12, 64); break; default: DMXQ_LN(D_, E_, 16, 64); break;               \
+    }                                                                                                \
+  } while (0)
+    if (dtype_in == DMXQ_F32) DMXQ_LN_V(DMXQ_F32, 4);
+    else if (dtype_in == DMXQ_BF16) { if (epl == 8) DMXQ_LN_V(DMXQ_BF16, 8); else DMXQ_LN_V(DMXQ_BF16, 4); }
+    else { if (epl == 8) DMXQ_LN_V(DMXQ_F16, 8); else DMXQ_LN_V(DMXQ_F16, 4); }
+#undef DMXQ_LN_V
 #undef DMXQ_LN
     return launch_status();
   }

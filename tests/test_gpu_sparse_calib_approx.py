@@ -234,3 +234,38 @@ def test_histogram_observer_group_equals_tensor(dmx, cuda):
             assert torch.allclose(a(W), b(W), rtol=0.0, atol=1e-8)
     with pytest.raises(NotImplementedError):
         dmx.HistogramObserver(qscheme=torch.per_channel_affine)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_softmax_layernorm_every_row_kernel_shape(dmx, cuda, dtype):
+    """Row lengths that select every register-resident kernel shape (approx.hip: 64 / 32 lanes per row, 1..16 vectors
+    per lane, 8-byte vectors for 16-bit rows that are only a multiple of 4, workgroup-per-row for long rows) and the
+    LDS / global fallbacks (odd lengths, mixed dtypes), with ragged row counts so that the clamped out-of-range rows
+    and lanes are exercised.  Same tolerances as above."""
+    F = torch.nn.functional
+    eps = torch.finfo(dtype).eps
+
+    def bad(got, ref32, ulps, absolute):
+        ref = ref32.to(dtype).float()
+        got = got.cpu().float()
+        both_nan = torch.isnan(got) & torch.isnan(ref)
+        return int((((got - ref).abs() > ulps * eps * ref.abs() + absolute) & ~both_nan).sum()
+                   + (torch.isnan(got) ^ torch.isnan(ref)).sum())
+
+    for n, cols in enumerate((4, 8, 64, 252, 256, 264, 768, 1024, 1280, 1500, 1536, 2048, 2304, 2560, 3072, 4096, 5120,
+                              6144, 7168, 8192, 12288, 16384, 777, 1501)):
+        rows = (1, 7, 33, 130)[n % 4]
+        x = (make("normal", (rows, cols), seed=100 + n) * 2).to(dtype)
+        if rows > 2:
+            x[1, : cols // 2] = float("-inf")      # a masked row: exp(-inf) = 0
+        assert bad(dmx.ops.softmax(x.to(cuda), -1), F.softmax(x.float(), -1), 1, 2e-6) == 0, ("softmax", cols, rows)
+        if rows > 2:
+            y = x.clone(); y[2] = float("-inf")    # a fully masked row is NaN in torch too
+            assert bad(dmx.ops.softmax(y.to(cuda), -1), F.softmax(y.float(), -1), 1, 2e-6) == 0, ("softmax -inf row", cols)
+        x = (make("normal", (rows, cols), seed=200 + n) * 2 + 0.5).to(dtype)
+        w = (make("normal", (cols,), seed=12) * 0.1 + 1).to(dtype)
+        b = (make("normal", (cols,), seed=13) * 0.1).to(dtype)
+        for ww, bb in ((w, b), (w, None), (None, None)):
+            got = dmx.ops.layernorm(x.to(cuda), (cols,), None if ww is None else ww.to(cuda), None if bb is None else bb.to(cuda), 1e-5)
+            ref = F.layer_norm(x.float(), (cols,), None if ww is None else ww.float(), None if bb is None else bb.float(), 1e-5)
+            assert bad(got, ref, 2, 4e-6) == 0, ("layernorm", cols, rows, ww is not None, bb is not None)
