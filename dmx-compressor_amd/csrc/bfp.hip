@@ -141,7 +141,10 @@ static int dispatch_mode(const void* in, void* out, int64_t outer, int64_t L, in
 extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int man_bits,
                               int exp_bits, int exp_bias, int flush_subnormal, int unsigned_abs, int rounding,
                               uint64_t seed, void* stream);
-// bfp_ragged.hip: LDS-staged kernel for ragged / unaligned rows; DMXQ_ERR_UNSUPPORTED = not applicable
+// bfp_urows.hip: direct (unaligned 16-byte access) kernel for ragged / unaligned rows, same-size dtypes
+extern "C" int dmxq_internal_bfp_urows(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t L,
+                                       int64_t B, int wl, int rounding, int symmetric, uint64_t seed, void* stream);
+// bfp_ragged.hip: LDS-staged kernel for the remaining ragged / unaligned cases; DMXQ_ERR_UNSUPPORTED = not applicable
 extern "C" int dmxq_internal_bfp_ragged(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t L,
                                         int64_t B, int wl, int rounding, int symmetric, uint64_t seed, void* stream);
 // bfp_cols.hip: register-tiled kernel for blocks along a non-contiguous dimension; DMXQ_ERR_UNSUPPORTED = not applicable
@@ -168,6 +171,9 @@ extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_o
     const bool pow2 = (block_size & (block_size - 1)) == 0;
     const bool rows_ok = L % block_size == 0 && pow2 && block_size >= epl && block_size <= 64 * epl && aligned16(in) && aligned16(out);
     if (!rows_ok) {
+      const int ru = dmxq_internal_bfp_urows(in, out, dtype_in, dtype_out, outer, L, block_size, precision, rounding,
+                                             symmetric, seed, stream);
+      if (ru != DMXQ_ERR_UNSUPPORTED) return ru;
       const int rc = dmxq_internal_bfp_ragged(in, out, dtype_in, dtype_out, outer, L, block_size, precision, rounding,
                                               symmetric, seed, stream);
       if (rc != DMXQ_ERR_UNSUPPORTED) return rc;

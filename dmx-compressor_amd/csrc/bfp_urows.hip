@@ -1,0 +1,182 @@
+// csrc/bfp_urows.hip — BFP Q->DQ along the contiguous dim for rows the flat-stream kernel (bfp_rows.hpp) cannot take:
+// L % B != 0 (torch.split's ragged last block, numerical/format.py:324-326 — LeNet fc in = 400, attention rows of
+// 1500, ...) and/or rows or bases that are not 16-byte aligned — WITHOUT staging through LDS.
+//
+// gfx950 serves 16-byte global accesses at any element alignment at 93-97 % of the aligned rate (measured:
+// tools/scratch/unal.hip, 2- / 4- / 8-byte offsets), so a row is read directly as ceil(L / EPL) lane-vectors starting
+// at its first element, whatever the row pitch.  The vectors of all rows are numbered in a VIRTUAL flat space in which
+// every row is padded to a multiple of the block's lane count (nvrp vectors per row): a block is then B / EPL adjacent
+// lanes of one wave exactly as in the aligned kernel (block max by DPP, same arithmetic, bfp_math.hpp), padding
+// vectors read nothing and count as zeros (= the reference's shorter last block), and the one partial vector at the
+// end of a row (L % EPL elements) is read and written in 8 / 4 / 2-byte pieces so that nothing outside the row is
+// touched.  HBM traffic is 1 read + 1 write per element; same-size input and output dtypes.
+#include "bfp_math.hpp"
+
+namespace dmxq {
+
+typedef u32x4 u32x4_u __attribute__((aligned(2)));
+typedef u32x2 u32x2_u __attribute__((aligned(2)));
+typedef uint32_t u32_u __attribute__((aligned(2)));
+
+// the first t elements (t < EPL, wave-uniform) of the vector at p, rest zero
+template <int EB>
+__device__ __forceinline__ u32x4 tail_load(const char* p, int t) {
+  uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+  if (EB == 2) {
+    if (t & 4) { const u32x2 a = *(const u32x2_u*)p; w0 = a.x; w1 = a.y; }
+    if (t & 2) { const uint32_t x = *(const u32_u*)(p + (t & 4) * 2); if (t & 4) w2 = x; else w0 = x; }
+    if (t & 1) {
+      const uint32_t x = *(const uint16_t*)(p + (t & 6) * 2);
+      switch (t >> 1) { case 0: w0 = x; break; case 1: w1 = x; break; case 2: w2 = x; break; default: w3 = x; break; }
+    }
+  } else {
+    if (t & 2) { const u32x2 a = *(const u32x2_u*)p; w0 = a.x; w1 = a.y; }
+    if (t & 1) { const uint32_t x = *(const u32_u*)(p + (t & 2) * 4); if (t & 2) w2 = x; else w0 = x; }
+  }
+  return u32x4{w0, w1, w2, w3};
+}
+template <int EB>
+__device__ __forceinline__ void tail_store(char* p, int t, const u32x4& o) {
+  if (EB == 2) {
+    if (t & 4) *(u32x2_u*)p = u32x2{o.x, o.y};
+    if (t & 2) *(u32_u*)(p + (t & 4) * 2) = (t & 4) ? o.z : o.x;
+    if (t & 1) {
+      uint32_t x;
+      switch (t >> 1) { case 0: x = o.x; break; case 1: x = o.y; break; case 2: x = o.z; break; default: x = o.w; break; }
+      *(uint16_t*)(p + (t & 6) * 2) = (uint16_t)x;
+    }
+  } else {
+    if (t & 2) *(u32x2_u*)p = u32x2{o.x, o.y};
+    if (t & 1) *(u32_u*)(p + (t & 2) * 4) = (t & 2) ? o.z : o.x;
+  }
+}
+
+template <int DTI, int DTO, int RND, bool ASYM, int FAST, int UNROLL>
+__global__ __launch_bounds__(kThreads) void bfp_urows_kernel(const void* __restrict__ in, void* __restrict__ out,
+                                                            int64_t rows, int64_t L, int nvr /*vectors per row*/,
+                                                            int nvrp /*... padded to whole blocks*/, int tail,
+                                                            int lpb_arg, int wl, int rounding, uint64_t seed) {
+  static_assert(Elem<DTI>::bytes == Elem<DTO>::bytes, "same-size dtypes");
+  constexpr int EB = Elem<DTI>::bytes, EPL = 16 / EB;
+  constexpr bool kFast = FAST != 0 && RND == DMXQ_ROUND_NEAREST;
+  constexpr int64_t TILE = (int64_t)kThreads * UNROLL;
+  const bool stoch = (RND == kRuntimeRounding) && rounding == DMXQ_ROUND_STOCHASTIC;
+  const int lpb = __builtin_amdgcn_readfirstlane(lpb_arg);
+  const int64_t total = rows * nvrp;
+  const int64_t n_tiles = (total + TILE - 1) / TILE;
+  const int dq = kThreads / nvrp, dr = kThreads % nvrp;  // (row, vector) step between a lane's consecutive vectors
+  const int last = nvr - 1;
+  const bool has_tail = tail < EPL;                       // the last vector of a row is partial
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t u0 = tile * TILE + threadIdx.x;
+    int64_t r = total < ((int64_t)1 << 31) ? (int64_t)((uint32_t)u0 / (uint32_t)nvrp) : u0 / nvrp;
+    int v = (int)(u0 - r * nvrp);
+    u32x4 raw[UNROLL];
+    int64_t eoff[UNROLL];  // element offset of the vector; -1: nothing to read or write (padding, past the end)
+    bool part[UNROLL];     // the partial last vector of its row
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const bool real = r < rows && v < nvr;
+      part[u] = real && has_tail && v == last;
+      eoff[u] = real ? r * L + (int64_t)v * EPL : -1;
+      // whole vectors: one 16-byte access at any alignment; everything else reads vector 0 of the tensor (in bounds,
+      // discarded) so that the loads stay unconditional and are issued back to back
+      const bool whole = real && !part[u];
+      raw[u] = __builtin_nontemporal_load((const u32x4_u*)((const char*)in + (whole ? eoff[u] : 0) * EB));
+      if (!whole) raw[u] = u32x4{0u, 0u, 0u, 0u};
+      v += dr; r += dq;
+      if (v >= nvrp) { v -= nvrp; r += 1; }
+    }
+    if (has_tail) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++)
+        if (part[u]) raw[u] = tail_load<EB>((const char*)in + eoff[u] * EB, tail);
+    }
+    u32x4 o[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const uint32_t mb = group_max_u32(absmax_bits<DTI>(raw[u]), lpb);
+      float x[EPL], y[EPL];
+      widen<DTI, EPL>(raw[u], x);
+      if (kFast && __builtin_amdgcn_ballot_w64(!bfp_fast_ok(mb, wl)) == 0ull) {
+        const BfpBlockParams p = bfp_block_params<ASYM, true>(mb, wl);
+#pragma unroll
+        for (int k = 0; k < EPL; k++) y[k] = bfp_q1_fast<FAST == 2, ASYM>(x[k], p);
+      } else {
+        const BfpBlockParams p = bfp_block_params<ASYM, false>(mb, wl);
+#pragma unroll
+        for (int k = 0; k < EPL; k++)
+          y[k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, rnd_if(stoch, seed, (uint64_t)(eoff[u] + k)));
+      }
+      const OutVec<DTO, EPL> pk = pack_vec<DTO, EPL>(y);
+      o[u] = u32x4{pk.w[0], pk.w[1], pk.w[2], pk.w[3]};
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++)
+      if (eoff[u] >= 0 && !part[u]) __builtin_nontemporal_store(o[u], (u32x4_u*)((char*)out + eoff[u] * EB));
+    if (has_tail) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++)
+        if (part[u]) tail_store<EB>((char*)out + eoff[u] * EB, tail, o[u]);
+    }
+  }
+}
+
+template <int DTI, int DTO, int RND, bool ASYM>
+static int launch_urows(const void* in, void* out, int64_t rows, int64_t L, int64_t B, int wl, int rounding,
+                        uint64_t seed, hipStream_t s) {
+  constexpr int EPL = 16 / Elem<DTI>::bytes;
+  constexpr int UNROLL = 3;  // 2..4 are within 3 % of each other, 8 is 10 % slower (tools/scratch, rows of 1500 / 4088 / 4100)
+  const int lpb = (int)(B / EPL);
+  const int64_t nvr = (L + EPL - 1) / EPL, nvrp = (nvr + lpb - 1) / lpb * lpb;
+  const int tail = (int)(L - (nvr - 1) * EPL);  // 1..EPL elements in the last vector of a row
+  const int64_t tiles = (rows * nvrp + (int64_t)kThreads * UNROLL - 1) / ((int64_t)kThreads * UNROLL);
+  const int grid = (int)(tiles < (1 << 20) ? tiles : (1 << 20));
+  const int fast = (RND == DMXQ_ROUND_NEAREST && wl <= 20) ? (bfp_single_rounding_ok<DTI>(wl) ? 2 : 1) : 0;
+#define DMXQ_UR(F_)                                                                                                \
+  hipLaunchKernelGGL((bfp_urows_kernel<DTI, DTO, RND, ASYM, F_, UNROLL>), dim3(grid), dim3(kThreads), 0, s, in, out, \
+                     rows, L, (int)nvr, (int)nvrp, tail, lpb, wl, rounding, seed)
+  constexpr bool in16 = Elem<DTI>::bytes == 2;
+  if constexpr (RND == kRuntimeRounding) {
+    DMXQ_UR(0);
+  } else {
+    if (in16 && fast == 2) {
+      if constexpr (in16) DMXQ_UR(2);
+    } else {
+      DMXQ_UR(1);
+    }
+  }
+#undef DMXQ_UR
+  return launch_status();
+}
+
+}  // namespace dmxq
+
+using namespace dmxq;
+
+// internal entry used by dmxq_bfp_qdq (bfp.hip) for inner == 1 tensors the flat-stream kernel cannot take.
+// DMXQ_ERR_UNSUPPORTED = not applicable (caller goes on to the LDS-staged kernel, bfp_ragged.hip).
+extern "C" int dmxq_internal_bfp_urows(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t L,
+                                       int64_t B, int wl, int rounding, int symmetric, uint64_t seed, void* stream) {
+  const int epl = dtype_in == DMXQ_F32 ? 4 : 8;
+  const bool same_size = (dtype_in == DMXQ_F32) == (dtype_out == DMXQ_F32);
+  if (!same_size || B < epl || B > 64 * epl || (B & (B - 1)) != 0 || wl > 22 || L < epl) return DMXQ_ERR_UNSUPPORTED;
+  if ((L + epl - 1) / epl + 64 >= ((int64_t)1 << 31)) return DMXQ_ERR_UNSUPPORTED;
+  const uintptr_t eb = dtype_in == DMXQ_F32 ? 4 : 2;
+  if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & (eb - 1)) return DMXQ_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const bool asym = !symmetric;
+#define DMXQ_DT(I_, O_)                                                                                          \
+  if (dtype_in == I_ && dtype_out == O_) {                                                                       \
+    if (rounding == DMXQ_ROUND_NEAREST && wl <= 20)                                                              \
+      return asym ? launch_urows<I_, O_, DMXQ_ROUND_NEAREST, true>(in, out, rows, L, B, wl, rounding, seed, s)    \
+                  : launch_urows<I_, O_, DMXQ_ROUND_NEAREST, false>(in, out, rows, L, B, wl, rounding, seed, s);  \
+    return asym ? launch_urows<I_, O_, kRuntimeRounding, true>(in, out, rows, L, B, wl, rounding, seed, s)        \
+                : launch_urows<I_, O_, kRuntimeRounding, false>(in, out, rows, L, B, wl, rounding, seed, s);      \
+  }
+  DMXQ_DT(DMXQ_BF16, DMXQ_BF16)
+  DMXQ_DT(DMXQ_F16, DMXQ_F16)
+  DMXQ_DT(DMXQ_F32, DMXQ_F32)
+#undef DMXQ_DT
+  return DMXQ_ERR_UNSUPPORTED;
+}

@@ -67,9 +67,14 @@ def test_block_dim_layouts(dmx, cuda, oracle, dim, B):
 
 @pytest.mark.parametrize("B", [8, 16, 64, 256])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_ragged_and_unaligned_rows_lds_kernel(dmx, cuda, oracle, B, dtype):
-    """Row lengths that are not whole blocks and/or not 16-byte aligned: the LDS-staged kernel (bfp_ragged.hip),
-    every copy width (16/8/4/2 bytes), rows longer than one LDS segment, a view that starts mid-buffer."""
+def test_ragged_and_unaligned_rows(dmx, cuda, oracle, B, dtype):
+    """Row lengths that are not whole blocks and/or not 16-byte aligned: the direct unaligned-access kernel
+    (bfp_urows.hip; same-size dtypes) and the LDS-staged one (bfp_ragged.hip; widening / narrowing casts, every copy
+    width), every tail length of the last lane-vector, rows longer than one LDS segment, a view that starts
+    mid-buffer."""
+    for L in range(4, 24):
+        x = make("mixed", (5, L), seed=B + L, dtype=dtype, block=4)
+        assert _run(dmx, cuda, oracle, x, 8, B) == 0, L
     for shape in ((7, 400), (33, 1500), (5, 84), (3, 1001), (2, 9001), (1, 13), (64, 120), (3, 5, 2, 50)):
         x = make("mixed", shape, seed=B + shape[-1], dtype=dtype, block=8)
         assert _run(dmx, cuda, oracle, x, 8, B) == 0, shape
