@@ -14,45 +14,74 @@
 
 namespace dmxq {
 
+// codes of one 16-byte input vector.  Nearest-even through the magic add of bfp_math.hpp (2): with t = fl(x + base),
+// fl(t + M) lies in M's binade, whose ulp is the quantum, and so does K = M + base: the INTEGER difference of the two
+// bit patterns is the code.  Clamp and asymmetric rule as bfp_q1_fast (double-rounding form, any input dtype).
+template <int DTI, int EPL>
+__device__ __forceinline__ void pack_codes(const u32x4& raw, uint32_t mb, int wl, int asym, bool fast, int (&code)[EPL]) {
+  const uint32_t Eb = (mb & 0x7F800000u) >> 23;
+  float x[EPL];
+  widen<DTI, EPL>(raw, x);
+  if (Eb == 0u || Eb == 255u) {
+#pragma unroll
+    for (int k = 0; k < EPL; k++) code[k] = 0;
+  } else if (fast) {
+    const BfpBlockParams p = bfp_block_params<true, true>(mb, wl);
+    const int cmax = (1 << (wl - 1)) - 1;
+    const uint32_t kb = f2u(p.K);
+#pragma unroll
+    for (int k = 0; k < EPL; k++) {
+      const int ci = (int)(f2u((x[k] + p.base) + p.M) - kb);
+      int c = ci < -cmax ? -cmax : (ci > cmax ? cmax : ci);
+      if (asym) c = (x[k] <= p.thr) ? -cmax - 1 : c;
+      code[k] = c;
+    }
+  } else {
+    const float inv_quantum = u2f((uint32_t)(127 - ((int)Eb - 127 - (wl - 2))) << 23);  // 2^-(e-(p-2))
+    const BfpBlockParams p = bfp_block_params<true, false>(mb, wl);
+#pragma unroll
+    for (int k = 0; k < EPL; k++) {
+      const float q = asym ? bfp_q1<DMXQ_ROUND_NEAREST, true>(x[k], p, wl, DMXQ_ROUND_NEAREST, 0u)
+                           : bfp_q1<DMXQ_ROUND_NEAREST, false>(x[k], p, wl, DMXQ_ROUND_NEAREST, 0u);
+      code[k] = (int)(q * inv_quantum);  // exact: q is a multiple of the quantum, |code| <= 2^(p-1)
+    }
+  }
+}
+
 template <int DTI>
 __global__ __launch_bounds__(kThreads) void bfp_pack_rows_kernel(const void* __restrict__ in, int8_t* __restrict__ mant,
                                                                 uint8_t* __restrict__ exps, int64_t n_vec, int lpb_arg,
-                                                                int wl, int asym) {
+                                                                int lpb_log, int wl, int asym) {
   constexpr int EPL = 16 / Elem<DTI>::bytes;
+  constexpr int U = 4;  // vectors in flight per lane
   const int lpb = __builtin_amdgcn_readfirstlane(lpb_arg);
+  const bool leader = (threadIdx.x & (lpb - 1)) == 0;  // v = threadIdx (mod lpb): strides are multiples of 64
   const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < n_vec; v += stride) {
-    const u32x4 raw = load_raw16<true>(in, v * 16);
-    const uint32_t mb = group_max_u32(absmax_bits<DTI>(raw), lpb);
-    const uint32_t Eb = (mb & 0x7F800000u) >> 23;
-    float x[EPL];
-    widen<DTI, EPL>(raw, x);
-    int8_t code[EPL];
-    if (Eb == 0u || Eb == 255u) {
+  for (int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; v0 < n_vec; v0 += U * stride) {
+    u32x4 raw[U];
 #pragma unroll
-      for (int k = 0; k < EPL; k++) code[k] = 0;
-    } else {
-      const float inv_quantum = u2f((uint32_t)(127 - ((int)Eb - 127 - (wl - 2)) ) << 23);  // 2^-(e-(p-2))
+    for (int u = 0; u < U; u++) {
+      const int64_t v = v0 + u * stride < n_vec ? v0 + u * stride : v0;  // clamped (whole blocks: v0's block): unconditional loads
+      raw[u] = load_raw16<true>(in, v * 16);
+    }
 #pragma unroll
-      for (int k = 0; k < EPL; k++) {
-        float q;
-        if (asym) { const BfpBlockParams p = bfp_block_params<true, false>(mb, wl); q = bfp_q1<DMXQ_ROUND_NEAREST, true>(x[k], p, wl, DMXQ_ROUND_NEAREST, 0u); }
-        else { const BfpBlockParams p = bfp_block_params<false, false>(mb, wl); q = bfp_q1<DMXQ_ROUND_NEAREST, false>(x[k], p, wl, DMXQ_ROUND_NEAREST, 0u); }
-        code[k] = (int8_t)(int)(q * inv_quantum);  // exact: q is a multiple of the quantum, |code| <= 2^(p-1)
+    for (int u = 0; u < U; u++) {
+      const int64_t v = v0 + u * stride;
+      const uint32_t mb = group_max_u32(absmax_bits<DTI>(raw[u]), lpb);
+      const bool fast = __builtin_amdgcn_ballot_w64(!bfp_fast_ok(mb, wl)) == 0ull;
+      int code[EPL];
+      pack_codes<DTI, EPL>(raw[u], mb, wl, asym, fast, code);
+      if (v < n_vec) {
+        uint32_t w[EPL / 4];
+#pragma unroll
+        for (int j = 0; j < EPL / 4; j++)
+          w[j] = ((uint32_t)code[4 * j] & 0xFFu) | (((uint32_t)code[4 * j + 1] & 0xFFu) << 8) |
+                 (((uint32_t)code[4 * j + 2] & 0xFFu) << 16) | ((uint32_t)code[4 * j + 3] << 24);
+        if (EPL == 8) __builtin_nontemporal_store(u32x2{w[0], w[EPL / 4 - 1]}, (u32x2*)(mant + v * 8));
+        else __builtin_nontemporal_store(w[0], (uint32_t*)(mant + v * 4));
+        if (leader) exps[v >> lpb_log] = (uint8_t)((mb & 0x7F800000u) >> 23);
       }
     }
-    if (EPL == 8) {
-      uint32_t lo = 0, hi = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) { lo |= (uint32_t)(uint8_t)code[k] << (8 * k); hi |= (uint32_t)(uint8_t)code[4 + k] << (8 * k); }
-      *(u32x2*)(mant + v * 8) = u32x2{lo, hi};
-    } else {
-      uint32_t lo = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) lo |= (uint32_t)(uint8_t)code[k] << (8 * k);
-      *(uint32_t*)(mant + v * 4) = lo;
-    }
-    if ((v % lpb) == 0) exps[v / lpb] = (uint8_t)Eb;
   }
 }
 
@@ -103,6 +132,44 @@ __global__ __launch_bounds__(kThreads) void bfp_unpack_kernel(const int8_t* __re
   }
 }
 
+// vector twin: rows of whole power-of-two blocks of >= 8 codes.  A lane turns 8 codes (one 8-byte load) of ONE block
+// into 8 outputs (one or two 16-byte stores); the block index is a shift of the flat element index.
+// value = (code * 2^-(p-2)) * 2^(E-127): the first product is exact, the second rounds once (only a denormal result
+// rounds at all) -- the same value as the scalar kernel's ldexpf -- and cannot overflow.
+template <int DTO>
+__global__ __launch_bounds__(kThreads) void bfp_unpack_vec_kernel(const int8_t* __restrict__ mant,
+                                                                 const uint8_t* __restrict__ exps, void* __restrict__ out,
+                                                                 int64_t n_vec, int b_shift /*log2(B / 8)*/, int wl) {
+  const float down = u2f((uint32_t)(127 - (wl - 2)) << 23);
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; v0 < n_vec; v0 += 4 * stride) {
+    u32x2 m[4];
+    uint32_t eb[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t v = v0 + u * stride < n_vec ? v0 + u * stride : n_vec - 1;  // clamped: unconditional loads
+      m[u] = __builtin_nontemporal_load((const u32x2*)(mant + v * 8));
+      eb[u] = exps[v >> b_shift];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t v = v0 + u * stride;
+      if (v < n_vec) {
+        const float up = eb[u] == 255u ? u2f(0x7FC00000u) : u2f(eb[u] << 23);
+        if (eb[u] == 0u) m[u] = u32x2{0u, 0u};  // zero / denormal block: +0 whatever the codes (as the scalar kernel)
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const uint32_t w = k < 4 ? m[u].x : m[u].y;
+          const int c = (int)(w << (24 - 8 * (k & 3))) >> 24;  // sign-extended byte k
+          y[k] = ((float)c * down) * up;                       // NaN block: c * NaN = NaN (also for c = 0)
+        }
+        store_vec<DTO, 8, true>(out, v * 8, y);
+      }
+    }
+  }
+}
+
 }  // namespace dmxq
 
 using namespace dmxq;
@@ -120,10 +187,12 @@ extern "C" int dmxq_bfp_pack(const void* in, int dtype_in, int8_t* mant, uint8_t
   const int asym = symmetric ? 0 : 1;
   if (L % B == 0 && pow2 && B >= epl && B <= 64 * epl && aligned16(in) && (reinterpret_cast<uintptr_t>(mant) & 7u) == 0) {
     const int64_t n_vec = n / epl;
-    const int grid = grid_for(n_vec);
-    if (dtype_in == DMXQ_F32) hipLaunchKernelGGL(bfp_pack_rows_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), precision, asym);
-    else if (dtype_in == DMXQ_F16) hipLaunchKernelGGL(bfp_pack_rows_kernel<DMXQ_F16>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), precision, asym);
-    else hipLaunchKernelGGL(bfp_pack_rows_kernel<DMXQ_BF16>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), precision, asym);
+    const int grid = grid_for((n_vec + 3) / 4);
+    int lpb_log = 0;
+    while (((int64_t)epl << lpb_log) < B) lpb_log++;
+    if (dtype_in == DMXQ_F32) hipLaunchKernelGGL(bfp_pack_rows_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
+    else if (dtype_in == DMXQ_F16) hipLaunchKernelGGL(bfp_pack_rows_kernel<DMXQ_F16>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
+    else hipLaunchKernelGGL(bfp_pack_rows_kernel<DMXQ_BF16>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
   } else {
     const int grid = grid_for(rows * ((L + B - 1) / B));
     if (dtype_in == DMXQ_F32) hipLaunchKernelGGL(bfp_pack_generic_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, rows, L, B, precision, asym);
@@ -139,6 +208,18 @@ extern "C" int dmxq_bfp_unpack(const int8_t* mant, const uint8_t* exps, void* ou
   if (precision < 2 || precision > 8) return DMXQ_ERR_UNSUPPORTED;
   if (rows * L == 0) return DMXQ_OK;
   if (!mant || !exps || !out) return DMXQ_ERR_BAD_ARG;
+  const int64_t B = block_size;
+  if (L % B == 0 && (B & (B - 1)) == 0 && B >= 8 && aligned16(out) && (reinterpret_cast<uintptr_t>(mant) & 7u) == 0) {
+    const int64_t n_vec = rows * L / 8;
+    int b_shift = 0;
+    while (((int64_t)8 << b_shift) < B) b_shift++;
+    const int grid = grid_for((n_vec + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype_out == DMXQ_F32) hipLaunchKernelGGL(bfp_unpack_vec_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision);
+    else if (dtype_out == DMXQ_F16) hipLaunchKernelGGL(bfp_unpack_vec_kernel<DMXQ_F16>, dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision);
+    else hipLaunchKernelGGL(bfp_unpack_vec_kernel<DMXQ_BF16>, dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision);
+    return launch_status();
+  }
   hipLaunchKernelGGL(bfp_unpack_kernel, dim3(grid_for(rows * L)), dim3(kThreads), 0, (hipStream_t)stream, mant, exps, out,
                      dtype_out, rows, L, block_size, precision);
   return launch_status();

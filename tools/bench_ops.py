@@ -128,6 +128,19 @@ def main():
         lambda i: L.dmxq_weight_hypernet(vp(xs[i].data_ptr()), _lib.BF16, vp(ss[i % k2].data_ptr()), _lib.F32, 2, 4, vp(sq.data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, R, C, 64, 8, 1, sp), k2, n * 8)
     run("weight_hypernet dense + SmoothQuant scale + BFP16_64, bf16 -> bf16",
         lambda i: L.dmxq_weight_hypernet(vp(xs[i].data_ptr()), _lib.BF16, None, 0, 0, 0, vp(sq.data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, R, C, 64, 8, 1, sp), k, n * 4)
+    # ---------------------------------------------------------------- composite block formats, packed BFP
+    run("sbfp_qdq bf16 SBFP12_16 (XP[4,0] codes, FP[0|4|4,7] scaler) [weight storage rule]",
+        lambda i: L.dmxq_sbfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, R, C, 1, 16, 4, 1, 1, 4, 4, 7, 1, sp), k, n * 4)
+    run("mxfp_qdq bf16 MXFP8[E4M3]{32}",
+        lambda i: L.dmxq_mxfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, R, C, 1, 32, 3, 4, sp), k, n * 4)
+    run("mxfp_qdq bf16 MXFP4[E2M1]{32}",
+        lambda i: L.dmxq_mxfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, R, C, 1, 32, 1, 2, sp), k, n * 4)
+    mant = [torch.empty(R, C, dtype=torch.int8, device=dev) for _ in range(k)]
+    exps = [torch.empty(R, C // 16, dtype=torch.uint8, device=dev) for _ in range(k)]
+    run("bfp_pack bf16 -> int8 codes + uint8 exponents, B=16",
+        lambda i: L.dmxq_bfp_pack(vp(xs[i].data_ptr()), _lib.BF16, vp(mant[i].data_ptr()), vp(exps[i].data_ptr()), R, C, 16, 8, 1, sp), k, n * 3 + n // 16)
+    run("bfp_unpack int8 codes + uint8 exponents -> bf16, B=16",
+        lambda i: L.dmxq_bfp_unpack(vp(mant[i].data_ptr()), vp(exps[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, R, C, 16, 8, sp), k, n * 3 + n // 16)
     # ---------------------------------------------------------------- reductions
     mn = torch.empty(R, device=dev)
     mx = torch.empty(R, device=dev)
