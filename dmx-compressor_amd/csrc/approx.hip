@@ -168,7 +168,7 @@ __device__ __forceinline__ float seg_max(float v) {
   return v;
 }
 // row slots per wave iteration: about 32 fp32 values per lane (occupancy beats bytes in flight per wave here: 64 was
-// 1-4 % slower on every shape of tools/bench_shapes)
+// 1-4 % slower on every shape of tools/bench_rows.py)
 constexpr int rows_per_wave(int vpl, int epl) { return 32 / (vpl * epl) >= 4 ? 4 : (32 / (vpl * epl) >= 2 ? 2 : 1); }
 
 // 16-bit outputs: exp(x - m) as v_exp_f32(fma(x, log2 e, -m log2 e)) and one reciprocal per row -- relative error

@@ -3,7 +3,7 @@
 // 1500, ...) and/or rows or bases that are not 16-byte aligned — WITHOUT staging through LDS.
 //
 // gfx950 serves 16-byte global accesses at any element alignment at 93-97 % of the aligned rate (measured:
-// tools/scratch/unal.hip, 2- / 4- / 8-byte offsets), so a row is read directly as ceil(L / EPL) lane-vectors starting
+// tools/unaligned_access.hip, 2- / 4- / 8-byte offsets), so a row is read directly as ceil(L / EPL) lane-vectors starting
 // at its first element, whatever the row pitch.  The vectors of all rows are numbered in a VIRTUAL flat space in which
 // every row is padded to a multiple of the block's lane count (nvrp vectors per row): a block is then B / EPL adjacent
 // lanes of one wave exactly as in the aligned kernel (block max by DPP, same arithmetic, bfp_math.hpp), padding
@@ -126,7 +126,7 @@ template <int DTI, int DTO, int RND, bool ASYM>
 static int launch_urows(const void* in, void* out, int64_t rows, int64_t L, int64_t B, int wl, int rounding,
                         uint64_t seed, hipStream_t s) {
   constexpr int EPL = 16 / Elem<DTI>::bytes;
-  constexpr int UNROLL = 3;  // 2..4 are within 3 % of each other, 8 is 10 % slower (tools/scratch, rows of 1500 / 4088 / 4100)
+  constexpr int UNROLL = 3;  // 2..4 are within 3 % of each other, 8 is 10 % slower (rows of 1500 / 4088 / 4100)
   const int lpb = (int)(B / EPL);
   const int64_t nvr = (L + EPL - 1) / EPL, nvrp = (nvr + lpb - 1) / lpb * lpb;
   const int tail = (int)(L - (nvr - 1) * EPL);  // 1..EPL elements in the last vector of a row
