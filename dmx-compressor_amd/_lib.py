@@ -31,6 +31,9 @@ SIGNATURES = {
     "dmxq_float_qdq": [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _u64, _vp],
     "dmxq_fixed_qdq": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _u64, _vp],
     "dmxq_nm_mask": [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
+    "dmxq_topk_workspace_bytes": [_i64],
+    "dmxq_topk_mask": [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp],
+    "dmxq_bernoulli_mask": [_vp, _vp, _i32, _i32, _i64, _u64, _vp],
     "dmxq_group_minmax": [_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "dmxq_qparams": [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
     "dmxq_histc": [_vp, _i32, _i64, _i64, _f32, _f32, _vp, _vp],
@@ -64,6 +67,7 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
+        L.dmxq_topk_workspace_bytes.restype = ctypes.c_int64
         L.dmxq_status_string.argtypes = [ctypes.c_int]
         L.dmxq_status_string.restype = ctypes.c_char_p
         L.dmxq_abi_version.restype = ctypes.c_int

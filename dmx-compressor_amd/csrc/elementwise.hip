@@ -254,6 +254,20 @@ struct GeluOp {
   }
 };
 
+// Bernoulli supermask (sparse.py:201-221 torch.bernoulli(score)): mask = 1 with probability score, drawn from the
+// counter-based stream of common.hpp (the reference draws from torch's global generator: statistical parity only)
+struct BernoulliOp {
+  uint64_t seed;
+  __device__ __forceinline__ void apply_one(float p, float& y, int64_t e) const {
+    y = rnd_unit(seed, (uint64_t)e) < p ? 1.0f : 0.0f;
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
+#pragma unroll
+    for (int k = 0; k < N; k++) apply_one(x[k], y[k], e0 + k);
+  }
+};
+
 static inline ChannelMap make_channel_map(int64_t C, int64_t inner, int64_t group_size, int64_t n) {
   return ChannelMap{C < 1 ? 1 : C, inner < 1 ? 1 : inner, group_size, n < (int64_t)1 << 31 ? 1 : 0};
 }
@@ -344,6 +358,14 @@ extern "C" int dmxq_gelu(const void* in, void* out, int dtype_in, int dtype_out,
   if (n == 0) return DMXQ_OK;
   if (!in || !out) return DMXQ_ERR_BAD_ARG;
   return dispatch_stream(in, out, dtype_in, dtype_out, n, GeluOp{tanh_form}, (hipStream_t)stream);
+}
+
+extern "C" int dmxq_bernoulli_mask(const void* score, void* mask_out, int dtype_score, int dtype_mask, int64_t n,
+                                   uint64_t seed, void* stream) {
+  if (!valid_dtype(dtype_score) || !valid_dtype(dtype_mask) || n < 0) return DMXQ_ERR_BAD_ARG;
+  if (n == 0) return DMXQ_OK;
+  if (!score || !mask_out) return DMXQ_ERR_BAD_ARG;
+  return dispatch_stream(score, mask_out, dtype_score, dtype_mask, n, BernoulliOp{seed}, (hipStream_t)stream);
 }
 
 extern "C" const char* dmxq_status_string(int status) {

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
 
 __all__ = [
-    "bfp_qdq", "bfp_pack", "bfp_unpack", "weight_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "nm_mask", "nm_sparsify", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "bfp_pack", "bfp_unpack", "weight_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "softmax", "layernorm",
 ]
 
@@ -183,6 +183,46 @@ def _nm(score, x, K, M, block_dim, want_mask, want_y, mask_dtype, y_dtype):
                              ptr(y), dtype_code(y.dtype) if want_y else 0, outer, L, inner, K, M, stream_of(sc)),
           "dmxq_nm_mask")
     return mask, y
+
+
+def _topk(score, x, density, want_mask, want_y, mask_dtype, y_dtype):
+    sc = _prep(score, "topk_mask")
+    n = sc.numel()
+    n_zero = int(n * (1.0 - density))  # sparse.py:116
+    xc = None
+    if want_y:
+        xc = _prep(x, "topk_sparsify")
+        if xc.shape != sc.shape:
+            xc = xc.expand(sc.shape).contiguous()
+    mask = torch.empty(sc.shape, dtype=mask_dtype or sc.dtype, device=sc.device) if want_mask else None
+    y = torch.empty(sc.shape, dtype=y_dtype, device=sc.device) if want_y else None
+    ws = torch.empty(max(1, (lib().dmxq_topk_workspace_bytes(n) + 7) // 8), dtype=torch.int64, device=sc.device)
+    check(lib().dmxq_topk_mask(ptr(sc), dtype_code(sc.dtype), ptr(xc), dtype_code(xc.dtype) if want_y else 0,
+                               ptr(mask), dtype_code(mask.dtype) if want_mask else 0,
+                               ptr(y), dtype_code(y.dtype) if want_y else 0, n, n_zero, ptr(ws), stream_of(sc)),
+          "dmxq_topk_mask")
+    return mask, y
+
+
+def topk_mask(score, density: float, mask_dtype: Optional[torch.dtype] = None):
+    """Global top-k mask (sparse.py:109-123): the int(n * (1 - density)) lowest scores are zeroed; float mask in the
+    score's dtype.  No sort: a radix select + one masking pass (csrc/topk.hip)."""
+    return _topk(score, None, density, True, False, mask_dtype, None)[0]
+
+
+def topk_sparsify(x, score, density: float, return_mask: bool = False):
+    """x * topk_mask(score) in the same final pass (sparse.py:300), torch's type promotion for the product."""
+    mask, y = _topk(score, x, density, return_mask, True, None, torch.promote_types(x.dtype, score.dtype))
+    return (y, mask) if return_mask else y
+
+
+def bernoulli_mask(score, seed: Optional[int] = None, mask_dtype: Optional[torch.dtype] = None):
+    """Bernoulli supermask (sparse.py:201-221): 1 with probability score."""
+    sc = _prep(score, "bernoulli_mask")
+    mask = torch.empty(sc.shape, dtype=mask_dtype or sc.dtype, device=sc.device)
+    check(lib().dmxq_bernoulli_mask(ptr(sc), ptr(mask), dtype_code(sc.dtype), dtype_code(mask.dtype), sc.numel(),
+                                    _next_seed() if seed is None else seed, stream_of(sc)), "dmxq_bernoulli_mask")
+    return mask
 
 
 def nm_mask(score, K: int, M: int, block_dim: int = -1, mask_dtype: Optional[torch.dtype] = None):

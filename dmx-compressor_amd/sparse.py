@@ -3,7 +3,8 @@
 Hot path: `BlockTopK` (N:M structured sparsity, sparse.py:140-198) and `Sparsify.forward` (sparse.py:287-301).
 The reference builds the mask with argsort (int64 indices, 8 B/elem) + ones + scatter and then multiplies;
 here mask and `x * mask` come out of ONE kernel in which each lane ranks its M-group in registers.
-`TopK` (global, needs a full sort/select) and `Bernoulli` are vocabulary-only ("next"/out of scope).
+`TopK` (global unstructured: a radix select + one masking pass instead of a whole-tensor argsort, csrc/topk.hip) and
+`Bernoulli` (counter-based draws) are device launches too.
 """
 import re
 from typing import Optional
@@ -55,8 +56,20 @@ class Dense(Sparseness):
         return "DENSE"
 
 
+class _TopKMask(Function):
+    """mask = TopK(score); identity gradient to the score (sparse.py:125-127)."""
+
+    @staticmethod
+    def forward(ctx, score, density):
+        return ops.topk_mask(score, density)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
 class TopK(Sparseness):
-    """Global top-K (sparse.py:95-137): vocabulary only — a whole-tensor selection, not part of the N:M hot path."""
+    """Global top-K (sparse.py:95-137): the int(n * (1 - density)) lowest scores of the whole tensor are zeroed."""
 
     def __init__(self, density=0.5, mask_gradient=False):
         super().__init__(mask_gradient)
@@ -64,7 +77,7 @@ class TopK(Sparseness):
         self.density = density
 
     def get_mask(self, score):
-        raise NotImplementedError("TOPK (global unstructured top-K) is outside the accelerated N:M path (SURVEY §2 row 8)")
+        return _TopKMask.apply(score, self.density)
 
     @classmethod
     def from_shorthand(cls, sh: str):
@@ -143,11 +156,25 @@ class BlockTopK(Sparseness):
         return f"BTOPK{{{self.K}:{self.block_size},{self.block_dim}}}({'M' if self.mask_gradient else 'U'})"
 
 
+class _BernoulliMask(Function):
+    @staticmethod
+    def forward(ctx, score):
+        return ops.bernoulli_mask(score)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 class Bernoulli(Sparseness):
-    """Bernoulli supermask sampler (sparse.py:201-242): vocabulary only (random, no parity to pin)."""
+    """Bernoulli supermask sampler (sparse.py:201-242).  Draws come from a counter-based stream, not torch's global
+    generator: statistical parity with the reference."""
 
     def get_mask(self, score):
-        raise NotImplementedError("BERN sampling is outside the accelerated N:M path")
+        # sparse.py:211-213: the scores need to be within [0, 1] (a device->host read, as in the reference)
+        mn, mx = ops.group_minmax(score.detach().reshape(1, -1), 0, 1)
+        assert float(mx) <= 1 and float(mn) >= 0
+        return _BernoulliMask.apply(score)
 
     @classmethod
     def from_shorthand(cls, sh: str):
@@ -197,6 +224,9 @@ class Sparsify(torch.nn.Module):
         else:
             score = self.score
         if not isinstance(self.sparseness, BlockTopK):
+            if isinstance(self.sparseness, TopK) and not (torch.is_grad_enabled() and (x.requires_grad or score.requires_grad)):
+                y, self.mask = ops.topk_sparsify(x, score.to(x.device), self.sparseness.density, return_mask=True)
+                return y    # mask and x * mask out of the same final pass
             self.update_mask(score)
             return x * self.mask
         sp = self.sparseness

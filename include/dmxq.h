@@ -104,6 +104,22 @@ int dmxq_fixed_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64
 int dmxq_nm_mask(const void* score, int dtype_score, const void* x, int dtype_x, void* mask_out, int dtype_mask,
                  void* y_out, int dtype_y, int64_t outer, int64_t L, int64_t inner, int K, int M, void* stream);
 
+/* Unstructured top-k mask ("TOPK{density}") and its application: the n_zero lowest scores of the flattened tensor are
+ * zeroed.  Replaces: sparse.py:109-123 TopK.forward (argsort + scatter; n_zero = int(n * (1 - density))) and
+ * sparse.py:300 `x * mask`.  Order: ascending, -0 == +0, NaN largest; scores equal to the threshold value are zeroed
+ * lowest index first (the reference's unstable argsort leaves that choice undefined).  mask_out (float 0/1 in
+ * dtype_mask) and/or y_out = x * mask may be NULL.  workspace: dmxq_topk_workspace_bytes(n) bytes of device memory,
+ * 8-byte aligned, contents irrelevant before and after.  n < 2^32. */
+int64_t dmxq_topk_workspace_bytes(int64_t n);
+int dmxq_topk_mask(const void* score, int dtype_score, const void* x, int dtype_x, void* mask_out, int dtype_mask,
+                   void* y_out, int dtype_y, int64_t n, int64_t n_zero, void* workspace, void* stream);
+
+/* Bernoulli supermask ("BERN"): mask[i] = 1 with probability score[i] (scores in [0, 1]), else 0.
+ * Replaces: sparse.py:201-221 Bernoulli.forward (torch.bernoulli on the global generator; here a counter-based
+ * stream keyed by `seed` and the element index, reproducible, statistically equivalent). */
+int dmxq_bernoulli_mask(const void* score, void* mask_out, int dtype_score, int dtype_mask, int64_t n, uint64_t seed,
+                        void* stream);
+
 /* Per-group min/max over slabs of `group_size` channels (MinMaxObserver on torch.split slabs).
  * Replaces: numerical/cast.py:179-226 _observer_step + numerical/observer.py:173-193.
  * mn/mx: float[ceil(C/group_size)] device buffers (fully overwritten). */

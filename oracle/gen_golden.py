@@ -255,6 +255,38 @@ def nm_cases():
         check(rsparse.Sparseness.from_shorthand(f"BTOPK{{{K}:{M},-1}}(U)").get_mask(big), O.nm_mask(big, K, M), f"nm big {K}:{M}")
 
 
+
+# ------------------------------------------------------------------------------------------------ global TopK
+def topk_cases():
+    """TOPK{density} (sparse.py:109-123) on the reference.  Its argsort is UNSTABLE, so only inputs whose threshold
+    value is unique define the mask; those are recorded.  On tied inputs the reference is checked for the properties
+    any valid answer has (exact count of zeros, no zeroed score above a kept one), which the oracle shares."""
+    store = {}
+    n = 0
+    for shape, seed in (((64, 96), 61), ((4099,), 62), ((3, 5, 7, 11), 63)):
+        s = make("normal", shape, seed=seed)
+        assert s.unique().numel() == s.numel()  # no ties at all
+        store[f"s{n}"] = bits(s)
+        for density in (0.5, 0.25, 0.9, 0.01, 1.0, 0.0):
+            m = rsparse.Sparseness.from_shorthand(f"TOPK{{{density}}}(U)").get_mask(s).contiguous()
+            check(m, O.topk_mask(s, density), f"topk {shape} {density}")
+            store[f"m{n}_{density}"] = bits(m)
+        n += 1
+    store["n"] = np.array(n)
+    x = make("normal", (64, 96), seed=64, dtype=torch.bfloat16)
+    sm = rsparse.Sparsify(x.shape, sparseness="TOPK{0.5}(U)")
+    sm.score.data = make("normal", (64, 96), seed=61)
+    y = sm(x).detach()
+    check(y, x * O.topk_mask(sm.score.data, 0.5), "sparsify TOPK bf16 x fp32 score")
+    store["sp_x"], store["sp_y"] = bits(x), bits(y)
+    tied = (make("normal", (5000,), seed=65) * 2).round()
+    for density in (0.3, 0.5):
+        for m in (rsparse.Sparseness.from_shorthand(f"TOPK{{{density}}}(U)").get_mask(tied), O.topk_mask(tied, density)):
+            assert int((m == 0).sum()) == int(tied.numel() * (1.0 - density))
+            assert tied[m == 0].max() <= tied[m == 1].min()
+    np.savez_compressed(os.path.join(GOLD, "topk.npz"), **store)
+
+
 # ------------------------------------------------------------------------------------------------ SmoothQuant
 def smoothquant_cases():
     from dmx.compressor.numerical.smoothquant import ActivationWeightSmoothQuant as RefSQ
@@ -489,6 +521,7 @@ if __name__ == "__main__":
     bfp_cases()
     elementwise_cases()
     nm_cases()
+    topk_cases()
     smoothquant_cases()
     composite_cases()
     module_cases()

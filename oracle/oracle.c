@@ -417,3 +417,13 @@ int oracle_histc(const float* x, int64_t n, int64_t bins, float lo, float hi, fl
   }
   return 0;
 }
+
+/* sparse.py:201-221 Bernoulli.forward with the counter-based stream of rnd_bits in place of torch.bernoulli's global
+ * generator: mask = (u < score), u = (rnd >> 8) * 2^-24 in [0, 1). */
+int oracle_bernoulli_mask(const float* score, float* mask, int64_t n, uint64_t seed) {
+  for (int64_t i = 0; i < n; i++) {
+    const float u = (float)(rnd_bits(seed, (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
+    mask[i] = u < score[i] ? 1.0f : 0.0f;
+  }
+  return 0;
+}

@@ -47,8 +47,9 @@ def lib():
         L.oracle_qparams.argtypes = [fp, fp, i64, i32, i32, i32, fp, fp]
         L.oracle_channel_maxabs.argtypes = [fp, i64, i64, i64, fp]
         L.oracle_histc.argtypes = [fp, i64, i64, ctypes.c_float, ctypes.c_float, fp]
+        L.oracle_bernoulli_mask.argtypes = [fp, fp, i64, u64]
         for f in ("oracle_sbfp_qdq", "oracle_mxfp_qdq", "oracle_float_qdq", "oracle_bfp_qdq", "oracle_fixed_qdq", "oracle_nm_mask",
-                  "oracle_group_minmax", "oracle_qparams", "oracle_channel_maxabs", "oracle_histc"):
+                  "oracle_group_minmax", "oracle_qparams", "oracle_channel_maxabs", "oracle_histc", "oracle_bernoulli_mask"):
             getattr(L, f).restype = ctypes.c_int
         _lib = L
     return _lib
@@ -220,3 +221,24 @@ def histc(x, bins, lo, hi):
     out = torch.empty(bins)
     _check(lib().oracle_histc(_ptr(xi), xi.numel(), bins, ctypes.c_float(lo), ctypes.c_float(hi), _ptr(out)), "histc")
     return out
+
+
+def topk_mask(score, density):
+    """sparse.py:109-123 TopK.forward: the int(n * (1 - density)) lowest scores are zeroed (float mask in the score's
+    dtype).  The reference sorts with torch.argsort's default UNSTABLE algorithm, so which of several scores equal to the
+    threshold value are dropped is implementation-defined there; this restatement (and the HIP kernel) use the stable
+    order -- lowest index first, -0 == +0, NaN largest -- and are pinned against the reference on inputs without a tie
+    at the threshold (oracle/gen_golden.py)."""
+    s = score.detach().to(torch.float32).reshape(-1).numpy()
+    n_zero = int(score.numel() * (1.0 - density))
+    idx = np.argsort(s, kind="stable")[:n_zero]
+    mask = np.ones(s.shape, dtype=np.float32)
+    mask[idx] = 0.0
+    return torch.from_numpy(mask).reshape(score.shape).to(score.dtype)
+
+
+def bernoulli_mask(score, seed):
+    sc = _f32c(score)
+    out = torch.empty_like(sc)
+    _check(lib().oracle_bernoulli_mask(_ptr(sc), _ptr(out), sc.numel(), seed), "bernoulli_mask")
+    return out.to(score.dtype)

@@ -234,6 +234,22 @@ def test_nm_mask_fixtures(backend):
 
 
 @pytest.mark.parametrize("backend", backends(), indirect=True)
+def test_topk_fixtures(backend, dmx, oracle):
+    """TOPK{density} masks recorded from the reference's TopK.get_mask (inputs without ties: its argsort is unstable)
+    and Sparsify.forward with the TOPK shorthand."""
+    g = load("topk.npz")
+    hip = isinstance(backend, HipBackend)
+    for n in range(int(g["n"])):
+        s = tensor(g[f"s{n}"], torch.float32)
+        for density in (0.5, 0.25, 0.9, 0.01, 1.0, 0.0):
+            got = dmx.ops.topk_mask(s.to(backend.dev), density) if hip else oracle.topk_mask(s, density)
+            assert mism(got, g[f"m{n}_{density}"], torch.float32) == 0, (n, density)
+    x, s = tensor(g["sp_x"], torch.bfloat16), tensor(g["s0"], torch.float32)
+    y = dmx.ops.topk_sparsify(x.to(backend.dev), s.to(backend.dev), 0.5) if hip else x * oracle.topk_mask(s, 0.5)
+    assert mism(y, g["sp_y"], torch.float32) == 0
+
+
+@pytest.mark.parametrize("backend", backends(), indirect=True)
 def test_smoothquant_fixtures(backend, dmx):
     g = load("smoothquant.npz")
     a, w = tensor(g["a"], torch.float32), tensor(g["w"], torch.float32)

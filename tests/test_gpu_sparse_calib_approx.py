@@ -5,7 +5,7 @@ import math
 import pytest
 import torch
 
-from _data import bits_equal, make
+from _data import bits_equal, make, mismatches_nan_aware
 
 pytestmark = pytest.mark.gpu
 
@@ -269,3 +269,61 @@ def test_softmax_layernorm_every_row_kernel_shape(dmx, cuda, dtype):
             got = dmx.ops.layernorm(x.to(cuda), (cols,), None if ww is None else ww.to(cuda), None if bb is None else bb.to(cuda), 1e-5)
             ref = F.layer_norm(x.float(), (cols,), None if ww is None else ww.float(), None if bb is None else bb.float(), 1e-5)
             assert bad(got, ref, 2, 4e-6) == 0, ("layernorm", cols, rows, ww is not None, bb is not None)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_topk_mask_matches_oracle(dmx, cuda, oracle, dtype):
+    """Global TOPK{density} (sparse.py:109-123) by radix select: every density edge, sizes around the chunk / workgroup
+    boundaries, heavy ties at the threshold (16-bit scores, integer scores, constant tensors: the index-ordered tie
+    path), -0 / +0, NaN (largest), inf; mask and fused x * mask."""
+    for n, (shape, density) in enumerate([((1,), 0.5), ((7,), 0.5), ((2048,), 0.25), ((2049,), 0.75), ((333, 77), 0.5),
+                                          ((64, 4096), 0.5), ((1000, 1000), 0.1), ((5, 1 << 17), 0.9), ((4097,), 0.0),
+                                          ((4097,), 1.0), ((123, 457), 0.999), ((123, 457), 0.001)]):
+        s = make("normal", shape, seed=300 + n, dtype=dtype)
+        want = oracle.topk_mask(s, density)
+        got = dmx.ops.topk_mask(s.to(cuda), density)
+        assert bits_equal(got, want) == 0, (shape, density)
+        assert int(want.float().sum()) == s.numel() - int(s.numel() * (1.0 - density))
+    # ties everywhere
+    for n, s in enumerate([torch.zeros(5000), torch.ones(3, 4099), (make("normal", (70000,), seed=5) * 3).round(),
+                           torch.tensor([0.0, -0.0] * 3000), make("normal", (1 << 18,), seed=6).to(torch.bfloat16).float()]):
+        s = s.to(dtype)
+        if n == 2:
+            s[17] = float("nan"); s[900] = float("inf"); s[901] = float("-inf"); s[55555] = float("nan")
+        for density in (0.3, 0.5, 0.97):
+            assert bits_equal(dmx.ops.topk_mask(s.to(cuda), density), oracle.topk_mask(s, density)) == 0, (n, density)
+    s = make("normal", (257, 1025), seed=9, dtype=dtype)
+    x = make("heavy", (257, 1025), seed=10, dtype=dtype)
+    y, m = dmx.ops.topk_sparsify(x.to(cuda), s.to(cuda), 0.5, return_mask=True)
+    assert bits_equal(m, oracle.topk_mask(s, 0.5)) == 0 and mismatches_nan_aware(y, x * oracle.topk_mask(s, 0.5)) == 0
+    # module level: Sparsify with the TOPK shorthand, inference (fused) and training (mask * x with autograd)
+    sp = dmx.Sparsify(s.shape, "TOPK{0.5}(U)").to(cuda)
+    sp.score.data = s.to(cuda)
+    with torch.no_grad():
+        assert mismatches_nan_aware(sp(x.to(cuda)), x * oracle.topk_mask(s, 0.5)) == 0
+    xg = x.to(cuda).float().requires_grad_(True)
+    sp.score.data = s.to(cuda).float()
+    out = sp(xg)
+    out.sum().backward()
+    assert torch.equal(xg.grad.cpu(), oracle.topk_mask(s.float(), 0.5))
+
+
+def test_bernoulli_mask(dmx, cuda, oracle):
+    """BERN (sparse.py:201-242): the counter-based draws are reproducible and bit-identical to the oracle's; against the
+    reference (torch.bernoulli on the global generator) parity is statistical: mean of the mask = mean of the scores."""
+    p = (make("normal", (1 << 20,), seed=77) * 0.2 + 0.5).clamp(0, 1)
+    p[:3] = torch.tensor([0.0, 1.0, 0.5])
+    got = dmx.ops.bernoulli_mask(p.to(cuda), seed=1234)
+    assert bits_equal(got, oracle.bernoulli_mask(p, 1234)) == 0
+    assert got[0] == 0 and got[1] == 1
+    assert abs(float(got.mean()) - float(p.mean())) < 3e-3
+    assert not torch.equal(got, dmx.ops.bernoulli_mask(p.to(cuda), seed=1235))
+    sp = dmx.Sparsify(p.shape, "BERN").to(cuda)
+    sp.score.data = p.to(cuda)
+    x = torch.ones_like(p).to(cuda)
+    with torch.no_grad():
+        y = sp(x)
+    assert abs(float(y.mean()) - float(p.mean())) < 3e-3 and set(y.unique().tolist()) <= {0.0, 1.0}
+    sp.score.data = (p * 3).to(cuda)
+    with pytest.raises(AssertionError):  # scores outside [0, 1] (sparse.py:211-213)
+        sp(x)
