@@ -228,6 +228,9 @@ class Sparsify(torch.nn.Module):
                 y, self.mask = ops.topk_sparsify(x, score.to(x.device), self.sparseness.density, return_mask=True)
                 return y    # mask and x * mask out of the same final pass
             self.update_mask(score)
+            if self.training:  # sparse.py:296-300
+                x = x if self.enable_weight_gradient else x.detach()
+                self.mask = self.mask if self.enable_mask_gradient else self.mask.detach()
             return x * self.mask
         sp = self.sparseness
         if score.device != x.device:

@@ -327,3 +327,40 @@ def test_bernoulli_mask(dmx, cuda, oracle):
     sp.score.data = (p * 3).to(cuda)
     with pytest.raises(AssertionError):  # scores outside [0, 1] (sparse.py:211-213)
         sp(x)
+
+
+@pytest.mark.parametrize("sparseness", ["TOPK{0.5}(U)", "TOPK{0.5}(M)", "BTOPK{4:8,-1}(U)", "BTOPK{4:8,-1}(M)", "BTOPK{2:8,-1}(U)", "BERN"])
+@pytest.mark.parametrize("backward_mode", ["STE", "supermask", "joint"])
+def test_sparsify_gradient_routing(dmx, cuda, sparseness, backward_mode):
+    """The reference's tests/test_sparse.py::test_sparsify: which of (input, score) receives a gradient in each
+    backward mode, for every sparseness class; plus the values: d(x * mask)/dx = mask, d/dscore = x (identity through
+    the mask function)."""
+    for shape in ((64, 128), (4, 16, 8, 8), (8, 32, 32)):
+        sp = dmx.Sparsify(shape, sparseness, backward_mode).to(cuda)
+        x = torch.randn(shape, requires_grad=True, device=cuda)
+        y = sp(x)
+        y.backward(torch.ones_like(y))
+        if backward_mode == "STE":
+            assert isinstance(x.grad, torch.Tensor) and sp.score.grad is None
+            assert torch.equal(x.grad, sp.mask.to(x.grad.dtype))
+        elif backward_mode == "supermask":
+            assert x.grad is None and isinstance(sp.score.grad, torch.Tensor)
+            assert torch.equal(sp.score.grad, x.detach())
+        else:
+            assert isinstance(x.grad, torch.Tensor) and isinstance(sp.score.grad, torch.Tensor)
+        assert torch.equal(y.detach(), x.detach() * sp.mask.detach())
+
+
+def test_sparsify_reconfiguration(dmx):
+    """tests/test_sparse.py::test_transformation: sparseness / backward mode / score function can be swapped in place."""
+    sp = dmx.Sparsify((8, 16))
+    assert repr(sp.sparseness) == "DENSE" and sp.backward_mode == "STE"
+    sp.configure(sparseness="BERN", backward_mode="supermask", score_func=lambda score, input: score)
+    assert repr(sp.sparseness) == "BERN" and sp.backward_mode == "supermask" and sp.plastic
+    sp.sparseness = dmx.Sparseness.from_shorthand("DENSE")
+    sp.backward_mode = "STE"
+    assert repr(sp.sparseness) == "DENSE"
+    sp.configure(sparseness="TOPK{0.5}(U)", backward_mode="joint", score_func=lambda score, input: torch.abs(input))
+    assert repr(sp.sparseness) == "TOPK{0.5}(U)" and sp.backward_mode == "joint"
+    sp.sparseness = dmx.Sparseness.from_shorthand("BTOPK{4:8,-1}(U)")
+    assert repr(sp.sparseness) == "BTOPK{4:8,-1}(U)"
