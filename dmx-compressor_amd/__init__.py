@@ -13,7 +13,8 @@ from .format import (ROUNDING_MODE, BlockFloatingPoint, FixedPoint, FloatingPoin
                      ScaledBlockFloatingPoint)
 from . import nn
 from .approximate import Approximate, ApproximationFunction, NoApproximation, TorchFunctionApproximation
-from .nn import DmxConfigRule, DmxModule, configure_model
+from .nn import (DmxConfigRule, DmxModule, DmxModuleQuantizerCalibrationHyperparams, DmxModuleSmoothQuantHyperparams,
+                 DmxQuantizerCalibrationHyperparams, configure_model)
 from .observer import DummyObserver, HistogramObserver, MinMaxObserver, PercentileObserver
 from .smoothquant import ActivationWeightSmoothQuant
 from .config import apply_legacy_config, load_legacy_config

@@ -21,6 +21,9 @@ from .approximate import Approximate, NoApproximation
 from .cast import CastTo, CastToDict
 from .format import Same
 from .smoothquant import ActivationWeightSmoothQuant
+from contextlib import contextmanager
+from dataclasses import dataclass
+from typing import Any, Dict, Optional as _Opt
 from .sparse import Dense, Sparsify
 
 __all__ = ["DmxModule", "Linear", "Conv1d", "Conv2d", "ResAdd", "ActActMatMul", "Softmax", "LayerNorm", "GELU", "ReLU",
@@ -37,6 +40,36 @@ class _LazySparsify(Sparsify):
         if not isinstance(self.sparseness, Dense) and self.score.shape != x.shape:
             self.score = torch.nn.Parameter(torch.rand(x.shape, device=x.device), requires_grad=True)
         return super().forward(x)
+
+
+@dataclass
+class DmxQuantizerCalibrationHyperparams:
+    """advanced_recipe.py:42-51: how one CastTo is calibrated."""
+    observer_cls: Any = None
+    qscheme_to_overload: Any = torch.per_tensor_symmetric
+    group_size: _Opt[int] = None
+    ch_axis: _Opt[int] = None
+
+    def __post_init__(self):
+        if self.observer_cls is None:
+            from .observer import HistogramObserver
+            self.observer_cls = HistogramObserver
+
+
+@dataclass
+class DmxModuleQuantizerCalibrationHyperparams:
+    """advanced_recipe.py:54-63"""
+    inputs: _Opt[Dict[str, DmxQuantizerCalibrationHyperparams]] = None
+    outputs: _Opt[Dict[str, DmxQuantizerCalibrationHyperparams]] = None
+    weight: _Opt[DmxQuantizerCalibrationHyperparams] = None
+    weight_storage: _Opt[DmxQuantizerCalibrationHyperparams] = None
+
+
+@dataclass
+class DmxModuleSmoothQuantHyperparams:
+    """advanced_recipe.py:66-73"""
+    migration_strength: float = 0.5
+    fuse_to_weight: bool = False
 
 
 class DmxModule(torch.nn.Module):
@@ -205,8 +238,11 @@ class DmxModule(torch.nn.Module):
         if self.smoothquant is not None:  # layer_reconstruction.py:32-34: calibrates against the MASKED weight
             self.smoothquant(input, self.effective_weight)
 
-    def enable_smoothquant_calib(self, state: bool, migration_strength: float = 0.5, fuse_to_weight: bool = False):
-        """layer_reconstruction.py:57-68"""
+    def enable_smoothquant_calib(self, state: bool, hyperparams=None, migration_strength: float = 0.5,
+                                 fuse_to_weight: bool = False):
+        """layer_reconstruction.py:57-68; `hyperparams` is a DmxModuleSmoothQuantHyperparams (or pass the two fields)."""
+        if hyperparams is not None:
+            migration_strength, fuse_to_weight = hyperparams.migration_strength, hyperparams.fuse_to_weight
         if self.smoothquant is not None:
             if self.smoothquant._flag("fused_to_weight"):
                 raise RuntimeError("SmoothQuant cannot be calibrated because it has been fused to weight already")
@@ -216,6 +252,32 @@ class DmxModule(torch.nn.Module):
             self.smoothquant.calibrating = state
             if not state and fuse_to_weight:
                 self.smoothquant.fuse_to_weight(self.weight)
+
+    def enable_quantizer_calib(self, state: bool, hyperparams) -> None:
+        """layer_reconstruction.py:36-55: switch the boundary / weight casts between observing and fake-quantising."""
+        if hyperparams.inputs is not None:
+            for k in self.input_casts.keys():
+                self.input_casts[k].enable_calibration(state, **vars(hyperparams.inputs[k]))
+        if hyperparams.outputs is not None:
+            for k in self.output_casts.keys():
+                self.output_casts[k].enable_calibration(state, **vars(hyperparams.outputs[k]))
+        if getattr(self, "weight", None) is not None and self.weight_cast is not None:
+            if hyperparams.weight is not None:
+                self.weight_cast.enable_calibration(state, **vars(hyperparams.weight))
+            if hyperparams.weight_storage is not None and self.weight_storage_cast is not None:
+                self.weight_storage_cast.enable_calibration(state, **vars(hyperparams.weight_storage))
+
+    @contextmanager
+    def calibrating_quantizers(self, hyperparams):
+        self.enable_quantizer_calib(True, hyperparams)
+        yield self
+        self.enable_quantizer_calib(False, hyperparams)
+
+    @contextmanager
+    def calibrating_smoothquant(self, hyperparams):
+        self.enable_smoothquant_calib(True, hyperparams)
+        yield self
+        self.enable_smoothquant_calib(False, hyperparams)
 
     def forward(self, input, *args, **kwargs):
         _dtype = input.dtype

@@ -21,6 +21,28 @@ from .format import Format
 __all__ = ["ActivationWeightSmoothQuant"]
 
 
+class _ScaleChannels(torch.autograd.Function):
+    """x / s[c] or x * s[c] along a channel axis as one launch; the scale is a constant (a buffer computed under
+    no_grad in the reference too), so the gradient is the incoming one scaled the same way."""
+
+    @staticmethod
+    def forward(ctx, x, scale, ch_axis, divide, out_dtype):
+        ctx.save_for_backward(scale)
+        ctx.ch_axis, ctx.divide, ctx.in_dtype = ch_axis, divide, x.dtype
+        return ops.scale_channels(x, scale, ch_axis, divide=divide, out_dtype=out_dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        return ops.scale_channels(g.contiguous(), scale, ctx.ch_axis, divide=ctx.divide, out_dtype=ctx.in_dtype), None, None, None, None
+
+
+def _scale(x, scale, ch_axis, divide, out_dtype):
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _ScaleChannels.apply(x, scale, ch_axis, divide, out_dtype)
+    return ops.scale_channels(x, scale, ch_axis, divide=divide, out_dtype=out_dtype)
+
+
 class ActivationWeightSmoothQuant(HostFlags, torch.nn.Module):
     _flag_names = ("enabled", "dynamic", "fused_to_weight")
 
@@ -75,13 +97,12 @@ class ActivationWeightSmoothQuant(HostFlags, torch.nn.Module):
     def scale_input(self, inp: torch.Tensor) -> torch.Tensor:
         if self._flag("enabled"):
             # reference: a / scale.view(...) -> torch promotion of (input dtype, fp32 scale)
-            return ops.scale_channels(inp, self.scale, self.ch_axis, divide=True,
-                                      out_dtype=torch.promote_types(inp.dtype, torch.float32))
+            return _scale(inp, self.scale, self.ch_axis, True, torch.promote_types(inp.dtype, torch.float32))
         return inp
 
     def scale_weight(self, wgt: torch.Tensor) -> torch.Tensor:
         if self._flag("enabled"):
-            return ops.scale_channels(wgt, self.scale, self.win_ch_axis, divide=False, out_dtype=wgt.dtype)  # .to(wgt.dtype)
+            return _scale(wgt, self.scale, self.win_ch_axis, False, wgt.dtype)  # .to(wgt.dtype)
         return wgt
 
     def fuse_to_weight(self, wgt: torch.Tensor) -> None:
