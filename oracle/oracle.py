@@ -92,18 +92,20 @@ def floating_point_cast(x, man, exp, bias, flush_subnormal, unsigned=False, roun
 
 
 def bfp_cast(x, precision, block_size, block_dim=-1, symmetric=True, rounding="nearest", seed=0):
-    """numerical/format.py:304-343 BlockFloatingPoint.cast: fp32 result, same shape, with the reference's
-    transposed-view strides when block_dim != -1 (values are what the tests compare)."""
+    """numerical/format.py:304-343 BlockFloatingPoint.cast: fp32 result, same shape (values are what the tests
+    compare).  The reference brings the block dim last with transpose(block_dim, -1); here movedim(block_dim, -1) --
+    the same blocks and values, but a row order in which the stochastic draws are numbered like the kernels number
+    them, (outer index, inner index, position along the block dim), also for tensors of more than two dims."""
     xf = x.detach().to(torch.float32)
     if block_size == 1:
         return float_quantize(xf, precision - 2, 8, 127, False, rounding, seed)
-    xt = xf.transpose(block_dim, -1)
+    xt = xf.movedim(block_dim, -1)
     shp = xt.shape
     x2 = xt.reshape(-1, shp[-1]).contiguous()
     out = torch.empty_like(x2)
     _check(lib().oracle_bfp_qdq(_ptr(x2), _ptr(out), x2.shape[0], x2.shape[1], block_size, precision,
                                 ROUNDING[rounding], int(symmetric), seed), "bfp_qdq")
-    return out.reshape(shp).transpose_(block_dim, -1)
+    return out.reshape(shp).movedim(-1, block_dim)
 
 
 def fixed_point_cast(x, precision, fraction, clamp=True, symmetric=True, rounding="nearest", seed=0):
