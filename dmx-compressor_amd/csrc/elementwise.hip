@@ -148,23 +148,33 @@ struct FixedOp {
     }
     y = q(x, sc, z, e);
   }
+  // the vector's (scale, zero point) when it has a single one: fetched ahead of the arithmetic (stream.hpp OpPrep)
+  struct Prep { float sc, z; };
+  __device__ __forceinline__ Prep prepare(int64_t e0) const {
+    Prep p{1.0f, 0.0f};
+    if (MODE == kTensor) { p.sc = scale[0]; p.z = (float)zp[0]; }
+    if (MODE == kUniform) {
+      ChanIter it;
+      it.start(cm, e0);
+      p.sc = scale[it.g];
+      p.z = (float)zp[it.g];
+    }
+    return p;
+  }
   template <int N>
   __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
+    apply_vec(x, y, e0, prepare(e0));
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0, const Prep& pp) const {
     if (MODE == kNone || MODE == kTensor || MODE == kUniform) {
-      float sc = 1.0f, z = 0.0f;
-      if (MODE == kTensor) { sc = scale[0]; z = (float)zp[0]; }
-      if (MODE == kUniform) {
-        ChanIter it;
-        it.start(cm, e0);
-        sc = scale[it.g];
-        z = (float)zp[it.g];
-      }
+      const float sc = pp.sc, z = pp.z;
 #pragma unroll
       for (int k = 0; k < N; k++) y[k] = q(x[k], sc, z, e0 + k);
     } else if (MODE == kLast) {
       // c0 is a multiple of N and the tables are 16-byte aligned (pick_mode): N scales = N/4 and N zero points = N/2
       // 16-byte loads instead of 2N scalar ones
-      const int64_t c0 = cm.small ? (int64_t)((uint32_t)e0 % (uint32_t)cm.C) : e0 % cm.C;
+      const int64_t c0 = cm.small ? (int64_t)((uint32_t)e0 - cm.f_C.div((uint32_t)e0) * (uint32_t)cm.C) : e0 % cm.C;
       float sc[N], z[N];
 #pragma unroll
       for (int k = 0; k < N; k += 4) {
@@ -204,16 +214,28 @@ struct ScaleOp {
     const float s = scale[it.g];
     y = DIVIDE ? x / s : x * s;
   }
-  template <int N>
-  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
+  struct Prep { float s; };
+  __device__ __forceinline__ Prep prepare(int64_t e0) const {
+    Prep p{1.0f};
     if (MODE == kTensor || MODE == kUniform) {
       ChanIter it;
       it.start(cm, e0);
-      const float s = scale[it.g];
+      p.s = scale[it.g];
+    }
+    return p;
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
+    apply_vec(x, y, e0, prepare(e0));
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0, const Prep& pp) const {
+    if (MODE == kTensor || MODE == kUniform) {
+      const float s = pp.s;
 #pragma unroll
       for (int k = 0; k < N; k++) y[k] = DIVIDE ? x[k] / s : x[k] * s;
     } else if (MODE == kLast) {
-      const int64_t c0 = cm.small ? (int64_t)((uint32_t)e0 % (uint32_t)cm.C) : e0 % cm.C;
+      const int64_t c0 = cm.small ? (int64_t)((uint32_t)e0 - cm.f_C.div((uint32_t)e0) * (uint32_t)cm.C) : e0 % cm.C;
 #pragma unroll
       for (int k = 0; k < N; k += 4) {
         const f32x4 t = *(const f32x4*)(scale + c0 + k);  // 16-byte aligned: c0 % N == 0, aligned table (pick_mode)
@@ -269,7 +291,9 @@ struct BernoulliOp {
 };
 
 static inline ChannelMap make_channel_map(int64_t C, int64_t inner, int64_t group_size, int64_t n) {
-  return ChannelMap{C < 1 ? 1 : C, inner < 1 ? 1 : inner, group_size, n < (int64_t)1 << 31 ? 1 : 0};
+  const int64_t c = C < 1 ? 1 : C, in = inner < 1 ? 1 : inner;
+  const int small = (n < (int64_t)1 << 31 && c < (int64_t)1 << 31 && in < (int64_t)1 << 31) ? 1 : 0;
+  return ChannelMap{c, in, group_size, small, make_fastdiv31(in), make_fastdiv31(c), make_fastdiv31(group_size)};
 }
 
 }  // namespace dmxq

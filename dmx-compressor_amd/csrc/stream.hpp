@@ -5,9 +5,34 @@
 // issued back to back, then every vector is converted into registers, then all stores go out as one burst.
 // OP::apply_vec(x[EPL], y[EPL], e0) maps EPL consecutive elements (flat index e0..) to their outputs in fp32.
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace dmxq {
+
+// Optional per-vector prefetch: an OP with a nested `Prep` type and `prepare(e0)` gets it called for ALL vectors of a
+// tile right after the data loads, before any arithmetic, and receives the result in apply_vec(x, y, e0, prep).  The
+// per-group scale / zero-point reads of the affine ops are a dependent L2 access per vector; fetched inside the
+// vector-by-vector compute loop (whose sched_barriers keep live ranges short) each of them exposed its full latency.
+template <class OP, class = void>
+struct OpPrep {
+  using type = int;
+  static __device__ __forceinline__ type get(const OP&, int64_t) { return 0; }
+  template <int N>
+  static __device__ __forceinline__ void apply(const OP& op, const float (&x)[N], float (&y)[N], int64_t e0, const type&) {
+    op.apply_vec(x, y, e0);
+  }
+};
+template <class OP>
+struct OpPrep<OP, std::void_t<typename OP::Prep>> {
+  using type = typename OP::Prep;
+  static __device__ __forceinline__ type get(const OP& op, int64_t e0) { return op.prepare(e0); }
+  template <int N>
+  static __device__ __forceinline__ void apply(const OP& op, const float (&x)[N], float (&y)[N], int64_t e0, const type& p) {
+    op.apply_vec(x, y, e0, p);
+  }
+};
 
 template <int DTI, int DTO, int UNROLL, int THREADS, class OP>
 __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict__ in, void* __restrict__ out,
@@ -26,13 +51,16 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict_
       u32x4 raw[UNROLL];
 #pragma unroll
       for (int u = 0; u < UNROLL; u++) raw[u] = load_raw16<true>(src + u * (THREADS * 16), lane_in);
+      typename OpPrep<OP>::type prep[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) prep[u] = OpPrep<OP>::get(op, (v0 + (int64_t)u * THREADS) * EPL);
       __builtin_amdgcn_sched_barrier(0);
       OutVec<DTO, EPL> o[UNROLL];
 #pragma unroll
       for (int u = 0; u < UNROLL; u++) {
         float x[EPL], y[EPL];
         widen<DTI, EPL>(raw[u], x);
-        op.apply_vec(x, y, (v0 + (int64_t)u * THREADS) * EPL);
+        OpPrep<OP>::apply(op, x, y, (v0 + (int64_t)u * THREADS) * EPL, prep[u]);
         o[u] = pack_vec<DTO, EPL>(y);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -121,20 +149,37 @@ static int dispatch_stream(const void* in, void* out, int dti, int dto, int64_t 
 // ---------------------------------------------------------------------------------------------------------
 // Channel / group walker for tensors viewed as [outer, C, inner]: group(e) = ((e / inner) % C) / group_size.
 // One division per VECTOR (32-bit when the tensor is small enough), then incremental carries per element.
+// n / d for n < 2^31 and a launch-invariant d < 2^31 as one multiply-high and a shift (magic number from the host):
+// M = ceil(2^(31+l) / d), l = ceil(log2 d); q = umulhi(n, M) >> (l - 1); d = 1 is the identity.  (A 32-bit division by
+// a runtime value is ~28 VALU instructions, and the walker below needs three per lane-vector.)
+struct FastDiv31 {
+  uint32_t M, sh, d;
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return d == 1u ? n : __umulhi(n, M) >> sh; }
+};
+inline FastDiv31 make_fastdiv31(int64_t d64) {
+  const uint32_t d = d64 < 1 ? 1u : (d64 > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)d64);
+  if (d == 1u) return FastDiv31{0u, 0u, 1u};
+  int l = 0;
+  while (((uint64_t)1 << l) < d) l++;
+  return FastDiv31{(uint32_t)((((uint64_t)1 << (31 + l)) + d - 1) / d), (uint32_t)(l - 1), d};
+}
+
 struct ChannelMap {
   int64_t C, inner, group_size;
   int small;  // 1: n < 2^31, 32-bit index arithmetic
+  FastDiv31 f_inner, f_C, f_gs;
 };
 
 struct ChanIter {
   int64_t c, i, g, r;
   __device__ __forceinline__ void start(const ChannelMap& m, int64_t e) {
     if (m.small) {
-      const uint32_t q = (uint32_t)e / (uint32_t)m.inner;
+      const uint32_t q = m.f_inner.div((uint32_t)e);
       i = (uint32_t)e - q * (uint32_t)m.inner;
-      c = q % (uint32_t)m.C;
-      g = (uint32_t)c / (uint32_t)m.group_size;
-      r = (uint32_t)c - (uint32_t)g * (uint32_t)m.group_size;
+      const uint32_t cc = q - m.f_C.div(q) * (uint32_t)m.C;
+      const uint32_t gg = m.f_gs.div(cc);
+      c = cc; g = gg;
+      r = cc - gg * (uint32_t)m.group_size;
     } else {
       const int64_t q = e / m.inner;
       i = e - q * m.inner;
