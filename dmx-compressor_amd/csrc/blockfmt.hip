@@ -2,12 +2,13 @@
 //   SBFP  numerical/format.py:453-479  per block: s = max|x| / (2^(p-1)-1); fixed(x/s) * |float(s)|
 //   MXFP  numerical/format.py:545-564  per block: scale = 2^floor(log2 max|x|) / 2^(2^(e-1)); float(x/scale) * scale
 // The reference composes each from 6+ ATen passes per CHUNK inside a Python loop; here: one read, one write.
-//   rows kernel     inner == 1, L % B == 0, B = 2^k covering whole 16-byte vectors: one vector per lane, block max
-//                   across B/EPL lanes by DPP (same layout idea as bfp_rows.hpp), 4 vectors in flight per lane
+//   rows path       inner == 1, L % B == 0, B = 2^k covering whole 16-byte vectors: an op of the streaming skeleton
+//                   (stream.hpp), one vector per lane, block max across B/EPL lanes by DPP (as bfp_rows.hpp)
 //   generic kernel  any [outer, L, inner], ragged tails: one lane per block, two strided passes
 #include <math.h>
 
-#include "common.hpp"
+#include "floatq.hpp"
+#include "stream.hpp"
 
 namespace dmxq {
 
@@ -40,7 +41,7 @@ __device__ __forceinline__ float fixed_rne(float a) {  // sim_helper.cpp:14-21 w
 }
 
 struct SbfpFmt { int p, clamp; float t_min, t_max, man_scaling; int man, exp_bits, bias, flush; };
-struct MxfpFmt { int man, exp_bits, bias; float big; };
+struct MxfpFmt { int man, exp_bits, bias; float big; FloatFast fast; int big_log2, exact_exponent; };
 
 struct SbfpBlock {
   float s, sc;
@@ -54,47 +55,70 @@ struct SbfpBlock {
     if (f.clamp) q = q > f.t_max ? f.t_max : (q < f.t_min ? f.t_min : q);
     return q * sc;
   }
+  template <int N>
+  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], const SbfpFmt& f) const {
+#pragma unroll
+    for (int k = 0; k < N; k++) y[k] = apply(x[k], f);
+  }
 };
 struct MxfpBlock {
-  float scale;
-  bool zero;
+  float scale, inv;
+  bool zero, pow2;  // pow2: the scale is a normal power of two whose reciprocal is representable -> x / scale == x * inv exactly
   __device__ __forceinline__ void setup(uint32_t maxbits, const MxfpFmt& f) {
     const float m = u2f(maxbits);
     zero = m == 0.0f;
-    scale = exp2f(floorf(log2f(m))) / f.big;  // the reference evaluates exactly this in fp32 (format.py:551-555)
+    // the reference evaluates 2^floor(log2 m) / 2^(2^(e-1)) in fp32 (format.py:551-555).  For a maximum with at most
+    // 11 significant bits (bf16 / fp16 inputs) log2f cannot round across an integer, so floor(log2 m) is m's exponent
+    // field and the scale is assembled from bits; fp32 inputs keep the libm form (known divergences).
+    const int eb = (int)(maxbits >> 23), se = eb - f.big_log2;
+    if (f.exact_exponent && eb >= 1 && eb <= 254 && se >= 1 && se <= 254) scale = u2f((uint32_t)se << 23);
+    else scale = exp2f(floorf(log2f(m))) / f.big;
+    const uint32_t sb = f2u(scale);
+    pow2 = (sb & 0x007FFFFFu) == 0u && (sb >> 23) >= 1u && (sb >> 23) <= 253u;
+    inv = u2f((254u - (sb >> 23)) << 23);
   }
   __device__ __forceinline__ float apply(float x, const MxfpFmt& f) const {
     if (zero) return x * 0.0f;
     return float_q_nearest(x / scale, f.man, f.exp_bits, f.bias, 0) * scale;
   }
-};
-
-template <int DTI, int DTO, class FMT, class BLK>
-__global__ __launch_bounds__(kThreads) void blockfmt_rows_kernel(const void* __restrict__ in, void* __restrict__ out,
-                                                                int64_t n_vec, int lpb_arg, FMT f) {
-  constexpr int EPL = 16 / Elem<DTI>::bytes, UNROLL = 4;
-  const int lpb = __builtin_amdgcn_readfirstlane(lpb_arg);
-  const int64_t sweep = (int64_t)gridDim.x * kThreads * UNROLL;
-  for (int64_t v0 = (int64_t)blockIdx.x * kThreads * UNROLL + threadIdx.x; v0 < n_vec; v0 += sweep) {
-    u32x4 raw[UNROLL];
+  // a whole lane-vector; the branch-free element form when the wave's blocks and values allow it (floatq.hpp)
+  template <int N>
+  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], const MxfpFmt& f) const {
+    if (f.fast.usable) {
+      bool ok = pow2 || zero;
+      float v[N];
 #pragma unroll
-    for (int u = 0; u < UNROLL; u++)
-      if (v0 + (int64_t)u * kThreads < n_vec) raw[u] = load_raw16<true>(in, (v0 + (int64_t)u * kThreads) * 16);
+      for (int k = 0; k < N; k++) { v[k] = x[k] * inv; ok = ok && float_fast_ok(v[k], f.fast); }
+      if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
 #pragma unroll
-    for (int u = 0; u < UNROLL; u++) {
-      const int64_t vi = v0 + (int64_t)u * kThreads;
-      if (vi < n_vec) {  // a block never straddles this predicate (n_vec % lpb == 0, lpb | kThreads)
-        BLK b;
-        b.setup(group_max_u32(absmax_bits<DTI>(raw[u]), lpb), f);
-        float x[EPL], y[EPL];
-        widen<DTI, EPL>(raw[u], x);
-#pragma unroll
-        for (int k = 0; k < EPL; k++) y[k] = b.apply(x[k], f);
-        store_vec<DTO, EPL, true>(out, vi * EPL, y);
+        for (int k = 0; k < N; k++) y[k] = zero ? x[k] * 0.0f : float_q1_fast(v[k], f.fast, false, false) * scale;
+        return;
       }
     }
+#pragma unroll
+    for (int k = 0; k < N; k++) y[k] = apply(x[k], f);
   }
-}
+};
+
+// rows path as an op of the streaming skeleton (stream.hpp: contiguous tiles, all loads of a tile in flight before the
+// arithmetic, store burst): a block is lpb adjacent lanes of one wave, its max an integer max over |x| bit patterns
+// reduced with DPP moves.  A block never straddles the skeleton's partial-tile predicate (n_vec % lpb == 0, lpb | 256).
+template <class FMT, class BLK>
+struct BlockOp {
+  static constexpr bool kHeavy = true;
+  FMT f;
+  int lpb;
+  __device__ __forceinline__ void apply_one(float x, float& y, int64_t) const { y = x; }  // (no scalar tail: n % B == 0)
+  template <int N>
+  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t) const {
+    uint32_t mb = 0u;
+#pragma unroll
+    for (int k = 0; k < N; k++) mb = max(mb, f2u(x[k]) & 0x7FFFFFFFu);
+    BLK b;
+    b.setup(group_max_u32(mb, lpb), f);
+    b.apply_vec(x, y, f);
+  }
+};
 
 template <int DTI, int DTO, class FMT, class BLK>
 __global__ __launch_bounds__(kThreads) void blockfmt_generic_kernel(const void* __restrict__ in, void* __restrict__ out,
@@ -122,9 +146,7 @@ static int launch_blockfmt(const void* in, void* out, int64_t outer, int64_t L, 
   const int64_t n = outer * L * inner;
   const bool pow2 = (B & (B - 1)) == 0;
   if (inner == 1 && L % B == 0 && pow2 && B >= EPL && B <= 64 * EPL && aligned16(in) && aligned16(out)) {
-    const int64_t n_vec = n / EPL;
-    hipLaunchKernelGGL((blockfmt_rows_kernel<DTI, DTO, FMT, BLK>), dim3(grid_for((n_vec + 3) / 4)), dim3(kThreads), 0, s, in,
-                       out, n_vec, (int)(B / EPL), f);
+    return launch_stream<DTI, DTO>(in, out, n, BlockOp<FMT, BLK>{f, (int)(B / EPL)}, s);
   } else {
     const int64_t nblk = (L + B - 1) / B;
     hipLaunchKernelGGL((blockfmt_generic_kernel<DTI, DTO, FMT, BLK>), dim3(grid_for(outer * nblk * inner)), dim3(kThreads), 0,
@@ -177,6 +199,8 @@ extern "C" int dmxq_mxfp_qdq(const void* in, void* out, int dtype_in, int dtype_
   if (man_bits > 22) return DMXQ_ERR_UNSUPPORTED;
   if (outer * L * inner == 0) return DMXQ_OK;
   if (!in || !out) return DMXQ_ERR_BAD_ARG;
-  const MxfpFmt f{man_bits, exp_bits, (1 << (exp_bits - 1)) - 1, (float)ldexp(1.0, 1 << (exp_bits - 1))};
+  const MxfpFmt f{man_bits, exp_bits, (1 << (exp_bits - 1)) - 1, (float)ldexp(1.0, 1 << (exp_bits - 1)),
+                  make_float_fast(man_bits, exp_bits, (1 << (exp_bits - 1)) - 1), 1 << (exp_bits - 1),
+                  dtype_in != DMXQ_F32 ? 1 : 0};
   return dispatch_blockfmt<MxfpFmt, MxfpBlock>(in, out, dtype_in, dtype_out, outer, L, inner, block_size, f, (hipStream_t)stream);
 }

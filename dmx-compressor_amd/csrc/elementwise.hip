@@ -5,8 +5,7 @@
 //   * per-channel scaling      (numerical/smoothquant.py:255-283)
 // All share one skeleton: each lane moves 16 B of input per step (global_load_dwordx4), UNROLL steps in flight,
 // fp32 arithmetic, one RNE narrowing to the output dtype, 16-byte stores.  HBM-bound: 2+2 B/elem for 16-bit I/O.
-#include <string.h>
-
+#include "floatq.hpp"
 #include "stream.hpp"
 
 namespace dmxq {
@@ -45,58 +44,6 @@ __device__ __forceinline__ float float_q1(float a, const FloatFmt& f, uint32_t r
     }
     q = u2f(qb);
   }
-  return f.unsigned_abs ? fabsf(q) : q;
-}
-
-// Nearest-even without the two data-dependent branches (normal / subnormal of the simulated format; both run in
-// practically every wave, ~30 VALU instructions per element together).  With E' = max(exponent(a), min_exp):
-//   M = +-1.5 * 2^(23 + E' - man)   (fl(t + M) lies in M's binade, whose ulp is the quantum 2^(E' - man): the add rounds
-//                                    to the nearest multiple, ties to the even one = the kept LSB of the bit pattern)
-//   S = +-2^min_exp if exponent(a) < min_exp else 0      (the reference's subnormal shift; its add is the same fp32 add)
-//   q = fl(fl(a + S) + M) - (M + S),  then the saturation as a clamp at +-max_val (rounding is monotone, so "rounded
-//   exponent > max_e" <=> |q| > max_val)
-// all constants carrying a's sign, which also reproduces the +0 the reference returns when a negative subnormal
-// rounds to zero.  Valid for finite a with exponent <= 103 + man (M finite) and 1 <= man <= 20; the caller falls back to
-// the bit-level form for a wave that holds anything else.
-struct FloatFast {
-  uint32_t min_exp_bits;  // (127 + min_exp) << 23
-  uint32_t k1;            // ((23 - man) << 23) | 0x00400000
-  uint32_t max_ok_bits;   // largest exponent field the fast form takes
-  float max_val;          // saturation value, +inf when the format's exponent range is fp32's
-  int usable;             // man <= 20 and min_exp in range
-};
-inline FloatFast make_float_fast(const FloatFmt& f) {
-  FloatFast k{};
-  const int min_exp = -(f.bias - 1);
-  // man = 0: the reference's tie rule then looks at the exponent's lowest bit, not at a mantissa bit -> bit-level form
-  k.usable = (f.man >= 1 && f.man <= 20 && min_exp >= -126 && min_exp <= 100) ? 1 : 0;
-  k.min_exp_bits = (uint32_t)(127 + (k.usable ? min_exp : 0)) << 23;
-  k.k1 = ((uint32_t)(23 - f.man) << 23) | 0x00400000u;
-  k.max_ok_bits = (uint32_t)(103 + f.man + 127 > 254 ? 254 : 103 + f.man + 127) << 23;
-  const int max_e = (1 << (f.exp_bits - 1)) + 127;
-  if (max_e >= 255) {
-    k.max_val = INFINITY;
-  } else {
-    uint32_t b = ((uint32_t)max_e << 23) | ((0x007FFFFFu >> (23 - f.man)) << (23 - f.man));
-    float v;
-    memcpy(&v, &b, 4);
-    k.max_val = v;
-  }
-  return k;
-}
-__device__ __forceinline__ bool float_fast_ok(float a, const FloatFast& k) {
-  const uint32_t eb = f2u(a) & 0x7F800000u;
-  return eb <= k.max_ok_bits;  // finite, and M representable
-}
-__device__ __forceinline__ float float_q1_fast(float a, const FloatFmt& f, const FloatFast& k) {
-  const uint32_t t = f2u(a), sign = t & 0x80000000u, eb = t & 0x7F800000u;
-  const bool sub = eb < k.min_exp_bits;
-  const uint32_t e2 = sub ? k.min_exp_bits : eb;
-  const float M = u2f((e2 + k.k1) | sign);
-  const float S = u2f(sub ? (k.min_exp_bits | sign) : sign);  // +-2^min_exp, or +-0
-  float q = ((a + S) + M) - (M + S);
-  q = __builtin_amdgcn_fmed3f(q, -k.max_val, k.max_val);
-  if (f.flush) q = sub ? 0.0f : q;
   return f.unsigned_abs ? fabsf(q) : q;
 }
 
@@ -154,7 +101,7 @@ struct FloatOp {
       for (int j = 0; j < N; j++) ok = ok && float_fast_ok(x[j], k);
       if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {  // wave-uniform: everything finite and in range
 #pragma unroll
-        for (int j = 0; j < N; j++) y[j] = float_q1_fast(x[j], f, k);
+        for (int j = 0; j < N; j++) y[j] = float_q1_fast(x[j], k, f.flush != 0, f.unsigned_abs != 0);
         return;
       }
     }
@@ -375,8 +322,8 @@ extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype
   if (!in || !out) return DMXQ_ERR_BAD_ARG;
   const FloatFmt f{man_bits, exp_bits, exp_bias, flush_subnormal ? 1 : 0, unsigned_abs ? 1 : 0, rounding, seed};
   hipStream_t s = (hipStream_t)stream;
-  if (rounding == DMXQ_ROUND_NEAREST) return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<DMXQ_ROUND_NEAREST>{f, make_float_fast(f)}, s);
-  return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<kRuntimeRounding>{f, make_float_fast(f)}, s);
+  if (rounding == DMXQ_ROUND_NEAREST) return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<DMXQ_ROUND_NEAREST>{f, make_float_fast(f.man, f.exp_bits, f.bias)}, s);
+  return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<kRuntimeRounding>{f, make_float_fast(f.man, f.exp_bits, f.bias)}, s);
 }
 
 extern "C" int dmxq_fixed_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t C,
