@@ -21,8 +21,9 @@
 //                     lanes and the block max is reduced with DPP moves (no LDS, no second read).
 //   bfp_cols_kernel   inner > 1 (block_dim = -2 / conv dim 1), inner % VEC == 0: lanes run along the
 //                     contiguous inner dim, each lane keeps its B x VEC column tile in registers.
-//   bfp_lds_rows_kernel inner == 1, any L / B (ragged tails, odd row pitch): a workgroup stages a span of whole
-//                     blocks in LDS with coalesced loads, lanes then own blocks inside LDS.
+//   bfp_urows_kernel  inner == 1, ragged rows (L % B != 0) and / or rows and bases at any element alignment: rows read
+//                     directly with unaligned 16-byte accesses, vectors numbered in a virtual space padded to whole
+//                     blocks (bfp_urows.hip).
 //   bfp_generic_kernel  everything else: one lane per block, strided two-pass (correct for any layout).
 #include "bfp_rows.hpp"
 
@@ -141,12 +142,9 @@ static int dispatch_mode(const void* in, void* out, int64_t outer, int64_t L, in
 extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int man_bits,
                               int exp_bits, int exp_bias, int flush_subnormal, int unsigned_abs, int rounding,
                               uint64_t seed, void* stream);
-// bfp_urows.hip: direct (unaligned 16-byte access) kernel for ragged / unaligned rows, same-size dtypes
+// bfp_urows.hip: direct (unaligned 16-byte access) kernel for ragged / unaligned rows
 extern "C" int dmxq_internal_bfp_urows(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t L,
                                        int64_t B, int wl, int rounding, int symmetric, uint64_t seed, void* stream);
-// bfp_ragged.hip: LDS-staged kernel for the remaining ragged / unaligned cases; DMXQ_ERR_UNSUPPORTED = not applicable
-extern "C" int dmxq_internal_bfp_ragged(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t L,
-                                        int64_t B, int wl, int rounding, int symmetric, uint64_t seed, void* stream);
 // bfp_cols.hip: register-tiled kernel for blocks along a non-contiguous dimension; DMXQ_ERR_UNSUPPORTED = not applicable
 extern "C" int dmxq_internal_bfp_cols(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L,
                                       int64_t inner, int64_t B, int wl, int rounding, int symmetric, uint64_t seed,
@@ -174,9 +172,6 @@ extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_o
       const int ru = dmxq_internal_bfp_urows(in, out, dtype_in, dtype_out, outer, L, block_size, precision, rounding,
                                              symmetric, seed, stream);
       if (ru != DMXQ_ERR_UNSUPPORTED) return ru;
-      const int rc = dmxq_internal_bfp_ragged(in, out, dtype_in, dtype_out, outer, L, block_size, precision, rounding,
-                                              symmetric, seed, stream);
-      if (rc != DMXQ_ERR_UNSUPPORTED) return rc;
     }
   }
   if (inner > 1) {

@@ -9,45 +9,43 @@
 // lanes of one wave exactly as in the aligned kernel (block max by DPP, same arithmetic, bfp_math.hpp), padding
 // vectors read nothing and count as zeros (= the reference's shorter last block), and the one partial vector at the
 // end of a row (L % EPL elements) is read and written in 8 / 4 / 2-byte pieces so that nothing outside the row is
-// touched.  HBM traffic is 1 read + 1 write per element; same-size input and output dtypes.
+// touched (element by element: one lane per row).  HBM traffic is 1 read + 1 write per element.
 #include "bfp_math.hpp"
 
 namespace dmxq {
 
 typedef u32x4 u32x4_u __attribute__((aligned(2)));
 typedef u32x2 u32x2_u __attribute__((aligned(2)));
-typedef uint32_t u32_u __attribute__((aligned(2)));
 
-// the first t elements (t < EPL, wave-uniform) of the vector at p, rest zero
-template <int EB>
-__device__ __forceinline__ u32x4 tail_load(const char* p, int t) {
-  uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-  if (EB == 2) {
-    if (t & 4) { const u32x2 a = *(const u32x2_u*)p; w0 = a.x; w1 = a.y; }
-    if (t & 2) { const uint32_t x = *(const u32_u*)(p + (t & 4) * 2); if (t & 4) w2 = x; else w0 = x; }
-    if (t & 1) {
-      const uint32_t x = *(const uint16_t*)(p + (t & 6) * 2);
-      switch (t >> 1) { case 0: w0 = x; break; case 1: w1 = x; break; case 2: w2 = x; break; default: w3 = x; break; }
+// the first t elements (t < EPL, wave-uniform) of the lane-vector at element offset e, rest zero: element-wise loads,
+// packed into the raw layout with compile-time positions (only the one tail lane of a row runs this)
+template <int DTI, int EPL>
+__device__ __forceinline__ u32x4 tail_load(const void* in, int64_t e, int t) {
+  uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int k = 0; k < EPL; k++) {
+    if (k < t) {
+      if (Elem<DTI>::bytes == 4) w[k] = ((const uint32_t*)in)[e + k];
+      else w[k / 2] |= (uint32_t)((const uint16_t*)in)[e + k] << (16 * (k & 1));
     }
-  } else {
-    if (t & 2) { const u32x2 a = *(const u32x2_u*)p; w0 = a.x; w1 = a.y; }
-    if (t & 1) { const uint32_t x = *(const u32_u*)(p + (t & 2) * 4); if (t & 2) w2 = x; else w0 = x; }
   }
-  return u32x4{w0, w1, w2, w3};
+  return u32x4{w[0], w[1], w[2], w[3]};
 }
-template <int EB>
-__device__ __forceinline__ void tail_store(char* p, int t, const u32x4& o) {
-  if (EB == 2) {
-    if (t & 4) *(u32x2_u*)p = u32x2{o.x, o.y};
-    if (t & 2) *(u32_u*)(p + (t & 4) * 2) = (t & 4) ? o.z : o.x;
-    if (t & 1) {
-      uint32_t x;
-      switch (t >> 1) { case 0: x = o.x; break; case 1: x = o.y; break; case 2: x = o.z; break; default: x = o.w; break; }
-      *(uint16_t*)(p + (t & 6) * 2) = (uint16_t)x;
-    }
+
+// EPL consecutive outputs at element offset e, any alignment: 16-byte accesses (one, or two for fp32 outputs of a 16-bit
+// lane-vector), 8 bytes for 16-bit outputs of an fp32 lane-vector
+template <int DTO, int EPL>
+__device__ __forceinline__ void store_unaligned(void* out, int64_t e, const float (&y)[EPL]) {
+  char* p = (char*)out + e * Elem<DTO>::bytes;
+  if (DTO == DMXQ_F32) {
+#pragma unroll
+    for (int k = 0; k < EPL; k += 4)
+      __builtin_nontemporal_store(u32x4{f2u(y[k]), f2u(y[k + 1]), f2u(y[k + 2]), f2u(y[k + 3])}, (u32x4_u*)(p + 4 * k));
+  } else if (EPL == 8) {
+    __builtin_nontemporal_store(u32x4{pack2<DTO>(y[0], y[1]), pack2<DTO>(y[2], y[3]), pack2<DTO>(y[4], y[5]), pack2<DTO>(y[6], y[7])},
+                                (u32x4_u*)p);
   } else {
-    if (t & 2) *(u32x2_u*)p = u32x2{o.x, o.y};
-    if (t & 1) *(u32_u*)(p + (t & 2) * 4) = (t & 2) ? o.z : o.x;
+    __builtin_nontemporal_store(u32x2{pack2<DTO>(y[0], y[1]), pack2<DTO>(y[2], y[3])}, (u32x2_u*)p);
   }
 }
 
@@ -56,7 +54,6 @@ __global__ __launch_bounds__(kThreads) void bfp_urows_kernel(const void* __restr
                                                             int64_t rows, int64_t L, int nvr /*vectors per row*/,
                                                             int nvrp /*... padded to whole blocks*/, int tail,
                                                             int lpb_arg, int wl, int rounding, uint64_t seed) {
-  static_assert(Elem<DTI>::bytes == Elem<DTO>::bytes, "same-size dtypes");
   constexpr int EB = Elem<DTI>::bytes, EPL = 16 / EB;
   constexpr bool kFast = FAST != 0 && RND == DMXQ_ROUND_NEAREST;
   constexpr int64_t TILE = (int64_t)kThreads * UNROLL;
@@ -90,34 +87,36 @@ __global__ __launch_bounds__(kThreads) void bfp_urows_kernel(const void* __restr
     if (has_tail) {
 #pragma unroll
       for (int u = 0; u < UNROLL; u++)
-        if (part[u]) raw[u] = tail_load<EB>((const char*)in + eoff[u] * EB, tail);
+        if (part[u]) raw[u] = tail_load<DTI, EPL>(in, eoff[u], tail);
     }
-    u32x4 o[UNROLL];
+    float y[UNROLL][EPL];
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
       const uint32_t mb = group_max_u32(absmax_bits<DTI>(raw[u]), lpb);
-      float x[EPL], y[EPL];
+      float x[EPL];
       widen<DTI, EPL>(raw[u], x);
       if (kFast && __builtin_amdgcn_ballot_w64(!bfp_fast_ok(mb, wl)) == 0ull) {
         const BfpBlockParams p = bfp_block_params<ASYM, true>(mb, wl);
 #pragma unroll
-        for (int k = 0; k < EPL; k++) y[k] = bfp_q1_fast<FAST == 2, ASYM>(x[k], p);
+        for (int k = 0; k < EPL; k++) y[u][k] = bfp_q1_fast<FAST == 2, ASYM>(x[k], p);
       } else {
         const BfpBlockParams p = bfp_block_params<ASYM, false>(mb, wl);
 #pragma unroll
         for (int k = 0; k < EPL; k++)
-          y[k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, rnd_if(stoch, seed, (uint64_t)(eoff[u] + k)));
+          y[u][k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, rnd_if(stoch, seed, (uint64_t)(eoff[u] + k)));
       }
-      const OutVec<DTO, EPL> pk = pack_vec<DTO, EPL>(y);
-      o[u] = u32x4{pk.w[0], pk.w[1], pk.w[2], pk.w[3]};
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; u++)
-      if (eoff[u] >= 0 && !part[u]) __builtin_nontemporal_store(o[u], (u32x4_u*)((char*)out + eoff[u] * EB));
+      if (eoff[u] >= 0 && !part[u]) store_unaligned<DTO, EPL>(out, eoff[u], y[u]);
     if (has_tail) {
 #pragma unroll
       for (int u = 0; u < UNROLL; u++)
-        if (part[u]) tail_store<EB>((char*)out + eoff[u] * EB, tail, o[u]);
+        if (part[u]) {
+#pragma unroll
+          for (int k = 0; k < EPL; k++)
+            if (k < tail) store1<DTO>(out, eoff[u] + k, y[u][k]);
+        }
     }
   }
 }
@@ -155,15 +154,15 @@ static int launch_urows(const void* in, void* out, int64_t rows, int64_t L, int6
 using namespace dmxq;
 
 // internal entry used by dmxq_bfp_qdq (bfp.hip) for inner == 1 tensors the flat-stream kernel cannot take.
-// DMXQ_ERR_UNSUPPORTED = not applicable (caller goes on to the LDS-staged kernel, bfp_ragged.hip).
+// DMXQ_ERR_UNSUPPORTED = not applicable (caller goes on to the generic one-lane-per-block kernel).
 extern "C" int dmxq_internal_bfp_urows(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t L,
                                        int64_t B, int wl, int rounding, int symmetric, uint64_t seed, void* stream) {
   const int epl = dtype_in == DMXQ_F32 ? 4 : 8;
-  const bool same_size = (dtype_in == DMXQ_F32) == (dtype_out == DMXQ_F32);
-  if (!same_size || B < epl || B > 64 * epl || (B & (B - 1)) != 0 || wl > 22 || L < epl) return DMXQ_ERR_UNSUPPORTED;
+  if (B < epl || B > 64 * epl || (B & (B - 1)) != 0 || wl > 22 || L < epl) return DMXQ_ERR_UNSUPPORTED;
   if ((L + epl - 1) / epl + 64 >= ((int64_t)1 << 31)) return DMXQ_ERR_UNSUPPORTED;
-  const uintptr_t eb = dtype_in == DMXQ_F32 ? 4 : 2;
-  if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & (eb - 1)) return DMXQ_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(in) & (dtype_in == DMXQ_F32 ? 3u : 1u)) ||
+      (reinterpret_cast<uintptr_t>(out) & (dtype_out == DMXQ_F32 ? 3u : 1u)))
+    return DMXQ_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const bool asym = !symmetric;
 #define DMXQ_DT(I_, O_)                                                                                          \
@@ -177,6 +176,10 @@ extern "C" int dmxq_internal_bfp_urows(const void* in, void* out, int dtype_in, 
   DMXQ_DT(DMXQ_BF16, DMXQ_BF16)
   DMXQ_DT(DMXQ_F16, DMXQ_F16)
   DMXQ_DT(DMXQ_F32, DMXQ_F32)
+  DMXQ_DT(DMXQ_BF16, DMXQ_F32)
+  DMXQ_DT(DMXQ_F16, DMXQ_F32)
+  DMXQ_DT(DMXQ_F32, DMXQ_BF16)
+  DMXQ_DT(DMXQ_F32, DMXQ_F16)
 #undef DMXQ_DT
   return DMXQ_ERR_UNSUPPORTED;
 }
