@@ -145,7 +145,7 @@ static int launch_blockfmt(const void* in, void* out, int64_t outer, int64_t L, 
   constexpr int EPL = 16 / Elem<DTI>::bytes;
   const int64_t n = outer * L * inner;
   const bool pow2 = (B & (B - 1)) == 0;
-  if (inner == 1 && L % B == 0 && pow2 && B >= EPL && B <= 64 * EPL && aligned16(in) && aligned16(out)) {
+  if (inner == 1 && L % B == 0 && pow2 && B >= EPL && B <= 64 * EPL) {  // (any base alignment: stream.hpp)
     return launch_stream<DTI, DTO>(in, out, n, BlockOp<FMT, BLK>{f, (int)(B / EPL)}, s);
   } else {
     const int64_t nblk = (L + B - 1) / B;

@@ -199,19 +199,24 @@ __device__ __forceinline__ OutVec<DT, N> pack_vec(const float (&y)[N]) {
   return o;
 }
 
-template <int DT, int N, bool NT>
+// UNAL: the address is only element-aligned.  gfx950 serves such 16-byte accesses at 93-97 % of the aligned rate
+// (profiles/r01_unaligned_access.txt); the 2-byte-aligned pointer types only stop the compiler from assuming more.
+typedef u32x4 u32x4_unal __attribute__((aligned(2)));
+typedef u32x2 u32x2_unal __attribute__((aligned(2)));
+template <int DT, int N, bool NT, bool UNAL = false>
 __device__ __forceinline__ void store_out(void* p, const OutVec<DT, N>& o) {
   constexpr int W = OutVec<DT, N>::kWords;
   if (W % 4 == 0) {
 #pragma unroll
     for (int k = 0; k < W; k += 4) {
       u32x4 v = {o.w[k], o.w[k + 1], o.w[k + 2], o.w[k + 3]};
-      u32x4* dst = (u32x4*)p + k / 4;
-      if (NT) __builtin_nontemporal_store(v, dst); else *dst = v;
+      if (UNAL) { u32x4_unal* dst = (u32x4_unal*)p + k / 4; if (NT) __builtin_nontemporal_store(v, dst); else *dst = v; }
+      else { u32x4* dst = (u32x4*)p + k / 4; if (NT) __builtin_nontemporal_store(v, dst); else *dst = v; }
     }
   } else {  // 2 words: 4 sixteen-bit outputs
     u32x2 v = {o.w[0], o.w[1]};
-    if (NT) __builtin_nontemporal_store(v, (u32x2*)p); else *(u32x2*)p = v;
+    if (UNAL) { if (NT) __builtin_nontemporal_store(v, (u32x2_unal*)p); else *(u32x2_unal*)p = v; }
+    else { if (NT) __builtin_nontemporal_store(v, (u32x2*)p); else *(u32x2*)p = v; }
   }
 }
 
@@ -247,8 +252,12 @@ __device__ __forceinline__ uint32_t group_max_u32(uint32_t m, int lanes) {
 // raw 16-byte input vector: load once, then (a) widen to fp32 and (b) take max|x| on the raw bit patterns.
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 
-template <bool NT, typename OFF = int64_t>
+template <bool NT, typename OFF = int64_t, bool UNAL = false>
 __device__ __forceinline__ u32x4 load_raw16(const void* p, OFF byte_off) {
+  if (UNAL) {
+    const u32x4_unal* src = (const u32x4_unal*)((const char*)p + byte_off);
+    return NT ? __builtin_nontemporal_load(src) : *src;
+  }
   const u32x4* src = (const u32x4*)((const char*)p + byte_off);
   return NT ? __builtin_nontemporal_load(src) : *src;
 }

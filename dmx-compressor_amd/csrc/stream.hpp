@@ -34,7 +34,7 @@ struct OpPrep<OP, std::void_t<typename OP::Prep>> {
   }
 };
 
-template <int DTI, int DTO, int UNROLL, int THREADS, class OP>
+template <int DTI, int DTO, int UNROLL, int THREADS, class OP, bool UNAL = false>
 __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                         int64_t n, OP op) {
   constexpr int EPL = 16 / Elem<DTI>::bytes;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict_
     if ((tile + 1) * TILE <= n_vec) {
       u32x4 raw[UNROLL];
 #pragma unroll
-      for (int u = 0; u < UNROLL; u++) raw[u] = load_raw16<true>(src + u * (THREADS * 16), lane_in);
+      for (int u = 0; u < UNROLL; u++) raw[u] = load_raw16<true, uint32_t, UNAL>(src + u * (THREADS * 16), lane_in);
       typename OpPrep<OP>::type prep[UNROLL];
 #pragma unroll
       for (int u = 0; u < UNROLL; u++) prep[u] = OpPrep<OP>::get(op, (v0 + (int64_t)u * THREADS) * EPL);
@@ -65,16 +65,16 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict_
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int u = 0; u < UNROLL; u++) store_out<DTO, EPL, true>(dst + u * (THREADS * OVB) + lane_out, o[u]);
+      for (int u = 0; u < UNROLL; u++) store_out<DTO, EPL, true, UNAL>(dst + u * (THREADS * OVB) + lane_out, o[u]);
     } else {
       for (int u = 0; u < UNROLL; u++) {
         const int64_t vi = v0 + (int64_t)u * THREADS;
         if (vi < n_vec) {
-          const u32x4 raw = load_raw16<true>(src + u * (THREADS * 16), lane_in);
+          const u32x4 raw = load_raw16<true, uint32_t, UNAL>(src + u * (THREADS * 16), lane_in);
           float x[EPL], y[EPL];
           widen<DTI, EPL>(raw, x);
           op.apply_vec(x, y, vi * EPL);
-          store_out<DTO, EPL, true>(dst + u * (THREADS * OVB) + lane_out, pack_vec<DTO, EPL>(y));
+          store_out<DTO, EPL, true, UNAL>(dst + u * (THREADS * OVB) + lane_out, pack_vec<DTO, EPL>(y));
         }
       }
     }
@@ -85,18 +85,6 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict_
     float x1[1] = {load1<DTI>(in, e)}, y1[1];
     op.apply_one(x1[0], y1[0], e);
     store1<DTO>(out, e, y1[0]);
-  }
-}
-
-// pointers not 16-byte aligned: scalar accesses
-template <int DTI, int DTO, class OP>
-__global__ __launch_bounds__(kThreads) void stream_scalar_kernel(const void* __restrict__ in, void* __restrict__ out,
-                                                                int64_t n, OP op) {
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < n; e += stride) {
-    float y;
-    op.apply_one(load1<DTI>(in, e), y, e);
-    store1<DTO>(out, e, y);
   }
 }
 
@@ -111,11 +99,14 @@ template <int DTI, int DTO, class OP>
 static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hipStream_t s) {
   constexpr int EPL = 16 / Elem<DTI>::bytes;
   constexpr int UB = (Elem<DTO>::bytes > Elem<DTI>::bytes) ? 8 : 16;
-  if (!aligned16(in) || !aligned16(out)) {
-    hipLaunchKernelGGL((stream_scalar_kernel<DTI, DTO, OP>), dim3(grid_for(n)), dim3(kThreads), 0, s, in, out, n, op);
+  const int64_t n_vec = n / EPL;
+  if (!aligned16(in) || !aligned16(out)) {  // views that start mid-allocation: same schedule on unaligned 16-byte accesses
+    int64_t tiles = (n_vec + (int64_t)256 * 4 - 1) / ((int64_t)256 * 4);
+    if (tiles < 1) tiles = 1;
+    if (tiles > (1 << 20)) tiles = 1 << 20;
+    hipLaunchKernelGGL((stream_kernel<DTI, DTO, 4, 256, OP, true>), dim3((unsigned)tiles), dim3(256), 0, s, in, out, n, op);
     return launch_status();
   }
-  const int64_t n_vec = n / EPL;
 #define DMXQ_STREAM(T_, U_)                                                                                       \
   do {                                                                                                            \
     int64_t tiles = (n_vec + (int64_t)(T_) * (U_) - 1) / ((int64_t)(T_) * (U_));                                  \

@@ -59,8 +59,14 @@ def test_elementwise_random_cases(dmx, cuda, oracle, chunk):
         shape = _shape(rng)
         dtype = rng.choice(DT)
         x = make(rng.choice(["normal", "heavy", "ties"]), shape, seed=chunk * 100 + case, dtype=dtype) * rng.choice([1.0, 10.0, 100.0])
-        xg = x.to(cuda)
-        tag = (chunk, case, shape, dtype)
+        off = rng.choice([0, 0, 1, 3])  # a view that starts `off` elements into its allocation (unaligned 16-byte accesses)
+        if off:
+            base = torch.empty(x.numel() + off, dtype=dtype)
+            base[off:] = x.reshape(-1)
+            xg = base.to(cuda)[off:].view(shape)
+        else:
+            xg = x.to(cuda)
+        tag = (chunk, case, shape, dtype, off)
         which = rng.choice(["float", "fixed", "affine"])
         if which == "float":
             man, exp = rng.choice([(10, 5), (7, 8), (3, 4), (2, 5), (1, 2), (0, 8), (3, 2), (22, 8)])
