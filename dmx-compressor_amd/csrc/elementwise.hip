@@ -269,14 +269,37 @@ struct ScaleOp {
   }
 };
 
-// torch.nn.functional.gelu, erf and tanh forms (approximator slot, see approx.hip)
+// torch.nn.functional.gelu, erf and tanh forms (approximator slot, see approx.hip).
+// FAST (16-bit outputs only): the libm calls are replaced by short closed forms whose error (< 8e-7 absolute on the
+// result for |x| <= 10, exact saturation beyond) is far inside the output format's half-ulp:
+//   erf form : with z = |x| / sqrt 2, erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2), t = 1 / (1 + p z)
+//              (Abramowitz-Stegun 7.1.26, |error| < 1.5e-7), gelu = x >= 0 ? x - x erfc / 2 : x erfc / 2 -- the erfc form
+//              keeps RELATIVE accuracy in the negative tail, where 1 + erf cancels;
+//   tanh form: x (1 + tanh u) / 2 = x / (1 + exp(-2u)).
+template <bool FAST>
 struct GeluOp {
   static constexpr bool kHeavy = true;
   int tanh_form;
   __device__ __forceinline__ void apply_one(float x, float& y, int64_t) const {
     if (tanh_form) {
       const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-      y = 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));
+      const float u = k0 * (x + k1 * x * x * x);
+      if (FAST) {  // x (1 + tanh u) / 2 = x / (1 + exp(-2u)): no cancellation in the negative tail
+        y = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -2.8853900817779268f));
+      } else {
+        y = 0.5f * x * (1.0f + tanhf(u));
+      }
+    } else if (FAST) {
+      const float z = fabsf(x) * 0.7071067811865476f;
+      const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+      float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+      p = __builtin_fmaf(t, p, 1.421413741f);
+      p = __builtin_fmaf(t, p, -0.284496736f);
+      p = __builtin_fmaf(t, p, 0.254829592f);
+      const float erfc = p * t * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+      const float g = 0.5f * x * erfc;
+      y = x > 0.0f ? x - g : g;  // (x = -0: g = -0, as torch)
+      if (x != x) y = x;
     } else {
       y = 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
     }
@@ -393,7 +416,8 @@ extern "C" int dmxq_gelu(const void* in, void* out, int dtype_in, int dtype_out,
   if (!valid_dtype(dtype_in) || !valid_dtype(dtype_out) || n < 0) return DMXQ_ERR_BAD_ARG;
   if (n == 0) return DMXQ_OK;
   if (!in || !out) return DMXQ_ERR_BAD_ARG;
-  return dispatch_stream(in, out, dtype_in, dtype_out, n, GeluOp{tanh_form}, (hipStream_t)stream);
+  if (dtype_out != DMXQ_F32) return dispatch_stream(in, out, dtype_in, dtype_out, n, GeluOp<true>{tanh_form}, (hipStream_t)stream);
+  return dispatch_stream(in, out, dtype_in, dtype_out, n, GeluOp<false>{tanh_form}, (hipStream_t)stream);
 }
 
 extern "C" int dmxq_bernoulli_mask(const void* score, void* mask_out, int dtype_score, int dtype_mask, int64_t n,

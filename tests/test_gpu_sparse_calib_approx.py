@@ -364,3 +364,28 @@ def test_sparsify_reconfiguration(dmx):
     assert repr(sp.sparseness) == "TOPK{0.5}(U)" and sp.backward_mode == "joint"
     sp.sparseness = dmx.Sparseness.from_shorthand("BTOPK{4:8,-1}(U)")
     assert repr(sp.sparseness) == "BTOPK{4:8,-1}(U)"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_gelu_tails_and_special_values(dmx, cuda, dtype):
+    """GELU (erf and tanh forms; closed-form fast paths for 16-bit outputs): the negative tail where 1 + erf cancels,
+    saturation, signed zeros, inf / NaN exactly as torch."""
+    F = torch.nn.functional
+    eps = torch.finfo(dtype).eps
+    x = torch.cat([torch.linspace(-14, 14, 4001), torch.tensor([0.0, -0.0, 1e-30, -1e-30, 20.0, -20.0, 100.0, -100.0, 1e4, -1e4,
+                                                               float("inf"), float("-inf"), float("nan")])]).to(dtype)
+    for approx in ("none", "tanh"):
+        got = dmx.ops.gelu(x.to(cuda), approx).cpu().float()
+        ref = F.gelu(x.float(), approximate=approx).to(dtype).float()
+        if approx == "none":  # torch's vectorised CPU erf form returns NaN at +inf; the mathematical value is +inf
+            keep = x.float() != float("inf")
+            got, ref, xs = got[keep], ref[keep], x.float()[keep]
+        else:
+            xs = x.float()
+        fin = torch.isfinite(ref)
+        assert torch.equal(torch.isnan(got), torch.isnan(ref)), approx
+        assert torch.equal(got[~fin & ~torch.isnan(ref)], ref[~fin & ~torch.isnan(ref)]), approx
+        assert int(((got[fin] - ref[fin]).abs() > eps * ref[fin].abs() + 2e-6).sum()) == 0, approx
+        z = (xs == 0) | (xs.abs() >= 20)       # exact results incl. the sign of zero
+        z &= fin
+        assert torch.equal(got[z].view(torch.int32), ref[z].view(torch.int32)), approx
