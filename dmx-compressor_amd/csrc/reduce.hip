@@ -75,6 +75,34 @@ __global__ __launch_bounds__(kThreads) void group_minmax_kernel(const void* __re
   }
 }
 
+// 8 consecutive elements, compile-time dtype: the RAW 16-byte vectors first (so that a batch of loads is issued back to
+// back), widened afterwards.  (The runtime-dtype load8_rt below wraps every load in a dtype branch whose conversion
+// waits for that load: one access in flight per lane.)
+template <int DT>
+struct Raw8 {
+  u32x4 a, b;  // b only for fp32
+};
+template <int DT>
+__device__ __forceinline__ Raw8<DT> load8_raw(const void* p, int64_t e) {
+  Raw8<DT> r;
+  if (DT == DMXQ_F32) { r.a = *(const u32x4*)((const float*)p + e); r.b = *(const u32x4*)((const float*)p + e + 4); }
+  else { r.a = *(const u32x4*)((const uint16_t*)p + e); r.b = r.a; }
+  return r;
+}
+template <int DT>
+__device__ __forceinline__ void widen8(const Raw8<DT>& r, float (&v)[8]) {
+  if (DT == DMXQ_F32) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) { v[j] = u2f(r.a[j]); v[4 + j] = u2f(r.b[j]); }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (DT == DMXQ_BF16) { v[2 * j] = u2f(r.a[j] << 16); v[2 * j + 1] = u2f(r.a[j] & 0xFFFF0000u); }
+      else { v[2 * j] = half_lo(r.a[j]); v[2 * j + 1] = half_hi(r.a[j]); }
+    }
+  }
+}
+
 // 8 consecutive elements as fp32 (16-byte accesses; the address must be 16-byte aligned)
 __device__ __forceinline__ void load8_rt(const void* p, int dt, int64_t e, float (&v)[8]) {
   if (dt == DMXQ_F32) {
@@ -92,7 +120,8 @@ __device__ __forceinline__ void load8_rt(const void* p, int dt, int64_t e, float
 
 // vectorised twin of group_minmax_kernel: every run of a group is a whole number of aligned 8-element vectors
 constexpr int kMinmaxThreads = 1024;  // big workgroups: few contended atomics per group, 16 waves of loads in flight
-__global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const void* __restrict__ in, int dt,
+template <int DT>
+__global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const void* __restrict__ in,
                                                                          int64_t outer, int64_t C, int64_t inner,
                                                                          int64_t gs, float* mn, float* mx) {
   constexpr int kThreads = kMinmaxThreads;  // shadows the namespace constant inside this kernel
@@ -107,23 +136,27 @@ __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const 
   int64_t o = t / lenv, r = t % lenv;
   const int64_t so = stride / lenv, sr = stride % lenv;
   while (t < total) {
-    float v[4][8];
+    Raw8<DT> raw[4];
     int nv = 0;
+    int64_t last = (o * C + c0) * inner + r * 8;  // out-of-range slots re-read the last valid vector (harmless for min/max)
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       if (t < total) {
-        load8_rt(in, dt, (o * C + c0) * inner + r * 8, v[u]);
+        last = (o * C + c0) * inner + r * 8;
         nv = u + 1;
         t += stride; o += so; r += sr;
         if (r >= lenv) { r -= lenv; o += 1; }
       }
+      raw[u] = load8_raw<DT>(in, last);
     }
+    (void)nv;
 #pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (u < nv) {
+    for (int u = 0; u < 4; u++) {
+      float v[8];
+      widen8<DT>(raw[u], v);
 #pragma unroll
-        for (int k = 0; k < 8; k++) { lo = fminf(lo, v[u][k]); hi = fmaxf(hi, v[u][k]); }
-      }
+      for (int k = 0; k < 8; k++) { lo = fminf(lo, v[k]); hi = fmaxf(hi, v[k]); }
+    }
   }
   lo = wave_min(lo);
   hi = wave_max(hi);
@@ -145,7 +178,8 @@ __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const 
 // (C x inner) plane; a lane owns 8 columns, the 4 waves take different rows (4 row loads in flight each), their
 // partial maxima are combined through LDS and ONE wave issues the integer atomics.
 constexpr int kMaxabsThreads = 1024;  // 16 waves over rows per column strip: parallelism without more atomics
-__global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(const void* __restrict__ in, int dt,
+template <int DT>
+__global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(const void* __restrict__ in,
                                                                            int64_t outer, int64_t C, int64_t inner,
                                                                            float* out) {
   constexpr int W = kMaxabsThreads / kWave;
@@ -160,17 +194,20 @@ __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(cons
   int64_t o = (int64_t)blockIdx.y * W + w;
   if (ok) {
     for (; o + 3 * step < outer; o += 4 * step) {
-      float v[4][8];
+      Raw8<DT> raw[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) load8_rt(in, dt, (o + u * step) * plane + col0, v[u]);
+      for (int u = 0; u < 4; u++) raw[u] = load8_raw<DT>(in, (o + u * step) * plane + col0);
 #pragma unroll
-      for (int u = 0; u < 4; u++)
+      for (int u = 0; u < 4; u++) {
+        float v[8];
+        widen8<DT>(raw[u], v);
 #pragma unroll
-        for (int k = 0; k < 8; k++) m[k] = fmaxf(m[k], fabsf(v[u][k]));
+        for (int k = 0; k < 8; k++) m[k] = fmaxf(m[k], fabsf(v[k]));
+      }
     }
     for (; o < outer; o += step) {
       float v[8];
-      load8_rt(in, dt, o * plane + col0, v);
+      widen8<DT>(load8_raw<DT>(in, o * plane + col0), v);
 #pragma unroll
       for (int k = 0; k < 8; k++) m[k] = fmaxf(m[k], fabsf(v[k]));
     }
@@ -244,8 +281,10 @@ __device__ __forceinline__ void hist_add(uint32_t* s, float v, float lo, float h
     atomicAdd(&s[pos], 1u);
   }
 }
-__global__ __launch_bounds__(kHistThreads) void histc_kernel(const void* __restrict__ in, int dt, int64_t n, int bins,
+template <int DT>
+__global__ __launch_bounds__(kHistThreads) void histc_kernel(const void* __restrict__ in, int64_t n, int bins,
                                                              float lo, float hi, int vec, uint32_t* counts) {
+  constexpr int dt = DT;
   extern __shared__ uint32_t s_hist[];
   for (int b = threadIdx.x; b < bins; b += kHistThreads) s_hist[b] = 0;
   __syncthreads();
@@ -257,8 +296,9 @@ __global__ __launch_bounds__(kHistThreads) void histc_kernel(const void* __restr
     for (int64_t t = t0; t < nv; t += 2 * stride) {
       float a[8], b[8];
       const bool two = t + stride < nv;
-      load8_rt(in, dt, t * 8, a);
-      if (two) load8_rt(in, dt, (t + stride) * 8, b);
+      const Raw8<DT> ra = load8_raw<DT>(in, t * 8), rb = load8_raw<DT>(in, (two ? t + stride : t) * 8);
+      widen8<DT>(ra, a);
+      widen8<DT>(rb, b);
 #pragma unroll
       for (int k = 0; k < 8; k++) hist_add(s_hist, a[k], lo, hi, fb, width, bins);
       if (two) {
@@ -307,8 +347,9 @@ extern "C" int dmxq_group_minmax(const void* in, int dtype_in, int64_t outer, in
       const int64_t capv = (512 + G - 1) / G;  // ~512 workgroups of 1024 threads in total
       if (sv > capv) sv = capv;
       if (sv < 1) sv = 1;
-      hipLaunchKernelGGL(group_minmax_vec_kernel, dim3((unsigned)sv, (unsigned)G), dim3(kMinmaxThreads), 0, s, in, dtype_in,
-                         outer, C, inner, group_size, mn, mx);
+#define DMXQ_MM(D_) hipLaunchKernelGGL(group_minmax_vec_kernel<D_>, dim3((unsigned)sv, (unsigned)G), dim3(kMinmaxThreads), 0, s, in, outer, C, inner, group_size, mn, mx)
+      if (dtype_in == DMXQ_F32) DMXQ_MM(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_MM(DMXQ_F16); else DMXQ_MM(DMXQ_BF16);
+#undef DMXQ_MM
     } else
       hipLaunchKernelGGL(group_minmax_kernel, dim3((unsigned)splits, (unsigned)G), dim3(kThreads), 0, s, in, dtype_in,
                          outer, C, inner, group_size, mn, mx);
@@ -348,8 +389,9 @@ extern "C" int dmxq_channel_maxabs(const void* in, int dtype_in, int64_t outer, 
     }
     if (gy > 65535) gy = 65535;
     if (vec)
-      hipLaunchKernelGGL(channel_maxabs_vec_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kMaxabsThreads), 0, s, in,
-                         dtype_in, outer, C, inner, out);
+#define DMXQ_MA(D_) hipLaunchKernelGGL(channel_maxabs_vec_kernel<D_>, dim3((unsigned)gx, (unsigned)gy), dim3(kMaxabsThreads), 0, s, in, outer, C, inner, out)
+    { if (dtype_in == DMXQ_F32) DMXQ_MA(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_MA(DMXQ_F16); else DMXQ_MA(DMXQ_BF16); }
+#undef DMXQ_MA
     else
       hipLaunchKernelGGL(channel_maxabs_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, s, in, dtype_in,
                          outer, C, inner, out);
@@ -378,8 +420,9 @@ extern "C" int dmxq_histc(const void* in, int dtype_in, int64_t n, int64_t bins,
     if (!in) return DMXQ_ERR_BAD_ARG;
     int64_t blocks = (n + kHistThreads * 32 - 1) / (kHistThreads * 32);
     if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(histc_kernel, dim3((unsigned)blocks), dim3(kHistThreads), (size_t)bins * sizeof(uint32_t), s, in,
-                       dtype_in, n, (int)bins, lo, hi, aligned16(in) ? 1 : 0, (uint32_t*)hist);
+#define DMXQ_HC(D_) hipLaunchKernelGGL(histc_kernel<D_>, dim3((unsigned)blocks), dim3(kHistThreads), (size_t)bins * sizeof(uint32_t), s, in, n, (int)bins, lo, hi, aligned16(in) ? 1 : 0, (uint32_t*)hist)
+    if (dtype_in == DMXQ_F32) DMXQ_HC(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_HC(DMXQ_F16); else DMXQ_HC(DMXQ_BF16);
+#undef DMXQ_HC
     hipLaunchKernelGGL(hist_to_float_kernel, dim3((unsigned)((bins + 255) / 256)), dim3(256), 0, s, (uint32_t*)hist, (int)bins);
   }
   return launch_status();
