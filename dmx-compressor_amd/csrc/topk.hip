@@ -2,19 +2,22 @@
 // application (`x * mask`, sparse.py:300) for gfx950.
 //
 // The reference argsorts the whole flattened score tensor (int64 indices, 8 B/elem) to zero its n_zero smallest
-// entries.  Here: a 4-level most-significant-digit radix SELECT finds the key T of the n_zero-th smallest score
-// (one 256-bin histogram pass per level over an order-preserving 32-bit key; the bucket choice between levels is a
+// entries.  Here: a 3-level most-significant-digit radix SELECT (digits of 11, 11, 10 bits) finds the key T of the n_zero-th smallest score
+// (one 2048-bin histogram pass per level over an order-preserving 32-bit key; the bucket choice between levels is a
 // one-wave kernel, so there is no host round trip), which also yields how many scores are below T and how many equal
 // it; a final pass writes mask / x*mask.  Ties at T: exactly the first r_eq of them in index order are zeroed (stable
 // ascending order, the rule of nm_mask.hip: -0 == +0, NaN largest) -- the reference's unstable sort leaves that
 // choice undefined.  Only when r_eq is fewer than all ties does an index-ordered count run (per-chunk tie counts,
 // a scan over chunks, per-thread prefixes inside a chunk); otherwise those two launches return immediately.
-// Passes over the scores: 4 + 1 (+ 1 with boundary ties), one write.
+// Passes over the scores: 3 + 1 (+ 1 with boundary ties), one write.
 #include "common.hpp"
 
 namespace dmxq {
 
 constexpr int kTopkChunk = kThreads * 8;  // elements per chunk: 8 consecutive per thread
+constexpr int kTopkLevels = 3, kTopkBins = 2048;  // digits of 11, 11 and 10 bits, most significant first
+__host__ __device__ constexpr int topk_shift(int level) { return level == 0 ? 21 : (level == 1 ? 10 : 0); }
+__host__ __device__ constexpr int topk_bits(int level) { return level == 2 ? 10 : 11; }
 
 struct TopkState {
   uint32_t prefix;      // key bits fixed so far (high bits)
@@ -23,7 +26,7 @@ struct TopkState {
   int64_t less;         // number of keys known to be below the wanted one
   int64_t count_eq;     // after the last level: number of keys equal to T
 };
-// workspace layout: TopkState | uint32 hist[256] | int64 chunk_counts[ceil(n / kTopkChunk)]
+// workspace layout: TopkState | uint32 hist[2048] | int64 chunk_counts[ceil(n / kTopkChunk)]
 struct TopkWs {
   TopkState* st;
   uint32_t* hist;
@@ -31,7 +34,7 @@ struct TopkWs {
 };
 __host__ __device__ inline TopkWs topk_ws(void* base) {
   char* p = (char*)base;
-  return TopkWs{(TopkState*)p, (uint32_t*)(p + 64), (int64_t*)(p + 64 + 1024)};
+  return TopkWs{(TopkState*)p, (uint32_t*)(p + 64), (int64_t*)(p + 64 + 4 * kTopkBins)};
 }
 
 // unsigned order-preserving key: -0 == +0, every NaN the same, largest key
@@ -42,59 +45,132 @@ __device__ __forceinline__ uint32_t ukey(float s) {
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// 8 consecutive scores as keys; compile-time dtype, 16-byte loads when the base allows it (fp32: two), scalar otherwise.
+// e + 8 <= n required.
+template <int DT>
+__device__ __forceinline__ void load8_keys(const void* p, int64_t e, bool vec, uint32_t (&key)[8]) {
+  float v[8];
+  if (vec) {
+    if (DT == DMXQ_F32) {
+      const f32x4 a = *(const f32x4*)((const float*)p + e), b = *(const f32x4*)((const float*)p + e + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+      const u32x4 t = *(const u32x4*)((const uint16_t*)p + e);
+      widen<DT, 8>(t, v);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = load1<DT>(p, e + k);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) key[k] = ukey(v[k]);
+}
+
+__device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// runtime-dtype 8-wide access for x / mask / y (16-byte accesses when `vec`)
+__device__ __forceinline__ void load8_any(const void* p, int dt, int64_t e, bool vec, float (&v)[8]) {
+  if (vec && dt == DMXQ_F32) {
+    const f32x4 a = *(const f32x4*)((const float*)p + e), b = *(const f32x4*)((const float*)p + e + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else if (vec && dt == DMXQ_BF16) {
+    widen<DMXQ_BF16, 8>(*(const u32x4*)((const uint16_t*)p + e), v);
+  } else if (vec) {
+    widen<DMXQ_F16, 8>(*(const u32x4*)((const uint16_t*)p + e), v);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = load_rt(p, dt, e + k);
+  }
+}
+__device__ __forceinline__ void store8_any(void* p, int dt, int64_t e, bool vec, const float (&v)[8]) {
+  if (vec && dt == DMXQ_F32) store_vec<DMXQ_F32, 8>(p, e, v);
+  else if (vec && dt == DMXQ_BF16) store_vec<DMXQ_BF16, 8>(p, e, v);
+  else if (vec) store_vec<DMXQ_F16, 8>(p, e, v);
+  else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) store_rt(p, dt, e + k, v[k]);
+  }
+}
+
 __global__ void topk_init_kernel(TopkWs ws, int64_t n_zero) {
   if (threadIdx.x == 0) *ws.st = TopkState{0u, 0u, n_zero - 1, 0, 0};
-  ws.hist[threadIdx.x] = 0u;
+  for (int i = threadIdx.x; i < kTopkBins; i += blockDim.x) ws.hist[i] = 0u;
 }
 
-// level 0..3: histogram of byte (3 - level) of the keys whose higher bytes equal st->prefix
-__global__ __launch_bounds__(kThreads) void topk_hist_kernel(const void* __restrict__ score, int dt, int64_t n, int level,
+// level 0..2: histogram of this level's digit over the keys whose higher digits equal st->prefix.  The scores of real
+// tensors crowd into a few exponent values (11-bit digits split them by the top mantissa bits), and the workgroup
+// additionally keeps kHistCopies copies of the histogram in LDS, lane -> copy, to spread same-address atomics; they are
+// summed when the workgroup flushes.  (A 13-bit first digit in 32 KiB of LDS measured slower: 148 vs 120 us.)
+constexpr int kHistCopies = 4;
+template <int DT>
+__global__ __launch_bounds__(kThreads) void topk_hist_kernel(const void* __restrict__ score, int64_t n, int level, int vec,
                                                             TopkWs ws) {
-  __shared__ uint32_t h[256];
-  h[threadIdx.x] = 0u;
+  __shared__ uint32_t h[kHistCopies][kTopkBins];
+  for (int i = threadIdx.x; i < kHistCopies * kTopkBins; i += kThreads) (&h[0][0])[i] = 0u;
   __syncthreads();
   const uint32_t prefix = ws.st->prefix;
-  const int shift = 24 - 8 * level;
+  const int shift = topk_shift(level), above = shift + topk_bits(level);  // bits above this digit are fixed by `prefix`
+  const uint32_t dmask = (1u << topk_bits(level)) - 1u;
+  uint32_t* mine = h[threadIdx.x & (kHistCopies - 1)];
+  const int64_t n8 = n / 8;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t e0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; e0 < n; e0 += 4 * stride) {
-    float v[4];
+  for (int64_t u = (int64_t)blockIdx.x * kThreads + threadIdx.x; u < n8; u += stride) {
+    uint32_t key[8];
+    load8_keys<DT>(score, u * 8, vec != 0, key);
 #pragma unroll
-    for (int u = 0; u < 4; u++) v[u] = load_rt(score, dt, e0 + u * stride < n ? e0 + u * stride : e0);  // 4 loads in flight
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const uint32_t k = ukey(v[u]);
-      if (e0 + u * stride < n && (level == 0 || (k >> (shift + 8)) == prefix)) atomicAdd(&h[(k >> shift) & 255u], 1u);
-    }
+    for (int k = 0; k < 8; k++)
+      if (level == 0 || (key[k] >> above) == prefix) atomicAdd(&mine[(key[k] >> shift) & dmask], 1u);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n8 * 8)) {  // tail
+    const uint32_t k = ukey(load1<DT>(score, n8 * 8 + threadIdx.x));
+    if (level == 0 || (k >> above) == prefix) atomicAdd(&mine[(k >> shift) & dmask], 1u);
   }
   __syncthreads();
-  if (h[threadIdx.x]) atomicAdd(&ws.hist[threadIdx.x], h[threadIdx.x]);
+  for (int b = threadIdx.x; b < kTopkBins; b += kThreads) {
+    uint32_t sum = 0u;
+#pragma unroll
+    for (int c = 0; c < kHistCopies; c++) sum += h[c][b];
+    if (sum) atomicAdd(&ws.hist[b], sum);
+  }
 }
 
-// one workgroup of 256: pick the bucket that holds rank, descend
+// one workgroup of 256 threads, 8 bins each: pick the bin that holds `rank`, descend
 __global__ void topk_select_kernel(TopkWs ws, int level) {
-  __shared__ int64_t cum[256];
+  constexpr int PER = kTopkBins / 256;
+  __shared__ int64_t tsum[256];
   const int t = threadIdx.x;
-  cum[t] = ws.hist[t];
+  uint32_t c[PER];
+  int64_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < PER; k++) { c[k] = ws.hist[t * PER + k]; mine += c[k]; }
+  tsum[t] = mine;
   __syncthreads();
   if (t == 0) {
     int64_t run = 0;
-    for (int b = 0; b < 256; b++) { const int64_t c = cum[b]; cum[b] = run; run += c; }  // exclusive prefix
+    for (int b = 0; b < 256; b++) { const int64_t v = tsum[b]; tsum[b] = run; run += v; }  // exclusive prefix over threads
   }
   __syncthreads();
   const int64_t rank = ws.st->rank;
-  const int64_t mine = cum[t], cnt = ws.hist[t];
+  int64_t below = tsum[t];
   __syncthreads();
-  if (cnt > 0 && rank >= mine && rank < mine + cnt) {
-    ws.st->prefix = (ws.st->prefix << 8) | (uint32_t)t;
-    ws.st->rank = rank - mine;
-    ws.st->less += mine;
-    if (level == 3) ws.st->count_eq = cnt;
+  if (mine > 0 && rank >= below && rank < below + mine) {
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      if (rank >= below && rank < below + c[k]) {
+        ws.st->prefix = (ws.st->prefix << topk_bits(level)) | (uint32_t)(t * PER + k);
+        ws.st->rank = rank - below;
+        ws.st->less += below;
+        if (level == kTopkLevels - 1) ws.st->count_eq = c[k];
+      }
+      below += c[k];
+    }
   }
-  ws.hist[t] = 0u;
+#pragma unroll
+  for (int k = 0; k < PER; k++) ws.hist[t * PER + k] = 0u;
 }
 
 // number of keys equal to T in every chunk (skipped when all ties are zeroed anyway)
-__global__ __launch_bounds__(kThreads) void topk_tie_count_kernel(const void* __restrict__ score, int dt, int64_t n,
+template <int DT>
+__global__ __launch_bounds__(kThreads) void topk_tie_count_kernel(const void* __restrict__ score, int64_t n, int vec,
                                                                  int64_t n_zero, TopkWs ws) {
   const TopkState st = *ws.st;
   if (n_zero - st.less >= st.count_eq) return;
@@ -104,9 +180,16 @@ __global__ __launch_bounds__(kThreads) void topk_tie_count_kernel(const void* __
   for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const int64_t e0 = c * kTopkChunk + (int64_t)threadIdx.x * 8;
     int cnt = 0;
+    if (e0 + 8 <= n) {
+      uint32_t key[8];
+      load8_keys<DT>(score, e0, vec != 0, key);
 #pragma unroll
-    for (int k = 0; k < 8; k++)
-      if (e0 + k < n) cnt += ukey(load_rt(score, dt, e0 + k)) == T ? 1 : 0;
+      for (int k = 0; k < 8; k++) cnt += key[k] == T ? 1 : 0;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (e0 + k < n) cnt += ukey(load1<DT>(score, e0 + k)) == T ? 1 : 0;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     __syncthreads();
@@ -147,7 +230,8 @@ __global__ __launch_bounds__(kThreads) void topk_scan_kernel(int64_t n_chunks, i
   }
 }
 
-__global__ __launch_bounds__(kThreads) void topk_apply_kernel(const void* __restrict__ score, int dts,
+template <int DT>
+__global__ __launch_bounds__(kThreads) void topk_apply_kernel(const void* __restrict__ score, int vec,
                                                              const void* __restrict__ x, int dtx, void* __restrict__ mask,
                                                              int dtm, void* __restrict__ y, int dty, int64_t n,
                                                              int64_t n_zero, TopkWs ws) {
@@ -162,11 +246,14 @@ __global__ __launch_bounds__(kThreads) void topk_apply_kernel(const void* __rest
     const int64_t e0 = c * kTopkChunk + (int64_t)threadIdx.x * 8;
     uint32_t key[8];
     int cnt = 0;
+    if (e0 + 8 <= n) {
+      load8_keys<DT>(score, e0, vec != 0, key);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      key[k] = e0 + k < n ? ukey(load_rt(score, dts, e0 + k)) : 0xFFFFFFFFu;
-      cnt += (e0 + k < n && key[k] == T) ? 1 : 0;
+      for (int k = 0; k < 8; k++) key[k] = e0 + k < n ? ukey(load1<DT>(score, e0 + k)) : 0xFFFFFFFFu;
     }
+#pragma unroll
+    for (int k = 0; k < 8; k++) cnt += (e0 + k < n && key[k] == T) ? 1 : 0;
     int64_t before = 0;  // ties with a lower index than this thread's first element
     if (scan) {
       int incl = cnt;    // inclusive scan over the lanes of the wave, then over the waves
@@ -179,16 +266,31 @@ __global__ __launch_bounds__(kThreads) void topk_apply_kernel(const void* __rest
       for (int i = 0; i < wv; i++) wbase += part[i];
       before = ws.chunks[c] + wbase + (incl - cnt);
     }
+    float mk[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      const int64_t e = e0 + k;
-      if (e < n) {
-        bool keep = key[k] > T;
-        if (key[k] == T) { keep = scan ? before >= r_eq : false; before += 1; }
-        if (n_zero <= 0) keep = true;
-        const float mk = keep ? 1.0f : 0.0f;
-        if (mask) store_rt(mask, dtm, e, mk);
-        if (y) store_rt(y, dty, e, load_rt(x, dtx, e) * mk);
+      bool keep = key[k] > T;
+      if (key[k] == T) { keep = scan ? before >= r_eq : false; before += 1; }
+      if (n_zero <= 0) keep = true;
+      mk[k] = keep ? 1.0f : 0.0f;
+    }
+    if (e0 + 8 <= n) {  // whole 8-element unit: 16-byte accesses where the bases allow them
+      if (mask) store8_any(mask, dtm, e0, al16(mask), mk);
+      if (y) {
+        float xv[8], yv[8];
+        load8_any(x, dtx, e0, al16(x), xv);
+#pragma unroll
+        for (int k = 0; k < 8; k++) yv[k] = xv[k] * mk[k];
+        store8_any(y, dty, e0, al16(y), yv);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int64_t e = e0 + k;
+        if (e < n) {
+          if (mask) store_rt(mask, dtm, e, mk[k]);
+          if (y) store_rt(y, dty, e, load_rt(x, dtx, e) * mk[k]);
+        }
       }
     }
   }
@@ -200,7 +302,7 @@ using namespace dmxq;
 
 extern "C" int64_t dmxq_topk_workspace_bytes(int64_t n) {
   const int64_t chunks = n > 0 ? (n + kTopkChunk - 1) / kTopkChunk : 0;
-  return 64 + 1024 + 8 * chunks;
+  return 64 + 4 * kTopkBins + 8 * chunks;
 }
 
 extern "C" int dmxq_topk_mask(const void* score, int dtype_score, const void* x, int dtype_x, void* mask_out,
@@ -215,17 +317,26 @@ extern "C" int dmxq_topk_mask(const void* score, int dtype_score, const void* x,
   hipStream_t s = (hipStream_t)stream;
   const TopkWs ws = topk_ws(workspace);
   const int64_t n_chunks = (n + kTopkChunk - 1) / kTopkChunk;
-  const int grid = grid_for(n), cgrid = (int)(n_chunks < kMaxBlocks ? n_chunks : kMaxBlocks);
+  const int cgrid = (int)(n_chunks < kMaxBlocks ? n_chunks : kMaxBlocks);
+  const int vec = aligned16(score) ? 1 : 0;
+  const int hgrid = grid_for((n + 7) / 8);
   hipLaunchKernelGGL(topk_init_kernel, dim3(1), dim3(256), 0, s, ws, n_zero > 0 ? n_zero : 1);
-  if (n_zero > 0) {
-    for (int level = 0; level < 4; level++) {
-      hipLaunchKernelGGL(topk_hist_kernel, dim3(grid), dim3(kThreads), 0, s, score, dtype_score, n, level, ws);
-      hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(256), 0, s, ws, level);
-    }
-    hipLaunchKernelGGL(topk_tie_count_kernel, dim3(cgrid), dim3(kThreads), 0, s, score, dtype_score, n, n_zero, ws);
-    hipLaunchKernelGGL(topk_scan_kernel, dim3(1), dim3(kThreads), 0, s, n_chunks, n_zero, ws);
-  }
-  hipLaunchKernelGGL(topk_apply_kernel, dim3(cgrid), dim3(kThreads), 0, s, score, dtype_score, x, dtype_x, mask_out,
-                     dtype_mask, y_out, dtype_y, n, n_zero, ws);
+#define DMXQ_TOPK(D_)                                                                                                  \
+  do {                                                                                                                 \
+    if (n_zero > 0) {                                                                                                  \
+      for (int level = 0; level < kTopkLevels; level++) {                                                              \
+        hipLaunchKernelGGL(topk_hist_kernel<D_>, dim3(hgrid), dim3(kThreads), 0, s, score, n, level, vec, ws);         \
+        hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(256), 0, s, ws, level);                                   \
+      }                                                                                                                \
+      hipLaunchKernelGGL(topk_tie_count_kernel<D_>, dim3(cgrid), dim3(kThreads), 0, s, score, n, vec, n_zero, ws);     \
+      hipLaunchKernelGGL(topk_scan_kernel, dim3(1), dim3(kThreads), 0, s, n_chunks, n_zero, ws);                       \
+    }                                                                                                                  \
+    hipLaunchKernelGGL(topk_apply_kernel<D_>, dim3(cgrid), dim3(kThreads), 0, s, score, vec, x, dtype_x, mask_out,     \
+                       dtype_mask, y_out, dtype_y, n, n_zero, ws);                                                     \
+  } while (0)
+  if (dtype_score == DMXQ_F32) DMXQ_TOPK(DMXQ_F32);
+  else if (dtype_score == DMXQ_F16) DMXQ_TOPK(DMXQ_F16);
+  else DMXQ_TOPK(DMXQ_BF16);
+#undef DMXQ_TOPK
   return launch_status();
 }

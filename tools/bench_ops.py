@@ -129,7 +129,7 @@ def main():
     run("weight_hypernet dense + SmoothQuant scale + BFP16_64, bf16 -> bf16",
         lambda i: L.dmxq_weight_hypernet(vp(xs[i].data_ptr()), _lib.BF16, None, 0, 0, 0, vp(sq.data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, R, C, 64, 8, 1, sp), k, n * 4)
     ws = torch.empty(L.dmxq_topk_workspace_bytes(n) // 8 + 1, dtype=torch.int64, device=dev)
-    run("topk_sparsify TOPK{0.5} fp32 score, bf16 x -> bf16 y (radix select + apply; 5 score reads)",
+    run("topk_sparsify TOPK{0.5} fp32 score, bf16 x -> bf16 y (radix select + apply; 4 score reads)",
         lambda i: L.dmxq_topk_mask(vp(ss[i % k2].data_ptr()), _lib.F32, vp(xs[i].data_ptr()), _lib.BF16, None, 0, vp(ys[i].data_ptr()), _lib.BF16, n, n // 2, vp(ws.data_ptr()), sp), k2, n * 8)
     # ---------------------------------------------------------------- composite block formats, packed BFP
     run("sbfp_qdq bf16 SBFP12_16 (XP[4,0] codes, FP[0|4|4,7] scaler) [weight storage rule]",
