@@ -6,7 +6,6 @@ affine] -> shortcut restore -> inverse shaping -> `.to(physical_dtype)`), but th
 (`.float()`, `x/sc + zp`, the format cast, `(x - zp)*sc`, the final narrowing) is ONE kernel launch with the
 input and output in the tensor's own dtype, instead of 5-7 elementwise ATen passes around a chunked native call.
 """
-import math
 import warnings
 from typing import Dict, Optional, Union
 
@@ -15,7 +14,7 @@ from torch.autograd import Function
 
 from . import ops
 from ._flags import HostFlags
-from .format import BlockFloatingPoint, FixedPoint, Format, Same
+from .format import FixedPoint, Format, Same
 from .observer import _PER_CHANNEL, DummyObserver, HistogramObserver, MinMaxObserver, ObserverBase
 
 __all__ = ["CastToFormat", "CastTo", "CastToDict"]

@@ -12,7 +12,9 @@ Order of operations reproduced (core.py:178-264):
 """
 import re
 from collections import OrderedDict
-from typing import Optional
+from contextlib import contextmanager
+from dataclasses import dataclass
+from typing import Any, Dict, Optional
 
 import torch
 import torch.nn.functional as F
@@ -21,12 +23,10 @@ from .approximate import Approximate, NoApproximation
 from .cast import CastTo, CastToDict
 from .format import Same
 from .smoothquant import ActivationWeightSmoothQuant
-from contextlib import contextmanager
-from dataclasses import dataclass
-from typing import Any, Dict, Optional as _Opt
 from .sparse import Dense, Sparsify
 
-__all__ = ["DmxModule", "Linear", "Conv1d", "Conv2d", "ResAdd", "ActActMatMul", "Softmax", "LayerNorm", "GELU", "ReLU",
+__all__ = ["DmxModule", "DmxQuantizerCalibrationHyperparams", "DmxModuleQuantizerCalibrationHyperparams",
+           "DmxModuleSmoothQuantHyperparams", "Linear", "Conv1d", "Conv2d", "ResAdd", "ActActMatMul", "Softmax", "LayerNorm", "GELU", "ReLU",
            "MaxPool2d", "AvgPool2d", "Embedding", "DmxConfigRule", "configure_model"]
 
 
@@ -47,8 +47,8 @@ class DmxQuantizerCalibrationHyperparams:
     """advanced_recipe.py:42-51: how one CastTo is calibrated."""
     observer_cls: Any = None
     qscheme_to_overload: Any = torch.per_tensor_symmetric
-    group_size: _Opt[int] = None
-    ch_axis: _Opt[int] = None
+    group_size: Optional[int] = None
+    ch_axis: Optional[int] = None
 
     def __post_init__(self):
         if self.observer_cls is None:
@@ -59,10 +59,10 @@ class DmxQuantizerCalibrationHyperparams:
 @dataclass
 class DmxModuleQuantizerCalibrationHyperparams:
     """advanced_recipe.py:54-63"""
-    inputs: _Opt[Dict[str, DmxQuantizerCalibrationHyperparams]] = None
-    outputs: _Opt[Dict[str, DmxQuantizerCalibrationHyperparams]] = None
-    weight: _Opt[DmxQuantizerCalibrationHyperparams] = None
-    weight_storage: _Opt[DmxQuantizerCalibrationHyperparams] = None
+    inputs: Optional[Dict[str, DmxQuantizerCalibrationHyperparams]] = None
+    outputs: Optional[Dict[str, DmxQuantizerCalibrationHyperparams]] = None
+    weight: Optional[DmxQuantizerCalibrationHyperparams] = None
+    weight_storage: Optional[DmxQuantizerCalibrationHyperparams] = None
 
 
 @dataclass
