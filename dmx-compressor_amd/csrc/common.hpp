@@ -311,6 +311,21 @@ inline int grid_for(int64_t work_items_of_one_thread) {
   return (int)b;
 }
 
+// n / d for n < 2^31 and a launch-invariant d < 2^31 as one multiply-high and a shift (magic number from the host):
+// M = ceil(2^(31+l) / d), l = ceil(log2 d); q = umulhi(n, M) >> (l - 1); d = 1 is the identity.  (A 32-bit division by
+// a runtime value is ~28 VALU instructions, and the walker below needs three per lane-vector.)
+struct FastDiv31 {
+  uint32_t M, sh, d;
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return d == 1u ? n : __umulhi(n, M) >> sh; }
+};
+inline FastDiv31 make_fastdiv31(int64_t d64) {
+  const uint32_t d = d64 < 1 ? 1u : (d64 > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t)d64);
+  if (d == 1u) return FastDiv31{0u, 0u, 1u};
+  int l = 0;
+  while (((uint64_t)1 << l) < d) l++;
+  return FastDiv31{(uint32_t)((((uint64_t)1 << (31 + l)) + d - 1) / d), (uint32_t)(l - 1), d};
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? DMXQ_OK : DMXQ_ERR_LAUNCH; }
 
 inline bool valid_dtype(int d) { return d == DMXQ_F32 || d == DMXQ_F16 || d == DMXQ_BF16; }

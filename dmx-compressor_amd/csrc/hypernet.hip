@@ -45,6 +45,8 @@ struct HnArgs {
   const void* w; const void* score; const float* scale; void* out;
   int64_t n_units, L;
   int K, lpb, wl, asym;
+  int small;        // n < 2^31: the column of a unit by magic-number division (common.hpp FastDiv31)
+  FastDiv31 f_L;
 };
 
 // DTW weight dtype, DTS score dtype (ignored when M == 0), DTO output dtype, M = 0 (no mask) / 2 / 4 / 8
@@ -53,14 +55,35 @@ __global__ __launch_bounds__(kThreads) void hypernet_rows_kernel(HnArgs a) {
   // T1: dtype after the mask multiply = torch promotion of (w, score); without a mask it stays the weight dtype
   constexpr int T1 = (M == 0) ? DTW : ((DTW == DMXQ_F32 || DTS == DMXQ_F32 || DTW != DTS) ? DMXQ_F32 : DTW);
   const int lpb = __builtin_amdgcn_readfirstlane(a.lpb);
+  constexpr int UN = 4;  // units in flight per lane: all their loads are issued before the first one is ranked
   const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t u = (int64_t)blockIdx.x * kThreads + threadIdx.x; u < a.n_units; u += stride) {
+  for (int64_t u0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; u0 < a.n_units; u0 += UN * stride) {
+    float xa[UN][8], sa[M != 0 ? UN : 1][8], sva[HAS_SCALE ? UN : 1][8];
+#pragma unroll
+    for (int r = 0; r < UN; r++) {
+      const int64_t uc = u0 + r * stride < a.n_units ? u0 + r * stride : u0;  // clamped: unconditional loads
+      load8<DTW>(a.w, uc * 8, xa[r]);
+      if (M != 0) load8<DTS>(a.score, uc * 8, sa[M != 0 ? r : 0]);
+      if (HAS_SCALE) {
+        const int64_t ec = uc * 8;
+        const int64_t c0 = a.small ? (int64_t)((uint32_t)ec - a.f_L.div((uint32_t)ec) * (uint32_t)a.L) : ec % a.L;
+        const f32x4 s0 = *(const f32x4*)(a.scale + c0), s1 = *(const f32x4*)(a.scale + c0 + 4);
+        sva[r][0] = s0.x; sva[r][1] = s0.y; sva[r][2] = s0.z; sva[r][3] = s0.w;
+        sva[r][4] = s1.x; sva[r][5] = s1.y; sva[r][6] = s1.z; sva[r][7] = s1.w;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < UN; r++) {
+    const int64_t u = u0 + r * stride;
+    if (u >= a.n_units) break;
     const int64_t e0 = u * 8;
     float x[8];
-    load8<DTW>(a.w, e0, x);
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = xa[r][k];
     if (M != 0) {
       float s[8];
-      load8<DTS>(a.score, e0, s);
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = sa[M != 0 ? r : 0][k];
 #pragma unroll
       for (int g = 0; g < 8; g += (M ? M : 8)) {
         int32_t key[M ? M : 1];
@@ -80,11 +103,8 @@ __global__ __launch_bounds__(kThreads) void hypernet_rows_kernel(HnArgs a) {
       }
     }
     if (HAS_SCALE) {
-      const int64_t c0 = e0 % a.L;
-      const f32x4 s0 = *(const f32x4*)(a.scale + c0), s1 = *(const f32x4*)(a.scale + c0 + 4);
-      const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
-      for (int k = 0; k < 8; k++) x[k] = round_to<T1>(x[k] * sv[k]);
+      for (int k = 0; k < 8; k++) x[k] = round_to<T1>(x[k] * sva[HAS_SCALE ? r : 0][k]);
     }
     uint32_t mb = 0u;
 #pragma unroll
@@ -108,13 +128,14 @@ __global__ __launch_bounds__(kThreads) void hypernet_rows_kernel(HnArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) y[k] = round_to<T1>(y[k]);   // CastTo's `.to(physical_dtype)`, then the caller's dtype
-    store_vec<DTO, 8, false>(a.out, e0, y);
+    store_vec<DTO, 8, true>(a.out, e0, y);
+    }
   }
 }
 
 template <int DTW, int DTS, int DTO>
 static int launch_hn(const HnArgs& a, int M, bool has_scale, hipStream_t s) {
-  const int grid = grid_for(a.n_units);
+  const int grid = grid_for((a.n_units + 3) / 4);
 #define DMXQ_HN(M_, S_) hipLaunchKernelGGL((hypernet_rows_kernel<DTW, DTS, DTO, M_, S_>), dim3(grid), dim3(kThreads), 0, s, a)
   if (has_scale) { switch (M) { case 0: DMXQ_HN(0, true); break; case 2: DMXQ_HN(2, true); break; case 4: DMXQ_HN(4, true); break; default: DMXQ_HN(8, true); } }
   else { switch (M) { case 0: DMXQ_HN(0, false); break; case 2: DMXQ_HN(2, false); break; case 4: DMXQ_HN(4, false); break; default: DMXQ_HN(8, false); } }
@@ -139,7 +160,8 @@ extern "C" int dmxq_weight_hypernet(const void* w, int dtype_w, const void* scor
   if (rows * L == 0) return DMXQ_OK;
   if (!w || !out || !aligned16(w) || !aligned16(out) || (score && !aligned16(score)) || (sq_scale && !aligned16(sq_scale)))
     return w && out ? DMXQ_ERR_UNSUPPORTED : DMXQ_ERR_BAD_ARG;
-  const HnArgs a{w, score, sq_scale, out, rows * L / 8, L, K, (int)(B / 8), precision, symmetric ? 0 : 1};
+  const HnArgs a{w, score, sq_scale, out, rows * L / 8, L, K, (int)(B / 8), precision, symmetric ? 0 : 1,
+                 rows * L < ((int64_t)1 << 31) ? 1 : 0, make_fastdiv31(L)};
   hipStream_t s = (hipStream_t)stream;
   const int ds = M ? dtype_score : dtype_w;
 #define DMXQ_DT(W_, S_, O_) \
