@@ -160,6 +160,28 @@ struct FixedOp {
     }
     y = q(x, sc, z, e);
   }
+  // lastdim_kernel interface (per-channel along the contiguous dim): the N channels of a lane stay in registers
+  template <int N> struct ChanParams { float sc[N], z[N]; };
+  template <int N>
+  __device__ __forceinline__ ChanParams<N> load_params(int64_t c0) const {
+    ChanParams<N> p;
+#pragma unroll
+    for (int k = 0; k < N; k += 4) {
+      const f32x4 t = *(const f32x4*)(scale + c0 + k);
+      p.sc[k] = t.x; p.sc[k + 1] = t.y; p.sc[k + 2] = t.z; p.sc[k + 3] = t.w;
+    }
+#pragma unroll
+    for (int k = 0; k < N; k += 2) {
+      const i64x2 t = *(const i64x2*)(zp + c0 + k);
+      p.z[k] = (float)t.x; p.z[k + 1] = (float)t.y;
+    }
+    return p;
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_chan(const float (&x)[N], const ChanParams<N>& p, float (&y)[N], int64_t e0) const {
+#pragma unroll
+    for (int k = 0; k < N; k++) y[k] = q(x[k], p.sc[k], p.z[k], e0 + k);
+  }
   // the vector's (scale, zero point) when it has a single one: fetched ahead of the arithmetic (stream.hpp OpPrep)
   struct Prep { float sc, z; };
   __device__ __forceinline__ Prep prepare(int64_t e0) const {
@@ -225,6 +247,22 @@ struct ScaleOp {
     it.start(cm, e);
     const float s = scale[it.g];
     y = DIVIDE ? x / s : x * s;
+  }
+  template <int N> struct ChanParams { float s[N]; };
+  template <int N>
+  __device__ __forceinline__ ChanParams<N> load_params(int64_t c0) const {
+    ChanParams<N> p;
+#pragma unroll
+    for (int k = 0; k < N; k += 4) {
+      const f32x4 t = *(const f32x4*)(scale + c0 + k);
+      p.s[k] = t.x; p.s[k + 1] = t.y; p.s[k + 2] = t.z; p.s[k + 3] = t.w;
+    }
+    return p;
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_chan(const float (&x)[N], const ChanParams<N>& p, float (&y)[N], int64_t) const {
+#pragma unroll
+    for (int k = 0; k < N; k++) y[k] = DIVIDE ? x[k] / p.s[k] : x[k] * p.s[k];
   }
   struct Prep { float s; };
   __device__ __forceinline__ Prep prepare(int64_t e0) const {
@@ -325,6 +363,70 @@ struct BernoulliOp {
   }
 };
 
+// Per-channel parameters along the CONTIGUOUS dim (activations per hidden channel, SmoothQuant's input / weight
+// scaling): a lane keeps the parameters of its EPL channels in registers and walks down the rows, instead of
+// re-reading the scale / zero-point tables (12 B per element, 3x the data itself) for every lane-vector.
+// Layout: lpr = min(cv, 256) lanes per row (cv = C / EPL vectors per row), rpp = 256 / lpr rows side by side in a
+// workgroup, column strips of 256 vectors (grid.y) when rows are longer; RPI row groups in flight per iteration.
+template <int DTI, int DTO, class OP>
+__global__ __launch_bounds__(kThreads) void lastdim_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t rows,
+                                                          int64_t C, int cv, int lpr, int rpp, OP op) {
+  constexpr int EPL = 16 / Elem<DTI>::bytes, OVB = EPL * Elem<DTO>::bytes, RPI = 4;
+  const int t = threadIdx.x;
+  const int sub = t / lpr, sl = t - sub * lpr;
+  const int cb = blockIdx.y * lpr + sl;
+  const bool active = sub < rpp && cb < cv;
+  const int cbc = cb < cv ? cb : cv - 1;
+  const auto p = op.template load_params<EPL>((int64_t)cbc * EPL);
+  const int subc = sub < rpp ? sub : rpp - 1;
+  const int64_t step = (int64_t)gridDim.x * rpp * RPI;
+  for (int64_t r0 = (int64_t)blockIdx.x * rpp * RPI; r0 < rows; r0 += step) {
+    u32x4 raw[RPI];
+#pragma unroll
+    for (int j = 0; j < RPI; j++) {
+      const int64_t r = r0 + (int64_t)j * rpp + subc;
+      raw[j] = load_raw16<true>(in, ((r < rows ? r : rows - 1) * cv + cbc) * 16);  // clamped: unconditional loads
+    }
+#pragma unroll
+    for (int j = 0; j < RPI; j++) {
+      const int64_t r = r0 + (int64_t)j * rpp + sub;
+      if (active && r < rows) {
+        float x[EPL], y[EPL];
+        widen<DTI, EPL>(raw[j], x);
+        op.apply_chan(x, p, y, r * C + (int64_t)cb * EPL);
+        store_out<DTO, EPL, true>((char*)out + (r * cv + cb) * OVB, pack_vec<DTO, EPL>(y));
+      }
+    }
+  }
+}
+
+// DMXQ_ERR_UNSUPPORTED: not applicable (caller keeps the streaming kernel)
+template <class OP>
+static int launch_lastdim(const void* in, void* out, int dti, int dto, int64_t rows, int64_t C, const OP& op, hipStream_t s) {
+  const int epl = dti == DMXQ_F32 ? 4 : 8;
+  if (C % epl != 0 || !aligned16(in) || !aligned16(out) || C / epl > 0x7FFFFFFF || rows < 1) return DMXQ_ERR_UNSUPPORTED;
+  const int cv = (int)(C / epl), lpr = cv < kThreads ? cv : kThreads, rpp = kThreads / lpr;
+  const int strips = (cv + lpr - 1) / lpr;
+  int64_t gx = (rows + (int64_t)rpp * 4 - 1) / ((int64_t)rpp * 4);
+  const int64_t cap = (2048 + strips - 1) / strips;
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  if (strips > 65535) return DMXQ_ERR_UNSUPPORTED;
+#define DMXQ_LD(I_, O_)                                                                                               \
+  if (dti == I_ && dto == O_) {                                                                                       \
+    hipLaunchKernelGGL((lastdim_kernel<I_, O_, OP>), dim3((unsigned)gx, (unsigned)strips), dim3(kThreads), 0, s, in, out, \
+                       rows, C, cv, lpr, rpp, op);                                                                    \
+    return launch_status();                                                                                           \
+  }
+  DMXQ_LD(DMXQ_BF16, DMXQ_BF16)
+  DMXQ_LD(DMXQ_F16, DMXQ_F16)
+  DMXQ_LD(DMXQ_F32, DMXQ_F32)
+  DMXQ_LD(DMXQ_BF16, DMXQ_F32)
+  DMXQ_LD(DMXQ_F16, DMXQ_F32)
+#undef DMXQ_LD
+  return DMXQ_ERR_UNSUPPORTED;
+}
+
 static inline ChannelMap make_channel_map(int64_t C, int64_t inner, int64_t group_size, int64_t n) {
   const int64_t c = C < 1 ? 1 : C, in = inner < 1 ? 1 : inner;
   const int small = (n < (int64_t)1 << 31 && c < (int64_t)1 << 31 && in < (int64_t)1 << 31) ? 1 : 0;
@@ -371,6 +473,11 @@ extern "C" int dmxq_fixed_qdq(const void* in, void* out, int dtype_in, int dtype
   const int mode = scale ? pick_mode(C, inner, group_size, dtype_in == DMXQ_F32 ? 4 : 8, scale, zero_point) : kNone;
   const float* sc_ = scale;
   const int64_t* zp_ = zero_point;
+  if (mode == kLast) {  // per-channel along the contiguous dim: parameters in registers (lastdim_kernel)
+    const int rc = simple ? launch_lastdim(in, out, dtype_in, dtype_out, outer, C, FixedOp<kLast, true>{f, cm, sc_, zp_}, s)
+                          : launch_lastdim(in, out, dtype_in, dtype_out, outer, C, FixedOp<kLast, false>{f, cm, sc_, zp_}, s);
+    if (rc != DMXQ_ERR_UNSUPPORTED) return rc;
+  }
 #define DMXQ_FIX(M_, S_) return dispatch_stream(in, out, dtype_in, dtype_out, n, FixedOp<M_, S_>{f, cm, sc_, zp_}, s)
   if (simple) {
     switch (mode) {
@@ -399,6 +506,11 @@ extern "C" int dmxq_scale_channels(const void* in, void* out, int dtype_in, int 
   const ChannelMap cm = make_channel_map(C, inner, 1, n);
   hipStream_t s = (hipStream_t)stream;
   const int mode = pick_mode(C, inner, 1, dtype_in == DMXQ_F32 ? 4 : 8, scale, nullptr);
+  if (mode == kLast) {
+    const int rc = divide ? launch_lastdim(in, out, dtype_in, dtype_out, outer, C, ScaleOp<true, kLast>{cm, scale}, s)
+                          : launch_lastdim(in, out, dtype_in, dtype_out, outer, C, ScaleOp<false, kLast>{cm, scale}, s);
+    if (rc != DMXQ_ERR_UNSUPPORTED) return rc;
+  }
 #define DMXQ_SCALE(D_, M_) return dispatch_stream(in, out, dtype_in, dtype_out, n, ScaleOp<D_, M_>{cm, scale}, s)
   if (divide) {
     if (mode == kTensor || mode == kUniform) DMXQ_SCALE(true, kUniform);

@@ -181,3 +181,24 @@ def test_scale_channels(dmx, cuda):
     assert bits_equal(got, want) == 0
     got = dmx.ops.scale_channels(x.to(cuda), s, 1, divide=False, out_dtype=torch.float32)
     assert bits_equal(got, x.float() * s.view(1, 40, 1)) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_per_channel_along_the_contiguous_dim(dmx, cuda, oracle, dtype):
+    """Per-channel affine quantisation and SmoothQuant-style scaling along the LAST dim (lastdim_kernel: channel parameters
+    in registers): channel counts that give every lanes-per-row / rows-per-workgroup / column-strip layout, ragged row
+    counts, INT8 (the short form) and a fractional format (the general form)."""
+    for n, (rows, C) in enumerate([(1, 8), (5, 16), (37, 24), (33, 40), (130, 256), (7, 768), (19, 2048), (9, 2056), (3, 5120),
+                                   (1030, 64), (2, 16384)]):
+        x = make("heavy", (rows, C), seed=40 + n, dtype=dtype)
+        sc = torch.rand(C) * 0.2 + 0.01
+        zp = torch.randint(-10, 10, (C,))
+        for p, f in ((8, 0), (8, 3)):
+            got = dmx.ops.fixed_qdq(x.to(cuda), p, f, True, True, scale=sc.to(cuda), zero_point=zp.to(cuda), ch_axis=-1)
+            want = oracle.fixed_point_affine_cast(x, p, f, True, True, sc, zp, ch_axis=-1).to(dtype)
+            assert bits_equal(got, want) == 0, (rows, C, p, f)
+        for divide in (True, False):
+            out_dtype = torch.float32 if divide else dtype
+            got = dmx.ops.scale_channels(x.to(cuda), sc.to(cuda), -1, divide, out_dtype=out_dtype)
+            want = (x.float() / sc if divide else x.float() * sc).to(out_dtype)
+            assert bits_equal(got, want) == 0, (rows, C, divide)
