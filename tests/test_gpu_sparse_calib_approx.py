@@ -389,3 +389,16 @@ def test_gelu_tails_and_special_values(dmx, cuda, dtype):
         z = (xs == 0) | (xs.abs() >= 20)       # exact results incl. the sign of zero
         z &= fin
         assert torch.equal(got[z].view(torch.int32), ref[z].view(torch.int32)), approx
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_softmax_on_a_view_that_starts_mid_allocation(dmx, cuda, dtype):
+    """Rows at element alignment only (a view one element into its buffer): the unaligned-access form of the row kernel."""
+    F = torch.nn.functional
+    eps = torch.finfo(dtype).eps
+    for rows, cols in ((9, 256), (5, 1500), (3, 197), (2, 4096)):
+        base = (make("normal", (rows * cols + 1,), seed=cols, dtype=dtype) * 2)
+        xg = base.to(cuda)[1:].view(rows, cols)
+        got = dmx.ops.softmax(xg, -1).cpu().float()
+        ref = F.softmax(base[1:].view(rows, cols).float(), -1).to(dtype).float()
+        assert int(((got - ref).abs() > eps * ref.abs() + 2e-6).sum()) == 0, (rows, cols)
