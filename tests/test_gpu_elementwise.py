@@ -202,3 +202,30 @@ def test_per_channel_along_the_contiguous_dim(dmx, cuda, oracle, dtype):
             got = dmx.ops.scale_channels(x.to(cuda), sc.to(cuda), -1, divide, out_dtype=out_dtype)
             want = (x.float() / sc if divide else x.float() * sc).to(out_dtype)
             assert bits_equal(got, want) == 0, (rows, C, divide)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_affine_int_codes_at_rounding_boundaries(dmx, cuda, oracle, dtype):
+    """INT8 / INT4 affine quantisation where x / scale + zero_point sits on, or a few ulp either side of, a rounding
+    boundary k + 1/2 (and at the clamp limits), for per-tensor and per-group scales of any value: the codes depend on the
+    correctly rounded IEEE quotient there (a multiply-by-reciprocal shortcut was tried and measured slower; this test is
+    what any such shortcut has to survive)."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for p in (8, 4):
+        lim = 2 ** (p - 1)
+        for trial in range(6):
+            G = 64
+            sc = torch.from_numpy(rng.uniform(1e-3, 3.0, G).astype(np.float32))
+            if trial == 0:
+                sc[:] = torch.tensor([0.1, 1.0 / 3.0, 0.7, 1.9999999, 1e-3, 2.5e-2, 0.3, 3.0]).repeat(8)
+            zp = torch.from_numpy(rng.integers(-lim, lim, G)) if trial % 2 else torch.zeros(G, dtype=torch.int64)
+            k = torch.from_numpy(rng.integers(-lim - 2, lim + 2, (G, 512)).astype(np.float32)) + 0.5
+            x = (k - zp[:, None].float()) * sc[:, None]                     # x / sc + z ~ k + 1/2
+            bits = x.view(torch.int32) + torch.from_numpy(rng.integers(-3, 4, (G, 512)).astype(np.int32))
+            x = bits.view(torch.float32).to(dtype)
+            for mode, kw in (("group", dict(ch_axis=0, group_size=1)), ("tensor", dict())):
+                s_, z_ = (sc, zp) if mode == "group" else (sc[:1], zp[:1])
+                got = dmx.ops.fixed_qdq(x.to(cuda), p, 0, True, True, scale=s_.to(cuda), zero_point=z_.to(cuda), **kw)
+                want = oracle.fixed_point_affine_cast(x, p, 0, True, True, s_, z_, **kw).to(dtype)
+                assert bits_equal(got, want) == 0, (p, trial, mode)
