@@ -149,7 +149,9 @@ def main():
         if not args.no_graph:
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
+            # thread_local: with RCCL initialised (N > 1) its watchdog thread polls events while we capture; only calls
+            # made by THIS thread belong to the capture
+            with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
                 for i in range(args.steps):
                     launch(i % args.nbuf, sp)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
