@@ -43,7 +43,11 @@ __device__ __forceinline__ void accumulate_absmax(const u32x4& v, uint32_t (&mb)
   }
 }
 
-template <int DTI, int DTO, int RND, bool ASYM, int RPL, int RS, int FAST>
+// UNAL: rows (inner elements) that are not whole aligned 16-byte vectors -- 14x14 or 7x7 feature maps, views that start
+// mid-allocation.  Accesses are 16 bytes at element alignment (common.hpp load_raw16 / store_out UNAL), and the last,
+// partial vector of a row is replaced by the vector that ENDS at the row end: every column is its own block, so the
+// overlap with the previous lane just computes (and stores) those columns twice, with identical results.
+template <int DTI, int DTO, int RND, bool ASYM, int RPL, int RS, int FAST, bool UNAL = false>
 __global__ __launch_bounds__(kThreads) void bfp_cols_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                            int64_t outer, int64_t L, int64_t inner, int wl,
                                                            int rounding, uint64_t seed) {
@@ -56,7 +60,8 @@ __global__ __launch_bounds__(kThreads) void bfp_cols_kernel(const void* __restri
   const int lane = threadIdx.x & (kWave - 1);
   const int grp = lane / LPR, lig = lane % LPR;  // row group, lane in group
   const int64_t nblk = (L + B - 1) / B;
-  const int64_t cvec = inner / EPL;                       // 16-byte vectors per row (inner % EPL == 0)
+  const int64_t cfull = inner / EPL;                      // whole 16-byte vectors per row
+  const int64_t cvec = UNAL ? (inner + EPL - 1) / EPL : cfull;
   const int64_t ctiles = (cvec + LPR - 1) / LPR;
   const int64_t units = outer * nblk * ctiles;            // one unit = one wave's [B rows x LPR vectors] tile
   const int64_t wave_id = (int64_t)blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave;
@@ -68,7 +73,8 @@ __global__ __launch_bounds__(kThreads) void bfp_cols_kernel(const void* __restri
     const int64_t cv = ct * LPR + lig;                    // this lane's column vector
     const bool col_ok = cv < cvec;
     const int64_t row0 = blk * B + grp * RPL;             // first row of this lane's share of the block
-    const int64_t base_e = (o * L + row0) * inner + cv * EPL;
+    const int64_t ce = (UNAL && cv >= cfull) ? inner - EPL : cv * EPL;  // first column of this lane's vector
+    const int64_t base_e = (o * L + row0) * inner + ce;
     u32x4 raw[RPL];
     uint32_t mb[EPL];
 #pragma unroll
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(kThreads) void bfp_cols_kernel(const void* __restri
 #pragma unroll
     for (int r = 0; r < RPL; r++) {                        // all row loads in flight
       const bool ok = col_ok && row0 + r < L;              // ragged last block: rows beyond L count as absent
-      raw[r] = ok ? load_raw16<true>(in, (base_e + r * inner) * Elem<DTI>::bytes) : u32x4{0u, 0u, 0u, 0u};
+      raw[r] = ok ? load_raw16<true, int64_t, UNAL>(in, (base_e + r * inner) * Elem<DTI>::bytes) : u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int r = 0; r < RPL; r++) accumulate_absmax<DTI, EPL>(raw[r], mb);
@@ -89,8 +95,8 @@ __global__ __launch_bounds__(kThreads) void bfp_cols_kernel(const void* __restri
       if (kFast) all_fast = all_fast && bfp_fast_ok(m, wl);
       mfin[k] = m;
     }
-    char* const obase = (char*)out + base_e / EPL * OVB;
-    const int64_t ostride = inner / EPL * OVB;
+    char* const obase = (char*)out + base_e * Elem<DTO>::bytes;
+    const int64_t ostride = inner * Elem<DTO>::bytes;
     if (kFast && __builtin_amdgcn_ballot_w64(!all_fast) == 0ull) {  // wave-uniform
       BfpBlockParams p[EPL];
 #pragma unroll
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(kThreads) void bfp_cols_kernel(const void* __restri
         widen<DTI, EPL>(raw[r], x);
 #pragma unroll
         for (int k = 0; k < EPL; k++) y[k] = bfp_q1_fast<FAST == 2, ASYM>(x[k], p[k]);
-        if (col_ok && row0 + r < L) store_out<DTO, EPL, true>(obase + r * ostride, pack_vec<DTO, EPL>(y));
+        if (col_ok && row0 + r < L) store_out<DTO, EPL, true, UNAL>(obase + r * ostride, pack_vec<DTO, EPL>(y));
       }
     } else {
       BfpBlockParams p[EPL];
@@ -114,10 +120,10 @@ __global__ __launch_bounds__(kThreads) void bfp_cols_kernel(const void* __restri
 #pragma unroll
         for (int k = 0; k < EPL; k++) {
           // the oracle numbers random draws by position in the transposed [outer*inner, L] matrix
-          const uint64_t ridx = (uint64_t)((o * inner + cv * EPL + k) * L + row0 + r);
+          const uint64_t ridx = (uint64_t)((o * inner + ce + k) * L + row0 + r);
           y[k] = bfp_q1<RND, ASYM>(x[k], p[k], wl, rounding, rnd_if(stoch, seed, ridx));
         }
-        if (col_ok && row0 + r < L) store_out<DTO, EPL, true>(obase + r * ostride, pack_vec<DTO, EPL>(y));
+        if (col_ok && row0 + r < L) store_out<DTO, EPL, true, UNAL>(obase + r * ostride, pack_vec<DTO, EPL>(y));
       }
     }
   }
@@ -125,18 +131,24 @@ __global__ __launch_bounds__(kThreads) void bfp_cols_kernel(const void* __restri
 
 template <int DTI, int DTO, int RND, bool ASYM, int RPL, int RS>
 static int launch_cols_geom(const void* in, void* out, int64_t outer, int64_t L, int64_t inner, int wl, int rounding,
-                            uint64_t seed, hipStream_t s) {
+                            uint64_t seed, bool unal, hipStream_t s) {
   constexpr int EPL = 16 / Elem<DTI>::bytes;
   constexpr int B = RPL * RS, LPR = kWave / RS;
-  const int64_t nblk = (L + B - 1) / B, cvec = inner / EPL, ctiles = (cvec + LPR - 1) / LPR;
+  const int64_t nblk = (L + B - 1) / B, cvec = (inner + EPL - 1) / EPL, ctiles = (cvec + LPR - 1) / LPR;
   const int64_t units = outer * nblk * ctiles;
   int64_t grid = (units + 3) / 4;
   if (grid < 1) grid = 1;
   if (grid > (1 << 20)) grid = 1 << 20;
   const int fast = (RND == DMXQ_ROUND_NEAREST && wl <= 20) ? (bfp_single_rounding_ok<DTI>(wl) ? 2 : 1) : 0;
 #define DMXQ_COLS(F_)                                                                                             \
-  hipLaunchKernelGGL((bfp_cols_kernel<DTI, DTO, RND, ASYM, RPL, RS, F_>), dim3((unsigned)grid), dim3(kThreads), 0, s, \
-                     in, out, outer, L, inner, wl, rounding, seed)
+  do {                                                                                                            \
+    if (unal)                                                                                                     \
+      hipLaunchKernelGGL((bfp_cols_kernel<DTI, DTO, RND, ASYM, RPL, RS, F_, true>), dim3((unsigned)grid), dim3(kThreads), 0, \
+                         s, in, out, outer, L, inner, wl, rounding, seed);                                        \
+    else                                                                                                          \
+      hipLaunchKernelGGL((bfp_cols_kernel<DTI, DTO, RND, ASYM, RPL, RS, F_, false>), dim3((unsigned)grid), dim3(kThreads), 0, \
+                         s, in, out, outer, L, inner, wl, rounding, seed);                                        \
+  } while (0)
   // instantiate only what can run: the literal path for the runtime-rounding build; magic-add (double / single
   // rounding) for nearest-even.  (nearest with wl > 20 is routed to the runtime-rounding build by the caller.)
   constexpr bool in16 = Elem<DTI>::bytes == 2;
@@ -155,8 +167,8 @@ static int launch_cols_geom(const void* in, void* out, int64_t outer, int64_t L,
 
 template <int DTI, int DTO, int RND, bool ASYM>
 static int launch_cols(const void* in, void* out, int64_t outer, int64_t L, int64_t inner, int64_t B, int wl,
-                       int rounding, uint64_t seed, hipStream_t s) {
-#define DMXQ_G(RPL_, RS_) return launch_cols_geom<DTI, DTO, RND, ASYM, RPL_, RS_>(in, out, outer, L, inner, wl, rounding, seed, s)
+                       int rounding, uint64_t seed, bool unal, hipStream_t s) {
+#define DMXQ_G(RPL_, RS_) return launch_cols_geom<DTI, DTO, RND, ASYM, RPL_, RS_>(in, out, outer, L, inner, wl, rounding, seed, unal, s)
   switch (B) {
     case 8: DMXQ_G(8, 1);
     case 16: DMXQ_G(16, 1);
@@ -178,17 +190,25 @@ extern "C" int dmxq_internal_bfp_cols(const void* in, void* out, int dtype_in, i
                                       int64_t inner, int64_t B, int wl, int rounding, int symmetric, uint64_t seed,
                                       void* stream) {
   const int epl = dtype_in == DMXQ_F32 ? 4 : 8;
-  if (inner % epl != 0 || !aligned16(in) || !aligned16(out) || wl > 22) return DMXQ_ERR_UNSUPPORTED;
+  if (wl > 22) return DMXQ_ERR_UNSUPPORTED;
+  // rows that are whole aligned vectors: aligned form.  Anything else with at least one whole vector per row: the
+  // unaligned form -- not in place (its overlapping tail vectors may belong to different waves), and element-aligned
+  const bool unal = inner % epl != 0 || !aligned16(in) || !aligned16(out);
+  if (unal) {
+    const uintptr_t ib = dtype_in == DMXQ_F32 ? 4 : 2, ob = dtype_out == DMXQ_F32 ? 4 : 2;
+    if (inner < epl || in == out || (reinterpret_cast<uintptr_t>(in) & (ib - 1)) || (reinterpret_cast<uintptr_t>(out) & (ob - 1)))
+      return DMXQ_ERR_UNSUPPORTED;
+  }
   if (!(B == 8 || B == 16 || B == 32 || B == 64 || B == 128)) return DMXQ_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const bool asym = !symmetric;
 #define DMXQ_DT(I_, O_)                                                                                           \
   if (dtype_in == I_ && dtype_out == O_) {                                                                        \
     if (rounding == DMXQ_ROUND_NEAREST && wl <= 20)                                                               \
-      return asym ? launch_cols<I_, O_, DMXQ_ROUND_NEAREST, true>(in, out, outer, L, inner, B, wl, rounding, seed, s)  \
-                  : launch_cols<I_, O_, DMXQ_ROUND_NEAREST, false>(in, out, outer, L, inner, B, wl, rounding, seed, s); \
-    return asym ? launch_cols<I_, O_, kRuntimeRounding, true>(in, out, outer, L, inner, B, wl, rounding, seed, s)     \
-                : launch_cols<I_, O_, kRuntimeRounding, false>(in, out, outer, L, inner, B, wl, rounding, seed, s);   \
+      return asym ? launch_cols<I_, O_, DMXQ_ROUND_NEAREST, true>(in, out, outer, L, inner, B, wl, rounding, seed, unal, s)  \
+                  : launch_cols<I_, O_, DMXQ_ROUND_NEAREST, false>(in, out, outer, L, inner, B, wl, rounding, seed, unal, s); \
+    return asym ? launch_cols<I_, O_, kRuntimeRounding, true>(in, out, outer, L, inner, B, wl, rounding, seed, unal, s)     \
+                : launch_cols<I_, O_, kRuntimeRounding, false>(in, out, outer, L, inner, B, wl, rounding, seed, unal, s);   \
   }
   DMXQ_DT(DMXQ_BF16, DMXQ_BF16)
   DMXQ_DT(DMXQ_F16, DMXQ_F16)

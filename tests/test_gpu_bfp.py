@@ -326,3 +326,33 @@ def test_masked_attention_scores(dmx, cuda, oracle, dtype):
     w = x[0].contiguous()
     want = oracle.bfp_cast(w, 8, 64, -1, True)
     assert mismatches_nan_aware(dmx.ops.bfp_qdq(w.to(cuda), 8, 64, -1, True, out_dtype=torch.float32), want.float()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_column_blocks_on_odd_feature_maps(dmx, cuda, oracle, dtype):
+    """Blocks along the channel dim of [N, C, H, W] activations whose H*W is not a whole number of 16-byte vectors
+    (14x14, 7x7, 5x5: the unaligned form of the column kernel, whose last vector of a row ends AT the row end and
+    overlaps its neighbour), every block size of that kernel, ragged channel counts, rounding modes, a widening cast, a
+    view that starts mid-allocation, and in-place (which must still be right: it takes the generic kernel)."""
+    for n, (shape, B) in enumerate([((2, 64, 14, 14), 64), ((3, 128, 7, 7), 128), ((2, 40, 5, 5), 16), ((1, 72, 3, 3), 8),
+                                    ((2, 100, 14, 14), 32), ((4, 64, 9), 64), ((2, 256, 197), 64)]):
+        x = make("mixed", shape, seed=60 + n, dtype=dtype, block=8)
+        assert _run(dmx, cuda, oracle, x, 8, B, dim=1) == 0, (shape, B)
+        assert _run(dmx, cuda, oracle, make("mixed_nd", shape, seed=n, dtype=dtype, block=8), 4, B, dim=1, sym=False) == 0, (shape, B)
+    x = make("heavy", (2, 64, 7, 7), seed=3, dtype=dtype)
+    for rounding in ("down", "up", "stochastic"):
+        assert _run(dmx, cuda, oracle, x, 8, 64, dim=1, rounding=rounding, seed=9) == 0, rounding
+    if dtype != torch.float32:
+        assert _run(dmx, cuda, oracle, x, 8, 64, dim=1, out_dtype=torch.float32) == 0
+    flat = make("normal", (1 + 2 * 64 * 49,), seed=4, dtype=dtype).to(cuda)
+    xv = flat[1:].view(2, 64, 7, 7)
+    assert bits_equal(dmx.ops.bfp_qdq(xv, 8, 64, 1), oracle.bfp_cast(xv.cpu(), 8, 64, 1).to(dtype).contiguous()) == 0
+    # in place through the C ABI
+    import ctypes
+    from dmx_compressor_amd import _lib
+    t = x.to(cuda).contiguous()
+    vp = ctypes.c_void_p
+    code = _lib.dtype_code(dtype)
+    assert _lib.lib().dmxq_bfp_qdq(vp(t.data_ptr()), vp(t.data_ptr()), code, code, 2, 64, 49, 64, 8, 2, 1, 0,
+                                   vp(torch.cuda.current_stream().cuda_stream)) == 0
+    assert bits_equal(t, oracle.bfp_cast(x, 8, 64, 1).to(dtype).contiguous()) == 0
