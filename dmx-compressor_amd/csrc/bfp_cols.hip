@@ -217,6 +217,9 @@ extern "C" int dmxq_internal_bfp_cols(const void* in, void* out, int dtype_in, i
       return DMXQ_ERR_UNSUPPORTED;
   }
   if (!(B == 8 || B == 16 || B == 32 || B == 64 || B == 128)) return DMXQ_ERR_UNSUPPORTED;
+  // fewer rows than half a block (RGB input of a first conv layer: L = 3): there is exactly one, ragged, block per
+  // column whatever the nominal size, so run the smallest tile that still holds it instead of mostly absent rows
+  while (B > 8 && L <= B / 2) B /= 2;
   hipStream_t s = (hipStream_t)stream;
   const bool asym = !symmetric;
 #define DMXQ_DT(I_, O_)                                                                                           \
