@@ -2,26 +2,38 @@
 """bench.py — headline benchmark of BASELINE.json: Gelements/s of fused Q->DQ, BFP[8|8]{16}(SN) ("BFP16,
 group 16"), on a 4096x4096 bf16 tensor, and % of the MI355X HBM roofline.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|llama-shard] [--replays R]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N)
 
-One "step" = one pass of the hot path (`dmxq_bfp_qdq`, one kernel launch through the C ABI) over one
-4096x4096 bf16 tensor already resident in HBM.  Steps rotate over NBUF distinct input/output buffer pairs whose
-total footprint (>= 1.25 GiB) exceeds the 256 MiB Infinity Cache, so every step streams from/to HBM.
-Each rank (one process per GPU) works on its own tensors: the path shards with no data-path collective
- -> weak scaling; RCCL is used only for the barrier and the max-over-ranks of the timing.
+Workloads (one process per GPU, no data-path collective: SURVEY.md §8e)
+  c2 (default)   one "step" = one pass of the hot path (`dmxq_bfp_qdq`, ONE kernel launch through the C ABI) over this
+                 rank's [4096, 4096] row shard of a global [N*4096, 4096] bf16 tensor (parallel.row_shards), already
+                 resident in HBM.  At N = 1 that is BASELINE.json configs[1].  Per-GPU work is fixed -> "weak".
+                 Steps rotate over NBUF distinct global tensors (>= 1.25 GiB per rank > 256 MiB Infinity Cache).
+  llama-shard    one "step" = one pass over the 7 weight matrices of one Llama-3-8B decoder layer (BASELINE.json
+                 configs[3]), each ROW-SHARDED over the N ranks; total work is fixed -> "strong".  --op hypernet
+                 (default): 2:4 N:M mask -> BFP16_64 in one launch per weight (`dmxq_weight_hypernet`, the weight path of
+                 modeling/nn/core.py:178-198); --op bfp: plain BFP16_16 (`dmxq_bfp_qdq`).
+  Outside the timed region the output shards are RCCL-all_gathered once and rank 0 asserts bit-equality with its own
+  whole-tensor result (shard -> op -> concat == op on the whole).
+
+Timing: W eager warm-up steps, the K steps captured into one hipGraph, ONE untimed replay (graph upload, clocks), then R
+timed replays of the same K steps, each bracketed by barrier + synchronize on both sides; per replay the MAX over ranks;
+`ms_per_step` / `value` come from the MEDIAN replay (`config.replays`, `config.replay_ms` list them all).
 
 The JSON line carries
-  roofline     : algorithmic bytes (4 B/element: 2 read + 2 written) / average launch duration measured with
-                 HIP events on the launch stream over the timed region, vs 8.0 TB/s peak HBM.
-  cpu_baseline : the reference's own compiled CPU kernel (oracle/_ref/quant_cpu.so, built from the reference
-                 sources) driven by a restatement of the reference's Format.cast loop, timed on this box's host
-                 cores (rank 0, N = 1 only, bounded sample).  Falls back to the C oracle port if _ref is absent.
+  roofline     : algorithmic bytes per launch / average launch duration, measured with HIP events on the launch stream
+                 over the same timed replays, vs 8.0 TB/s peak HBM.  `kernel` is what the library's dispatcher reports
+                 for this call (dmxq_bfp_qdq_describe), `traffic` is labelled with its source.
+  cpu_baseline : three labelled legs on this box's host cores (rank 0, N = 1 only, bounded samples): the reference's
+                 own compiled CPU kernel (oracle/_ref/quant_cpu.so) inside a restatement of the reference's
+                 Format.cast loop ("reference"), and the C oracle port on all cores and on one thread ("port").
 """
 import argparse
 import ctypes
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,6 +46,9 @@ ROWS = COLS = 4096
 BLOCK, PRECISION = 16, 8
 PEAK_HBM = 8.0e12  # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 BYTES_PER_ELEM = 4  # bf16 in + bf16 out (CastTo contract, numerical/cast.py:262,306)
+# Llama-3-8B decoder layer (hidden 4096, 32 heads / 8 KV heads, intermediate 14336): [out_features, in_features]
+LLAMA_LAYER = [("q_proj", 4096, 4096), ("k_proj", 1024, 4096), ("v_proj", 1024, 4096), ("o_proj", 4096, 4096),
+               ("gate_proj", 14336, 4096), ("up_proj", 14336, 4096), ("down_proj", 4096, 14336)]
 
 
 def parse():
@@ -41,63 +56,195 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--nbuf", type=int, default=20, help="distinct in/out buffer pairs (20 x 64 MiB = 1.25 GiB)")
+    ap.add_argument("--workload", choices=["c2", "replica", "llama-shard"], default="c2")
+    ap.add_argument("--op", choices=["hypernet", "bfp"], default="hypernet", help="llama-shard only")
+    ap.add_argument("--replays", type=int, default=15, help="timed replays of the K-step graph (median reported)")
+    ap.add_argument("--nbuf", type=int, default=20, help="c2: distinct in/out buffer pairs (20 x 64 MiB = 1.25 GiB)")
+    ap.add_argument("--layers", type=int, default=2, help="llama-shard: distinct layer copies rotated over")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the gather + whole-tensor equality check")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--resident", action="store_true", help="also report the cache-resident (single buffer) rate")
     return ap.parse_args()
 
 
-def synth(seed, device):
+def synth(seed, rows, cols, device):
     """N(0,1) * exp(2 * N(0,1)) in bf16: per-block exponent spread, generated on the device."""
     g = torch.Generator(device=device).manual_seed(seed)
-    a = torch.randn(ROWS, COLS, generator=g, device=device)
-    b = torch.randn(ROWS, COLS, generator=g, device=device)
+    a = torch.randn(rows, cols, generator=g, device=device)
+    b = torch.randn(rows, cols, generator=g, device=device)
     return (a * torch.exp(2.0 * b)).to(torch.bfloat16)
 
 
-def cpu_baseline(seconds):
-    """Times the reference CPU path on the host cores for the same 4096x4096 bf16 workload."""
-    import numpy as np  # noqa: F401
+def _time_cpu(fn, seconds, max_n):
+    fn()  # cold call (page-in, allocator)
+    best, n, t_end = float("inf"), 0, time.perf_counter() + seconds
+    while n < 2 or (time.perf_counter() < t_end and n < max_n):
+        t0 = time.perf_counter()
+        fn()
+        best = min(best, time.perf_counter() - t0)
+        n += 1
+    return best, n
 
+
+def cpu_baseline(seconds):
+    """Times the CPU paths on the host cores for the same 4096x4096 bf16 workload (three labelled legs)."""
     x = (torch.randn(ROWS, COLS, generator=torch.Generator().manual_seed(0))).to(torch.bfloat16)
+    legs = []
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
-    kind, fn = None, None
     try:
         sys.path.insert(0, ref_dir)
         import quant_cpu  # the reference's C++ extension, compiled from its own sources by oracle/Makefile
 
-        def fn():
+        def ref_fn():
             # restatement of numerical/format.py:322-341 + cast.py:306 around the reference's native call
             xf = x.float()
             chunks = torch.split(xf.reshape(-1, COLS), BLOCK, dim=-1)
             out = torch.cat([quant_cpu.block_quantize_nearest(c.contiguous(), PRECISION, 0, True) for c in chunks], dim=-1)
             return out.reshape(ROWS, COLS).to(torch.bfloat16)
 
-        kind = "reference"
-    except Exception:
+        best, n = _time_cpu(ref_fn, seconds, 50)
+        legs.append({"kind": "reference", "value": round(ROWS * COLS / best / 1e9, 5), "unit": "Gelements/s",
+                     "cores": torch.get_num_threads(),
+                     "sample": f"{n} full passes over one 4096x4096 bf16 tensor (min {best * 1e3:.1f} ms): reference "
+                               "quant_cpu.block_quantize_nearest per [4096,16] chunk inside the reference's split/cat loop"})
+    except Exception as e:  # _ref not built (never on the GPU box: the prebuilt .so travels with the snapshot)
+        legs.append({"kind": "reference", "value": None, "error": repr(e)[:200]})
+    try:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as O
 
-        def fn():
+        gomp = ctypes.CDLL("libgomp.so.1")
+        ncores = os.cpu_count() or 1
+
+        def port_fn():
             return O.bfp_cast(x, PRECISION, BLOCK).to(torch.bfloat16)
 
-        kind = "port"
-    fn()  # cold call (page-in, allocator)
-    best, n, t_end = float("inf"), 0, time.perf_counter() + seconds
-    while n < 2 or (time.perf_counter() < t_end and n < 50):
-        t0 = time.perf_counter()
-        fn()
-        best = min(best, time.perf_counter() - t0)
-        n += 1
-    return {
-        "value": round(ROWS * COLS / best / 1e9, 5), "unit": "Gelements/s", "cores": torch.get_num_threads(),
-        "kind": kind,
-        "sample": f"{n} full passes over one 4096x4096 bf16 tensor (min time {best * 1e3:.1f} ms), "
-                  + ("reference quant_cpu.block_quantize_nearest per [4096,16] chunk inside the reference's split/cat loop"
-                     if kind == "reference" else "oracle/oracle.c OpenMP port, whole tensor"),
-    }
+        for threads, budget in ((ncores, min(4.0, seconds)), (1, min(6.0, seconds))):
+            gomp.omp_set_num_threads(threads)
+            best, n = _time_cpu(port_fn, budget, 200)
+            legs.append({"kind": "port", "value": round(ROWS * COLS / best / 1e9, 5), "unit": "Gelements/s",
+                         "cores": threads,
+                         "sample": f"{n} full passes over one 4096x4096 bf16 tensor (min {best * 1e3:.1f} ms): "
+                                   f"oracle/oracle.c whole-tensor port, OpenMP threads = {threads}"})
+        gomp.omp_set_num_threads(ncores)
+    except Exception as e:
+        legs.append({"kind": "port", "value": None, "error": repr(e)[:200]})
+    head = next((l for l in legs if l.get("value")), legs[0])
+    return {"value": head["value"], "unit": "Gelements/s", "cores": head.get("cores"), "kind": head["kind"],
+            "sample": head.get("sample"), "legs": legs}
+
+
+class Workload:
+    """What one step launches on this rank, and how to check it.  All launches go through the C ABI (include/dmxq.h)."""
+
+    def __init__(self, args, L, lib, rank, world, dev):
+        from dmx_compressor_amd import parallel
+
+        self.args, self.L, self.lib, self.rank, self.world, self.dev = args, L, lib, rank, world, dev
+        self.P = parallel
+        bf16 = lib.BF16
+        self.calls = []   # per rotation slot: list of (fn_name, tuple_of_args_without_stream)
+        self.bytes_per_step = 0
+        self.elems_per_step_rank = 0
+        if args.workload in ("c2", "replica"):
+            self.scaling = "weak"
+            self.global_rows = ROWS * world
+            self.shard = parallel.row_shards(self.global_rows, world)[rank]
+            rows = self.shard[1] - self.shard[0]
+            self.ins = [synth(1000 * rank + i, rows, COLS, dev) for i in range(args.nbuf)]
+            self.outs = [torch.empty_like(t) for t in self.ins]
+            for i in range(args.nbuf):
+                self.calls.append([("dmxq_bfp_qdq", (ctypes.c_void_p(self.ins[i].data_ptr()), ctypes.c_void_p(self.outs[i].data_ptr()),
+                                                     bf16, bf16, rows, COLS, 1, BLOCK, PRECISION, lib.ROUND_NEAREST, 1, 0))])
+            self.elems_per_step_rank = rows * COLS
+            self.bytes_per_step = BYTES_PER_ELEM * rows * COLS
+            self.launches_per_step = 1
+            self.describe_args = (bf16, bf16, rows, COLS, 1, BLOCK, PRECISION, lib.ROUND_NEAREST, 1)
+            self.name = ("BFP[8|8]{16}(SN) fused Q->DQ, 4096x4096 bf16 -> bf16 per GPU, block_dim=-1, RNE (BASELINE.json "
+                         "configs[1]); rank r owns rows [4096 r, 4096 (r+1)) of a global [N*4096, 4096] tensor")
+        else:
+            self.scaling = "strong"
+            hyper = args.op == "hypernet"
+            B = 64 if hyper else 16
+            self.layers = []
+            for c in range(args.layers):
+                layer = []
+                for t, (nm, rows, cols) in enumerate(LLAMA_LAYER):
+                    s, e = parallel.row_shards(rows, world)[rank]
+                    # every rank synthesises the SAME global tensor (seeded by copy/tensor) and keeps its rows, so the
+                    # gathered result can be compared with rank 0's whole-tensor launch
+                    w_full = synth(77 + 10 * c + t, rows, cols, dev)
+                    w = w_full[s:e].clone()
+                    sc = None
+                    if hyper:
+                        g = torch.Generator(device=dev).manual_seed(5000 + 10 * c + t)
+                        sc = torch.rand(rows, cols, generator=g, device=dev).to(torch.bfloat16)[s:e].clone()
+                    del w_full
+                    layer.append((nm, rows, cols, (s, e), w, sc, torch.empty_like(w)))
+                self.layers.append(layer)
+            torch.cuda.empty_cache()
+            for layer in self.layers:
+                cl = []
+                for nm, rows, cols, (s, e), w, sc, out in layer:
+                    n = (e - s)
+                    if n == 0:
+                        continue
+                    if hyper:
+                        cl.append(("dmxq_weight_hypernet", (ctypes.c_void_p(w.data_ptr()), bf16, ctypes.c_void_p(sc.data_ptr()), bf16, 2, 4,
+                                                            None, ctypes.c_void_p(out.data_ptr()), bf16, n, cols, B, PRECISION, 1)))
+                    else:
+                        cl.append(("dmxq_bfp_qdq", (ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(out.data_ptr()), bf16, bf16, n, cols, 1, B,
+                                                    PRECISION, lib.ROUND_NEAREST, 1, 0)))
+                self.calls.append(cl)
+            per_elem = 6 if hyper else 4  # w + score + out | in + out, all bf16
+            mine = sum((e - s) * cols for _, _, cols, (s, e), *_ in self.layers[0])
+            self.elems_per_step_rank = mine
+            self.bytes_per_step = per_elem * mine
+            self.launches_per_step = len(self.calls[0])
+            self.describe_args = None
+            self.name = ("Llama-3-8B decoder-layer weights (q,k,v,o,gate,up,down = 218.1 M elements, bf16), each row-sharded over "
+                         "the N ranks; " + ("BTOPK{2:4,-1} mask -> BFP[8|8]{64}(SN) in one launch per weight (dmxq_weight_hypernet), "
+                                            "score bf16" if hyper else "BFP[8|8]{16}(SN) Q->DQ (dmxq_bfp_qdq)")
+                         + " (BASELINE.json configs[3])")
+        self.total_elems_per_step = None  # filled by main (sum over ranks)
+
+    def launch(self, slot, stream_ptr):
+        for name, a in self.calls[slot % len(self.calls)]:
+            rc = getattr(self.L, name)(*a, stream_ptr)
+            if rc != 0:
+                raise RuntimeError(f"{name} failed: {rc}")
+
+    def check(self, dist):
+        """gather the output shards of slot 0 (RCCL all_gather, harness only) and compare with a whole-tensor launch on
+        rank 0: shard -> op -> concat must equal op on the whole tensor, bit for bit."""
+        import dmx_compressor_amd as d
+
+        P, rank, world = self.P, self.rank, self.world
+        if self.args.workload in ("c2", "replica"):
+            full_in = P.gather_rows(self.ins[0], self.global_rows, world)
+            full_out = P.gather_rows(self.outs[0], self.global_rows, world)
+            if rank == 0:
+                whole = d.CastTo(format="BFP[8|8]{16}(SN)")(full_in)
+                assert torch.equal(whole.view(torch.int16), full_out.view(torch.int16)), \
+                    "gathered shard outputs differ from the whole-tensor CastTo result"
+            return f"all_gather of {world} row shards == whole-tensor CastTo on rank 0 (bit-exact)" if world > 1 \
+                else "outs[0] == CastTo(ins[0]) (bit-exact)"
+        hyper = self.args.op == "hypernet"
+        for nm, rows, cols, (s, e), w, sc, out in self.layers[0]:
+            full_w = P.gather_rows(w, rows, world)
+            full_o = P.gather_rows(out, rows, world)
+            full_s = P.gather_rows(sc, rows, world) if hyper else None
+            if rank == 0:
+                if hyper:
+                    whole = d.ops.weight_hypernet(full_w, PRECISION, 64, True, full_s, 2, 4)
+                    chain = d.ops.bfp_qdq(d.ops.nm_sparsify(full_w, full_s, 2, 4), PRECISION, 64)
+                    assert torch.equal(whole.view(torch.int16), chain.view(torch.int16)), f"{nm}: fused != mask -> BFP chain"
+                else:
+                    whole = d.ops.bfp_qdq(full_w, PRECISION, 16)
+                assert torch.equal(whole.view(torch.int16), full_o.view(torch.int16)), f"{nm}: gathered shards differ from whole tensor"
+            del full_w, full_o, full_s
+        return f"7 weights: all_gather of {world} row shards == whole-tensor result on rank 0 (bit-exact)"
 
 
 def main():
@@ -118,20 +265,11 @@ def main():
 
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
-    import dmx_compressor_amd as d
     from dmx_compressor_amd import _lib
 
     L = _lib.lib()  # raises if libdmxq.so is missing: no fallback
-    ins = [synth(1000 * rank + i, dev) for i in range(args.nbuf)]
-    outs = [torch.empty_like(t) for t in ins]
-    numel = ROWS * COLS
-    bf16 = _lib.BF16
-
-    def launch(i, stream_ptr):
-        rc = L.dmxq_bfp_qdq(ctypes.c_void_p(ins[i].data_ptr()), ctypes.c_void_p(outs[i].data_ptr()), bf16, bf16,
-                            ROWS, COLS, 1, BLOCK, PRECISION, _lib.ROUND_NEAREST, 1, 0, stream_ptr)
-        if rc != 0:
-            raise RuntimeError(f"dmxq_bfp_qdq failed: {rc}")
+    wl = Workload(args, L, _lib, rank, world, dev)
+    K, R = args.steps, max(1, args.replays)
 
     stream = torch.cuda.Stream(device=dev)
     sp = ctypes.c_void_p(stream.cuda_stream)
@@ -142,9 +280,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    walls, evs = [], []
     with torch.cuda.stream(stream):
         for i in range(args.warmup):
-            launch(i % args.nbuf, sp)
+            wl.launch(i, sp)
         graph = None
         if not args.no_graph:
             torch.cuda.synchronize(dev)
@@ -152,71 +291,119 @@ def main():
             # thread_local: with RCCL initialised (N > 1) its watchdog thread polls events while we capture; only calls
             # made by THIS thread belong to the capture
             with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
-                for i in range(args.steps):
-                    launch(i % args.nbuf, sp)
+                for i in range(K):
+                    wl.launch(i, sp)
+            graph.replay()  # untimed: the first replay uploads the graph
+            torch.cuda.synchronize(dev)
+        def run_k():
+            if graph is not None:
+                graph.replay()
+            else:
+                for i in range(K):
+                    wl.launch(i, sp)
+
+        # (a) whole-job wall clock: R timed regions of exactly K steps, barrier + synchronize on both sides
+        for _ in range(R):
+            barrier()
+            t0 = time.perf_counter()
+            run_k()
+            torch.cuda.synchronize(dev)
+            walls.append(time.perf_counter() - t0)
+            barrier()
+        # (b) the kernels' own time with HIP events on the launch stream, over R more regions of the same K steps.  A
+        # short device-side delay is queued in front of the first event so that the host has finished enqueueing the
+        # region before the GPU reaches it: the events then bracket back-to-back kernel execution and not the
+        # host's graph-launch latency (~15 us per replay, i.e. ~0.8 us per step at K = 20, which (a) rightly includes)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        barrier()
-        t0 = time.perf_counter()
         e0.record(stream)
-        if graph is not None:
-            graph.replay()
-        else:
-            for i in range(args.steps):
-                launch(i % args.nbuf, sp)
+        torch.cuda._sleep(2_000_000)
         e1.record(stream)
+        torch.cuda.synchronize(dev)
+        cycles_per_us = 2_000_000 / max(e0.elapsed_time(e1) * 1e3, 1e-3)
+        delay = int(cycles_per_us * (60.0 if graph is not None else 15.0 * min(K, 200)))
+        for _ in range(R):
+            barrier()
+            torch.cuda._sleep(delay)
+            e0.record(stream)
+            run_k()
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            evs.append(e0.elapsed_time(e1) / 1e3)
         barrier()
-        wall = time.perf_counter() - t0
-    ev_ms = e0.elapsed_time(e1)
 
-    t = torch.tensor([wall, ev_ms / 1e3], device=dev, dtype=torch.float64)
+    t = torch.tensor([walls, evs], device=dev, dtype=torch.float64)
+    elems = torch.tensor([float(wl.elems_per_step_rank)], device=dev, dtype=torch.float64)
     if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max, ev_max = float(t[0]), float(t[1])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # per replay: the slowest rank
+        dist.all_reduce(elems, op=dist.ReduceOp.SUM)
+    walls, evs = t[0].tolist(), t[1].tolist()
+    wall_med, ev_med = statistics.median(walls), statistics.median(evs)
+    total_elems = float(elems[0])
 
+    # cache-resident rate (one buffer pair, 64 MiB < 256 MiB Infinity Cache): always on record, never `value`
     resident = None
-    if args.resident:
+    if args.workload in ("c2", "replica"):
         with torch.cuda.stream(stream):
             for _ in range(50):
-                launch(0, sp)
+                wl.launch(0, sp)
             r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             r0.record(stream)
-            for _ in range(500):
-                launch(0, sp)
+            for _ in range(300):
+                wl.launch(0, sp)
             r1.record(stream)
             torch.cuda.synchronize(dev)
-        resident = numel / (r0.elapsed_time(r1) / 500 * 1e-3) / 1e9
+        resident = wl.elems_per_step_rank * world / (r0.elapsed_time(r1) / 300 * 1e-3) / 1e9
 
-    # sanity: the timed launches really produced the quantised tensors (spot-check one pair against the module API)
-    chk = d.CastTo(format="BFP[8|8]{16}(SN)")(ins[0])
-    assert torch.equal(chk, outs[0]), "bench output differs from CastTo output"
+    checked = None if args.no_check else wl.check(dist)
 
     if rank == 0:
-        ms_per_step = wall_max * 1e3 / args.steps
-        value = numel * world / (wall_max / args.steps) / 1e9
-        launch_s = ev_max / args.steps
-        achieved = BYTES_PER_ELEM * numel / launch_s
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        ms_per_step = wall_med * 1e3 / K
+        value = total_elems / (wall_med / K) / 1e9
+        step_s = ev_med / K
+        launch_s = step_s / wl.launches_per_step
+        achieved = wl.bytes_per_step / step_s
+        traffic, traffic_src = None, None
+        for fn in ("r02_traffic.json", "traffic.json"):
+            tp = os.path.join(ROOT, "profiles", fn)
+            if os.path.exists(tp) and args.workload != "llama-shard":
+                try:
+                    traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                    traffic_src = f"profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, committed; NOT measured in this run)"
+                    break
+                except Exception:
+                    pass
+        kernel = None
+        if wl.describe_args is not None and hasattr(L, "dmxq_bfp_qdq_describe"):
+            buf = ctypes.create_string_buffer(256)
+            if L.dmxq_bfp_qdq_describe(*wl.describe_args, 1, buf, 256) == 0:
+                kernel = buf.value.decode()
         line = {
-            "metric": "Gelements/s fused Q->DQ (BFP16, group=16) on 4096x4096 bf16",
-            "value": round(value, 2), "unit": "Gelements/s", "n_gpus": world, "steps": args.steps,
+            "metric": "Gelements/s fused Q->DQ (BFP16, group=16) on 4096x4096 bf16" if args.workload != "llama-shard"
+                      else "Gelements/s over row-sharded Llama-3-8B layer weights",
+            "value": round(value, 2), "unit": "Gelements/s", "n_gpus": world, "steps": K,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BFP[8|8]{16}(SN) fused Q->DQ, 4096x4096 bf16 -> bf16, block_dim=-1, RNE "
-                                   "(BASELINE.json configs[1])",
-                       "buffers": f"{args.nbuf} rotating in/out pairs = {args.nbuf * 2 * numel * 2 / 2**30:.2f} GiB (> 256 MiB Infinity Cache)",
-                       "launch": "eager C-ABI calls" if args.no_graph else "hipGraph replay of the K C-ABI launches",
-                       "per_gpu_elements_per_step": numel},
+            "scaling": wl.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl.name,
+                       "buffers": (f"{args.nbuf} rotating in/out pairs = {args.nbuf * 2 * ROWS * COLS * 2 / 2**30:.2f} GiB per GPU "
+                                   "(> 256 MiB Infinity Cache)") if args.workload != "llama-shard"
+                                  else f"{args.layers} rotating layer copies ({wl.bytes_per_step / 2**20:.0f} MiB touched per step on this rank)",
+                       "launch": "eager C-ABI calls" if args.no_graph else "hipGraph replay of the K steps' C-ABI launches",
+                       "launches_per_step": wl.launches_per_step,
+                       "replays": R,
+                       "replay_ms": [round(w * 1e3, 4) for w in walls],
+                       "timing": "one untimed replay, then R wall-clock regions of exactly K steps (barrier+sync, K steps, sync; "
+                                 "max over ranks; median region -> ms_per_step, value) and R HIP-event regions of the same K steps "
+                                 "(events on the launch stream, a queued device-side delay in front so that host launch latency is "
+                                 "not inside the events; median region -> roofline)",
+                       "per_gpu_elements_per_step": wl.elems_per_step_rank,
+                       "check": checked},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                         "frac": round(achieved / PEAK_HBM, 4), "traffic": traffic,
-                         "kernel": "dmxq::bfp_rows_kernel<bf16,bf16,nearest,sym,U16,nt,T512,fast2>",
-                         "algorithmic_bytes_per_launch": BYTES_PER_ELEM * numel,
-                         "avg_launch_us": round(launch_s * 1e6, 3)},
+                         "frac": round(achieved / PEAK_HBM, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel, "kernel_source": "dmxq_bfp_qdq_describe (the dispatcher's own choice for this call)" if kernel else None,
+                         "algorithmic_bytes_per_launch": wl.bytes_per_step // wl.launches_per_step if wl.launches_per_step == 1 else None,
+                         "algorithmic_bytes_per_step": wl.bytes_per_step,
+                         "avg_launch_us": round(launch_s * 1e6, 3),
+                         "event_us_per_step": [round(e * 1e6 / K, 3) for e in evs]},
         }
         if resident is not None:
             line["cache_resident_value"] = round(resident, 2)

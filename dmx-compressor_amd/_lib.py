@@ -23,6 +23,7 @@ _vp, _i64, _i32, _u64, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, cty
 # name -> argtypes; mirrors include/dmxq.h one to one (tests/test_abi.py checks header <-> table <-> .so)
 SIGNATURES = {
     "dmxq_bfp_qdq": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _u64, _vp],
+    "dmxq_bfp_qdq_describe": [_i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, ctypes.c_char_p, _i64],
     "dmxq_sbfp_qdq": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "dmxq_mxfp_qdq": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_bfp_pack": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],

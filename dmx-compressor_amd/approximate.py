@@ -6,6 +6,7 @@ public repository, where every default therefore collapses to NONE.  This mirror
 "dmxq": the exact torch.nn.functional contract evaluated by libdmxq's HIP kernels (GELU / SOFTMAX / LAYER_NORM).
 Approximation arithmetic itself is parity-unpinned and is not invented here.
 """
+import ast
 import re
 from typing import Any, Dict, Union
 
@@ -23,7 +24,7 @@ def _parse_kwargs(s: str) -> Dict[str, Any]:
     for item in filter(None, (t.strip() for t in s.split(","))):
         k, v = item.split("=")
         try:
-            out[k.strip()] = eval(v, {"__builtins__": {}}, {"True": True, "False": False, "None": None})
+            out[k.strip()] = ast.literal_eval(v.strip())
         except Exception:
             out[k.strip()] = v.strip()
     return out

@@ -59,9 +59,10 @@ class CastTo(HostFlags, torch.nn.Module):
     observer_enabled, qscheme, ch_axis.  The two switches are read from host mirrors (_flags.py): forward never
     waits for the device."""
     _flag_names = ("fake_quant_enabled", "observer_enabled")
-    #: the reference returns a COPY from a SAME-format cast (numerical/format.py:89-90); here a no-op cast hands its
-    #: input back, as the un-wrapped torch module would.  Set to True for a fresh tensor per cast.
-    copy_on_same = False
+    #: a SAME-format cast returns a COPY, like the reference's Same.cast (`x.clone()`, numerical/format.py:89-90): the
+    #: caller may mutate the result in place.  DmxModule switches this off on the casts it owns (their results are
+    #: consumed inside the module) and re-establishes the no-alias guarantee once, at the module boundary (nn.py).
+    copy_on_same = True
 
     def __init__(self, format="SAME", observer=DummyObserver, group_size=None, block_dim=-1,
                  qscheme=torch.per_tensor_affine, ch_axis=-1, **observer_kwargs):

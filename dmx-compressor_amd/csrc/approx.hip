@@ -16,6 +16,7 @@
 //   * fallback for everything else (odd lengths, mixed dtypes): one workgroup per row, the row staged ONCE in LDS as
 //     fp32 (gfx950 has 160 KiB per CU), wave shuffles + a 4-entry LDS exchange; rows too long for LDS take a 3-pass
 //     global version.
+#include <atomic>
 #include <math.h>
 
 #include "common.hpp"
@@ -535,15 +536,22 @@ using namespace dmxq;
 // THIS kernel x number of CUs; queried once per kernel and cached), or fewer when the tensor is small
 template <typename K>
 static int resident_grid(K kernel, int64_t wanted) {
-  static int per_device = 0;  // one static per kernel instantiation
-  if (per_device == 0) {
-    int dev = 0, cus = 256, per_cu = 2;
+  // one table per kernel instantiation, one slot per device (a process may drive several GPUs: the CU count and the
+  // occupancy belong to the device that is current for THIS launch)
+  constexpr int kMaxDev = 64;
+  static std::atomic<int> per_device[kMaxDev] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+  int cap = per_device[dev].load(std::memory_order_relaxed);
+  if (cap == 0) {
+    int cus = 256, per_cu = 2;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-    per_device = cus * per_cu;
+    cap = cus * per_cu;
+    per_device[dev].store(cap, std::memory_order_relaxed);
   }
-  return (int)(wanted < per_device ? (wanted < 1 ? 1 : wanted) : per_device);
+  return (int)(wanted < cap ? (wanted < 1 ? 1 : wanted) : cap);
 }
 
 static inline int row_grid(int64_t rows) { return (int)(rows < 256 * 16 ? (rows < 1 ? 1 : rows) : 256 * 16); }
@@ -573,13 +581,13 @@ extern "C" int dmxq_softmax(const void* in, void* out, int dtype_in, int dtype_o
     constexpr int per_wg = 4 * rows_per_wave(V_, E_) * (64 / (L_));                                                   \
     if constexpr ((E_) * Elem<D_>::bytes == 16) {                                                                     \
       if (rag) {                                                                                                      \
-        hipLaunchKernelGGL((softmax_wave_kernel<D_, E_, V_, L_, true>),                                               \
+        DMXQ_LAUNCH((softmax_wave_kernel<D_, E_, V_, L_, true>),                                               \
                            dim3((unsigned)resident_grid(softmax_wave_kernel<D_, E_, V_, L_, true>, (rows + per_wg - 1) / per_wg)), \
                            dim3(kThreads), 0, s, in, out, rows, cols, input_clamp_min);                               \
         break;                                                                                                        \
       }                                                                                                               \
     }                                                                                                                 \
-      hipLaunchKernelGGL((softmax_wave_kernel<D_, E_, V_, L_, false>),                                                \
+      DMXQ_LAUNCH((softmax_wave_kernel<D_, E_, V_, L_, false>),                                                \
                          dim3((unsigned)resident_grid(softmax_wave_kernel<D_, E_, V_, L_, false>, (rows + per_wg - 1) / per_wg)), \
                          dim3(kThreads), 0, s, in, out, rows, cols, input_clamp_min);                                 \
   } while (0)
@@ -603,10 +611,10 @@ extern "C" int dmxq_softmax(const void* in, void* out, int dtype_in, int dtype_o
   }
   const size_t scratch = (kThreads / kWave) * sizeof(float);
   if (cols <= kRowLdsFloats)
-    hipLaunchKernelGGL(softmax_rows_kernel<true>, dim3(row_grid(rows)), dim3(kThreads), scratch + cols * sizeof(float), s,
+    DMXQ_LAUNCH(softmax_rows_kernel<true>, dim3(row_grid(rows)), dim3(kThreads), scratch + cols * sizeof(float), s,
                        in, out, dtype_in, dtype_out, rows, cols, input_clamp_min);
   else
-    hipLaunchKernelGGL(softmax_rows_kernel<false>, dim3(row_grid(rows)), dim3(kThreads), scratch, s, in, out, dtype_in,
+    DMXQ_LAUNCH(softmax_rows_kernel<false>, dim3(row_grid(rows)), dim3(kThreads), scratch, s, in, out, dtype_in,
                        dtype_out, rows, cols, input_clamp_min);
   return launch_status();
 }
@@ -627,7 +635,7 @@ extern "C" int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype
 #define DMXQ_LNB(D_, E_, V_)                                                                                          \
   do {                                                                                                                \
     constexpr int rpw = (V_) * (E_) <= 32 ? 2 : 1;                                                                    \
-    hipLaunchKernelGGL((layernorm_block_kernel<D_, E_, V_>),                                                          \
+    DMXQ_LAUNCH((layernorm_block_kernel<D_, E_, V_>),                                                          \
                        dim3((unsigned)resident_grid(layernorm_block_kernel<D_, E_, V_>, (rows + rpw - 1) / rpw)),     \
                        dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps);                                 \
   } while (0)
@@ -651,7 +659,7 @@ extern "C" int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype
 #define DMXQ_LN(D_, E_, V_, L_)                                                                                       \
   do {                                                                                                                \
     constexpr int per_wg = 4 * rows_per_wave(V_, E_) * (64 / (L_));                                                   \
-    hipLaunchKernelGGL((layernorm_wave_kernel<D_, E_, V_, L_>),                                                       \
+    DMXQ_LAUNCH((layernorm_wave_kernel<D_, E_, V_, L_>),                                                       \
                        dim3((unsigned)resident_grid(layernorm_wave_kernel<D_, E_, V_, L_>, (rows + per_wg - 1) / per_wg)), \
                        dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps);                                 \
   } while (0)
@@ -675,10 +683,10 @@ extern "C" int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype
   }
   const size_t scratch = (kThreads / kWave) * sizeof(float);
   if (cols <= kRowLdsFloats)
-    hipLaunchKernelGGL(layernorm_rows_kernel<true>, dim3(row_grid(rows)), dim3(kThreads), scratch + cols * sizeof(float),
+    DMXQ_LAUNCH(layernorm_rows_kernel<true>, dim3(row_grid(rows)), dim3(kThreads), scratch + cols * sizeof(float),
                        s, in, out, dtype_in, dtype_out, rows, cols, weight, bias, dtype_wb, eps);
   else
-    hipLaunchKernelGGL(layernorm_rows_kernel<false>, dim3(row_grid(rows)), dim3(kThreads), scratch, s, in, out,
+    DMXQ_LAUNCH(layernorm_rows_kernel<false>, dim3(row_grid(rows)), dim3(kThreads), scratch, s, in, out,
                        dtype_in, dtype_out, rows, cols, weight, bias, dtype_wb, eps);
   return launch_status();
 }

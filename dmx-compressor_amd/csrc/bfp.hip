@@ -25,6 +25,8 @@
 //                     directly with unaligned 16-byte accesses, vectors numbered in a virtual space padded to whole
 //                     blocks (bfp_urows.hip).
 //   bfp_generic_kernel  everything else: one lane per block, strided two-pass (correct for any layout).
+#include <stdio.h>
+
 #include "bfp_rows.hpp"
 
 namespace dmxq {
@@ -32,6 +34,17 @@ namespace dmxq {
 // 16-byte vectors in flight per lane on big tensors; 8 when the output vector is 32 B (16-bit in -> fp32 out)
 template <int DTI, int DTO> struct RowsUnroll { static constexpr int big = 16; };
 constexpr int kRowsMaxGrid = 1 << 20;
+
+// Tile geometry of the flat-stream kernel for a tensor of n_vec lane-vectors (tools/tune_bfp, profiles/):
+// workgroup-contiguous tiles of threads x unroll vectors.
+struct RowsPlan { int threads, unroll; int64_t tiles; };
+static inline RowsPlan rows_plan(int64_t n_vec, int unroll_big, bool allow_big) {
+  auto tiles_of = [&](int t, int u) { return (n_vec + (int64_t)t * u - 1) / ((int64_t)t * u); };
+  const int64_t big_tiles = tiles_of(512, unroll_big);
+  if (allow_big && big_tiles <= 256 && big_tiles >= 224) return RowsPlan{512, unroll_big, big_tiles};  // ONE full round, 1 WG per CU
+  if (n_vec >= (int64_t)256 * 256 * 4) return RowsPlan{256, 4, tiles_of(256, 4)};  // many rounds: small tiles desynchronise
+  return RowsPlan{256, 1, tiles_of(256, 1)};
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Generic fallback: one lane per block; two strided passes.  Correct for every (outer, L, inner, B) incl.
@@ -92,16 +105,16 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
   do {                                                                                                           \
     const int64_t tiles = (n_vec + (int64_t)(T_) * (U_) - 1) / ((int64_t)(T_) * (U_));                           \
     const int grid = (int)(tiles < kRowsMaxGrid ? tiles : kRowsMaxGrid);                                         \
-    hipLaunchKernelGGL((bfp_rows_kernel<DTI, DTO, RND, ASYM, U_, MODE, T_, F_, U_, IVB>), dim3(grid), dim3(T_), 0, s, in, \
+    DMXQ_LAUNCH((bfp_rows_kernel<DTI, DTO, RND, ASYM, U_, MODE, T_, F_, U_, IVB>), dim3(grid), dim3(T_), 0, s, in, \
                        out, n_vec, lpb, wl, rounding, seed);                                                     \
   } while (0)
 #define DMXQ_ROWS_GEOM(F_)                                                                         \
   do {                                                                                             \
-    const int64_t big_tiles = (n_vec + (int64_t)512 * UB - 1) / ((int64_t)512 * UB);               \
+    const RowsPlan pl = rows_plan(n_vec, UB, (F_) != 4);                                           \
     if constexpr ((F_) != 4) { /* (the any-rounding build would spill at 16 vectors per lane) */ \
-      if (big_tiles <= 256 && big_tiles >= 224) { DMXQ_ROWS(512, UB, F_); break; } /* ONE full round, 1 WG per CU */ \
+      if (pl.threads == 512) { DMXQ_ROWS(512, UB, F_); break; }                                    \
     }                                                                                              \
-    if (n_vec >= (int64_t)256 * 256 * 4) DMXQ_ROWS(256, 4, F_);  /* many rounds: small tiles desynchronise */ \
+    if (pl.unroll == 4) DMXQ_ROWS(256, 4, F_);                                                     \
     else DMXQ_ROWS(256, 1, F_);                                                                    \
   } while (0)
     // instantiate only what can run (see bfp_cols.hip): literal path for the runtime-rounding build, magic-add for
@@ -122,7 +135,7 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
   }
   const int64_t nblk = (L + B - 1) / B;
   const int grid = grid_for(outer * nblk * inner);
-  hipLaunchKernelGGL((bfp_generic_kernel<DTI, DTO, RND, ASYM>), dim3(grid), dim3(kThreads), 0, s, in, out, outer, L,
+  DMXQ_LAUNCH((bfp_generic_kernel<DTI, DTO, RND, ASYM>), dim3(grid), dim3(kThreads), 0, s, in, out, outer, L,
                      inner, B, wl, rounding, seed);
   return launch_status();
 }
@@ -193,4 +206,36 @@ extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_o
   DMXQ_DT(DMXQ_F32, DMXQ_F16)
 #undef DMXQ_DT
   return DMXQ_ERR_BAD_ARG;
+}
+
+// What would dmxq_bfp_qdq launch for these arguments?  (bench.py reports it next to the roofline numbers.)
+extern "C" int dmxq_bfp_qdq_describe(int dtype_in, int dtype_out, int64_t outer, int64_t L, int64_t inner,
+                                     int64_t block_size, int precision, int rounding, int symmetric, int aligned,
+                                     char* buf, int64_t buf_len) {
+  using namespace dmxq;
+  if (!buf || buf_len < 16 || !valid_dtype(dtype_in) || !valid_dtype(dtype_out) || !valid_rounding(rounding)) return DMXQ_ERR_BAD_ARG;
+  if (outer < 0 || L < 0 || inner < 0 || block_size < 1 || precision < 2) return DMXQ_ERR_BAD_ARG;
+  static const char* dn[] = {"f32", "f16", "bf16"};
+  static const char* rn[] = {"up", "down", "nearest", "stochastic"};
+  const int64_t n = outer * L * inner;
+  const bool widening = dtype_in != DMXQ_F32 && dtype_out == DMXQ_F32;
+  const int epl = (dtype_in == DMXQ_F32 || widening) ? 4 : 8;
+  const bool pow2 = (block_size & (block_size - 1)) == 0;
+  if (n == 0) { snprintf(buf, (size_t)buf_len, "none (empty tensor)"); return DMXQ_OK; }
+  if (block_size == 1) { snprintf(buf, (size_t)buf_len, "dmxq::stream_kernel<FloatOp> (block size 1: float_quantize detour)"); return DMXQ_OK; }
+  if (precision > 22) return DMXQ_ERR_UNSUPPORTED;
+  if (inner == 1 && L % block_size == 0 && pow2 && block_size >= epl && block_size <= 64 * epl && aligned) {
+    const bool nearest = rounding == DMXQ_ROUND_NEAREST && precision <= 20;
+    const bool single = nearest && ((dtype_in == DMXQ_BF16 && precision <= 14) || (dtype_in == DMXQ_F16 && precision <= 11));
+    const int ub = 16;
+    const RowsPlan pl = rows_plan(n / epl, ub, nearest);
+    const int64_t grid = pl.tiles < kRowsMaxGrid ? pl.tiles : kRowsMaxGrid;
+    snprintf(buf, (size_t)buf_len, "dmxq::bfp_rows_kernel<%s,%s,%s,%s,%s> tile %dx%d vectors, grid %lld, nt loads+stores",
+             dn[dtype_in], dn[dtype_out], nearest ? "nearest" : rn[rounding], symmetric ? "sym" : "asym",
+             !nearest ? "literal+clamp" : (single ? "magic-add single rounding" : "magic-add double rounding"),
+             pl.threads, pl.unroll, (long long)grid);
+    return DMXQ_OK;
+  }
+  snprintf(buf, (size_t)buf_len, "%s", inner == 1 ? "dmxq::bfp_urows_kernel (ragged / unaligned rows)" : "dmxq::bfp_cols_kernel or bfp_generic_kernel (blocks along a strided dim)");
+  return DMXQ_OK;
 }

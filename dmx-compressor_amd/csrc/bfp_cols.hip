@@ -160,10 +160,10 @@ static int launch_cols_geom(const void* in, void* out, int64_t outer, int64_t L,
 #define DMXQ_COLS(F_)                                                                                             \
   do {                                                                                                            \
     if (unal)                                                                                                     \
-      hipLaunchKernelGGL((bfp_cols_kernel<DTI, DTO, RND, ASYM, RPL, RS, F_, true>), dim3((unsigned)grid), dim3(kThreads), 0, \
+      DMXQ_LAUNCH((bfp_cols_kernel<DTI, DTO, RND, ASYM, RPL, RS, F_, true>), dim3((unsigned)grid), dim3(kThreads), 0, \
                          s, in, out, outer, L, inner, wl, rounding, seed);                                        \
     else                                                                                                          \
-      hipLaunchKernelGGL((bfp_cols_kernel<DTI, DTO, RND, ASYM, RPL, RS, F_, false>), dim3((unsigned)grid), dim3(kThreads), 0, \
+      DMXQ_LAUNCH((bfp_cols_kernel<DTI, DTO, RND, ASYM, RPL, RS, F_, false>), dim3((unsigned)grid), dim3(kThreads), 0, \
                          s, in, out, outer, L, inner, wl, rounding, seed);                                        \
   } while (0)
   // instantiate only what can run: the literal path for the runtime-rounding build; magic-add (double / single

@@ -190,14 +190,14 @@ extern "C" int dmxq_bfp_pack(const void* in, int dtype_in, int8_t* mant, uint8_t
     const int grid = grid_for((n_vec + 3) / 4);
     int lpb_log = 0;
     while (((int64_t)epl << lpb_log) < B) lpb_log++;
-    if (dtype_in == DMXQ_F32) hipLaunchKernelGGL(bfp_pack_rows_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
-    else if (dtype_in == DMXQ_F16) hipLaunchKernelGGL(bfp_pack_rows_kernel<DMXQ_F16>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
-    else hipLaunchKernelGGL(bfp_pack_rows_kernel<DMXQ_BF16>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
+    if (dtype_in == DMXQ_F32) DMXQ_LAUNCH(bfp_pack_rows_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
+    else if (dtype_in == DMXQ_F16) DMXQ_LAUNCH(bfp_pack_rows_kernel<DMXQ_F16>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
+    else DMXQ_LAUNCH(bfp_pack_rows_kernel<DMXQ_BF16>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
   } else {
     const int grid = grid_for(rows * ((L + B - 1) / B));
-    if (dtype_in == DMXQ_F32) hipLaunchKernelGGL(bfp_pack_generic_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, rows, L, B, precision, asym);
-    else if (dtype_in == DMXQ_F16) hipLaunchKernelGGL(bfp_pack_generic_kernel<DMXQ_F16>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, rows, L, B, precision, asym);
-    else hipLaunchKernelGGL(bfp_pack_generic_kernel<DMXQ_BF16>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, rows, L, B, precision, asym);
+    if (dtype_in == DMXQ_F32) DMXQ_LAUNCH(bfp_pack_generic_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, rows, L, B, precision, asym);
+    else if (dtype_in == DMXQ_F16) DMXQ_LAUNCH(bfp_pack_generic_kernel<DMXQ_F16>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, rows, L, B, precision, asym);
+    else DMXQ_LAUNCH(bfp_pack_generic_kernel<DMXQ_BF16>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, rows, L, B, precision, asym);
   }
   return launch_status();
 }
@@ -215,12 +215,12 @@ extern "C" int dmxq_bfp_unpack(const int8_t* mant, const uint8_t* exps, void* ou
     while (((int64_t)8 << b_shift) < B) b_shift++;
     const int grid = grid_for((n_vec + 3) / 4);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype_out == DMXQ_F32) hipLaunchKernelGGL(bfp_unpack_vec_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision);
-    else if (dtype_out == DMXQ_F16) hipLaunchKernelGGL(bfp_unpack_vec_kernel<DMXQ_F16>, dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision);
-    else hipLaunchKernelGGL(bfp_unpack_vec_kernel<DMXQ_BF16>, dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision);
+    if (dtype_out == DMXQ_F32) DMXQ_LAUNCH(bfp_unpack_vec_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision);
+    else if (dtype_out == DMXQ_F16) DMXQ_LAUNCH(bfp_unpack_vec_kernel<DMXQ_F16>, dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision);
+    else DMXQ_LAUNCH(bfp_unpack_vec_kernel<DMXQ_BF16>, dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision);
     return launch_status();
   }
-  hipLaunchKernelGGL(bfp_unpack_kernel, dim3(grid_for(rows * L)), dim3(kThreads), 0, (hipStream_t)stream, mant, exps, out,
+  DMXQ_LAUNCH(bfp_unpack_kernel, dim3(grid_for(rows * L)), dim3(kThreads), 0, (hipStream_t)stream, mant, exps, out,
                      dtype_out, rows, L, block_size, precision);
   return launch_status();
 }

@@ -133,7 +133,7 @@ static int launch_urows(const void* in, void* out, int64_t rows, int64_t L, int6
   const int grid = (int)(tiles < (1 << 20) ? tiles : (1 << 20));
   const int fast = (RND == DMXQ_ROUND_NEAREST && wl <= 20) ? (bfp_single_rounding_ok<DTI>(wl) ? 2 : 1) : 0;
 #define DMXQ_UR(F_)                                                                                                \
-  hipLaunchKernelGGL((bfp_urows_kernel<DTI, DTO, RND, ASYM, F_, UNROLL>), dim3(grid), dim3(kThreads), 0, s, in, out, \
+  DMXQ_LAUNCH((bfp_urows_kernel<DTI, DTO, RND, ASYM, F_, UNROLL>), dim3(grid), dim3(kThreads), 0, s, in, out, \
                      rows, L, (int)nvr, (int)nvrp, tail, lpb, wl, rounding, seed)
   constexpr bool in16 = Elem<DTI>::bytes == 2;
   if constexpr (RND == kRuntimeRounding) {

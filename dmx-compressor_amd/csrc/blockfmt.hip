@@ -149,7 +149,7 @@ static int launch_blockfmt(const void* in, void* out, int64_t outer, int64_t L, 
     return launch_stream<DTI, DTO>(in, out, n, BlockOp<FMT, BLK>{f, (int)(B / EPL)}, s);
   } else {
     const int64_t nblk = (L + B - 1) / B;
-    hipLaunchKernelGGL((blockfmt_generic_kernel<DTI, DTO, FMT, BLK>), dim3(grid_for(outer * nblk * inner)), dim3(kThreads), 0,
+    DMXQ_LAUNCH((blockfmt_generic_kernel<DTI, DTO, FMT, BLK>), dim3(grid_for(outer * nblk * inner)), dim3(kThreads), 0,
                        s, in, out, outer, L, inner, B, f);
   }
   return launch_status();

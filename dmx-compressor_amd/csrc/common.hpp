@@ -326,7 +326,26 @@ inline FastDiv31 make_fastdiv31(int64_t d64) {
   return FastDiv31{(uint32_t)((((uint64_t)1 << (31 + l)) + d - 1) / d), (uint32_t)(l - 1), d};
 }
 
-inline int launch_status() { return hipGetLastError() == hipSuccess ? DMXQ_OK : DMXQ_ERR_LAUNCH; }
+// Launch-error scoping.  HIP keeps ONE "last error" per host thread, shared with every other HIP user of the thread
+// (torch, RCCL): hipGetLastError() alone would report -- and clear -- somebody else's earlier failure as ours.  So the
+// first launch of a call records whether an error was ALREADY pending (DMXQ_LAUNCH -> launch_pre), and launch_status()
+// only claims (and clears) an error that appeared since then; a foreign pending error is left untouched for its owner.
+struct LaunchTls { bool armed = false; hipError_t pre = hipSuccess; };
+inline LaunchTls& launch_tls() { static thread_local LaunchTls t; return t; }
+inline void launch_pre() {
+  LaunchTls& t = launch_tls();
+  if (!t.armed) { t.pre = hipPeekAtLastError(); t.armed = true; }
+}
+inline int launch_status() {
+  LaunchTls& t = launch_tls();
+  const bool foreign = t.armed && t.pre != hipSuccess;
+  t.armed = false;
+  if (foreign) return DMXQ_OK;  // cannot tell ours from theirs; a failed launch stays visible through their check
+  if (hipPeekAtLastError() == hipSuccess) return DMXQ_OK;
+  (void)hipGetLastError();
+  return DMXQ_ERR_LAUNCH;
+}
+#define DMXQ_LAUNCH(...) do { ::dmxq::launch_pre(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 inline bool valid_dtype(int d) { return d == DMXQ_F32 || d == DMXQ_F16 || d == DMXQ_BF16; }
 inline bool valid_rounding(int r) { return r >= 0 && r <= 3; }

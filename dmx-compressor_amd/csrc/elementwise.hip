@@ -414,7 +414,7 @@ static int launch_lastdim(const void* in, void* out, int dti, int dto, int64_t r
   if (strips > 65535) return DMXQ_ERR_UNSUPPORTED;
 #define DMXQ_LD(I_, O_)                                                                                               \
   if (dti == I_ && dto == O_) {                                                                                       \
-    hipLaunchKernelGGL((lastdim_kernel<I_, O_, OP>), dim3((unsigned)gx, (unsigned)strips), dim3(kThreads), 0, s, in, out, \
+    DMXQ_LAUNCH((lastdim_kernel<I_, O_, OP>), dim3((unsigned)gx, (unsigned)strips), dim3(kThreads), 0, s, in, out, \
                        rows, C, cv, lpr, rpp, op);                                                                    \
     return launch_status();                                                                                           \
   }
@@ -550,4 +550,4 @@ extern "C" const char* dmxq_status_string(int status) {
   return "unknown status";
 }
 
-extern "C" int dmxq_abi_version(void) { return 1; }
+extern "C" int dmxq_abi_version(void) { return 2; }

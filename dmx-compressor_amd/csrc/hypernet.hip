@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void hypernet_rows_kernel(HnArgs a) {
 template <int DTW, int DTS, int DTO>
 static int launch_hn(const HnArgs& a, int M, bool has_scale, hipStream_t s) {
   const int grid = grid_for((a.n_units + 3) / 4);
-#define DMXQ_HN(M_, S_) hipLaunchKernelGGL((hypernet_rows_kernel<DTW, DTS, DTO, M_, S_>), dim3(grid), dim3(kThreads), 0, s, a)
+#define DMXQ_HN(M_, S_) DMXQ_LAUNCH((hypernet_rows_kernel<DTW, DTS, DTO, M_, S_>), dim3(grid), dim3(kThreads), 0, s, a)
   if (has_scale) { switch (M) { case 0: DMXQ_HN(0, true); break; case 2: DMXQ_HN(2, true); break; case 4: DMXQ_HN(4, true); break; default: DMXQ_HN(8, true); } }
   else { switch (M) { case 0: DMXQ_HN(0, false); break; case 2: DMXQ_HN(2, false); break; case 4: DMXQ_HN(4, false); break; default: DMXQ_HN(8, false); } }
 #undef DMXQ_HN

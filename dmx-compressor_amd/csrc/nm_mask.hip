@@ -162,7 +162,7 @@ template <int M>
 static void launch_nm_vec(const NmArgs& a, int64_t n, hipStream_t s) {
   constexpr int U = M <= 8 ? 8 : 16, UNROLL = 2;
   const int64_t n_units = n / U;
-  hipLaunchKernelGGL((nm_mask_vec_kernel<M, UNROLL>), dim3(grid_for((n_units + UNROLL - 1) / UNROLL)), dim3(kThreads), 0, s,
+  DMXQ_LAUNCH((nm_mask_vec_kernel<M, UNROLL>), dim3(grid_for((n_units + UNROLL - 1) / UNROLL)), dim3(kThreads), 0, s,
                      a, n_units);
 }
 
@@ -221,11 +221,11 @@ extern "C" int dmxq_nm_mask(const void* score, int dtype_score, const void* x, i
   }
   const int grid = grid_for(n / M);
   switch (M) {
-    case 2: hipLaunchKernelGGL(nm_mask_kernel<2>, dim3(grid), dim3(kThreads), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(nm_mask_kernel<4>, dim3(grid), dim3(kThreads), 0, s, a); break;
-    case 8: hipLaunchKernelGGL(nm_mask_kernel<8>, dim3(grid), dim3(kThreads), 0, s, a); break;
-    case 16: hipLaunchKernelGGL(nm_mask_kernel<16>, dim3(grid), dim3(kThreads), 0, s, a); break;
-    default: hipLaunchKernelGGL(nm_mask_anyM_kernel, dim3(grid), dim3(kThreads), 0, s, a, M); break;
+    case 2: DMXQ_LAUNCH(nm_mask_kernel<2>, dim3(grid), dim3(kThreads), 0, s, a); break;
+    case 4: DMXQ_LAUNCH(nm_mask_kernel<4>, dim3(grid), dim3(kThreads), 0, s, a); break;
+    case 8: DMXQ_LAUNCH(nm_mask_kernel<8>, dim3(grid), dim3(kThreads), 0, s, a); break;
+    case 16: DMXQ_LAUNCH(nm_mask_kernel<16>, dim3(grid), dim3(kThreads), 0, s, a); break;
+    default: DMXQ_LAUNCH(nm_mask_anyM_kernel, dim3(grid), dim3(kThreads), 0, s, a, M); break;
   }
   return launch_status();
 }

@@ -332,7 +332,7 @@ extern "C" int dmxq_group_minmax(const void* in, int dtype_in, int64_t outer, in
   hipStream_t s = (hipStream_t)stream;
   const int64_t G = (C + group_size - 1) / group_size;
   if (G > 65535) return DMXQ_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(fill2_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, mn, INFINITY, mx, -INFINITY, G);
+  DMXQ_LAUNCH(fill2_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, mn, INFINITY, mx, -INFINITY, G);
   if (outer * inner > 0) {
     if (!in) return DMXQ_ERR_BAD_ARG;
     const int64_t per_group = outer * group_size * inner;
@@ -347,11 +347,11 @@ extern "C" int dmxq_group_minmax(const void* in, int dtype_in, int64_t outer, in
       const int64_t capv = (512 + G - 1) / G;  // ~512 workgroups of 1024 threads in total
       if (sv > capv) sv = capv;
       if (sv < 1) sv = 1;
-#define DMXQ_MM(D_) hipLaunchKernelGGL(group_minmax_vec_kernel<D_>, dim3((unsigned)sv, (unsigned)G), dim3(kMinmaxThreads), 0, s, in, outer, C, inner, group_size, mn, mx)
+#define DMXQ_MM(D_) DMXQ_LAUNCH(group_minmax_vec_kernel<D_>, dim3((unsigned)sv, (unsigned)G), dim3(kMinmaxThreads), 0, s, in, outer, C, inner, group_size, mn, mx)
       if (dtype_in == DMXQ_F32) DMXQ_MM(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_MM(DMXQ_F16); else DMXQ_MM(DMXQ_BF16);
 #undef DMXQ_MM
     } else
-      hipLaunchKernelGGL(group_minmax_kernel, dim3((unsigned)splits, (unsigned)G), dim3(kThreads), 0, s, in, dtype_in,
+      DMXQ_LAUNCH(group_minmax_kernel, dim3((unsigned)splits, (unsigned)G), dim3(kThreads), 0, s, in, dtype_in,
                          outer, C, inner, group_size, mn, mx);
   }
   return launch_status();
@@ -362,7 +362,7 @@ extern "C" int dmxq_qparams(const float* mn, const float* mx, int64_t n_groups, 
   if (n_groups < 0 || qmax <= qmin) return DMXQ_ERR_BAD_ARG;
   if (n_groups == 0) return DMXQ_OK;
   if (!mn || !mx || !scale || !zero_point) return DMXQ_ERR_BAD_ARG;
-  hipLaunchKernelGGL(qparams_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mn,
+  DMXQ_LAUNCH(qparams_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mn,
                      mx, n_groups, qmin, qmax, symmetric_qscheme, scale, zero_point);
   return launch_status();
 }
@@ -373,7 +373,7 @@ extern "C" int dmxq_channel_maxabs(const void* in, int dtype_in, int64_t outer, 
   if (C == 0) return DMXQ_OK;
   if (!out) return DMXQ_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(fill2_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, out, 0.0f, (float*)nullptr, 0.0f, C);
+  DMXQ_LAUNCH(fill2_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, out, 0.0f, (float*)nullptr, 0.0f, C);
   const int64_t plane = C * inner;
   if (outer * plane > 0) {
     if (!in) return DMXQ_ERR_BAD_ARG;
@@ -389,11 +389,11 @@ extern "C" int dmxq_channel_maxabs(const void* in, int dtype_in, int64_t outer, 
     }
     if (gy > 65535) gy = 65535;
     if (vec)
-#define DMXQ_MA(D_) hipLaunchKernelGGL(channel_maxabs_vec_kernel<D_>, dim3((unsigned)gx, (unsigned)gy), dim3(kMaxabsThreads), 0, s, in, outer, C, inner, out)
+#define DMXQ_MA(D_) DMXQ_LAUNCH(channel_maxabs_vec_kernel<D_>, dim3((unsigned)gx, (unsigned)gy), dim3(kMaxabsThreads), 0, s, in, outer, C, inner, out)
     { if (dtype_in == DMXQ_F32) DMXQ_MA(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_MA(DMXQ_F16); else DMXQ_MA(DMXQ_BF16); }
 #undef DMXQ_MA
     else
-      hipLaunchKernelGGL(channel_maxabs_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, s, in, dtype_in,
+      DMXQ_LAUNCH(channel_maxabs_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, s, in, dtype_in,
                          outer, C, inner, out);
   }
   return launch_status();
@@ -404,7 +404,7 @@ extern "C" int dmxq_smoothquant_scale(const float* a_maxabs, const float* b_maxa
   if (C < 0) return DMXQ_ERR_BAD_ARG;
   if (C == 0) return DMXQ_OK;
   if (!a_maxabs || !b_maxabs || !scale) return DMXQ_ERR_BAD_ARG;
-  hipLaunchKernelGGL(smoothquant_scale_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  DMXQ_LAUNCH(smoothquant_scale_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      a_maxabs, b_maxabs, C, alpha, scale_min, scale);
   return launch_status();
 }
@@ -420,10 +420,10 @@ extern "C" int dmxq_histc(const void* in, int dtype_in, int64_t n, int64_t bins,
     if (!in) return DMXQ_ERR_BAD_ARG;
     int64_t blocks = (n + kHistThreads * 32 - 1) / (kHistThreads * 32);
     if (blocks > 512) blocks = 512;
-#define DMXQ_HC(D_) hipLaunchKernelGGL(histc_kernel<D_>, dim3((unsigned)blocks), dim3(kHistThreads), (size_t)bins * sizeof(uint32_t), s, in, n, (int)bins, lo, hi, aligned16(in) ? 1 : 0, (uint32_t*)hist)
+#define DMXQ_HC(D_) DMXQ_LAUNCH(histc_kernel<D_>, dim3((unsigned)blocks), dim3(kHistThreads), (size_t)bins * sizeof(uint32_t), s, in, n, (int)bins, lo, hi, aligned16(in) ? 1 : 0, (uint32_t*)hist)
     if (dtype_in == DMXQ_F32) DMXQ_HC(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_HC(DMXQ_F16); else DMXQ_HC(DMXQ_BF16);
 #undef DMXQ_HC
-    hipLaunchKernelGGL(hist_to_float_kernel, dim3((unsigned)((bins + 255) / 256)), dim3(256), 0, s, (uint32_t*)hist, (int)bins);
+    DMXQ_LAUNCH(hist_to_float_kernel, dim3((unsigned)((bins + 255) / 256)), dim3(256), 0, s, (uint32_t*)hist, (int)bins);
   }
   return launch_status();
 }

@@ -104,7 +104,7 @@ static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hip
     int64_t tiles = (n_vec + (int64_t)256 * 4 - 1) / ((int64_t)256 * 4);
     if (tiles < 1) tiles = 1;
     if (tiles > (1 << 20)) tiles = 1 << 20;
-    hipLaunchKernelGGL((stream_kernel<DTI, DTO, 4, 256, OP, true>), dim3((unsigned)tiles), dim3(256), 0, s, in, out, n, op);
+    DMXQ_LAUNCH((stream_kernel<DTI, DTO, 4, 256, OP, true>), dim3((unsigned)tiles), dim3(256), 0, s, in, out, n, op);
     return launch_status();
   }
 #define DMXQ_STREAM(T_, U_)                                                                                       \
@@ -112,7 +112,7 @@ static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hip
     int64_t tiles = (n_vec + (int64_t)(T_) * (U_) - 1) / ((int64_t)(T_) * (U_));                                  \
     if (tiles < 1) tiles = 1;                                                                                     \
     if (tiles > (1 << 20)) tiles = 1 << 20;                                                                       \
-    hipLaunchKernelGGL((stream_kernel<DTI, DTO, U_, T_, OP>), dim3((unsigned)tiles), dim3(T_), 0, s, in, out, n, op); \
+    DMXQ_LAUNCH((stream_kernel<DTI, DTO, U_, T_, OP>), dim3((unsigned)tiles), dim3(T_), 0, s, in, out, n, op); \
   } while (0)
   const int64_t big_tiles = (n_vec + (int64_t)512 * UB - 1) / ((int64_t)512 * UB);
   if (!OpHeavy<OP>::value && big_tiles <= 256 && big_tiles >= 224) DMXQ_STREAM(512, UB);  // one full round (bfp.hip)

@@ -320,18 +320,18 @@ extern "C" int dmxq_topk_mask(const void* score, int dtype_score, const void* x,
   const int cgrid = (int)(n_chunks < kMaxBlocks ? n_chunks : kMaxBlocks);
   const int vec = aligned16(score) ? 1 : 0;
   const int hgrid = grid_for((n + 7) / 8);
-  hipLaunchKernelGGL(topk_init_kernel, dim3(1), dim3(256), 0, s, ws, n_zero > 0 ? n_zero : 1);
+  DMXQ_LAUNCH(topk_init_kernel, dim3(1), dim3(256), 0, s, ws, n_zero > 0 ? n_zero : 1);
 #define DMXQ_TOPK(D_)                                                                                                  \
   do {                                                                                                                 \
     if (n_zero > 0) {                                                                                                  \
       for (int level = 0; level < kTopkLevels; level++) {                                                              \
-        hipLaunchKernelGGL(topk_hist_kernel<D_>, dim3(hgrid), dim3(kThreads), 0, s, score, n, level, vec, ws);         \
-        hipLaunchKernelGGL(topk_select_kernel, dim3(1), dim3(256), 0, s, ws, level);                                   \
+        DMXQ_LAUNCH(topk_hist_kernel<D_>, dim3(hgrid), dim3(kThreads), 0, s, score, n, level, vec, ws);         \
+        DMXQ_LAUNCH(topk_select_kernel, dim3(1), dim3(256), 0, s, ws, level);                                   \
       }                                                                                                                \
-      hipLaunchKernelGGL(topk_tie_count_kernel<D_>, dim3(cgrid), dim3(kThreads), 0, s, score, n, vec, n_zero, ws);     \
-      hipLaunchKernelGGL(topk_scan_kernel, dim3(1), dim3(kThreads), 0, s, n_chunks, n_zero, ws);                       \
+      DMXQ_LAUNCH(topk_tie_count_kernel<D_>, dim3(cgrid), dim3(kThreads), 0, s, score, n, vec, n_zero, ws);     \
+      DMXQ_LAUNCH(topk_scan_kernel, dim3(1), dim3(kThreads), 0, s, n_chunks, n_zero, ws);                       \
     }                                                                                                                  \
-    hipLaunchKernelGGL(topk_apply_kernel<D_>, dim3(cgrid), dim3(kThreads), 0, s, score, vec, x, dtype_x, mask_out,     \
+    DMXQ_LAUNCH(topk_apply_kernel<D_>, dim3(cgrid), dim3(kThreads), 0, s, score, vec, x, dtype_x, mask_out,     \
                        dtype_mask, y_out, dtype_y, n, n_zero, ws);                                                     \
   } while (0)
   if (dtype_score == DMXQ_F32) DMXQ_TOPK(DMXQ_F32);

@@ -72,6 +72,23 @@ class DmxModuleSmoothQuantHyperparams:
     fuse_to_weight: bool = False
 
 
+def _shares_storage(a, b) -> bool:
+    return (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.device == b.device
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.numel() > 0)
+
+
+def _aliases_any(out, inputs, module) -> bool:
+    if not isinstance(out, torch.Tensor):
+        return False
+    for t in inputs:
+        if out is t or _shares_storage(out, t):
+            return True
+    for p in module._parameters.values():
+        if p is not None and _shares_storage(out, p):
+            return True
+    return False
+
+
 class DmxModule(torch.nn.Module):
     """Mixin base: call `_dmx_init()` after the torch module's own __init__ (see the concrete classes)."""
 
@@ -95,6 +112,16 @@ class DmxModule(torch.nn.Module):
         self.weight_sparsifier = _LazySparsify() if sparsifiable else None
         self.approximator = Approximate()
         self.approximation_error = None
+        self._mark_internal_casts()
+
+    def _mark_internal_casts(self):
+        """The casts a DmxModule owns are internal: what they return is consumed by `_forward` (read-only) or handed to
+        the next internal stage, so a SAME-format cast does not need the reference's defensive `x.clone()`
+        (numerical/format.py:89-90) at every site.  The guarantee that clone gives the CALLER -- the module's result
+        never aliases its inputs or parameters -- is re-established once in `forward` / `_weight` / `_bias`."""
+        for c in self.modules():
+            if isinstance(c, CastTo):
+                c.copy_on_same = False
 
     # ------------------------------------------------------------------ configuration (core.py:65-108)
     def configure(self, config) -> None:
@@ -205,12 +232,24 @@ class DmxModule(torch.nn.Module):
         return _weight_hypernet
 
     @property
-    def _weight(self):
+    def _weight_ro(self):
+        """the weight as `_forward` consumes it: READ-ONLY, may be the Parameter itself when every stage is a no-op"""
         return self.weight_hypernet(self.weight)
 
     @property
-    def _bias(self):
+    def _bias_ro(self):
         return self.bias_cast(self.bias) if (self.bias_cast is not None and self.bias is not None) else None
+
+    @property
+    def _weight(self):
+        """core.py:200-203; never aliases the Parameter (the reference's chain ends in at least one `clone()`)"""
+        w = self._weight_ro
+        return w.clone() if _shares_storage(w, self.weight) else w
+
+    @property
+    def _bias(self):
+        b = self._bias_ro
+        return b.clone() if b is not None and _shares_storage(b, self.bias) else b
 
     @property
     def effective_weight(self):
@@ -232,6 +271,7 @@ class DmxModule(torch.nn.Module):
             if self.weight_cast is not None and not isinstance(self.weight_cast.format, Same):
                 self.weight.data = self.weight_cast(self.weight.data)
                 self.weight_cast = CastTo(format=Same())
+        self._mark_internal_casts()
 
     # ------------------------------------------------------------------ forward (core.py:215-264)
     def update_smoothquant_scale(self, input):
@@ -290,6 +330,14 @@ class DmxModule(torch.nn.Module):
         output = self.output_casts(_output, output=True)
         if self.align_boundary_dtype:
             output = (type(output)(a.to(_dtype) for a in output) if isinstance(output, (tuple, list)) else output.to(_dtype))
+        # module boundary: the reference's SAME casts clone, so its result never aliases an input (a caller may run
+        # `out.add_()`); the internal casts here do not copy, so check once and copy only when an alias got through
+        # (all-SAME pass-through modules such as a BASELINE-mode Dropout / ResAdd-free identity)
+        ins = [t for t in (input, *args, *kwargs.values()) if isinstance(t, torch.Tensor)]
+        if isinstance(output, (tuple, list)):
+            output = type(output)(o.clone() if _aliases_any(o, ins, self) else o for o in output)
+        elif _aliases_any(output, ins, self):
+            output = output.clone()
         return output
 
     # approximator slot (functional/approximate.py:300-327): exact function first, then overwritten by the approximation
@@ -320,12 +368,12 @@ class Linear(DmxModule, torch.nn.Linear):
 
     def _forward(self, _input):
         if isinstance(self.accum_format, Same):  # torch_modules.py:346-350
-            _weight = self._weight.to(_input.dtype)
-            _bias = self._bias  # (a property: one cast launch per evaluation)
+            _weight = self._weight_ro.to(_input.dtype)
+            _bias = self._bias_ro  # (a property: one cast launch per evaluation)
             return F.linear(_input, _weight, None if _bias is None else _bias.to(_input.dtype))
-        _weight = self._weight
+        _weight = self._weight_ro
         _product = self.accum_cast(torch.matmul(_input.to(_weight.dtype), _weight.t()))
-        return torch.add(_product, self._bias) if self.bias is not None else _product
+        return torch.add(_product, self._bias_ro) if self.bias is not None else _product
 
     @classmethod
     def from_raw(cls, raw):
@@ -345,10 +393,10 @@ class _ConvNd(DmxModule):
             self.bias_cast.block_dim = -1
 
     def _forward(self, _input):  # torch_modules.py:677-686 (Conv2d), 585-594 (Conv1d)
-        _weight = self._weight
+        _weight = self._weight_ro
         _convolution = self.accum_cast(self._conv_forward(_input.to(_weight.dtype), _weight, None))
         if self.bias is not None:
-            _b = self._bias
+            _b = self._bias_ro
             for _ in range(_convolution.dim() - 2):
                 _b = _b.unsqueeze(-1)
             return torch.add(_convolution, _b)
@@ -409,7 +457,7 @@ class LayerNorm(DmxModule, torch.nn.LayerNorm):
         self.functional_forward = F.layer_norm
 
     def _forward(self, _input):
-        return self.approx_forward((_input,), self.normalized_shape, self._weight, self._bias, self.eps)
+        return self.approx_forward((_input,), self.normalized_shape, self._weight_ro, self._bias_ro, self.eps)
 
 
 class GELU(DmxModule, torch.nn.GELU):
@@ -455,7 +503,7 @@ class Embedding(DmxModule, torch.nn.Embedding):
         self._dmx_init(sparsifiable=True)
 
     def forward(self, input):  # integer indices: no input cast, no dtype alignment (reference Embedding)
-        _output = F.embedding(input, self._weight, self.padding_idx, self.max_norm, self.norm_type,
+        _output = F.embedding(input, self._weight_ro, self.padding_idx, self.max_norm, self.norm_type,
                               self.scale_grad_by_freq, self.sparse)
         return self.output_casts(_output, output=True)
 

@@ -4,6 +4,7 @@ return, quant/quant_cuda/quant_cuda.cpp:116-139 — here `empty`, every element 
 
 No CPU path: a non-GPU tensor or a missing libdmxq.so raises `DmxqError`.
 """
+import functools
 import math
 from typing import Optional
 
@@ -22,7 +23,16 @@ _SEED_COUNTER = [0x5EED]
 
 def _next_seed() -> int:
     """Stochastic rounding draws from a counter-based stream keyed by (seed, element index); a fresh seed per
-    call, derived from torch's generator state so `torch.manual_seed` makes runs reproducible."""
+    call, derived from `torch.initial_seed()` (the DEFAULT generator's seed: `torch.manual_seed` makes runs
+    reproducible; a non-default `torch.Generator` is not consulted -- pass `seed=` explicitly for that).
+
+    The seed is a kernel ARGUMENT, so a hipGraph capture would freeze it and every replay would repeat the same
+    draws (accumulated rounding would no longer be unbiased): implicit seeding is refused while the current stream is
+    capturing.  An explicit `seed=` is the caller's statement that frozen draws are intended."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise DmxqError("stochastic rounding with an implicit seed inside a hipGraph capture: the seed would be frozen "
+                        "into the graph and every replay would reuse the same random draws; pass seed= explicitly or "
+                        "keep stochastic casts outside the captured region")
     _SEED_COUNTER[0] += 1
     return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _SEED_COUNTER[0]) & 0xFFFFFFFFFFFFFFFF
 
@@ -352,3 +362,23 @@ def layernorm(x, normalized_shape, weight=None, bias=None, eps: float = 1e-5,
     check(lib().dmxq_layernorm(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), rows, cols, ptr(w),
                                ptr(b), wb_dtype, float(eps), stream_of(xc)), "dmxq_layernorm")
     return out
+
+
+def _on_tensor_device(fn):
+    """HIP launches go to the CURRENT device: a tensor that lives on another GPU of this process (single-process
+    multi-GPU, device_map pipeline splits) needs its device made current around the C-ABI call (include/dmxq.h
+    conventions), exactly like torch's own kernels do with a device guard.  One integer compare when it already is."""
+
+    @functools.wraps(fn)
+    def guarded(x, *args, **kwargs):
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):
+                return fn(x, *args, **kwargs)
+        return fn(x, *args, **kwargs)
+
+    return guarded
+
+
+for _name in __all__ + ["histc"]:
+    globals()[_name] = _on_tensor_device(globals()[_name])
+del _name

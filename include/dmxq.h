@@ -11,6 +11,8 @@
  *   - caller-allocated outputs (the reference allocates with zeros_like and returns a new tensor,
  *     quant_cuda.cpp:116-139 — the host mirror keeps that ownership contract above this ABI);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are asynchronous;
+ *   - as for any HIP launch, the device that owns the pointers and the stream must be CURRENT on the calling thread
+ *     (the host mirror and the torch extension switch to the tensor's device around every call and restore it);
  *   - return value: DMXQ_OK, or an error code (see dmxq_status_string); nothing is launched on error;
  *   - tensors are described as a contiguous [outer, L, inner] (or [outer, C, inner]) view: `L`/`C` is the
  *     extent of the blocked / channel dimension, `inner` the product of the dimensions after it
@@ -49,6 +51,12 @@ int dmxq_abi_version(void);
  * precision = total mantissa bits incl. sign ("8" in BFP[8|8]); 2 <= precision <= 22 when block_size > 1. */
 int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L, int64_t inner,
                  int64_t block_size, int precision, int rounding, int symmetric, uint64_t seed, void* stream);
+
+/* Introspection (no launch): writes into buf (NUL-terminated, at most buf_len bytes) the kernel and tile geometry that
+ * dmxq_bfp_qdq would launch for these arguments; `aligned` = both pointers are 16-byte aligned.  bench.py reports it
+ * next to the roofline numbers, so that the named kernel is the dispatcher's own choice, not a constant. */
+int dmxq_bfp_qdq_describe(int dtype_in, int dtype_out, int64_t outer, int64_t L, int64_t inner, int64_t block_size,
+                          int precision, int rounding, int symmetric, int aligned, char* buf, int64_t buf_len);
 
 /* Scaled block floating point Q->DQ ("SBFP<XP[p,0](CSN)><FP[0|e|m,bias](FN)>{B}", e.g. SBFP12_16 weight storage).
  * Replaces: numerical/format.py:453-479 ScaledBlockFloatingPoint.cast.  Per block: s = max|x| / (2^(p-1)-1);

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(dmx):
         assert hasattr(L, name), f"libdmxq.so does not export {name}"
     # the ctypes table covers the whole header (minus the two helpers bound separately)
     assert declared - {"dmxq_status_string", "dmxq_abi_version"} == set(dmx._lib.SIGNATURES)
-    assert L.dmxq_abi_version() == 1
+    assert L.dmxq_abi_version() == 2
     assert L.dmxq_status_string(0) == b"ok" and b"bad" in L.dmxq_status_string(1)
 
 
@@ -136,13 +136,14 @@ def test_castto_configuration_surface(dmx):
     assert repr(d["input_cast"].format) == "BFP[8|8]{16}(SN)" and repr(d["other_cast"].format) == "SAME"
     with pytest.raises(RuntimeError):
         d.set_format({"nope": "SAME", "x": "SAME"})
-    # SAME format needs no GPU: the input itself by default, a clone (the reference's Same.cast) on request
+    # SAME format needs no GPU: a clone by default, like the reference's Same.cast (numerical/format.py:89-90); the
+    # zero-copy form is what DmxModule sets on the casts it owns
     t = torch.randn(3)
-    assert dmx.CastTo()(t) is t
     c = dmx.CastTo()
-    c.copy_on_same = True
     out = c(t)
-    assert torch.equal(out, t) and out.data_ptr() != t.data_ptr()
+    assert torch.equal(out, t) and out is not t and out.data_ptr() != t.data_ptr()
+    c.copy_on_same = False
+    assert c(t) is t
     # the two switches are mirrored on the host (forward never reads a device buffer) and survive a state_dict round trip
     c.enable_calibration(True, dmx.DummyObserver)
     assert c._flag("fake_quant_enabled") == 0 and c._flag("observer_enabled") == 1 and int(c.observer_enabled[0]) == 1
@@ -239,3 +240,46 @@ def test_rule_sets_and_module_surface(dmx):
     assert f.wrapper_params == {"input_clamp": -100} and f.extra_params == {"max_adjust": 0.1141} and repr(f).startswith("SOFTMAX[dmxq]")
     with pytest.raises(ValueError):
         dmx.ApproximationFunction.from_shorthand("FOO[x]{}()")
+
+
+def test_module_results_never_alias_inputs_or_parameters(dmx):
+    """Reference semantics (every SAME cast is `x.clone()`, numerical/format.py:89-90): whatever a DmxModule returns may
+    be mutated in place by the caller without touching the module's input or parameters.  The casts a DmxModule owns
+    do not copy; the guarantee is re-established at the module boundary.  All-SAME (BASELINE) modules run on the CPU."""
+    nn = dmx.nn
+    lin = nn.Linear(8, 4)
+    assert all(not c.copy_on_same for c in lin.modules() if isinstance(c, dmx.CastTo))
+    x = torch.randn(3, 8)
+    x0 = x.clone()
+    y = lin(x)
+    y.add_(100.0)
+    assert torch.equal(x, x0)
+    # pass-through shapes: the result of the internal chain IS the input -> one clone at the boundary
+    class Identity(nn.DmxModule):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self._dmx_init()
+
+        def _forward(self, _input):
+            return _input
+
+    ident = Identity()
+    out = ident(x)
+    assert out is not x and out.untyped_storage().data_ptr() != x.untyped_storage().data_ptr() and torch.equal(out, x)
+    out.zero_()
+    assert torch.equal(x, x0)
+    sliced = Identity()
+    sliced._forward = lambda _input: _input[1:]        # a view of the input must not escape either
+    out = sliced(x)
+    out.zero_()
+    assert torch.equal(x, x0)
+    # the weight / bias views handed to a caller are copies; the read-only internal ones may be the Parameters
+    w0 = lin.weight.detach().clone()
+    assert lin._weight_ro.data_ptr() == lin.weight.data_ptr()
+    lin._weight.data.zero_()
+    lin._bias.data.zero_()
+    assert torch.equal(lin.weight, w0)
+    lin.fold_weight_and_bias()
+    lin._weight.data.zero_()
+    assert torch.equal(lin.weight, w0)
+    assert all(not c.copy_on_same for c in lin.modules() if isinstance(c, dmx.CastTo))

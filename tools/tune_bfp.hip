@@ -39,13 +39,17 @@ __global__ __launch_bounds__(THREADS) void copy_kernel(const void* __restrict__ 
 struct Variant { std::string name; std::function<void(const void*, void*, hipStream_t)> run; std::vector<float> us; };
 
 int main(int argc, char** argv) {
-  const int64_t rows = argc > 2 ? atoll(argv[2]) : 4096, cols = 4096, n = rows * cols, n_vec = n / 8;
-  const int NBUF = (int)std::max<int64_t>(2, std::min<int64_t>(20, (int64_t)1280 * 1024 * 1024 / (n * 4))), LAUNCHES = 50, ROUNDS = argc > 1 ? atoi(argv[1]) : 7;
+  // usage: tune_bfp [rounds] [rows] [cols] [alloc_rows]   (alloc_rows >= rows: size of each hipMalloc in rows, to
+  // separate the effect of the allocation size / alignment from the amount of work)
+  const int64_t rows = argc > 2 ? atoll(argv[2]) : 4096, cols = argc > 3 ? atoll(argv[3]) : 4096, n = rows * cols, n_vec = n / 8;
+  const int64_t alloc_rows = argc > 4 ? std::max<int64_t>(rows, atoll(argv[4])) : rows, n_alloc = alloc_rows * cols;
+  const int NBUF = (int)std::max<int64_t>(2, std::min<int64_t>(48, (int64_t)1280 * 1024 * 1024 / (n * 4))), LAUNCHES = 50, ROUNDS = argc > 1 ? atoi(argv[1]) : 7;
   std::vector<void*> in(NBUF), out(NBUF);
   std::vector<uint16_t> h(n);
   uint64_t s = 88172645463325252ull;
   for (int64_t i = 0; i < n; i++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = (uint16_t)(((s >> 20) & 0x8FFF) | 0x3000) ^ (uint16_t)((s >> 40) & 0x0F00); }
-  for (int b = 0; b < NBUF; b++) { CK(hipMalloc(&in[b], n * 2)); CK(hipMalloc(&out[b], n * 2)); CK(hipMemcpy(in[b], h.data(), n * 2, hipMemcpyHostToDevice)); }
+  for (int b = 0; b < NBUF; b++) { CK(hipMalloc(&in[b], n_alloc * 2)); CK(hipMalloc(&out[b], n_alloc * 2)); CK(hipMemcpy(in[b], h.data(), n * 2, hipMemcpyHostToDevice)); }
+  printf("# rows %lld cols %lld alloc_rows %lld nbuf %d  in[0]=%p out[0]=%p in[1]=%p\n", (long long)rows, (long long)cols, (long long)alloc_rows, NBUF, in[0], out[0], in[1]);
   hipStream_t st; CK(hipStreamCreate(&st));
   std::vector<Variant> vs;
 #define ADD_BFPG(U, M, T, GRID, F, GR) vs.push_back({"bfp  U" #U " M" #M " T" #T " G" #GRID " F" #F " grp" #GR, [=](const void* i, void* o, hipStream_t q) { \
@@ -57,11 +61,10 @@ int main(int argc, char** argv) {
     int g = (GRID) > 0 ? (GRID) : (int)((n_vec + (int64_t)T * U - 1) / ((int64_t)T * U)); \
     hipLaunchKernelGGL((copy_kernel<U, M, T>), dim3(g), dim3(T), 0, q, i, o, n_vec); }, {}})
   // G0 = exact grid.  M bits: 1 nt-load, 2 nt-store (copy: 4 = workgroup-contiguous tiles; bfp is always tiled)
-  ADD_COPY(16, 7, 512, 0); ADD_COPY(16, 7, 256, 0); ADD_COPY(8, 7, 256, 0); ADD_COPY(4, 7, 256, 0);
-  ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPG(16, 3, 256, 0, 2, 16); ADD_BFPG(8, 3, 512, 0, 2, 8); ADD_BFPG(8, 3, 256, 0, 2, 8);
-  ADD_BFPG(4, 3, 256, 0, 2, 4); ADD_BFPG(4, 3, 512, 0, 2, 4); ADD_BFPG(2, 3, 256, 0, 2, 2); ADD_BFPG(16, 3, 512, 256, 2, 16);
-  ADD_BFPG(16, 3, 512, 512, 2, 16); ADD_BFPG(16, 3, 256, 512, 2, 16); ADD_BFPG(16, 3, 256, 1024, 2, 16); ADD_BFPG(8, 3, 256, 1024, 2, 8);
-  ADD_BFPG(8, 3, 256, 2048, 2, 8); ADD_BFPG(4, 3, 256, 2048, 2, 4); ADD_BFPG(16, 3, 128, 0, 2, 16); ADD_BFPG(16, 3, 1024, 0, 2, 16);
+  ADD_COPY(16, 7, 512, 0); ADD_COPY(4, 7, 256, 0); ADD_COPY(2, 7, 512, 0);
+  ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPG(8, 3, 512, 0, 2, 8); ADD_BFPG(4, 3, 512, 0, 2, 4); ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPG(1, 3, 512, 0, 2, 1);
+  ADD_BFPG(16, 3, 256, 0, 2, 16); ADD_BFPG(8, 3, 256, 0, 2, 8); ADD_BFPG(4, 3, 256, 0, 2, 4); ADD_BFPG(2, 3, 256, 0, 2, 2); ADD_BFPG(1, 3, 256, 0, 2, 1);
+  ADD_BFPG(2, 3, 128, 0, 2, 2); ADD_BFPG(1, 3, 128, 0, 2, 1); ADD_BFPG(3, 3, 512, 0, 2, 3); ADD_BFPG(6, 3, 512, 0, 2, 6); ADD_BFPG(12, 3, 512, 0, 2, 12);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto& v : vs) for (int i = 0; i < 10; i++) v.run(in[i % NBUF], out[i % NBUF], st);
   CK(hipStreamSynchronize(st));
