@@ -17,9 +17,12 @@ Workloads (one process per GPU, no data-path collective: SURVEY.md §8e)
   Outside the timed region the output shards are RCCL-all_gathered once and rank 0 asserts bit-equality with its own
   whole-tensor result (shard -> op -> concat == op on the whole).
 
-Timing: W eager warm-up steps, the K steps captured into one hipGraph, ONE untimed replay (graph upload, clocks), then R
-timed replays of the same K steps, each bracketed by barrier + synchronize on both sides; per replay the MAX over ranks;
-`ms_per_step` / `value` come from the MEDIAN replay (`config.replays`, `config.replay_ms` list them all).
+Timing: W eager warm-up steps; the K steps are enqueued either as K eager C-ABI calls (K <= 64) or as one replay of a
+hipGraph captured from them (larger K; one untimed replay first: graph upload).  Then R wall-clock regions of exactly K
+steps, each bracketed by barrier + synchronize on both sides, per region the MAX over ranks; `ms_per_step` / `value` come
+from the MEDIAN region (`config.replays`, `config.replay_ms` list them all).  Then R HIP-event regions of the same K steps
+for the roofline (events on the launch stream; a queued device-side delay in front of the first event keeps host enqueue
+latency out of the events).
 
 The JSON line carries
   roofline     : algorithmic bytes per launch / average launch duration, measured with HIP events on the launch stream
@@ -61,10 +64,15 @@ def parse():
     ap.add_argument("--replays", type=int, default=15, help="timed replays of the K-step graph (median reported)")
     ap.add_argument("--nbuf", type=int, default=20, help="c2: distinct in/out buffer pairs (20 x 64 MiB = 1.25 GiB)")
     ap.add_argument("--layers", type=int, default=2, help="llama-shard: distinct layer copies rotated over")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
+                    help="how the K steps are enqueued: one hipGraph replay, or K eager C-ABI calls.  auto = eager up to 64 "
+                         "steps (a graph launch costs ~15 us on the GPU timeline before its first kernel: 0.8 us per step at "
+                         "K = 20, measured), graph beyond (0.3 us per launch less than eager enqueueing)")
+    ap.add_argument("--no-graph", action="store_true", help="same as --launch eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the gather + whole-tensor equality check")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--preroll", type=int, default=0, help="untimed launches queued right in front of each HIP-event region")
     return ap.parse_args()
 
 
@@ -115,7 +123,8 @@ def cpu_baseline(seconds):
         import oracle as O
 
         gomp = ctypes.CDLL("libgomp.so.1")
-        ncores = os.cpu_count() or 1
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncores = max(1, min(ncores, torch.get_num_threads()))
 
         def port_fn():
             return O.bfp_cast(x, PRECISION, BLOCK).to(torch.bfloat16)
@@ -270,6 +279,11 @@ def main():
     L = _lib.lib()  # raises if libdmxq.so is missing: no fallback
     wl = Workload(args, L, _lib, rank, world, dev)
     K, R = args.steps, max(1, args.replays)
+    if args.no_graph:
+        args.launch = "eager"
+    if args.launch == "auto":
+        args.launch = "eager" if K * wl.launches_per_step <= 64 else "graph"
+    args.no_graph = args.launch == "eager"
 
     stream = torch.cuda.Stream(device=dev)
     sp = ctypes.c_void_p(stream.cuda_stream)
@@ -324,6 +338,8 @@ def main():
         for _ in range(R):
             barrier()
             torch.cuda._sleep(delay)
+            for i in range(args.preroll):
+                wl.launch(K + i, sp)
             e0.record(stream)
             run_k()
             e1.record(stream)
@@ -387,7 +403,7 @@ def main():
                        "buffers": (f"{args.nbuf} rotating in/out pairs = {args.nbuf * 2 * ROWS * COLS * 2 / 2**30:.2f} GiB per GPU "
                                    "(> 256 MiB Infinity Cache)") if args.workload != "llama-shard"
                                   else f"{args.layers} rotating layer copies ({wl.bytes_per_step / 2**20:.0f} MiB touched per step on this rank)",
-                       "launch": "eager C-ABI calls" if args.no_graph else "hipGraph replay of the K steps' C-ABI launches",
+                       "launch": "K eager C-ABI calls per region" if args.no_graph else "one hipGraph replay of the K steps' C-ABI launches per region",
                        "launches_per_step": wl.launches_per_step,
                        "replays": R,
                        "replay_ms": [round(w * 1e3, 4) for w in walls],

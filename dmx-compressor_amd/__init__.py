@@ -73,7 +73,7 @@ def _rule_sets():
     f = format
     S, F16, B64 = f.SAME, f.FLOAT16, f.BFP16_64
     conv_like = (nn.Conv1d, nn.Conv2d)
-    act_like = (nn.Softmax, nn.LayerNorm, nn.GELU, nn.ReLU)
+    act_like = (nn.Softmax, nn.LayerNorm, nn.GELU, nn.ReLU, nn.SiLU, nn.QuickGELU, nn.RMSNorm, nn.Exp)
     pools = (nn.MaxPool2d, nn.AvgPool2d)
 
     def wb(inp, w, b, out):

@@ -23,6 +23,7 @@ _vp, _i64, _i32, _u64, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, cty
 # name -> argtypes; mirrors include/dmxq.h one to one (tests/test_abi.py checks header <-> table <-> .so)
 SIGNATURES = {
     "dmxq_bfp_qdq": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _u64, _vp],
+    "dmxq_bfp_qdq_multi": [_vp, _i64, _i32, _i32, _i64, _i32, _i32, _i32, _u64, _vp],
     "dmxq_bfp_qdq_describe": [_i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, ctypes.c_char_p, _i64],
     "dmxq_sbfp_qdq": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "dmxq_mxfp_qdq": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
@@ -42,9 +43,16 @@ SIGNATURES = {
     "dmxq_smoothquant_scale": [_vp, _vp, _i64, _f32, _f32, _vp, _vp],
     "dmxq_scale_channels": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _vp],
     "dmxq_gelu": [_vp, _vp, _i32, _i32, _i64, _i32, _vp],
+    "dmxq_unary": [_vp, _vp, _i32, _i32, _i64, _i32, _f32, _vp],
+    "dmxq_rmsnorm": [_vp, _vp, _i32, _i32, _i64, _i64, _vp, _i32, _f32, _vp],
     "dmxq_softmax": [_vp, _vp, _i32, _i32, _i64, _i64, _f32, _vp],
     "dmxq_layernorm": [_vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _i32, _f32, _vp],
 }
+
+
+class TensorDesc(ctypes.Structure):
+    """dmxq_tensor_desc (include/dmxq.h)"""
+    _fields_ = [("in_", _vp), ("out", _vp), ("outer", _i64), ("L", _i64), ("inner", _i64)]
 
 
 class DmxqError(RuntimeError):

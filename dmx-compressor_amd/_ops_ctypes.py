@@ -1,0 +1,470 @@
+"""ctypes binding of the tensor-level front ends (see ops.py): the C ABI of lib/libdmxq.so called directly, outputs
+allocated with torch.empty, torch's current stream passed as a raw hipStream_t.  Same signatures and results as
+`_ops_torch`; no autograd registration and no meta kernels (not traceable by torch.compile).
+
+No CPU path: a non-GPU tensor or a missing libdmxq.so raises `DmxqError`.
+"""
+import functools
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
+
+__all__ = [
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "softmax", "layernorm",
+    "rmsnorm", "histc",
+]
+
+_SEED_COUNTER = [0x5EED]
+
+
+def _next_seed() -> int:
+    """Stochastic rounding draws from a counter-based stream keyed by (seed, element index); a fresh seed per
+    call, derived from `torch.initial_seed()` (the DEFAULT generator's seed: `torch.manual_seed` makes runs
+    reproducible; a non-default `torch.Generator` is not consulted -- pass `seed=` explicitly for that).
+
+    The seed is a kernel ARGUMENT, so a hipGraph capture would freeze it and every replay would repeat the same
+    draws (accumulated rounding would no longer be unbiased): implicit seeding is refused while the current stream is
+    capturing.  An explicit `seed=` is the caller's statement that frozen draws are intended."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise DmxqError("stochastic rounding with an implicit seed inside a hipGraph capture: the seed would be frozen "
+                        "into the graph and every replay would reuse the same random draws; pass seed= explicitly or "
+                        "keep stochastic casts outside the captured region")
+    _SEED_COUNTER[0] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _SEED_COUNTER[0]) & 0xFFFFFFFFFFFFFFFF
+
+
+def _prep(x: torch.Tensor, what: str) -> torch.Tensor:
+    require_gpu(x, what)
+    dtype_code(x.dtype)
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def bfp_qdq(x, precision: int, block_size: int, block_dim: int = -1, symmetric: bool = True,
+            rounding: str = "nearest", out_dtype: Optional[torch.dtype] = None, seed: Optional[int] = None):
+    """BlockFloatingPoint Q->DQ of a whole tensor in one launch (numerical/format.py:304-343 semantics).
+    Blocks run along `block_dim`; output has x's shape, contiguous, dtype `out_dtype` (default x.dtype)."""
+    xc = _prep(x, "bfp_qdq")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    if xc.dim() == 0:
+        outer, L, inner = 1, 1, 1
+    else:
+        outer, L, inner = split3(xc.shape, block_dim)
+    seed = _next_seed() if (seed is None and rounding == "stochastic") else (seed or 0)
+    check(lib().dmxq_bfp_qdq(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), outer, L, inner,
+                             block_size, precision, _lib.ROUNDING_CODE[rounding], int(symmetric), seed, stream_of(xc)),
+          "dmxq_bfp_qdq")
+    return out
+
+
+def block_quantize(a2d, wl: int, symmetric: bool = True, rounding: str = "nearest", seed: Optional[int] = None):
+    """The pybind seam on a [rows, L] float32 view, one block per row (quant_cpu.cpp:299-311).  symmetric False is the
+    NATIVE asymmetric branch (:247-253), which is not the asymmetric FORMAT of bfp_qdq(symmetric=False)."""
+    xc = _prep(a2d, "block_quantize")
+    out = torch.empty_like(xc)
+    seed = _next_seed() if (seed is None and rounding == "stochastic") else (seed or 0)
+    check(lib().dmxq_bfp_qdq(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), xc.shape[0], xc.shape[1], 1,
+                             max(xc.shape[1], 2), wl, _lib.ROUNDING_CODE[rounding], 1 if symmetric else 2, seed,
+                             stream_of(xc)), "dmxq_bfp_qdq")
+    return out
+
+
+def bfp_qdq_multi(tensors, precision: int, block_size: int, block_dim: int = -1, symmetric: bool = True,
+                  rounding: str = "nearest", out_dtype: Optional[torch.dtype] = None, seed: Optional[int] = None):
+    """BFP Q->DQ of MANY tensors of one dtype on one device in as few launches as possible (`dmxq_bfp_qdq_multi`): the
+    same results as `[bfp_qdq(t, ...) for t in tensors]`.  Made for the many small weights of a model (each of them is
+    launch-bound on its own)."""
+    tensors = list(tensors)
+    if not tensors:
+        return []
+    xs = [_prep(t, "bfp_qdq_multi") for t in tensors]
+    dt, dev = xs[0].dtype, xs[0].device
+    if any(x.dtype != dt or x.device != dev for x in xs):
+        raise ValueError("bfp_qdq_multi: all tensors must share one dtype and one device")
+    outs = [torch.empty(x.shape, dtype=out_dtype or dt, device=dev) for x in xs]
+    descs = (_lib.TensorDesc * len(xs))()
+    for d, x, o in zip(descs, xs, outs):
+        outer, L, inner = split3(x.shape, block_dim) if x.dim() else (1, 1, 1)
+        d.in_, d.out, d.outer, d.L, d.inner = x.data_ptr(), o.data_ptr(), outer, L, inner
+    seed = _next_seed() if (seed is None and rounding == "stochastic") else (seed or 0)
+    with torch.cuda.device(dev):
+        check(lib().dmxq_bfp_qdq_multi(descs, len(xs), dtype_code(dt), dtype_code(outs[0].dtype), block_size, precision,
+                                       _lib.ROUNDING_CODE[rounding], int(symmetric), seed, stream_of(xs[0])),
+              "dmxq_bfp_qdq_multi")
+    return outs
+
+
+def bfp_pack(x, precision: int, block_size: int, symmetric: bool = True):
+    """Packed on-wire BFP of a tensor blocked along its last dim: (int8 mantissa codes, same shape; uint8 shared
+    exponents, [..., ceil(L / block_size)]).  bfp_unpack(*bfp_pack(x)) == bfp_qdq(x)."""
+    xc = _prep(x, "bfp_pack")
+    L = xc.shape[-1] if xc.dim() else 1
+    rows = xc.numel() // max(L, 1)
+    nblk = -(-L // block_size)
+    mant = torch.empty(xc.shape, dtype=torch.int8, device=xc.device)
+    exps = torch.empty(tuple(xc.shape[:-1]) + (nblk,), dtype=torch.uint8, device=xc.device)
+    check(lib().dmxq_bfp_pack(ptr(xc), dtype_code(xc.dtype), ptr(mant), ptr(exps), rows, L, block_size, precision,
+                              int(symmetric), stream_of(xc)), "dmxq_bfp_pack")
+    return mant, exps
+
+
+def bfp_unpack(mant, exps, precision: int, block_size: int, out_dtype: torch.dtype = torch.float32):
+    require_gpu(mant, "bfp_unpack")
+    m, e = mant.contiguous(), exps.contiguous()
+    L = m.shape[-1] if m.dim() else 1
+    rows = m.numel() // max(L, 1)
+    out = torch.empty(m.shape, dtype=out_dtype, device=m.device)
+    check(lib().dmxq_bfp_unpack(ptr(m), ptr(e), ptr(out), dtype_code(out_dtype), rows, L, block_size, precision,
+                                stream_of(m)), "dmxq_bfp_unpack")
+    return out
+
+
+def weight_hypernet(w, precision: int, block_size: int, symmetric: bool = True, score=None, K: int = 0, M: int = 0,
+                    sq_scale=None, out_dtype: Optional[torch.dtype] = None):
+    """Fused N:M mask -> SmoothQuant scale -> BFP Q->DQ over a weight blocked along its last dim (one launch).
+    Returns None when the geometry / dtype combination is not fusable (the caller runs the unfused chain)."""
+    wc = _prep(w, "weight_hypernet")
+    L = wc.shape[-1] if wc.dim() else 1
+    rows = wc.numel() // max(L, 1)
+    sc = _prep(score, "weight_hypernet") if (score is not None and M) else None
+    if sc is not None and sc.shape != wc.shape:
+        return None
+    t1 = torch.promote_types(wc.dtype, sc.dtype) if sc is not None else wc.dtype
+    od = out_dtype or t1
+    out = torch.empty(wc.shape, dtype=od, device=wc.device)
+    sq = sq_scale.detach().to(device=wc.device, dtype=torch.float32).contiguous() if sq_scale is not None else None
+    if sq is not None and sq.numel() != L:
+        return None
+    rc = lib().dmxq_weight_hypernet(ptr(wc), dtype_code(wc.dtype), ptr(sc), dtype_code(sc.dtype) if sc is not None else 0,
+                                    K, M if sc is not None else 0, ptr(sq), ptr(out), dtype_code(od), rows, L, block_size,
+                                    precision, int(symmetric), stream_of(wc))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    check(rc, "dmxq_weight_hypernet")
+    return out
+
+
+def sbfp_qdq(x, precision: int, block_size: int, scaler_man: int, scaler_exp: int, scaler_bias: int,
+             scaler_flush: bool = True, clamp: bool = True, symmetric: bool = True, block_dim: int = -1,
+             out_dtype: Optional[torch.dtype] = None):
+    """ScaledBlockFloatingPoint Q->DQ (numerical/format.py:453-479), one launch."""
+    xc = _prep(x, "sbfp_qdq")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    outer, L, inner = split3(xc.shape, block_dim) if xc.dim() else (1, 1, 1)
+    check(lib().dmxq_sbfp_qdq(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), outer, L, inner, block_size,
+                              precision, int(clamp), int(symmetric), scaler_man, scaler_exp, scaler_bias,
+                              int(scaler_flush), stream_of(xc)), "dmxq_sbfp_qdq")
+    return out
+
+
+def mxfp_qdq(x, man: int, exp: int, block_size: int, block_dim: int = -1, out_dtype: Optional[torch.dtype] = None):
+    """MXFP Q->DQ (numerical/format.py:545-564), one launch."""
+    xc = _prep(x, "mxfp_qdq")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    outer, L, inner = split3(xc.shape, block_dim) if xc.dim() else (1, 1, 1)
+    check(lib().dmxq_mxfp_qdq(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), outer, L, inner, block_size,
+                              man, exp, stream_of(xc)), "dmxq_mxfp_qdq")
+    return out
+
+
+def float_qdq(x, man: int, exp: int, bias: int, flush_subnormal: bool, unsigned: bool = False,
+              rounding: str = "nearest", out_dtype: Optional[torch.dtype] = None, seed: Optional[int] = None):
+    """Low-bit float Q->DQ (quant/quant_function.py:120-152 semantics), one launch."""
+    xc = _prep(x, "float_qdq")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    seed = _next_seed() if (seed is None and rounding == "stochastic") else (seed or 0)
+    check(lib().dmxq_float_qdq(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), xc.numel(), man, exp,
+                               bias, int(flush_subnormal), int(unsigned), _lib.ROUNDING_CODE[rounding], seed,
+                               stream_of(xc)), "dmxq_float_qdq")
+    return out
+
+
+def fixed_qdq(x, precision: int, fraction: int, clamp: bool = True, symmetric: bool = True, rounding: str = "nearest",
+              scale: Optional[torch.Tensor] = None, zero_point: Optional[torch.Tensor] = None,
+              ch_axis: Optional[int] = None, group_size: Optional[int] = None,
+              out_dtype: Optional[torch.dtype] = None, seed: Optional[int] = None):
+    """Fixed-point Q->DQ with the affine wrapper of numerical/cast.py:278-296 fused in, one launch.
+    scale None: bare FixedPoint.cast.  ch_axis None: per-tensor scale; else per-channel (group_size None) or
+    per-group slabs of `group_size` channels."""
+    xc = _prep(x, "fixed_qdq")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    sc = zp = None
+    outer, C, inner, gs = 1, 1, xc.numel(), 1
+    if scale is not None:
+        sc = scale.detach().to(device=xc.device, dtype=torch.float32).contiguous()
+        zp = zero_point.detach().to(device=xc.device, dtype=torch.int64).contiguous()
+        if ch_axis is not None and xc.dim() > 0:
+            outer, C, inner = split3(xc.shape, ch_axis)
+            gs = group_size or 1
+            need = -(-C // gs)
+        else:
+            need = 1
+        if sc.numel() < need or zp.numel() < need:
+            raise ValueError(f"fixed_qdq: need {need} scale/zero_point entries, got {sc.numel()}/{zp.numel()}")
+    seed = _next_seed() if (seed is None and rounding == "stochastic") else (seed or 0)
+    check(lib().dmxq_fixed_qdq(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), outer, C, inner,
+                               precision, fraction, int(clamp), int(symmetric), _lib.ROUNDING_CODE[rounding],
+                               ptr(sc), ptr(zp), gs, seed, stream_of(xc)), "dmxq_fixed_qdq")
+    return out
+
+
+def _nm(score, x, K, M, block_dim, want_mask, want_y, mask_dtype, y_dtype):
+    sc = _prep(score, "nm_mask")
+    if sc.dim() == 0 or sc.shape[block_dim] % M != 0:
+        # sparse.py:166-168
+        raise AssertionError(
+            f"score has size {tuple(sc.shape)} at dimension {block_dim}, not a multiple of block size {M}")
+    outer, L, inner = split3(sc.shape, block_dim)
+    xc = None
+    if want_y:
+        xc = _prep(x, "nm_sparsify")
+        if xc.shape != sc.shape:
+            xc = xc.expand(sc.shape).contiguous()
+    mask = torch.empty(sc.shape, dtype=mask_dtype or sc.dtype, device=sc.device) if want_mask else None
+    y = torch.empty(sc.shape, dtype=y_dtype, device=sc.device) if want_y else None
+    check(lib().dmxq_nm_mask(ptr(sc), dtype_code(sc.dtype), ptr(xc), dtype_code(xc.dtype) if want_y else 0,
+                             ptr(mask), dtype_code(mask.dtype) if want_mask else 0,
+                             ptr(y), dtype_code(y.dtype) if want_y else 0, outer, L, inner, K, M, stream_of(sc)),
+          "dmxq_nm_mask")
+    return mask, y
+
+
+def _topk(score, x, density, want_mask, want_y, mask_dtype, y_dtype):
+    sc = _prep(score, "topk_mask")
+    n = sc.numel()
+    n_zero = int(n * (1.0 - density))  # sparse.py:116
+    xc = None
+    if want_y:
+        xc = _prep(x, "topk_sparsify")
+        if xc.shape != sc.shape:
+            xc = xc.expand(sc.shape).contiguous()
+    mask = torch.empty(sc.shape, dtype=mask_dtype or sc.dtype, device=sc.device) if want_mask else None
+    y = torch.empty(sc.shape, dtype=y_dtype, device=sc.device) if want_y else None
+    ws = torch.empty(max(1, (lib().dmxq_topk_workspace_bytes(n) + 7) // 8), dtype=torch.int64, device=sc.device)
+    check(lib().dmxq_topk_mask(ptr(sc), dtype_code(sc.dtype), ptr(xc), dtype_code(xc.dtype) if want_y else 0,
+                               ptr(mask), dtype_code(mask.dtype) if want_mask else 0,
+                               ptr(y), dtype_code(y.dtype) if want_y else 0, n, n_zero, ptr(ws), stream_of(sc)),
+          "dmxq_topk_mask")
+    return mask, y
+
+
+def topk_mask(score, density: float, mask_dtype: Optional[torch.dtype] = None):
+    """Global top-k mask (sparse.py:109-123): the int(n * (1 - density)) lowest scores are zeroed; float mask in the
+    score's dtype.  No sort: a radix select + one masking pass (csrc/topk.hip)."""
+    return _topk(score, None, density, True, False, mask_dtype, None)[0]
+
+
+def topk_sparsify(x, score, density: float, return_mask: bool = False):
+    """x * topk_mask(score) in the same final pass (sparse.py:300), torch's type promotion for the product."""
+    mask, y = _topk(score, x, density, return_mask, True, None, torch.promote_types(x.dtype, score.dtype))
+    return (y, mask) if return_mask else y
+
+
+def bernoulli_mask(score, seed: Optional[int] = None, mask_dtype: Optional[torch.dtype] = None):
+    """Bernoulli supermask (sparse.py:201-221): 1 with probability score."""
+    sc = _prep(score, "bernoulli_mask")
+    mask = torch.empty(sc.shape, dtype=mask_dtype or sc.dtype, device=sc.device)
+    check(lib().dmxq_bernoulli_mask(ptr(sc), ptr(mask), dtype_code(sc.dtype), dtype_code(mask.dtype), sc.numel(),
+                                    _next_seed() if seed is None else seed, stream_of(sc)), "dmxq_bernoulli_mask")
+    return mask
+
+
+def nm_mask(score, K: int, M: int, block_dim: int = -1, mask_dtype: Optional[torch.dtype] = None):
+    """N:M mask (sparse.py:163-180): float mask in the score's dtype."""
+    return _nm(score, None, K, M, block_dim, True, False, mask_dtype, None)[0]
+
+
+def nm_sparsify(x, score, K: int, M: int, block_dim: int = -1, out_dtype: Optional[torch.dtype] = None,
+                return_mask: bool = False):
+    """Fused mask + apply: y = x * mask(score) (sparse.py:287-301); out dtype defaults to torch's promotion of
+    (x.dtype, score.dtype), i.e. what `x * mask` yields in the reference."""
+    yd = out_dtype or torch.promote_types(x.dtype, score.dtype)
+    mask, y = _nm(score, x, K, M, block_dim, return_mask, True, None, yd)
+    return (y, mask) if return_mask else y
+
+
+def group_minmax(x, ch_axis: int, group_size: int):
+    """Per-group (slabs of `group_size` channels along ch_axis) min and max: two float32 [G] tensors."""
+    xc = _prep(x, "group_minmax")
+    outer, C, inner = split3(xc.shape, ch_axis)
+    G = -(-C // group_size)
+    mn = torch.empty(G, dtype=torch.float32, device=xc.device)
+    mx = torch.empty(G, dtype=torch.float32, device=xc.device)
+    check(lib().dmxq_group_minmax(ptr(xc), dtype_code(xc.dtype), outer, C, inner, group_size, ptr(mn), ptr(mx),
+                                  stream_of(xc)), "dmxq_group_minmax")
+    return mn, mx
+
+
+def qparams(mn, mx, qmin: int, qmax: int, symmetric_qscheme: bool):
+    """(min,max) -> (scale fp32, zero_point int64), numerical/observer.py:59-115."""
+    require_gpu(mn, "qparams")
+    mn = mn.to(torch.float32).contiguous()
+    mx = mx.to(torch.float32).contiguous()
+    scale = torch.empty_like(mn)
+    zp = torch.empty(mn.shape, dtype=torch.int64, device=mn.device)
+    check(lib().dmxq_qparams(ptr(mn), ptr(mx), mn.numel(), qmin, qmax, int(symmetric_qscheme), ptr(scale), ptr(zp),
+                             stream_of(mn)), "dmxq_qparams")
+    return scale, zp
+
+
+def histc(x, bins: int, lo: float = 0.0, hi: float = 0.0):
+    """torch.histc(x, bins, min=lo, max=hi) as the HistogramObserver uses it (numerical/observer.py:470-472,
+    489-491): float32 [bins] counts.  lo == hi selects the data's own range, widened by one either side when the
+    data is constant (torch.histc's convention)."""
+    xc = _prep(x, "histc").reshape(-1)
+    lo, hi = float(lo), float(hi)
+    if lo == hi and xc.numel():
+        mn, mx = group_minmax(xc.reshape(1, -1), 0, 1)
+        lo, hi = float(mn), float(mx)
+        if lo == hi:
+            lo, hi = lo - 1.0, hi + 1.0
+    out = torch.empty(int(bins), dtype=torch.float32, device=xc.device)
+    if xc.numel() == 0 and not lo < hi:
+        return out.zero_()
+    check(lib().dmxq_histc(ptr(xc), dtype_code(xc.dtype), xc.numel(), int(bins), lo, hi, ptr(out), stream_of(xc)),
+          "dmxq_histc")
+    return out
+
+
+def channel_maxabs(x, ch_axis: int):
+    """max|x| per channel along ch_axis (numerical/smoothquant.py:285-299): float32 [C]."""
+    xc = _prep(x, "channel_maxabs")
+    outer, C, inner = split3(xc.shape, ch_axis)
+    out = torch.empty(C, dtype=torch.float32, device=xc.device)
+    check(lib().dmxq_channel_maxabs(ptr(xc), dtype_code(xc.dtype), outer, C, inner, ptr(out), stream_of(xc)),
+          "dmxq_channel_maxabs")
+    return out
+
+
+def smoothquant_scale(a_maxabs, b_maxabs, alpha: float, scale_min: float = 1e-5):
+    require_gpu(a_maxabs, "smoothquant_scale")
+    a = a_maxabs.to(torch.float32).contiguous()
+    b = b_maxabs.to(device=a.device, dtype=torch.float32).contiguous()
+    out = torch.empty_like(a)
+    check(lib().dmxq_smoothquant_scale(ptr(a), ptr(b), a.numel(), float(alpha), float(scale_min), ptr(out),
+                                       stream_of(a)), "dmxq_smoothquant_scale")
+    return out
+
+
+def scale_channels(x, scale, ch_axis: int, divide: bool, out_dtype: Optional[torch.dtype] = None):
+    xc = _prep(x, "scale_channels")
+    outer, C, inner = split3(xc.shape, ch_axis)
+    sc = scale.detach().to(device=xc.device, dtype=torch.float32).contiguous()
+    if sc.numel() != C:
+        raise ValueError(f"scale_channels: scale has {sc.numel()} entries for {C} channels")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    check(lib().dmxq_scale_channels(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), outer, C, inner,
+                                    ptr(sc), int(divide), stream_of(xc)), "dmxq_scale_channels")
+    return out
+
+
+def gelu(x, approximate: str = "none", out_dtype: Optional[torch.dtype] = None):
+    xc = _prep(x, "gelu")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    check(lib().dmxq_gelu(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), xc.numel(),
+                          int(approximate == "tanh"), stream_of(xc)), "dmxq_gelu")
+    return out
+
+
+UNARY_GELU, UNARY_GELU_TANH, UNARY_SILU, UNARY_QUICK_GELU, UNARY_EXP, UNARY_SILU_EXPERIMENTAL = range(6)
+
+
+def _unary(x, kind: int, param: float = 0.0, out_dtype: Optional[torch.dtype] = None):
+    xc = _prep(x, "unary")
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    check(lib().dmxq_unary(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), xc.numel(), kind, float(param),
+                           stream_of(xc)), "dmxq_unary")
+    return out
+
+
+def silu(x, out_dtype: Optional[torch.dtype] = None):
+    """torch.nn.functional.silu (modeling/nn/torch_modules.py:1559-1576), exact function."""
+    return _unary(x, UNARY_SILU, 0.0, out_dtype)
+
+
+def quick_gelu(x, out_dtype: Optional[torch.dtype] = None):
+    """transformers' QuickGELUActivation `x * sigmoid(1.702 * x)` in the input dtype (custom_modules.py:112-117)."""
+    return _unary(x, UNARY_QUICK_GELU, 0.0, out_dtype)
+
+
+def exp(x, out_dtype: Optional[torch.dtype] = None):
+    """torch.exp (modeling/nn/torch_modules.py:236-242 Exp)."""
+    return _unary(x, UNARY_EXP, 0.0, out_dtype)
+
+
+def silu_experimental(x, scale: float):
+    """the reference's `experimental.silu` (functional/functions.py:7-21): relu(x.to(float16)) * scale -> float16"""
+    return _unary(x, UNARY_SILU_EXPERIMENTAL, scale, torch.float16)
+
+
+def softmax(x, dim: int = -1, input_clamp: Optional[float] = None, out_dtype: Optional[torch.dtype] = None):
+    require_gpu(x, "softmax")
+    d = dim % x.dim()
+    xt = x if d == x.dim() - 1 else x.transpose(d, -1)
+    xc = xt.contiguous()
+    cols = xc.shape[-1]
+    rows = xc.numel() // max(cols, 1)
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    check(lib().dmxq_softmax(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), rows, cols,
+                             float(input_clamp) if input_clamp is not None else -math.inf, stream_of(xc)),
+          "dmxq_softmax")
+    return out if d == x.dim() - 1 else out.transpose(d, -1)
+
+
+def layernorm(x, normalized_shape, weight=None, bias=None, eps: float = 1e-5,
+              out_dtype: Optional[torch.dtype] = None):
+    xc = _prep(x, "layernorm")
+    cols = 1
+    for s in (normalized_shape if not isinstance(normalized_shape, int) else (normalized_shape,)):
+        cols *= s
+    rows = xc.numel() // max(cols, 1)
+    w = weight.detach().contiguous() if weight is not None else None
+    b = bias.detach().contiguous() if bias is not None else None
+    if w is not None and b is not None and w.dtype != b.dtype:
+        b = b.to(w.dtype)
+    wb_dtype = dtype_code((w if w is not None else b).dtype) if (w is not None or b is not None) else 0
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    check(lib().dmxq_layernorm(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), rows, cols, ptr(w),
+                               ptr(b), wb_dtype, float(eps), stream_of(xc)), "dmxq_layernorm")
+    return out
+
+
+def rmsnorm(x, normalized_shape, weight=None, eps: Optional[float] = None, out_dtype: Optional[torch.dtype] = None):
+    """torch.nn.functional.rms_norm over the trailing `normalized_shape` (modeling/nn/torch_modules.py:1144-1170);
+    eps None = torch.finfo(x.dtype).eps, as torch."""
+    xc = _prep(x, "rmsnorm")
+    cols = 1
+    for s_ in (normalized_shape if not isinstance(normalized_shape, int) else (normalized_shape,)):
+        cols *= s_
+    rows = xc.numel() // max(cols, 1)
+    w = weight.detach().contiguous() if weight is not None else None
+    out = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+    eps = torch.finfo(xc.dtype).eps if eps is None else eps
+    check(lib().dmxq_rmsnorm(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), rows, cols, ptr(w),
+                             dtype_code(w.dtype) if w is not None else 0, float(eps), stream_of(xc)), "dmxq_rmsnorm")
+    return out
+
+
+def _on_tensor_device(fn):
+    """HIP launches go to the CURRENT device: a tensor that lives on another GPU of this process (single-process
+    multi-GPU, device_map pipeline splits) needs its device made current around the C-ABI call (include/dmxq.h
+    conventions), exactly like torch's own kernels do with a device guard.  One integer compare when it already is."""
+
+    @functools.wraps(fn)
+    def guarded(x, *args, **kwargs):
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):
+                return fn(x, *args, **kwargs)
+        return fn(x, *args, **kwargs)
+
+    return guarded
+
+
+for _name in __all__:
+    if _name != "bfp_qdq_multi":  # (takes a list; switches device itself)
+        globals()[_name] = _on_tensor_device(globals()[_name])
+del _name

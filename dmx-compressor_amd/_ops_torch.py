@@ -1,0 +1,325 @@
+"""torch-extension binding of the tensor-level front ends (see ops.py): `torch.ops.dmxq.*`, registered by
+`lib/dmxq_torch.so` (csrc/torch_binding.cpp: device guard, torch's current HIP stream, output allocation, one C-ABI call
+per op, meta kernels).  This module adds what belongs on the Python side: argument spelling (rounding names, torch
+dtypes), the `DmxqError` for non-GPU tensors, seeds for stochastic rounding, and the straight-through-estimator backward
+(`torch.library.register_autograd`) of the fake-quantisation ops -- the reference's CastToFormat / STE
+(numerical/cast.py:19-55: `grad_output` passed through unchanged).
+
+No CPU path: a non-GPU tensor or a missing library raises `DmxqError`.
+"""
+import math
+import os
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import DmxqError, ROUNDING_CODE, require_gpu
+
+__all__ = [
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "softmax", "layernorm",
+    "rmsnorm", "histc",
+]
+
+TORCH_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "dmxq_torch.so")
+
+
+def _load():
+    _lib.lib()  # libdmxq.so first (raises DmxqError when it has not been built): dmxq_torch.so links against it
+    if not os.path.exists(TORCH_LIB_PATH):
+        raise DmxqError(f"{TORCH_LIB_PATH} not found: build the torch extension first (python dmx-compressor_amd/build.py or "
+                        "__graft_entry__.build()), or set DMXQ_BINDING=ctypes for the compiler-free binding")
+    torch.ops.load_library(TORCH_LIB_PATH)
+    return torch.ops.dmxq
+
+
+_ops = _load()
+
+
+# ---------------------------------------------------------------------------------------------------- autograd (STE)
+def _ste_setup(ctx, inputs, output):
+    ctx.in_dtype = inputs[0].dtype
+
+
+def _ste_backward(n_args):
+    def backward(ctx, g):
+        if g is not None and g.dtype != ctx.in_dtype:
+            g = g.to(ctx.in_dtype)
+        return (g,) + (None,) * (n_args - 1)
+
+    return backward
+
+
+for _name, _n in (("bfp_qdq", 8), ("sbfp_qdq", 11), ("mxfp_qdq", 6), ("float_qdq", 9), ("fixed_qdq", 12)):
+    torch.library.register_autograd(f"dmxq::{_name}", _ste_backward(_n), setup_context=_ste_setup)
+del _name, _n
+
+_SEED_COUNTER = [0x5EED]
+
+
+def _next_seed() -> int:
+    """Stochastic rounding draws from a counter-based stream keyed by (seed, element index); a fresh seed per call,
+    derived from `torch.initial_seed()` (the DEFAULT generator's seed: `torch.manual_seed` makes runs reproducible; a
+    non-default `torch.Generator` is not consulted -- pass `seed=` explicitly for that).
+
+    The seed is a kernel ARGUMENT, so a hipGraph capture would freeze it and every replay would repeat the same draws
+    (accumulated rounding would no longer be unbiased): implicit seeding is refused while the current stream is
+    capturing.  An explicit `seed=` is the caller's statement that frozen draws are intended."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise DmxqError("stochastic rounding with an implicit seed inside a hipGraph capture: the seed would be frozen "
+                        "into the graph and every replay would reuse the same random draws; pass seed= explicitly or "
+                        "keep stochastic casts outside the captured region")
+    _SEED_COUNTER[0] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _SEED_COUNTER[0]) & 0xFFFFFFFFFFFFFFFF
+
+
+def _seed_arg(seed, rounding):
+    s = _next_seed() if (seed is None and rounding == "stochastic") else (seed or 0)
+    return s - (1 << 64) if s >= (1 << 63) else s  # the schema's int is int64: same 64 bits
+
+
+# ---------------------------------------------------------------------------------------------------- block formats
+def bfp_qdq(x, precision: int, block_size: int, block_dim: int = -1, symmetric: bool = True,
+            rounding: str = "nearest", out_dtype: Optional[torch.dtype] = None, seed: Optional[int] = None):
+    """BlockFloatingPoint Q->DQ of a whole tensor in one launch (numerical/format.py:304-343 semantics).
+    Blocks run along `block_dim`; output has x's shape, contiguous, dtype `out_dtype` (default x.dtype)."""
+    require_gpu(x, "bfp_qdq")
+    return _ops.bfp_qdq(x, precision, block_size, block_dim, symmetric, ROUNDING_CODE[rounding], out_dtype, _seed_arg(seed, rounding))
+
+
+def block_quantize(a2d, wl: int, symmetric: bool = True, rounding: str = "nearest", seed: Optional[int] = None):
+    """The pybind seam on a [rows, L] float32 view, one block per row (quant_cpu.cpp:299-311).  symmetric False is the
+    NATIVE asymmetric branch (:247-253), which is not the asymmetric FORMAT of bfp_qdq(symmetric=False)."""
+    require_gpu(a2d, "block_quantize")
+    return _ops.block_quantize(a2d, wl, symmetric, ROUNDING_CODE[rounding], _seed_arg(seed, rounding))
+
+
+def bfp_qdq_multi(tensors, precision: int, block_size: int, block_dim: int = -1, symmetric: bool = True,
+                  rounding: str = "nearest", out_dtype: Optional[torch.dtype] = None, seed: Optional[int] = None):
+    """BFP Q->DQ of MANY tensors of one dtype on one device in as few launches as possible (`dmxq_bfp_qdq_multi`): the
+    same results as `[bfp_qdq(t, ...) for t in tensors]`."""
+    tensors = list(tensors)
+    for t in tensors:
+        require_gpu(t, "bfp_qdq_multi")
+    if tensors and any(t.dtype != tensors[0].dtype or t.device != tensors[0].device for t in tensors):
+        raise ValueError("bfp_qdq_multi: all tensors must share one dtype and one device")
+    return list(_ops.bfp_qdq_multi(tensors, precision, block_size, block_dim, symmetric, ROUNDING_CODE[rounding], out_dtype,
+                                   _seed_arg(seed, rounding)))
+
+
+def bfp_pack(x, precision: int, block_size: int, symmetric: bool = True):
+    """Packed on-wire BFP of a tensor blocked along its last dim: (int8 mantissa codes, same shape; uint8 shared
+    exponents, [..., ceil(L / block_size)]).  bfp_unpack(*bfp_pack(x)) == bfp_qdq(x)."""
+    require_gpu(x, "bfp_pack")
+    return _ops.bfp_pack(x, precision, block_size, symmetric)
+
+
+def bfp_unpack(mant, exps, precision: int, block_size: int, out_dtype: torch.dtype = torch.float32):
+    require_gpu(mant, "bfp_unpack")
+    return _ops.bfp_unpack(mant, exps, precision, block_size, out_dtype)
+
+
+def weight_hypernet(w, precision: int, block_size: int, symmetric: bool = True, score=None, K: int = 0, M: int = 0,
+                    sq_scale=None, out_dtype: Optional[torch.dtype] = None):
+    """Fused N:M mask -> SmoothQuant scale -> BFP Q->DQ over a weight blocked along its last dim (one launch).
+    Returns None when the geometry / dtype combination is not fusable (the caller runs the unfused chain)."""
+    require_gpu(w, "weight_hypernet")
+    try:
+        return _ops.weight_hypernet(w, precision, block_size, symmetric, score if M else None, K, M if score is not None else 0,
+                                    sq_scale, out_dtype)
+    except NotImplementedError:
+        return None
+
+
+def sbfp_qdq(x, precision: int, block_size: int, scaler_man: int, scaler_exp: int, scaler_bias: int,
+             scaler_flush: bool = True, clamp: bool = True, symmetric: bool = True, block_dim: int = -1,
+             out_dtype: Optional[torch.dtype] = None):
+    """ScaledBlockFloatingPoint Q->DQ (numerical/format.py:453-479), one launch."""
+    require_gpu(x, "sbfp_qdq")
+    return _ops.sbfp_qdq(x, precision, block_size, scaler_man, scaler_exp, scaler_bias, scaler_flush, clamp, symmetric, block_dim,
+                         out_dtype)
+
+
+def mxfp_qdq(x, man: int, exp: int, block_size: int, block_dim: int = -1, out_dtype: Optional[torch.dtype] = None):
+    """MXFP Q->DQ (numerical/format.py:545-564), one launch."""
+    require_gpu(x, "mxfp_qdq")
+    return _ops.mxfp_qdq(x, man, exp, block_size, block_dim, out_dtype)
+
+
+# ---------------------------------------------------------------------------------------------------- element formats
+def float_qdq(x, man: int, exp: int, bias: int, flush_subnormal: bool, unsigned: bool = False,
+              rounding: str = "nearest", out_dtype: Optional[torch.dtype] = None, seed: Optional[int] = None):
+    """Low-bit float Q->DQ (quant/quant_function.py:120-152 semantics), one launch."""
+    require_gpu(x, "float_qdq")
+    return _ops.float_qdq(x, man, exp, bias, flush_subnormal, unsigned, ROUNDING_CODE[rounding], out_dtype, _seed_arg(seed, rounding))
+
+
+def fixed_qdq(x, precision: int, fraction: int, clamp: bool = True, symmetric: bool = True, rounding: str = "nearest",
+              scale: Optional[torch.Tensor] = None, zero_point: Optional[torch.Tensor] = None,
+              ch_axis: Optional[int] = None, group_size: Optional[int] = None,
+              out_dtype: Optional[torch.dtype] = None, seed: Optional[int] = None):
+    """Fixed-point Q->DQ with the affine wrapper of numerical/cast.py:278-296 fused in, one launch.
+    scale None: bare FixedPoint.cast.  ch_axis None: per-tensor scale; else per-channel (group_size None) or
+    per-group slabs of `group_size` channels."""
+    require_gpu(x, "fixed_qdq")
+    return _ops.fixed_qdq(x, precision, fraction, clamp, symmetric, ROUNDING_CODE[rounding], scale, zero_point, ch_axis,
+                          group_size or None, out_dtype, _seed_arg(seed, rounding))
+
+
+# ---------------------------------------------------------------------------------------------------- sparsity
+def _nm(score, x, K, M, block_dim, want_mask, want_y, mask_dtype, y_dtype):
+    require_gpu(score, "nm_mask")
+    if score.dim() == 0 or score.shape[block_dim] % M != 0:
+        # sparse.py:166-168
+        raise AssertionError(
+            f"score has size {tuple(score.shape)} at dimension {block_dim}, not a multiple of block size {M}")
+    mask, y = _ops.nm_mask(score, x, K, M, block_dim, want_mask, want_y, mask_dtype, y_dtype)
+    return (mask if want_mask else None), (y if want_y else None)
+
+
+def nm_mask(score, K: int, M: int, block_dim: int = -1, mask_dtype: Optional[torch.dtype] = None):
+    """N:M mask (sparse.py:163-180): float mask in the score's dtype."""
+    return _nm(score, None, K, M, block_dim, True, False, mask_dtype, None)[0]
+
+
+def nm_sparsify(x, score, K: int, M: int, block_dim: int = -1, out_dtype: Optional[torch.dtype] = None,
+                return_mask: bool = False):
+    """Fused mask + apply: y = x * mask(score) (sparse.py:287-301); out dtype defaults to torch's promotion of
+    (x.dtype, score.dtype), i.e. what `x * mask` yields in the reference."""
+    require_gpu(x, "nm_sparsify")
+    mask, y = _nm(score, x, K, M, block_dim, return_mask, True, None, out_dtype)
+    return (y, mask) if return_mask else y
+
+
+def _topk(score, x, density, want_mask, want_y, mask_dtype, y_dtype):
+    require_gpu(score, "topk_mask")
+    n_zero = int(score.numel() * (1.0 - density))  # sparse.py:116
+    mask, y = _ops.topk_mask(score, x, n_zero, want_mask, want_y, mask_dtype, y_dtype)
+    return (mask if want_mask else None), (y if want_y else None)
+
+
+def topk_mask(score, density: float, mask_dtype: Optional[torch.dtype] = None):
+    """Global top-k mask (sparse.py:109-123): the int(n * (1 - density)) lowest scores are zeroed; float mask in the
+    score's dtype.  No sort: a radix select + one masking pass (csrc/topk.hip)."""
+    return _topk(score, None, density, True, False, mask_dtype, None)[0]
+
+
+def topk_sparsify(x, score, density: float, return_mask: bool = False):
+    """x * topk_mask(score) in the same final pass (sparse.py:300), torch's type promotion for the product."""
+    require_gpu(x, "topk_sparsify")
+    mask, y = _topk(score, x, density, return_mask, True, None, None)
+    return (y, mask) if return_mask else y
+
+
+def bernoulli_mask(score, seed: Optional[int] = None, mask_dtype: Optional[torch.dtype] = None):
+    """Bernoulli supermask (sparse.py:201-221): 1 with probability score."""
+    require_gpu(score, "bernoulli_mask")
+    return _ops.bernoulli_mask(score, _seed_arg(seed, "stochastic"), mask_dtype)
+
+
+# ---------------------------------------------------------------------------------------------------- calibration
+def group_minmax(x, ch_axis: int, group_size: int):
+    """Per-group (slabs of `group_size` channels along ch_axis) min and max: two float32 [G] tensors."""
+    require_gpu(x, "group_minmax")
+    return _ops.group_minmax(x, ch_axis, group_size)
+
+
+def qparams(mn, mx, qmin: int, qmax: int, symmetric_qscheme: bool):
+    """(min,max) -> (scale fp32, zero_point int64), numerical/observer.py:59-115."""
+    require_gpu(mn, "qparams")
+    return _ops.qparams(mn, mx, qmin, qmax, symmetric_qscheme)
+
+
+def histc(x, bins: int, lo: float = 0.0, hi: float = 0.0):
+    """torch.histc(x, bins, min=lo, max=hi) as the HistogramObserver uses it (numerical/observer.py:470-472,
+    489-491): float32 [bins] counts.  lo == hi selects the data's own range, widened by one either side when the
+    data is constant (torch.histc's convention)."""
+    require_gpu(x, "histc")
+    lo, hi = float(lo), float(hi)
+    if lo == hi and x.numel():
+        mn, mx = group_minmax(x.reshape(1, -1), 0, 1)
+        lo, hi = float(mn), float(mx)
+        if lo == hi:
+            lo, hi = lo - 1.0, hi + 1.0
+    if x.numel() == 0 and not lo < hi:
+        return torch.zeros(int(bins), dtype=torch.float32, device=x.device)
+    return _ops.histc(x, int(bins), lo, hi)
+
+
+def channel_maxabs(x, ch_axis: int):
+    """max|x| per channel along ch_axis (numerical/smoothquant.py:285-299): float32 [C]."""
+    require_gpu(x, "channel_maxabs")
+    return _ops.channel_maxabs(x, ch_axis)
+
+
+def smoothquant_scale(a_maxabs, b_maxabs, alpha: float, scale_min: float = 1e-5):
+    require_gpu(a_maxabs, "smoothquant_scale")
+    return _ops.smoothquant_scale(a_maxabs, b_maxabs, float(alpha), float(scale_min))
+
+
+def scale_channels(x, scale, ch_axis: int, divide: bool, out_dtype: Optional[torch.dtype] = None):
+    require_gpu(x, "scale_channels")
+    return _ops.scale_channels(x, scale, ch_axis, divide, out_dtype)
+
+
+# ---------------------------------------------------------------------------------------------------- approximator slot
+UNARY_GELU, UNARY_GELU_TANH, UNARY_SILU, UNARY_QUICK_GELU, UNARY_EXP, UNARY_SILU_EXPERIMENTAL = range(6)
+
+
+def gelu(x, approximate: str = "none", out_dtype: Optional[torch.dtype] = None):
+    require_gpu(x, "gelu")
+    return _ops.unary(x, UNARY_GELU_TANH if approximate == "tanh" else UNARY_GELU, 0.0, out_dtype)
+
+
+def silu(x, out_dtype: Optional[torch.dtype] = None):
+    """torch.nn.functional.silu (modeling/nn/torch_modules.py:1559-1576), exact function."""
+    require_gpu(x, "silu")
+    return _ops.unary(x, UNARY_SILU, 0.0, out_dtype)
+
+
+def quick_gelu(x, out_dtype: Optional[torch.dtype] = None):
+    """transformers' QuickGELUActivation `x * sigmoid(1.702 * x)` in the input dtype (custom_modules.py:112-117)."""
+    require_gpu(x, "quick_gelu")
+    return _ops.unary(x, UNARY_QUICK_GELU, 0.0, out_dtype)
+
+
+def exp(x, out_dtype: Optional[torch.dtype] = None):
+    """torch.exp (modeling/nn/torch_modules.py:236-242 Exp)."""
+    require_gpu(x, "exp")
+    return _ops.unary(x, UNARY_EXP, 0.0, out_dtype)
+
+
+def silu_experimental(x, scale: float):
+    """the reference's `experimental.silu` (functional/functions.py:7-21): relu(x.to(float16)) * scale -> float16"""
+    require_gpu(x, "silu_experimental")
+    return _ops.unary(x, UNARY_SILU_EXPERIMENTAL, float(scale), torch.float16)
+
+
+def softmax(x, dim: int = -1, input_clamp: Optional[float] = None, out_dtype: Optional[torch.dtype] = None):
+    require_gpu(x, "softmax")
+    d = dim % x.dim()
+    xt = x if d == x.dim() - 1 else x.transpose(d, -1)
+    out = _ops.softmax(xt, float(input_clamp) if input_clamp is not None else -math.inf, out_dtype)
+    return out if d == x.dim() - 1 else out.transpose(d, -1)
+
+
+def _cols(normalized_shape):
+    cols = 1
+    for s in (normalized_shape if not isinstance(normalized_shape, int) else (normalized_shape,)):
+        cols *= s
+    return cols
+
+
+def layernorm(x, normalized_shape, weight=None, bias=None, eps: float = 1e-5,
+              out_dtype: Optional[torch.dtype] = None):
+    require_gpu(x, "layernorm")
+    return _ops.norm(x, _cols(normalized_shape), weight, bias, float(eps), 0, out_dtype)
+
+
+def rmsnorm(x, normalized_shape, weight=None, eps: Optional[float] = None, out_dtype: Optional[torch.dtype] = None):
+    """torch.nn.functional.rms_norm over the trailing `normalized_shape` (modeling/nn/torch_modules.py:1144-1170);
+    eps None = torch.finfo(x.dtype).eps, as torch."""
+    require_gpu(x, "rmsnorm")
+    eps = torch.finfo(x.dtype).eps if eps is None else eps
+    return _ops.norm(x, _cols(normalized_shape), weight, None, float(eps), 1, out_dtype)

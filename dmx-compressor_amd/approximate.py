@@ -2,9 +2,12 @@
 
 `FUNC[algorithm]{wrapper_kwargs}(extra_kwargs)` shorthands are parsed like the reference
 (approximate.py:128-132).  The reference's only algorithm is "vsimd", a private package that is absent from the
-public repository, where every default therefore collapses to NONE.  This mirror registers ONE algorithm,
-"dmxq": the exact torch.nn.functional contract evaluated by libdmxq's HIP kernels (GELU / SOFTMAX / LAYER_NORM).
-Approximation arithmetic itself is parity-unpinned and is not invented here.
+public repository, where every default therefore collapses to NONE.  This mirror registers two algorithms:
+  "dmxq"          the exact torch function contract evaluated by libdmxq's HIP kernels (GELU, SILU, QUICK_GELU, EXP,
+                  SOFTMAX, LAYER_NORM, RMS_NORM) -- what the reference computes with vsimd absent;
+  "experimental"  the reference's one in-repo approximation, `experimental.silu` (functional/functions.py:7-21,
+                  dispatched by approximate.py:148-151), reproduced bit for bit by a HIP kernel.
+vsimd approximation arithmetic itself is parity-unpinned and is not invented here.
 """
 import ast
 import re
@@ -68,13 +71,25 @@ class TorchFunctionApproximation(ApproximationFunction):
         self.wrapper_params, self.extra_params = dict(wrapper_params or {}), dict(extra_params or {})
 
     def execute(self, *args, **kwargs):
+        kw = {**kwargs, **self.extra_params}
+        if self.algorithm == "experimental":
+            # approximate.py:148-151: eval(f"experimental.{func_name}")(*args, **kwargs, **extra_params)
+            if self.func_id != "SILU":
+                raise AttributeError(f"experimental has no approximation of {self.func_id} (functional/functions.py defines silu only)")
+            assert not kw.get("inplace", False), "inplace has to be False, not functionally meaningful anyway"
+            return ops.silu_experimental(args[0], kw["scale"])
         if self.algorithm != "dmxq":
             raise NotImplementedError(
-                f"approximation algorithm {self.algorithm!r}: only 'dmxq' (exact function on the HIP kernels) exists here; "
-                "the reference's 'vsimd' arithmetic lives in a private package (parity unpinned)")
-        kw = {**kwargs, **self.extra_params}
+                f"approximation algorithm {self.algorithm!r}: 'dmxq' (exact function on the HIP kernels) and 'experimental' "
+                "exist here; the reference's 'vsimd' arithmetic lives in a private package (parity unpinned)")
         if self.func_id == "GELU":
             return ops.gelu(args[0], approximate=kw.get("approximate", "none"))
+        if self.func_id == "SILU":
+            return ops.silu(args[0])
+        if self.func_id == "QUICK_GELU":
+            return ops.quick_gelu(args[0])
+        if self.func_id == "EXP":
+            return ops.exp(args[0])
         if self.func_id == "SOFTMAX":
             return ops.softmax(args[0], dim=kw.get("dim", -1))
         if self.func_id == "LAYER_NORM":
@@ -83,7 +98,13 @@ class TorchFunctionApproximation(ApproximationFunction):
             b = args[3] if len(args) > 3 else kw.get("bias")
             eps = args[4] if len(args) > 4 else kw.get("eps", 1e-5)
             return ops.layernorm(x, normalized_shape, w, b, eps)
-        raise NotImplementedError(f"{self.func_id}: no HIP kernel in the accelerated path")
+        if self.func_id == "RMS_NORM":
+            x, normalized_shape = args[0], args[1]
+            w = args[2] if len(args) > 2 else kw.get("weight")
+            eps = args[3] if len(args) > 3 else kw.get("eps")
+            return ops.rmsnorm(x, normalized_shape, w, eps)
+        raise NotImplementedError(f"{self.func_id}: no HIP kernel in the accelerated path (rotary embedding is index "
+                                  "shuffling + two multiplies, left to torch)")
 
     @classmethod
     def from_shorthand(cls, sh: str):

@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libdmxq.so")
-SOURCES = ["bfp.hip", "bfp_cols.hip", "bfp_urows.hip", "blockfmt.hip", "bfp_pack.hip", "hypernet.hip", "elementwise.hip", "nm_mask.hip", "topk.hip", "reduce.hip", "approx.hip"]
+TORCH_LIB = os.path.join(HERE, "lib", "dmxq_torch.so")
+SOURCES = ["bfp.hip", "bfp_cols.hip", "bfp_urows.hip", "blockfmt.hip", "bfp_pack.hip", "hypernet.hip", "elementwise.hip", "nm_mask.hip", "topk.hip", "reduce.hip", "approx.hip", "unary.hip"]
 # bit-exact fp32: no fast-math, no fma contraction; fp32 denormals stay on (gfx950 default)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
          "-fgpu-flush-denormals-to-zero" if False else "-fno-gpu-flush-denormals-to-zero"]
@@ -36,27 +37,77 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    hdrs = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "bfp_math.hpp"), os.path.join(CSRC, "bfp_rows.hpp"), os.path.join(CSRC, "stream.hpp"), os.path.join(HERE, "..", "include", "dmxq.h"), os.path.abspath(__file__)]
+    common = [os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "dmxq.h"), os.path.abspath(__file__)]
+    # per-source header dependencies (a change to the BFP tile code does not rebuild the elementwise kernels)
+    extra = {"bfp.hip": ["bfp_math.hpp", "bfp_rows.hpp"], "bfp_cols.hip": ["bfp_math.hpp"], "bfp_urows.hip": ["bfp_math.hpp"],
+             "bfp_pack.hip": ["bfp_math.hpp"], "hypernet.hip": ["bfp_math.hpp"], "blockfmt.hip": ["bfp_math.hpp", "floatq.hpp", "stream.hpp"],
+             "elementwise.hip": ["floatq.hpp", "stream.hpp"], "unary.hip": ["stream.hpp"]}
     hipcc = _hipcc()
 
     def compile_one(src):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + hdrs):
+        if force or _stale(o, [s] + common + [os.path.join(CSRC, h) for h in extra.get(src, [])]):
             cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
         return o
 
-    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, len(srcs) + 1)) as ex:
+        binding = ex.submit(build_torch_binding, force, verbose, False)  # g++ only: runs beside the hipcc jobs
         objs = list(ex.map(compile_one, srcs))
+        binding_obj = binding.result()
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    link_torch_binding(binding_obj, force, verbose)
     return LIB
+
+
+def _torch_flags():
+    import sysconfig
+
+    import torch.utils.cpp_extension as cpp
+
+    inc = []
+    for p in cpp.include_paths():
+        inc += ["-isystem", p]
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    inc += ["-isystem", os.path.join(rocm, "include"), "-isystem", sysconfig.get_paths()["include"]]
+    return inc, cpp.library_paths()[0]
+
+
+def build_torch_binding(force: bool = False, verbose: bool = False, link: bool = True) -> str:
+    """csrc/torch_binding.cpp -> build/torch_binding.o (host-only C++: g++ against the torch headers of this image;
+    the TORCH_LIBRARY(dmxq) registration over the C ABI)."""
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    obj = os.path.join(OBJ, "torch_binding.o")
+    os.makedirs(OBJ, exist_ok=True)
+    if force or _stale(obj, [src, os.path.join(HERE, "..", "include", "dmxq.h"), os.path.abspath(__file__)]):
+        inc, _ = _torch_flags()
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-fPIC", "-std=c++17", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+               "-D_GLIBCXX_USE_CXX11_ABI=1", "-Wno-deprecated-declarations"] + inc + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    if link:
+        link_torch_binding(obj, force, verbose)
+    return obj
+
+
+def link_torch_binding(obj: str, force: bool = False, verbose: bool = False) -> str:
+    if force or _stale(TORCH_LIB, [obj, LIB]):
+        _, tlib = _torch_flags()
+        cmd = [os.environ.get("CXX", "g++"), "-shared", "-fPIC", "-o", TORCH_LIB, obj, "-L" + os.path.dirname(LIB), "-ldmxq",
+               "-Wl,-rpath,$ORIGIN", "-L" + tlib, "-Wl,-rpath," + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip",
+               "-ltorch_hip"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return TORCH_LIB
 
 
 if __name__ == "__main__":

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kThreads) void softmax_rows_kernel(const void* __re
   }
 }
 
-template <bool LDS_ROW>
+template <bool LDS_ROW, bool RMS = false>
 __global__ __launch_bounds__(kThreads) void layernorm_rows_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                                  int dti, int dto, int64_t rows, int64_t cols,
                                                                  const void* __restrict__ w,
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_rows_kernel(const void* __
       if (LDS_ROW) row[c] = v;
       s += v;
     }
-    const float mean = block_allreduce<false>(s, scratch) / (float)cols;
+    const float mean = RMS ? 0.0f : block_allreduce<false>(s, scratch) / (float)cols;  // RMSNorm: no centring
     float q = 0.0f;
     for (int64_t c = threadIdx.x; c < cols; c += kThreads) {
       const float d = (LDS_ROW ? row[c] : load_rt(in, dti, base + c)) - mean;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
 // weight / bias (same dtype as the rows) are read ONCE per wave and kept across its rows: widened to fp32 for short
 // rows, packed for longer ones.  Per element: widen + add, subtract + fma, and (x - mean) * (rstd w) + b as
 // subtract + fma with rstd w formed once per (row, vector element).
-template <int DT, int EPL, int VPL, int LPR>
+template <int DT, int EPL, int VPL, int LPR, bool RMS = false>
 __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                                  int64_t rows, int64_t cols, const void* __restrict__ w,
                                                                  const void* __restrict__ b, float eps) {
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
       mean[j] = s;
     }
 #pragma unroll
-    for (int j = 0; j < RPW; j++) mean[j] = seg_sum<LPR>(mean[j]) * inv_n;
+    for (int j = 0; j < RPW; j++) mean[j] = RMS ? 0.0f : seg_sum<LPR>(mean[j]) * inv_n;  // RMSNorm: no centring
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
       float q = 0.0f;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
 // thread), two workgroup reductions per row through a 4-entry LDS exchange, RPW rows per iteration to amortise the two
 // barriers, weight / bias hoisted (packed) out of the persistent row loop.  The wave kernel at this size would hold
 // 128+ values per lane and re-read weight and bias (as much data as the row itself) for every row.
-template <int DT, int EPL, int VPL>
+template <int DT, int EPL, int VPL, bool RMS = false>
 __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                                   int64_t rows, int64_t cols, const void* __restrict__ w,
                                                                   const void* __restrict__ b, float eps) {
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* _
       float s = red[0][j][0];
 #pragma unroll
       for (int k = 1; k < NW; k++) s += red[0][j][k];
-      mean[j] = s * inv_n;
+      mean[j] = RMS ? 0.0f : s * inv_n;
       float q = 0.0f;
 #pragma unroll
       for (int i = 0; i < VPL; i++) {
@@ -619,8 +619,9 @@ extern "C" int dmxq_softmax(const void* in, void* out, int dtype_in, int dtype_o
   return launch_status();
 }
 
-extern "C" int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
-                              const void* weight, const void* bias, int dtype_wb, float eps, void* stream) {
+template <bool RMS>
+static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
+                         const void* weight, const void* bias, int dtype_wb, float eps, void* stream) {
   if (!valid_dtype(dtype_in) || !valid_dtype(dtype_out) || rows < 0 || cols < 0) return DMXQ_ERR_BAD_ARG;
   if ((weight || bias) && !valid_dtype(dtype_wb)) return DMXQ_ERR_BAD_ARG;
   if (rows * cols == 0) return DMXQ_OK;
@@ -635,8 +636,8 @@ extern "C" int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype
 #define DMXQ_LNB(D_, E_, V_)                                                                                          \
   do {                                                                                                                \
     constexpr int rpw = (V_) * (E_) <= 32 ? 2 : 1;                                                                    \
-    DMXQ_LAUNCH((layernorm_block_kernel<D_, E_, V_>),                                                          \
-                       dim3((unsigned)resident_grid(layernorm_block_kernel<D_, E_, V_>, (rows + rpw - 1) / rpw)),     \
+    DMXQ_LAUNCH((layernorm_block_kernel<D_, E_, V_, RMS>),                                                          \
+                       dim3((unsigned)resident_grid(layernorm_block_kernel<D_, E_, V_, RMS>, (rows + rpw - 1) / rpw)),     \
                        dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps);                                 \
   } while (0)
 #define DMXQ_LNB_V(D_, E_)                                                                                            \
@@ -659,8 +660,8 @@ extern "C" int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype
 #define DMXQ_LN(D_, E_, V_, L_)                                                                                       \
   do {                                                                                                                \
     constexpr int per_wg = 4 * rows_per_wave(V_, E_) * (64 / (L_));                                                   \
-    DMXQ_LAUNCH((layernorm_wave_kernel<D_, E_, V_, L_>),                                                       \
-                       dim3((unsigned)resident_grid(layernorm_wave_kernel<D_, E_, V_, L_>, (rows + per_wg - 1) / per_wg)), \
+    DMXQ_LAUNCH((layernorm_wave_kernel<D_, E_, V_, L_, RMS>),                                                       \
+                       dim3((unsigned)resident_grid(layernorm_wave_kernel<D_, E_, V_, L_, RMS>, (rows + per_wg - 1) / per_wg)), \
                        dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps);                                 \
   } while (0)
 #define DMXQ_LN_V(D_, E_)                                                                            \
@@ -683,10 +684,23 @@ extern "C" int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype
   }
   const size_t scratch = (kThreads / kWave) * sizeof(float);
   if (cols <= kRowLdsFloats)
-    DMXQ_LAUNCH(layernorm_rows_kernel<true>, dim3(row_grid(rows)), dim3(kThreads), scratch + cols * sizeof(float),
+    DMXQ_LAUNCH((layernorm_rows_kernel<true, RMS>), dim3(row_grid(rows)), dim3(kThreads), scratch + cols * sizeof(float),
                        s, in, out, dtype_in, dtype_out, rows, cols, weight, bias, dtype_wb, eps);
   else
-    DMXQ_LAUNCH(layernorm_rows_kernel<false>, dim3(row_grid(rows)), dim3(kThreads), scratch, s, in, out,
+    DMXQ_LAUNCH((layernorm_rows_kernel<false, RMS>), dim3(row_grid(rows)), dim3(kThreads), scratch, s, in, out,
                        dtype_in, dtype_out, rows, cols, weight, bias, dtype_wb, eps);
   return launch_status();
+}
+
+extern "C" int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
+                              const void* weight, const void* bias, int dtype_wb, float eps, void* stream) {
+  return norm_dispatch<false>(in, out, dtype_in, dtype_out, rows, cols, weight, bias, dtype_wb, eps, stream);
+}
+
+// RMSNorm (torch_modules.py:1144-1170 -> F.rms_norm): the same register-resident row kernels without the centring pass:
+// y = x * rsqrt(mean(x^2) + eps) * weight, fp32, one rounding.  (1 / sqrtf(.) here vs torch's rsqrt: both correctly
+// rounded to within an ulp of fp32, far inside the tolerance the tests state for 16-bit outputs.)
+extern "C" int dmxq_rmsnorm(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
+                            const void* weight, int dtype_w, float eps, void* stream) {
+  return norm_dispatch<true>(in, out, dtype_in, dtype_out, rows, cols, weight, nullptr, dtype_w, eps, stream);
 }

@@ -31,25 +31,37 @@
 
 namespace dmxq {
 
-// 16-byte vectors in flight per lane on big tensors; 8 when the output vector is 32 B (16-bit in -> fp32 out)
-template <int DTI, int DTO> struct RowsUnroll { static constexpr int big = 16; };
 constexpr int kRowsMaxGrid = 1 << 20;
 
-// Tile geometry of the flat-stream kernel for a tensor of n_vec lane-vectors (tools/tune_bfp, profiles/):
-// workgroup-contiguous tiles of threads x unroll vectors.
-struct RowsPlan { int threads, unroll; int64_t tiles; };
-static inline RowsPlan rows_plan(int64_t n_vec, int unroll_big, bool allow_big) {
-  auto tiles_of = [&](int t, int u) { return (n_vec + (int64_t)t * u - 1) / ((int64_t)t * u); };
-  const int64_t big_tiles = tiles_of(512, unroll_big);
-  if (allow_big && big_tiles <= 256 && big_tiles >= 224) return RowsPlan{512, unroll_big, big_tiles};  // ONE full round, 1 WG per CU
-  if (n_vec >= (int64_t)256 * 256 * 4) return RowsPlan{256, 4, tiles_of(256, 4)};  // many rounds: small tiles desynchronise
-  return RowsPlan{256, 1, tiles_of(256, 1)};
+// Tile geometry of the flat-stream kernel for a tensor of n_vec lane-vectors: workgroup-contiguous tiles of
+// threads x unroll vectors.  Measured on 4096-column bf16 tensors of 256 .. 16384 rows with tools/tune_bfp
+// (profiles/r02_tune_bfp_sweep.txt), 256 CUs:
+//   * up to 32 MiB of input the best shape keeps the WHOLE tensor in flight in one round of <= 2 workgroups per CU
+//     (every CU reads its share, computes, writes it: the phases stay in lockstep and HBM sees pure read bursts
+//     followed by pure write bursts): 512x1 (<= 4 MiB), 128x2 (<= 12 MiB: many small workgroups ramp fastest),
+//     512x4 (<= 16 MiB), 512x6 (<= 24 MiB), 512x16 (<= 32 MiB: the 4096x4096 bf16 headline tensor, 256 tiles);
+//   * beyond that several rounds per CU are needed anyway, and small 512x2 tiles (4 resident workgroups per CU that
+//     desynchronise, so reads of one overlap writes of another) win: 77-79 % of 8 TB/s vs 68-71 % for 512x16.
+struct RowsPlan { int id, threads, unroll; int64_t tiles; };
+static inline RowsPlan rows_plan(int64_t n_vec, bool allow_big) {
+  auto mk = [&](int id, int t, int u) { return RowsPlan{id, t, u, (n_vec + (int64_t)t * u - 1) / ((int64_t)t * u)}; };
+  if (n_vec <= ((int64_t)1 << 18)) return mk(0, 512, 1);
+  if (n_vec <= ((int64_t)3 << 18)) return mk(1, 128, 2);
+  if (allow_big) {  // (the any-rounding build would spill at many vectors per lane: it goes straight to 512x2)
+    if (n_vec <= ((int64_t)1 << 20)) return mk(2, 512, 4);
+    if (n_vec <= ((int64_t)3 << 19)) return mk(3, 512, 6);
+    if (n_vec <= ((int64_t)1 << 21)) return mk(4, 512, 16);
+  }
+  return mk(5, 512, 2);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Generic fallback: one lane per block; two strided passes.  Correct for every (outer, L, inner, B) incl.
 // ragged tails; coalesced across lanes when inner > 1.
-template <int DTI, int DTO, int RND, bool ASYM>
+// NATIVE: the reference's native symmetric == false branch (quant_cpu.cpp:247-253; the Python layer never requests it,
+// format.py:332): an element equal to -max, when the top 7 mantissa bits of the block maximum are all ones, is
+// quantised with the next exponent -- per element, no post-pass.  Only reachable through the S1 seam (quant.py).
+template <int DTI, int DTO, int RND, bool ASYM, bool NATIVE = false>
 __global__ __launch_bounds__(kThreads) void bfp_generic_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                               int64_t outer, int64_t L, int64_t inner, int64_t B,
                                                               int wl, int rounding, uint64_t seed) {
@@ -71,7 +83,13 @@ __global__ __launch_bounds__(kThreads) void bfp_generic_kernel(const void* __res
       const int64_t e = e0 + i * inner;
       // the oracle numbers random draws by the element's position in the transposed [rows, L] matrix
       const uint64_t ridx = (uint64_t)(((o * inner + j) * L) + l0 + i);
-      store1<DTO>(out, e, bfp_q1<RND, ASYM>(load1<DTI>(in, e), p, wl, rounding, rnd_if(stoch, seed, ridx)));
+      const float x = load1<DTI>(in, e);
+      if (NATIVE && x == -u2f(mb) && ((mb >> 16) & 0x7Fu) == 0x7Fu) {
+        const BfpBlockParams pe = bfp_block_params<false>(((mb >> 23) + 1u) << 23, wl);
+        store1<DTO>(out, e, bfp_q1<RND, false>(x, pe, wl, rounding, rnd_if(stoch, seed, ridx)));
+      } else {
+        store1<DTO>(out, e, bfp_q1<RND, ASYM>(x, p, wl, rounding, rnd_if(stoch, seed, ridx)));
+      }
     }
   }
 }
@@ -89,14 +107,9 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
   // (stochastic draws are numbered by flat element index in the rows kernel, which equals the oracle's
   //  numbering because inner == 1 on this path)
   if (inner == 1 && L % B == 0 && pow2 && B >= EPL && B <= 64 * EPL && aligned16(in) && aligned16(out)) {
-    // Geometry (tools/tune_bfp, profiles/): workgroup-contiguous tiles of THREADS*UNROLL 16-byte vectors,
-    // non-temporal loads and stores, every load of a tile in flight before the arithmetic starts, stores in
-    // one burst.  When the tensor is ONE round of 512 x 16 tiles (128 KiB of bf16 per workgroup; 4096x4096 bf16 =
-    // 256 tiles = one per CU) that shape wins (73 % of roofline); with several rounds per CU the rounds run in
-    // lockstep (read phase, compute, write phase), so bigger tensors take 256 x 4 tiles, whose many workgroups
-    // desynchronise and overlap reads with writes (77 %), and small ones 256 x 1 to cover the 256 CUs.
+    // Geometry: rows_plan() above; non-temporal loads and stores, every load of a tile in flight before the arithmetic
+    // starts, stores in one burst.
     constexpr int MODE = kRowsNtLoad | kRowsNtStore;
-    constexpr int UB = RowsUnroll<DTI, DTO>::big;
     const int64_t n_vec = n / EPL;
     const int lpb = (int)(B / EPL);
     // nearest-even: the magic-add path (bfp_math.hpp (2)); single rounding where the input dtype allows it
@@ -110,12 +123,15 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
   } while (0)
 #define DMXQ_ROWS_GEOM(F_)                                                                         \
   do {                                                                                             \
-    const RowsPlan pl = rows_plan(n_vec, UB, (F_) != 4);                                           \
-    if constexpr ((F_) != 4) { /* (the any-rounding build would spill at 16 vectors per lane) */ \
-      if (pl.threads == 512) { DMXQ_ROWS(512, UB, F_); break; }                                    \
+    const RowsPlan pl = rows_plan(n_vec, (F_) != 4);                                               \
+    if constexpr ((F_) != 4) {                                                                     \
+      if (pl.id == 2) { DMXQ_ROWS(512, 4, F_); break; }                                            \
+      if (pl.id == 3) { DMXQ_ROWS(512, 6, F_); break; }                                            \
+      if (pl.id == 4) { DMXQ_ROWS(512, 16, F_); break; }                                           \
     }                                                                                              \
-    if (pl.unroll == 4) DMXQ_ROWS(256, 4, F_);                                                     \
-    else DMXQ_ROWS(256, 1, F_);                                                                    \
+    if (pl.id == 0) DMXQ_ROWS(512, 1, F_);                                                         \
+    else if (pl.id == 1) DMXQ_ROWS(128, 2, F_);                                                    \
+    else DMXQ_ROWS(512, 2, F_);                                                                    \
   } while (0)
     // instantiate only what can run (see bfp_cols.hip): literal path for the runtime-rounding build, magic-add for
     // nearest-even; nearest with wl > 20 is routed to the runtime-rounding build by dispatch_mode
@@ -175,6 +191,13 @@ extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_o
   if (block_size == 1)  // numerical/format.py:312-320: BFP with block size 1 borrows float_quantize
     return dmxq_float_qdq(in, out, dtype_in, dtype_out, n, precision - 2, 8, 127, 0, 0, rounding, seed, stream);
   if (precision > 22) return DMXQ_ERR_UNSUPPORTED;  // reference shifts by a negative count (UB) beyond this
+  if (symmetric == DMXQ_BFP_ASYM_NATIVE) {  // the pybind seam's symmetric = false (float32 only, like the seam)
+    if (dtype_in != DMXQ_F32 || dtype_out != DMXQ_F32) return DMXQ_ERR_UNSUPPORTED;
+    const int64_t nblk = (L + block_size - 1) / block_size;
+    DMXQ_LAUNCH((bfp_generic_kernel<DMXQ_F32, DMXQ_F32, kRuntimeRounding, false, true>), dim3(grid_for(outer * nblk * inner)),
+                dim3(kThreads), 0, (hipStream_t)stream, in, out, outer, L, inner, block_size, precision, rounding, seed);
+    return launch_status();
+  }
   if (inner == 1) {
     // flat-stream kernel (launch_bfp) when rows are whole blocks and 16-byte aligned; otherwise LDS re-alignment
     const bool widening = dtype_in != DMXQ_F32 && dtype_out == DMXQ_F32;  // lane-vector of 8 B, see launch_bfp
@@ -208,6 +231,82 @@ extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_o
   return DMXQ_ERR_BAD_ARG;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Multi-tensor entry point: the same result as one dmxq_bfp_qdq call per tensor, in as few launches as possible.
+namespace dmxq {
+template <int DTI, int DTO>
+static int launch_multi(const MultiArgs& a, int64_t total_tiles, bool asym, int wl, hipStream_t s) {
+  constexpr int IVB = (Elem<DTO>::bytes > Elem<DTI>::bytes) ? 8 : 16;
+  constexpr bool in16 = Elem<DTI>::bytes == 2;
+  const bool single = in16 && bfp_single_rounding_ok<DTI>(wl);
+#define DMXQ_MULTI(A_, F_) \
+  DMXQ_LAUNCH((bfp_rows_multi_kernel<DTI, DTO, A_, kMultiUnroll, kMultiThreads, F_, IVB>), dim3((unsigned)total_tiles), dim3(kMultiThreads), 0, s, a)
+  if (single) {
+    if constexpr (in16) { if (asym) DMXQ_MULTI(true, 2); else DMXQ_MULTI(false, 2); }
+  } else {
+    if (asym) DMXQ_MULTI(true, 1); else DMXQ_MULTI(false, 1);
+  }
+#undef DMXQ_MULTI
+  return launch_status();
+}
+}  // namespace dmxq
+
+extern "C" int dmxq_bfp_qdq_multi(const dmxq_tensor_desc* tensors, int64_t n_tensors, int dtype_in, int dtype_out,
+                                  int64_t block_size, int precision, int rounding, int symmetric, uint64_t seed,
+                                  void* stream) {
+  using namespace dmxq;
+  if (n_tensors < 0 || (n_tensors > 0 && !tensors)) return DMXQ_ERR_BAD_ARG;
+  if (!valid_dtype(dtype_in) || !valid_dtype(dtype_out) || !valid_rounding(rounding) || block_size < 1 || precision < 2)
+    return DMXQ_ERR_BAD_ARG;
+  for (int64_t i = 0; i < n_tensors; i++) {
+    const dmxq_tensor_desc& t = tensors[i];
+    if (t.outer < 0 || t.L < 0 || t.inner < 0) return DMXQ_ERR_BAD_ARG;
+    if (t.outer * t.L * t.inner > 0 && (!t.in || !t.out)) return DMXQ_ERR_BAD_ARG;
+  }
+  if (block_size > 1 && precision > 22) return DMXQ_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const bool widening = dtype_in != DMXQ_F32 && dtype_out == DMXQ_F32;
+  const int epl = (dtype_in == DMXQ_F32 || widening) ? 4 : 8;
+  const bool pow2 = (block_size & (block_size - 1)) == 0;
+  const bool fmt_ok = rounding == DMXQ_ROUND_NEAREST && precision <= 20 && block_size > 1 && pow2 && block_size >= epl &&
+                      block_size <= 64 * epl;
+  constexpr int64_t TILE = (int64_t)kMultiThreads * kMultiUnroll;
+  MultiArgs a;
+  a.n = 0; a.lpb = (int)(block_size / epl); a.wl = precision;
+  int64_t tiles = 0;
+  int rc = DMXQ_OK;
+  auto flush = [&]() {
+    if (a.n == 0) return;
+    int r = DMXQ_ERR_BAD_ARG;
+#define DMXQ_DT(I_, O_) if (dtype_in == I_ && dtype_out == O_) r = launch_multi<I_, O_>(a, tiles, !symmetric, precision, s);
+    DMXQ_DT(DMXQ_BF16, DMXQ_BF16) DMXQ_DT(DMXQ_F16, DMXQ_F16) DMXQ_DT(DMXQ_F32, DMXQ_F32) DMXQ_DT(DMXQ_BF16, DMXQ_F32)
+    DMXQ_DT(DMXQ_F16, DMXQ_F32) DMXQ_DT(DMXQ_F32, DMXQ_BF16) DMXQ_DT(DMXQ_F32, DMXQ_F16)
+#undef DMXQ_DT
+    if (r != DMXQ_OK) rc = r;
+    a.n = 0; tiles = 0;
+  };
+  for (int64_t i = 0; i < n_tensors && rc == DMXQ_OK; i++) {
+    const dmxq_tensor_desc& t = tensors[i];
+    const int64_t n = t.outer * t.L * t.inner;
+    if (n == 0) continue;
+    const bool batch = fmt_ok && t.inner == 1 && t.L % block_size == 0 && aligned16(t.in) && aligned16(t.out) &&
+                       (n / epl + TILE - 1) / TILE < ((int64_t)1 << 30);
+    if (!batch) {  // ragged / strided / unaligned tensors and the other rounding modes: their own launch
+      const int r = dmxq_bfp_qdq(t.in, t.out, dtype_in, dtype_out, t.outer, t.L, t.inner, block_size, precision, rounding,
+                                 symmetric, seed + (uint64_t)i, stream);
+      if (r != DMXQ_OK) rc = r;
+      continue;
+    }
+    const int64_t nt = (n / epl + TILE - 1) / TILE;
+    if (a.n == kMultiMax || tiles + nt >= ((int64_t)1 << 31)) flush();
+    a.d[a.n] = MultiDesc{t.in, t.out, n / epl, tiles};
+    a.n++;
+    tiles += nt;
+  }
+  flush();
+  return rc;
+}
+
 // What would dmxq_bfp_qdq launch for these arguments?  (bench.py reports it next to the roofline numbers.)
 extern "C" int dmxq_bfp_qdq_describe(int dtype_in, int dtype_out, int64_t outer, int64_t L, int64_t inner,
                                      int64_t block_size, int precision, int rounding, int symmetric, int aligned,
@@ -227,8 +326,7 @@ extern "C" int dmxq_bfp_qdq_describe(int dtype_in, int dtype_out, int64_t outer,
   if (inner == 1 && L % block_size == 0 && pow2 && block_size >= epl && block_size <= 64 * epl && aligned) {
     const bool nearest = rounding == DMXQ_ROUND_NEAREST && precision <= 20;
     const bool single = nearest && ((dtype_in == DMXQ_BF16 && precision <= 14) || (dtype_in == DMXQ_F16 && precision <= 11));
-    const int ub = 16;
-    const RowsPlan pl = rows_plan(n / epl, ub, nearest);
+    const RowsPlan pl = rows_plan(n / epl, nearest);
     const int64_t grid = pl.tiles < kRowsMaxGrid ? pl.tiles : kRowsMaxGrid;
     snprintf(buf, (size_t)buf_len, "dmxq::bfp_rows_kernel<%s,%s,%s,%s,%s> tile %dx%d vectors, grid %lld, nt loads+stores",
              dn[dtype_in], dn[dtype_out], nearest ? "nearest" : rn[rounding], symmetric ? "sym" : "asym",

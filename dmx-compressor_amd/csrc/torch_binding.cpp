@@ -1,0 +1,500 @@
+// csrc/torch_binding.cpp — the thin torch extension over the C ABI of libdmxq.so (include/dmxq.h).
+//
+// Replaces the reference's pybind seam (quant/quant_cuda/quant_cuda.cpp:116-139: allocate with zeros_like, launch,
+// return a new tensor) for the whole hot path: `torch.ops.dmxq.*`.  This file contains NO arithmetic: every op
+//   1. checks / makes its tensors contiguous and factors the shape as [outer, L, inner] around the blocked dim,
+//   2. allocates the outputs (torch's caching allocator: the ownership contract of the reference's native functions),
+//   3. makes the tensor's device current (device guard) and passes torch's CURRENT HIP stream of that device,
+//   4. calls ONE extern "C" entry point of include/dmxq.h.
+// Meta kernels (shape / dtype propagation only) make the ops traceable by torch.compile / torch.export with fake
+// tensors (the reference's `export=True` path, fx/transform.py:133-178); the straight-through-estimator backward is
+// registered from Python (torch.library.register_autograd, dmx-compressor_amd/_torch_ops.py).
+// Host-only C++: compiled with g++ against the torch headers, linked to libdmxq.so; no device code here.
+#include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <torch/library.h>
+
+#include <tuple>
+#include <vector>
+
+#include "../../include/dmxq.h"
+
+namespace {
+
+using at::Tensor;
+using OptDtype = c10::optional<at::ScalarType>;
+using OptTensor = c10::optional<Tensor>;
+
+inline int dt_code(at::ScalarType t) {
+  switch (t) {
+    case at::kFloat: return DMXQ_F32;
+    case at::kHalf: return DMXQ_F16;
+    case at::kBFloat16: return DMXQ_BF16;
+    default: TORCH_CHECK_TYPE(false, "dmxq kernels take float32/float16/bfloat16 tensors, got ", t);
+  }
+  return -1;
+}
+
+inline void check(int rc, const char* what) {
+  if (rc == DMXQ_OK) return;
+  if (rc == DMXQ_ERR_UNSUPPORTED) TORCH_CHECK_NOT_IMPLEMENTED(false, what, ": ", dmxq_status_string(rc));
+  TORCH_CHECK(false, what, ": ", dmxq_status_string(rc), " (status ", rc, ")");
+}
+
+struct Split3 { int64_t outer, L, inner; };
+inline Split3 split3(const Tensor& x, int64_t dim) {
+  const int64_t nd = x.dim();
+  if (nd == 0) return {1, 1, 1};
+  const int64_t d = ((dim % nd) + nd) % nd;
+  Split3 s{1, x.size(d), 1};
+  for (int64_t i = 0; i < d; i++) s.outer *= x.size(i);
+  for (int64_t i = d + 1; i < nd; i++) s.inner *= x.size(i);
+  return s;
+}
+
+inline Tensor prep(const Tensor& x, const char* what) {
+  TORCH_CHECK(x.is_cuda(), what, ": tensor is on ", x.device(),
+              "; dmx_compressor_amd runs on MI355X (HIP) tensors only and has no CPU fallback");
+  dt_code(x.scalar_type());
+  return x.contiguous();
+}
+
+// device guard + torch's current stream on the tensor's device (never the null stream)
+struct Launch {
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard;
+  void* stream;
+  explicit Launch(const Tensor& x) : guard(x.device()) {
+    stream = (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(x.device().index()).stream();
+  }
+};
+
+inline Tensor empty_like_shape(const Tensor& x, OptDtype dt) {
+  return at::empty(x.sizes(), x.options().dtype(dt.value_or(x.scalar_type())).memory_format(at::MemoryFormat::Contiguous));
+}
+
+inline const void* cptr(const OptTensor& t) { return t.has_value() && t->defined() ? t->data_ptr() : nullptr; }
+
+// ------------------------------------------------------------------------------------------------ block formats
+Tensor bfp_qdq(const Tensor& x, int64_t precision, int64_t block_size, int64_t block_dim, bool symmetric, int64_t rounding,
+               OptDtype out_dtype, int64_t seed) {
+  const Tensor xc = prep(x, "bfp_qdq");
+  Tensor out = empty_like_shape(xc, out_dtype);
+  const Split3 s = split3(xc, block_dim);
+  Launch l(xc);
+  check(dmxq_bfp_qdq(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), dt_code(out.scalar_type()), s.outer, s.L, s.inner,
+                     block_size, (int)precision, (int)rounding, symmetric, (uint64_t)seed, l.stream), "dmxq_bfp_qdq");
+  return out;
+}
+Tensor bfp_qdq_meta(const Tensor& x, int64_t, int64_t, int64_t, bool, int64_t, OptDtype out_dtype, int64_t) {
+  return empty_like_shape(x, out_dtype);
+}
+
+// the pybind seam block_quantize_<rounding>(a, wl, dim, symmetric) on a [rows, L] float32 view, one block per row;
+// symmetric = false selects the NATIVE asymmetric branch (quant_cpu.cpp:247-253), not the "(_N)" format post-pass
+Tensor block_quantize(const Tensor& a, int64_t wl, bool symmetric, int64_t rounding, int64_t seed) {
+  const Tensor xc = prep(a, "block_quantize");
+  TORCH_CHECK(xc.dim() == 2, "block_quantize: expects a [rows, L] view");
+  Tensor out = at::empty_like(xc);
+  Launch l(xc);
+  check(dmxq_bfp_qdq(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), dt_code(out.scalar_type()), xc.size(0), xc.size(1), 1,
+                     std::max<int64_t>(xc.size(1), 2), (int)wl, (int)rounding, symmetric ? 1 : DMXQ_BFP_ASYM_NATIVE, (uint64_t)seed,
+                     l.stream), "dmxq_bfp_qdq");
+  return out;
+}
+Tensor block_quantize_meta(const Tensor& a, int64_t, bool, int64_t, int64_t) { return at::empty_like(a); }
+
+std::vector<Tensor> bfp_qdq_multi(at::TensorList xs, int64_t precision, int64_t block_size, int64_t block_dim, bool symmetric,
+                                  int64_t rounding, OptDtype out_dtype, int64_t seed) {
+  std::vector<Tensor> outs, ins;
+  if (xs.empty()) return outs;
+  std::vector<dmxq_tensor_desc> d(xs.size());
+  for (size_t i = 0; i < xs.size(); i++) {
+    ins.push_back(prep(xs[i], "bfp_qdq_multi"));
+    TORCH_CHECK(ins[i].scalar_type() == ins[0].scalar_type() && ins[i].device() == ins[0].device(),
+                "bfp_qdq_multi: all tensors must share one dtype and one device");
+    outs.push_back(empty_like_shape(ins[i], out_dtype));
+    const Split3 s = split3(ins[i], block_dim);
+    d[i] = dmxq_tensor_desc{ins[i].data_ptr(), outs[i].data_ptr(), s.outer, s.L, s.inner};
+  }
+  Launch l(ins[0]);
+  check(dmxq_bfp_qdq_multi(d.data(), (int64_t)d.size(), dt_code(ins[0].scalar_type()), dt_code(outs[0].scalar_type()), block_size,
+                           (int)precision, (int)rounding, symmetric, (uint64_t)seed, l.stream), "dmxq_bfp_qdq_multi");
+  return outs;
+}
+std::vector<Tensor> bfp_qdq_multi_meta(at::TensorList xs, int64_t, int64_t, int64_t, bool, int64_t, OptDtype out_dtype, int64_t) {
+  std::vector<Tensor> outs;
+  for (const Tensor& x : xs) outs.push_back(empty_like_shape(x, out_dtype));
+  return outs;
+}
+
+std::vector<int64_t> exps_shape(const Tensor& x, int64_t block_size) {
+  std::vector<int64_t> sh(x.sizes().begin(), x.sizes().end());
+  const int64_t L = sh.empty() ? 1 : sh.back();
+  if (sh.empty()) sh.push_back(0);
+  sh.back() = (L + block_size - 1) / block_size;
+  return sh;
+}
+std::tuple<Tensor, Tensor> bfp_pack(const Tensor& x, int64_t precision, int64_t block_size, bool symmetric) {
+  const Tensor xc = prep(x, "bfp_pack");
+  TORCH_CHECK(block_size >= 1, "bfp_pack: block_size must be positive");
+  const int64_t L = xc.dim() ? xc.size(-1) : 1;
+  const int64_t rows = L ? xc.numel() / L : 0;
+  Tensor mant = at::empty(xc.sizes(), xc.options().dtype(at::kChar));
+  Tensor exps = at::empty(exps_shape(xc, block_size), xc.options().dtype(at::kByte));
+  Launch l(xc);
+  check(dmxq_bfp_pack(xc.data_ptr(), dt_code(xc.scalar_type()), (int8_t*)mant.data_ptr(), (uint8_t*)exps.data_ptr(), rows, L,
+                      block_size, (int)precision, symmetric, l.stream), "dmxq_bfp_pack");
+  return {mant, exps};
+}
+std::tuple<Tensor, Tensor> bfp_pack_meta(const Tensor& x, int64_t, int64_t block_size, bool) {
+  return {at::empty(x.sizes(), x.options().dtype(at::kChar)), at::empty(exps_shape(x, block_size < 1 ? 1 : block_size), x.options().dtype(at::kByte))};
+}
+
+Tensor bfp_unpack(const Tensor& mant, const Tensor& exps, int64_t precision, int64_t block_size, at::ScalarType out_dtype) {
+  TORCH_CHECK(mant.is_cuda() && exps.is_cuda(), "bfp_unpack: tensors must be on the GPU (no CPU fallback)");
+  const Tensor m = mant.contiguous(), e = exps.contiguous();
+  const int64_t L = m.dim() ? m.size(-1) : 1;
+  const int64_t rows = L ? m.numel() / L : 0;
+  Tensor out = at::empty(m.sizes(), m.options().dtype(out_dtype));
+  Launch l(m);
+  check(dmxq_bfp_unpack((const int8_t*)m.data_ptr(), (const uint8_t*)e.data_ptr(), out.data_ptr(), dt_code(out_dtype), rows, L,
+                        block_size, (int)precision, l.stream), "dmxq_bfp_unpack");
+  return out;
+}
+Tensor bfp_unpack_meta(const Tensor& mant, const Tensor&, int64_t, int64_t, at::ScalarType out_dtype) {
+  return at::empty(mant.sizes(), mant.options().dtype(out_dtype));
+}
+
+at::ScalarType hypernet_dtype(const Tensor& w, const OptTensor& score, int64_t M, OptDtype out_dtype) {
+  const bool masked = score.has_value() && score->defined() && M != 0;
+  return out_dtype.value_or(masked ? at::promote_types(w.scalar_type(), score->scalar_type()) : w.scalar_type());
+}
+Tensor weight_hypernet(const Tensor& w, int64_t precision, int64_t block_size, bool symmetric, const OptTensor& score, int64_t K,
+                       int64_t M, const OptTensor& sq_scale, OptDtype out_dtype) {
+  const Tensor wc = prep(w, "weight_hypernet");
+  const bool masked = score.has_value() && score->defined() && M != 0;
+  Tensor sc, sq;
+  if (masked) {
+    sc = prep(*score, "weight_hypernet");
+    TORCH_CHECK_NOT_IMPLEMENTED(sc.sizes() == wc.sizes(), "weight_hypernet: score and weight shapes differ");
+  }
+  const int64_t L = wc.dim() ? wc.size(-1) : 1;
+  const int64_t rows = L ? wc.numel() / L : 0;
+  if (sq_scale.has_value() && sq_scale->defined()) {
+    sq = sq_scale->detach().to(wc.device(), at::kFloat).contiguous();
+    TORCH_CHECK_NOT_IMPLEMENTED(sq.numel() == L, "weight_hypernet: scale length differs from the channel count");
+  }
+  Tensor out = empty_like_shape(wc, hypernet_dtype(wc, score, M, out_dtype));
+  Launch l(wc);
+  check(dmxq_weight_hypernet(wc.data_ptr(), dt_code(wc.scalar_type()), masked ? sc.data_ptr() : nullptr,
+                             masked ? dt_code(sc.scalar_type()) : 0, (int)K, masked ? (int)M : 0,
+                             sq.defined() ? (const float*)sq.data_ptr() : nullptr, out.data_ptr(), dt_code(out.scalar_type()), rows, L,
+                             block_size, (int)precision, symmetric, l.stream), "dmxq_weight_hypernet");
+  return out;
+}
+Tensor weight_hypernet_meta(const Tensor& w, int64_t, int64_t, bool, const OptTensor& score, int64_t, int64_t M, const OptTensor&,
+                            OptDtype out_dtype) {
+  return empty_like_shape(w, hypernet_dtype(w, score, M, out_dtype));
+}
+
+Tensor sbfp_qdq(const Tensor& x, int64_t precision, int64_t block_size, int64_t sman, int64_t sexp, int64_t sbias, bool sflush,
+                bool clamp, bool symmetric, int64_t block_dim, OptDtype out_dtype) {
+  const Tensor xc = prep(x, "sbfp_qdq");
+  Tensor out = empty_like_shape(xc, out_dtype);
+  const Split3 s = split3(xc, block_dim);
+  Launch l(xc);
+  check(dmxq_sbfp_qdq(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), dt_code(out.scalar_type()), s.outer, s.L, s.inner,
+                      block_size, (int)precision, clamp, symmetric, (int)sman, (int)sexp, (int)sbias, sflush, l.stream), "dmxq_sbfp_qdq");
+  return out;
+}
+Tensor sbfp_qdq_meta(const Tensor& x, int64_t, int64_t, int64_t, int64_t, int64_t, bool, bool, bool, int64_t, OptDtype out_dtype) {
+  return empty_like_shape(x, out_dtype);
+}
+
+Tensor mxfp_qdq(const Tensor& x, int64_t man, int64_t exp, int64_t block_size, int64_t block_dim, OptDtype out_dtype) {
+  const Tensor xc = prep(x, "mxfp_qdq");
+  Tensor out = empty_like_shape(xc, out_dtype);
+  const Split3 s = split3(xc, block_dim);
+  Launch l(xc);
+  check(dmxq_mxfp_qdq(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), dt_code(out.scalar_type()), s.outer, s.L, s.inner,
+                      block_size, (int)man, (int)exp, l.stream), "dmxq_mxfp_qdq");
+  return out;
+}
+Tensor mxfp_qdq_meta(const Tensor& x, int64_t, int64_t, int64_t, int64_t, OptDtype out_dtype) { return empty_like_shape(x, out_dtype); }
+
+// ------------------------------------------------------------------------------------------------ element formats
+Tensor float_qdq(const Tensor& x, int64_t man, int64_t exp, int64_t bias, bool flush, bool unsigned_abs, int64_t rounding,
+                 OptDtype out_dtype, int64_t seed) {
+  const Tensor xc = prep(x, "float_qdq");
+  Tensor out = empty_like_shape(xc, out_dtype);
+  Launch l(xc);
+  check(dmxq_float_qdq(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), dt_code(out.scalar_type()), xc.numel(), (int)man,
+                       (int)exp, (int)bias, flush, unsigned_abs, (int)rounding, (uint64_t)seed, l.stream), "dmxq_float_qdq");
+  return out;
+}
+Tensor float_qdq_meta(const Tensor& x, int64_t, int64_t, int64_t, bool, bool, int64_t, OptDtype out_dtype, int64_t) {
+  return empty_like_shape(x, out_dtype);
+}
+
+Tensor fixed_qdq(const Tensor& x, int64_t precision, int64_t fraction, bool clamp, bool symmetric, int64_t rounding,
+                 const OptTensor& scale, const OptTensor& zero_point, c10::optional<int64_t> ch_axis,
+                 c10::optional<int64_t> group_size, OptDtype out_dtype, int64_t seed) {
+  const Tensor xc = prep(x, "fixed_qdq");
+  Tensor out = empty_like_shape(xc, out_dtype);
+  Tensor sc, zp;
+  Split3 s{1, 1, xc.numel()};
+  int64_t gs = 1;
+  if (scale.has_value() && scale->defined()) {
+    TORCH_CHECK(zero_point.has_value() && zero_point->defined(), "fixed_qdq: scale without zero_point");
+    sc = scale->detach().to(xc.device(), at::kFloat).contiguous();
+    zp = zero_point->detach().to(xc.device(), at::kLong).contiguous();
+    int64_t need = 1;
+    if (ch_axis.has_value() && xc.dim() > 0) {
+      s = split3(xc, *ch_axis);
+      gs = group_size.value_or(1);
+      if (gs < 1) gs = 1;
+      need = (s.L + gs - 1) / gs;
+    }
+    TORCH_CHECK_VALUE(sc.numel() >= need && zp.numel() >= need, "fixed_qdq: need ", need, " scale/zero_point entries, got ",
+                      sc.numel(), "/", zp.numel());
+  }
+  Launch l(xc);
+  check(dmxq_fixed_qdq(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), dt_code(out.scalar_type()), s.outer, s.L, s.inner,
+                       (int)precision, (int)fraction, clamp, symmetric, (int)rounding, sc.defined() ? (const float*)sc.data_ptr() : nullptr,
+                       zp.defined() ? (const int64_t*)zp.data_ptr() : nullptr, gs, (uint64_t)seed, l.stream), "dmxq_fixed_qdq");
+  return out;
+}
+Tensor fixed_qdq_meta(const Tensor& x, int64_t, int64_t, bool, bool, int64_t, const OptTensor&, const OptTensor&, c10::optional<int64_t>,
+                      c10::optional<int64_t>, OptDtype out_dtype, int64_t) {
+  return empty_like_shape(x, out_dtype);
+}
+
+// ------------------------------------------------------------------------------------------------ sparsity
+// (mask, y): an output that was not requested comes back as an empty 1-d tensor
+Tensor none_like(const Tensor& x) { return at::empty({0}, x.options()); }
+
+std::tuple<Tensor, Tensor> nm_mask(const Tensor& score, const OptTensor& x, int64_t K, int64_t M, int64_t block_dim, bool want_mask,
+                                   bool want_y, OptDtype mask_dtype, OptDtype y_dtype) {
+  const Tensor sc = prep(score, "nm_mask");
+  TORCH_CHECK(sc.dim() > 0 && M > 0 && sc.size(block_dim) % M == 0, "score has size ", sc.sizes(), " at dimension ", block_dim,
+              ", not a multiple of block size ", M);
+  const Split3 s = split3(sc, block_dim);
+  Tensor xc;
+  if (want_y) {
+    TORCH_CHECK(x.has_value() && x->defined(), "nm_sparsify: x required");
+    xc = prep(*x, "nm_sparsify");
+    if (xc.sizes() != sc.sizes()) xc = xc.expand(sc.sizes()).contiguous();
+  }
+  Tensor mask = want_mask ? empty_like_shape(sc, mask_dtype) : none_like(sc);
+  Tensor y = want_y ? empty_like_shape(sc, y_dtype.value_or(at::promote_types(xc.scalar_type(), sc.scalar_type()))) : none_like(sc);
+  Launch l(sc);
+  check(dmxq_nm_mask(sc.data_ptr(), dt_code(sc.scalar_type()), want_y ? xc.data_ptr() : nullptr, want_y ? dt_code(xc.scalar_type()) : 0,
+                     want_mask ? mask.data_ptr() : nullptr, want_mask ? dt_code(mask.scalar_type()) : 0,
+                     want_y ? y.data_ptr() : nullptr, want_y ? dt_code(y.scalar_type()) : 0, s.outer, s.L, s.inner, (int)K, (int)M,
+                     l.stream), "dmxq_nm_mask");
+  return {mask, y};
+}
+std::tuple<Tensor, Tensor> nm_mask_meta(const Tensor& score, const OptTensor& x, int64_t, int64_t, int64_t, bool want_mask, bool want_y,
+                                        OptDtype mask_dtype, OptDtype y_dtype) {
+  Tensor mask = want_mask ? empty_like_shape(score, mask_dtype) : none_like(score);
+  Tensor y = want_y ? empty_like_shape(score, y_dtype.value_or(at::promote_types(x->scalar_type(), score.scalar_type()))) : none_like(score);
+  return {mask, y};
+}
+
+std::tuple<Tensor, Tensor> topk_mask(const Tensor& score, const OptTensor& x, int64_t n_zero, bool want_mask, bool want_y,
+                                     OptDtype mask_dtype, OptDtype y_dtype) {
+  const Tensor sc = prep(score, "topk_mask");
+  const int64_t n = sc.numel();
+  Tensor xc;
+  if (want_y) {
+    TORCH_CHECK(x.has_value() && x->defined(), "topk_sparsify: x required");
+    xc = prep(*x, "topk_sparsify");
+    if (xc.sizes() != sc.sizes()) xc = xc.expand(sc.sizes()).contiguous();
+  }
+  Tensor mask = want_mask ? empty_like_shape(sc, mask_dtype) : none_like(sc);
+  Tensor y = want_y ? empty_like_shape(sc, y_dtype.value_or(at::promote_types(xc.scalar_type(), sc.scalar_type()))) : none_like(sc);
+  const int64_t ws_bytes = dmxq_topk_workspace_bytes(n);
+  Tensor ws = at::empty({std::max<int64_t>(1, (ws_bytes + 7) / 8)}, sc.options().dtype(at::kLong));
+  Launch l(sc);
+  check(dmxq_topk_mask(sc.data_ptr(), dt_code(sc.scalar_type()), want_y ? xc.data_ptr() : nullptr, want_y ? dt_code(xc.scalar_type()) : 0,
+                       want_mask ? mask.data_ptr() : nullptr, want_mask ? dt_code(mask.scalar_type()) : 0,
+                       want_y ? y.data_ptr() : nullptr, want_y ? dt_code(y.scalar_type()) : 0, n, n_zero, ws.data_ptr(), l.stream),
+        "dmxq_topk_mask");
+  return {mask, y};
+}
+std::tuple<Tensor, Tensor> topk_mask_meta(const Tensor& score, const OptTensor& x, int64_t, bool want_mask, bool want_y,
+                                          OptDtype mask_dtype, OptDtype y_dtype) {
+  return nm_mask_meta(score, x, 0, 1, -1, want_mask, want_y, mask_dtype, y_dtype);
+}
+
+Tensor bernoulli_mask(const Tensor& score, int64_t seed, OptDtype mask_dtype) {
+  const Tensor sc = prep(score, "bernoulli_mask");
+  Tensor mask = empty_like_shape(sc, mask_dtype);
+  Launch l(sc);
+  check(dmxq_bernoulli_mask(sc.data_ptr(), mask.data_ptr(), dt_code(sc.scalar_type()), dt_code(mask.scalar_type()), sc.numel(),
+                            (uint64_t)seed, l.stream), "dmxq_bernoulli_mask");
+  return mask;
+}
+Tensor bernoulli_mask_meta(const Tensor& score, int64_t, OptDtype mask_dtype) { return empty_like_shape(score, mask_dtype); }
+
+// ------------------------------------------------------------------------------------------------ calibration
+std::tuple<Tensor, Tensor> group_minmax(const Tensor& x, int64_t ch_axis, int64_t group_size) {
+  const Tensor xc = prep(x, "group_minmax");
+  TORCH_CHECK(group_size >= 1, "group_minmax: group_size must be positive");
+  const Split3 s = split3(xc, ch_axis);
+  const int64_t G = (s.L + group_size - 1) / group_size;
+  Tensor mn = at::empty({G}, xc.options().dtype(at::kFloat)), mx = at::empty({G}, xc.options().dtype(at::kFloat));
+  Launch l(xc);
+  check(dmxq_group_minmax(xc.data_ptr(), dt_code(xc.scalar_type()), s.outer, s.L, s.inner, group_size, (float*)mn.data_ptr(),
+                          (float*)mx.data_ptr(), l.stream), "dmxq_group_minmax");
+  return {mn, mx};
+}
+std::tuple<Tensor, Tensor> group_minmax_meta(const Tensor& x, int64_t ch_axis, int64_t group_size) {
+  const Split3 s = split3(x, ch_axis);
+  const int64_t G = (s.L + std::max<int64_t>(group_size, 1) - 1) / std::max<int64_t>(group_size, 1);
+  return {at::empty({G}, x.options().dtype(at::kFloat)), at::empty({G}, x.options().dtype(at::kFloat))};
+}
+
+std::tuple<Tensor, Tensor> qparams(const Tensor& mn, const Tensor& mx, int64_t qmin, int64_t qmax, bool symmetric) {
+  TORCH_CHECK(mn.is_cuda(), "qparams: tensors must be on the GPU (no CPU fallback)");
+  const Tensor a = mn.to(at::kFloat).contiguous(), b = mx.to(at::kFloat).contiguous();
+  Tensor scale = at::empty_like(a), zp = at::empty(a.sizes(), a.options().dtype(at::kLong));
+  Launch l(a);
+  check(dmxq_qparams((const float*)a.data_ptr(), (const float*)b.data_ptr(), a.numel(), (int)qmin, (int)qmax, symmetric,
+                     (float*)scale.data_ptr(), (int64_t*)zp.data_ptr(), l.stream), "dmxq_qparams");
+  return {scale, zp};
+}
+std::tuple<Tensor, Tensor> qparams_meta(const Tensor& mn, const Tensor&, int64_t, int64_t, bool) {
+  return {at::empty(mn.sizes(), mn.options().dtype(at::kFloat)), at::empty(mn.sizes(), mn.options().dtype(at::kLong))};
+}
+
+Tensor histc(const Tensor& x, int64_t bins, double lo, double hi) {
+  const Tensor xc = prep(x, "histc").reshape({-1});
+  Tensor out = at::empty({bins}, xc.options().dtype(at::kFloat));
+  Launch l(xc);
+  check(dmxq_histc(xc.data_ptr(), dt_code(xc.scalar_type()), xc.numel(), bins, (float)lo, (float)hi, (float*)out.data_ptr(), l.stream),
+        "dmxq_histc");
+  return out;
+}
+Tensor histc_meta(const Tensor& x, int64_t bins, double, double) { return at::empty({bins}, x.options().dtype(at::kFloat)); }
+
+Tensor channel_maxabs(const Tensor& x, int64_t ch_axis) {
+  const Tensor xc = prep(x, "channel_maxabs");
+  const Split3 s = split3(xc, ch_axis);
+  Tensor out = at::empty({s.L}, xc.options().dtype(at::kFloat));
+  Launch l(xc);
+  check(dmxq_channel_maxabs(xc.data_ptr(), dt_code(xc.scalar_type()), s.outer, s.L, s.inner, (float*)out.data_ptr(), l.stream),
+        "dmxq_channel_maxabs");
+  return out;
+}
+Tensor channel_maxabs_meta(const Tensor& x, int64_t ch_axis) { return at::empty({split3(x, ch_axis).L}, x.options().dtype(at::kFloat)); }
+
+Tensor smoothquant_scale(const Tensor& a_maxabs, const Tensor& b_maxabs, double alpha, double scale_min) {
+  TORCH_CHECK(a_maxabs.is_cuda(), "smoothquant_scale: tensors must be on the GPU (no CPU fallback)");
+  const Tensor a = a_maxabs.to(at::kFloat).contiguous(), b = b_maxabs.to(a.device(), at::kFloat).contiguous();
+  Tensor out = at::empty_like(a);
+  Launch l(a);
+  check(dmxq_smoothquant_scale((const float*)a.data_ptr(), (const float*)b.data_ptr(), a.numel(), (float)alpha, (float)scale_min,
+                               (float*)out.data_ptr(), l.stream), "dmxq_smoothquant_scale");
+  return out;
+}
+Tensor smoothquant_scale_meta(const Tensor& a, const Tensor&, double, double) { return at::empty(a.sizes(), a.options().dtype(at::kFloat)); }
+
+Tensor scale_channels(const Tensor& x, const Tensor& scale, int64_t ch_axis, bool divide, OptDtype out_dtype) {
+  const Tensor xc = prep(x, "scale_channels");
+  const Split3 s = split3(xc, ch_axis);
+  const Tensor sc = scale.detach().to(xc.device(), at::kFloat).contiguous();
+  TORCH_CHECK_VALUE(sc.numel() == s.L, "scale_channels: scale has ", sc.numel(), " entries for ", s.L, " channels");
+  Tensor out = empty_like_shape(xc, out_dtype);
+  Launch l(xc);
+  check(dmxq_scale_channels(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), dt_code(out.scalar_type()), s.outer, s.L, s.inner,
+                            (const float*)sc.data_ptr(), divide, l.stream), "dmxq_scale_channels");
+  return out;
+}
+Tensor scale_channels_meta(const Tensor& x, const Tensor&, int64_t, bool, OptDtype out_dtype) { return empty_like_shape(x, out_dtype); }
+
+// ------------------------------------------------------------------------------------------------ approximator slot
+// kind: the dmxq_unary_kind of include/dmxq.h (exact gelu / tanh gelu / silu / quick_gelu / exp / experimental silu)
+Tensor unary(const Tensor& x, int64_t kind, double param, OptDtype out_dtype) {
+  const Tensor xc = prep(x, "unary");
+  Tensor out = empty_like_shape(xc, out_dtype);
+  Launch l(xc);
+  check(dmxq_unary(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), dt_code(out.scalar_type()), xc.numel(), (int)kind, (float)param,
+                   l.stream), "dmxq_unary");
+  return out;
+}
+Tensor unary_meta(const Tensor& x, int64_t, double, OptDtype out_dtype) { return empty_like_shape(x, out_dtype); }
+
+Tensor softmax(const Tensor& x, double clamp_min, OptDtype out_dtype) {  // over the contiguous last dim
+  const Tensor xc = prep(x, "softmax");
+  const int64_t cols = xc.dim() ? xc.size(-1) : 1;
+  const int64_t rows = cols ? xc.numel() / cols : 0;
+  Tensor out = empty_like_shape(xc, out_dtype);
+  Launch l(xc);
+  check(dmxq_softmax(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), dt_code(out.scalar_type()), rows, cols, (float)clamp_min,
+                     l.stream), "dmxq_softmax");
+  return out;
+}
+Tensor softmax_meta(const Tensor& x, double, OptDtype out_dtype) { return empty_like_shape(x, out_dtype); }
+
+// norm: 0 = LayerNorm (mean / variance), 1 = RMSNorm; over the trailing `cols` elements
+Tensor norm(const Tensor& x, int64_t cols, const OptTensor& weight, const OptTensor& bias, double eps, int64_t kind, OptDtype out_dtype) {
+  const Tensor xc = prep(x, "norm");
+  const int64_t rows = cols ? xc.numel() / cols : 0;
+  Tensor w, b;
+  if (weight.has_value() && weight->defined()) w = weight->detach().contiguous();
+  if (bias.has_value() && bias->defined()) b = bias->detach().contiguous();
+  if (w.defined() && b.defined() && w.scalar_type() != b.scalar_type()) b = b.to(w.scalar_type());
+  const int wb = w.defined() ? dt_code(w.scalar_type()) : (b.defined() ? dt_code(b.scalar_type()) : 0);
+  Tensor out = empty_like_shape(xc, out_dtype);
+  Launch l(xc);
+  if (kind == 0)
+    check(dmxq_layernorm(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), dt_code(out.scalar_type()), rows, cols,
+                         w.defined() ? w.data_ptr() : nullptr, b.defined() ? b.data_ptr() : nullptr, wb, (float)eps, l.stream), "dmxq_layernorm");
+  else
+    check(dmxq_rmsnorm(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), dt_code(out.scalar_type()), rows, cols,
+                       w.defined() ? w.data_ptr() : nullptr, wb, (float)eps, l.stream), "dmxq_rmsnorm");
+  return out;
+}
+Tensor norm_meta(const Tensor& x, int64_t, const OptTensor&, const OptTensor&, double, int64_t, OptDtype out_dtype) {
+  return empty_like_shape(x, out_dtype);
+}
+
+}  // namespace
+
+TORCH_LIBRARY(dmxq, m) {
+  m.def("bfp_qdq(Tensor x, int precision, int block_size, int block_dim=-1, bool symmetric=True, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");
+  m.def("block_quantize(Tensor a, int wl, bool symmetric, int rounding, int seed=0) -> Tensor");
+  m.def("bfp_qdq_multi(Tensor[] xs, int precision, int block_size, int block_dim=-1, bool symmetric=True, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor[]");
+  m.def("bfp_pack(Tensor x, int precision, int block_size, bool symmetric=True) -> (Tensor, Tensor)");
+  m.def("bfp_unpack(Tensor mant, Tensor exps, int precision, int block_size, ScalarType out_dtype) -> Tensor");
+  m.def("weight_hypernet(Tensor w, int precision, int block_size, bool symmetric, Tensor? score, int K, int M, Tensor? sq_scale, ScalarType? out_dtype=None) -> Tensor");
+  m.def("sbfp_qdq(Tensor x, int precision, int block_size, int scaler_man, int scaler_exp, int scaler_bias, bool scaler_flush, bool clamp, bool symmetric, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
+  m.def("mxfp_qdq(Tensor x, int man, int exp, int block_size, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
+  m.def("float_qdq(Tensor x, int man, int exp, int bias, bool flush_subnormal, bool unsigned_abs=False, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");
+  m.def("fixed_qdq(Tensor x, int precision, int fraction, bool clamp, bool symmetric, int rounding, Tensor? scale, Tensor? zero_point, int? ch_axis, int? group_size, ScalarType? out_dtype=None, int seed=0) -> Tensor");
+  m.def("nm_mask(Tensor score, Tensor? x, int K, int M, int block_dim, bool want_mask, bool want_y, ScalarType? mask_dtype=None, ScalarType? y_dtype=None) -> (Tensor, Tensor)");
+  m.def("topk_mask(Tensor score, Tensor? x, int n_zero, bool want_mask, bool want_y, ScalarType? mask_dtype=None, ScalarType? y_dtype=None) -> (Tensor, Tensor)");
+  m.def("bernoulli_mask(Tensor score, int seed, ScalarType? mask_dtype=None) -> Tensor");
+  m.def("group_minmax(Tensor x, int ch_axis, int group_size) -> (Tensor, Tensor)");
+  m.def("qparams(Tensor mn, Tensor mx, int qmin, int qmax, bool symmetric_qscheme) -> (Tensor, Tensor)");
+  m.def("histc(Tensor x, int bins, float lo, float hi) -> Tensor");
+  m.def("channel_maxabs(Tensor x, int ch_axis) -> Tensor");
+  m.def("smoothquant_scale(Tensor a_maxabs, Tensor b_maxabs, float alpha, float scale_min) -> Tensor");
+  m.def("scale_channels(Tensor x, Tensor scale, int ch_axis, bool divide, ScalarType? out_dtype=None) -> Tensor");
+  m.def("unary(Tensor x, int kind, float param=0.0, ScalarType? out_dtype=None) -> Tensor");
+  m.def("softmax(Tensor x, float clamp_min, ScalarType? out_dtype=None) -> Tensor");
+  m.def("norm(Tensor x, int cols, Tensor? weight, Tensor? bias, float eps, int kind, ScalarType? out_dtype=None) -> Tensor");
+}
+
+#define DMXQ_IMPL(m, name) m.impl(#name, &name)
+#define DMXQ_META(m, name) m.impl(#name, &name##_meta)
+#define DMXQ_FOR_ALL(X, m) \
+  X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
+  X(m, float_qdq); X(m, fixed_qdq); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
+  X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, softmax); X(m, norm)
+
+// "CUDA" is the dispatch key of HIP tensors in a ROCm build of PyTorch
+TORCH_LIBRARY_IMPL(dmxq, CUDA, m) { DMXQ_FOR_ALL(DMXQ_IMPL, m); }
+TORCH_LIBRARY_IMPL(dmxq, Meta, m) { DMXQ_FOR_ALL(DMXQ_META, m); }

@@ -26,7 +26,7 @@ from .smoothquant import ActivationWeightSmoothQuant
 from .sparse import Dense, Sparsify
 
 __all__ = ["DmxModule", "DmxQuantizerCalibrationHyperparams", "DmxModuleQuantizerCalibrationHyperparams",
-           "DmxModuleSmoothQuantHyperparams", "Linear", "Conv1d", "Conv2d", "ResAdd", "ActActMatMul", "Softmax", "LayerNorm", "GELU", "ReLU",
+           "DmxModuleSmoothQuantHyperparams", "Linear", "Conv1d", "Conv2d", "ResAdd", "ActActMatMul", "Softmax", "LayerNorm", "GELU", "ReLU", "SiLU", "QuickGELU", "Exp", "Mul", "RMSNorm",
            "MaxPool2d", "AvgPool2d", "Embedding", "DmxConfigRule", "configure_model"]
 
 
@@ -350,7 +350,7 @@ class DmxModule(torch.nn.Module):
             with torch.no_grad():
                 _approx = self.approximator_wrapper(inputs, args, kwargs, **self.approximator.function.wrapper_params)
                 self.approximation_error = _approx - _output.data
-                _output.data = _approx.to(_output.dtype)
+                _output.data = _approx  # (no dtype alignment here, as in the reference: experimental.silu hands back float16)
         return _output
 
 
@@ -468,6 +468,64 @@ class GELU(DmxModule, torch.nn.GELU):
 
     def _forward(self, _input):
         return self.approx_forward((_input,), approximate=self.approximate)
+
+
+class SiLU(DmxModule, torch.nn.SiLU):
+    """torch_modules.py:1559-1576"""
+
+    def __init__(self, inplace: bool = False):
+        torch.nn.SiLU.__init__(self, inplace=False)
+        self._dmx_init()
+        self.functional_forward = F.silu
+
+    def _forward(self, _input):
+        return self.approx_forward((_input,))
+
+
+class QuickGELU(DmxModule):
+    """custom_modules.py:112-117: transformers' QuickGELUActivation, `x * sigmoid(1.702 * x)` in the input dtype"""
+
+    def __init__(self):
+        torch.nn.Module.__init__(self)
+        self._dmx_init()
+        self.functional_forward = lambda x: x * torch.sigmoid(1.702 * x)
+
+    def _forward(self, _input):
+        return self.approx_forward((_input,))
+
+
+class Exp(DmxModule):
+    """torch_modules.py:236-242 (no approximator slot in the reference: plain torch.exp between the casts)"""
+
+    def __init__(self):
+        torch.nn.Module.__init__(self)
+        self._dmx_init()
+
+    def _forward(self, _input):
+        return torch.exp(_input)
+
+
+class Mul(DmxModule):
+    """torch_modules.py:67-80: elementwise product of two cast inputs (Llama's gate * up)"""
+
+    def __init__(self):
+        torch.nn.Module.__init__(self)
+        self._dmx_init(input_names=("input_cast", "multiplier_cast"))
+
+    def _forward(self, _input, multiplier):
+        return _input * multiplier
+
+
+class RMSNorm(DmxModule, torch.nn.RMSNorm):
+    """torch_modules.py:1144-1170"""
+
+    def __init__(self, normalized_shape, eps: float = 1e-6):
+        torch.nn.RMSNorm.__init__(self, normalized_shape, eps=eps)
+        self._dmx_init()
+        self.functional_forward = F.rms_norm
+
+    def _forward(self, _input):
+        return self.approx_forward((_input,), self.normalized_shape, self._weight_ro, self.eps)
 
 
 class ReLU(DmxModule, torch.nn.ReLU):

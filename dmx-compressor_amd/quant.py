@@ -34,13 +34,16 @@ def _block(a, wl, dim, symmetric, rounding):
     _check_native_input(a, "block_quantize")
     if a.numel() == 0:
         return torch.zeros_like(a)
+    # one launch on a [rows, L] view with one block per row.  symmetric = False is the NATIVE branch of
+    # block_quantize_helper (quant_cpu.cpp:247-253), which the Python layer never requests (format.py:332) but which is
+    # part of this seam; it is NOT the asymmetric format "(_N)" (that is Format.cast's post-pass, ops.bfp_qdq).
     if dim == -1:  # one block = the whole tensor (get_max_entry dim == -1, quant_cpu.cpp:280-283)
-        return ops.bfp_qdq(a.reshape(1, -1), wl, a.numel(), -1, symmetric, rounding).reshape(a.shape)
+        return ops.block_quantize(a.reshape(1, -1), wl, symmetric, rounding).reshape(a.shape)
     if dim == 0:   # one block per leading index
-        return ops.bfp_qdq(a.reshape(a.shape[0], -1), wl, max(a[0].numel(), 1), -1, symmetric, rounding).reshape(a.shape)
+        return ops.block_quantize(a.reshape(a.shape[0], -1), wl, symmetric, rounding).reshape(a.shape)
     # one block per index of `dim`: the block runs over every other dimension (quant_cpu.cpp:289-295)
     t = a.transpose(0, dim).contiguous()
-    y = ops.bfp_qdq(t.reshape(t.shape[0], -1), wl, max(t[0].numel(), 1), -1, symmetric, rounding).reshape(t.shape)
+    y = ops.block_quantize(t.reshape(t.shape[0], -1), wl, symmetric, rounding).reshape(t.shape)
     return y.transpose(0, dim).contiguous()
 
 

@@ -48,9 +48,24 @@ int dmxq_abi_version(void);
  *           + the `.float()` / `.to(physical_dtype)` round trip of numerical/cast.py:262,306 (dtype_in/dtype_out).
  * Blocks are `block_size` consecutive indices along L (stride `inner`); a ragged last block is allowed
  * (torch.split semantics).  block_size == 1 takes the reference's float_quantize detour (format.py:312-320).
- * precision = total mantissa bits incl. sign ("8" in BFP[8|8]); 2 <= precision <= 22 when block_size > 1. */
+ * precision = total mantissa bits incl. sign ("8" in BFP[8|8]); 2 <= precision <= 22 when block_size > 1.
+ * symmetric: 1 = symmetric codes; 0 = the asymmetric format "(_N)" = symmetric pass + make_mantissa_asymmetric, which is
+ * all the Python layer ever asks for (format.py:332 forces the native flag to true); DMXQ_BFP_ASYM_NATIVE (2) = the
+ * native `symmetric = false` of the pybind seam block_quantize_*(a, wl, dim, symmetric) (quant_cpu.cpp:247-253: an
+ * element equal to -max whose maximum has its top 7 mantissa bits set takes the next exponent), float32 only. */
+#define DMXQ_BFP_ASYM_NATIVE 2
 int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L, int64_t inner,
                  int64_t block_size, int precision, int rounding, int symmetric, uint64_t seed, void* stream);
+
+/* Multi-tensor BFP Q->DQ: exactly the result of one dmxq_bfp_qdq call per tensor (same dtype pair and format for all),
+ * in as few launches as possible.  Replaces the per-module loop of modeling/model.py fold_weights_and_biases /
+ * DmxModule.weight_hypernet over MANY small weights (opt-125m: 73 Linear weights of 768x768 .. 3072x768, each of which
+ * is launch-bound on its own: ~4 us per launch for 0.4-1.6 us of streaming).  `tensors` is a HOST array; tensors that
+ * are flat row-blocked (inner == 1, L % block_size == 0, 16-byte aligned, nearest rounding) are packed 48 to a launch
+ * over a concatenated tile space, the others get their own launch (stochastic rounding: seed + index). */
+typedef struct { const void* in; void* out; int64_t outer, L, inner; } dmxq_tensor_desc;
+int dmxq_bfp_qdq_multi(const dmxq_tensor_desc* tensors, int64_t n_tensors, int dtype_in, int dtype_out,
+                       int64_t block_size, int precision, int rounding, int symmetric, uint64_t seed, void* stream);
 
 /* Introspection (no launch): writes into buf (NUL-terminated, at most buf_len bytes) the kernel and tile geometry that
  * dmxq_bfp_qdq would launch for these arguments; `aligned` = both pointers are 16-byte aligned.  bench.py reports it
@@ -176,6 +191,25 @@ int dmxq_weight_hypernet(const void* w, int dtype_w, const void* score, int dtyp
  * 989-998, `input_clamp` wrapper argument = input_clamp_min, -INFINITY disables) and LayerNorm (:1062-1082).
  * softmax / layernorm act on the contiguous last dim of a [rows, cols] view. weight/bias may be NULL. */
 int dmxq_gelu(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int tanh_form, void* stream);
+
+/* The other per-element function ids of the approximator slot (src/dmx/compressor/__init__.py:108-139).
+ * GELU / GELU_TANH / SILU / EXP: the exact torch function in fp32, rounded once to dtype_out (what the reference computes
+ * with vsimd absent, functional/approximate.py:300-304; modules torch_modules.py:1559-1576 SiLU, :236-242 Exp).
+ * QUICK_GELU: transformers' QuickGELUActivation `x * sigmoid(1.702 * x)` (modeling/nn/custom_modules.py:112-117),
+ * evaluated in the INPUT dtype like torch does (three roundings for 16-bit tensors).
+ * SILU_EXPERIMENTAL: the reference's one in-repo approximation, functional/functions.py:7-21
+ * `relu(x.to(float16)) * scale` (param = scale; dtype_out must be DMXQ_F16), reproduced bit for bit. */
+typedef enum {
+  DMXQ_UNARY_GELU = 0, DMXQ_UNARY_GELU_TANH = 1, DMXQ_UNARY_SILU = 2, DMXQ_UNARY_QUICK_GELU = 3, DMXQ_UNARY_EXP = 4,
+  DMXQ_UNARY_SILU_EXPERIMENTAL = 5
+} dmxq_unary_kind;
+int dmxq_unary(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int kind, float param, void* stream);
+
+/* RMSNorm over the contiguous last dim of a [rows, cols] view: y = x * rsqrt(mean(x^2) + eps) * weight, in fp32,
+ * rounded once to dtype_out (torch.nn.functional.rms_norm's CPU result).  Replaces: modeling/nn/torch_modules.py:
+ * 1144-1170 RMSNorm._forward -> approx_forward(F.rms_norm).  weight may be NULL. */
+int dmxq_rmsnorm(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols, const void* weight,
+                 int dtype_w, float eps, void* stream);
 int dmxq_softmax(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
                  float input_clamp_min, void* stream);
 int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,

@@ -115,6 +115,20 @@ int oracle_float_qdq(const float* in, float* out, int64_t n, int man, int exp_bi
 /* ------------------------------------------------------------------------------------------- block floating point
  * quant_cpu.cpp:239-275 block_quantize_helper for one element, given the block's max|x| (symmetric=true path,
  * the only one the Python layer ever requests: numerical/format.py:332). */
+static inline float bfp_q1n(float x, float maxabs, int wl, int rounding, uint32_t rnd, int native_asym) {
+  uint32_t max_num = f2u(maxabs);
+  /* quant_cpu.cpp:247-253, the NATIVE symmetric == false branch (never requested by the Python layer,
+   * numerical/format.py:332 forces true): an element that equals -max, when the top 7 mantissa bits of the maximum are
+   * all ones, is quantised with the NEXT exponent (per element: the loop variable max_num is local to the element). */
+  if (native_asym && x == -maxabs && ((max_num >> 16) << 25) == 0xFE000000u) max_num = ((max_num >> 23) + 1u) << 23;
+  const uint32_t max_exp = max_num & 0x7F800000u; /* (max_num << 1 >> 24 << 23) */
+  const float base = u2f(max_exp) * 6.0f;
+  const float t = x + base;
+  const uint32_t qb = round_bitwise(f2u(t), wl, rounding, rnd);
+  const float q = u2f(qb) - base;
+  return u2f(clip_max_exponent(wl - 2, max_exp, f2u(q)));
+}
+
 static inline float bfp_q1(float x, float maxabs, int wl, int rounding, uint32_t rnd) {
   const uint32_t max_exp = f2u(maxabs) & 0x7F800000u; /* (max_num << 1 >> 24 << 23) */
   const float base = u2f(max_exp) * 6.0f;
@@ -170,11 +184,13 @@ int oracle_bfp_qdq(const float* in, float* out, int64_t rows, int64_t L, int64_t
        * makes the block's exponent field 0xFF, base = inf and every element of the block NaN. */
       for (int64_t i = 0; i < len; i++) { float a = fabsf(xi[b0 + i]); if (a > m || isnan(a)) m = a; }
       for (int64_t i = 0; i < len; i++)
-        yo[b0 + i] = bfp_q1(xi[b0 + i], m, wl, rounding,
-                            rounding == R_STOCHASTIC ? rnd_bits(seed, (uint64_t)(r * L + b0 + i)) : 0u);
+        yo[b0 + i] = bfp_q1n(xi[b0 + i], m, wl, rounding,
+                             rounding == R_STOCHASTIC ? rnd_bits(seed, (uint64_t)(r * L + b0 + i)) : 0u, symmetric == 2);
       /* NaN/Inf maximum, or a maximum >= 2^126 whose base 6*2^e overflows: the symmetric pass already turned the
        * whole block into NaN and the reference's post-pass is garbage-in/garbage-out there -> the block stays NaN */
-      if (!symmetric && isfinite(m) && isfinite(u2f(f2u(m) & 0x7F800000u) * 6.0f)) bfp_asym_block(yo + b0, xi + b0, len, wl);
+      /* symmetric: 1 = symmetric, 0 = the Python layer's asymmetric post-pass (format.py:349-372), 2 = the native
+       * symmetric == false branch of block_quantize_helper (no post-pass) */
+      if (symmetric == 0 && isfinite(m) && isfinite(u2f(f2u(m) & 0x7F800000u) * 6.0f)) bfp_asym_block(yo + b0, xi + b0, len, wl);
     }
   }
   return 0;

@@ -108,6 +108,56 @@ def bfp_cast(x, precision, block_size, block_dim=-1, symmetric=True, rounding="n
     return out.reshape(shp).movedim(-1, block_dim)
 
 
+def block_quantize_native(a, wl, dim=-1, symmetric=True, rounding="nearest", seed=0):
+    """quant_cpu.cpp:299-311 block_quantize_<rounding>(a, wl, dim, symmetric) with get_max_entry's block layouts (:277-297):
+    dim -1 = the whole tensor is one block, 0 = one block per leading index, d > 0 = one block per index of dim d.
+    symmetric False = the NATIVE branch (:247-253), not the Python post-pass."""
+    af = a.detach().to(torch.float32).contiguous()
+    if af.numel() == 0:
+        return af.clone()
+    if dim == -1:
+        x2 = af.reshape(1, -1)
+    elif dim == 0:
+        x2 = af.reshape(af.shape[0], -1)
+    else:
+        t = af.transpose(0, dim).contiguous()
+        x2 = t.reshape(t.shape[0], -1)
+    out = torch.empty_like(x2)
+    _check(lib().oracle_bfp_qdq(_ptr(x2), _ptr(out), x2.shape[0], x2.shape[1], max(x2.shape[1], 2), wl, ROUNDING[rounding],
+                                1 if symmetric else 2, seed), "bfp_qdq(native)")
+    if dim in (-1, 0):
+        return out.reshape(af.shape)
+    return out.reshape(t.shape).transpose(0, dim).contiguous()
+
+
+def bfp_pack(x, precision, block_size, symmetric=True):
+    """Packed on-wire BFP (the QuantizeBFP / DequantizeBFP pair named by numerical/cast.py:34-55, ids numerical/onnx.py):
+    int8 two's-complement mantissa codes + one uint8 shared exponent per block, stated INDEPENDENTLY of the kernel's
+    code extraction: codes = Q->DQ(x) / 2^(e - (p-2)) with Q->DQ the oracle's BFP cast and e the exponent of the block
+    maximum; exps = biased fp32 exponent field of the block maximum.  Blocks with a zero / denormal maximum pack to
+    zero codes with exps = 0, Inf / NaN maxima to zero codes with exps = 255 (include/dmxq.h)."""
+    xf = x.detach().to(torch.float32).contiguous()
+    L = xf.shape[-1]
+    x2 = xf.reshape(-1, L)
+    q = bfp_cast(x2, precision, block_size, -1, symmetric).numpy().astype(np.float64)
+    nblk = -(-L // block_size)
+    pad = nblk * block_size - L
+    a = np.abs(x2.numpy())
+    a = np.pad(a, ((0, 0), (0, pad)))  # zeros do not change a maximum; NaN must win like torch.max: handled below
+    blk = a.reshape(-1, nblk, block_size)
+    m = np.where(np.isnan(blk).any(-1), np.float32(np.nan), blk.max(-1)).astype(np.float32)
+    eb = ((m.view(np.uint32) >> 23) & 0xFF).astype(np.int64)
+    quantum = np.ldexp(1.0, (eb - 127 - (precision - 2)))
+    qpad = np.pad(q, ((0, 0), (0, pad))).reshape(-1, nblk, block_size)
+    ok = ((eb > 0) & (eb < 255))[..., None]
+    codes = np.where(ok, qpad / quantum[..., None], 0.0)
+    codes = np.where(np.isfinite(codes), codes, 0.0)
+    assert np.all(codes == np.round(codes)) and np.all(np.abs(codes) <= 2 ** (precision - 1)), "codes must be integers"
+    mant = torch.from_numpy(codes.reshape(-1, nblk * block_size)[:, :L].astype(np.int8)).reshape(xf.shape)
+    exps = torch.from_numpy(eb.astype(np.uint8)).reshape(tuple(xf.shape[:-1]) + (nblk,))
+    return mant, exps
+
+
 def fixed_point_cast(x, precision, fraction, clamp=True, symmetric=True, rounding="nearest", seed=0):
     """numerical/format.py:134-142 FixedPoint.cast -> quant_cpu.cpp:148-167."""
     xi = _f32c(x)
@@ -244,3 +294,9 @@ def bernoulli_mask(score, seed):
     out = torch.empty_like(sc)
     _check(lib().oracle_bernoulli_mask(_ptr(sc), _ptr(out), sc.numel(), seed), "bernoulli_mask")
     return out.to(score.dtype)
+
+
+def silu_experimental(x, scale):
+    """functional/functions.py:7-21 `experimental.silu`: relu(input.to(float16)) * scale -> float16 (torch's own CPU ops:
+    the statement IS the algorithm).  Pinned against the reference's SiLU module in tests/golden/approx.npz."""
+    return torch.nn.functional.relu(x.detach().to(torch.float16)) * scale

@@ -39,7 +39,7 @@ class _Bidict(dict):
         return {v: k for k, v in self.items()}
 
 
-_TYPE_RE = {"d": r"[-+]?\d+", "w": r"\w", "l": r"[A-Za-z]", "f": r"[-+]?\d*\.?\d+(?:[eE][-+]?\d+)?"}
+_TYPE_RE = {"d": r"[-+]?\d+", "w": r"\w+", "l": r"[A-Za-z]+", "f": r"[-+]?\d*\.?\d+(?:[eE][-+]?\d+)?"}
 _CONV = {"d": int, "f": float}
 
 

@@ -312,3 +312,45 @@ def test_vocabulary_matches_reference(dmx):
         assert repr(mine[n]) == r, n
     for n, r in zip([str(s) for s in g["sparse_names"]], [str(s) for s in g["sparse_reprs"]]):
         assert repr(getattr(dmx.sparseness, n)) == r, n
+
+
+def test_native_asym_oracle_matches_the_reference_extension(oracle):
+    """oracle.block_quantize_native(symmetric=False) == the reference's compiled block_quantize_*(a, wl, dim, False)
+    (quant_cpu.cpp:247-253) on the committed fixture (oracle/gen_golden_r2.py)."""
+    z = np.load(os.path.join(GOLD, "native_asym.npz"))
+    shapes = {0: (16, 64), -1: (8, 32), 1: (4, 16, 8), 2: (4, 16, 8)}
+    n_diff = 0
+    for i in range(int(z["n"])):
+        dim = int(z[f"dim{i}"])
+        x = tensor(z[f"x{i}"], torch.float32).reshape(shapes[dim])
+        for wl in (4, 8, 12):
+            for rnd in ("nearest", "down", "up"):
+                want = tensor(z[f"y{i}_{wl}_{rnd}"], torch.float32).reshape(x.shape)
+                got = oracle.block_quantize_native(x, wl, dim, False, rnd)
+                assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (i, wl, rnd)
+                n_diff += int(not torch.equal(oracle.block_quantize_native(x, wl, dim, True, rnd).view(torch.int32), want.view(torch.int32)))
+    assert n_diff > 50   # the fixture really exercises the branch
+
+
+def test_experimental_silu_oracle_matches_the_reference_module(oracle):
+    z = np.load(os.path.join(GOLD, "approx.npz"))
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16), ("f16", torch.float16)):
+        x = tensor(z[f"x_{name}"], dt)
+        for i in range(4):
+            got = oracle.silu_experimental(x, float(z[f"scale_{i}"]))
+            want = tensor(z[f"raw_{name}_{i}"], torch.float16)
+            both_nan = torch.isnan(got) & torch.isnan(want)
+            assert bool(((got.view(torch.int16) == want.view(torch.int16)) | both_nan).all())
+
+
+def test_packed_bfp_oracle_is_consistent_with_the_cast_oracle(oracle):
+    """codes * 2^(exps - 127 - (p - 2)) reproduces the oracle's Q->DQ wherever the block maximum is a normal number"""
+    from _data import make
+    x = make("mixed", (16, 200), seed=3, dtype=torch.float32, block=16)
+    for wl, B, sym in ((8, 16, True), (8, 64, False), (4, 24, True)):
+        mant, exps = oracle.bfp_pack(x, wl, B, sym)
+        q = oracle.bfp_cast(x, wl, B, -1, sym)
+        e = exps.repeat_interleave(B, dim=-1)[..., : x.shape[-1]].to(torch.int32)
+        y = torch.ldexp(mant.float(), e - 127 - (wl - 2))
+        ok = (e > 0) & (e < 255)
+        assert torch.equal(y[ok].view(torch.int32), q[ok].view(torch.int32))

@@ -1,0 +1,175 @@
+"""-m gpu parity tests added in round 2: the multi-tensor entry point, every tile geometry of the flat-stream BFP kernel
+at the tensor sizes that select it (shape-dependent dispatch is where size-specific bugs hide), and the shapes of
+BASELINE.json configs 3 / 4 / 5 at FULL size against the oracle.
+
+Reference behaviour: numerical/format.py:304-343 (BFP), numerical/cast.py:278-296 (affine INT8 group quant),
+sparse.py:163-180 + 287-301 (N:M mask, apply), functional/approximate.py:300-327 (exact softmax).  Bit-exact unless a
+tolerance is written in the test.
+"""
+import ctypes
+
+import pytest
+import torch
+
+from _data import bits_equal, make
+
+pytestmark = pytest.mark.gpu
+
+
+def _opt125m_weight_shapes():
+    """the 73 Linear weights of facebook/opt-125m (12 layers x q,k,v,o 768x768 + fc1 3072x768 + fc2 768x3072) + lm_head"""
+    shapes = []
+    for _ in range(12):
+        shapes += [(768, 768)] * 4 + [(3072, 768), (768, 3072)]
+    return shapes + [(50272, 768)]
+
+
+def test_bfp_multi_matches_oracle_per_tensor(dmx, cuda, oracle):
+    # a mix of batchable tensors (flat row blocks), a ragged one, a strided-block one and an empty one
+    shapes = [(768, 768), (64, 3072), (5, 40), (3, 16, 7), (0, 64), (1, 16), (257, 512), (1024, 4096)]
+    dims = [-1, -1, -1, 1, -1, -1, -1, -1]
+    xs = [make("mixed" if i % 2 else "heavy", s, seed=40 + i, dtype=torch.bfloat16, block=16) for i, s in enumerate(shapes)]
+    # (block_dim is shared by a multi call: run the dim = 1 tensor in its own call, the others together)
+    same = [i for i, d in enumerate(dims) if d == -1]
+    got = dmx.ops.bfp_qdq_multi([xs[i].to(cuda) for i in same], 8, 16)
+    for g, i in zip(got, same):
+        assert bits_equal(g, oracle.bfp_cast(xs[i], 8, 16).to(torch.bfloat16)) == 0, shapes[i]
+    got = dmx.ops.bfp_qdq_multi([xs[3].to(cuda)], 8, 16, block_dim=1)
+    assert bits_equal(got[0], oracle.bfp_cast(xs[3], 8, 16, 1).to(torch.bfloat16).contiguous()) == 0
+
+
+@pytest.mark.parametrize("dtype,out_dtype,wl,B,sym", [(torch.bfloat16, None, 8, 64, True), (torch.float16, None, 8, 16, False),
+                                                      (torch.float32, None, 8, 32, True), (torch.bfloat16, torch.float32, 6, 128, True),
+                                                      (torch.float32, torch.float16, 16, 16, True), (torch.bfloat16, None, 16, 16, True)])
+def test_bfp_multi_dtype_pairs_equal_single_calls(dmx, cuda, dtype, out_dtype, wl, B, sym):
+    # more tensors than one launch takes (48), sizes from one block to a few tiles; compared with the single-tensor
+    # entry point, which the oracle tests pin
+    g = torch.Generator().manual_seed(wl * 7 + B)
+    xs = []
+    for i in range(61):
+        rows = int(torch.randint(1, 90, (1,), generator=g))
+        cols = B * int(torch.randint(1, 40, (1,), generator=g))
+        xs.append(make("mixed_nd" if i % 3 else "mixed", (rows, cols), seed=i, dtype=dtype, block=B).to(cuda))
+    got = dmx.ops.bfp_qdq_multi(xs, wl, B, symmetric=sym, out_dtype=out_dtype)
+    for x, y in zip(xs, got):
+        assert bits_equal(y, dmx.ops.bfp_qdq(x, wl, B, symmetric=sym, out_dtype=out_dtype)) == 0
+
+
+def test_bfp_multi_opt125m_weights_full_size(dmx, cuda, oracle):
+    """BASELINE.json configs[2] shapes: all 73 Linear weights in two launches; every tensor against the oracle."""
+    shapes = _opt125m_weight_shapes()
+    xs = [make("normal", s, seed=900 + i, dtype=torch.bfloat16) * 0.05 for i, s in enumerate(shapes)]
+    got = dmx.ops.bfp_qdq_multi([x.to(cuda) for x in xs], 8, 64)
+    for i, (x, y) in enumerate(zip(xs, got)):
+        if i % 6 in (0, 4, 5) or i == len(xs) - 1:   # one of each shape per layer keeps the CPU side to a few seconds
+            assert bits_equal(y, oracle.bfp_cast(x, 8, 64).to(torch.bfloat16)) == 0, (i, shapes[i])
+
+
+def test_bfp_multi_through_the_c_abi(dmx, cuda):
+    """argument checking and an in-place call, straight through include/dmxq.h"""
+    lib, L = dmx._lib, dmx._lib.lib()
+    x = make("heavy", (32, 256), seed=5, dtype=torch.bfloat16).to(cuda)
+    want = dmx.ops.bfp_qdq(x, 8, 16)
+    y = x.clone()
+    d = (lib.TensorDesc * 2)()
+    d[0].in_, d[0].out, d[0].outer, d[0].L, d[0].inner = y.data_ptr(), y.data_ptr(), 32, 256, 1
+    d[1].in_, d[1].out, d[1].outer, d[1].L, d[1].inner = None, None, 0, 16, 1
+    sp = lib.stream_of(x)
+    assert L.dmxq_bfp_qdq_multi(d, 2, lib.BF16, lib.BF16, 16, 8, lib.ROUND_NEAREST, 1, 0, sp) == lib.OK
+    assert bits_equal(y, want) == 0
+    assert L.dmxq_bfp_qdq_multi(d, -1, lib.BF16, lib.BF16, 16, 8, lib.ROUND_NEAREST, 1, 0, sp) == lib.ERR_BAD_ARG
+    assert L.dmxq_bfp_qdq_multi(None, 2, lib.BF16, lib.BF16, 16, 8, lib.ROUND_NEAREST, 1, 0, sp) == lib.ERR_BAD_ARG
+    assert L.dmxq_bfp_qdq_multi(d, 2, lib.BF16, lib.BF16, 0, 8, lib.ROUND_NEAREST, 1, 0, sp) == lib.ERR_BAD_ARG
+    d[1].outer = 4   # non-empty tensor with null pointers
+    assert L.dmxq_bfp_qdq_multi(d, 2, lib.BF16, lib.BF16, 16, 8, lib.ROUND_NEAREST, 1, 0, sp) == lib.ERR_BAD_ARG
+    assert L.dmxq_bfp_qdq_multi(d, 0, lib.BF16, lib.BF16, 16, 8, lib.ROUND_NEAREST, 1, 0, sp) == lib.OK
+
+
+# every tile geometry of rows_plan (csrc/bfp.hip): 512x1, 128x2, 512x4, 512x6, 512x16, 512x2, each with a partial last tile
+GEOMETRY_ROWS = [(200, "512x1"), (511, "512x1"), (1000, "128x2"), (1535, "128x2"), (2000, "512x4"), (2900, "512x6"),
+                 (3071, "512x6"), (4096, "512x16"), (3900, "512x16"), (5000, "512x2")]
+
+
+@pytest.mark.parametrize("rows,geom", GEOMETRY_ROWS)
+def test_bfp_every_tile_geometry_at_its_size(dmx, cuda, oracle, rows, geom):
+    lib, L = dmx._lib, dmx._lib.lib()
+    buf = ctypes.create_string_buffer(256)
+    assert L.dmxq_bfp_qdq_describe(lib.BF16, lib.BF16, rows, 4096, 1, 16, 8, lib.ROUND_NEAREST, 1, 1, buf, 256) == lib.OK
+    assert f"tile {geom} " in buf.value.decode(), buf.value
+    x = make("mixed", (rows, 4096), seed=rows, dtype=torch.bfloat16, block=16)
+    got = dmx.ops.bfp_qdq(x.to(cuda), 8, 16)
+    assert bits_equal(got, oracle.bfp_cast(x, 8, 16).to(torch.bfloat16)) == 0
+
+
+@pytest.mark.parametrize("rows", [1000, 2900, 4096, 5000])
+@pytest.mark.parametrize("dtype,out_dtype,rounding", [(torch.float32, None, "nearest"), (torch.bfloat16, torch.float32, "nearest"),
+                                                      (torch.bfloat16, None, "down"), (torch.float16, None, "stochastic")])
+def test_bfp_tile_geometries_other_builds(dmx, cuda, oracle, rows, dtype, out_dtype, rounding):
+    x = make("mixed_nd", (rows, 1024), seed=rows + 1, dtype=dtype, block=64)
+    got = dmx.ops.bfp_qdq(x.to(cuda), 8, 64, rounding=rounding, out_dtype=out_dtype, seed=11)
+    want = oracle.bfp_cast(x, 8, 64, -1, True, rounding, 11).to(out_dtype or dtype)
+    assert bits_equal(got, want) == 0
+
+
+# ------------------------------------------------------------------------------------------------ full-size config shapes
+def test_config3_opt125m_int8_group128_full_shapes(dmx, cuda, oracle):
+    """INT8 group_size = 128 along ch_axis 0 (cast.py:179-226, 278-296) on [768,768], [3072,768], [768,3072]: observer
+    (per-group min/max -> qparams) and affine Q->DQ, both on the device, vs the oracle."""
+    for i, shape in enumerate([(768, 768), (3072, 768), (768, 3072)]):
+        w = make("normal", shape, seed=300 + i, dtype=torch.bfloat16) * 0.04
+        mn, mx = oracle.group_minmax(w, 0, 128)
+        sc, zp = oracle.qparams(mn, mx, 8, True, False)
+        gmn, gmx = dmx.ops.group_minmax(w.to(cuda), 0, 128)
+        assert bits_equal(gmn, mn) == 0 and bits_equal(gmx, mx) == 0
+        gsc, gzp = dmx.ops.qparams(gmn, gmx, -127, 127, False)
+        assert bits_equal(gsc, sc) == 0 and torch.equal(gzp.cpu(), zp)
+        got = dmx.ops.fixed_qdq(w.to(cuda), 8, 0, True, True, scale=gsc, zero_point=gzp, ch_axis=0, group_size=128)
+        want = oracle.fixed_point_affine_cast(w, 8, 0, True, True, sc, zp, ch_axis=0, group_size=128).to(torch.bfloat16)
+        assert bits_equal(got, want) == 0, shape
+
+
+@pytest.mark.parametrize("shape", [(14336, 4096), (4096, 14336), (1024, 4096)])
+def test_config4_llama_weight_mask_then_bfp_full_shapes(dmx, cuda, oracle, shape):
+    """BTOPK{2:4,-1} -> BFP16_64 on Llama-3-8B weight shapes (core.py:178-198): fused launch == oracle chain."""
+    w = make("normal", shape, seed=shape[0], dtype=torch.bfloat16) * 0.02
+    score = make("normal", shape, seed=shape[1] + 1, dtype=torch.bfloat16).abs()
+    got = dmx.ops.weight_hypernet(w.to(cuda), 8, 64, True, score.to(cuda), 2, 4)
+    assert got is not None
+    want = oracle.bfp_cast(oracle.sparsify(w, score, 2, 4), 8, 64).to(torch.bfloat16)
+    assert bits_equal(got, want) == 0
+
+
+def test_config4_llama_activation_bfp_block_dim_minus2(dmx, cuda, oracle):
+    """K/V multipliers of the attention matmuls: BFP16_64 along dim -2 (torch_modules.py:197-204), [1, 8, 2048, 128]"""
+    x = make("heavy", (1, 8, 2048, 128), seed=77, dtype=torch.bfloat16, block=64)
+    got = dmx.ops.bfp_qdq(x.to(cuda), 8, 64, -2)
+    assert bits_equal(got, oracle.bfp_cast(x, 8, 64, -2).to(torch.bfloat16).contiguous()) == 0
+
+
+def test_config5_whisper_softmax_1500_full_shape(dmx, cuda):
+    """Whisper-small encoder attention probabilities: softmax over rows of 1500, [1, 12, 1500, 1500] fp32 and bf16.
+    Tolerance: 1 ulp of the output format against fp32 torch.nn.functional.softmax evaluated on the CPU."""
+    x = make("normal", (1, 12, 1500, 1500), seed=1500) * 3.0
+    want = torch.softmax(x, -1)
+    got = dmx.ops.softmax(x.to(cuda), -1).cpu()
+    ulp = torch.abs(want) * 2.0 ** -23 + 2.0 ** -149
+    assert bool((torch.abs(got - want) <= ulp).all())
+    xb = x.to(torch.bfloat16)
+    wantb = torch.softmax(xb.float(), -1).to(torch.bfloat16)
+    gotb = dmx.ops.softmax(xb.to(cuda), -1).cpu()
+    # bf16 output: the correctly rounded result or its neighbour (1 ulp of bf16)
+    d = (gotb.view(torch.int16).int() - wantb.view(torch.int16).int()).abs()
+    assert int(d.max()) <= 1
+
+
+def test_ops_follow_the_tensor_device_not_the_current_one(dmx, cuda):
+    """a tensor on a non-current device must be processed on ITS device (needs 2 GPUs)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    x = make("heavy", (64, 256), seed=2, dtype=torch.bfloat16)
+    want = dmx.ops.bfp_qdq(x.to("cuda:0"), 8, 16).cpu()
+    with torch.cuda.device(0):
+        got = dmx.ops.bfp_qdq(x.to("cuda:1"), 8, 16)
+        sm = dmx.ops.softmax(x.float().to("cuda:1"))
+    assert got.device.index == 1 and torch.equal(got.cpu(), want)
+    assert torch.allclose(sm.cpu(), torch.softmax(x.float(), -1), rtol=1e-6, atol=1e-7)

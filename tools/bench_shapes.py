@@ -49,6 +49,29 @@ def main():
         del xs, ys
         torch.cuda.empty_cache()  # fresh allocations per shape: blocks carved out of a fragmented cache measured up to 50 % slower
 
+    # many small weights: one launch per tensor vs the multi-tensor entry point (opt-125m's 73 Linear weights, BFP16_64)
+    from dmx_compressor_amd import ops
+    shapes = []
+    for _ in range(12):
+        shapes += [(768, 768)] * 4 + [(3072, 768), (768, 3072)]
+    shapes += [(50272, 768)]
+    sets = [[(torch.randn(s, device=dev) * 0.05).to(torch.bfloat16) for s in shapes] for _ in range(3)]  # 3 x 248 MB
+    n = sum(a * b for a, b in shapes)
+    for name, fn in (("one dmxq_bfp_qdq launch per tensor", lambda ws: [ops.bfp_qdq(w, 8, 64) for w in ws]),
+                     ("dmxq_bfp_qdq_multi (2 launches)", lambda ws: ops.bfp_qdq_multi(ws, 8, 64))):
+        for i in range(6):
+            fn(sets[i % 3])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(30):
+            fn(sets[i % 3])
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 30
+        print(f"opt-125m 73 Linear weights ({n / 1e6:.1f} M elements) BFP16_64, {name}: {us:9.1f} us  "
+              f"{n * 4 / (us * 1e-6) / 1e9:8.1f} GB/s  {100 * n * 4 / (us * 1e-6) / 8e12:5.1f}%", flush=True)
+
 
 if __name__ == "__main__":
     main()
