@@ -34,7 +34,20 @@ def _load():
     return torch.ops.dmxq
 
 
-_ops = _load()
+class _Overloads:
+    """`torch.ops.dmxq.<name>.default` resolved once: calling an OpOverload skips the packet's per-call overload
+    resolution (~1.5 us of the host cost of a call)."""
+
+    def __init__(self, ns):
+        self._ns = ns
+
+    def __getattr__(self, name):
+        op = getattr(self._ns, name).default
+        setattr(self, name, op)
+        return op
+
+
+_ops = _Overloads(_load())
 
 
 # ---------------------------------------------------------------------------------------------------- autograd (STE)
@@ -244,6 +257,8 @@ def histc(x, bins: int, lo: float = 0.0, hi: float = 0.0):
             lo, hi = lo - 1.0, hi + 1.0
     if x.numel() == 0 and not lo < hi:
         return torch.zeros(int(bins), dtype=torch.float32, device=x.device)
+    if not (lo < hi and math.isfinite(lo) and math.isfinite(hi)):
+        raise DmxqError(f"histc: needs a finite range with min < max, got [{lo}, {hi}]")
     return _ops.histc(x, int(bins), lo, hi)
 
 

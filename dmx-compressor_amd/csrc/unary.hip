@@ -28,7 +28,12 @@ __device__ __forceinline__ float round_dt(float v) {  // RNE to DT and back (exa
 // output format); fp32 outputs keep expf and the IEEE division.
 template <bool FAST>
 __device__ __forceinline__ float sigmoid_mul(float x, float t) {  // x * sigmoid(t)
-  if (FAST) return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f));
+  if (FAST) {
+    const float d = 1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f);
+    // v_rcp_f32 flushes a denormal RESULT to zero (1 / d for d > 2^126): the far negative tail, where the true value
+    // x / d is still a normal number (silu(-88) = -5.3e-37), takes the IEEE division instead (rare: t < -87)
+    return d > 8.5e37f ? x / d : x * __builtin_amdgcn_rcpf(d);
+  }
   return x / (1.0f + expf(-t));
 }
 
@@ -43,8 +48,14 @@ struct UnaryOp {
       y = FAST ? __builtin_amdgcn_exp2f(x * 1.4426950408889634f) : expf(x);
     } else if (KIND == DMXQ_UNARY_QUICK_GELU) {
       const float t = round_dt<DTI>(1.702f * x);
-      const float s = round_dt<DTI>((FAST && DTI != DMXQ_F32) ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f))
-                                                               : 1.0f / (1.0f + expf(-t)));
+      float s;
+      if (FAST && DTI != DMXQ_F32) {
+        const float d = 1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f);
+        s = d > 8.5e37f ? 1.0f / d : __builtin_amdgcn_rcpf(d);  // (v_rcp_f32 flushes denormal results: see sigmoid_mul)
+      } else {
+        s = 1.0f / (1.0f + expf(-t));
+      }
+      s = round_dt<DTI>(s);
       y = x * s;
     } else {  // DMXQ_UNARY_SILU_EXPERIMENTAL: relu(half(x)) * scale, the product rounded to half by the store
       const float h = round_dt<DMXQ_F16>(x);

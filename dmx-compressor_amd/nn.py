@@ -73,8 +73,11 @@ class DmxModuleSmoothQuantHyperparams:
 
 
 def _shares_storage(a, b) -> bool:
-    return (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.device == b.device
-            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.numel() > 0)
+    if not (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor)):
+        return False
+    if torch.compiler.is_compiling():  # storages have no addresses while tracing with fake tensors: identity only
+        return a is b
+    return a.device == b.device and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.numel() > 0
 
 
 def _aliases_any(out, inputs, module) -> bool:

@@ -73,3 +73,32 @@ def bits_equal(a: torch.Tensor, b: torch.Tensor) -> int:
     a, b = a.detach().cpu().contiguous(), b.detach().cpu().contiguous()
     it = {4: torch.int32, 2: torch.int16, 8: torch.int64}[a.element_size()]
     return int((a.view(it) != b.view(it)).sum())
+
+
+_EPS = {torch.float32: 2.0 ** -23, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}
+_TINY = {torch.float32: 2.0 ** -126, torch.bfloat16: 2.0 ** -126, torch.float16: 2.0 ** -14}
+
+
+def err_in_ulps(got: torch.Tensor, truth64: torch.Tensor, dtype, floor=None) -> float:
+    """Largest |got - truth| in units of the last place OF THE OUTPUT FORMAT `dtype`, against `truth64` (the function
+    evaluated in float64 on the same inputs; it is rounded to `dtype` here, once: the correctly rounded result).
+    ulp(v) = 2^floor(log2 |v|) * eps(dtype), never smaller than the format's smallest normal ulp.  `floor`: magnitude of
+    the terms that CANCEL in the formula (|x|/2 in gelu's 0.5 x + 0.5 x erf(.), (|x| + |mean|) rstd |w| + |b| in
+    layer_norm's centring): where the result is much smaller than those terms, no fp32 evaluation of the formula --
+    torch's own included -- is accurate relative to the RESULT, and the error is counted in ulps of the cancelling terms
+    (what a backward-stable evaluation guarantees).  NaN must meet NaN, +-inf must meet the same inf."""
+    g, t = got.detach().cpu().double(), truth64.detach().cpu().double().to(dtype).double()
+    nan_g, nan_t = torch.isnan(g), torch.isnan(t)
+    if bool((nan_g ^ nan_t).any()):
+        return float("inf")
+    inf_t = torch.isinf(t)
+    if bool((inf_t & (g != t)).any()):
+        return float("inf")
+    ok = ~(nan_t | inf_t)
+    mag = t.abs()
+    if floor is not None:
+        mag = torch.maximum(mag, floor.detach().cpu().double().abs())
+    mag = mag.clamp_min(_TINY[dtype])
+    ulp = torch.exp2(torch.floor(torch.log2(mag))) * _EPS[dtype]
+    e = ((g - t).abs() / ulp)[ok]
+    return float(e.max()) if e.numel() else 0.0

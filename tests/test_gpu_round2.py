@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from _data import bits_equal, make, mismatches_nan_aware
+from _data import bits_equal, err_in_ulps, make, mismatches_nan_aware
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -143,23 +143,35 @@ def test_host_overhead_of_one_cast_call(dmx, cuda):
     x = make("normal", (64, 256), seed=10, dtype=torch.bfloat16).to(cuda)
     c = dmx.CastTo(format="BFP[8|8]{16}(SN)").to(cuda)
     res = {}
-    for name, fn in (("torch.ops.dmxq.bfp_qdq", lambda: torch.ops.dmxq.bfp_qdq(x, 8, 16, -1, True, 2, None, 0)),
-                     ("ops.bfp_qdq", lambda: dmx.ops.bfp_qdq(x, 8, 16)), ("CastTo.forward", lambda: c(x))):
+    from dmx_compressor_amd import _ops_ctypes
+    raw = torch.ops.dmxq.bfp_qdq.default
+    y = torch.empty_like(x)
+    L, lib = dmx._lib.lib(), dmx._lib
+    import ctypes
+    cargs = (ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), lib.BF16, lib.BF16, 64, 256, 1, 16, 8, lib.ROUND_NEAREST, 1, 0, lib.stream_of(x))
+    for name, fn in (("C ABI dmxq_bfp_qdq alone (prebuilt ctypes arguments, no allocation)", lambda: L.dmxq_bfp_qdq(*cargs)),
+                     ("torch.ops.dmxq.bfp_qdq", lambda: raw(x, 8, 16, -1, True, 2, None, 0)),
+                     ("ops.bfp_qdq (torch binding)", lambda: dmx.ops.bfp_qdq(x, 8, 16)),
+                     ("ops.bfp_qdq (ctypes binding)", lambda: _ops_ctypes.bfp_qdq(x, 8, 16)), ("CastTo.forward", lambda: c(x))):
         with torch.no_grad():
             for _ in range(200):
                 fn()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(2000):
-                fn()
-            dt = (time.perf_counter() - t0) / 2000 * 1e6   # host time to ENQUEUE (the stream never fills: 2 us kernels)
-            torch.cuda.synchronize()
+            ts = []
+            for rep in range(10):           # bursts of 100 calls on an idle stream: the queue never fills, so each call's
+                for _ in range(100):        # duration is host time (Python + dispatcher + allocator + hipLaunchKernel)
+                    t0 = time.perf_counter_ns()
+                    fn()
+                    ts.append(time.perf_counter_ns() - t0)
+                torch.cuda.synchronize()
+            ts.sort()
+            dt = ts[len(ts) // 2] / 1e3   # median, microseconds
         res[name] = dt
     print("host microseconds per call:", {k: round(v, 2) for k, v in res.items()})
     out = os.path.join(os.path.dirname(GOLD), "..", "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "host_overhead.txt"), "w") as f:
-            f.write("\n".join(f"{k}: {v:.2f} us per call (host enqueue time, 2000 calls)" for k, v in res.items()) + "\n")
+            f.write("\n".join(f"{k}: {v:.2f} us per call (median host time of 1000 calls in bursts of 100 on an idle stream)" for k, v in res.items()) + "\n")
     assert res["torch.ops.dmxq.bfp_qdq"] < 10.0 and res["CastTo.forward"] < 16.0
 
 
@@ -227,47 +239,45 @@ def test_experimental_silu_matches_the_reference_bit_for_bit(dmx, cuda):
             assert repr(m.approximator.function) == f"SILU[experimental]{{}}(scale={scale})"
 
 
-def _max_ulp(got, want):
-    d = ulp_distance(got, want)
-    finite = torch.isfinite(want.float().cpu())
-    return int(d[finite].max()) if bool(finite.any()) else 0
-
-
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_silu_exp_quick_gelu_exact_functions(dmx, cuda, dtype):
-    """Exact-function contract vs torch on the CPU (what the reference evaluates with vsimd absent).  Tolerance: 16-bit
-    outputs within 1 ulp of the output format (the correctly rounded value or its neighbour: torch rounds an fp32 result
-    that itself carries ~1 ulp of fp32 error); fp32 within 2 ulp (ocml's expf vs Sleef's, one division)."""
-    x = torch.cat([make("normal", (1 << 16,), seed=21) * 4.0, torch.tensor([0.0, -0.0, 20.0, -20.0, 88.0, -88.0, -104.0])]).to(dtype)
-    tol = 2 if dtype == torch.float32 else 1
-    xe = x.float().clamp(-80, 80).to(dtype)
-    for got, want in ((dmx.ops.silu(x.to(cuda)), F.silu(x)), (dmx.ops.exp(xe.to(cuda)), torch.exp(xe)),
-                      (dmx.ops.quick_gelu(x.to(cuda)), x * torch.sigmoid(1.702 * x))):
-        assert got.dtype == dtype and _max_ulp(got, want) <= tol
-    for name, Mod in (("SILU", dmx.nn.SiLU), ("QUICK_GELU", dmx.nn.QuickGELU)):
+    """Exact-function contract.  Ground truth = the function in float64 on the same inputs, rounded ONCE to the output
+    format (tests/_data.py err_in_ulps).  Tolerance: 16-bit outputs within 1 ulp of the output format; fp32 within 3 ulp
+    (ocml expf <= 1 ulp, one addition, one division, and for quick_gelu a product more) -- torch's own fp32 CPU
+    result, what the reference evaluates, measures 2 / 1 / 3 on the same inputs (profiles/r02_accuracy_table.txt)."""
+    x = torch.cat([make("normal", (1 << 16,), seed=21) * 4.0, torch.tensor([0.0, -0.0, 20.0, -20.0, 87.0, -87.0, -80.0])]).to(dtype)   # (beyond -87 exp(-x) overflows fp32: torch and the kernel both return -0)
+    tol = 3.0 if dtype == torch.float32 else 1.0
+    xd, xe = x.double(), x.float().clamp(-80, 80).to(dtype)
+    # QuickGELU runs in the input dtype (three roundings; torch multiplies by float32(1.702)): truth = that chain with an exact sigmoid
+    t1 = (float(torch.tensor(1.702, dtype=torch.float32)) * xd).to(dtype)
+    qg_truth = xd * torch.sigmoid(t1.double()).to(dtype).double()
+    for name, got, truth in (("silu", dmx.ops.silu(x.to(cuda)), F.silu(xd)), ("exp", dmx.ops.exp(xe.to(cuda)), torch.exp(xe.double())),
+                             ("quick_gelu", dmx.ops.quick_gelu(x.to(cuda)), qg_truth)):
+        assert got.dtype == dtype and err_in_ulps(got, truth, dtype) <= tol, name
+    for name, Mod, truth in (("SILU", dmx.nn.SiLU, F.silu(xd)), ("QUICK_GELU", dmx.nn.QuickGELU, qg_truth)):
         m = Mod()
         m.configure(dict(approximation_function=f"{name}[dmxq]{{}}()"))
         with torch.no_grad():
             y = m(x.to(cuda))
-        ref = F.silu(x) if name == "SILU" else x * torch.sigmoid(1.702 * x)
-        assert _max_ulp(y, ref) <= tol
+        assert err_in_ulps(y, truth, dtype) <= tol, name
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cols", [4096, 768, 1000, 8192 + 8, 6])
 def test_rmsnorm_exact_function(dmx, cuda, dtype, cols):
-    """F.rms_norm (torch_modules.py:1144-1170): x * rsqrt(mean(x^2) + eps) * w in fp32, one rounding.  Tolerance: 1 ulp
-    of a 16-bit output format; fp32 4 ulp (the row sum of squares is accumulated in a different order than torch's
-    vectorised CPU reduction, ~sqrt(cols) * 2^-24 relative on the scale)."""
+    """F.rms_norm (torch_modules.py:1144-1170): x * rsqrt(mean(x^2) + eps) * w in fp32, one rounding.  Ground truth: float64,
+    rounded once.  Tolerance: 1 ulp of a 16-bit output format; fp32 4 ulp (a row sum of squares in fp32, rsqrt, two
+    products: measured 3-4, torch's fp32 CPU result measures 3, profiles/r02_accuracy_table.txt)."""
     x = (make("normal", (33, cols), seed=cols) * 2.0).to(dtype)
     w = (1.0 + 0.1 * make("normal", (cols,), seed=cols + 1)).to(dtype)
+    tol = 4.0 if dtype == torch.float32 else 1.0
     for weight in (w, None):
-        want = F.rms_norm(x, (cols,), weight, 1e-6)
+        truth = F.rms_norm(x.double(), (cols,), weight.double() if weight is not None else None, 1e-6)
         got = dmx.ops.rmsnorm(x.to(cuda), cols, weight.to(cuda) if weight is not None else None, 1e-6)
-        assert got.dtype == dtype and _max_ulp(got, want) <= (4 if dtype == torch.float32 else 1)
+        assert got.dtype == dtype and err_in_ulps(got, truth, dtype) <= tol
     m = dmx.nn.RMSNorm(cols, eps=1e-6).to(cuda).to(dtype)
     m.weight.data = w.to(cuda)
     m.configure(dict(approximation_function="RMS_NORM[dmxq]{}()"))
     with torch.no_grad():
         y = m(x.to(cuda))
-    assert _max_ulp(y, F.rms_norm(x, (cols,), w, 1e-6)) <= (4 if dtype == torch.float32 else 1)
+    assert err_in_ulps(y, F.rms_norm(x.double(), (cols,), w.double(), 1e-6), dtype) <= tol

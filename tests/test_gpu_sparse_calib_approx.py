@@ -157,45 +157,59 @@ def test_channel_maxabs_and_smoothquant_scale(dmx, cuda, oracle):
     for alpha in (0.0, 0.5, 0.25, 1.0):
         got = dmx.ops.smoothquant_scale(am, wm, alpha, 1e-5).cpu()
         b = wm.cpu().clamp(min=1e-5)
-        ref = ((am.cpu() ** alpha) / (b ** (1.0 - alpha))).clamp(min=1e-5)   # smoothquant.py:309-320 (CPU torch)
-        # floating point (two powf + a divide on different libms): within 4 ulp of fp32
-        assert torch.allclose(got, ref, rtol=4.8e-7, atol=0.0), (alpha, (got - ref).abs().max())
+        # smoothquant.py:309-320; ground truth in float64, rounded once.  Two powf and a division: within 4 ulp of fp32
+        # (measured 3-4; torch's own fp32 CPU evaluation measures 2-3 on the same inputs, profiles/r02_accuracy_table.txt)
+        from _data import err_in_ulps
+        truth = ((am.cpu().double() ** alpha) / (b.double() ** (1.0 - alpha))).clamp(min=1e-5)
+        assert err_in_ulps(got, truth, torch.float32) <= 4.0, alpha
     z = dmx.ops.smoothquant_scale(torch.zeros(4, device=cuda), torch.zeros(4, device=cuda), 0.5, 1e-5)
     assert torch.all(z == 1e-5)                                              # clamp at scale_min
 
 
+# Tolerances of the exact-function ops, in ulps of the OUTPUT format against the float64 truth rounded once
+# (tests/_data.py err_in_ulps; measured maxima for the kernels AND for torch's own CPU result, which is what the reference
+# evaluates, are in profiles/r02_accuracy_table.txt):
+#   16-bit outputs: 1 ulp everywhere ("within 1 ULP of the stated format");
+#   fp32 outputs: gelu 2 (erf / tanh + 3 products), softmax 8 (expf <= 1, a row sum of up to 16k fp32 terms, one division;
+#   the argument x - max is compensated -- torch's CPU softmax measures 7-24 on the same inputs), layer_norm 3 (two row
+#   reductions, rsqrt, fma).  gelu and layer_norm are counted against the magnitude of their CANCELLING terms.
+TOL = {"gelu": {torch.float32: 2.0}, "softmax": {torch.float32: 8.0}, "layernorm": {torch.float32: 3.0}}
+
+
+def _tol(op, dtype):
+    return TOL[op].get(dtype, 1.0)
+
+
+def _ln_truth(x, cols, w, b, eps=1e-5):
+    F = torch.nn.functional
+    xd = x.double()
+    truth = F.layer_norm(xd, (cols,), None if w is None else w.double(), None if b is None else b.double(), eps)
+    # cancelling terms of y = (x - mean) rstd w + b: the row mean is a sum of terms of the row's magnitude, so its rounding
+    # error -- and with it the error of every (x - mean) -- is relative to max|x| of the ROW, not to the element
+    mu, rstd = xd.mean(-1, keepdim=True), (xd.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
+    floor = (xd.abs().amax(-1, keepdim=True) + mu.abs()) * rstd * (1.0 if w is None else w.double().abs()) + (0.0 if b is None else b.double().abs())
+    return truth, floor
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gelu_softmax_layernorm_exact_function_parity(dmx, cuda, dtype):
-    """Approximator slot = exact torch.nn.functional result (vsimd absent).  Tolerance: 1 ULP of the output
-    format around the fp32-computed CPU reference (north_star: 'within 1 ULP of the stated format')."""
+    """Approximator slot = the exact torch.nn.functional function (vsimd absent).  Ground truth: float64, rounded once."""
     F = torch.nn.functional
-    eps = torch.finfo(dtype).eps
-
-    def close(got, ref32):
-        ref = ref32.to(dtype).float()
-        tol = eps * ref.abs().clamp(min=float(torch.finfo(dtype).tiny)) + 1e-30
-        # + 2e-6 absolute (torch CPU's vectorised erf is itself ~1e-6 off the fp64 value; ours is ~4.5e-7): 0.5*x*(1+erf(..)) cancels for x << 0, where fp32 libm differences dominate
-        bad = ((got.cpu().float() - ref).abs() > tol + 2e-6)
-        return int(bad.sum())
-
+    from _data import err_in_ulps
     x = (make("normal", (64, 1500), seed=11) * 3).to(dtype)
-    assert close(dmx.ops.gelu(x.to(cuda)), F.gelu(x.float())) == 0
-    assert close(dmx.ops.gelu(x.to(cuda), "tanh"), F.gelu(x.float(), approximate="tanh")) == 0
-    assert close(dmx.ops.softmax(x.to(cuda), -1), F.softmax(x.float(), -1)) == 0
-    xc = x.float().clamp(min=-1.0)
-    assert close(dmx.ops.softmax(x.to(cuda), -1, input_clamp=-1.0), F.softmax(xc, -1)) == 0
+    xd = x.double()
+    assert err_in_ulps(dmx.ops.gelu(x.to(cuda)), F.gelu(xd), dtype, floor=xd.abs() / 2) <= _tol("gelu", dtype)
+    assert err_in_ulps(dmx.ops.gelu(x.to(cuda), "tanh"), F.gelu(xd, approximate="tanh"), dtype, floor=xd.abs() / 2) <= _tol("gelu", dtype)
+    assert err_in_ulps(dmx.ops.softmax(x.to(cuda), -1), F.softmax(xd, -1), dtype) <= _tol("softmax", dtype)
+    assert err_in_ulps(dmx.ops.softmax(x.to(cuda), -1, input_clamp=-1.0), F.softmax(xd.clamp(min=-1.0), -1), dtype) <= _tol("softmax", dtype)
     x3 = x.reshape(8, 8, 1500)
-    assert close(dmx.ops.softmax(x3.to(cuda), 1), F.softmax(x3.float(), 1)) == 0
+    assert err_in_ulps(dmx.ops.softmax(x3.to(cuda), 1), F.softmax(x3.double(), 1), dtype) <= _tol("softmax", dtype)
     w = (make("normal", (1500,), seed=12) * 0.1 + 1).to(dtype)
     b = (make("normal", (1500,), seed=13) * 0.1).to(dtype)
-    got = dmx.ops.layernorm(x.to(cuda), (1500,), w.to(cuda), b.to(cuda), 1e-5)
-    ref = F.layer_norm(x.float(), (1500,), w.float(), b.float(), 1e-5)
-    # layernorm: two fp32 reductions in a different order than torch's -> allow 2 ulp of the output format
-    ref_d = ref.to(dtype).float()
-    tol = 2 * eps * ref_d.abs() + 4e-6
-    assert int(((got.cpu().float() - ref_d).abs() > tol).sum()) == 0
+    truth, floor = _ln_truth(x, 1500, w, b)
+    assert err_in_ulps(dmx.ops.layernorm(x.to(cuda), (1500,), w.to(cuda), b.to(cuda), 1e-5), truth, dtype, floor=floor) <= _tol("layernorm", dtype)
     big = (make("normal", (3, 20000), seed=14)).to(dtype)                     # longer than the LDS row buffer
-    assert close(dmx.ops.softmax(big.to(cuda), -1), F.softmax(big.float(), -1)) == 0
+    assert err_in_ulps(dmx.ops.softmax(big.to(cuda), -1), F.softmax(big.double(), -1), dtype) <= _tol("softmax", dtype)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
@@ -241,34 +255,26 @@ def test_softmax_layernorm_every_row_kernel_shape(dmx, cuda, dtype):
     """Row lengths that select every register-resident kernel shape (approx.hip: 64 / 32 lanes per row, 1..16 vectors
     per lane, 8-byte vectors for 16-bit rows that are only a multiple of 4, workgroup-per-row for long rows) and the
     LDS / global fallbacks (odd lengths, mixed dtypes), with ragged row counts so that the clamped out-of-range rows
-    and lanes are exercised.  Same tolerances as above."""
+    and lanes are exercised.  Same tolerances as above (float64 truth)."""
     F = torch.nn.functional
-    eps = torch.finfo(dtype).eps
-
-    def bad(got, ref32, ulps, absolute):
-        ref = ref32.to(dtype).float()
-        got = got.cpu().float()
-        both_nan = torch.isnan(got) & torch.isnan(ref)
-        return int((((got - ref).abs() > ulps * eps * ref.abs() + absolute) & ~both_nan).sum()
-                   + (torch.isnan(got) ^ torch.isnan(ref)).sum())
-
+    from _data import err_in_ulps
     for n, cols in enumerate((4, 8, 64, 252, 256, 264, 768, 1024, 1280, 1500, 1536, 2048, 2304, 2560, 3072, 4096, 5120,
                               6144, 7168, 8192, 12288, 16384, 777, 1501)):
         rows = (1, 7, 33, 130)[n % 4]
         x = (make("normal", (rows, cols), seed=100 + n) * 2).to(dtype)
         if rows > 2:
             x[1, : cols // 2] = float("-inf")      # a masked row: exp(-inf) = 0
-        assert bad(dmx.ops.softmax(x.to(cuda), -1), F.softmax(x.float(), -1), 1, 2e-6) == 0, ("softmax", cols, rows)
+        assert err_in_ulps(dmx.ops.softmax(x.to(cuda), -1), F.softmax(x.double(), -1), dtype) <= _tol("softmax", dtype), ("softmax", cols, rows)
         if rows > 2:
             y = x.clone(); y[2] = float("-inf")    # a fully masked row is NaN in torch too
-            assert bad(dmx.ops.softmax(y.to(cuda), -1), F.softmax(y.float(), -1), 1, 2e-6) == 0, ("softmax -inf row", cols)
+            assert err_in_ulps(dmx.ops.softmax(y.to(cuda), -1), F.softmax(y.double(), -1), dtype) <= _tol("softmax", dtype), ("softmax -inf row", cols)
         x = (make("normal", (rows, cols), seed=200 + n) * 2 + 0.5).to(dtype)
         w = (make("normal", (cols,), seed=12) * 0.1 + 1).to(dtype)
         b = (make("normal", (cols,), seed=13) * 0.1).to(dtype)
         for ww, bb in ((w, b), (w, None), (None, None)):
             got = dmx.ops.layernorm(x.to(cuda), (cols,), None if ww is None else ww.to(cuda), None if bb is None else bb.to(cuda), 1e-5)
-            ref = F.layer_norm(x.float(), (cols,), None if ww is None else ww.float(), None if bb is None else bb.float(), 1e-5)
-            assert bad(got, ref, 2, 4e-6) == 0, ("layernorm", cols, rows, ww is not None, bb is not None)
+            truth, floor = _ln_truth(x, cols, ww, bb)
+            assert err_in_ulps(got, truth, dtype, floor=floor) <= _tol("layernorm", dtype), ("layernorm", cols, rows, ww is not None, bb is not None)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""tools/accuracy_table.py — measured accuracy of the floating-point ops of the approximator slot and the SmoothQuant
+scale, per output dtype: maximum distance in ulps OF THE OUTPUT FORMAT from the ground truth
+(the function evaluated in float64 on the same inputs and rounded ONCE to the output format), for
+  * the HIP kernels of this repo, and
+  * torch's own CPU result in the tensor's dtype -- what the reference computes (functional/approximate.py:300-304) --
+so that "within 1 ulp of the stated format" is checked against the truth rather than against another rounded
+implementation.  Writes a table to stdout (committed as profiles/r02_accuracy_table.txt)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import dmx_compressor_amd as d  # noqa: E402
+from _data import err_in_ulps, make  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def row(name, dt, got, torch_cpu, truth64, floor=None):
+    """errors in ulps of the output format against the float64 truth rounded once (tests/_data.py err_in_ulps; `floor` = the
+    magnitude of the cancelling terms for gelu / layer_norm, see there)"""
+    a, b = err_in_ulps(got, truth64, dt, floor), err_in_ulps(torch_cpu, truth64, dt, floor)
+    print(f"{name:46s} {str(dt).replace('torch.', ''):9s} {a:10.2f} {b:14.2f}{'   (vs cancelling terms)' if floor is not None else ''}", flush=True)
+
+
+def main():
+    print(f"{'op (inputs)':46s} {'dtype':9s} {'HIP max ulp':>10s} {'torch CPU max ulp':>14s}   (vs float64 truth rounded once)")
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        x = (make("normal", (1 << 20,), seed=1) * 4.0).to(dt)
+        xd = x.double()
+        row("gelu erf, N(0,16)", dt, d.ops.gelu(x.to(dev)), F.gelu(x), F.gelu(xd), floor=xd.abs() / 2)
+        row("gelu tanh, N(0,16)", dt, d.ops.gelu(x.to(dev), "tanh"), F.gelu(x, approximate="tanh"), F.gelu(xd, approximate="tanh"), floor=xd.abs() / 2)
+        row("silu, N(0,16)", dt, d.ops.silu(x.to(dev)), F.silu(x), F.silu(xd))
+        row("exp, N(0,16) clamped to +-10", dt, d.ops.exp(x.clamp(-10, 10).to(dev)), torch.exp(x.clamp(-10, 10)), torch.exp(x.clamp(-10, 10).double()))
+        # quick_gelu is DEFINED in the input dtype (three roundings): truth = torch's own chain, evaluated with float64 sigmoid
+        t1 = (float(torch.tensor(1.702, dtype=torch.float32)) * xd).to(dt)   # torch multiplies by float32(1.702)
+        qg_truth = xd * torch.sigmoid(t1.double()).to(dt).double()
+        row("quick_gelu (dtype chain), N(0,16)", dt, d.ops.quick_gelu(x.to(dev)), x * torch.sigmoid(1.702 * x), qg_truth)
+        for cols, scale in ((1500, 3.0), (1500, 1.0), (768, 1.0), (4096, 1.0)):
+            r = (make("normal", (512, cols), seed=cols) * scale).to(dt)
+            row(f"softmax rows of {cols}, N(0,{scale * scale:g})", dt, d.ops.softmax(r.to(dev)), torch.softmax(r, -1), torch.softmax(r.double(), -1))
+        for cols in (768, 4096):
+            r = (make("normal", (512, cols), seed=cols + 7) * 2.0 + 0.3).to(dt)
+            w = (1.0 + 0.1 * make("normal", (cols,), seed=3)).to(dt)
+            b = (0.1 * make("normal", (cols,), seed=4)).to(dt)
+            rd = r.double()
+            mu, rstd = rd.mean(-1, keepdim=True), (rd.var(-1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+            row(f"layer_norm rows of {cols}, affine", dt, d.ops.layernorm(r.to(dev), cols, w.to(dev), b.to(dev), 1e-5), F.layer_norm(r, (cols,), w, b, 1e-5),
+                F.layer_norm(rd, (cols,), w.double(), b.double(), 1e-5), floor=(rd.abs().amax(-1, keepdim=True) + mu.abs()) * rstd * w.double().abs() + b.double().abs())
+            row(f"rms_norm rows of {cols}, weight", dt, d.ops.rmsnorm(r.to(dev), cols, w.to(dev), 1e-6), F.rms_norm(r, (cols,), w, 1e-6),
+                F.rms_norm(r.double(), (cols,), w.double(), 1e-6))
+    # SmoothQuant scale = clamp(a^alpha / clamp(b, min)^(1 - alpha), min): fp32 vectors (smoothquant.py:301-321)
+    a = make("normal", (1 << 16,), seed=5).abs() * 10 + 1e-3
+    b = make("normal", (1 << 16,), seed=6).abs() + 1e-3
+    for alpha in (0.5, 0.25, 0.8):
+        truth = (a.double().pow(alpha) / b.double().clamp(min=1e-5).pow(1 - alpha)).clamp(min=1e-5)
+        cpu = (a.pow(alpha) / b.clamp(min=1e-5).pow(1 - alpha)).clamp(min=1e-5)
+        row(f"smoothquant scale, alpha = {alpha}", torch.float32, d.ops.smoothquant_scale(a.to(dev), b.to(dev), alpha), cpu, truth)
+
+
+if __name__ == "__main__":
+    main()

@@ -49,29 +49,46 @@ def main():
         del xs, ys
         torch.cuda.empty_cache()  # fresh allocations per shape: blocks carved out of a fragmented cache measured up to 50 % slower
 
-    # many small weights: one launch per tensor vs the multi-tensor entry point (opt-125m's 73 Linear weights, BFP16_64)
-    from dmx_compressor_amd import ops
+    # many small weights: one launch per tensor vs the multi-tensor entry point (opt-125m's 73 Linear weights, BFP16_64).
+    # Straight C-ABI calls with prebuilt arguments / descriptors (the Python front end adds ~3 us per tensor for allocation
+    # and descriptor filling, which is a one-off at fold time and would hide the kernels here).
     shapes = []
     for _ in range(12):
         shapes += [(768, 768)] * 4 + [(3072, 768), (768, 3072)]
     shapes += [(50272, 768)]
     sets = [[(torch.randn(s, device=dev) * 0.05).to(torch.bfloat16) for s in shapes] for _ in range(3)]  # 3 x 248 MB
+    outs = [[torch.empty_like(w) for w in ws] for ws in sets]
     n = sum(a * b for a, b in shapes)
-    for name, fn in (("one dmxq_bfp_qdq launch per tensor", lambda ws: [ops.bfp_qdq(w, 8, 64) for w in ws]),
-                     ("dmxq_bfp_qdq_multi (2 launches)", lambda ws: ops.bfp_qdq_multi(ws, 8, 64))):
-        for i in range(6):
-            fn(sets[i % 3])
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(30):
-            fn(sets[i % 3])
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / 30
-        print(f"opt-125m 73 Linear weights ({n / 1e6:.1f} M elements) BFP16_64, {name}: {us:9.1f} us  "
-              f"{n * 4 / (us * 1e-6) / 1e9:8.1f} GB/s  {100 * n * 4 / (us * 1e-6) / 8e12:5.1f}%", flush=True)
+    single_args = [[(vp(w.data_ptr()), vp(o.data_ptr()), _lib.BF16, _lib.BF16, w.shape[0], w.shape[1], 1, 64, 8, 2, 1, 0, sp) for w, o in zip(ws, os_)]
+                   for ws, os_ in zip(sets, outs)]
+    descs = []
+    for ws, os_ in zip(sets, outs):
+        d = (_lib.TensorDesc * len(ws))()
+        for e, w, o in zip(d, ws, os_):
+            e.in_, e.out, e.outer, e.L, e.inner = w.data_ptr(), o.data_ptr(), w.shape[0], w.shape[1], 1
+        descs.append(d)
 
+    def one_by_one(i):
+        for a in single_args[i]:
+            L.dmxq_bfp_qdq(*a)
+
+    def multi(i):
+        assert L.dmxq_bfp_qdq_multi(descs[i], len(shapes), _lib.BF16, _lib.BF16, 64, 8, 2, 1, 0, sp) == 0
+
+    with torch.cuda.stream(stream):
+        for name, fn in (("one dmxq_bfp_qdq launch per tensor (73 launches)", one_by_one), ("dmxq_bfp_qdq_multi (2 launches)", multi)):
+            for i in range(6):
+                fn(i % 3)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for i in range(30):
+                fn(i % 3)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 30
+            print(f"opt-125m 73 Linear weights ({n / 1e6:.1f} M elements) BFP16_64, {name}: {us:9.1f} us  "
+                  f"{n * 4 / (us * 1e-6) / 1e9:8.1f} GB/s  {100 * n * 4 / (us * 1e-6) / 8e12:5.1f}%", flush=True)
 
 if __name__ == "__main__":
     main()
