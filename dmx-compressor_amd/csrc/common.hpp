@@ -304,6 +304,34 @@ __device__ __forceinline__ uint32_t absmax_bits(const u32x4& v) {
   return f2u((float)__builtin_bit_cast(_Float16, (uint16_t)h));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Division by a value shared by many elements (a per-tensor / per-group / per-channel scale) inside the affine
+// fixed-point cast  v = clamp(round(x / scale + zp))  (numerical/cast.py:293).  hipcc expands an fp32 `/` into ~11 VALU
+// operations (v_div_scale x2, v_rcp, four refinement FMAs, v_div_fmas, v_div_fixup) and the affine INT8 kernels were
+// bound by them (profiles/r02_pmc_second_tier.txt: 27 VALU per element, VALU issue time ~ kernel time).
+// With rs = RN(1 / d) formed ONCE per vector / channel by a true IEEE division, each quotient is
+//     q0 = RN(n * rs);   r = n - d * q0  (ONE fma, exact: q0 is a faithful rounding of n / d);   q = RN(q0 + r * rs)
+// which IS the IEEE quotient RN(n / d) (Markstein: correctly rounded reciprocal + exact residual => correctly rounded
+// quotient) whenever d is in [2^-20, 2^20] (checked once per vector by the caller: recip_ok) and 2^-100 <= |n| <= 2^100
+// (then q0 is normal and r, a multiple of 2^(e_n - 47), is exactly representable); tests/test_gpu_round2.py checks that
+// claim bit for bit on 10^7 operand pairs.  Outside that range of n the CLAMPED INTEGER result of the cast cannot depend
+// on the last bit of the quotient:
+//   |n| < 2^-100: |q| < 2^-80 either way, so q + zp rounds to zp (or to a zero with the sign of n when zp = 0);
+//   |n| > 2^100 : |q| > 2^80 either way and the result is the clamp limit;  n = +-0: r is formed as -(d q0 - n), which
+//   keeps q = q0 = +-0 with the sign of n;  n = +-Inf / NaN: q0 is already the IEEE result (the correction would turn
+//   Inf into NaN) and is selected by one v_cmp_class.
+// 5 VALU operations per element, no branch.  NOT a general division: callers that return the quotient itself
+// (SmoothQuant's x / s) keep the IEEE `/`.
+struct Recip { float d, rs; };
+__device__ __forceinline__ Recip make_recip(float d) { return Recip{d, 1.0f / d}; }
+__device__ __forceinline__ bool recip_ok(float d) { return d >= 9.5367431640625e-07f && d <= 1048576.0f; }  // [2^-20, 2^20]
+__device__ __forceinline__ float div_for_clamped_int(float n, const Recip& c) {
+  const float q0 = n * c.rs;
+  const float r = -__builtin_fmaf(c.d, q0, -n);
+  const float q = __builtin_fmaf(r, c.rs, q0);
+  return __builtin_amdgcn_classf(q0, 0x001 | 0x002 | 0x004 | 0x200) ? q0 : q;  // sNaN, qNaN, -inf, +inf
+}
+
 inline int grid_for(int64_t work_items_of_one_thread) {
   int64_t b = (work_items_of_one_thread + kThreads - 1) / kThreads;
   if (b < 1) b = 1;

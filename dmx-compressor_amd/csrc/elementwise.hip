@@ -137,8 +137,11 @@ struct FixedOp {
   ChannelMap cm;
   const float* scale;
   const int64_t* zp;
-  __device__ __forceinline__ float q(float x, float sc, float z, int64_t e) const {
-    if (MODE != kNone) x = x / sc + z;  // IEEE division, as torch CPU (cast.py:293)
+  // FAST: the caller has checked recip_ok(sc) for this vector and SIMPLE holds (clamped integer format): the quotient
+  // comes from div_for_clamped_int (common.hpp), whose final clamped integer equals the IEEE path's for every input
+  template <bool FAST = false>
+  __device__ __forceinline__ float q(float x, float sc, float z, int64_t e, float rs = 0.0f) const {
+    if (MODE != kNone) x = (FAST ? div_for_clamped_int(x, Recip{sc, rs}) : x / sc) + z;  // IEEE division, as torch CPU (cast.py:293)
     float v;
     if (SIMPLE) {
       v = rintf((x + 0.5f) - 0.5f);
@@ -161,7 +164,7 @@ struct FixedOp {
     y = q(x, sc, z, e);
   }
   // lastdim_kernel interface (per-channel along the contiguous dim): the N channels of a lane stay in registers
-  template <int N> struct ChanParams { float sc[N], z[N]; };
+  template <int N> struct ChanParams { float sc[N], z[N], rs[N]; bool fast; };
   template <int N>
   __device__ __forceinline__ ChanParams<N> load_params(int64_t c0) const {
     ChanParams<N> p;
@@ -175,12 +178,22 @@ struct FixedOp {
       const i64x2 t = *(const i64x2*)(zp + c0 + k);
       p.z[k] = (float)t.x; p.z[k + 1] = (float)t.y;
     }
+    // reciprocals of the lane's N channel scales, once per column strip (the lanes then walk down the rows)
+    bool ok = SIMPLE;
+#pragma unroll
+    for (int k = 0; k < N; k++) { p.rs[k] = 1.0f / p.sc[k]; ok = ok && recip_ok(p.sc[k]); }
+    p.fast = __builtin_amdgcn_ballot_w64(!ok) == 0ull;  // wave-uniform: one branch per row vector
     return p;
   }
   template <int N>
   __device__ __forceinline__ void apply_chan(const float (&x)[N], const ChanParams<N>& p, float (&y)[N], int64_t e0) const {
+    if (SIMPLE && p.fast) {
 #pragma unroll
-    for (int k = 0; k < N; k++) y[k] = q(x[k], p.sc[k], p.z[k], e0 + k);
+      for (int k = 0; k < N; k++) y[k] = q<true>(x[k], p.sc[k], p.z[k], e0 + k, p.rs[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; k++) y[k] = q(x[k], p.sc[k], p.z[k], e0 + k);
+    }
   }
   // the vector's (scale, zero point) when it has a single one: fetched ahead of the arithmetic (stream.hpp OpPrep)
   struct Prep { float sc, z; };
@@ -203,8 +216,15 @@ struct FixedOp {
   __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0, const Prep& pp) const {
     if (MODE == kNone || MODE == kTensor || MODE == kUniform) {
       const float sc = pp.sc, z = pp.z;
+      // one scale for the whole vector: its reciprocal once, then 5 VALU per quotient instead of ~11 (common.hpp)
+      if (SIMPLE && MODE != kNone && __builtin_amdgcn_ballot_w64(!recip_ok(sc)) == 0ull) {
+        const float rs = 1.0f / sc;
 #pragma unroll
-      for (int k = 0; k < N; k++) y[k] = q(x[k], sc, z, e0 + k);
+        for (int k = 0; k < N; k++) y[k] = q<true>(x[k], sc, z, e0 + k, rs);
+      } else {
+#pragma unroll
+        for (int k = 0; k < N; k++) y[k] = q(x[k], sc, z, e0 + k);
+      }
     } else if (MODE == kLast) {
       // c0 is a multiple of N and the tables are 16-byte aligned (pick_mode): N scales = N/4 and N zero points = N/2
       // 16-byte loads instead of 2N scalar ones
@@ -368,10 +388,15 @@ struct BernoulliOp {
 // re-reading the scale / zero-point tables (12 B per element, 3x the data itself) for every lane-vector.
 // Layout: lpr = min(cv, 256) lanes per row (cv = C / EPL vectors per row), rpp = 256 / lpr rows side by side in a
 // workgroup, column strips of 256 vectors (grid.y) when rows are longer; RPI row groups in flight per iteration.
-template <int DTI, int DTO, class OP>
+// RPI rows are in flight per lane and iteration: all their loads are issued first, every row is converted into registers,
+// then the stores go out as one burst (the schedule of bfp_rows.hpp).  The per-lane channel parameters (8 scales, 8 zero
+// points = 96 B, plus 8 reciprocals) cost more than a row's data (16 B in, 16 B out), so a workgroup must own MANY rows:
+// RPI = 8 and a grid of about four workgroups per CU (round 1 ran 4 rows per workgroup: the setup was most of the work,
+// 43 % of roofline for per-channel INT8).
+template <int DTI, int DTO, class OP, int RPI>
 __global__ __launch_bounds__(kThreads) void lastdim_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t rows,
                                                           int64_t C, int cv, int lpr, int rpp, OP op) {
-  constexpr int EPL = 16 / Elem<DTI>::bytes, OVB = EPL * Elem<DTO>::bytes, RPI = 4;
+  constexpr int EPL = 16 / Elem<DTI>::bytes, OVB = EPL * Elem<DTO>::bytes;
   const int t = threadIdx.x;
   const int sub = t / lpr, sl = t - sub * lpr;
   const int cb = blockIdx.y * lpr + sl;
@@ -387,15 +412,21 @@ __global__ __launch_bounds__(kThreads) void lastdim_kernel(const void* __restric
       const int64_t r = r0 + (int64_t)j * rpp + subc;
       raw[j] = load_raw16<true>(in, ((r < rows ? r : rows - 1) * cv + cbc) * 16);  // clamped: unconditional loads
     }
+    __builtin_amdgcn_sched_barrier(0);
+    OutVec<DTO, EPL> o[RPI];
 #pragma unroll
     for (int j = 0; j < RPI; j++) {
       const int64_t r = r0 + (int64_t)j * rpp + sub;
-      if (active && r < rows) {
-        float x[EPL], y[EPL];
-        widen<DTI, EPL>(raw[j], x);
-        op.apply_chan(x, p, y, r * C + (int64_t)cb * EPL);
-        store_out<DTO, EPL, true>((char*)out + (r * cv + cb) * OVB, pack_vec<DTO, EPL>(y));
-      }
+      float x[EPL], y[EPL];
+      widen<DTI, EPL>(raw[j], x);
+      op.apply_chan(x, p, y, r * C + (int64_t)cb * EPL);
+      o[j] = pack_vec<DTO, EPL>(y);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < RPI; j++) {
+      const int64_t r = r0 + (int64_t)j * rpp + sub;
+      if (active && r < rows) store_out<DTO, EPL, true>((char*)out + (r * cv + cb) * OVB, o[j]);
     }
   }
 }
@@ -407,15 +438,22 @@ static int launch_lastdim(const void* in, void* out, int dti, int dto, int64_t r
   if (C % epl != 0 || !aligned16(in) || !aligned16(out) || C / epl > 0x7FFFFFFF || rows < 1) return DMXQ_ERR_UNSUPPORTED;
   const int cv = (int)(C / epl), lpr = cv < kThreads ? cv : kThreads, rpp = kThreads / lpr;
   const int strips = (cv + lpr - 1) / lpr;
-  int64_t gx = (rows + (int64_t)rpp * 4 - 1) / ((int64_t)rpp * 4);
+  if (strips > 65535) return DMXQ_ERR_UNSUPPORTED;
+  // rows in flight per lane: 8 when there are enough rows to fill ~4 workgroups per CU with them, else 4
+  const bool big = rows >= (int64_t)rpp * 8 * ((1024 + strips - 1) / strips);
+  const int rpi = big ? 8 : 4;
+  int64_t gx = (rows + (int64_t)rpp * rpi - 1) / ((int64_t)rpp * rpi);
   const int64_t cap = (2048 + strips - 1) / strips;
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
-  if (strips > 65535) return DMXQ_ERR_UNSUPPORTED;
 #define DMXQ_LD(I_, O_)                                                                                               \
   if (dti == I_ && dto == O_) {                                                                                       \
-    DMXQ_LAUNCH((lastdim_kernel<I_, O_, OP>), dim3((unsigned)gx, (unsigned)strips), dim3(kThreads), 0, s, in, out, \
-                       rows, C, cv, lpr, rpp, op);                                                                    \
+    if (big)                                                                                                          \
+      DMXQ_LAUNCH((lastdim_kernel<I_, O_, OP, 8>), dim3((unsigned)gx, (unsigned)strips), dim3(kThreads), 0, s, in, out, \
+                  rows, C, cv, lpr, rpp, op);                                                                         \
+    else                                                                                                              \
+      DMXQ_LAUNCH((lastdim_kernel<I_, O_, OP, 4>), dim3((unsigned)gx, (unsigned)strips), dim3(kThreads), 0, s, in, out, \
+                  rows, C, cv, lpr, rpp, op);                                                                         \
     return launch_status();                                                                                           \
   }
   DMXQ_LD(DMXQ_BF16, DMXQ_BF16)
@@ -538,6 +576,21 @@ extern "C" int dmxq_bernoulli_mask(const void* score, void* mask_out, int dtype_
   if (n == 0) return DMXQ_OK;
   if (!score || !mask_out) return DMXQ_ERR_BAD_ARG;
   return dispatch_stream(score, mask_out, dtype_score, dtype_mask, n, BernoulliOp{seed}, (hipStream_t)stream);
+}
+
+// Test hook (not part of include/dmxq.h): out[r, c] = div_for_clamped_int(n[r, c], 1 / d[c]) -- lets the test suite
+// check the "equals the IEEE quotient inside the stated operand range" claim of common.hpp directly, bit for bit.
+namespace dmxq {
+__global__ void div_selftest_kernel(const float* n, const float* d, float* out, int64_t rows, int64_t cols) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows * cols) out[i] = div_for_clamped_int(n[i], make_recip(d[i % cols]));
+}
+}  // namespace dmxq
+extern "C" int dmxq_internal_div_selftest(const float* n, const float* d, float* out, int64_t rows, int64_t cols, void* stream) {
+  if (!n || !d || !out || rows < 0 || cols < 1) return DMXQ_ERR_BAD_ARG;
+  if (rows == 0) return DMXQ_OK;
+  DMXQ_LAUNCH(dmxq::div_selftest_kernel, dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, d, out, rows, cols);
+  return launch_status();
 }
 
 extern "C" const char* dmxq_status_string(int status) {

@@ -281,3 +281,72 @@ def test_rmsnorm_exact_function(dmx, cuda, dtype, cols):
     with torch.no_grad():
         y = m(x.to(cuda))
     assert err_in_ulps(y, F.rms_norm(x.double(), (cols,), w.double(), 1e-6), dtype) <= tol
+
+
+# ------------------------------------------------------------------------------------------------ division by a shared scale
+def _bits_f32(t):
+    return t.contiguous().view(torch.int32)
+
+
+def test_reciprocal_division_equals_ieee_division_in_its_stated_range(dmx, cuda):
+    """common.hpp div_for_clamped_int: q0 = n rs, r = n - d q0 (one exact fma), q = q0 + r rs with rs = RN(1/d) must be the
+    IEEE quotient RN(n / d) bit for bit for d in [2^-20, 2^20] and 2^-100 <= |n| <= 2^100 -- the claim the affine INT8
+    kernels rest on.  10^7 operand pairs: random bit patterns over the range, realistic scales, all-ones mantissas, powers of
+    two, and numerators placed on / one ulp beside products k.5 * d (quotients at the rounding boundaries of the cast).
+    Outside the range the documented properties are checked: sign of a zero, Inf and NaN pass through."""
+    import ctypes
+    L = ctypes.CDLL(dmx.LIB_PATH)
+    g = torch.Generator().manual_seed(99)
+    C, R = 4096, 2560
+    lo, hi = (127 - 20) << 23, (127 + 20) << 23
+    d = torch.randint(lo, hi, (C,), generator=g, dtype=torch.int64).to(torch.int32).view(torch.float32).clone()
+    d[:40] = torch.tensor([2.0 - 2.0 ** -23]) * 2.0 ** torch.arange(-20, 20).float()          # mantissa all ones
+    d[40:81] = 2.0 ** torch.arange(-20, 21).float()
+    d[128:2048] = torch.rand(1920, generator=g) * 0.2 + 1e-3                                  # realistic INT8 scales
+    nlo, nhi = (127 - 100) << 23, (127 + 100) << 23
+    mag = torch.randint(nlo, nhi, (R, C), generator=g, dtype=torch.int64)
+    sign = torch.randint(0, 2, (R, C), generator=g, dtype=torch.int64) << 31
+    n = (mag | sign).to(torch.int32).view(torch.float32).clone()
+    n[:512] = torch.randn(512, C, generator=g) * 3
+    k = torch.randint(-300, 300, (512, C), generator=g).float() + 0.5
+    prod = (k.double() * d.double()).float()
+    n[512:1024] = prod
+    n[1024:1536] = torch.nextafter(prod, torch.full_like(prod, float("inf")))
+    n[1536:2048] = torch.nextafter(prod, torch.full_like(prod, float("-inf")))
+    n = torch.where(n.abs() < 2.0 ** -100, torch.full_like(n, 1.5), n)                          # keep every operand inside the range
+    out = torch.empty(R, C, device=cuda)
+    nd, dd = n.to(cuda), d.to(cuda)
+    vp = ctypes.c_void_p
+    assert L.dmxq_internal_div_selftest(vp(nd.data_ptr()), vp(dd.data_ptr()), vp(out.data_ptr()), R, C, dmx._lib.stream_of(out)) == 0
+    got, want = out.cpu(), n / d
+    bad = _bits_f32(got) != _bits_f32(want)
+    if int(bad.sum()):
+        idx = bad.nonzero()[:6].tolist()
+        raise AssertionError(f"{int(bad.sum())} of {R * C} quotients differ from IEEE: " + str([(float(n[i, j]), float(d[j]), float(got[i, j]), float(want[i, j])) for i, j in idx]))
+    # outside the range: zeros keep their sign, Inf / NaN pass through like the IEEE division
+    sp = torch.tensor([[0.0, -0.0, float("inf"), float("-inf"), float("nan"), 0.0, -0.0, float("inf")]])
+    ds = torch.tensor([0.01, 0.01, 0.01, 0.01, 0.01, 3.0, 3.0, 3.0])
+    o2 = torch.empty(1, 8, device=cuda)
+    s2, d2 = sp.to(cuda), ds.to(cuda)
+    assert L.dmxq_internal_div_selftest(vp(s2.data_ptr()), vp(d2.data_ptr()), vp(o2.data_ptr()), 1, 8, dmx._lib.stream_of(o2)) == 0
+    assert mismatches_nan_aware(o2.cpu(), sp / ds) == 0
+
+
+def test_affine_int8_with_fast_division_matches_oracle_everywhere(dmx, cuda, oracle):
+    """the whole cast x/sc + zp -> INT8 -> (v - zp) sc through every scale layout (per tensor, per group of rows, per
+    channel along the last dim), on inputs that leave the fast division's exact range (tiny, huge, Inf, NaN, zeros) and with
+    scales outside [2^-20, 2^20] (those vectors take the IEEE division): bit-equal to the oracle's IEEE arithmetic."""
+    x = make("mixed", (256, 512), seed=31, dtype=torch.float32, block=16)
+    x[0, :8] = torch.tensor([0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1e-38, -3e38, 1e-45])
+    x[1] = make("normal", (512,), seed=32) * 1e-35
+    x[2] = make("normal", (512,), seed=33) * 1e30
+    for dt in (torch.float32, torch.bfloat16):
+        xx = x.to(dt)
+        for name, ch_axis, gs, G in (("tensor", None, None, 1), ("group16", 0, 16, 16), ("lastdim", -1, None, 512), ("rows", 0, None, 256)):
+            sc = torch.rand(G, generator=torch.Generator().manual_seed(G)) * 0.2 + 1e-3
+            if G >= 16:
+                sc[3], sc[5], sc[7] = 1e-9, 5e7, 2.0 ** -20
+            zp = torch.randint(-5, 6, (G,), generator=torch.Generator().manual_seed(G + 1))
+            got = dmx.ops.fixed_qdq(xx.to(cuda), 8, 0, True, True, scale=sc.to(cuda), zero_point=zp.to(cuda), ch_axis=ch_axis, group_size=gs)
+            want = oracle.fixed_point_affine_cast(xx, 8, 0, True, True, sc, zp, ch_axis=ch_axis, group_size=gs).to(dt)
+            assert mismatches_nan_aware(got, want) == 0 and bits_equal(torch.nan_to_num(got.float()), torch.nan_to_num(want.float())) == 0, (name, dt)

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--cols", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--only", default=None, help="comma-separated substrings: run only the ops whose name contains one of them")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     L = _lib.lib()
@@ -47,7 +48,11 @@ def main():
             out.append(t.to(dtype))
         return out
 
+    only = [t.strip() for t in args.only.split(",")] if args.only else None
+
     def run(name, launch, nbuf, bytes_per_launch, check=None):
+        if only is not None and not any(t in name for t in only):
+            return
         with torch.cuda.stream(stream):
             for i in range(20):
                 launch(i % nbuf)
@@ -144,6 +149,10 @@ def main():
         lambda i: L.dmxq_bfp_pack(vp(xs[i].data_ptr()), _lib.BF16, vp(mant[i].data_ptr()), vp(exps[i].data_ptr()), R, C, 16, 8, 1, sp), k, n * 3 + n // 16)
     run("bfp_unpack int8 codes + uint8 exponents -> bf16, B=16",
         lambda i: L.dmxq_bfp_unpack(vp(mant[i].data_ptr()), vp(exps[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, R, C, 16, 8, sp), k, n * 3 + n // 16)
+    run("unary silu bf16", lambda i: L.dmxq_unary(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, n, 2, ctypes.c_float(0.0), sp), k, n * 4)
+    run("unary quick_gelu bf16", lambda i: L.dmxq_unary(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, n, 3, ctypes.c_float(0.0), sp), k, n * 4)
+    wr = torch.ones(C, device=dev, dtype=torch.bfloat16)
+    run("rmsnorm bf16 rows of 4096 (Llama hidden)", lambda i: L.dmxq_rmsnorm(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, R, C, vp(wr.data_ptr()), _lib.BF16, ctypes.c_float(1e-5), sp), k, n * 4)
     # ---------------------------------------------------------------- reductions
     mn = torch.empty(R, device=dev)
     mx = torch.empty(R, device=dev)
