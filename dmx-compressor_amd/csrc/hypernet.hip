@@ -50,7 +50,10 @@ struct HnArgs {
 };
 
 // DTW weight dtype, DTS score dtype (ignored when M == 0), DTO output dtype, M = 0 (no mask) / 2 / 4 / 8
-template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE>
+// BFP = false: mask-and-multiply only (y = x * mask, sparse.py:300) -- the typed fast path of dmxq_nm_mask for whole rows
+// of 16-byte vectors (compile-time dtypes: every load of a lane is in flight before the first conversion; the generic
+// kernel of nm_mask.hip switches on runtime dtypes around each access and reached 48 % of roofline with a bf16 score).
+template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP = true>
 __global__ __launch_bounds__(kThreads) void hypernet_rows_kernel(HnArgs a) {
   // T1: dtype after the mask multiply = torch promotion of (w, score); without a mask it stays the weight dtype
   constexpr int T1 = (M == 0) ? DTW : ((DTW == DMXQ_F32 || DTS == DMXQ_F32 || DTW != DTS) ? DMXQ_F32 : DTW);
@@ -106,6 +109,10 @@ __global__ __launch_bounds__(kThreads) void hypernet_rows_kernel(HnArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; k++) x[k] = round_to<T1>(x[k] * sva[HAS_SCALE ? r : 0][k]);
     }
+    if (!BFP) {
+      store_vec<DTO, 8, true>(a.out, e0, x);
+      continue;
+    }
     uint32_t mb = 0u;
 #pragma unroll
     for (int k = 0; k < 8; k++) mb = max(mb, f2u(x[k]) & 0x7FFFFFFFu);
@@ -146,6 +153,33 @@ static int launch_hn(const HnArgs& a, int M, bool has_scale, hipStream_t s) {
 }  // namespace dmxq
 
 using namespace dmxq;
+
+// Typed N:M mask-and-multiply over a flat [n] stream of whole M-groups (inner == 1), y = x * mask(score); called by
+// dmxq_nm_mask (nm_mask.hip) before its generic kernels.  DMXQ_ERR_UNSUPPORTED: not one of the instantiated dtype triples.
+extern "C" int dmxq_internal_nm_sparsify_typed(const void* score, int dtype_score, const void* x, int dtype_x, void* y, int dtype_y,
+                                               int64_t n, int K, int M, void* stream) {
+  if (!(M == 2 || M == 4 || M == 8) || n % 8 != 0 || !aligned16(score) || !aligned16(x) || !aligned16(y)) return DMXQ_ERR_UNSUPPORTED;
+  const HnArgs a{x, score, nullptr, y, n / 8, n, K, 1, 8, 0, n < ((int64_t)1 << 31) ? 1 : 0, make_fastdiv31(n)};
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = grid_for((a.n_units + 3) / 4);
+#define DMXQ_NMT(W_, S_, O_)                                                                                          \
+  if (dtype_x == W_ && dtype_score == S_ && dtype_y == O_) {                                                          \
+    switch (M) {                                                                                                      \
+      case 2: DMXQ_LAUNCH((hypernet_rows_kernel<W_, S_, O_, 2, false, false>), dim3(grid), dim3(kThreads), 0, s, a); break; \
+      case 4: DMXQ_LAUNCH((hypernet_rows_kernel<W_, S_, O_, 4, false, false>), dim3(grid), dim3(kThreads), 0, s, a); break; \
+      default: DMXQ_LAUNCH((hypernet_rows_kernel<W_, S_, O_, 8, false, false>), dim3(grid), dim3(kThreads), 0, s, a); break; \
+    }                                                                                                                 \
+    return launch_status();                                                                                           \
+  }
+  DMXQ_NMT(DMXQ_BF16, DMXQ_BF16, DMXQ_BF16)
+  DMXQ_NMT(DMXQ_F16, DMXQ_F16, DMXQ_F16)
+  DMXQ_NMT(DMXQ_F32, DMXQ_F32, DMXQ_F32)
+  DMXQ_NMT(DMXQ_BF16, DMXQ_F32, DMXQ_F32)
+  DMXQ_NMT(DMXQ_F16, DMXQ_F32, DMXQ_F32)
+  DMXQ_NMT(DMXQ_BF16, DMXQ_F32, DMXQ_BF16)
+#undef DMXQ_NMT
+  return DMXQ_ERR_UNSUPPORTED;
+}
 
 extern "C" int dmxq_weight_hypernet(const void* w, int dtype_w, const void* score, int dtype_score, int K, int M,
                                     const float* sq_scale, void* out, int dtype_out, int64_t rows, int64_t L,

@@ -195,6 +195,10 @@ __global__ __launch_bounds__(kThreads) void nm_mask_anyM_kernel(NmArgs a, int M)
 
 using namespace dmxq;
 
+// hypernet.hip: compile-time typed mask-and-multiply (no mask output); DMXQ_ERR_UNSUPPORTED = not applicable
+extern "C" int dmxq_internal_nm_sparsify_typed(const void* score, int dtype_score, const void* x, int dtype_x, void* y, int dtype_y,
+                                               int64_t n, int K, int M, void* stream);
+
 extern "C" int dmxq_nm_mask(const void* score, int dtype_score, const void* x, int dtype_x, void* mask_out,
                             int dtype_mask, void* y_out, int dtype_y, int64_t outer, int64_t L, int64_t inner, int K,
                             int M, void* stream) {
@@ -210,6 +214,10 @@ extern "C" int dmxq_nm_mask(const void* score, int dtype_score, const void* x, i
   hipStream_t s = (hipStream_t)stream;
   const bool vec_ok = inner == 1 && (M == 2 || M == 4 || M == 8 || M == 16) && n % 16 == 0 && aligned16(score) &&
                       (!x || aligned16(x)) && (!mask_out || aligned16(mask_out)) && (!y_out || aligned16(y_out));
+  if (vec_ok && y_out && !mask_out) {
+    const int rc = dmxq_internal_nm_sparsify_typed(score, dtype_score, x, dtype_x, y_out, dtype_y, n, K, M, stream);
+    if (rc != DMXQ_ERR_UNSUPPORTED) return rc;
+  }
   if (vec_ok) {
     switch (M) {
       case 2: launch_nm_vec<2>(a, n, s); break;

@@ -1,0 +1,37 @@
+"""-m gpu, needs >= 2 GPUs (skipped on the 1-GPU box): the N > 1 path of bench.py as the driver launches it -- one process
+per GPU under torch.distributed.run, RCCL ("nccl") for the barrier, the max-over-ranks of the timing and the harness-only
+all_gather of the output shards, which rank 0 compares bit for bit with its own whole-tensor result (SURVEY.md §8e:
+shard -> op -> concat == op on the whole).  The CPU twin with gloo is tests/test_parallel_gloo.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--replays", "3", "--no-cpu-baseline"] + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]     # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra,scaling", [([], "weak"), (["--workload", "llama-shard", "--op", "bfp", "--layers", "1"], "strong"),
+                                           (["--workload", "llama-shard", "--layers", "1"], "strong")])
+def test_bench_two_ranks_shards_and_gathers(extra, scaling):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    line = _run(extra, 29500 + len(extra))
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == scaling
+    assert "all_gather of 2 row shards" in line["config"]["check"] and "bit-exact" in line["config"]["check"]
+    assert line["value"] > 0 and 0 < line["roofline"]["frac"] < 1.0
