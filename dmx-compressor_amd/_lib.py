@@ -32,6 +32,7 @@ SIGNATURES = {
     "dmxq_weight_hypernet": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_float_qdq": [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _u64, _vp],
     "dmxq_fixed_qdq": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _u64, _vp],
+    "dmxq_fixed_qdq_multi": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _u64, _vp],
     "dmxq_nm_mask": [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_topk_workspace_bytes": [_i64],
     "dmxq_topk_mask": [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp],
@@ -53,6 +54,11 @@ SIGNATURES = {
 class TensorDesc(ctypes.Structure):
     """dmxq_tensor_desc (include/dmxq.h)"""
     _fields_ = [("in_", _vp), ("out", _vp), ("outer", _i64), ("L", _i64), ("inner", _i64)]
+
+
+class AffineDesc(ctypes.Structure):
+    """dmxq_affine_desc (include/dmxq.h)"""
+    _fields_ = [("in_", _vp), ("out", _vp), ("scale", _vp), ("zero_point", _vp), ("outer", _i64), ("C", _i64), ("inner", _i64)]
 
 
 class DmxqError(RuntimeError):

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -210,6 +210,38 @@ def fixed_qdq(x, precision: int, fraction: int, clamp: bool = True, symmetric: b
                                precision, fraction, int(clamp), int(symmetric), _lib.ROUNDING_CODE[rounding],
                                ptr(sc), ptr(zp), gs, seed, stream_of(xc)), "dmxq_fixed_qdq")
     return out
+
+
+def fixed_qdq_multi(tensors, precision: int, fraction: int, clamp: bool, symmetric: bool, scales, zero_points,
+                    group_size: Optional[int] = None, rounding: str = "nearest", out_dtype: Optional[torch.dtype] = None,
+                    seed: Optional[int] = None):
+    """Affine integer Q->DQ (numerical/cast.py:278-296) of MANY weights of one dtype on one device in as few launches as
+    possible (`dmxq_fixed_qdq_multi`): the same results as `[fixed_qdq(t, ..., scale=s, zero_point=z, ch_axis=0 (or None when
+    s has one entry), group_size=group_size) for t, s, z in zip(tensors, scales, zero_points)]`."""
+    xs = [_prep(t, "fixed_qdq_multi") for t in tensors]
+    if not xs:
+        return []
+    dt, dev = xs[0].dtype, xs[0].device
+    if any(x.dtype != dt or x.device != dev for x in xs):
+        raise ValueError("fixed_qdq_multi: all tensors must share one dtype and one device")
+    outs = [torch.empty(x.shape, dtype=out_dtype or dt, device=dev) for x in xs]
+    scs = [s.detach().to(device=dev, dtype=torch.float32).contiguous() for s in scales]
+    zps = [z.detach().to(device=dev, dtype=torch.int64).contiguous() for z in zero_points]
+    gs = group_size or 1
+    descs = (_lib.AffineDesc * len(xs))()
+    for d, x, o, s, z in zip(descs, xs, outs, scs, zps):
+        if s.numel() == 1:
+            outer, C, inner = 1, 1, x.numel()
+        else:
+            outer, C, inner = split3(x.shape, 0)
+            if s.numel() < -(-C // gs):
+                raise ValueError("fixed_qdq_multi: not enough scale entries")
+        d.in_, d.out, d.scale, d.zero_point, d.outer, d.C, d.inner = x.data_ptr(), o.data_ptr(), s.data_ptr(), z.data_ptr(), outer, C, inner
+    seed = _next_seed() if (seed is None and rounding == "stochastic") else (seed or 0)
+    with torch.cuda.device(dev):
+        check(lib().dmxq_fixed_qdq_multi(descs, len(xs), dtype_code(dt), dtype_code(outs[0].dtype), precision, fraction, int(clamp),
+                                         int(symmetric), _lib.ROUNDING_CODE[rounding], gs, seed, stream_of(xs[0])), "dmxq_fixed_qdq_multi")
+    return outs
 
 
 def _nm(score, x, K, M, block_dim, want_mask, want_y, mask_dtype, y_dtype):
@@ -465,6 +497,6 @@ def _on_tensor_device(fn):
 
 
 for _name in __all__:
-    if _name != "bfp_qdq_multi":  # (takes a list; switches device itself)
+    if _name not in ("bfp_qdq_multi", "fixed_qdq_multi"):  # (take lists; switch device themselves)
         globals()[_name] = _on_tensor_device(globals()[_name])
 del _name

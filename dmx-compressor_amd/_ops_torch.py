@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import DmxqError, ROUNDING_CODE, require_gpu
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -178,6 +178,19 @@ def fixed_qdq(x, precision: int, fraction: int, clamp: bool = True, symmetric: b
     require_gpu(x, "fixed_qdq")
     return _ops.fixed_qdq(x, precision, fraction, clamp, symmetric, ROUNDING_CODE[rounding], scale, zero_point, ch_axis,
                           group_size or None, out_dtype, _seed_arg(seed, rounding))
+
+
+def fixed_qdq_multi(tensors, precision: int, fraction: int, clamp: bool, symmetric: bool, scales, zero_points,
+                    group_size: Optional[int] = None, rounding: str = "nearest", out_dtype: Optional[torch.dtype] = None,
+                    seed: Optional[int] = None):
+    """Affine integer Q->DQ (numerical/cast.py:278-296) of MANY weights of one dtype on one device in as few launches as
+    possible (`dmxq_fixed_qdq_multi`): the same results as `[fixed_qdq(t, ..., scale=s, zero_point=z, ch_axis=0 (or None when
+    s has one entry), group_size=group_size) for t, s, z in zip(tensors, scales, zero_points)]`."""
+    tensors = list(tensors)
+    for t in tensors:
+        require_gpu(t, "fixed_qdq_multi")
+    return list(_ops.fixed_qdq_multi(tensors, precision, fraction, clamp, symmetric, ROUNDING_CODE[rounding], list(scales),
+                                     list(zero_points), group_size or 1, out_dtype, _seed_arg(seed, rounding)))
 
 
 # ---------------------------------------------------------------------------------------------------- sparsity

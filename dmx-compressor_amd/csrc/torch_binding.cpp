@@ -270,6 +270,40 @@ Tensor fixed_qdq_meta(const Tensor& x, int64_t, int64_t, bool, bool, int64_t, co
   return empty_like_shape(x, out_dtype);
 }
 
+std::vector<Tensor> fixed_qdq_multi(at::TensorList xs, int64_t precision, int64_t fraction, bool clamp, bool symmetric, int64_t rounding,
+                                    at::TensorList scales, at::TensorList zero_points, int64_t group_size, OptDtype out_dtype, int64_t seed) {
+  // every tensor is [C, inner] (or any shape with ONE scale: C == 1) with its own scale / zero-point vectors, channels along dim 0
+  std::vector<Tensor> outs, ins, scs, zps;
+  if (xs.empty()) return outs;
+  TORCH_CHECK(scales.size() == xs.size() && zero_points.size() == xs.size(), "fixed_qdq_multi: one scale and one zero_point tensor per input");
+  std::vector<dmxq_affine_desc> d(xs.size());
+  for (size_t i = 0; i < xs.size(); i++) {
+    ins.push_back(prep(xs[i], "fixed_qdq_multi"));
+    TORCH_CHECK(ins[i].scalar_type() == ins[0].scalar_type() && ins[i].device() == ins[0].device(),
+                "fixed_qdq_multi: all tensors must share one dtype and one device");
+    outs.push_back(empty_like_shape(ins[i], out_dtype));
+    scs.push_back(scales[i].detach().to(ins[i].device(), at::kFloat).contiguous());
+    zps.push_back(zero_points[i].detach().to(ins[i].device(), at::kLong).contiguous());
+    const bool per_tensor = scs[i].numel() == 1;
+    const Split3 s = per_tensor ? Split3{1, 1, ins[i].numel()} : split3(ins[i], 0);
+    const int64_t gs = std::max<int64_t>(group_size, 1);
+    const int64_t need = per_tensor ? 1 : (s.L + gs - 1) / gs;
+    TORCH_CHECK_VALUE(scs[i].numel() >= need && zps[i].numel() >= need, "fixed_qdq_multi: tensor ", i, " needs ", need, " scale/zero_point entries");
+    d[i] = dmxq_affine_desc{ins[i].data_ptr(), outs[i].data_ptr(), (const float*)scs[i].data_ptr(), (const int64_t*)zps[i].data_ptr(), s.outer, s.L, s.inner};
+  }
+  Launch l(ins[0]);
+  check(dmxq_fixed_qdq_multi(d.data(), (int64_t)d.size(), dt_code(ins[0].scalar_type()), dt_code(outs[0].scalar_type()), (int)precision,
+                             (int)fraction, clamp, symmetric, (int)rounding, std::max<int64_t>(group_size, 1), (uint64_t)seed, l.stream),
+        "dmxq_fixed_qdq_multi");
+  return outs;
+}
+std::vector<Tensor> fixed_qdq_multi_meta(at::TensorList xs, int64_t, int64_t, bool, bool, int64_t, at::TensorList, at::TensorList, int64_t,
+                                         OptDtype out_dtype, int64_t) {
+  std::vector<Tensor> outs;
+  for (const Tensor& x : xs) outs.push_back(empty_like_shape(x, out_dtype));
+  return outs;
+}
+
 // ------------------------------------------------------------------------------------------------ sparsity
 // (mask, y): an output that was not requested comes back as an empty 1-d tensor
 Tensor none_like(const Tensor& x) { return at::empty({0}, x.options()); }
@@ -474,6 +508,7 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("mxfp_qdq(Tensor x, int man, int exp, int block_size, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
   m.def("float_qdq(Tensor x, int man, int exp, int bias, bool flush_subnormal, bool unsigned_abs=False, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");
   m.def("fixed_qdq(Tensor x, int precision, int fraction, bool clamp, bool symmetric, int rounding, Tensor? scale, Tensor? zero_point, int? ch_axis, int? group_size, ScalarType? out_dtype=None, int seed=0) -> Tensor");
+  m.def("fixed_qdq_multi(Tensor[] xs, int precision, int fraction, bool clamp, bool symmetric, int rounding, Tensor[] scales, Tensor[] zero_points, int group_size, ScalarType? out_dtype=None, int seed=0) -> Tensor[]");
   m.def("nm_mask(Tensor score, Tensor? x, int K, int M, int block_dim, bool want_mask, bool want_y, ScalarType? mask_dtype=None, ScalarType? y_dtype=None) -> (Tensor, Tensor)");
   m.def("topk_mask(Tensor score, Tensor? x, int n_zero, bool want_mask, bool want_y, ScalarType? mask_dtype=None, ScalarType? y_dtype=None) -> (Tensor, Tensor)");
   m.def("bernoulli_mask(Tensor score, int seed, ScalarType? mask_dtype=None) -> Tensor");
@@ -492,7 +527,7 @@ TORCH_LIBRARY(dmxq, m) {
 #define DMXQ_META(m, name) m.impl(#name, &name##_meta)
 #define DMXQ_FOR_ALL(X, m) \
   X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
-  X(m, float_qdq); X(m, fixed_qdq); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
+  X(m, float_qdq); X(m, fixed_qdq); X(m, fixed_qdq_multi); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
   X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, softmax); X(m, norm)
 
 // "CUDA" is the dispatch key of HIP tensors in a ROCm build of PyTorch

@@ -118,6 +118,16 @@ int dmxq_fixed_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64
                    int precision, int fraction, int clamp, int symmetric, int rounding, const float* scale,
                    const int64_t* zero_point, int64_t group_size, uint64_t seed, void* stream);
 
+/* Multi-tensor twin of dmxq_fixed_qdq: exactly the result of one dmxq_fixed_qdq call per tensor (same dtype pair, format
+ * and group_size for all; each tensor its own scale / zero-point arrays), in as few launches as possible.  Replaces the
+ * per-module loop over the INT8 group-quantised Linear weights of a whole model (numerical/cast.py:278-296 once per module;
+ * opt-125m: 73 weights).  `tensors` is a HOST array.  Batched (40 tensors per launch): integer formats (fraction 0, clamped,
+ * nearest), outer == 1 with row slabs of group_size channels or a single group, inner a multiple of the 16-byte vector,
+ * < 2^31 elements; every other tensor gets its own launch (stochastic rounding: seed + index). */
+typedef struct { const void* in; void* out; const float* scale; const int64_t* zero_point; int64_t outer, C, inner; } dmxq_affine_desc;
+int dmxq_fixed_qdq_multi(const dmxq_affine_desc* tensors, int64_t n_tensors, int dtype_in, int dtype_out, int precision,
+                         int fraction, int clamp, int symmetric, int rounding, int64_t group_size, uint64_t seed, void* stream);
+
 /* N:M structured-sparsity mask ("BTOPK{K:M,dim}") and its application.
  * Replaces: sparse.py:163-180 BlockTopK.forward (argsort + scatter) and sparse.py:300 `x * mask`.
  * Groups are M consecutive indices along L (stride inner); L % M == 0 required (sparse.py:166-168).

@@ -85,6 +85,33 @@ def test_bfp_multi_through_the_c_abi(dmx, cuda):
     assert L.dmxq_bfp_qdq_multi(d, 0, lib.BF16, lib.BF16, 16, 8, lib.ROUND_NEAREST, 1, 0, sp) == lib.OK
 
 
+def test_fixed_multi_opt125m_int8_group128_matches_oracle(dmx, cuda, oracle):
+    """BASELINE.json configs[2]: INT8 group_size = 128 (ch_axis 0) on all 73 Linear weights of opt-125m in two launches
+    (`dmxq_fixed_qdq_multi`), each tensor with its own calibrated scales; vs the oracle per tensor, and vs the single-tensor
+    entry point for every tensor.  A per-tensor-scale weight, a non-batchable one (inner not a multiple of 8) and an
+    out-of-range scale ride along."""
+    shapes = _opt125m_weight_shapes() + [(64, 100), (300, 40), (16, 64)]
+    ws, scs, zps = [], [], []
+    for i, s in enumerate(shapes):
+        w = make("normal", s, seed=700 + i, dtype=torch.bfloat16) * 0.05
+        per_tensor = i == len(shapes) - 1
+        mn, mx = oracle.group_minmax(w if not per_tensor else w.reshape(1, -1), 0, 128 if not per_tensor else 1)
+        sc, zp = oracle.qparams(mn, mx, 8, True, True)
+        if i == 5:
+            sc[0] = 3e-8          # outside the reciprocal's proven range: that group takes the IEEE division
+        ws.append(w); scs.append(sc); zps.append(zp)
+    got = dmx.ops.fixed_qdq_multi([w.to(cuda) for w in ws], 8, 0, True, True, [s.to(cuda) for s in scs], [z.to(cuda) for z in zps], group_size=128)
+    for i, (w, sc, zp, y) in enumerate(zip(ws, scs, zps, got)):
+        per_tensor = sc.numel() == 1
+        single = dmx.ops.fixed_qdq(w.to(cuda), 8, 0, True, True, scale=sc.to(cuda), zero_point=zp.to(cuda),
+                                   ch_axis=None if per_tensor else 0, group_size=None if per_tensor else 128)
+        assert bits_equal(y, single) == 0, (i, shapes[i])
+        if i % 6 in (0, 4, 5) or i >= len(shapes) - 4:
+            want = oracle.fixed_point_affine_cast(w, 8, 0, True, True, sc, zp, ch_axis=None if per_tensor else 0,
+                                                  group_size=None if per_tensor else 128).to(torch.bfloat16)
+            assert bits_equal(y, want) == 0, (i, shapes[i])
+
+
 # every tile geometry of rows_plan (csrc/bfp.hip): 512x1, 128x2, 512x4, 512x6, 512x16, 512x2, each with a partial last tile
 GEOMETRY_ROWS = [(200, "512x1"), (511, "512x1"), (1000, "128x2"), (1535, "128x2"), (2000, "512x4"), (2900, "512x6"),
                  (3071, "512x6"), (4096, "512x16"), (3900, "512x16"), (5000, "512x2")]

@@ -89,6 +89,40 @@ def main():
             us = e0.elapsed_time(e1) * 1e3 / 30
             print(f"opt-125m 73 Linear weights ({n / 1e6:.1f} M elements) BFP16_64, {name}: {us:9.1f} us  "
                   f"{n * 4 / (us * 1e-6) / 1e9:8.1f} GB/s  {100 * n * 4 / (us * 1e-6) / 8e12:5.1f}%", flush=True)
+    # the INT8 group-quant twin (BASELINE.json configs[2]: group_size = 128 rows): one dmxq_fixed_qdq per tensor vs dmxq_fixed_qdq_multi
+    scales = [[(torch.rand(-(-s[0] // 128), device=dev) * 0.002 + 0.0005) for s in shapes] for _ in range(3)]
+    zps = [[torch.zeros(-(-s[0] // 128), dtype=torch.int64, device=dev) for s in shapes] for _ in range(3)]
+    f_args = [[(vp(w.data_ptr()), vp(o.data_ptr()), _lib.BF16, _lib.BF16, 1, w.shape[0], w.shape[1], 8, 0, 1, 1, 2, vp(sc.data_ptr()), vp(z.data_ptr()), 128, 0, sp)
+               for w, o, sc, z in zip(ws, os_, scs, zs)] for ws, os_, scs, zs in zip(sets, outs, scales, zps)]
+    adescs = []
+    for ws, os_, scs, zs in zip(sets, outs, scales, zps):
+        d = (_lib.AffineDesc * len(ws))()
+        for e, w, o, sc, z in zip(d, ws, os_, scs, zs):
+            e.in_, e.out, e.scale, e.zero_point, e.outer, e.C, e.inner = w.data_ptr(), o.data_ptr(), sc.data_ptr(), z.data_ptr(), 1, w.shape[0], w.shape[1]
+        adescs.append(d)
+
+    def f_one_by_one(i):
+        for a in f_args[i]:
+            L.dmxq_fixed_qdq(*a)
+
+    def f_multi(i):
+        assert L.dmxq_fixed_qdq_multi(adescs[i], len(shapes), _lib.BF16, _lib.BF16, 8, 0, 1, 1, 2, 128, 0, sp) == 0
+
+    with torch.cuda.stream(stream):
+        for name, fn in (("one dmxq_fixed_qdq launch per tensor (73 launches)", f_one_by_one), ("dmxq_fixed_qdq_multi (2 launches)", f_multi)):
+            for i in range(6):
+                fn(i % 3)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for i in range(30):
+                fn(i % 3)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 30
+            print(f"opt-125m 73 Linear weights ({n / 1e6:.1f} M elements) INT8 group 128, {name}: {us:9.1f} us  "
+                  f"{n * 4 / (us * 1e-6) / 1e9:8.1f} GB/s  {100 * n * 4 / (us * 1e-6) / 8e12:5.1f}%", flush=True)
+
 
 if __name__ == "__main__":
     main()
