@@ -27,7 +27,7 @@ from .sparse import Dense, Sparsify
 
 __all__ = ["DmxModule", "DmxQuantizerCalibrationHyperparams", "DmxModuleQuantizerCalibrationHyperparams",
            "DmxModuleSmoothQuantHyperparams", "Linear", "Conv1d", "Conv2d", "ResAdd", "ActActMatMul", "Softmax", "LayerNorm", "GELU", "ReLU", "SiLU", "QuickGELU", "Exp", "Mul", "RMSNorm",
-           "MaxPool2d", "AvgPool2d", "Embedding", "DmxConfigRule", "configure_model"]
+           "MaxPool2d", "AvgPool2d", "Embedding", "DmxConfigRule", "configure_model", "fold_weights_and_biases"]
 
 
 class _LazySparsify(Sparsify):
@@ -586,6 +586,54 @@ class DmxConfigRule:
         for n, m in model.named_modules():
             if isinstance(m, DmxModule) and isinstance(m, self.module_types) and self.name_rule.match(n):
                 m.configure(self.module_config)
+
+
+def fold_weights_and_biases(model: torch.nn.Module) -> torch.nn.Module:
+    """`DmxModel.fold_weights_and_biases` (modeling/model.py: every DmxModule's `fold_weight_and_bias`, core.py:146-176) for a
+    model built from these modules: weights are quantised ONCE instead of on every forward.  The per-module weight casts are
+    the launch-bound part on a small model (opt-125m: 73 Linear weights of 0.6-2.4 M elements, ~4 us of launch each for
+    0.4-1.6 us of streaming), so the modules whose weight path is a single plain cast are BATCHED through the multi-tensor
+    entry points (`ops.bfp_qdq_multi` for BFP formats, `ops.fixed_qdq_multi` for calibrated INT8 / INT4 per-tensor or
+    row-group quantisation: one launch per 40-48 tensors); everything else -- sparsifiers, SmoothQuant, storage formats,
+    pre-transforms, the biases -- goes through the module's own `fold_weight_and_bias`, which also finishes the batched ones
+    (their weight cast is already SAME by then).  Bit-identical to folding module by module."""
+    from . import ops
+    from .format import BlockFloatingPoint, FixedPoint
+    from .sparse import Dense
+    mods = [m for m in model.modules() if isinstance(m, DmxModule) and getattr(m, "weight", None) is not None]
+    groups = {}
+    with torch.no_grad():
+        for m in mods:
+            wc, st, sp, sq = m.weight_cast, m.weight_storage_cast, m.weight_sparsifier, m.smoothquant
+            if (wc is None or wc.pre_transform or not wc._flag("fake_quant_enabled") or wc._flag("observer_enabled") or not m.weight.is_cuda
+                    or (sp is not None and not isinstance(sp.sparseness, Dense))
+                    or (sq is not None and not sq._flag("fused_to_weight") and sq._flag("enabled"))
+                    or (st is not None and not (isinstance(st.format, Same) and not st.pre_transform))):
+                continue
+            fmt, w = wc.format, m.weight
+            if isinstance(fmt, BlockFloatingPoint) and fmt.block_size > 1 and wc.block_dim in (-1, w.dim() - 1):
+                key = ("bfp", w.dtype, w.device, fmt.precision, fmt.block_size, fmt.symmetric, fmt.rounding)
+            elif isinstance(fmt, FixedPoint) and not wc.is_per_channel and (wc.group_size is None or wc.ch_axis in (0, -w.dim())):
+                key = ("fixed", w.dtype, w.device, fmt.precision, fmt.fraction, fmt.clamp, fmt.symmetric, fmt.rounding, wc.group_size)
+            else:
+                continue
+            groups.setdefault(key, []).append(m)
+        for key, ms in groups.items():
+            ws = [m.weight.data for m in ms]
+            if key[0] == "bfp":
+                _, _, _, precision, block_size, symmetric, rounding = key
+                outs = ops.bfp_qdq_multi(ws, precision, block_size, -1, symmetric, rounding)
+            else:
+                _, _, _, precision, fraction, clamp, symmetric, rounding, gs = key
+                outs = ops.fixed_qdq_multi(ws, precision, fraction, clamp, symmetric, [m.weight_cast.scale for m in ms],
+                                           [m.weight_cast.zero_point for m in ms], group_size=gs, rounding=rounding)
+            for m, o in zip(ms, outs):
+                m.weight.data = o
+                m.weight_cast = CastTo(format=Same())
+        for m in model.modules():
+            if isinstance(m, DmxModule):
+                m.fold_weight_and_bias()
+    return model
 
 
 def configure_model(model: torch.nn.Module, *rules: DmxConfigRule):

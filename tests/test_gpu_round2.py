@@ -350,3 +350,44 @@ def test_affine_int8_with_fast_division_matches_oracle_everywhere(dmx, cuda, ora
             got = dmx.ops.fixed_qdq(xx.to(cuda), 8, 0, True, True, scale=sc.to(cuda), zero_point=zp.to(cuda), ch_axis=ch_axis, group_size=gs)
             want = oracle.fixed_point_affine_cast(xx, 8, 0, True, True, sc, zp, ch_axis=ch_axis, group_size=gs).to(dt)
             assert mismatches_nan_aware(got, want) == 0 and bits_equal(torch.nan_to_num(got.float()), torch.nan_to_num(want.float())) == 0, (name, dt)
+
+
+# ------------------------------------------------------------------------------------------------ model-level fold (multi-tensor launches)
+def test_model_fold_through_multi_tensor_launches_equals_module_by_module(dmx, cuda):
+    """nn.fold_weights_and_biases batches the plain weight casts of a whole model through dmxq_bfp_qdq_multi /
+    dmxq_fixed_qdq_multi; the folded parameters and the forward must equal folding module by module
+    (DmxModule.fold_weight_and_bias, core.py:146-176) bit for bit -- BASIC (BFP16_64 weights, BFP32_1 biases), calibrated INT8
+    row groups, and a module the batch must leave alone (2:4 sparsity)."""
+    import copy
+
+    def build():
+        torch.manual_seed(3)
+        layers = [dmx.nn.Linear(256, 192), dmx.nn.ReLU(), dmx.nn.Linear(192, 128), dmx.nn.LayerNorm(128), dmx.nn.Linear(128, 64, bias=False),
+                  dmx.nn.Linear(64, 64)]
+        m = torch.nn.Sequential(*layers).to(cuda).to(torch.bfloat16)
+        dmx.nn.configure_model(m, *dmx.config_rules.BASIC)
+        m[5].configure(dict(weight_sparseness="BTOPK{2:4,-1}(U)"))
+        return m.eval()
+
+    for variant in ("bfp", "int8"):
+        a = build()
+        if variant == "int8":
+            hp = dmx.nn.DmxModuleQuantizerCalibrationHyperparams(weight=dmx.nn.DmxQuantizerCalibrationHyperparams(
+                observer_cls=dmx.MinMaxObserver, qscheme_to_overload=torch.per_tensor_symmetric, group_size=64, ch_axis=0))
+            for i in (0, 2, 4):
+                a[i].configure(dict(weight_format=dmx.format.INT8))
+                with a[i].calibrating_quantizers(hp), torch.no_grad():
+                    a[i]._weight
+        x = make("normal", (8, 256), seed=1, dtype=torch.bfloat16).to(cuda)
+        with torch.no_grad():
+            a(x)                                   # materialises the lazy score of the sparse layer
+            b = copy.deepcopy(a)
+            want = a(x)
+            for mod in a.modules():
+                if isinstance(mod, dmx.nn.DmxModule):
+                    mod.fold_weight_and_bias()
+            dmx.nn.fold_weights_and_biases(b)
+            for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+                assert na == nb and bits_equal(pa.data, pb.data) == 0, (variant, na)
+            assert bits_equal(a(x), b(x)) == 0 and bits_equal(b(x), want) == 0
+        assert all(isinstance(mod.weight_cast.format, dmx.Same) for mod in b if isinstance(mod, dmx.nn.Linear))
