@@ -94,6 +94,8 @@ def _rule_sets():
             DmxConfigRule(module_types=(nn.Embedding,), module_config=dict(output_formats=[elt])),
             DmxConfigRule(module_types=pools, module_config=io(1, elt, elt)),
             DmxConfigRule(module_types=act_like, module_config=io(1, elt, elt, default_approx.NONE)),
+            DmxConfigRule(module_types=(nn.ApplyRotaryPosEmb,), module_config=dict(input_formats=[elt] * 4, output_formats=[elt] * 2,
+                                                                                   approximation_function=default_approx.NONE)),
         ]
 
     return SimpleNamespace(

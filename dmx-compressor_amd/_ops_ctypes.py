@@ -15,7 +15,7 @@ from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, s
 
 __all__ = [
     "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
-    "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "softmax", "layernorm",
+    "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
 
@@ -431,6 +431,25 @@ def exp(x, out_dtype: Optional[torch.dtype] = None):
 def silu_experimental(x, scale: float):
     """the reference's `experimental.silu` (functional/functions.py:7-21): relu(x.to(float16)) * scale -> float16"""
     return _unary(x, UNARY_SILU_EXPERIMENTAL, scale, torch.float16)
+
+
+def rope(x, cos, sin, unsqueeze_dim: int = 1):
+    """APPLY_LLAMA_ROPE for ONE of q / k: (x * cos) + (rotate_half(x) * sin) in the tensor dtype (custom_modules.py:142-172);
+    x [B, n1, n2, D], cos / sin [B, S, D].  Returns None when the HIP kernel does not take this shape / dtype mix (the
+    caller keeps torch's own ops)."""
+    xc = _prep(x, "rope")
+    if xc.dim() != 4 or cos.dim() != 3 or sin.dim() != 3 or unsqueeze_dim not in (1, 2) or cos.dtype != xc.dtype or sin.dtype != xc.dtype:
+        return None
+    c, s = _prep(cos, "rope"), _prep(sin, "rope")
+    B, n1, n2, D = xc.shape
+    if tuple(c.shape) != (B, n2 if unsqueeze_dim == 1 else n1, D) or s.shape != c.shape:
+        return None
+    out = torch.empty_like(xc)
+    rc = lib().dmxq_rope(ptr(xc), ptr(c), ptr(s), ptr(out), dtype_code(xc.dtype), B, n1, n2, D, int(unsqueeze_dim == 1), stream_of(xc))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    check(rc, "dmxq_rope")
+    return out
 
 
 def softmax(x, dim: int = -1, input_clamp: Optional[float] = None, out_dtype: Optional[torch.dtype] = None):

@@ -18,7 +18,7 @@ from ._lib import DmxqError, ROUNDING_CODE, require_gpu
 
 __all__ = [
     "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
-    "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "softmax", "layernorm",
+    "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
 
@@ -322,6 +322,17 @@ def silu_experimental(x, scale: float):
     """the reference's `experimental.silu` (functional/functions.py:7-21): relu(x.to(float16)) * scale -> float16"""
     require_gpu(x, "silu_experimental")
     return _ops.unary(x, UNARY_SILU_EXPERIMENTAL, float(scale), torch.float16)
+
+
+def rope(x, cos, sin, unsqueeze_dim: int = 1):
+    """APPLY_LLAMA_ROPE for ONE of q / k: (x * cos) + (rotate_half(x) * sin) in the tensor dtype (custom_modules.py:142-172);
+    x [B, n1, n2, D], cos / sin [B, S, D].  Returns None when the HIP kernel does not take this shape / dtype mix (the
+    caller keeps torch's own ops)."""
+    require_gpu(x, "rope")
+    try:
+        return _ops.rope(x, cos, sin, unsqueeze_dim)
+    except NotImplementedError:
+        return None
 
 
 def softmax(x, dim: int = -1, input_clamp: Optional[float] = None, out_dtype: Optional[torch.dtype] = None):

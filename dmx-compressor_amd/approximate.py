@@ -4,7 +4,7 @@
 (approximate.py:128-132).  The reference's only algorithm is "vsimd", a private package that is absent from the
 public repository, where every default therefore collapses to NONE.  This mirror registers two algorithms:
   "dmxq"          the exact torch function contract evaluated by libdmxq's HIP kernels (GELU, SILU, QUICK_GELU, EXP,
-                  SOFTMAX, LAYER_NORM, RMS_NORM) -- what the reference computes with vsimd absent;
+                  SOFTMAX, LAYER_NORM, RMS_NORM, APPLY_LLAMA_ROPE) -- what the reference computes with vsimd absent;
   "experimental"  the reference's one in-repo approximation, `experimental.silu` (functional/functions.py:7-21,
                   dispatched by approximate.py:148-151), reproduced bit for bit by a HIP kernel.
 vsimd approximation arithmetic itself is parity-unpinned and is not invented here.
@@ -103,8 +103,16 @@ class TorchFunctionApproximation(ApproximationFunction):
             w = args[2] if len(args) > 2 else kw.get("weight")
             eps = args[3] if len(args) > 3 else kw.get("eps")
             return ops.rmsnorm(x, normalized_shape, w, eps)
-        raise NotImplementedError(f"{self.func_id}: no HIP kernel in the accelerated path (rotary embedding is index "
-                                  "shuffling + two multiplies, left to torch)")
+        if self.func_id == "APPLY_LLAMA_ROPE":
+            # custom_modules.py:142-172 forward(q, k, cos, sin, unsqueeze_dim=1) -> (q_embed, k_embed)
+            q, k, cos, sin = args[:4]
+            ud = args[4] if len(args) > 4 else kw.get("unsqueeze_dim", 1)
+            qe, ke = ops.rope(q, cos, sin, ud), ops.rope(k, cos, sin, ud)
+            if qe is None or ke is None:
+                raise NotImplementedError("APPLY_LLAMA_ROPE[dmxq]: this shape / dtype mix is not taken by the HIP kernel "
+                                          "(needs 4-d q / k, 3-d cos / sin of the same dtype, head_dim a multiple of 16)")
+            return qe, ke
+        raise NotImplementedError(f"{self.func_id}: unknown function id")
 
     @classmethod
     def from_shorthand(cls, sh: str):

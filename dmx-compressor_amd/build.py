@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libdmxq.so")
 TORCH_LIB = os.path.join(HERE, "lib", "dmxq_torch.so")
-SOURCES = ["bfp.hip", "bfp_cols.hip", "bfp_urows.hip", "blockfmt.hip", "bfp_pack.hip", "hypernet.hip", "elementwise.hip", "nm_mask.hip", "topk.hip", "reduce.hip", "approx.hip", "unary.hip", "fixed_multi.hip"]
+SOURCES = ["bfp.hip", "bfp_cols.hip", "bfp_urows.hip", "blockfmt.hip", "bfp_pack.hip", "hypernet.hip", "elementwise.hip", "nm_mask.hip", "topk.hip", "reduce.hip", "approx.hip", "unary.hip", "fixed_multi.hip", "rope.hip"]
 # bit-exact fp32: no fast-math, no fma contraction; fp32 denormals stay on (gfx950 default)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
          "-fgpu-flush-denormals-to-zero" if False else "-fno-gpu-flush-denormals-to-zero"]

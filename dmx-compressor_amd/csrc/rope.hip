@@ -1,0 +1,79 @@
+// csrc/rope.hip — APPLY_LLAMA_ROPE, the last function id of the approximator slot (src/dmx/compressor/__init__.py:136-138).
+//
+// The reference's exact function is transformers' apply_rotary_pos_emb as restated in modeling/nn/custom_modules.py:142-172:
+//     x_embed = (x * cos) + (rotate_half(x) * sin),   rotate_half(x) = cat(-x[..., D/2:], x[..., :D/2])
+// with cos / sin of shape [B, S, D] unsqueezed so that they broadcast over the heads.  torch evaluates it IN THE TENSOR
+// DTYPE: two products and a sum, each rounded to the dtype -- reproduced here (fp32 arithmetic, round to the dtype after
+// every operation, -ffp-contract=off), so the result equals torch's CPU result BIT FOR BIT, not within a tolerance.
+// x is viewed as [B, n1, n2, D]; cos / sin rows are indexed by (b, n2) when the embedding broadcasts over dim 1
+// (unsqueeze_dim = 1: x = [B, heads, S, D]) or by (b, n1) (unsqueeze_dim = 2: x = [B, S, heads, D]).
+// One lane owns 8 (16-bit) or 4 (fp32) consecutive d of one row and also loads the partner vector at d +- D/2 (a second
+// read of x, served by L2: the two halves of a row are 128-256 bytes apart): algorithmic traffic = x in + x out (+ the
+// cos / sin tables once per head).
+#include "common.hpp"
+
+namespace dmxq {
+
+template <int DT>
+__device__ __forceinline__ float rnd_dt(float v) {
+  if (DT == DMXQ_BF16) return (float)(__bf16)v;
+  if (DT == DMXQ_F16) return (float)(_Float16)opaque(v);
+  return v;
+}
+
+template <int DT>
+__global__ __launch_bounds__(kThreads) void rope_kernel(const void* __restrict__ x, const void* __restrict__ cs,
+                                                       const void* __restrict__ sn, void* __restrict__ out, int64_t n_vec,
+                                                       int vpr /*vectors per row*/, FastDiv31 f_vpr, FastDiv31 f_n2, FastDiv31 f_n1,
+                                                       int n1, int n2, int over_dim1) {
+  constexpr int EPL = 16 / Elem<DT>::bytes;
+  const int half = vpr / 2;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < n_vec; v += stride) {
+    const uint32_t row = f_vpr.div((uint32_t)v), vc = (uint32_t)v - row * (uint32_t)vpr;       // (row, vector in row)
+    const uint32_t r12 = f_n2.div(row), i2 = row - r12 * (uint32_t)n2;                          // row = (b * n1 + i1) * n2 + i2
+    const uint32_t b = f_n1.div(r12), i1 = r12 - b * (uint32_t)n1;
+    const uint32_t crow = over_dim1 ? b * (uint32_t)n2 + i2 : b * (uint32_t)n1 + i1;
+    const bool lo = (int)vc < half;
+    const int64_t pv = lo ? v + half : v - half;                                                // partner vector
+    const u32x4 rx = load_raw16<true>(x, v * 16), rp = *(const u32x4*)((const char*)x + pv * 16);
+    const u32x4 rc = *(const u32x4*)((const char*)cs + ((int64_t)crow * vpr + vc) * 16);
+    const u32x4 rs = *(const u32x4*)((const char*)sn + ((int64_t)crow * vpr + vc) * 16);
+    float xv[EPL], pvv[EPL], c[EPL], s[EPL], y[EPL];
+    widen<DT, EPL>(rx, xv); widen<DT, EPL>(rp, pvv); widen<DT, EPL>(rc, c); widen<DT, EPL>(rs, s);
+#pragma unroll
+    for (int k = 0; k < EPL; k++) {
+      const float rot = lo ? -pvv[k] : pvv[k];
+      const float t1 = rnd_dt<DT>(xv[k] * c[k]);
+      const float t2 = rnd_dt<DT>(rot * s[k]);
+      y[k] = t1 + t2;   // rounded to DT by the store
+    }
+    store_out<DT, EPL, true>((char*)out + v * 16, pack_vec<DT, EPL>(y));
+  }
+}
+
+}  // namespace dmxq
+
+using namespace dmxq;
+
+extern "C" int dmxq_rope(const void* x, const void* cos_tab, const void* sin_tab, void* out, int dtype, int64_t B, int64_t n1,
+                         int64_t n2, int64_t D, int broadcast_over_dim1, void* stream) {
+  if (!valid_dtype(dtype) || B < 0 || n1 < 0 || n2 < 0 || D < 0) return DMXQ_ERR_BAD_ARG;
+  const int64_t n = B * n1 * n2 * D;
+  if (n == 0) return DMXQ_OK;
+  if (!x || !cos_tab || !sin_tab || !out) return DMXQ_ERR_BAD_ARG;
+  const int epl = dtype == DMXQ_F32 ? 4 : 8;
+  // whole aligned vectors in each half of a row, 31-bit indices; anything else is left to the caller (torch's own ops)
+  if (D % (2 * epl) != 0 || n >= ((int64_t)1 << 31) || !aligned16(x) || !aligned16(out) || !aligned16(cos_tab) || !aligned16(sin_tab) ||
+      x == out)
+    return DMXQ_ERR_UNSUPPORTED;
+  const int vpr = (int)(D / epl);
+  const int64_t n_vec = n / epl;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = grid_for((n_vec + 1) / 2);
+#define DMXQ_ROPE(D_) DMXQ_LAUNCH(rope_kernel<D_>, dim3(grid), dim3(kThreads), 0, s, x, cos_tab, sin_tab, out, n_vec, vpr, make_fastdiv31(vpr), \
+                                  make_fastdiv31(n2), make_fastdiv31(n1), (int)n1, (int)n2, broadcast_over_dim1 ? 1 : 0)
+  if (dtype == DMXQ_F32) DMXQ_ROPE(DMXQ_F32); else if (dtype == DMXQ_F16) DMXQ_ROPE(DMXQ_F16); else DMXQ_ROPE(DMXQ_BF16);
+#undef DMXQ_ROPE
+  return launch_status();
+}

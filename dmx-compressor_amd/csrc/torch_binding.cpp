@@ -460,6 +460,24 @@ Tensor unary(const Tensor& x, int64_t kind, double param, OptDtype out_dtype) {
 }
 Tensor unary_meta(const Tensor& x, int64_t, double, OptDtype out_dtype) { return empty_like_shape(x, out_dtype); }
 
+// x: [B, n1, n2, D]; cos / sin: [B, S, D] with S = n2 (unsqueeze_dim = 1) or n1 (unsqueeze_dim = 2)
+Tensor rope(const Tensor& x, const Tensor& cos_t, const Tensor& sin_t, int64_t unsqueeze_dim) {
+  const Tensor xc = prep(x, "rope");
+  TORCH_CHECK_NOT_IMPLEMENTED(xc.dim() == 4 && cos_t.dim() == 3 && sin_t.dim() == 3 && (unsqueeze_dim == 1 || unsqueeze_dim == 2),
+                              "rope: expects x [B, n1, n2, D], cos / sin [B, S, D], unsqueeze_dim 1 or 2");
+  TORCH_CHECK_NOT_IMPLEMENTED(cos_t.scalar_type() == xc.scalar_type() && sin_t.scalar_type() == xc.scalar_type(),
+                              "rope: x, cos and sin must share one dtype (torch's promotion rules are not reproduced)");
+  const Tensor c = prep(cos_t, "rope"), sn = prep(sin_t, "rope");
+  const int64_t B = xc.size(0), n1 = xc.size(1), n2 = xc.size(2), D = xc.size(3), S = unsqueeze_dim == 1 ? n2 : n1;
+  TORCH_CHECK_NOT_IMPLEMENTED(c.size(0) == B && c.size(1) == S && c.size(2) == D && sn.sizes() == c.sizes(), "rope: cos / sin shape");
+  Tensor out = at::empty_like(xc);
+  Launch l(xc);
+  check(dmxq_rope(xc.data_ptr(), c.data_ptr(), sn.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), B, n1, n2, D, unsqueeze_dim == 1,
+                  l.stream), "dmxq_rope");
+  return out;
+}
+Tensor rope_meta(const Tensor& x, const Tensor&, const Tensor&, int64_t) { return at::empty_like(x, x.options().memory_format(at::MemoryFormat::Contiguous)); }
+
 Tensor softmax(const Tensor& x, double clamp_min, OptDtype out_dtype) {  // over the contiguous last dim
   const Tensor xc = prep(x, "softmax");
   const int64_t cols = xc.dim() ? xc.size(-1) : 1;
@@ -519,6 +537,7 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("smoothquant_scale(Tensor a_maxabs, Tensor b_maxabs, float alpha, float scale_min) -> Tensor");
   m.def("scale_channels(Tensor x, Tensor scale, int ch_axis, bool divide, ScalarType? out_dtype=None) -> Tensor");
   m.def("unary(Tensor x, int kind, float param=0.0, ScalarType? out_dtype=None) -> Tensor");
+  m.def("rope(Tensor x, Tensor cos, Tensor sin, int unsqueeze_dim=1) -> Tensor");
   m.def("softmax(Tensor x, float clamp_min, ScalarType? out_dtype=None) -> Tensor");
   m.def("norm(Tensor x, int cols, Tensor? weight, Tensor? bias, float eps, int kind, ScalarType? out_dtype=None) -> Tensor");
 }
@@ -528,7 +547,7 @@ TORCH_LIBRARY(dmxq, m) {
 #define DMXQ_FOR_ALL(X, m) \
   X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
   X(m, float_qdq); X(m, fixed_qdq); X(m, fixed_qdq_multi); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
-  X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, softmax); X(m, norm)
+  X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, rope); X(m, softmax); X(m, norm)
 
 // "CUDA" is the dispatch key of HIP tensors in a ROCm build of PyTorch
 TORCH_LIBRARY_IMPL(dmxq, CUDA, m) { DMXQ_FOR_ALL(DMXQ_IMPL, m); }

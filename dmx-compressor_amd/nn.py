@@ -26,7 +26,7 @@ from .smoothquant import ActivationWeightSmoothQuant
 from .sparse import Dense, Sparsify
 
 __all__ = ["DmxModule", "DmxQuantizerCalibrationHyperparams", "DmxModuleQuantizerCalibrationHyperparams",
-           "DmxModuleSmoothQuantHyperparams", "Linear", "Conv1d", "Conv2d", "ResAdd", "ActActMatMul", "Softmax", "LayerNorm", "GELU", "ReLU", "SiLU", "QuickGELU", "Exp", "Mul", "RMSNorm",
+           "DmxModuleSmoothQuantHyperparams", "Linear", "Conv1d", "Conv2d", "ResAdd", "ActActMatMul", "Softmax", "LayerNorm", "GELU", "ReLU", "SiLU", "QuickGELU", "Exp", "Mul", "RMSNorm", "ApplyRotaryPosEmb",
            "MaxPool2d", "AvgPool2d", "Embedding", "DmxConfigRule", "configure_model", "fold_weights_and_biases"]
 
 
@@ -352,8 +352,14 @@ class DmxModule(torch.nn.Module):
         if not isinstance(self.approximator.function, NoApproximation):
             with torch.no_grad():
                 _approx = self.approximator_wrapper(inputs, args, kwargs, **self.approximator.function.wrapper_params)
-                self.approximation_error = _approx - _output.data
-                _output.data = _approx  # (no dtype alignment here, as in the reference: experimental.silu hands back float16)
+                if isinstance(_approx, tuple):  # modules that return several values (approximate.py:311-319)
+                    assert isinstance(_output, tuple), "module and its approximation should both return a tuple"
+                    self.approximation_error = [x - y.data for x, y in zip(_approx, _output)]
+                    for x, y in zip(_approx, _output):
+                        y.data = x
+                else:
+                    self.approximation_error = _approx - _output.data
+                    _output.data = _approx  # (no dtype alignment here, as in the reference: experimental.silu hands back float16)
         return _output
 
 
@@ -517,6 +523,30 @@ class Mul(DmxModule):
 
     def _forward(self, _input, multiplier):
         return _input * multiplier
+
+
+class ApplyRotaryPosEmb(DmxModule):
+    """custom_modules.py:142-194: rotary position embedding of q and k between four input casts and two output casts"""
+
+    def __init__(self):
+        torch.nn.Module.__init__(self)
+        self._dmx_init(input_names=("q_cast", "k_cast", "cos_cast", "sin_cast"))
+        self.output_casts = CastToDict(OrderedDict({"q_embed_cast": CastTo(), "k_embed_cast": CastTo()}))
+        self._mark_internal_casts()
+        self.functional_forward = self._rope
+
+    @staticmethod
+    def rotate_half(x):
+        x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+        return torch.cat((-x2, x1), dim=-1)
+
+    @classmethod
+    def _rope(cls, q, k, cos, sin, unsqueeze_dim=1):
+        cos, sin = cos.unsqueeze(unsqueeze_dim), sin.unsqueeze(unsqueeze_dim)
+        return (q * cos) + (cls.rotate_half(q) * sin), (k * cos) + (cls.rotate_half(k) * sin)
+
+    def _forward(self, q, k, cos, sin, unsqueeze_dim=1):
+        return self.approx_forward((q, k, cos, sin, unsqueeze_dim))
 
 
 class RMSNorm(DmxModule, torch.nn.RMSNorm):

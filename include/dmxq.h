@@ -225,6 +225,15 @@ int dmxq_softmax(const void* in, void* out, int dtype_in, int dtype_out, int64_t
 int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
                    const void* weight, const void* bias, int dtype_wb, float eps, void* stream);
 
+/* APPLY_LLAMA_ROPE: x_embed = (x * cos) + (rotate_half(x) * sin), evaluated in the tensor dtype like torch does (every
+ * product and the sum rounded to the dtype: bit-identical to torch's CPU result).  Replaces: modeling/nn/custom_modules.py:
+ * 142-172 ApplyRotaryPosEmbBase.forward for ONE of q / k (call it twice).  x, out: [B, n1, n2, D] contiguous, out != x;
+ * cos_tab / sin_tab: [B, n2, D] when broadcast_over_dim1 != 0 (unsqueeze_dim = 1: x = [B, heads, S, D]), else [B, n1, D]
+ * (unsqueeze_dim = 2: x = [B, S, heads, D]); all of dtype `dtype`.  DMXQ_ERR_UNSUPPORTED: D not a multiple of two 16-byte
+ * vectors, unaligned pointers, >= 2^31 elements (the caller keeps torch's own ops). */
+int dmxq_rope(const void* x, const void* cos_tab, const void* sin_tab, void* out, int dtype, int64_t B, int64_t n1, int64_t n2,
+              int64_t D, int broadcast_over_dim1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -391,3 +391,48 @@ def test_model_fold_through_multi_tensor_launches_equals_module_by_module(dmx, c
                 assert na == nb and bits_equal(pa.data, pb.data) == 0, (variant, na)
             assert bits_equal(a(x), b(x)) == 0 and bits_equal(b(x), want) == 0
         assert all(isinstance(mod.weight_cast.format, dmx.Same) for mod in b if isinstance(mod, dmx.nn.Linear))
+
+
+# ------------------------------------------------------------------------------------------------ APPLY_LLAMA_ROPE
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("unsqueeze_dim", [1, 2])
+def test_rope_equals_torch_bit_for_bit(dmx, cuda, dtype, unsqueeze_dim):
+    """custom_modules.py:142-172 `(x * cos) + (rotate_half(x) * sin)` runs in the tensor dtype (two products and a sum, each
+    rounded): the kernel reproduces the roundings, so the comparison with torch's CPU evaluation is BIT-EXACT.  Llama-3-8B
+    shapes (32 query heads, 8 KV heads, head_dim 128) and a small odd one; through ops.rope and through the module with
+    `APPLY_LLAMA_ROPE[dmxq]{}()`."""
+    B, S, D = 2, 96, 128
+    shapes = ((B, 32, S, D), (B, 8, S, D)) if unsqueeze_dim == 1 else ((B, S, 32, D), (B, S, 8, D))
+    q = (make("normal", shapes[0], seed=1) * 2).to(dtype)
+    k = (make("normal", shapes[1], seed=2) * 2).to(dtype)
+    ang = make("normal", (B, S, D), seed=3) * 3.0
+    cos, sin = torch.cos(ang).to(dtype), torch.sin(ang).to(dtype)
+    want_q, want_k = dmx.nn.ApplyRotaryPosEmb._rope(q, k, cos, sin, unsqueeze_dim)
+    got_q = dmx.ops.rope(q.to(cuda), cos.to(cuda), sin.to(cuda), unsqueeze_dim)
+    got_k = dmx.ops.rope(k.to(cuda), cos.to(cuda), sin.to(cuda), unsqueeze_dim)
+    assert bits_equal(got_q, want_q) == 0 and bits_equal(got_k, want_k) == 0
+    m = dmx.nn.ApplyRotaryPosEmb()
+    m.configure(dict(approximation_function="APPLY_LLAMA_ROPE[dmxq]{}()"))
+    with torch.no_grad():
+        yq, yk = m(q.to(cuda), k.to(cuda), cos.to(cuda), sin.to(cuda), unsqueeze_dim)
+    assert bits_equal(yq, want_q) == 0 and bits_equal(yk, want_k) == 0
+    # shapes the kernel does not take: the front end says so (None) instead of computing something else
+    assert dmx.ops.rope(q[..., :20].contiguous().to(cuda), cos[..., :20].contiguous().to(cuda), sin[..., :20].contiguous().to(cuda), unsqueeze_dim) is None
+    if dtype != torch.float32:
+        assert dmx.ops.rope(q.to(cuda), cos.float().to(cuda), sin.float().to(cuda), unsqueeze_dim) is None
+
+
+def test_rope_module_under_basic_rules(dmx, cuda):
+    """BASIC: four FLOAT16 input casts, two FLOAT16 output casts around the rotary embedding (reference __init__.py:456-468);
+    with the approximator NONE the module evaluates torch's own ops between this repo's casts."""
+    m = dmx.nn.ApplyRotaryPosEmb()
+    dmx.nn.configure_model(m, *dmx.config_rules.BASIC)
+    assert [repr(f) for f in m.input_formats] == ["FP[1|5|10,15](FN)"] * 4 and [repr(f) for f in m.output_formats] == ["FP[1|5|10,15](FN)"] * 2
+    q = (make("normal", (1, 4, 16, 32), seed=5) * 2).to(torch.bfloat16).to(cuda)
+    k = (make("normal", (1, 2, 16, 32), seed=6) * 2).to(torch.bfloat16).to(cuda)
+    cos, sin = torch.cos(make("normal", (1, 16, 32), seed=7)).to(torch.bfloat16).to(cuda), torch.sin(make("normal", (1, 16, 32), seed=7)).to(torch.bfloat16).to(cuda)
+    with torch.no_grad():
+        yq, yk = m(q, k, cos, sin)
+        f16 = dmx.CastTo(format=dmx.format.FLOAT16)
+        eq, ek = dmx.nn.ApplyRotaryPosEmb._rope(f16(q), f16(k), f16(cos), f16(sin), 1)
+    assert bits_equal(yq, f16(eq)) == 0 and bits_equal(yk, f16(ek)) == 0
