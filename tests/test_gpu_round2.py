@@ -118,7 +118,8 @@ def test_torch_ops_straight_through_backward(dmx, cuda):
     assert torch.equal(x2.grad, torch.full_like(x2, 3.0))
 
 
-def test_torch_compile_fullgraph_of_a_basic_linear(dmx, cuda):
+@pytest.mark.parametrize("backend", ["aot_eager", "inductor"])
+def test_torch_compile_fullgraph_of_a_basic_linear(dmx, cuda, backend):
     """the reference's export path traces its CastTo through custom ops (fx/transform.py:133-178); here the whole BASIC
     Linear forward (input BFP cast, fused weight path, bias cast, F.linear, FLOAT16 output cast) must trace as ONE graph
     through torch.ops.dmxq with fake tensors -- no graph break, no fallback -- and give the eager result."""
@@ -130,7 +131,7 @@ def test_torch_compile_fullgraph_of_a_basic_linear(dmx, cuda):
     x = make("heavy", (32, 256), seed=9, dtype=torch.bfloat16).clamp(-100, 100).to(cuda)
     with torch.no_grad():
         want = lin(x)
-        compiled = torch.compile(lin, fullgraph=True, backend="aot_eager")
+        compiled = torch.compile(lin, fullgraph=True, backend=backend)   # inductor: the custom ops stay opaque extern calls
         got = compiled(x)
         got2 = compiled(x + 1)   # a second call reuses the graph
     assert got.dtype == want.dtype and torch.equal(got, want)
