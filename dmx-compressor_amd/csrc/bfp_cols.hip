@@ -201,6 +201,47 @@ static int launch_cols(const void* in, void* out, int64_t outer, int64_t L, int6
 
 using namespace dmxq;
 
+// This file is compiled THREE times (build.py: -DDMXQ_EW_PART=1 / 2 / 3), one object per input dtype: the cross product of
+// 5 dtype pairs x 2 rounding builds x sym / asym x 5 block sizes x aligned / unaligned x fast paths was a 4-minute
+// translation unit, the longest of the library.  Without the macro everything is compiled into one object.
+#ifndef DMXQ_EW_PART
+#define DMXQ_EW_PART 0
+#endif
+#define DMXQ_CP(P_) (DMXQ_EW_PART == 0 || DMXQ_EW_PART == (P_))
+
+#define DMXQ_COLS_ARGS const void* in, void* out, int dtype_out, int64_t outer, int64_t L, int64_t inner, int64_t B, int wl, int rounding, \
+                       bool asym, uint64_t seed, bool unal, hipStream_t s
+#define DMXQ_DT(I_, O_)                                                                                           \
+  if (dtype_out == O_) {                                                                                          \
+    if (rounding == DMXQ_ROUND_NEAREST && wl <= 20)                                                               \
+      return asym ? launch_cols<I_, O_, DMXQ_ROUND_NEAREST, true>(in, out, outer, L, inner, B, wl, rounding, seed, unal, s)  \
+                  : launch_cols<I_, O_, DMXQ_ROUND_NEAREST, false>(in, out, outer, L, inner, B, wl, rounding, seed, unal, s); \
+    return asym ? launch_cols<I_, O_, kRuntimeRounding, true>(in, out, outer, L, inner, B, wl, rounding, seed, unal, s)     \
+                : launch_cols<I_, O_, kRuntimeRounding, false>(in, out, outer, L, inner, B, wl, rounding, seed, unal, s);   \
+  }
+int dmxq_cols_from_bf16(DMXQ_COLS_ARGS);
+int dmxq_cols_from_f16(DMXQ_COLS_ARGS);
+int dmxq_cols_from_f32(DMXQ_COLS_ARGS);
+#if DMXQ_CP(1)
+int dmxq_cols_from_bf16(DMXQ_COLS_ARGS) {
+  DMXQ_DT(DMXQ_BF16, DMXQ_BF16)
+  DMXQ_DT(DMXQ_BF16, DMXQ_F32)
+  return DMXQ_ERR_UNSUPPORTED;
+}
+#endif
+#if DMXQ_CP(2)
+int dmxq_cols_from_f16(DMXQ_COLS_ARGS) {
+  DMXQ_DT(DMXQ_F16, DMXQ_F16)
+  DMXQ_DT(DMXQ_F16, DMXQ_F32)
+  return DMXQ_ERR_UNSUPPORTED;
+}
+#endif
+#if DMXQ_CP(3)
+int dmxq_cols_from_f32(DMXQ_COLS_ARGS) {
+  DMXQ_DT(DMXQ_F32, DMXQ_F32)
+  return DMXQ_ERR_UNSUPPORTED;
+}
+
 // internal entry used by dmxq_bfp_qdq (bfp.hip): returns DMXQ_ERR_UNSUPPORTED when this path does not apply, in
 // which case the caller falls back to the generic kernel.
 extern "C" int dmxq_internal_bfp_cols(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L,
@@ -222,19 +263,10 @@ extern "C" int dmxq_internal_bfp_cols(const void* in, void* out, int dtype_in, i
   while (B > 8 && L <= B / 2) B /= 2;
   hipStream_t s = (hipStream_t)stream;
   const bool asym = !symmetric;
-#define DMXQ_DT(I_, O_)                                                                                           \
-  if (dtype_in == I_ && dtype_out == O_) {                                                                        \
-    if (rounding == DMXQ_ROUND_NEAREST && wl <= 20)                                                               \
-      return asym ? launch_cols<I_, O_, DMXQ_ROUND_NEAREST, true>(in, out, outer, L, inner, B, wl, rounding, seed, unal, s)  \
-                  : launch_cols<I_, O_, DMXQ_ROUND_NEAREST, false>(in, out, outer, L, inner, B, wl, rounding, seed, unal, s); \
-    return asym ? launch_cols<I_, O_, kRuntimeRounding, true>(in, out, outer, L, inner, B, wl, rounding, seed, unal, s)     \
-                : launch_cols<I_, O_, kRuntimeRounding, false>(in, out, outer, L, inner, B, wl, rounding, seed, unal, s);   \
-  }
-  DMXQ_DT(DMXQ_BF16, DMXQ_BF16)
-  DMXQ_DT(DMXQ_F16, DMXQ_F16)
-  DMXQ_DT(DMXQ_F32, DMXQ_F32)
-  DMXQ_DT(DMXQ_BF16, DMXQ_F32)
-  DMXQ_DT(DMXQ_F16, DMXQ_F32)
-#undef DMXQ_DT
+  if (dtype_in == DMXQ_BF16) return dmxq_cols_from_bf16(in, out, dtype_out, outer, L, inner, B, wl, rounding, asym, seed, unal, s);
+  if (dtype_in == DMXQ_F16) return dmxq_cols_from_f16(in, out, dtype_out, outer, L, inner, B, wl, rounding, asym, seed, unal, s);
+  if (dtype_in == DMXQ_F32) return dmxq_cols_from_f32(in, out, dtype_out, outer, L, inner, B, wl, rounding, asym, seed, unal, s);
   return DMXQ_ERR_UNSUPPORTED;
 }
+#endif
+#undef DMXQ_DT

@@ -475,6 +475,15 @@ static inline ChannelMap make_channel_map(int64_t C, int64_t inner, int64_t grou
 
 using namespace dmxq;
 
+// This file is compiled THREE times (build.py: -DDMXQ_EW_PART=1 / 2 / 3), one object per group of entry points, so that the
+// template cross products (7 dtype pairs x op flavours x tile geometries) of the float, fixed and scaling ops compile in
+// parallel instead of forming one 3.5-minute translation unit.  Without the macro everything is compiled into one object.
+#ifndef DMXQ_EW_PART
+#define DMXQ_EW_PART 0
+#endif
+#define DMXQ_EW(P_) (DMXQ_EW_PART == 0 || DMXQ_EW_PART == (P_))
+
+#if DMXQ_EW(1)
 extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int man_bits,
                               int exp_bits, int exp_bias, int flush_subnormal, int unsigned_abs, int rounding,
                               uint64_t seed, void* stream) {
@@ -489,6 +498,8 @@ extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype
   return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<kRuntimeRounding>{f, make_float_fast(f.man, f.exp_bits, f.bias)}, s);
 }
 
+#endif  // part 1a
+#if DMXQ_EW(2)
 extern "C" int dmxq_fixed_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t C,
                               int64_t inner, int precision, int fraction, int clamp, int symmetric, int rounding,
                               const float* scale, const int64_t* zero_point, int64_t group_size, uint64_t seed,
@@ -535,6 +546,8 @@ extern "C" int dmxq_fixed_qdq(const void* in, void* out, int dtype_in, int dtype
 #undef DMXQ_FIX
 }
 
+#endif  // part 2
+#if DMXQ_EW(3)
 extern "C" int dmxq_scale_channels(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t C,
                                    int64_t inner, const float* scale, int divide, void* stream) {
   if (!valid_dtype(dtype_in) || !valid_dtype(dtype_out) || outer < 0 || C < 0 || inner < 0) return DMXQ_ERR_BAD_ARG;
@@ -561,6 +574,8 @@ extern "C" int dmxq_scale_channels(const void* in, void* out, int dtype_in, int 
 #undef DMXQ_SCALE
 }
 
+#endif  // part 3
+#if DMXQ_EW(1)
 extern "C" int dmxq_gelu(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int tanh_form,
                          void* stream) {
   if (!valid_dtype(dtype_in) || !valid_dtype(dtype_out) || n < 0) return DMXQ_ERR_BAD_ARG;
@@ -604,3 +619,4 @@ extern "C" const char* dmxq_status_string(int status) {
 }
 
 extern "C" int dmxq_abi_version(void) { return 2; }
+#endif  // part 1b
