@@ -16,6 +16,24 @@
 namespace dmxq {
 
 constexpr int kRowsNtLoad = 1, kRowsNtStore = 2;
+constexpr int kRowsSc1Store = 4, kRowsSc0Store = 8;  // experiment flavours (tools/tune_bfp): write-through / sc0 stores via inline asm
+
+// 16-byte stores with an explicit cache policy (KIND 2: sc1, 3: sc0); everything else through store_out
+template <int DTO, int EPL, int KIND>
+__device__ __forceinline__ void store_out_kind(void* p, const OutVec<DTO, EPL>& o) {
+  constexpr int W = OutVec<DTO, EPL>::kWords;
+  if constexpr (W % 4 == 0 && KIND >= 2) {
+#pragma unroll
+    for (int k = 0; k < W; k += 4) {
+      const u32x4 v = {o.w[k], o.w[k + 1], o.w[k + 2], o.w[k + 3]};
+      u32x4* dst = (u32x4*)p + k / 4;
+      if (KIND == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");
+      else asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(dst), "v"(v) : "memory");
+    }
+  } else {
+    store_out<DTO, EPL, KIND == 1>(p, o);
+  }
+}
 
 // one 16-byte input vector -> its packed outputs, given the block's max bits.  PATH_FAST selects the magic-add
 // arithmetic (nearest-even only); `vi` = index of the input vector (numbers the random draws).
@@ -71,6 +89,7 @@ __device__ __forceinline__ void bfp_rows_tile(const void* __restrict__ in, void*
                                               int64_t tile, int lpb, int wl, int rounding, bool stoch, uint64_t seed) {
   static_assert(UNROLL % GROUP == 0, "GROUP must divide UNROLL");
   constexpr bool NTS = (MODE & kRowsNtStore) != 0;
+  constexpr int SK = (MODE & kRowsSc1Store) ? 2 : ((MODE & kRowsSc0Store) ? 3 : (NTS ? 1 : 0));
   constexpr int64_t TILE = (int64_t)THREADS * UNROLL;
   constexpr int EPL = IVB / Elem<DTI>::bytes;
   constexpr int OVB = EPL * Elem<DTO>::bytes;  // output bytes per input vector
@@ -119,7 +138,7 @@ __device__ __forceinline__ void bfp_rows_tile(const void* __restrict__ in, void*
       }
       __builtin_amdgcn_sched_barrier(0);  // ... and the group's stores go out as one burst
 #pragma unroll
-      for (int u = 0; u < GROUP; u++) store_out<DTO, EPL, NTS>(dst + (g + u) * (THREADS * OVB) + lane_out, o[u]);
+      for (int u = 0; u < GROUP; u++) store_out_kind<DTO, EPL, SK>(dst + (g + u) * (THREADS * OVB) + lane_out, o[u]);
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {  // last, partial tile: a block never straddles the predicate (n_vec % lpb == 0, lpb | THREADS)

@@ -60,11 +60,11 @@ int main(int argc, char** argv) {
 #define ADD_COPY(U, M, T, GRID) vs.push_back({"copy U" #U " M" #M " T" #T " G" #GRID, [=](const void* i, void* o, hipStream_t q) { \
     int g = (GRID) > 0 ? (GRID) : (int)((n_vec + (int64_t)T * U - 1) / ((int64_t)T * U)); \
     hipLaunchKernelGGL((copy_kernel<U, M, T>), dim3(g), dim3(T), 0, q, i, o, n_vec); }, {}})
-  // G0 = exact grid.  M bits: 1 nt-load, 2 nt-store (copy: 4 = workgroup-contiguous tiles; bfp is always tiled)
-  ADD_COPY(16, 7, 512, 0); ADD_COPY(4, 7, 256, 0); ADD_COPY(2, 7, 512, 0);
-  ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPG(8, 3, 512, 0, 2, 8); ADD_BFPG(4, 3, 512, 0, 2, 4); ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPG(1, 3, 512, 0, 2, 1);
-  ADD_BFPG(16, 3, 256, 0, 2, 16); ADD_BFPG(8, 3, 256, 0, 2, 8); ADD_BFPG(4, 3, 256, 0, 2, 4); ADD_BFPG(2, 3, 256, 0, 2, 2); ADD_BFPG(1, 3, 256, 0, 2, 1);
-  ADD_BFPG(2, 3, 128, 0, 2, 2); ADD_BFPG(1, 3, 128, 0, 2, 1); ADD_BFPG(3, 3, 512, 0, 2, 3); ADD_BFPG(6, 3, 512, 0, 2, 6); ADD_BFPG(12, 3, 512, 0, 2, 12);
+  // G0 = exact grid.  M bits: 1 nt-load, 2 nt-store, 4 sc1-store, 8 sc0-store (copy: 4 = workgroup-contiguous tiles; bfp is always tiled)
+  ADD_COPY(16, 7, 512, 0);
+  ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPG(16, 5, 512, 0, 2, 16); ADD_BFPG(16, 9, 512, 0, 2, 16); ADD_BFPG(16, 1, 512, 0, 2, 16);
+  ADD_BFPG(16, 3, 256, 0, 2, 16); ADD_BFPG(16, 5, 256, 0, 2, 16); ADD_BFPG(16, 9, 256, 0, 2, 16);
+  ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPG(2, 5, 512, 0, 2, 2); ADD_BFPG(2, 9, 512, 0, 2, 2);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto& v : vs) for (int i = 0; i < 10; i++) v.run(in[i % NBUF], out[i % NBUF], st);
   CK(hipStreamSynchronize(st));
