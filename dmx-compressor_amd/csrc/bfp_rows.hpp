@@ -84,9 +84,12 @@ __device__ __forceinline__ u32x4 load_rawv(const void* p, uint32_t off) {
 
 // ONE tile (THREADS*UNROLL lane-vectors) of a flat tensor of n_vec vectors: `tile` is the tile index inside that tensor.
 // Shared by the single-tensor kernel below and the multi-tensor kernel of bfp.hip.
-template <int DTI, int DTO, int RND, bool ASYM, int UNROLL, int MODE, int THREADS, int FAST, int GROUP, int IVB>
+// LPBC: lanes per block as a compile-time constant (0 = the runtime value `lpb_rt`): the DPP reduction of the block maximum
+// then has no scalar branches (six `s_cbranch` + `s_nop` per vector otherwise, which also fence the VALU scheduling).
+template <int DTI, int DTO, int RND, bool ASYM, int UNROLL, int MODE, int THREADS, int FAST, int GROUP, int IVB, int LPBC = 0>
 __device__ __forceinline__ void bfp_rows_tile(const void* __restrict__ in, void* __restrict__ out, int64_t n_vec,
-                                              int64_t tile, int lpb, int wl, int rounding, bool stoch, uint64_t seed) {
+                                              int64_t tile, int lpb_rt, int wl, int rounding, bool stoch, uint64_t seed) {
+  const int lpb = LPBC > 0 ? LPBC : lpb_rt;
   static_assert(UNROLL % GROUP == 0, "GROUP must divide UNROLL");
   constexpr bool NTS = (MODE & kRowsNtStore) != 0;
   constexpr int SK = (MODE & kRowsSc1Store) ? 2 : ((MODE & kRowsSc0Store) ? 3 : (NTS ? 1 : 0));
@@ -155,7 +158,7 @@ __device__ __forceinline__ void bfp_rows_tile(const void* __restrict__ in, void*
 }
 
 template <int DTI, int DTO, int RND, bool ASYM, int UNROLL, int MODE, int THREADS, int FAST = 0, int GROUP = UNROLL,
-          int IVB = 16>
+          int IVB = 16, int LPBC = 0>
 __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                           int64_t n_vec, int lpb_arg /*lanes per block*/, int wl,
                                                           int rounding, uint64_t seed) {
@@ -163,8 +166,25 @@ __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restric
   const bool stoch = (RND == kRuntimeRounding) && rounding == DMXQ_ROUND_STOCHASTIC;
   const int lpb = __builtin_amdgcn_readfirstlane(lpb_arg);
   const int64_t n_tiles = (n_vec + TILE - 1) / TILE;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)
-    bfp_rows_tile<DTI, DTO, RND, ASYM, UNROLL, MODE, THREADS, FAST, GROUP, IVB>(in, out, n_vec, tile, lpb, wl, rounding, stoch, seed);
+#define DMXQ_TILE_LOOP(L_)                                                                                          \
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)                                                \
+    bfp_rows_tile<DTI, DTO, RND, ASYM, UNROLL, MODE, THREADS, FAST, GROUP, IVB, L_>(in, out, n_vec, tile, lpb, wl, rounding, stoch, seed)
+  // One-round geometries (UNROLL >= 4) on the magic-add paths: the lanes-per-block of the usual block sizes as a compile-time
+  // constant, chosen ONCE per launch -- with a runtime value every vector's DPP reduction is a chain of six scalar
+  // branches, which cost 6.7 % of the 64 MiB headline launch (tools/tune_bfp: 11.71 -> 10.93 us).  Multi-round 512x2
+  // tiles measured no difference and keep the single runtime form.
+  if constexpr (LPBC == 0 && UNROLL >= 4 && (FAST == 1 || FAST == 2)) {
+    switch (lpb) {
+      case 2: DMXQ_TILE_LOOP(2); break;
+      case 4: DMXQ_TILE_LOOP(4); break;
+      case 8: DMXQ_TILE_LOOP(8); break;
+      case 16: DMXQ_TILE_LOOP(16); break;
+      default: DMXQ_TILE_LOOP(0); break;
+    }
+  } else {
+    DMXQ_TILE_LOOP(LPBC);
+  }
+#undef DMXQ_TILE_LOOP
 }
 
 // Multi-tensor form: up to kMultiMax flat tensors in ONE launch (small weights are launch-bound one by one: an empty

@@ -53,11 +53,13 @@ struct HnArgs {
 // BFP = false: mask-and-multiply only (y = x * mask, sparse.py:300) -- the typed fast path of dmxq_nm_mask for whole rows
 // of 16-byte vectors (compile-time dtypes: every load of a lane is in flight before the first conversion; the generic
 // kernel of nm_mask.hip switches on runtime dtypes around each access and reached 48 % of roofline with a bf16 score).
-template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP = true>
-__global__ __launch_bounds__(kThreads) void hypernet_rows_kernel(HnArgs a) {
+// LPBC: lanes per BFP block as a compile-time constant (0 = runtime a.lpb), see bfp_rows.hpp: the DPP block maximum is then
+// free of scalar branches.
+template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP, int LPBC>
+__device__ __forceinline__ void hypernet_rows_body(const HnArgs& a) {
   // T1: dtype after the mask multiply = torch promotion of (w, score); without a mask it stays the weight dtype
   constexpr int T1 = (M == 0) ? DTW : ((DTW == DMXQ_F32 || DTS == DMXQ_F32 || DTW != DTS) ? DMXQ_F32 : DTW);
-  const int lpb = __builtin_amdgcn_readfirstlane(a.lpb);
+  const int lpb = LPBC > 0 ? LPBC : __builtin_amdgcn_readfirstlane(a.lpb);
   constexpr int UN = 4;  // units in flight per lane: all their loads are issued before the first one is ranked
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   for (int64_t u0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; u0 < a.n_units; u0 += UN * stride) {
@@ -138,6 +140,13 @@ __global__ __launch_bounds__(kThreads) void hypernet_rows_kernel(HnArgs a) {
     store_vec<DTO, 8, true>(a.out, e0, y);
     }
   }
+}
+
+template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP = true>
+__global__ __launch_bounds__(kThreads) void hypernet_rows_kernel(HnArgs a) {
+  // BFP16_64 (8 lanes per block: the BASIC rule's weight format) gets the branch-free form; other block sizes the runtime one
+  if (BFP && __builtin_amdgcn_readfirstlane(a.lpb) == 8) hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 8>(a);
+  else hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 0>(a);
 }
 
 template <int DTW, int DTS, int DTO>

@@ -55,6 +55,9 @@ int main(int argc, char** argv) {
 #define ADD_BFPG(U, M, T, GRID, F, GR) vs.push_back({"bfp  U" #U " M" #M " T" #T " G" #GRID " F" #F " grp" #GR, [=](const void* i, void* o, hipStream_t q) { \
     int g = (GRID) > 0 ? (GRID) : (int)((n_vec + (int64_t)T * U - 1) / ((int64_t)T * U)); \
     hipLaunchKernelGGL((bfp_rows_kernel<DMXQ_BF16, DMXQ_BF16, DMXQ_ROUND_NEAREST, false, U, M, T, F, GR>), dim3(g), dim3(T), 0, q, i, o, n_vec, 2, 8, 2, 0ull); }, {}})
+#define ADD_BFPL(U, M, T, GRID, F, GR, LPBC) vs.push_back({"bfp  U" #U " M" #M " T" #T " G" #GRID " F" #F " grp" #GR " lpbc" #LPBC, [=](const void* i, void* o, hipStream_t q) { \
+    int g = (GRID) > 0 ? (GRID) : (int)((n_vec + (int64_t)T * U - 1) / ((int64_t)T * U)); \
+    hipLaunchKernelGGL((bfp_rows_kernel<DMXQ_BF16, DMXQ_BF16, DMXQ_ROUND_NEAREST, false, U, M, T, F, GR, 16, LPBC>), dim3(g), dim3(T), 0, q, i, o, n_vec, 2, 8, 2, 0ull); }, {}})
 #define ADD_BFPF(U, M, T, GRID, F) ADD_BFPG(U, M, T, GRID, F, U)
 #define ADD_BFP(U, M, T, GRID) ADD_BFPF(U, M, T, GRID, 0)
 #define ADD_COPY(U, M, T, GRID) vs.push_back({"copy U" #U " M" #M " T" #T " G" #GRID, [=](const void* i, void* o, hipStream_t q) { \
@@ -62,9 +65,8 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL((copy_kernel<U, M, T>), dim3(g), dim3(T), 0, q, i, o, n_vec); }, {}})
   // G0 = exact grid.  M bits: 1 nt-load, 2 nt-store, 4 sc1-store, 8 sc0-store (copy: 4 = workgroup-contiguous tiles; bfp is always tiled)
   ADD_COPY(16, 7, 512, 0);
-  ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPG(16, 5, 512, 0, 2, 16); ADD_BFPG(16, 9, 512, 0, 2, 16); ADD_BFPG(16, 1, 512, 0, 2, 16);
-  ADD_BFPG(16, 3, 256, 0, 2, 16); ADD_BFPG(16, 5, 256, 0, 2, 16); ADD_BFPG(16, 9, 256, 0, 2, 16);
-  ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPG(2, 5, 512, 0, 2, 2); ADD_BFPG(2, 9, 512, 0, 2, 2);
+  ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPL(16, 3, 512, 0, 2, 16, 2); ADD_BFPG(16, 3, 256, 0, 2, 16); ADD_BFPL(16, 3, 256, 0, 2, 16, 2);
+  ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPL(2, 3, 512, 0, 2, 2, 2); ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPL(16, 3, 512, 0, 2, 16, 2);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto& v : vs) for (int i = 0; i < 10; i++) v.run(in[i % NBUF], out[i % NBUF], st);
   CK(hipStreamSynchronize(st));
