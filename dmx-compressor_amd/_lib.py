@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdmxq.so")
+LIB_PATH = os.environ.get("DMXQ_LIB_PATH") or os.path.join(_HERE, "lib", "libdmxq.so")  # (override: A/B runs of two builds)
 
 F32, F16, BF16 = 0, 1, 2
 ROUND_UP, ROUND_DOWN, ROUND_NEAREST, ROUND_STOCHASTIC = 0, 1, 2, 3

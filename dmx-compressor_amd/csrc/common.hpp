@@ -239,10 +239,18 @@ __device__ __forceinline__ float group_max(float m, int lanes) {
 // same reduction on unsigned integers (abs-value bit patterns order like the magnitudes they encode, and a
 // NaN pattern is the largest of all, which reproduces torch.max's NaN propagation in get_max_entry)
 __device__ __forceinline__ uint32_t group_max_u32(uint32_t m, int lanes) {
-  if (lanes >= 2) m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, m, 0xB1, 0xF, 0xF, false));
-  if (lanes >= 4) m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, m, 0x4E, 0xF, 0xF, false));
-  if (lanes >= 8) m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, m, 0x141, 0xF, 0xF, false));
-  if (lanes >= 16) m = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, m, 0x140, 0xF, 0xF, false));
+  // `lanes` is wave-uniform but only known at run time on most paths.  The four DPP stages are executed UNCONDITIONALLY and
+  // each result is kept or dropped with a select on a scalar condition: 8 VALU operations and no control flow.  (As a chain
+  // of `if (lanes >= k)` every vector paid up to six scalar branches, which also fence the VALU scheduling around them:
+  // 6.7 % of the 64 MiB headline launch, tools/tune_bfp.)  A compile-time `lanes` folds the selects away.
+  const uint32_t a = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, m, 0xB1, 0xF, 0xF, false));   // quad_perm 1,0,3,2
+  m = lanes >= 2 ? a : m;
+  const uint32_t b = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, m, 0x4E, 0xF, 0xF, false));   // quad_perm 2,3,0,1
+  m = lanes >= 4 ? b : m;
+  const uint32_t c = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, m, 0x141, 0xF, 0xF, false));  // row_half_mirror
+  m = lanes >= 8 ? c : m;
+  const uint32_t d = max(m, (uint32_t)__builtin_amdgcn_update_dpp(0, m, 0x140, 0xF, 0xF, false));  // row_mirror
+  m = lanes >= 16 ? d : m;
   if (lanes >= 32) m = max(m, (uint32_t)__shfl_xor((int)m, 16));
   if (lanes >= 64) m = max(m, (uint32_t)__shfl_xor((int)m, 32));
   return m;
