@@ -33,27 +33,7 @@ namespace dmxq {
 
 constexpr int kRowsMaxGrid = 1 << 20;
 
-// Tile geometry of the flat-stream kernel for a tensor of n_vec lane-vectors: workgroup-contiguous tiles of
-// threads x unroll vectors.  Measured on 4096-column bf16 tensors of 256 .. 16384 rows with tools/tune_bfp
-// (profiles/r02_tune_bfp_sweep.txt), 256 CUs:
-//   * up to 32 MiB of input the best shape keeps the WHOLE tensor in flight in one round of <= 2 workgroups per CU
-//     (every CU reads its share, computes, writes it: the phases stay in lockstep and HBM sees pure read bursts
-//     followed by pure write bursts): 512x1 (<= 4 MiB), 128x2 (<= 12 MiB: many small workgroups ramp fastest),
-//     512x4 (<= 16 MiB), 512x6 (<= 24 MiB), 512x16 (<= 32 MiB: the 4096x4096 bf16 headline tensor, 256 tiles);
-//   * beyond that several rounds per CU are needed anyway, and small 512x2 tiles (4 resident workgroups per CU that
-//     desynchronise, so reads of one overlap writes of another) win: 77-79 % of 8 TB/s vs 68-71 % for 512x16.
-struct RowsPlan { int id, threads, unroll; int64_t tiles; };
-static inline RowsPlan rows_plan(int64_t n_vec, bool allow_big) {
-  auto mk = [&](int id, int t, int u) { return RowsPlan{id, t, u, (n_vec + (int64_t)t * u - 1) / ((int64_t)t * u)}; };
-  if (n_vec <= ((int64_t)1 << 18)) return mk(0, 512, 1);
-  if (n_vec <= ((int64_t)3 << 18)) return mk(1, 128, 2);
-  if (allow_big) {  // (the any-rounding build would spill at many vectors per lane: it goes straight to 512x2)
-    if (n_vec <= ((int64_t)1 << 20)) return mk(2, 512, 4);
-    if (n_vec <= ((int64_t)3 << 19)) return mk(3, 512, 6);
-    if (n_vec <= ((int64_t)1 << 21)) return mk(4, 512, 16);
-  }
-  return mk(5, 512, 2);
-}
+// (tile geometry: rows_plan, common.hpp)
 
 // ---------------------------------------------------------------------------------------------------------
 // Generic fallback: one lane per block; two strided passes.  Correct for every (outer, L, inner, B) incl.

@@ -484,6 +484,79 @@ using namespace dmxq;
 #define DMXQ_EW(P_) (DMXQ_EW_PART == 0 || DMXQ_EW_PART == (P_))
 
 #if DMXQ_EW(1)
+// ------------------------------------------------------------------------------------------------- FLOAT16-style casts of bf16 tensors
+// The most frequent cast of the BASIC rule set is FP[1|5|10,15](FN) ("FLOAT16") applied to activations that ARE bf16
+// (src/dmx/compressor/__init__.py:306-469: every output / elementwise cast).  A bf16 value has 7 mantissa bits, so keeping
+// `man >= 7` of them with nearest rounding changes NOTHING in the format's normal range (round_bitwise adds less than the
+// dropped field's weight to all-zero dropped bits); what is left of quant_cpu.cpp:359-402 + bit_helper.cpp:4-22 is the range
+// handling, and that works on the raw 16-bit words, two per dword, without widening to fp32:
+//   exponent below the format's smallest normal (flush_subnormal = 1) -> +0.0;
+//   exponent above its largest                                        -> sign | max_val, which rounds (the `.to(bf16)` of
+//     cast.py:306) to the bf16 word (max_e + 1) << 7 when man > 7 -- i.e. min_u16(|x| bits, limit) -- Inf and NaN included
+//     (the reference reserves no Inf / NaN codes: they saturate too).
+// 3.5 VALU operations per element instead of ~18, so the op streams like a copy; tile geometry by size as for BFP (rows_plan).
+struct Range16 { uint32_t limit2, minb2; };  // both halves of a dword: clamp limit and smallest-normal threshold (bf16 bit patterns)
+__device__ __forceinline__ uint32_t range16_word(uint32_t w, const Range16& r) {
+  const u16x2 a = __builtin_bit_cast(u16x2, w & 0x7FFF7FFFu);
+  const u16x2 cl = __builtin_elementwise_min(a, __builtin_bit_cast(u16x2, r.limit2));
+  const uint32_t res = (w & 0x80008000u) | __builtin_bit_cast(uint32_t, cl);
+  // per half: keep iff |x| bits >= minb (saturating subtract -> 0 / non-zero -> 0 / 0xFFFF)
+  const u16x2 d = __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(a, (u16x2){1, 1}), __builtin_bit_cast(u16x2, r.minb2));
+  const u16x2 keep = __builtin_elementwise_min(d, (u16x2){1, 1}) * (u16x2){0xFFFF, 0xFFFF};
+  return res & __builtin_bit_cast(uint32_t, keep);
+}
+template <int T, int U>
+__global__ __launch_bounds__(T) void float_range_bf16_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t n_vec, Range16 r) {
+  constexpr int64_t TILE = (int64_t)T * U;
+  const int64_t n_tiles = (n_vec + TILE - 1) / TILE;
+  const uint32_t lane = threadIdx.x * 16u;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // workgroup-uniform tile bases + 32-bit lane offsets, no predicates on full tiles (the schedule of bfp_rows.hpp)
+    const char* src = (const char*)in + tile * (TILE * 16);
+    char* dst = (char*)out + tile * (TILE * 16);
+    if ((tile + 1) * TILE <= n_vec) {
+      u32x4 raw[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) raw[u] = load_raw16<true>(src + u * (T * 16), lane);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) raw[u][j] = range16_word(raw[u][j], r);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; u++) __builtin_nontemporal_store(raw[u], (u32x4*)(dst + u * (T * 16) + lane));
+    } else {
+      for (int u = 0; u < U; u++) {
+        const int64_t v = tile * TILE + (int64_t)u * T + threadIdx.x;
+        if (v < n_vec) {
+          u32x4 w = load_raw16<true>(src + u * (T * 16), lane);
+#pragma unroll
+          for (int j = 0; j < 4; j++) w[j] = range16_word(w[j], r);
+          __builtin_nontemporal_store(w, (u32x4*)(dst + u * (T * 16) + lane));
+        }
+      }
+    }
+  }
+}
+
+static int launch_float_range_bf16(const void* in, void* out, int64_t n_vec, const Range16& r, hipStream_t s) {
+  const RowsPlan pl = rows_plan(n_vec, true);
+  const unsigned grid = (unsigned)(pl.tiles < (1 << 20) ? pl.tiles : (1 << 20));
+#define DMXQ_RG(T_, U_) DMXQ_LAUNCH((float_range_bf16_kernel<T_, U_>), dim3(grid), dim3(T_), 0, s, in, out, n_vec, r)
+  switch (pl.id) {
+    case 0: DMXQ_RG(512, 1); break;
+    case 1: DMXQ_RG(128, 2); break;
+    case 2: DMXQ_RG(512, 4); break;
+    case 3: DMXQ_RG(512, 6); break;
+    case 4: DMXQ_RG(512, 16); break;
+    default: DMXQ_RG(512, 2); break;
+  }
+#undef DMXQ_RG
+  return launch_status();
+}
+
 extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int man_bits,
                               int exp_bits, int exp_bias, int flush_subnormal, int unsigned_abs, int rounding,
                               uint64_t seed, void* stream) {
@@ -494,6 +567,20 @@ extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype
   if (!in || !out) return DMXQ_ERR_BAD_ARG;
   const FloatFmt f{man_bits, exp_bits, exp_bias, flush_subnormal ? 1 : 0, unsigned_abs ? 1 : 0, rounding, seed};
   hipStream_t s = (hipStream_t)stream;
+  // bf16 -> bf16, nearest, at least bf16's 7 mantissa bits kept, subnormals flushed, signed: the packed range-only kernel
+  {
+    const int min_exp = -(exp_bias - 1), max_e = (1 << (exp_bits - 1)) + 127;
+    if (dtype_in == DMXQ_BF16 && dtype_out == DMXQ_BF16 && rounding == DMXQ_ROUND_NEAREST && man_bits >= 7 && flush_subnormal &&
+        !unsigned_abs && n % 8 == 0 && aligned16(in) && aligned16(out) && min_exp >= -126 && min_exp <= 127) {
+      // |x| bits of every value whose exponent field exceeds max_e are replaced by bf16(max_val): (max_e + 1) << 7 when man > 7
+      // (max_val = 2^(max_e-127) (2 - 2^-man) rounds up), (max_e << 7) | 0x7F when man == 7; max_e = 255: no limit at all
+      const uint32_t limit = max_e >= 255 ? 0xFFFFu : (man_bits > 7 ? (uint32_t)(max_e + 1) << 7 : ((uint32_t)max_e << 7) | 0x7Fu);
+      const uint32_t minb = (uint32_t)(127 + min_exp) << 7;   // bf16 bits of 2^min_exp: below it the value is flushed to +0
+      // keep iff a >= minb  <=>  sat(sat(a + 1) - minb) != 0
+      const Range16 r{limit | (limit << 16), minb | (minb << 16)};
+      return launch_float_range_bf16(in, out, n / 8, r, s);
+    }
+  }
   if (rounding == DMXQ_ROUND_NEAREST) return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<DMXQ_ROUND_NEAREST>{f, make_float_fast(f.man, f.exp_bits, f.bias)}, s);
   return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<kRuntimeRounding>{f, make_float_fast(f.man, f.exp_bits, f.bias)}, s);
 }
