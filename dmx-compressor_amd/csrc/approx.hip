@@ -149,6 +149,15 @@ template <int DT, int EPL>
 __device__ __forceinline__ RowVec<DT, EPL> row_load(const void* p, int64_t e) {
   RowVec<DT, EPL> r;
   const char* a = (const char*)p + e * Elem<DT>::bytes;
+  // non-temporal: every row is read once and written once (weight / bias vectors go through row_load_keep)
+  if (RowVec<DT, EPL>::kWords == 4) { const u32x4 t = __builtin_nontemporal_load((const u32x4*)a); r.w[0] = t.x; r.w[1] = t.y; r.w[2] = t.z; r.w[3] = t.w; }
+  else { const u32x2 t = __builtin_nontemporal_load((const u32x2*)a); r.w[0] = t.x; r.w[1] = t.y; }
+  return r;
+}
+template <int DT, int EPL>
+__device__ __forceinline__ RowVec<DT, EPL> row_load_keep(const void* p, int64_t e) {  // re-used data (weight, bias): cached
+  RowVec<DT, EPL> r;
+  const char* a = (const char*)p + e * Elem<DT>::bytes;
   if (RowVec<DT, EPL>::kWords == 4) { const u32x4 t = *(const u32x4*)a; r.w[0] = t.x; r.w[1] = t.y; r.w[2] = t.z; r.w[3] = t.w; }
   else { const u32x2 t = *(const u32x2*)a; r.w[0] = t.x; r.w[1] = t.y; }
   return r;
@@ -165,9 +174,9 @@ __device__ __forceinline__ void row_widen(const RowVec<DT, EPL>& r, float (&x)[E
 template <int DT, int EPL>
 __device__ __forceinline__ void row_store(void* p, int64_t e, const float (&y)[EPL]) {
   char* a = (char*)p + e * Elem<DT>::bytes;
-  if (DT == DMXQ_F32) *(f32x4*)a = f32x4{y[0], y[1], y[2], y[3]};
-  else if (EPL == 8) *(u32x4*)a = u32x4{pack2<DT>(y[0], y[1]), pack2<DT>(y[2], y[3]), pack2<DT>(y[4], y[5]), pack2<DT>(y[6], y[7])};
-  else *(u32x2*)a = u32x2{pack2<DT>(y[0], y[1]), pack2<DT>(y[2], y[3])};
+  if (DT == DMXQ_F32) __builtin_nontemporal_store(f32x4{y[0], y[1], y[2], y[3]}, (f32x4*)a);
+  else if (EPL == 8) __builtin_nontemporal_store(u32x4{pack2<DT>(y[0], y[1]), pack2<DT>(y[2], y[3]), pack2<DT>(y[4], y[5]), pack2<DT>(y[6], y[7])}, (u32x4*)a);
+  else __builtin_nontemporal_store(u32x2{pack2<DT>(y[0], y[1]), pack2<DT>(y[2], y[3])}, (u32x2*)a);
 }
 // RAG variants: rows of ANY length / alignment (attention rows of 1500 or 197 elements): whole lane-vectors are read and
 // written with 16-byte accesses at element alignment (93-97 % of the aligned rate on gfx950,
@@ -342,11 +351,11 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
       const int v = i * LPR + sl;
       const int64_t c = (int64_t)(v < nv ? v : nv - 1) * EPL;
       if (HOIST_F32) {
-        if (w) row_widen<DT, EPL>(row_load<DT, EPL>(w, c), wf[i]);
-        if (b) row_widen<DT, EPL>(row_load<DT, EPL>(b, c), bf[i]);
+        if (w) row_widen<DT, EPL>(row_load_keep<DT, EPL>(w, c), wf[i]);
+        if (b) row_widen<DT, EPL>(row_load_keep<DT, EPL>(b, c), bf[i]);
       } else {
-        if (w) wr[i] = row_load<DT, EPL>(w, c);
-        if (b) br[i] = row_load<DT, EPL>(b, c);
+        if (w) wr[i] = row_load_keep<DT, EPL>(w, c);
+        if (b) br[i] = row_load_keep<DT, EPL>(b, c);
       }
     }
   }
@@ -398,8 +407,8 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
       if (v < nv) {
         float ww[EPL], bb[EPL];
         if (!HOIST_F32) {
-          if (w) row_widen<DT, EPL>(HOIST_RAW ? wr[i] : row_load<DT, EPL>(w, (int64_t)v * EPL), ww);
-          if (b) row_widen<DT, EPL>(HOIST_RAW ? br[i] : row_load<DT, EPL>(b, (int64_t)v * EPL), bb);
+          if (w) row_widen<DT, EPL>(HOIST_RAW ? wr[i] : row_load_keep<DT, EPL>(w, (int64_t)v * EPL), ww);
+          if (b) row_widen<DT, EPL>(HOIST_RAW ? br[i] : row_load_keep<DT, EPL>(b, (int64_t)v * EPL), bb);
         }
 #pragma unroll
         for (int j = 0; j < RPW; j++) {
@@ -439,8 +448,8 @@ __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* _
   for (int i = 0; i < VPL; i++) {
     const int v = i * kThreads + t;
     const int64_t c = (int64_t)(v < nv ? v : nv - 1) * EPL;
-    if (w) wr[i] = row_load<DT, EPL>(w, c);
-    if (b) br[i] = row_load<DT, EPL>(b, c);
+    if (w) wr[i] = row_load_keep<DT, EPL>(w, c);
+    if (b) br[i] = row_load_keep<DT, EPL>(b, c);
   }
   for (int64_t r0 = (int64_t)blockIdx.x * RPW; r0 < rows; r0 += (int64_t)gridDim.x * RPW) {
     RowVec<DT, EPL> raw[RPW][VPL];
