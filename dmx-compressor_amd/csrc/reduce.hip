@@ -85,8 +85,9 @@ struct Raw8 {
 template <int DT>
 __device__ __forceinline__ Raw8<DT> load8_raw(const void* p, int64_t e) {
   Raw8<DT> r;
-  if (DT == DMXQ_F32) { r.a = *(const u32x4*)((const float*)p + e); r.b = *(const u32x4*)((const float*)p + e + 4); }
-  else { r.a = *(const u32x4*)((const uint16_t*)p + e); r.b = r.a; }
+  // non-temporal: the reductions read their operand exactly once
+  if (DT == DMXQ_F32) { r.a = __builtin_nontemporal_load((const u32x4*)((const float*)p + e)); r.b = __builtin_nontemporal_load((const u32x4*)((const float*)p + e + 4)); }
+  else { r.a = __builtin_nontemporal_load((const u32x4*)((const uint16_t*)p + e)); r.b = r.a; }
   return r;
 }
 template <int DT>
