@@ -96,14 +96,21 @@ struct FloatOp {
   template <int N>
   __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
     if (RND == DMXQ_ROUND_NEAREST && k.usable) {
+      // the branch-free form for every element, unconditionally; the (rare) elements it does not cover -- Inf, NaN, exponents
+      // too large for the magic constant -- are redone with the bit-level form behind ONE cold wave-uniform branch, so that the
+      // hot path is straight-line code the scheduler can interleave across the vectors of a tile
       bool ok = true;
 #pragma unroll
-      for (int j = 0; j < N; j++) ok = ok && float_fast_ok(x[j], k);
-      if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {  // wave-uniform: everything finite and in range
-#pragma unroll
-        for (int j = 0; j < N; j++) y[j] = float_q1_fast(x[j], k, f.flush != 0, f.unsigned_abs != 0);
-        return;
+      for (int j = 0; j < N; j++) {
+        ok = ok && float_fast_ok(x[j], k);
+        y[j] = float_q1_fast(x[j], k, f.flush != 0, f.unsigned_abs != 0);
       }
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ull, 0)) {
+#pragma unroll
+        for (int j = 0; j < N; j++)
+          if (!float_fast_ok(x[j], k)) apply_one(x[j], y[j], e0 + j);
+      }
+      return;
     }
 #pragma unroll
     for (int j = 0; j < N; j++) apply_one(x[j], y[j], e0 + j);
