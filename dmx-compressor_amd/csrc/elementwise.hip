@@ -189,14 +189,22 @@ struct FixedOp {
     bool ok = SIMPLE;
 #pragma unroll
     for (int k = 0; k < N; k++) { p.rs[k] = 1.0f / p.sc[k]; ok = ok && recip_ok(p.sc[k]); }
-    p.fast = __builtin_amdgcn_ballot_w64(!ok) == 0ull;  // wave-uniform: one branch per row vector
+    p.fast = ok;  // per lane: every one of its N scales has an exact-enough reciprocal
     return p;
   }
   template <int N>
   __device__ __forceinline__ void apply_chan(const float (&x)[N], const ChanParams<N>& p, float (&y)[N], int64_t e0) const {
-    if (SIMPLE && p.fast) {
+    if (SIMPLE) {
+      // reciprocal form unconditionally (straight-line code); lanes holding a scale outside its range redo theirs with the
+      // IEEE division behind one cold branch (as bfp_rows.hpp does for its literal path)
 #pragma unroll
       for (int k = 0; k < N; k++) y[k] = q<true>(x[k], p.sc[k], p.z[k], e0 + k, p.rs[k]);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(!p.fast) != 0ull, 0)) {
+        if (!p.fast) {
+#pragma unroll
+          for (int k = 0; k < N; k++) y[k] = q(x[k], p.sc[k], p.z[k], e0 + k);
+        }
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < N; k++) y[k] = q(x[k], p.sc[k], p.z[k], e0 + k);
@@ -224,10 +232,17 @@ struct FixedOp {
     if (MODE == kNone || MODE == kTensor || MODE == kUniform) {
       const float sc = pp.sc, z = pp.z;
       // one scale for the whole vector: its reciprocal once, then 5 VALU per quotient instead of ~11 (common.hpp)
-      if (SIMPLE && MODE != kNone && __builtin_amdgcn_ballot_w64(!recip_ok(sc)) == 0ull) {
+      if (SIMPLE && MODE != kNone) {
         const float rs = 1.0f / sc;
+        const bool ok = recip_ok(sc);
 #pragma unroll
         for (int k = 0; k < N; k++) y[k] = q<true>(x[k], sc, z, e0 + k, rs);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ull, 0)) {  // cold: scale outside [2^-20, 2^20]
+          if (!ok) {
+#pragma unroll
+            for (int k = 0; k < N; k++) y[k] = q(x[k], sc, z, e0 + k);
+          }
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < N; k++) y[k] = q(x[k], sc, z, e0 + k);

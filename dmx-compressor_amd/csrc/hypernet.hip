@@ -55,7 +55,7 @@ struct HnArgs {
 // kernel of nm_mask.hip switches on runtime dtypes around each access and reached 48 % of roofline with a bf16 score).
 // LPBC: lanes per BFP block as a compile-time constant (0 = runtime a.lpb), see bfp_rows.hpp: the DPP block maximum is then
 // free of scalar branches.
-template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP, int LPBC>
+template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP, int LPBC, bool ASYM>
 __device__ __forceinline__ void hypernet_rows_body(const HnArgs& a) {
   // T1: dtype after the mask multiply = torch promotion of (w, score); without a mask it stays the weight dtype
   constexpr int T1 = (M == 0) ? DTW : ((DTW == DMXQ_F32 || DTS == DMXQ_F32 || DTW != DTS) ? DMXQ_F32 : DTW);
@@ -120,20 +120,22 @@ __device__ __forceinline__ void hypernet_rows_body(const HnArgs& a) {
     for (int k = 0; k < 8; k++) mb = max(mb, f2u(x[k]) & 0x7FFFFFFFu);
     mb = group_max_u32(mb, lpb);
     float y[8];
-    if (__builtin_amdgcn_ballot_w64(!bfp_fast_ok(mb, a.wl)) == 0ull) {
-      if (a.asym) { const BfpBlockParams p = bfp_block_params<true, true>(mb, a.wl);
+    // the magic-add form for every lane, unconditionally (straight-line code the scheduler can interleave across the units in
+    // flight); blocks it does not cover (denormal / huge maxima, bfp_math.hpp) are redone with the literal bit path behind one
+    // cold wave-uniform branch -- the structure of bfp_rows.hpp.  (As a two-sided `if (all fast) ... else ...` per unit the
+    // branch fenced the schedule.)
+    const bool fast_ok = bfp_fast_ok(mb, a.wl);
+    {
+      const BfpBlockParams p = bfp_block_params<ASYM, true>(mb, a.wl);
 #pragma unroll
-        for (int k = 0; k < 8; k++) y[k] = bfp_q1_fast<false, true>(x[k], p); }
-      else { const BfpBlockParams p = bfp_block_params<false, true>(mb, a.wl);
+      for (int k = 0; k < 8; k++) y[k] = bfp_q1_fast<false, ASYM>(x[k], p);
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast_ok) != 0ull, 0)) {
+      if (!fast_ok) {
+        const BfpBlockParams p = bfp_block_params<ASYM, false>(mb, a.wl);
 #pragma unroll
-        for (int k = 0; k < 8; k++) y[k] = bfp_q1_fast<false, false>(x[k], p); }
-    } else {
-      if (a.asym) { const BfpBlockParams p = bfp_block_params<true, false>(mb, a.wl);
-#pragma unroll
-        for (int k = 0; k < 8; k++) y[k] = bfp_q1<DMXQ_ROUND_NEAREST, true>(x[k], p, a.wl, DMXQ_ROUND_NEAREST, 0u); }
-      else { const BfpBlockParams p = bfp_block_params<false, false>(mb, a.wl);
-#pragma unroll
-        for (int k = 0; k < 8; k++) y[k] = bfp_q1<DMXQ_ROUND_NEAREST, false>(x[k], p, a.wl, DMXQ_ROUND_NEAREST, 0u); }
+        for (int k = 0; k < 8; k++) y[k] = bfp_q1<DMXQ_ROUND_NEAREST, ASYM>(x[k], p, a.wl, DMXQ_ROUND_NEAREST, 0u);
+      }
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) y[k] = round_to<T1>(y[k]);   // CastTo's `.to(physical_dtype)`, then the caller's dtype
@@ -145,8 +147,15 @@ __device__ __forceinline__ void hypernet_rows_body(const HnArgs& a) {
 template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP = true>
 __global__ __launch_bounds__(kThreads) void hypernet_rows_kernel(HnArgs a) {
   // BFP16_64 (8 lanes per block: the BASIC rule's weight format) gets the branch-free form; other block sizes the runtime one
-  if (BFP && __builtin_amdgcn_readfirstlane(a.lpb) == 8) hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 8>(a);
-  else hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 0>(a);
+  // symmetric / asymmetric codes: chosen once per launch as well, not once per unit
+  const bool asym = BFP && __builtin_amdgcn_readfirstlane(a.asym) != 0;
+  if (BFP && __builtin_amdgcn_readfirstlane(a.lpb) == 8) {
+    if (asym) hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 8, true>(a);
+    else hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 8, false>(a);
+  } else {
+    if (asym) hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 0, true>(a);
+    else hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 0, false>(a);
+  }
 }
 
 template <int DTW, int DTS, int DTO>

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const 
 // (C x inner) plane; a lane owns 8 columns, the 4 waves take different rows (4 row loads in flight each), their
 // partial maxima are combined through LDS and ONE wave issues the integer atomics.
 constexpr int kMaxabsThreads = 1024;  // 16 waves over rows per column strip: parallelism without more atomics
+constexpr int kMaxabsRows = 8;        // rows in flight per lane
 template <int DT>
 __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(const void* __restrict__ in,
                                                                            int64_t outer, int64_t C, int64_t inner,
@@ -191,39 +192,41 @@ __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(cons
   float m[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) m[k] = 0.0f;
-  const int64_t step = (int64_t)gridDim.y * W;
-  int64_t o = (int64_t)blockIdx.y * W + w;
+  // a workgroup takes W * U consecutive rows per pass: wave w rows w, w + W, ...; the U row loads of a lane are all in flight
+  // before the first is consumed (tools/tune_reduce.hip: W16 x U8 = 9.4 us on 4096 x 4096 bf16 against 11.6 us with 4 loads per
+  // batch and 16 row splits).  Rows past the end re-read the last row: harmless for a maximum.
+  constexpr int U = kMaxabsRows;
   if (ok) {
-    for (; o + 3 * step < outer; o += 4 * step) {
-      Raw8<DT> raw[4];
+    for (int64_t o = (int64_t)blockIdx.y * (W * U) + w; o < outer; o += (int64_t)gridDim.y * (W * U)) {
+      Raw8<DT> raw[U];
 #pragma unroll
-      for (int u = 0; u < 4; u++) raw[u] = load8_raw<DT>(in, (o + u * step) * plane + col0);
+      for (int u = 0; u < U; u++) {
+        const int64_t r = o + u * W < outer ? o + u * W : outer - 1;
+        raw[u] = load8_raw<DT>(in, r * plane + col0);
+      }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < U; u++) {
         float v[8];
         widen8<DT>(raw[u], v);
 #pragma unroll
         for (int k = 0; k < 8; k++) m[k] = fmaxf(m[k], fabsf(v[k]));
       }
     }
-    for (; o < outer; o += step) {
-      float v[8];
-      widen8<DT>(load8_raw<DT>(in, o * plane + col0), v);
-#pragma unroll
-      for (int k = 0; k < 8; k++) m[k] = fmaxf(m[k], fabsf(v[k]));
-    }
   }
-  __shared__ float sm[W][8][kWave];
+  __shared__ float sm[W][kWave * 8];  // [wave][column of the strip]: written 8 consecutive floats per lane, read one per thread
 #pragma unroll
-  for (int k = 0; k < 8; k++) sm[w][k][lane] = m[k];
+  for (int k = 0; k < 8; k++) sm[w][lane * 8 + k] = m[k];
   __syncthreads();
-  if (w == 0 && ok) {
+  // the strip's 512 columns over the first 512 threads (8 waves), each combining the W partial maxima of its column
+  if (threadIdx.x < 8 * kWave) {
+    const int c = threadIdx.x;
+    const int64_t col = (int64_t)blockIdx.x * (kWave * 8) + c;
+    if (col < plane) {
+      float r = sm[0][c];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      float r = sm[0][k][lane];
-#pragma unroll
-      for (int i = 1; i < W; i++) r = fmaxf(r, sm[i][k][lane]);
-      atomicMax((int*)&out[(col0 + k) / inner], (int)f2u(r));  // r >= 0: int order == float order
+      for (int i = 1; i < W; i++) r = fmaxf(r, sm[i][c]);
+      const int64_t ch = inner == 1 ? col : (plane < (1ll << 31) ? (int64_t)((uint32_t)col / (uint32_t)inner) : col / inner);
+      atomicMax((int*)&out[ch], (int)f2u(r));  // r >= 0: int order == float order
     }
   }
 }
@@ -383,10 +386,10 @@ extern "C" int dmxq_channel_maxabs(const void* in, int dtype_in, int64_t outer, 
     int64_t gy = kMaxBlocks / gx;
     if (gy < 1) gy = 1;
     if (gy > outer) gy = outer;
-    if (vec) {  // few row splits: every split costs one contended atomic per channel (same-address atomics serialise)
-      if (gy > 16) gy = 16;  // measured optimum on MI355X for a 4096 x 4096 bf16 operand (profiles/)
-      if (gy > (outer + 31) / 32) gy = (outer + 31) / 32;
-      if (gy < 1) gy = 1;
+    if (vec) {  // one pass of 16 waves x 8 rows per workgroup, at most 64 row splits (each costs one atomic per channel)
+      const int64_t rows_per_pass = (kMaxabsThreads / kWave) * kMaxabsRows;
+      gy = (outer + rows_per_pass - 1) / rows_per_pass;
+      if (gy > 64) gy = 64;
     }
     if (gy > 65535) gy = 65535;
     if (vec)
