@@ -62,14 +62,12 @@ __global__ __launch_bounds__(kFmThreads) void fixed_multi_kernel(const FixedMult
     float x[EPL], y[EPL];
     widen<DTI, EPL>(raw[u], x);
     const float rs = 1.0f / sc[u];
-    const bool ok = recip_ok(sc[u]);
+    if (__builtin_amdgcn_ballot_w64(!recip_ok(sc[u])) == 0ull) {
 #pragma unroll
-    for (int j = 0; j < EPL; j++) y[j] = fixed_simple_q(x[j], sc[u], z[u], rs, true, a.t_min, a.t_max);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ull, 0)) {  // cold: IEEE division for scales outside [2^-20, 2^20]
-      if (!ok) {
+      for (int j = 0; j < EPL; j++) y[j] = fixed_simple_q(x[j], sc[u], z[u], rs, true, a.t_min, a.t_max);
+    } else {
 #pragma unroll
-        for (int j = 0; j < EPL; j++) y[j] = fixed_simple_q(x[j], sc[u], z[u], rs, false, a.t_min, a.t_max);
-      }
+      for (int j = 0; j < EPL; j++) y[j] = fixed_simple_q(x[j], sc[u], z[u], rs, false, a.t_min, a.t_max);
     }
     o[u] = pack_vec<DTO, EPL>(y);
     __builtin_amdgcn_sched_barrier(0);

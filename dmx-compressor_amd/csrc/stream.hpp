@@ -34,6 +34,11 @@ struct OpPrep<OP, std::void_t<typename OP::Prep>> {
   }
 };
 
+// Optional per-TILE side data: an OP with `bool tile_prepare(int64_t e0, int64_t len, Prep&) const` is asked, with wave-uniform
+// arguments, whether the elements [e0, e0 + len) all use the same Prep (then filled in from scalar loads).
+template <class OP, class = void> struct OpTilePrep { static constexpr bool value = false; };
+template <class OP> struct OpTilePrep<OP, std::void_t<decltype(OP::kTilePrep)>> { static constexpr bool value = OP::kTilePrep; };
+
 template <int DTI, int DTO, int UNROLL, int THREADS, class OP, bool UNAL = false>
 __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                         int64_t n, OP op) {
@@ -48,24 +53,40 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict_
     char* dst = (char*)out + tile * (TILE * OVB);
     const int64_t v0 = tile * TILE + threadIdx.x;
     if ((tile + 1) * TILE <= n_vec) {
-      u32x4 raw[UNROLL];
+      // load burst + compute + store burst of a full tile, with the per-vector side data coming from prep_of(u).  The side data
+      // (scale / zero-point reads) is requested BEFORE the tile's own loads: vector memory returns in order, so behind them it
+      // would only arrive after the whole tile, and the first vector's arithmetic could not start while the rest streams in.
+      auto finish = [&](auto prep_of) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 raw[UNROLL];
 #pragma unroll
-      for (int u = 0; u < UNROLL; u++) raw[u] = load_raw16<true, uint32_t, UNAL>(src + u * (THREADS * 16), lane_in);
+        for (int u = 0; u < UNROLL; u++) raw[u] = load_raw16<true, uint32_t, UNAL>(src + u * (THREADS * 16), lane_in);
+        __builtin_amdgcn_sched_barrier(0);
+        OutVec<DTO, EPL> o[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+          float x[EPL], y[EPL];
+          widen<DTI, EPL>(raw[u], x);
+          OpPrep<OP>::apply(op, x, y, (v0 + (int64_t)u * THREADS) * EPL, prep_of(u));
+          o[u] = pack_vec<DTO, EPL>(y);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) store_out<DTO, EPL, true, UNAL>(dst + u * (THREADS * OVB) + lane_out, o[u]);
+      };
+      if constexpr (OpTilePrep<OP>::value) {
+        // the whole tile shares one set of side data (one quantisation group): fetched once, from a wave-uniform address,
+        // instead of an index computation and two dependent loads per 16-byte vector
+        typename OP::Prep tp;
+        if (op.tile_prepare(tile * (TILE * EPL), TILE * EPL, tp)) {  // wave-uniform
+          finish([&](int) -> const typename OP::Prep& { return tp; });
+          continue;
+        }
+      }
       typename OpPrep<OP>::type prep[UNROLL];
 #pragma unroll
       for (int u = 0; u < UNROLL; u++) prep[u] = OpPrep<OP>::get(op, (v0 + (int64_t)u * THREADS) * EPL);
-      __builtin_amdgcn_sched_barrier(0);
-      OutVec<DTO, EPL> o[UNROLL];
-#pragma unroll
-      for (int u = 0; u < UNROLL; u++) {
-        float x[EPL], y[EPL];
-        widen<DTI, EPL>(raw[u], x);
-        OpPrep<OP>::apply(op, x, y, (v0 + (int64_t)u * THREADS) * EPL, prep[u]);
-        o[u] = pack_vec<DTO, EPL>(y);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int u = 0; u < UNROLL; u++) store_out<DTO, EPL, true, UNAL>(dst + u * (THREADS * OVB) + lane_out, o[u]);
+      finish([&](int u) -> const typename OpPrep<OP>::type& { return prep[u]; });
     } else {
       for (int u = 0; u < UNROLL; u++) {
         const int64_t vi = v0 + (int64_t)u * THREADS;
@@ -88,17 +109,29 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict_
   }
 }
 
-// geometry as in bfp.hip: 512 x 16 tiles for big tensors (8 when the output vector is 32 B), 256 x 4, 256 x 1.
-// The big tile puts ONE workgroup on each CU, all in the same phase (load / compute / store): right for ops whose
-// arithmetic is a small fraction of the memory time.  VALU-heavy ops (OP::kHeavy: erf, divisions) use 256 x 4
-// tiles instead, so that several workgroups per CU interleave their compute with each other's memory phases.
+// Geometry.  Small tensors: 256 x 1 tiles (many workgroups).  Big ones (>= 256 workgroups of 256 x 4 vectors): the op says
+// how many 16-byte vectors a lane keeps in flight, by how much arithmetic it carries per element -- measured on 4096 x 4096
+// bf16 (profiles/r02_stream_geometry.txt, one box, all eight geometries per op):
+//   kTileUnroll 16  almost no arithmetic (INT8 without affine, scale multiply): ONE round of 512 x 16 tiles, one workgroup per CU,
+//                   when the tensor is 224-256 such tiles (11.6 us vs 12.7 us); otherwise 256 x 8
+//   kTileUnroll 8   light (minifloat cast, silu, INT8 with a per-group scale): 256 x 8   (E4M3 12.1 vs 13.5 us, silu 11.4 vs 12.7 us)
+//   kTileUnroll 4   default for kHeavy ops
+//   kTileUnroll 2   VALU-heavy (erf gelu, quick_gelu's dtype chain, the composite block formats): 256 x 2 -- or 512 x 2 with
+//                   kTileThreads 512 (SBFP: 17.4 vs 18.3 us) -- so that several workgroups per CU interleave their compute with
+//                   each other's memory phases
 template <class OP, class = void> struct OpHeavy { static constexpr bool value = false; };
 template <class OP> struct OpHeavy<OP, decltype((void)OP::kHeavy)> { static constexpr bool value = OP::kHeavy; };
+template <class OP, class = void> struct OpTileUnroll { static constexpr int value = OpHeavy<OP>::value ? 4 : 16; };
+template <class OP> struct OpTileUnroll<OP, decltype((void)OP::kTileUnroll)> { static constexpr int value = OP::kTileUnroll; };
+template <class OP, class = void> struct OpTileThreads { static constexpr int value = 256; };
+template <class OP> struct OpTileThreads<OP, decltype((void)OP::kTileThreads)> { static constexpr int value = OP::kTileThreads; };
 
 template <int DTI, int DTO, class OP>
 static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hipStream_t s) {
   constexpr int EPL = 16 / Elem<DTI>::bytes;
   constexpr int UB = (Elem<DTO>::bytes > Elem<DTI>::bytes) ? 8 : 16;
+  constexpr int TU = OpTileUnroll<OP>::value, TT = OpTileThreads<OP>::value;
+  static_assert(TU == 16 || TU == 8 || TU == 4 || TU == 2, "kTileUnroll");
   const int64_t n_vec = n / EPL;
   if (!aligned16(in) || !aligned16(out)) {  // views that start mid-allocation: same schedule on unaligned 16-byte accesses
     int64_t tiles = (n_vec + (int64_t)256 * 4 - 1) / ((int64_t)256 * 4);
@@ -114,10 +147,12 @@ static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hip
     if (tiles > (1 << 20)) tiles = 1 << 20;                                                                       \
     DMXQ_LAUNCH((stream_kernel<DTI, DTO, U_, T_, OP>), dim3((unsigned)tiles), dim3(T_), 0, s, in, out, n, op); \
   } while (0)
-  const int64_t big_tiles = (n_vec + (int64_t)512 * UB - 1) / ((int64_t)512 * UB);
-  if (!OpHeavy<OP>::value && big_tiles <= 256 && big_tiles >= 224) DMXQ_STREAM(512, UB);  // one full round (bfp.hip)
-  else if (n_vec >= (int64_t)256 * 256 * 4) DMXQ_STREAM(256, 4);
-  else DMXQ_STREAM(256, 1);
+  if (n_vec < (int64_t)256 * 256 * 4) DMXQ_STREAM(256, 1);
+  else if constexpr (TU == 16) {
+    const int64_t big_tiles = (n_vec + (int64_t)512 * UB - 1) / ((int64_t)512 * UB);
+    if (big_tiles <= 256 && big_tiles >= 224) DMXQ_STREAM(512, UB);  // one full round
+    else DMXQ_STREAM(256, 8);
+  } else DMXQ_STREAM(TT, TU);
 #undef DMXQ_STREAM
   return launch_status();
 }

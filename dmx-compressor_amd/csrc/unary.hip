@@ -40,6 +40,7 @@ __device__ __forceinline__ float sigmoid_mul(float x, float t) {  // x * sigmoid
 template <int KIND, int DTI, bool FAST>
 struct UnaryOp {
   static constexpr bool kHeavy = true;
+  static constexpr int kTileUnroll = KIND == DMXQ_UNARY_SILU ? 8 : (KIND == DMXQ_UNARY_QUICK_GELU ? 2 : 4);  // stream.hpp
   float param;
   __device__ __forceinline__ void apply_one(float x, float& y, int64_t) const {
     if (KIND == DMXQ_UNARY_SILU) {

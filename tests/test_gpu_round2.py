@@ -173,7 +173,9 @@ def test_host_overhead_of_one_cast_call(dmx, cuda):
     if os.path.isdir(out):
         with open(os.path.join(out, "host_overhead.txt"), "w") as f:
             f.write("\n".join(f"{k}: {v:.2f} us per call (median host time of 1000 calls in bursts of 100 on an idle stream)" for k, v in res.items()) + "\n")
-    assert res["torch.ops.dmxq.bfp_qdq"] < 10.0 and res["CastTo.forward"] < 16.0
+    # measured 7.6-8.0 / 9.7-10.1 us on idle boxes; the bound is 2x that (a shared or cold host must not fail the suite), still
+    # below what a Python-marshalling regression costs (round 1: 11 us of ctypes marshalling on top of the launch)
+    assert res["torch.ops.dmxq.bfp_qdq"] < 16.0 and res["CastTo.forward"] < 20.0, res
 
 
 # ------------------------------------------------------------------------------------------------ S1: native symmetric = false
