@@ -40,14 +40,17 @@ __device__ __forceinline__ float fixed_rne(float a) {  // sim_helper.cpp:14-21 w
   return mag >= 8388608.0f ? (odd ? a1 - 1.0f : a1) : rintf(a1 - 0.5f);
 }
 
-struct SbfpFmt { static constexpr int kThreads = 512; int p, clamp; float t_min, t_max, man_scaling; int man, exp_bits, bias, flush; };
-struct MxfpFmt { static constexpr int kThreads = 256; int man, exp_bits, bias; float big; FloatFast fast; int big_log2, exact_exponent; };
+struct SbfpFmt { static constexpr int kThreads = 512, kUnroll = 2; int p, clamp; float t_min, t_max, man_scaling; int man, exp_bits, bias, flush; };
+struct MxfpFmt { static constexpr int kThreads = 256, kUnroll = 2; int man, exp_bits, bias; float big; FloatFast fast; int big_log2, exact_exponent; };
 
 struct SbfpBlock {
-  float s, sc;
+  float s, sc, rs;
+  bool fast;  // clamped codes and a block scale whose reciprocal carries the exact-quotient argument of common.hpp
   __device__ __forceinline__ void setup(uint32_t maxbits, const SbfpFmt& f) {
     s = u2f(maxbits) / f.man_scaling;
     sc = fabsf(float_q_nearest(s, f.man, f.exp_bits, f.bias, f.flush));
+    rs = 1.0f / s;
+    fast = f.clamp != 0 && recip_ok(s);
   }
   __device__ __forceinline__ float apply(float x, const SbfpFmt& f) const {
     if (!(s > 0.0f)) return x;  // zero (or NaN) block: passed through (format.py:467-474 torch.where)
@@ -55,10 +58,25 @@ struct SbfpBlock {
     if (f.clamp) q = q > f.t_max ? f.t_max : (q < f.t_min ? f.t_min : q);
     return q * sc;
   }
+  // The codes are CLAMPED integers (|code| <= 2^(p-1) - 1), so the quotient x / s may come from div_for_clamped_int (3 FMA-class
+  // operations instead of the ~14 of an IEEE division; the clamped code is the same for every x) and fixed_rne's |a| >= 2^23 branch
+  // cannot matter (such values clamp whatever they round to): straight-line code for every lane, and the lanes whose block has
+  // no such reciprocal (zero / NaN / denormal-range block maximum, unclamped format) redo theirs behind one cold branch.
   template <int N>
   __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], const SbfpFmt& f) const {
+    const Recip rc{s, rs};
 #pragma unroll
-    for (int k = 0; k < N; k++) y[k] = apply(x[k], f);
+    for (int k = 0; k < N; k++) {
+      float q = rintf((div_for_clamped_int(x[k], rc) + 0.5f) - 0.5f);
+      q = q > f.t_max ? f.t_max : (q < f.t_min ? f.t_min : q);
+      y[k] = q * sc;
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast) != 0ull, 0)) {
+      if (!fast) {
+#pragma unroll
+        for (int k = 0; k < N; k++) y[k] = apply(x[k], f);
+      }
+    }
   }
 };
 struct MxfpBlock {
@@ -106,7 +124,7 @@ struct MxfpBlock {
 template <class FMT, class BLK>
 struct BlockOp {
   static constexpr bool kHeavy = true;
-  static constexpr int kTileUnroll = 2, kTileThreads = FMT::kThreads;  // stream.hpp: SBFP 512 x 2 (17.4 vs 18.3 us), MXFP 256 x 2 (15.0 vs 15.5 us)
+  static constexpr int kTileUnroll = FMT::kUnroll, kTileThreads = FMT::kThreads;  // stream.hpp: SBFP 512 x 2 (17.4 vs 18.3 us), MXFP 256 x 2 (15.0 vs 15.5 us)
   FMT f;
   int lpb;
   __device__ __forceinline__ void apply_one(float x, float& y, int64_t) const { y = x; }  // (no scalar tail: n % B == 0)

@@ -330,14 +330,6 @@ __device__ __forceinline__ uint32_t absmax_bits(const u32x4& v) {
 //   Inf into NaN) and is selected by one v_cmp_class.
 // 5 VALU operations per element, no branch.  NOT a general division: callers that return the quotient itself
 // (SmoothQuant's x / s) keep the IEEE `/`.
-// a value the program knows to be the same in every lane, moved to scalar registers (what follows it -- index arithmetic,
-// table loads -- then runs on the scalar unit / as s_load)
-__device__ __forceinline__ int64_t uniform_i64(int64_t v) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
-  return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-
 struct Recip { float d, rs; };
 __device__ __forceinline__ Recip make_recip(float d) { return Recip{d, 1.0f / d}; }
 __device__ __forceinline__ bool recip_ok(float d) { return d >= 9.5367431640625e-07f && d <= 1048576.0f; }  // [2^-20, 2^20]
@@ -346,6 +338,14 @@ __device__ __forceinline__ float div_for_clamped_int(float n, const Recip& c) {
   const float r = -__builtin_fmaf(c.d, q0, -n);
   const float q = __builtin_fmaf(r, c.rs, q0);
   return __builtin_amdgcn_classf(q0, 0x001 | 0x002 | 0x004 | 0x200) ? q0 : q;  // sNaN, qNaN, -inf, +inf
+}
+
+// a value the program knows to be the same in every lane, moved to scalar registers (what follows it -- index arithmetic,
+// table loads -- then runs on the scalar unit / as s_load)
+__device__ __forceinline__ int64_t uniform_i64(int64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
 // Tile geometry of the flat-stream kernel for a tensor of n_vec lane-vectors: workgroup-contiguous tiles of

@@ -387,13 +387,14 @@ struct ScaleOp {
 //              (Abramowitz-Stegun 7.1.26, |error| < 1.5e-7), gelu = x >= 0 ? x - x erfc / 2 : x erfc / 2 -- the erfc form
 //              keeps RELATIVE accuracy in the negative tail, where 1 + erf cancels;
 //   tanh form: x (1 + tanh u) / 2 = x / (1 + exp(-2u)).
-template <bool FAST>
+// TANH is a template parameter, not a kernel argument: as a run-time flag it was a scalar branch around EVERY element (16 per
+// pair of vectors), which kept the compiler from interleaving the elements' rcp / exp chains
+template <bool FAST, bool TANH>
 struct GeluOp {
   static constexpr bool kHeavy = true;
   static constexpr int kTileUnroll = 2;
-  int tanh_form;
   __device__ __forceinline__ void apply_one(float x, float& y, int64_t) const {
-    if (tanh_form) {
+    if (TANH) {
       const float k0 = 0.7978845608028654f, k1 = 0.044715f;
       const float u = k0 * (x + k1 * x * x * x);
       if (FAST) {  // x (1 + tanh u) / 2 = x / (1 + exp(-2u)): no cancellation in the negative tail
@@ -722,8 +723,10 @@ extern "C" int dmxq_gelu(const void* in, void* out, int dtype_in, int dtype_out,
   if (!valid_dtype(dtype_in) || !valid_dtype(dtype_out) || n < 0) return DMXQ_ERR_BAD_ARG;
   if (n == 0) return DMXQ_OK;
   if (!in || !out) return DMXQ_ERR_BAD_ARG;
-  if (dtype_out != DMXQ_F32) return dispatch_stream(in, out, dtype_in, dtype_out, n, GeluOp<true>{tanh_form}, (hipStream_t)stream);
-  return dispatch_stream(in, out, dtype_in, dtype_out, n, GeluOp<false>{tanh_form}, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype_out != DMXQ_F32)
+    return tanh_form ? dispatch_stream(in, out, dtype_in, dtype_out, n, GeluOp<true, true>{}, s) : dispatch_stream(in, out, dtype_in, dtype_out, n, GeluOp<true, false>{}, s);
+  return tanh_form ? dispatch_stream(in, out, dtype_in, dtype_out, n, GeluOp<false, true>{}, s) : dispatch_stream(in, out, dtype_in, dtype_out, n, GeluOp<false, false>{}, s);
 }
 
 extern "C" int dmxq_bernoulli_mask(const void* score, void* mask_out, int dtype_score, int dtype_mask, int64_t n,
