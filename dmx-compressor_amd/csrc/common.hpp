@@ -332,7 +332,7 @@ __device__ __forceinline__ uint32_t absmax_bits(const u32x4& v) {
 // (SmoothQuant's x / s) keep the IEEE `/`.
 struct Recip { float d, rs; };
 __device__ __forceinline__ Recip make_recip(float d) { return Recip{d, 1.0f / d}; }
-__device__ __forceinline__ bool recip_ok(float d) { return d >= 9.5367431640625e-07f && d <= 1048576.0f; }  // [2^-20, 2^20]
+__host__ __device__ __forceinline__ bool recip_ok(float d) { return d >= 9.5367431640625e-07f && d <= 1048576.0f; }  // [2^-20, 2^20]
 __device__ __forceinline__ float div_for_clamped_int(float n, const Recip& c) {
   const float q0 = n * c.rs;
   const float r = -__builtin_fmaf(c.d, q0, -n);

@@ -278,41 +278,51 @@ __global__ void smoothquant_scale_kernel(const float* a, const float* b, int64_t
 // multiply and divide: (int64)((x - lo) * bins / (hi - lo)), right edge into the last bin, out-of-range and NaN dropped.
 constexpr int kHistThreads = 1024;
 constexpr int kHistMaxBins = 8192;  // 32 KiB of LDS counters
-__device__ __forceinline__ void hist_add(uint32_t* s, float v, float lo, float hi, float fb, float width, int bins) {
+// FAST: width in [2^-20, 2^20] (checked on the host): the quotient comes from div_for_clamped_int (common.hpp), which IS the IEEE
+// quotient for 2^-100 <= |n| <= 2^100; n = (v - lo) * bins is below 2^34 for an in-range v, and a smaller |n| truncates to bin 0
+// whatever its last bit is.  3 FMA-class operations instead of the ~14 of v_div_scale/fmas/fixup per element.
+// (Tried and measured slower on the same box, profiles/r02_histc_variants.txt: a branch-free add of 0 for out-of-range elements;
+// 2 / 4 / 8 interleaved copies of the counters against same-bin collisions; 128 or 512 workgroups.)
+template <bool FAST>
+__device__ __forceinline__ void hist_add(uint32_t* s, float v, float lo, float hi, float fb, const Recip& width, int bins) {
   if (v >= lo && v <= hi) {
-    int pos = (int)((v - lo) * fb / width);
+    const float n = (v - lo) * fb;
+    int pos = (int)(FAST ? div_for_clamped_int(n, width) : n / width.d);
     pos = pos < bins ? pos : bins - 1;
     atomicAdd(&s[pos], 1u);
   }
 }
-template <int DT>
+template <int DT, bool FAST>
 __global__ __launch_bounds__(kHistThreads) void histc_kernel(const void* __restrict__ in, int64_t n, int bins,
                                                              float lo, float hi, int vec, uint32_t* counts) {
   constexpr int dt = DT;
   extern __shared__ uint32_t s_hist[];
   for (int b = threadIdx.x; b < bins; b += kHistThreads) s_hist[b] = 0;
   __syncthreads();
-  const float fb = (float)bins, width = hi - lo;
+  const float fb = (float)bins;
+  const Recip width = make_recip(hi - lo);
   const int64_t stride = (int64_t)gridDim.x * kHistThreads;
   const int64_t t0 = (int64_t)blockIdx.x * kHistThreads + threadIdx.x;
   if (vec) {
+    constexpr int U = 4;  // 16-byte loads in flight per lane
     const int64_t nv = n / 8;
-    for (int64_t t = t0; t < nv; t += 2 * stride) {
-      float a[8], b[8];
-      const bool two = t + stride < nv;
-      const Raw8<DT> ra = load8_raw<DT>(in, t * 8), rb = load8_raw<DT>(in, (two ? t + stride : t) * 8);
-      widen8<DT>(ra, a);
-      widen8<DT>(rb, b);
+    for (int64_t t = t0; t < nv; t += U * stride) {
+      Raw8<DT> raw[U];
 #pragma unroll
-      for (int k = 0; k < 8; k++) hist_add(s_hist, a[k], lo, hi, fb, width, bins);
-      if (two) {
+      for (int u = 0; u < U; u++) raw[u] = load8_raw<DT>(in, (t + u * stride < nv ? t + u * stride : t) * 8);
 #pragma unroll
-        for (int k = 0; k < 8; k++) hist_add(s_hist, b[k], lo, hi, fb, width, bins);
+      for (int u = 0; u < U; u++) {
+        if (u == 0 || t + u * stride < nv) {
+          float a[8];
+          widen8<DT>(raw[u], a);
+#pragma unroll
+          for (int k = 0; k < 8; k++) hist_add<FAST>(s_hist, a[k], lo, hi, fb, width, bins);
+        }
       }
     }
-    for (int64_t e = nv * 8 + t0; e < n; e += stride) hist_add(s_hist, load_rt(in, dt, e), lo, hi, fb, width, bins);
+    for (int64_t e = nv * 8 + t0; e < n; e += stride) hist_add<FAST>(s_hist, load_rt(in, dt, e), lo, hi, fb, width, bins);
   } else {
-    for (int64_t e = t0; e < n; e += stride) hist_add(s_hist, load_rt(in, dt, e), lo, hi, fb, width, bins);
+    for (int64_t e = t0; e < n; e += stride) hist_add<FAST>(s_hist, load_rt(in, dt, e), lo, hi, fb, width, bins);
   }
   __syncthreads();
   for (int b = threadIdx.x; b < bins; b += kHistThreads) {
@@ -422,9 +432,16 @@ extern "C" int dmxq_histc(const void* in, int dtype_in, int64_t n, int64_t bins,
   if (hipMemsetAsync(hist, 0, (size_t)bins * sizeof(float), s) != hipSuccess) return DMXQ_ERR_LAUNCH;
   if (n > 0) {
     if (!in) return DMXQ_ERR_BAD_ARG;
+    // one workgroup of 16 waves per CU: every workgroup ends with one global atomic per non-empty bin (512 workgroups x 2048
+    // bins were 1 M atomics), and 128 leave half the CUs idle
     int64_t blocks = (n + kHistThreads * 32 - 1) / (kHistThreads * 32);
-    if (blocks > 512) blocks = 512;
-#define DMXQ_HC(D_) DMXQ_LAUNCH(histc_kernel<D_>, dim3((unsigned)blocks), dim3(kHistThreads), (size_t)bins * sizeof(uint32_t), s, in, n, (int)bins, lo, hi, aligned16(in) ? 1 : 0, (uint32_t*)hist)
+    if (blocks > 256) blocks = 256;
+    const bool fast = recip_ok(hi - lo);
+#define DMXQ_HC(D_)                                                                                                              \
+  do {                                                                                                                           \
+    if (fast) DMXQ_LAUNCH((histc_kernel<D_, true>), dim3((unsigned)blocks), dim3(kHistThreads), (size_t)bins * sizeof(uint32_t), s, in, n, (int)bins, lo, hi, aligned16(in) ? 1 : 0, (uint32_t*)hist); \
+    else DMXQ_LAUNCH((histc_kernel<D_, false>), dim3((unsigned)blocks), dim3(kHistThreads), (size_t)bins * sizeof(uint32_t), s, in, n, (int)bins, lo, hi, aligned16(in) ? 1 : 0, (uint32_t*)hist); \
+  } while (0)
     if (dtype_in == DMXQ_F32) DMXQ_HC(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_HC(DMXQ_F16); else DMXQ_HC(DMXQ_BF16);
 #undef DMXQ_HC
     DMXQ_LAUNCH(hist_to_float_kernel, dim3((unsigned)((bins + 255) / 256)), dim3(256), 0, s, (uint32_t*)hist, (int)bins);
