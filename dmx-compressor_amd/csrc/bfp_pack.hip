@@ -17,70 +17,82 @@ namespace dmxq {
 // codes of one 16-byte input vector.  Nearest-even through the magic add of bfp_math.hpp (2): with t = fl(x + base),
 // fl(t + M) lies in M's binade, whose ulp is the quantum, and so does K = M + base: the INTEGER difference of the two
 // bit patterns is the code.  Clamp and asymmetric rule as bfp_q1_fast (double-rounding form, any input dtype).
-template <int DTI, int EPL>
-__device__ __forceinline__ void pack_codes(const u32x4& raw, uint32_t mb, int wl, int asym, bool fast, int (&code)[EPL]) {
+template <int EPL>
+__device__ __forceinline__ void pack_codes_fast(const float (&x)[EPL], uint32_t mb, int wl, int asym, int (&code)[EPL]) {
+  const BfpBlockParams p = bfp_block_params<true, true>(mb, wl);
+  const int cmax = (1 << (wl - 1)) - 1;
+  const uint32_t kb = f2u(p.K);
+  const float thr = asym ? p.thr : -INFINITY;  // symmetric: x <= -inf never holds for a finite block
+#pragma unroll
+  for (int k = 0; k < EPL; k++) {
+    const int ci = (int)(f2u((x[k] + p.base) + p.M) - kb);
+    const int c = ci < -cmax ? -cmax : (ci > cmax ? cmax : ci);
+    code[k] = (x[k] <= thr) ? -cmax - 1 : c;
+  }
+}
+// the literal form, for the blocks bfp_fast_ok does not cover and the zero / denormal / Inf / NaN maxima (all-zero codes)
+template <int EPL>
+__device__ __forceinline__ void pack_codes_literal(const float (&x)[EPL], uint32_t mb, int wl, int asym, int (&code)[EPL]) {
   const uint32_t Eb = (mb & 0x7F800000u) >> 23;
-  float x[EPL];
-  widen<DTI, EPL>(raw, x);
   if (Eb == 0u || Eb == 255u) {
 #pragma unroll
     for (int k = 0; k < EPL; k++) code[k] = 0;
-  } else if (fast) {
-    const BfpBlockParams p = bfp_block_params<true, true>(mb, wl);
-    const int cmax = (1 << (wl - 1)) - 1;
-    const uint32_t kb = f2u(p.K);
+    return;
+  }
+  const float inv_quantum = u2f((uint32_t)(127 - ((int)Eb - 127 - (wl - 2))) << 23);  // 2^-(e-(p-2))
+  const BfpBlockParams p = bfp_block_params<true, false>(mb, wl);
 #pragma unroll
-    for (int k = 0; k < EPL; k++) {
-      const int ci = (int)(f2u((x[k] + p.base) + p.M) - kb);
-      int c = ci < -cmax ? -cmax : (ci > cmax ? cmax : ci);
-      if (asym) c = (x[k] <= p.thr) ? -cmax - 1 : c;
-      code[k] = c;
-    }
-  } else {
-    const float inv_quantum = u2f((uint32_t)(127 - ((int)Eb - 127 - (wl - 2))) << 23);  // 2^-(e-(p-2))
-    const BfpBlockParams p = bfp_block_params<true, false>(mb, wl);
-#pragma unroll
-    for (int k = 0; k < EPL; k++) {
-      const float q = asym ? bfp_q1<DMXQ_ROUND_NEAREST, true>(x[k], p, wl, DMXQ_ROUND_NEAREST, 0u)
-                           : bfp_q1<DMXQ_ROUND_NEAREST, false>(x[k], p, wl, DMXQ_ROUND_NEAREST, 0u);
-      code[k] = (int)(q * inv_quantum);  // exact: q is a multiple of the quantum, |code| <= 2^(p-1)
-    }
+  for (int k = 0; k < EPL; k++) {
+    const float q = asym ? bfp_q1<DMXQ_ROUND_NEAREST, true>(x[k], p, wl, DMXQ_ROUND_NEAREST, 0u)
+                         : bfp_q1<DMXQ_ROUND_NEAREST, false>(x[k], p, wl, DMXQ_ROUND_NEAREST, 0u);
+    code[k] = (int)(q * inv_quantum);  // exact: q is a multiple of the quantum, |code| <= 2^(p-1)
   }
 }
 
+// rows of whole power-of-two blocks: a workgroup takes a contiguous tile of kPackThreads x kPackUnroll 16-byte vectors, all of a
+// lane's loads in flight before the first block maximum; the magic-add codes for every lane as straight-line code, the blocks
+// that form does not cover redone behind one cold branch (the structure of bfp_rows.hpp)
+constexpr int kPackThreads = 256, kPackUnroll = 8;
 template <int DTI>
-__global__ __launch_bounds__(kThreads) void bfp_pack_rows_kernel(const void* __restrict__ in, int8_t* __restrict__ mant,
-                                                                uint8_t* __restrict__ exps, int64_t n_vec, int lpb_arg,
-                                                                int lpb_log, int wl, int asym) {
+__global__ __launch_bounds__(kPackThreads) void bfp_pack_rows_kernel(const void* __restrict__ in, int8_t* __restrict__ mant,
+                                                                    uint8_t* __restrict__ exps, int64_t n_vec, int lpb_arg,
+                                                                    int lpb_log, int wl, int asym) {
   constexpr int EPL = 16 / Elem<DTI>::bytes;
-  constexpr int U = 4;  // vectors in flight per lane
+  constexpr int U = kPackUnroll, T = kPackThreads;
   const int lpb = __builtin_amdgcn_readfirstlane(lpb_arg);
-  const bool leader = (threadIdx.x & (lpb - 1)) == 0;  // v = threadIdx (mod lpb): strides are multiples of 64
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; v0 < n_vec; v0 += U * stride) {
-    u32x4 raw[U];
+  const int in_blk = threadIdx.x & (lpb - 1);  // v = threadIdx (mod lpb): tile bases and T are multiples of 64
+  const int64_t base = (int64_t)blockIdx.x * (T * U) + threadIdx.x;
+  u32x4 raw[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int64_t v = v0 + u * stride < n_vec ? v0 + u * stride : v0;  // clamped (whole blocks: v0's block): unconditional loads
-      raw[u] = load_raw16<true>(in, v * 16);
+  for (int u = 0; u < U; u++) {
+    const int64_t v = base + u * T;
+    // past the end: the same lane position of the LAST block (whole blocks: n_vec % lpb == 0), so that every lane of a
+    // wave takes part in the block maxima with defined data; nothing is stored for it
+    raw[u] = load_raw16<true>(in, (v < n_vec ? v : n_vec - lpb + in_blk) * 16);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int64_t v = base + u * T;
+    const uint32_t mb = group_max_u32(absmax_bits<DTI>(raw[u]), lpb);
+    const uint32_t Eb = (mb & 0x7F800000u) >> 23;
+    const bool fast = bfp_fast_ok(mb, wl) && Eb != 0u && Eb != 255u;
+    float x[EPL];
+    widen<DTI, EPL>(raw[u], x);
+    int code[EPL];
+    pack_codes_fast<EPL>(x, mb, wl, asym, code);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast) != 0ull, 0)) {
+      if (!fast) pack_codes_literal<EPL>(x, mb, wl, asym, code);
     }
+    if (v < n_vec) {
+      uint32_t w[EPL / 4];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int64_t v = v0 + u * stride;
-      const uint32_t mb = group_max_u32(absmax_bits<DTI>(raw[u]), lpb);
-      const bool fast = __builtin_amdgcn_ballot_w64(!bfp_fast_ok(mb, wl)) == 0ull;
-      int code[EPL];
-      pack_codes<DTI, EPL>(raw[u], mb, wl, asym, fast, code);
-      if (v < n_vec) {
-        uint32_t w[EPL / 4];
-#pragma unroll
-        for (int j = 0; j < EPL / 4; j++)
-          w[j] = ((uint32_t)code[4 * j] & 0xFFu) | (((uint32_t)code[4 * j + 1] & 0xFFu) << 8) |
-                 (((uint32_t)code[4 * j + 2] & 0xFFu) << 16) | ((uint32_t)code[4 * j + 3] << 24);
-        if (EPL == 8) __builtin_nontemporal_store(u32x2{w[0], w[EPL / 4 - 1]}, (u32x2*)(mant + v * 8));
-        else __builtin_nontemporal_store(w[0], (uint32_t*)(mant + v * 4));
-        if (leader) exps[v >> lpb_log] = (uint8_t)((mb & 0x7F800000u) >> 23);
-      }
+      for (int j = 0; j < EPL / 4; j++)
+        w[j] = ((uint32_t)code[4 * j] & 0xFFu) | (((uint32_t)code[4 * j + 1] & 0xFFu) << 8) |
+               (((uint32_t)code[4 * j + 2] & 0xFFu) << 16) | ((uint32_t)code[4 * j + 3] << 24);
+      if (EPL == 8) __builtin_nontemporal_store(u32x2{w[0], w[EPL / 4 - 1]}, (u32x2*)(mant + v * 8));
+      else __builtin_nontemporal_store(w[0], (uint32_t*)(mant + v * 4));
+      if (in_blk == 0) exps[v >> lpb_log] = (uint8_t)Eb;
     }
   }
 }
@@ -187,12 +199,14 @@ extern "C" int dmxq_bfp_pack(const void* in, int dtype_in, int8_t* mant, uint8_t
   const int asym = symmetric ? 0 : 1;
   if (L % B == 0 && pow2 && B >= epl && B <= 64 * epl && aligned16(in) && (reinterpret_cast<uintptr_t>(mant) & 7u) == 0) {
     const int64_t n_vec = n / epl;
-    const int grid = grid_for((n_vec + 3) / 4);
+    const int64_t tiles = (n_vec + kPackThreads * kPackUnroll - 1) / (kPackThreads * kPackUnroll);
+    if (tiles > 0x7FFFFFFF) return DMXQ_ERR_UNSUPPORTED;
+    const unsigned grid = (unsigned)tiles;
     int lpb_log = 0;
     while (((int64_t)epl << lpb_log) < B) lpb_log++;
-    if (dtype_in == DMXQ_F32) DMXQ_LAUNCH(bfp_pack_rows_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
-    else if (dtype_in == DMXQ_F16) DMXQ_LAUNCH(bfp_pack_rows_kernel<DMXQ_F16>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
-    else DMXQ_LAUNCH(bfp_pack_rows_kernel<DMXQ_BF16>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
+    if (dtype_in == DMXQ_F32) DMXQ_LAUNCH(bfp_pack_rows_kernel<DMXQ_F32>, dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
+    else if (dtype_in == DMXQ_F16) DMXQ_LAUNCH(bfp_pack_rows_kernel<DMXQ_F16>, dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
+    else DMXQ_LAUNCH(bfp_pack_rows_kernel<DMXQ_BF16>, dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
   } else {
     const int grid = grid_for(rows * ((L + B - 1) / B));
     if (dtype_in == DMXQ_F32) DMXQ_LAUNCH(bfp_pack_generic_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, rows, L, B, precision, asym);
