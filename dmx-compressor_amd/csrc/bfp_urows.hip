@@ -52,7 +52,7 @@ __device__ __forceinline__ void store_unaligned(void* out, int64_t e, const floa
 template <int DTI, int DTO, int RND, bool ASYM, int FAST, int UNROLL>
 __global__ __launch_bounds__(kThreads) void bfp_urows_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                             int64_t rows, int64_t L, int nvr /*vectors per row*/,
-                                                            int nvrp /*... padded to whole blocks*/, int tail,
+                                                            int nvrp /*... padded to whole blocks*/, int tail, int back,
                                                             int lpb_arg, int wl, int rounding, uint64_t seed) {
   constexpr int EB = Elem<DTI>::bytes, EPL = 16 / EB;
   constexpr bool kFast = FAST != 0 && RND == DMXQ_ROUND_NEAREST;
@@ -63,7 +63,10 @@ __global__ __launch_bounds__(kThreads) void bfp_urows_kernel(const void* __restr
   const int64_t n_tiles = (total + TILE - 1) / TILE;
   const int dq = kThreads / nvrp, dr = kThreads % nvrp;  // (row, vector) step between a lane's consecutive vectors
   const int last = nvr - 1;
-  const bool has_tail = tail < EPL;                       // the last vector of a row is partial
+  // the last vector of a row is partial.  back > 0: it is read and written as the 16 bytes that END at the row end instead (its
+  // first `back` elements repeat the previous lane's last ones -- same block, same values, a benign duplicate store), so the
+  // row has no partial access at all; the host allows it when the ragged block holds a whole vector and out != in
+  const bool has_tail = tail < EPL && back == 0;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t u0 = tile * TILE + threadIdx.x;
     int64_t r = total < ((int64_t)1 << 31) ? (int64_t)((uint32_t)u0 / (uint32_t)nvrp) : u0 / nvrp;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(kThreads) void bfp_urows_kernel(const void* __restr
     for (int u = 0; u < UNROLL; u++) {
       const bool real = r < rows && v < nvr;
       part[u] = real && has_tail && v == last;
-      eoff[u] = real ? r * L + (int64_t)v * EPL : -1;
+      eoff[u] = real ? r * L + (int64_t)v * EPL - (v == last ? back : 0) : -1;
       // whole vectors: one 16-byte access at any alignment; everything else reads vector 0 of the tensor (in bounds,
       // discarded) so that the loads stay unconditional and are issued back to back
       const bool whole = real && !part[u];
@@ -95,10 +98,21 @@ __global__ __launch_bounds__(kThreads) void bfp_urows_kernel(const void* __restr
       const uint32_t mb = group_max_u32(absmax_bits<DTI>(raw[u]), lpb);
       float x[EPL];
       widen<DTI, EPL>(raw[u], x);
-      if (kFast && __builtin_amdgcn_ballot_w64(!bfp_fast_ok(mb, wl)) == 0ull) {
-        const BfpBlockParams p = bfp_block_params<ASYM, true>(mb, wl);
+      if constexpr (kFast) {
+        // magic-add form for every lane (straight-line), literal redo of the blocks it does not cover behind one cold branch
+        const bool ok = bfp_fast_ok(mb, wl);
+        {
+          const BfpBlockParams p = bfp_block_params<ASYM, true>(mb, wl);
 #pragma unroll
-        for (int k = 0; k < EPL; k++) y[u][k] = bfp_q1_fast<FAST == 2, ASYM>(x[k], p);
+          for (int k = 0; k < EPL; k++) y[u][k] = bfp_q1_fast<FAST == 2, ASYM>(x[k], p);
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ull, 0)) {
+          if (!ok) {
+            const BfpBlockParams p = bfp_block_params<ASYM, false>(mb, wl);
+#pragma unroll
+            for (int k = 0; k < EPL; k++) y[u][k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, 0u);
+          }
+        }
       } else {
         const BfpBlockParams p = bfp_block_params<ASYM, false>(mb, wl);
 #pragma unroll
@@ -129,12 +143,13 @@ static int launch_urows(const void* in, void* out, int64_t rows, int64_t L, int6
   const int lpb = (int)(B / EPL);
   const int64_t nvr = (L + EPL - 1) / EPL, nvrp = (nvr + lpb - 1) / lpb * lpb;
   const int tail = (int)(L - (nvr - 1) * EPL);  // 1..EPL elements in the last vector of a row
+  const int back = (tail < EPL && L % B >= EPL && in != out) ? EPL - tail : 0;
   const int64_t tiles = (rows * nvrp + (int64_t)kThreads * UNROLL - 1) / ((int64_t)kThreads * UNROLL);
   const int grid = (int)(tiles < (1 << 20) ? tiles : (1 << 20));
   const int fast = (RND == DMXQ_ROUND_NEAREST && wl <= 20) ? (bfp_single_rounding_ok<DTI>(wl) ? 2 : 1) : 0;
 #define DMXQ_UR(F_)                                                                                                \
   DMXQ_LAUNCH((bfp_urows_kernel<DTI, DTO, RND, ASYM, F_, UNROLL>), dim3(grid), dim3(kThreads), 0, s, in, out, \
-                     rows, L, (int)nvr, (int)nvrp, tail, lpb, wl, rounding, seed)
+                     rows, L, (int)nvr, (int)nvrp, tail, back, lpb, wl, rounding, seed)
   constexpr bool in16 = Elem<DTI>::bytes == 2;
   if constexpr (RND == kRuntimeRounding) {
     DMXQ_UR(0);

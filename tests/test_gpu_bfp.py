@@ -269,11 +269,17 @@ def test_inplace_through_the_c_abi(dmx, cuda, oracle):
     L = _lib.lib()
     vp = ctypes.c_void_p
     s = vp(torch.cuda.current_stream().cuda_stream)
-    for shape, dim, B in (((64, 512), -1, 16), ((4, 64, 48), 1, 16), ((7, 400), -1, 64), ((5, 84), -1, 24)):
+    # (37, 1500) / (9, 1004): rows that are not a whole number of 16-byte vectors (bfp_urows.hip), whose last vector is read as
+    # the 16 bytes ENDING at the row end when out != in -- and must NOT be when out == in (the overlap would re-read stored data)
+    for shape, dim, B in (((64, 512), -1, 16), ((4, 64, 48), 1, 16), ((7, 400), -1, 64), ((5, 84), -1, 24), ((37, 1500), -1, 64),
+                          ((37, 1500), -1, 16), ((9, 1004), -1, 16), ((300, 1500), -1, 64)):
         x = make("heavy", shape, seed=B, dtype=torch.bfloat16)
         want = oracle.bfp_cast(x, 8, B, dim).to(torch.bfloat16).contiguous()
         t = x.to(cuda).contiguous()
         outer, Ld, inner = _lib.split3(t.shape, dim)
+        o = torch.empty_like(t)
+        assert L.dmxq_bfp_qdq(vp(t.data_ptr()), vp(o.data_ptr()), _lib.BF16, _lib.BF16, outer, Ld, inner, B, 8, 2, 1, 0, s) == 0
+        assert bits_equal(o, want) == 0, ("out of place", shape, dim, B)
         assert L.dmxq_bfp_qdq(vp(t.data_ptr()), vp(t.data_ptr()), _lib.BF16, _lib.BF16, outer, Ld, inner, B, 8, 2, 1, 0, s) == 0
         assert bits_equal(t, want) == 0, (shape, dim, B)
     x = make("heavy", (1000,), seed=1)
