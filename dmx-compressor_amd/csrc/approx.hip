@@ -450,7 +450,10 @@ __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* _
     if (w) wr[i] = row_load_keep<DT, EPL>(w, c);
     if (b) br[i] = row_load_keep<DT, EPL>(b, c);
   }
+  int par = 0;  // RMSNorm: ONE barrier per iteration, so the exchange buffer alternates (a fast wave's next write must not overtake a slow wave's read)
   for (int64_t r0 = (int64_t)blockIdx.x * RPW; r0 < rows; r0 += (int64_t)gridDim.x * RPW) {
+    const int qb = RMS ? par : 1;
+    par ^= 1;
     RowVec<DT, EPL> raw[RPW][VPL];
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
@@ -468,20 +471,27 @@ __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* _
 #pragma unroll
       for (int i = 0; i < VPL; i++) {
         row_widen<DT, EPL>(raw[j][i], x[j][i]);
-        float u = 0.0f;
+        if constexpr (!RMS) {
+          float u = 0.0f;
 #pragma unroll
-        for (int k = 0; k < EPL; k++) u += x[j][i][k];
-        s += (i * kThreads + t < nv) ? u : 0.0f;
+          for (int k = 0; k < EPL; k++) u += x[j][i][k];
+          s += (i * kThreads + t < nv) ? u : 0.0f;
+        }
       }
-      s = seg_sum<kWave>(s);
-      if (lane == 0) red[0][j][wv] = s;
+      if constexpr (!RMS) {
+        s = seg_sum<kWave>(s);
+        if (lane == 0) red[0][j][wv] = s;
+      }
     }
-    __syncthreads();
+    if constexpr (!RMS) __syncthreads();  // RMSNorm has no centring pass: one exchange (and one barrier) per iteration, not two
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
-      float s = red[0][j][0];
+      float s = 0.0f;
+      if constexpr (!RMS) {
+        s = red[0][j][0];
 #pragma unroll
-      for (int k = 1; k < NW; k++) s += red[0][j][k];
+        for (int k = 1; k < NW; k++) s += red[0][j][k];
+      }
       mean[j] = RMS ? 0.0f : s * inv_n;
       float q = 0.0f;
 #pragma unroll
@@ -492,14 +502,14 @@ __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* _
         q += (i * kThreads + t < nv) ? u : 0.0f;
       }
       q = seg_sum<kWave>(q);
-      if (lane == 0) red[1][j][wv] = q;
+      if (lane == 0) red[qb][j][wv] = q;
     }
     __syncthreads();  // (also orders this iteration's reads of red[0] before the next iteration's writes)
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
-      float q = red[1][j][0];
+      float q = red[qb][j][0];
 #pragma unroll
-      for (int k = 1; k < NW; k++) q += red[1][j][k];
+      for (int k = 1; k < NW; k++) q += red[qb][j][k];
       rstd[j] = 1.0f / sqrtf(q * inv_n + eps);  // biased variance, as F.layer_norm
     }
 #pragma unroll
