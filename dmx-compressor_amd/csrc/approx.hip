@@ -212,17 +212,38 @@ __device__ __forceinline__ RowVec<DT, EPL> row_load_tail(const void* p, int64_t 
   return r;
 }
 
+// Sum / max over the LPR (64 or 32) adjacent lanes that own a row, every lane receiving the result.  Inside a row of 16 lanes: four
+// DPP steps (quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- VALU operand modifiers, no LDS); across the rows of 16: the four
+// row totals through v_readlane.  The SAME summation tree as an xor butterfly (so the same bits), which as `__shfl_xor` compiled
+// to five or six dependent ds_bpermute_b32 round trips through the LDS per reduction, two or three reductions per row.
+#define DMXQ_DPP_F32(v_, ctrl_) u2f((uint32_t)__builtin_amdgcn_update_dpp(0, (int)f2u(v_), ctrl_, 0xF, 0xF, false))
 template <int LPR>
 __device__ __forceinline__ float seg_sum(float v) {
-#pragma unroll
-  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  static_assert(LPR == 64 || LPR == 32, "rows are owned by 64 or 32 lanes");
+  v += DMXQ_DPP_F32(v, 0xB1);
+  v += DMXQ_DPP_F32(v, 0x4E);
+  v += DMXQ_DPP_F32(v, 0x141);
+  v += DMXQ_DPP_F32(v, 0x140);
+  const int b = (int)f2u(v);
+  const float r0 = u2f((uint32_t)__builtin_amdgcn_readlane(b, 0)), r1 = u2f((uint32_t)__builtin_amdgcn_readlane(b, 16));
+  const float r2 = u2f((uint32_t)__builtin_amdgcn_readlane(b, 32)), r3 = u2f((uint32_t)__builtin_amdgcn_readlane(b, 48));
+  const float lo = r0 + r1, hi = r2 + r3;
+  if (LPR == 64) return lo + hi;
+  return (threadIdx.x & 32) ? hi : lo;
 }
 template <int LPR>
 __device__ __forceinline__ float seg_max(float v) {
-#pragma unroll
-  for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  static_assert(LPR == 64 || LPR == 32, "rows are owned by 64 or 32 lanes");
+  v = fmaxf(v, DMXQ_DPP_F32(v, 0xB1));
+  v = fmaxf(v, DMXQ_DPP_F32(v, 0x4E));
+  v = fmaxf(v, DMXQ_DPP_F32(v, 0x141));
+  v = fmaxf(v, DMXQ_DPP_F32(v, 0x140));
+  const int b = (int)f2u(v);
+  const float r0 = u2f((uint32_t)__builtin_amdgcn_readlane(b, 0)), r1 = u2f((uint32_t)__builtin_amdgcn_readlane(b, 16));
+  const float r2 = u2f((uint32_t)__builtin_amdgcn_readlane(b, 32)), r3 = u2f((uint32_t)__builtin_amdgcn_readlane(b, 48));
+  const float lo = fmaxf(r0, r1), hi = fmaxf(r2, r3);
+  if (LPR == 64) return fmaxf(lo, hi);
+  return (threadIdx.x & 32) ? hi : lo;
 }
 // row slots per wave iteration: about 32 fp32 values per lane (occupancy beats bytes in flight per wave here: 64 was
 // 1-4 % slower on every shape of tools/bench_rows.py)
