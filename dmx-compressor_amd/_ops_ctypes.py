@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -145,6 +145,24 @@ def weight_hypernet(w, precision: int, block_size: int, symmetric: bool = True, 
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     check(rc, "dmxq_weight_hypernet")
+    return out
+
+
+def input_hypernet(x, sq_scale, precision: int, block_size: int, symmetric: bool = True):
+    """Fused SmoothQuant input scaling -> BFP input cast along the last dim (one launch): BFP_QDQ(x / sq_scale) in float32, the
+    dtype `a / scale` has in the reference (smoothquant.py:255-268).  None when the geometry is not fusable."""
+    xc = _prep(x, "input_hypernet")
+    L = xc.shape[-1] if xc.dim() else 1
+    rows = xc.numel() // max(L, 1)
+    sq = sq_scale.detach().to(device=xc.device, dtype=torch.float32).contiguous()
+    if sq.numel() != L:
+        return None
+    out = torch.empty(xc.shape, dtype=torch.float32, device=xc.device)
+    rc = lib().dmxq_input_hypernet(ptr(xc), dtype_code(xc.dtype), ptr(sq), ptr(out), dtype_code(torch.float32), rows, L, block_size,
+                                   precision, int(symmetric), stream_of(xc))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    check(rc, "dmxq_input_hypernet")
     return out
 
 

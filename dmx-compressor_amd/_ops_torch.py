@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import DmxqError, ROUNDING_CODE, require_gpu
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -141,6 +141,16 @@ def weight_hypernet(w, precision: int, block_size: int, symmetric: bool = True, 
     try:
         return _ops.weight_hypernet(w, precision, block_size, symmetric, score if M else None, K, M if score is not None else 0,
                                     sq_scale, out_dtype)
+    except NotImplementedError:
+        return None
+
+
+def input_hypernet(x, sq_scale, precision: int, block_size: int, symmetric: bool = True):
+    """Fused SmoothQuant input scaling -> BFP input cast along the last dim (one launch): BFP_QDQ(x / sq_scale) in float32, the
+    dtype `a / scale` has in the reference (smoothquant.py:255-268).  None when the geometry is not fusable."""
+    require_gpu(x, "input_hypernet")
+    try:
+        return _ops.input_hypernet(x, sq_scale, precision, block_size, symmetric)
     except NotImplementedError:
         return None
 

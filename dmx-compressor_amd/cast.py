@@ -266,7 +266,8 @@ class CastTo(HostFlags, torch.nn.Module):
 class CastToDict(torch.nn.ModuleDict):
     """Keyed collection of CastTo's applied to a module's positional / keyword tensors (cast.py:58-134)."""
 
-    def forward(self, x, *args, output=False, **kwargs):
+    def forward(self, x, *args, output=False, first_done=False, **kwargs):
+        """first_done: `x` already went through its cast (the fused input path of DmxModule.forward)."""
         keys = list(self.keys())
         if output:
             if isinstance(x, (tuple, list)):
@@ -282,7 +283,7 @@ class CastToDict(torch.nn.ModuleDict):
                 new_args.append(a)
         for k, v in kwargs.items():
             new_kwargs[k] = self[k + "_cast"](v) if isinstance(v, torch.Tensor) else v
-        return self[keys[0]](x), new_args, new_kwargs
+        return (x if first_done else self[keys[0]](x)), new_args, new_kwargs
 
     def pack_to_dict(self, param):
         keys = list(self.keys())

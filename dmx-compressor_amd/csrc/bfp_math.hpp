@@ -75,11 +75,13 @@ __device__ __forceinline__ BfpBlockParams bfp_block_params(uint32_t maxabs_bits,
 // may this block take the magic-add path?  M must be representable, and:
 // E == 0 with a non-zero (denormal) maximum: base = 0, so a negative x that rounds to zero keeps its sign in the
 // reference (-0.0) while the magic add yields +0.0 -> literal path.  All-zero blocks stay fast.
-// An Inf/NaN maximum (eb = 255; e.g. the -inf of an attention mask) is fine: the formulas produce the all-NaN block
-// by themselves, see bfp_block_params.
+// An Inf maximum (e.g. the -inf of an attention mask) is fine: the formulas produce the all-NaN block by themselves, see
+// bfp_block_params.  A NaN maximum is NOT: the reference rounds the mantissa bits of a NaN ELEMENT like any other value, so what
+// such an element becomes depends on its payload (0xFFFF0000 at wl = 4 carries into the exponent and comes out as -inf, the
+// canonical 0x7FC00000 stays NaN) -- only the literal bit path reproduces that.
 __device__ __forceinline__ bool bfp_fast_ok(uint32_t maxabs_bits, int wl) {
   const uint32_t eb = (maxabs_bits & 0x7F800000u) >> 23;
-  return (eb + 25u - (uint32_t)wl <= 254u || eb == 255u) && (eb != 0u || maxabs_bits == 0u);
+  return (eb + 25u - (uint32_t)wl <= 254u || maxabs_bits == 0x7F800000u) && (eb != 0u || maxabs_bits == 0u);
 }
 
 // literal bit path (every rounding mode)

@@ -55,10 +55,12 @@ struct HnArgs {
 // kernel of nm_mask.hip switches on runtime dtypes around each access and reached 48 % of roofline with a bf16 score).
 // LPBC: lanes per BFP block as a compile-time constant (0 = runtime a.lpb), see bfp_rows.hpp: the DPP block maximum is then
 // free of scalar branches.
-template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP, int LPBC, bool ASYM>
+// DIVIDE: the ACTIVATION path of a SmoothQuant module (dmxq_input_hypernet): x / scale instead of w * scale, the quotient kept in
+// torch's promotion of (x dtype, fp32 scale) = fp32, which is then also the dtype the BFP cast sees and hands back.
+template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP, int LPBC, bool ASYM, bool DIVIDE = false>
 __device__ __forceinline__ void hypernet_rows_body(const HnArgs& a) {
   // T1: dtype after the mask multiply = torch promotion of (w, score); without a mask it stays the weight dtype
-  constexpr int T1 = (M == 0) ? DTW : ((DTW == DMXQ_F32 || DTS == DMXQ_F32 || DTW != DTS) ? DMXQ_F32 : DTW);
+  constexpr int T1 = DIVIDE ? DMXQ_F32 : ((M == 0) ? DTW : ((DTW == DMXQ_F32 || DTS == DMXQ_F32 || DTW != DTS) ? DMXQ_F32 : DTW));
   const int lpb = LPBC > 0 ? LPBC : __builtin_amdgcn_readfirstlane(a.lpb);
   constexpr int UN = 4;  // units in flight per lane: all their loads are issued before the first one is ranked
   const int64_t stride = (int64_t)gridDim.x * kThreads;
@@ -109,7 +111,7 @@ __device__ __forceinline__ void hypernet_rows_body(const HnArgs& a) {
     }
     if (HAS_SCALE) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) x[k] = round_to<T1>(x[k] * sva[HAS_SCALE ? r : 0][k]);
+      for (int k = 0; k < 8; k++) x[k] = round_to<T1>(DIVIDE ? x[k] / sva[HAS_SCALE ? r : 0][k] : x[k] * sva[HAS_SCALE ? r : 0][k]);  // IEEE division (smoothquant.py:255-268)
     }
     if (!BFP) {
       store_vec<DTO, 8, true>(a.out, e0, x);
@@ -144,17 +146,17 @@ __device__ __forceinline__ void hypernet_rows_body(const HnArgs& a) {
   }
 }
 
-template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP = true>
+template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP = true, bool DIVIDE = false>
 __global__ __launch_bounds__(kThreads) void hypernet_rows_kernel(HnArgs a) {
   // BFP16_64 (8 lanes per block: the BASIC rule's weight format) gets the branch-free form; other block sizes the runtime one
   // symmetric / asymmetric codes: chosen once per launch as well, not once per unit
   const bool asym = BFP && __builtin_amdgcn_readfirstlane(a.asym) != 0;
   if (BFP && __builtin_amdgcn_readfirstlane(a.lpb) == 8) {
-    if (asym) hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 8, true>(a);
-    else hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 8, false>(a);
+    if (asym) hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 8, true, DIVIDE>(a);
+    else hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 8, false, DIVIDE>(a);
   } else {
-    if (asym) hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 0, true>(a);
-    else hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 0, false>(a);
+    if (asym) hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 0, true, DIVIDE>(a);
+    else hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 0, false, DIVIDE>(a);
   }
 }
 
@@ -227,4 +229,26 @@ extern "C" int dmxq_weight_hypernet(const void* w, int dtype_w, const void* scor
   DMXQ_DT(DMXQ_F32, DMXQ_F32, DMXQ_F32)
 #undef DMXQ_DT
   return DMXQ_ERR_UNSUPPORTED;
+}
+
+// The activation twin: SmoothQuant input scaling -> input cast in one pass over x[rows, L] (channels and BFP blocks along the
+// contiguous last dim): out = BFP_QDQ(x / sq_scale[c]) with the quotient in fp32 (torch's promotion of the input dtype and the fp32
+// scale: what `a / scale` yields in smoothquant.py:255-268 and what CastTo then takes as its physical dtype, cast.py:262,306).
+extern "C" int dmxq_input_hypernet(const void* x, int dtype_x, const float* sq_scale, void* out, int dtype_out, int64_t rows,
+                                   int64_t L, int64_t block_size, int precision, int symmetric, void* stream) {
+  if (!valid_dtype(dtype_x) || !valid_dtype(dtype_out) || rows < 0 || L < 0 || block_size < 1) return DMXQ_ERR_BAD_ARG;
+  const int64_t B = block_size;
+  if ((B & (B - 1)) != 0 || B < 8 || B > 512 || L % B != 0 || L % 8 != 0 || precision < 2 || precision > 20 || dtype_out != DMXQ_F32)
+    return DMXQ_ERR_UNSUPPORTED;
+  if (rows * L == 0) return DMXQ_OK;
+  if (!x || !out || !sq_scale) return DMXQ_ERR_BAD_ARG;
+  if (!aligned16(x) || !aligned16(out) || !aligned16(sq_scale)) return DMXQ_ERR_UNSUPPORTED;
+  const HnArgs a{x, nullptr, sq_scale, out, rows * L / 8, L, 0, (int)(B / 8), precision, symmetric ? 0 : 1,
+                 rows * L < ((int64_t)1 << 31) ? 1 : 0, make_fastdiv31(L)};
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = grid_for((a.n_units + 3) / 4);
+#define DMXQ_IH(W_) DMXQ_LAUNCH((hypernet_rows_kernel<W_, W_, DMXQ_F32, 0, true, true, true>), dim3(grid), dim3(kThreads), 0, s, a)
+  if (dtype_x == DMXQ_BF16) DMXQ_IH(DMXQ_BF16); else if (dtype_x == DMXQ_F16) DMXQ_IH(DMXQ_F16); else DMXQ_IH(DMXQ_F32);
+#undef DMXQ_IH
+  return launch_status();
 }

@@ -198,6 +198,20 @@ Tensor weight_hypernet_meta(const Tensor& w, int64_t, int64_t, bool, const OptTe
   return empty_like_shape(w, hypernet_dtype(w, score, M, out_dtype));
 }
 
+Tensor input_hypernet(const Tensor& x, const Tensor& sq_scale, int64_t precision, int64_t block_size, bool symmetric) {
+  const Tensor xc = prep(x, "input_hypernet");
+  const int64_t L = xc.dim() ? xc.size(-1) : 1;
+  const int64_t rows = L ? xc.numel() / L : 0;
+  const Tensor sq = sq_scale.detach().to(xc.device(), at::kFloat).contiguous();
+  TORCH_CHECK_NOT_IMPLEMENTED(sq.numel() == L, "input_hypernet: scale length differs from the channel count");
+  Tensor out = empty_like_shape(xc, at::kFloat);
+  Launch l(xc);
+  check(dmxq_input_hypernet(xc.data_ptr(), dt_code(xc.scalar_type()), (const float*)sq.data_ptr(), out.data_ptr(), dt_code(at::kFloat), rows,
+                            L, block_size, (int)precision, symmetric, l.stream), "dmxq_input_hypernet");
+  return out;
+}
+Tensor input_hypernet_meta(const Tensor& x, const Tensor&, int64_t, int64_t, bool) { return empty_like_shape(x, at::kFloat); }
+
 Tensor sbfp_qdq(const Tensor& x, int64_t precision, int64_t block_size, int64_t sman, int64_t sexp, int64_t sbias, bool sflush,
                 bool clamp, bool symmetric, int64_t block_dim, OptDtype out_dtype) {
   const Tensor xc = prep(x, "sbfp_qdq");
@@ -522,6 +536,7 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("bfp_pack(Tensor x, int precision, int block_size, bool symmetric=True) -> (Tensor, Tensor)");
   m.def("bfp_unpack(Tensor mant, Tensor exps, int precision, int block_size, ScalarType out_dtype) -> Tensor");
   m.def("weight_hypernet(Tensor w, int precision, int block_size, bool symmetric, Tensor? score, int K, int M, Tensor? sq_scale, ScalarType? out_dtype=None) -> Tensor");
+  m.def("input_hypernet(Tensor x, Tensor sq_scale, int precision, int block_size, bool symmetric) -> Tensor");
   m.def("sbfp_qdq(Tensor x, int precision, int block_size, int scaler_man, int scaler_exp, int scaler_bias, bool scaler_flush, bool clamp, bool symmetric, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
   m.def("mxfp_qdq(Tensor x, int man, int exp, int block_size, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
   m.def("float_qdq(Tensor x, int man, int exp, int bias, bool flush_subnormal, bool unsigned_abs=False, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");
@@ -545,7 +560,7 @@ TORCH_LIBRARY(dmxq, m) {
 #define DMXQ_IMPL(m, name) m.impl(#name, &name)
 #define DMXQ_META(m, name) m.impl(#name, &name##_meta)
 #define DMXQ_FOR_ALL(X, m) \
-  X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
+  X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, input_hypernet); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
   X(m, float_qdq); X(m, fixed_qdq); X(m, fixed_qdq_multi); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
   X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, rope); X(m, softmax); X(m, norm)
 

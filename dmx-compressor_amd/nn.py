@@ -322,13 +322,42 @@ class DmxModule(torch.nn.Module):
         yield self
         self.enable_smoothquant_calib(False, hyperparams)
 
+    #: use the single-kernel activation path (dmxq_input_hypernet) when the configuration allows it; results are bit-identical
+    fuse_input_hypernet = True
+
+    def _fused_input(self, x):
+        """SmoothQuant `x / scale` -> BFP input cast in ONE launch (6 B/element instead of 14 for a bf16 input), or None when this
+        configuration must take the two steps: inference only, channels and blocks along the last dim, plain BFP input format
+        with nearest rounding, no observer / pre-transform on the input cast."""
+        from .format import BlockFloatingPoint
+        sq = self.smoothquant
+        if (not self.fuse_input_hypernet or not sq._flag("enabled") or not isinstance(x, torch.Tensor) or not x.is_floating_point()
+                or x.dim() == 0 or sq.ch_axis not in (-1, x.dim() - 1) or torch.is_grad_enabled() and x.requires_grad
+                or torch.compiler.is_compiling()):
+            return None
+        ic = self.input_casts[next(iter(self.input_casts.keys()))] if len(self.input_casts) else None
+        if ic is None:
+            return None
+        fmt = ic.format
+        if (not isinstance(fmt, BlockFloatingPoint) or fmt.rounding != "nearest" or fmt.block_size < 8 or ic.pre_transform
+                or ic.block_dim not in (-1, x.dim() - 1) or not ic._flag("fake_quant_enabled") or ic._flag("observer_enabled")):
+            return None
+        from . import ops
+        return ops.input_hypernet(x.detach(), sq.scale, fmt.precision, fmt.block_size, fmt.symmetric)
+
     def forward(self, input, *args, **kwargs):
         _dtype = input.dtype
+        fused = None
         if self.smoothquant is not None:
             if self.smoothquant._flag("dynamic") or self.smoothquant.calibrating:
                 self.update_smoothquant_scale(input)
-            input = self.smoothquant.scale_input(input)
-        _input, args, kwargs = self.input_casts(input, *args, **kwargs)
+            fused = self._fused_input(input)
+            if fused is None:
+                input = self.smoothquant.scale_input(input)
+        if fused is not None:
+            _input, args, kwargs = self.input_casts(fused, *args, first_done=True, **kwargs)
+        else:
+            _input, args, kwargs = self.input_casts(input, *args, **kwargs)
         _output = self._forward(_input, *args, **kwargs)
         output = self.output_casts(_output, output=True)
         if self.align_boundary_dtype:

@@ -194,6 +194,16 @@ int dmxq_weight_hypernet(const void* w, int dtype_w, const void* score, int dtyp
                          const float* sq_scale, void* out, int dtype_out, int64_t rows, int64_t L, int64_t block_size,
                          int precision, int symmetric, void* stream);
 
+/* The activation twin of the fused weight path: SmoothQuant input scaling -> BFP input cast in one pass over x[rows, L]
+ * (channels and blocks along the contiguous last dim).  out = BFP_QDQ(x / sq_scale[c]); the quotient is an IEEE fp32 division
+ * and stays fp32 -- torch's promotion of (input dtype, fp32 scale), i.e. what `a / scale` returns in
+ * numerical/smoothquant.py:255-268 -- which is then the dtype CastTo sees and returns (numerical/cast.py:262,306), so
+ * dtype_out must be DMXQ_F32.  Replaces the first two steps of DmxModule.forward (modeling/nn/core.py:228-232:
+ * smoothquant.scale_input -> input_casts) for Linear-layout modules: 6 B/element (bf16 in) instead of 14 (2+4, then 4+4).
+ * Bit-identical to dmxq_scale_channels(divide) followed by dmxq_bfp_qdq.  DMXQ_ERR_UNSUPPORTED as dmxq_weight_hypernet. */
+int dmxq_input_hypernet(const void* x, int dtype_x, const float* sq_scale, void* out, int dtype_out, int64_t rows, int64_t L,
+                        int64_t block_size, int precision, int symmetric, void* stream);
+
 /* Approximator-slot ops.  The reference evaluates the exact torch.nn.functional op and then overwrites it with a
  * vsimd approximation that lives in a private package (functional/approximate.py:9-14, 300-327); with vsimd
  * absent (the public reference) the exact function is the result, and that is what these compute, in fp32.

@@ -238,6 +238,38 @@ def test_inf_nan_poison_the_block_like_the_reference(dmx, cuda, oracle, dtype):
         assert int(torch.isnan(got).sum()) == (4 * B if B != 24 else int(torch.isnan(want).sum()))
 
 
+def test_nan_payloads_in_nan_and_inf_blocks(dmx, cuda, oracle):
+    """The reference rounds the mantissa bits of a NaN element like any other value: what it becomes depends on its PAYLOAD (and on
+    wl).  Every row geometry (tile plans by size, ragged rows, column blocks), NaNs of several payloads and signs next to Inf and
+    finite values, against the oracle (bit for bit, any NaN == any NaN: the payload of a NaN RESULT is the host FPU's)."""
+    payloads = [0x7FC00000, 0xFFC00000, 0x7F800001, 0x7FFFFFFF, 0xFFFF0000, 0x7FA00000, 0xFF812345, 0x7FC00001]
+    for shape, dim in (((1, 128), -1), ((3, 50, 256), -1), ((64, 4096), -1), ((37, 1500), -1), ((128, 96), 0), ((5, 84), -1)):
+        x = make("heavy", shape, seed=21).clamp(-1e4, 1e4)
+        flat = x.view(-1).view(torch.int32)
+        n = flat.numel()
+        for i, pl in enumerate(payloads):
+            flat[(i * 997 + 3) % n] = pl - (1 << 32) if pl >= (1 << 31) else pl
+        x.view(-1)[(5 * 997) % n] = float("inf")
+        x.view(-1)[(11 * 997 + 1) % n] = float("-inf")
+        for wl in (4, 8, 12):
+            for B in (16, 64, 128):
+                for sym in (True, False):
+                    got = dmx.ops.bfp_qdq(x.to(cuda), wl, B, dim, sym).cpu()
+                    want = oracle.bfp_cast(x, wl, B, dim, sym)
+                    assert mismatches_nan_aware(got, want) == 0, (shape, dim, wl, B, sym)
+    # 16-bit inputs carry 7 / 10 payload bits
+    for dt, pats in ((torch.bfloat16, [0x7FC0, 0xFFC0, 0x7F81, 0x7FFF, 0xFFFF, 0xFFA0]), (torch.float16, [0x7E00, 0xFE00, 0x7C01, 0x7FFF, 0xFFFF, 0xFD55])):
+        x = make("heavy", (40, 512), seed=22).clamp(-1e4, 1e4).to(dt)
+        flat = x.view(-1).view(torch.int16)
+        for i, pl in enumerate(pats):
+            flat[(i * 991 + 7) % flat.numel()] = pl - (1 << 16) if pl >= (1 << 15) else pl
+        for wl in (4, 8):
+            for B in (16, 64):
+                got = dmx.ops.bfp_qdq(x.to(cuda), wl, B, -1, True, out_dtype=torch.float32).cpu()
+                want = oracle.bfp_cast(x, wl, B, -1, True)
+                assert mismatches_nan_aware(got, want) == 0, (dt, wl, B)
+
+
 def test_inplace_and_noncontiguous(dmx, cuda, oracle):
     x = make("normal", (64, 96), seed=2, dtype=torch.bfloat16)
     xt = x.t()  # non-contiguous view

@@ -133,6 +133,11 @@ def main():
         lambda i: L.dmxq_weight_hypernet(vp(xs[i].data_ptr()), _lib.BF16, vp(ss[i % k2].data_ptr()), _lib.F32, 2, 4, vp(sq.data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, R, C, 64, 8, 1, sp), k2, n * 8)
     run("weight_hypernet dense + SmoothQuant scale + BFP16_64, bf16 -> bf16",
         lambda i: L.dmxq_weight_hypernet(vp(xs[i].data_ptr()), _lib.BF16, None, 0, 0, 0, vp(sq.data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, R, C, 64, 8, 1, sp), k, n * 4)
+    run("input_hypernet SmoothQuant x / s + BFP16_64, bf16 -> fp32 (vs scale_channels + bfp_qdq: 14 B/elem)",
+        lambda i: L.dmxq_input_hypernet(vp(xs[i].data_ptr()), _lib.BF16, vp(sq.data_ptr()), vp(yf[i % k2].data_ptr()), _lib.F32, R, C, 64, 8, 1, sp), k2, n * 6)
+    run("  the two launches it replaces: scale_channels bf16 -> fp32, then bfp_qdq fp32 -> fp32",
+        lambda i: (L.dmxq_scale_channels(vp(xs[i].data_ptr()), vp(yf[i % k2].data_ptr()), _lib.BF16, _lib.F32, R, C, 1, vp(sq.data_ptr()), 1, sp),
+                   L.dmxq_bfp_qdq(vp(yf[i % k2].data_ptr()), vp(yf[(i + 1) % k2].data_ptr()), _lib.F32, _lib.F32, R, C, 1, 64, 8, 2, 1, 0, sp)), k2, n * 6)
     ws = torch.empty(L.dmxq_topk_workspace_bytes(n) // 8 + 1, dtype=torch.int64, device=dev)
     run("topk_sparsify TOPK{0.5} fp32 score, bf16 x -> bf16 y (radix select + apply; 4 score reads)",
         lambda i: L.dmxq_topk_mask(vp(ss[i % k2].data_ptr()), _lib.F32, vp(xs[i].data_ptr()), _lib.BF16, None, 0, vp(ys[i].data_ptr()), _lib.BF16, n, n // 2, vp(ws.data_ptr()), sp), k2, n * 8)
