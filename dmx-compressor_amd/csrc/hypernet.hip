@@ -13,6 +13,7 @@
 //   BFP nearest-even on the T1 value (bfp_math.hpp), result rounded to T1, then to dtype_out (`.to(input dtype)`).
 // Scope: inner == 1, L % B == 0, B = 2^k in [8, 512], L % 8 == 0, M in {0 (dense), 2, 4, 8}, nearest rounding.
 #include "bfp_math.hpp"
+#include "bfp_rows.hpp"
 
 namespace dmxq {
 
@@ -170,6 +171,77 @@ static int launch_hn(const HnArgs& a, int M, bool has_scale, hipStream_t s) {
   return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Activation path (dmxq_input_hypernet): x / scale[c] -> BFP, tiled like the hot kernel (bfp_rows.hpp).  A lane owns 4 ELEMENTS
+// per vector -- 8 bytes of a 16-bit input, 16 of an fp32 one -- so that every fp32 store instruction of a wave covers one contiguous
+// KiB (two strided 16-byte halves per lane cost ~40 % of the bandwidth, bfp_rows.hpp).  The quotients (IEEE fp32 divisions: they
+// ARE the result, common.hpp's reciprocal form does not apply) replace the raw vector in registers and from there on the tile is
+// an fp32 -> fp32 tile of bfp_rows_vector: block maximum by DPP, magic-add codes (double rounding) with a cold literal redo.
+// The 4 scales of a vector are requested BEFORE the tile's own loads (vector memory returns in order).
+constexpr int kInThreads = 256, kInUnroll = 2;  // measured on 4096x4096 bf16: 256x8 21.6, 256x4 21.1, 256x2 19.5, 512x2 20.6 us (the IEEE divisions make this VALU-heavy: small tiles stagger)
+struct InArgs {
+  const void* x; const float* scale; void* out;
+  int64_t n_vec, L;   // 4-element vectors
+  int lpb, wl, asym, small;
+  FastDiv31 f_L;
+};
+template <int DTX, bool ASYM, int LPBC>
+__device__ __forceinline__ void input_rows_tile(const InArgs& a) {
+  constexpr int U = kInUnroll, T = kInThreads;
+  constexpr int IVB = 4 * Elem<DTX>::bytes;  // 8 or 16 input bytes per lane-vector
+  const int lpb = LPBC > 0 ? LPBC : __builtin_amdgcn_readfirstlane(a.lpb);
+  const int in_blk = threadIdx.x & (lpb - 1);
+  const int64_t base = (int64_t)blockIdx.x * (T * U) + threadIdx.x;
+  f32x4 sc[U];
+  int64_t vc[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int64_t v = base + u * T;
+    vc[u] = v < a.n_vec ? v : a.n_vec - lpb + in_blk;  // past the end: the same lane position of the last block (not stored)
+    const int64_t e = vc[u] * 4;
+    const int64_t c = a.small ? (int64_t)((uint32_t)e - a.f_L.div((uint32_t)e) * (uint32_t)a.L) : e % a.L;
+    sc[u] = *(const f32x4*)(a.scale + c);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  u32x4 raw[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) raw[u] = load_rawv<IVB>((const char*)a.x + vc[u] * IVB, 0u);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    float xw[16 / Elem<DTX>::bytes];
+    widen<DTX, 16 / Elem<DTX>::bytes>(raw[u], xw);
+    u32x4 q;
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = f2u(xw[k] / sc[u][k]);  // smoothquant.py:255-268 `a / scale`, fp32
+    const uint32_t mb = group_max_u32(absmax_bits<DMXQ_F32>(q), lpb);
+    const bool ok = bfp_fast_ok(mb, a.wl);
+    OutVec<DMXQ_F32, 4> o = bfp_rows_vector<DMXQ_F32, DMXQ_F32, DMXQ_ROUND_NEAREST, ASYM, 1, true, 4>(q, mb, 0, a.wl, DMXQ_ROUND_NEAREST, false, 0ull);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ull, 0)) {
+      if (!ok) o = bfp_rows_vector<DMXQ_F32, DMXQ_F32, DMXQ_ROUND_NEAREST, ASYM, 1, false, 4>(q, mb, 0, a.wl, DMXQ_ROUND_NEAREST, false, 0ull);
+    }
+    raw[u] = u32x4{o.w[0], o.w[1], o.w[2], o.w[3]};
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int64_t v = base + u * T;
+    if (v < a.n_vec) __builtin_nontemporal_store(raw[u], (u32x4*)((char*)a.out + v * 16));
+  }
+}
+template <int DTX>
+__global__ __launch_bounds__(kInThreads) void input_rows_kernel(InArgs a) {
+  const int lpb = __builtin_amdgcn_readfirstlane(a.lpb);
+  const bool asym = __builtin_amdgcn_readfirstlane(a.asym) != 0;
+#define DMXQ_IN(L_) do { if (asym) input_rows_tile<DTX, true, L_>(a); else input_rows_tile<DTX, false, L_>(a); } while (0)
+  switch (lpb) {  // the usual block sizes with a compile-time lane count (branch-free DPP maxima), as bfp_rows_kernel
+    case 4: DMXQ_IN(4); break;
+    case 16: DMXQ_IN(16); break;
+    default: DMXQ_IN(0); break;
+  }
+#undef DMXQ_IN
+}
+
 }  // namespace dmxq
 
 using namespace dmxq;
@@ -243,9 +315,20 @@ extern "C" int dmxq_input_hypernet(const void* x, int dtype_x, const float* sq_s
   if (rows * L == 0) return DMXQ_OK;
   if (!x || !out || !sq_scale) return DMXQ_ERR_BAD_ARG;
   if (!aligned16(x) || !aligned16(out) || !aligned16(sq_scale)) return DMXQ_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (B / 4 <= 64) {  // the tiled kernel: a block = B / 4 adjacent lanes of one wave
+    const int64_t n_vec = rows * L / 4, tiles = (n_vec + kInThreads * kInUnroll - 1) / (kInThreads * kInUnroll);
+    if (tiles <= 0x7FFFFFFF) {
+      const InArgs ia{x, sq_scale, out, n_vec, L, (int)(B / 4), precision, symmetric ? 0 : 1, rows * L < ((int64_t)1 << 31) ? 1 : 0,
+                      make_fastdiv31(L)};
+      if (dtype_x == DMXQ_BF16) DMXQ_LAUNCH(input_rows_kernel<DMXQ_BF16>, dim3((unsigned)tiles), dim3(kInThreads), 0, s, ia);
+      else if (dtype_x == DMXQ_F16) DMXQ_LAUNCH(input_rows_kernel<DMXQ_F16>, dim3((unsigned)tiles), dim3(kInThreads), 0, s, ia);
+      else DMXQ_LAUNCH(input_rows_kernel<DMXQ_F32>, dim3((unsigned)tiles), dim3(kInThreads), 0, s, ia);
+      return launch_status();
+    }
+  }
   const HnArgs a{x, nullptr, sq_scale, out, rows * L / 8, L, 0, (int)(B / 8), precision, symmetric ? 0 : 1,
                  rows * L < ((int64_t)1 << 31) ? 1 : 0, make_fastdiv31(L)};
-  hipStream_t s = (hipStream_t)stream;
   const int grid = grid_for((a.n_units + 3) / 4);
 #define DMXQ_IH(W_) DMXQ_LAUNCH((hypernet_rows_kernel<W_, W_, DMXQ_F32, 0, true, true, true>), dim3(grid), dim3(kThreads), 0, s, a)
   if (dtype_x == DMXQ_BF16) DMXQ_IH(DMXQ_BF16); else if (dtype_x == DMXQ_F16) DMXQ_IH(DMXQ_F16); else DMXQ_IH(DMXQ_F32);
