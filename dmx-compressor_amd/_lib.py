@@ -31,6 +31,7 @@ SIGNATURES = {
     "dmxq_bfp_unpack": [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp],
     "dmxq_weight_hypernet": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_input_hypernet": [_vp, _i32, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
+    "dmxq_binary_cast": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
     "dmxq_float_qdq": [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _u64, _vp],
     "dmxq_fixed_qdq": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _u64, _vp],
     "dmxq_fixed_qdq_multi": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _u64, _vp],
@@ -56,6 +57,11 @@ SIGNATURES = {
 class TensorDesc(ctypes.Structure):
     """dmxq_tensor_desc (include/dmxq.h)"""
     _fields_ = [("in_", _vp), ("out", _vp), ("outer", _i64), ("L", _i64), ("inner", _i64)]
+
+
+class FloatFmt(ctypes.Structure):
+    """dmxq_float_fmt (include/dmxq.h)"""
+    _fields_ = [("man_bits", _i32), ("exp_bits", _i32), ("exp_bias", _i32), ("flush_subnormal", _i32)]
 
 
 class AffineDesc(ctypes.Structure):

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -163,6 +163,27 @@ def input_hypernet(x, sq_scale, precision: int, block_size: int, symmetric: bool
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     check(rc, "dmxq_input_hypernet")
+    return out
+
+
+def binary_cast(a, b, op: str, cast_a=None, cast_b=None, cast_out=None):
+    """A binary DmxModule in one launch: cast_out(cast_a(a) op cast_b(b)), op in {"add", "mul"}; each cast is a FloatingPoint
+    format (nearest, signed) or None = SAME.  None when not fusable (the caller runs the casts and the op one by one)."""
+    ac, bc = _prep(a, "binary_cast"), _prep(b, "binary_cast")
+    if ac.shape != bc.shape or ac.dtype != bc.dtype or ac.device != bc.device:
+        return None
+    structs = []
+    for f in (cast_a, cast_b, cast_out):
+        if f is not None and (f.rounding != "nearest" or f.unsigned):
+            return None
+        structs.append(None if f is None else _lib.FloatFmt(int(f.mantissa), int(f.exponent), int(f.bias), int(bool(f.flush_subnormal))))
+    out = torch.empty_like(ac)
+    import ctypes
+    ptrs = [ctypes.cast(ctypes.pointer(st), ctypes.c_void_p) if st is not None else None for st in structs]
+    rc = lib().dmxq_binary_cast(ptr(ac), ptr(bc), ptr(out), dtype_code(ac.dtype), ac.numel(), {"add": 0, "mul": 1}[op], *ptrs, stream_of(ac))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    check(rc, "dmxq_binary_cast")
     return out
 
 

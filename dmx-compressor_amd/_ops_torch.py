@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import DmxqError, ROUNDING_CODE, require_gpu
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -151,6 +151,23 @@ def input_hypernet(x, sq_scale, precision: int, block_size: int, symmetric: bool
     require_gpu(x, "input_hypernet")
     try:
         return _ops.input_hypernet(x, sq_scale, precision, block_size, symmetric)
+    except NotImplementedError:
+        return None
+
+
+def _fmt4(f):
+    return [] if f is None else [int(f.mantissa), int(f.exponent), int(f.bias), int(bool(f.flush_subnormal))]
+
+
+def binary_cast(a, b, op: str, cast_a=None, cast_b=None, cast_out=None):
+    """A binary DmxModule in one launch: cast_out(cast_a(a) op cast_b(b)), op in {"add", "mul"}; each cast is a FloatingPoint
+    format (nearest, signed) or None = SAME.  None when not fusable (the caller runs the casts and the op one by one)."""
+    require_gpu(a, "binary_cast")
+    for f in (cast_a, cast_b, cast_out):
+        if f is not None and (f.rounding != "nearest" or f.unsigned):
+            return None
+    try:
+        return _ops.binary_cast(a, b, {"add": 0, "mul": 1}[op], _fmt4(cast_a), _fmt4(cast_b), _fmt4(cast_out))
     except NotImplementedError:
         return None
 

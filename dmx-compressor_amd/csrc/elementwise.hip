@@ -640,6 +640,71 @@ extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype
   return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<kRuntimeRounding>{f, make_float_fast(f.man, f.exp_bits, f.bias)}, s);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Binary module in one pass (dmxq_binary_cast): out = cast_out(cast_a(a) (+|*) cast_b(b)) on bf16 tensors whose casts are
+// range-only (the FLOAT16-style formats of the BASIC rules: range16_word above).  Replaces the four launches of a ResAdd / Mul
+// DmxModule (modeling/nn/core.py:228-264: two input casts, the torch op, the output cast): 6 B/element instead of 18.
+// The op itself is torch's: fp32 arithmetic on the widened operands, one RNE rounding to bf16.
+static bool range16_of(const dmxq_float_fmt* f, Range16* r) {  // false: this format is not a range-only cast of bf16 values
+  if (!f || f->exp_bits == 0) { *r = Range16{0xFFFFFFFFu, 0u}; return true; }  // SAME: identity
+  if (f->exp_bits < 1 || f->exp_bits > 8 || f->man_bits < 7 || f->man_bits > 22 || !f->flush_subnormal) return false;
+  const int min_exp = -(f->exp_bias - 1), max_e = (1 << (f->exp_bits - 1)) + 127;
+  if (min_exp < -126 || min_exp > 127) return false;
+  const uint32_t limit = max_e >= 255 ? 0xFFFFu : (f->man_bits > 7 ? (uint32_t)(max_e + 1) << 7 : ((uint32_t)max_e << 7) | 0x7Fu);
+  const uint32_t minb = (uint32_t)(127 + min_exp) << 7;
+  *r = Range16{limit | (limit << 16), minb | (minb << 16)};
+  return true;
+}
+struct BinArgs { const void* a; const void* b; void* out; int64_t n_vec; Range16 ra, rb, ro; };
+template <int OP, int T, int U>
+__global__ __launch_bounds__(T) void binary_range_bf16_kernel(const BinArgs g) {
+  constexpr int64_t TILE = (int64_t)T * U;
+  const int64_t base = (int64_t)blockIdx.x * TILE + threadIdx.x;
+  u32x4 ra[U], rb[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int64_t v = base + u * T < g.n_vec ? base + u * T : g.n_vec - 1;  // clamped: unconditional loads
+    ra[u] = load_raw16<true>(g.a, v * 16);
+    rb[u] = load_raw16<true>(g.b, v * 16);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t wa = range16_word(ra[u][j], g.ra), wb = range16_word(rb[u][j], g.rb);
+      const float a0 = u2f(wa << 16), a1 = u2f(wa & 0xFFFF0000u), b0 = u2f(wb << 16), b1 = u2f(wb & 0xFFFF0000u);
+      const float c0 = OP == 0 ? a0 + b0 : a0 * b0, c1 = OP == 0 ? a1 + b1 : a1 * b1;
+      ra[u][j] = range16_word(pack2<DMXQ_BF16>(c0, c1), g.ro);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int64_t v = base + u * T;
+    if (v < g.n_vec) __builtin_nontemporal_store(ra[u], (u32x4*)((char*)g.out + v * 16));
+  }
+}
+
+extern "C" int dmxq_binary_cast(const void* a, const void* b, void* out, int dtype, int64_t n, int op, const dmxq_float_fmt* cast_a,
+                                const dmxq_float_fmt* cast_b, const dmxq_float_fmt* cast_out, void* stream) {
+  if (!valid_dtype(dtype) || n < 0 || (op != DMXQ_BINARY_ADD && op != DMXQ_BINARY_MUL)) return DMXQ_ERR_BAD_ARG;
+  if (n == 0) return DMXQ_OK;
+  if (!a || !b || !out) return DMXQ_ERR_BAD_ARG;
+  BinArgs g{a, b, out, n / 8, {}, {}, {}};
+  if (dtype != DMXQ_BF16 || n % 8 != 0 || !aligned16(a) || !aligned16(b) || !aligned16(out) || !range16_of(cast_a, &g.ra) ||
+      !range16_of(cast_b, &g.rb) || !range16_of(cast_out, &g.ro))
+    return DMXQ_ERR_UNSUPPORTED;
+  constexpr int T = 256, U = 4;
+  const int64_t tiles = (g.n_vec + T * U - 1) / (T * U);
+  if (tiles > 0x7FFFFFFF) return DMXQ_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (op == DMXQ_BINARY_ADD) DMXQ_LAUNCH((binary_range_bf16_kernel<0, T, U>), dim3((unsigned)tiles), dim3(T), 0, s, g);
+  else DMXQ_LAUNCH((binary_range_bf16_kernel<1, T, U>), dim3((unsigned)tiles), dim3(T), 0, s, g);
+  return launch_status();
+}
+
 #endif  // part 1a
 #if DMXQ_EW(2)
 extern "C" int dmxq_fixed_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t C,

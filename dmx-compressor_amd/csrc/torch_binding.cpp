@@ -212,6 +212,28 @@ Tensor input_hypernet(const Tensor& x, const Tensor& sq_scale, int64_t precision
 }
 Tensor input_hypernet_meta(const Tensor& x, const Tensor&, int64_t, int64_t, bool) { return empty_like_shape(x, at::kFloat); }
 
+// a cast as [man_bits, exp_bits, exp_bias, flush_subnormal]; empty = SAME
+static const dmxq_float_fmt* fmt_of(at::IntArrayRef v, dmxq_float_fmt* slot) {
+  if (v.empty()) return nullptr;
+  TORCH_CHECK(v.size() == 4, "binary_cast: a cast is [man_bits, exp_bits, exp_bias, flush_subnormal]");
+  *slot = dmxq_float_fmt{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+  return slot;
+}
+Tensor binary_cast(const Tensor& a, const Tensor& b, int64_t op, at::IntArrayRef cast_a, at::IntArrayRef cast_b, at::IntArrayRef cast_out) {
+  const Tensor ac = prep(a, "binary_cast"), bc = prep(b, "binary_cast");
+  TORCH_CHECK_NOT_IMPLEMENTED(ac.sizes() == bc.sizes() && ac.scalar_type() == bc.scalar_type() && ac.device() == bc.device(),
+                              "binary_cast: operands must share shape, dtype and device (no broadcasting)");
+  Tensor out = empty_like_shape(ac, ac.scalar_type());
+  dmxq_float_fmt fa, fb, fo;
+  Launch l(ac);
+  check(dmxq_binary_cast(ac.data_ptr(), bc.data_ptr(), out.data_ptr(), dt_code(ac.scalar_type()), ac.numel(), (int)op, fmt_of(cast_a, &fa),
+                         fmt_of(cast_b, &fb), fmt_of(cast_out, &fo), l.stream), "dmxq_binary_cast");
+  return out;
+}
+Tensor binary_cast_meta(const Tensor& a, const Tensor&, int64_t, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef) {
+  return empty_like_shape(a, a.scalar_type());
+}
+
 Tensor sbfp_qdq(const Tensor& x, int64_t precision, int64_t block_size, int64_t sman, int64_t sexp, int64_t sbias, bool sflush,
                 bool clamp, bool symmetric, int64_t block_dim, OptDtype out_dtype) {
   const Tensor xc = prep(x, "sbfp_qdq");
@@ -537,6 +559,7 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("bfp_unpack(Tensor mant, Tensor exps, int precision, int block_size, ScalarType out_dtype) -> Tensor");
   m.def("weight_hypernet(Tensor w, int precision, int block_size, bool symmetric, Tensor? score, int K, int M, Tensor? sq_scale, ScalarType? out_dtype=None) -> Tensor");
   m.def("input_hypernet(Tensor x, Tensor sq_scale, int precision, int block_size, bool symmetric) -> Tensor");
+  m.def("binary_cast(Tensor a, Tensor b, int op, int[] cast_a, int[] cast_b, int[] cast_out) -> Tensor");
   m.def("sbfp_qdq(Tensor x, int precision, int block_size, int scaler_man, int scaler_exp, int scaler_bias, bool scaler_flush, bool clamp, bool symmetric, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
   m.def("mxfp_qdq(Tensor x, int man, int exp, int block_size, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
   m.def("float_qdq(Tensor x, int man, int exp, int bias, bool flush_subnormal, bool unsigned_abs=False, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");
@@ -560,7 +583,7 @@ TORCH_LIBRARY(dmxq, m) {
 #define DMXQ_IMPL(m, name) m.impl(#name, &name)
 #define DMXQ_META(m, name) m.impl(#name, &name##_meta)
 #define DMXQ_FOR_ALL(X, m) \
-  X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, input_hypernet); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
+  X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, input_hypernet); X(m, binary_cast); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
   X(m, float_qdq); X(m, fixed_qdq); X(m, fixed_qdq_multi); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
   X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, rope); X(m, softmax); X(m, norm)
 

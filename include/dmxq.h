@@ -204,6 +204,18 @@ int dmxq_weight_hypernet(const void* w, int dtype_w, const void* score, int dtyp
 int dmxq_input_hypernet(const void* x, int dtype_x, const float* sq_scale, void* out, int dtype_out, int64_t rows, int64_t L,
                         int64_t block_size, int precision, int symmetric, void* stream);
 
+/* A binary DmxModule (ResAdd, Mul) in one pass: out = cast_out(cast_a(a) op cast_b(b)), all three tensors of one dtype, the op
+ * evaluated as torch does (fp32 arithmetic on the widened operands, one RNE rounding to the tensor dtype).  Replaces the four
+ * launches of modeling/nn/core.py:228-264 for such a module (CastToDict.forward on both inputs, numerical/cast.py:59-86; the op;
+ * the output cast): 6 B/element instead of 18.  A cast is described by its FloatingPoint format (numerical/format.py:174-233,
+ * nearest rounding, signed); NULL or exp_bits == 0 = SAME.  Fused only when every cast is RANGE-ONLY for the tensor dtype (bf16
+ * tensors, man_bits >= 7, subnormals flushed: the FLOAT16-style formats of the BASIC rules); anything else returns
+ * DMXQ_ERR_UNSUPPORTED and the caller runs the unfused ops.  Bit-identical to that chain. */
+typedef struct { int man_bits, exp_bits, exp_bias, flush_subnormal; } dmxq_float_fmt;
+enum { DMXQ_BINARY_ADD = 0, DMXQ_BINARY_MUL = 1 };
+int dmxq_binary_cast(const void* a, const void* b, void* out, int dtype, int64_t n, int op, const dmxq_float_fmt* cast_a,
+                     const dmxq_float_fmt* cast_b, const dmxq_float_fmt* cast_out, void* stream);
+
 /* Approximator-slot ops.  The reference evaluates the exact torch.nn.functional op and then overwrites it with a
  * vsimd approximation that lives in a private package (functional/approximate.py:9-14, 300-327); with vsimd
  * absent (the public reference) the exact function is the result, and that is what these compute, in fp32.

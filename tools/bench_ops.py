@@ -138,6 +138,15 @@ def main():
     run("  the two launches it replaces: scale_channels bf16 -> fp32, then bfp_qdq fp32 -> fp32",
         lambda i: (L.dmxq_scale_channels(vp(xs[i].data_ptr()), vp(yf[i % k2].data_ptr()), _lib.BF16, _lib.F32, R, C, 1, vp(sq.data_ptr()), 1, sp),
                    L.dmxq_bfp_qdq(vp(yf[i % k2].data_ptr()), vp(yf[(i + 1) % k2].data_ptr()), _lib.F32, _lib.F32, R, C, 1, 64, 8, 2, 1, 0, sp)), k2, n * 6)
+    f16 = _lib.FloatFmt(10, 5, 15, 1)
+    pf = ctypes.cast(ctypes.pointer(f16), ctypes.c_void_p)
+    run("binary_cast ResAdd: FLOAT16 casts on both inputs and the output, bf16 (one launch, 6 B/elem)",
+        lambda i: L.dmxq_binary_cast(vp(xs[i].data_ptr()), vp(xs[(i + 1) % k].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, n, 0, pf, pf, pf, sp), k, n * 6)
+    run("  the four launches it replaces (3 x float_qdq FLOAT16 + torch add)",
+        lambda i: (L.dmxq_float_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, n, 10, 5, 15, 1, 0, 2, 0, sp),
+                   L.dmxq_float_qdq(vp(xs[(i + 1) % k].data_ptr()), vp(ys[(i + 1) % k].data_ptr()), _lib.BF16, _lib.BF16, n, 10, 5, 15, 1, 0, 2, 0, sp),
+                   torch.add(ys[i], ys[(i + 1) % k], out=ys[(i + 2) % k]),
+                   L.dmxq_float_qdq(vp(ys[(i + 2) % k].data_ptr()), vp(ys[(i + 3) % k].data_ptr()), _lib.BF16, _lib.BF16, n, 10, 5, 15, 1, 0, 2, 0, sp)), k, n * 6)
     ws = torch.empty(L.dmxq_topk_workspace_bytes(n) // 8 + 1, dtype=torch.int64, device=dev)
     run("topk_sparsify TOPK{0.5} fp32 score, bf16 x -> bf16 y (radix select + apply; 4 score reads)",
         lambda i: L.dmxq_topk_mask(vp(ss[i % k2].data_ptr()), _lib.F32, vp(xs[i].data_ptr()), _lib.BF16, None, 0, vp(ys[i].data_ptr()), _lib.BF16, n, n // 2, vp(ws.data_ptr()), sp), k2, n * 8)
