@@ -14,7 +14,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libdmxq.so")
 TORCH_LIB = os.path.join(HERE, "lib", "dmxq_torch.so")
 # "file.hip" or "file.hip#N": the file compiled with -DDMXQ_EW_PART=N into file_pN.o (elementwise.hip: three objects, in parallel)
-SOURCES = ["elementwise.hip#2", "elementwise.hip#1", "elementwise.hip#3", "bfp_cols.hip#1", "bfp_cols.hip#2", "bfp_cols.hip#3", "bfp.hip", "bfp_urows.hip", "blockfmt.hip", "bfp_pack.hip", "hypernet.hip", "nm_mask.hip", "topk.hip", "reduce.hip", "approx.hip", "unary.hip", "fixed_multi.hip", "rope.hip"]
+SOURCES = ["elementwise.hip#2", "elementwise.hip#1", "elementwise.hip#3", "bfp_cols.hip#1", "bfp_cols.hip#2", "bfp_cols.hip#3", "bfp.hip", "bfp_urows.hip", "bfp_smallinner.hip", "blockfmt.hip", "bfp_pack.hip", "hypernet.hip", "nm_mask.hip", "topk.hip", "reduce.hip", "approx.hip", "unary.hip", "fixed_multi.hip", "rope.hip"]
 # bit-exact fp32: no fast-math, no fma contraction; fp32 denormals stay on (gfx950 default)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
          "-fgpu-flush-denormals-to-zero" if False else "-fno-gpu-flush-denormals-to-zero"]
@@ -40,7 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s.split("#")[0]))]
     common = [os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "dmxq.h"), os.path.abspath(__file__)]
     # per-source header dependencies (a change to the BFP tile code does not rebuild the elementwise kernels)
-    extra = {"bfp.hip": ["bfp_math.hpp", "bfp_rows.hpp"], "bfp_cols.hip": ["bfp_math.hpp"], "bfp_urows.hip": ["bfp_math.hpp"],
+    extra = {"bfp.hip": ["bfp_math.hpp", "bfp_rows.hpp"], "bfp_cols.hip": ["bfp_math.hpp"], "bfp_urows.hip": ["bfp_math.hpp"], "bfp_smallinner.hip": ["bfp_math.hpp"],
              "bfp_pack.hip": ["bfp_math.hpp"], "hypernet.hip": ["bfp_math.hpp"], "blockfmt.hip": ["bfp_math.hpp", "floatq.hpp", "stream.hpp"],
              "elementwise.hip": ["floatq.hpp", "stream.hpp"], "unary.hip": ["stream.hpp"]}
     hipcc = _hipcc()

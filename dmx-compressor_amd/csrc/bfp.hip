@@ -159,6 +159,9 @@ extern "C" int dmxq_internal_bfp_cols(const void* in, void* out, int dtype_in, i
                                       int64_t inner, int64_t B, int wl, int rounding, int symmetric, uint64_t seed,
                                       void* stream);
 
+extern "C" int dmxq_internal_bfp_smallinner(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L,
+                                            int64_t inner, int64_t B, int wl, int rounding, int symmetric, void* stream);
+
 extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L,
                             int64_t inner, int64_t block_size, int precision, int rounding, int symmetric,
                             uint64_t seed, void* stream) {
@@ -189,6 +192,11 @@ extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_o
                                              symmetric, seed, stream);
       if (ru != DMXQ_ERR_UNSUPPORTED) return ru;
     }
+  }
+  if (inner > 1 && inner <= 64) {  // a few elements between the members of a block: sub-slabs through the LDS (bfp_smallinner.hip)
+    const int rc = dmxq_internal_bfp_smallinner(in, out, dtype_in, dtype_out, outer, L, inner, block_size, precision, rounding, symmetric,
+                                                stream);
+    if (rc != DMXQ_ERR_UNSUPPORTED) return rc;
   }
   if (inner > 1) {
     const int rc = dmxq_internal_bfp_cols(in, out, dtype_in, dtype_out, outer, L, inner, block_size, precision, rounding,

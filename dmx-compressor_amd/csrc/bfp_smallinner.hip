@@ -1,0 +1,110 @@
+// csrc/bfp_smallinner.hip — BFP Q->DQ with blocks along a dim whose INNER extent is small (2 .. 64 elements): conv weights
+// [out, in, kh, kw] blocked along `in` (inner = kh * kw = 9, 3, 49 ...), 7 x 7 feature maps blocked along channels.  The elements of a
+// block are then `inner` apart, a row of the column kernel (bfp_cols.hip) is only a few bytes long, and one lane per block with
+// strided global accesses moves a 64-byte line per element (5.8 % of the roofline on [512, 512, 3, 3], profiles/r01_conv_shapes.txt).
+//
+// Here the B x inner elements that hold `inner` interleaved blocks -- a SUB-SLAB -- are contiguous in memory, and so is the
+// sequence of all sub-slabs of the tensor (L % B == 0).  A workgroup copies G consecutive sub-slabs to the LDS with coalesced
+// 16-byte accesses, one lane per block walks its B elements there (stride `inner` halfwords; sub-slabs padded by one dword so
+// that the lanes of different sub-slabs fall into different banks), writes the results back in place, and the tile leaves with
+// coalesced 16-byte stores.  HBM traffic is 1 read + 1 write per element; arithmetic and results are those of every other BFP
+// kernel (bfp_math.hpp).  Scope: 16-bit tensors with the same dtype in and out, nearest rounding, L % B == 0, B = 2^k in [8, 256].
+#include "bfp_math.hpp"
+
+namespace dmxq {
+
+constexpr int kSiThreads = 256;
+struct SiArgs {
+  const void* in; void* out;
+  int64_t n_sub;          // sub-slabs in the tensor: outer * (L / B)
+  int S8, K, B, G, wl;    // 16-byte vectors per sub-slab (B * K / 8), inner extent, block size, sub-slabs per tile, precision
+};
+
+template <int DT>
+__device__ __forceinline__ float si_widen(uint32_t h) {
+  if (DT == DMXQ_BF16) return u2f(h << 16);
+  return half_lo(h);
+}
+
+// FAST: 1 = magic-add double rounding, 2 = single rounding (bfp_single_rounding_ok<DT>(wl))
+template <int DT, bool ASYM, int FAST>
+__global__ __launch_bounds__(kSiThreads) void bfp_smallinner_kernel(const SiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t si_lds[];
+  uint16_t* lds = (uint16_t*)si_lds;
+  const int S = a.S8 * 8, SP = S + 2;  // sub-slab length and its padded pitch in halfwords (pitch in dwords is odd + ... : see header)
+  const int64_t s0 = (int64_t)blockIdx.x * a.G;
+  const int g_cnt = (int)((a.n_sub - s0 < a.G) ? (a.n_sub - s0) : a.G);
+  const int nv = g_cnt * a.S8;
+  const u32x4* src = (const u32x4*)a.in + s0 * a.S8;
+  u32x4* dst = (u32x4*)a.out + s0 * a.S8;
+  for (int v = threadIdx.x; v < nv; v += kSiThreads) {
+    const u32x4 raw = __builtin_nontemporal_load(src + v);
+    const int g = v / a.S8, off = (v - g * a.S8) * 8;
+    uint32_t* p = si_lds + (g * SP + off) / 2;  // g * SP + off is even
+    p[0] = raw.x; p[1] = raw.y; p[2] = raw.z; p[3] = raw.w;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < g_cnt * a.K; t += kSiThreads) {
+    const int g = t / a.K, k = t - g * a.K;
+    uint16_t* blk = lds + g * SP + k;
+    uint32_t m16 = 0u;
+    for (int i = 0; i < a.B; i++) m16 = max(m16, (uint32_t)blk[i * a.K] & 0x7FFFu);  // abs bit patterns order like the values
+    const uint32_t mb = f2u(si_widen<DT>(m16));
+    if (bfp_fast_ok(mb, a.wl)) {
+      const BfpBlockParams p = bfp_block_params<ASYM, true>(mb, a.wl);
+      for (int i = 0; i < a.B; i++) {
+        const float y = bfp_q1_fast<FAST == 2, ASYM>(si_widen<DT>(blk[i * a.K]), p);
+        blk[i * a.K] = (uint16_t)(pack2<DT>(y, 0.0f) & 0xFFFFu);
+      }
+    } else {
+      const BfpBlockParams p = bfp_block_params<ASYM, false>(mb, a.wl);
+      for (int i = 0; i < a.B; i++) {
+        const float y = bfp_q1<DMXQ_ROUND_NEAREST, ASYM>(si_widen<DT>(blk[i * a.K]), p, a.wl, DMXQ_ROUND_NEAREST, 0u);
+        blk[i * a.K] = (uint16_t)(pack2<DT>(y, 0.0f) & 0xFFFFu);
+      }
+    }
+  }
+  __syncthreads();
+  for (int v = threadIdx.x; v < nv; v += kSiThreads) {
+    const int g = v / a.S8, off = (v - g * a.S8) * 8;
+    const uint32_t* p = si_lds + (g * SP + off) / 2;
+    __builtin_nontemporal_store(u32x4{p[0], p[1], p[2], p[3]}, dst + v);
+  }
+}
+
+}  // namespace dmxq
+
+using namespace dmxq;
+
+// internal entry used by dmxq_bfp_qdq (bfp.hip) before the column kernel.  DMXQ_ERR_UNSUPPORTED = not applicable.
+extern "C" int dmxq_internal_bfp_smallinner(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L,
+                                            int64_t inner, int64_t B, int wl, int rounding, int symmetric, void* stream) {
+  if (dtype_in != dtype_out || (dtype_in != DMXQ_BF16 && dtype_in != DMXQ_F16) || rounding != DMXQ_ROUND_NEAREST) return DMXQ_ERR_UNSUPPORTED;
+  if (inner < 2 || inner > 64 || L % B != 0 || (B & (B - 1)) != 0 || B < 8 || B > 256 || wl > 20) return DMXQ_ERR_UNSUPPORTED;
+  if (!aligned16(in) || !aligned16(out)) return DMXQ_ERR_UNSUPPORTED;
+  const int64_t S = B * inner;                       // halfwords per sub-slab (a multiple of 8)
+  const int64_t lds_cap = 48 * 1024;
+  int64_t G = kSiThreads / inner;                    // one lane per block: G * inner <= 256 lanes per pass
+  if (G < 1) G = 1;
+  const int64_t fit = lds_cap / ((S + 2) * 2);
+  if (fit < 1) return DMXQ_ERR_UNSUPPORTED;
+  if (G > fit) G = fit;
+  const int64_t n_sub = outer * (L / B);
+  const int64_t tiles = (n_sub + G - 1) / G;
+  if (tiles > 0x7FFFFFFF || S / 8 > 0x7FFFFFF) return DMXQ_ERR_UNSUPPORTED;
+  const SiArgs a{in, out, n_sub, (int)(S / 8), (int)inner, (int)B, (int)G, wl};
+  const size_t lds = (size_t)(G * (S + 2) * 2);
+  hipStream_t s = (hipStream_t)stream;
+  const bool asym = !symmetric;
+#define DMXQ_SI(D_)                                                                                                                   \
+  do {                                                                                                                                \
+    const bool single = bfp_single_rounding_ok<D_>(wl);                                                                               \
+    if (single) { if (asym) DMXQ_LAUNCH((bfp_smallinner_kernel<D_, true, 2>), dim3((unsigned)tiles), dim3(kSiThreads), lds, s, a);    \
+                  else DMXQ_LAUNCH((bfp_smallinner_kernel<D_, false, 2>), dim3((unsigned)tiles), dim3(kSiThreads), lds, s, a); }      \
+    else { if (asym) DMXQ_LAUNCH((bfp_smallinner_kernel<D_, true, 1>), dim3((unsigned)tiles), dim3(kSiThreads), lds, s, a);           \
+           else DMXQ_LAUNCH((bfp_smallinner_kernel<D_, false, 1>), dim3((unsigned)tiles), dim3(kSiThreads), lds, s, a); }             \
+  } while (0)
+  if (dtype_in == DMXQ_BF16) DMXQ_SI(DMXQ_BF16); else DMXQ_SI(DMXQ_F16);
+#undef DMXQ_SI
+  return launch_status();
+}

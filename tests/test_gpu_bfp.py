@@ -270,6 +270,36 @@ def test_nan_payloads_in_nan_and_inf_blocks(dmx, cuda, oracle):
                 assert mismatches_nan_aware(got, want) == 0, (dt, wl, B)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_blocks_with_a_small_inner_extent(dmx, cuda, oracle, dtype):
+    """csrc/bfp_smallinner.hip: conv weights blocked along `in` ([out, in, kh, kw]: inner = 9, 3, 49, 2 ...), 7 x 7 maps blocked
+    along channels -- sub-slabs staged through the LDS, one lane per block -- against the oracle, incl. denormal / Inf / NaN /
+    all-zero blocks, asymmetric codes, several precisions, and in place."""
+    for shape, dim in (((16, 128, 3, 3), 1), ((8, 64, 7, 7), 1), ((4, 256, 3), 1), ((2, 64, 2), 1), ((3, 128, 5, 5), 1), ((300, 64, 9), 1),
+                       ((2, 3, 128, 64), -2), ((5, 512, 33), 1)):
+        x = make("heavy", shape, seed=31).clamp(-6e4, 6e4).to(dtype)
+        flat = x.view(-1)
+        flat[0], flat[7], flat[31] = float("inf"), float("nan"), -float("inf")
+        x.select(dim if dim >= 0 else x.dim() + dim, 0).zero_()  # zeros spread over blocks
+        tiny = 2.0 ** -130 if dtype == torch.bfloat16 else 2.0 ** -20
+        x.view(-1)[-shape[-1] * 8:] *= 0
+        x.view(-1)[-3] = tiny
+        for wl, B, sym in ((8, 64, True), (8, 16, False), (4, 128, True), (12, 8, True), (8, 32, False)):
+            if x.shape[dim] % B:
+                continue
+            want = oracle.bfp_cast(x, wl, B, dim, sym).to(dtype)
+            got = dmx.ops.bfp_qdq(x.to(cuda), wl, B, dim, sym)
+            assert got.dtype == dtype and mismatches_nan_aware(got.cpu(), want) == 0, (shape, dim, wl, B, sym)
+    import ctypes
+    from dmx_compressor_amd import _lib
+    x = make("normal", (6, 128, 3, 3), seed=32).to(dtype)
+    t = x.to(cuda).contiguous()
+    vp = ctypes.c_void_p
+    assert _lib.lib().dmxq_bfp_qdq(vp(t.data_ptr()), vp(t.data_ptr()), _lib.dtype_code(dtype), _lib.dtype_code(dtype), 6, 128, 9, 64, 8, 2, 1, 0,
+                                   vp(torch.cuda.current_stream().cuda_stream)) == 0
+    assert bits_equal(t.cpu(), oracle.bfp_cast(x, 8, 64, 1, True).to(dtype)) == 0
+
+
 def test_inplace_and_noncontiguous(dmx, cuda, oracle):
     x = make("normal", (64, 96), seed=2, dtype=torch.bfloat16)
     xt = x.t()  # non-contiguous view
