@@ -27,7 +27,10 @@ __device__ __forceinline__ float si_widen(uint32_t h) {
 }
 
 // FAST: 1 = magic-add double rounding, 2 = single rounding (bfp_single_rounding_ok<DT>(wl))
-template <int DT, bool ASYM, int FAST>
+// LPB: lanes per block (1, or 4 = the lanes of one quad, each walking a quarter of the block; the block maximum through two DPP
+// quad permutes): four times as many lanes per sub-slab, so four times smaller tiles for the same lane count -- [512,512,3,3]
+// is then 585 workgroups of 8 KB instead of 147 of 32 KB whose lanes each walk 64 elements (8.4 us by rocprofv3)
+template <int DT, bool ASYM, int FAST, int LPB>
 __global__ __launch_bounds__(kSiThreads) void bfp_smallinner_kernel(const SiArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t si_lds[];
   uint16_t* lds = (uint16_t*)si_lds;
@@ -37,28 +40,61 @@ __global__ __launch_bounds__(kSiThreads) void bfp_smallinner_kernel(const SiArgs
   const int nv = g_cnt * a.S8;
   const u32x4* src = (const u32x4*)a.in + s0 * a.S8;
   u32x4* dst = (u32x4*)a.out + s0 * a.S8;
-  for (int v = threadIdx.x; v < nv; v += kSiThreads) {
-    const u32x4 raw = __builtin_nontemporal_load(src + v);
-    const int g = v / a.S8, off = (v - g * a.S8) * 8;
-    uint32_t* p = si_lds + (g * SP + off) / 2;  // g * SP + off is even
-    p[0] = raw.x; p[1] = raw.y; p[2] = raw.z; p[3] = raw.w;
+  // the tile's global loads in batches of 4 per lane, all of a batch issued before its LDS writes (one load at a time exposed a
+  // full HBM round trip per iteration of the copy loop)
+  for (int v0 = threadIdx.x; v0 < nv; v0 += 4 * kSiThreads) {
+    u32x4 raw[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int v = v0 + j * kSiThreads;
+      raw[j] = __builtin_nontemporal_load(src + (v < nv ? v : v0));  // clamped: unconditional, back to back
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int v = v0 + j * kSiThreads;
+      if (v < nv) {
+        const int g = v / a.S8, off = (v - g * a.S8) * 8;
+        uint32_t* p = si_lds + (g * SP + off) / 2;  // g * SP + off is even
+        p[0] = raw[j].x; p[1] = raw[j].y; p[2] = raw[j].z; p[3] = raw[j].w;
+      }
+    }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < g_cnt * a.K; t += kSiThreads) {
-    const int g = t / a.K, k = t - g * a.K;
-    uint16_t* blk = lds + g * SP + k;
+  const int per = a.B / LPB;  // elements of a block per lane (a multiple of 8)
+  // (the trip count is rounded up to whole quads so that the DPP exchange below always has its four lanes active)
+  for (int t = threadIdx.x; t < g_cnt * a.K * LPB; t += kSiThreads) {
+    const int bidx = t / LPB, part = t - bidx * LPB;
+    const int g = bidx / a.K, k = bidx - g * a.K;
+    uint16_t* blk = lds + g * SP + k + part * per * a.K;
+    // 8 elements at a time: the 8 LDS reads are independent and in flight together (one by one each would expose its latency)
     uint32_t m16 = 0u;
-    for (int i = 0; i < a.B; i++) m16 = max(m16, (uint32_t)blk[i * a.K] & 0x7FFFu);  // abs bit patterns order like the values
+    for (int i = 0; i < per; i += 8) {
+      uint32_t h[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) h[j] = blk[(i + j) * a.K];
+#pragma unroll
+      for (int j = 0; j < 8; j++) m16 = max(m16, h[j] & 0x7FFFu);  // abs bit patterns order like the values
+    }
+    if (LPB == 4) {
+      m16 = max(m16, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m16, 0xB1, 0xF, 0xF, false));  // quad_perm 1,0,3,2
+      m16 = max(m16, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m16, 0x4E, 0xF, 0xF, false));  // quad_perm 2,3,0,1
+    }
     const uint32_t mb = f2u(si_widen<DT>(m16));
     if (bfp_fast_ok(mb, a.wl)) {
       const BfpBlockParams p = bfp_block_params<ASYM, true>(mb, a.wl);
-      for (int i = 0; i < a.B; i++) {
-        const float y = bfp_q1_fast<FAST == 2, ASYM>(si_widen<DT>(blk[i * a.K]), p);
-        blk[i * a.K] = (uint16_t)(pack2<DT>(y, 0.0f) & 0xFFFFu);
+      for (int i = 0; i < per; i += 8) {
+        uint32_t h[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) h[j] = blk[(i + j) * a.K];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const float y = bfp_q1_fast<FAST == 2, ASYM>(si_widen<DT>(h[j]), p);
+          blk[(i + j) * a.K] = (uint16_t)(pack2<DT>(y, 0.0f) & 0xFFFFu);
+        }
       }
     } else {
       const BfpBlockParams p = bfp_block_params<ASYM, false>(mb, a.wl);
-      for (int i = 0; i < a.B; i++) {
+      for (int i = 0; i < per; i++) {
         const float y = bfp_q1<DMXQ_ROUND_NEAREST, ASYM>(si_widen<DT>(blk[i * a.K]), p, a.wl, DMXQ_ROUND_NEAREST, 0u);
         blk[i * a.K] = (uint16_t)(pack2<DT>(y, 0.0f) & 0xFFFFu);
       }
@@ -84,7 +120,8 @@ extern "C" int dmxq_internal_bfp_smallinner(const void* in, void* out, int dtype
   if (!aligned16(in) || !aligned16(out)) return DMXQ_ERR_UNSUPPORTED;
   const int64_t S = B * inner;                       // halfwords per sub-slab (a multiple of 8)
   const int64_t lds_cap = 48 * 1024;
-  int64_t G = kSiThreads / inner;                    // one lane per block: G * inner <= 256 lanes per pass
+  const int lpb = B >= 32 ? 4 : 1;                // a quad per block when each of its lanes still gets >= 8 elements
+  int64_t G = kSiThreads / (inner * lpb);            // G * inner * lpb <= 256 lanes: one pass over the tile's blocks
   if (G < 1) G = 1;
   const int64_t fit = lds_cap / ((S + 2) * 2);
   if (fit < 1) return DMXQ_ERR_UNSUPPORTED;
@@ -96,15 +133,19 @@ extern "C" int dmxq_internal_bfp_smallinner(const void* in, void* out, int dtype
   const size_t lds = (size_t)(G * (S + 2) * 2);
   hipStream_t s = (hipStream_t)stream;
   const bool asym = !symmetric;
+#define DMXQ_SI2(D_, A_, F_)                                                                                                          \
+  do {                                                                                                                                \
+    if (lpb == 4) DMXQ_LAUNCH((bfp_smallinner_kernel<D_, A_, F_, 4>), dim3((unsigned)tiles), dim3(kSiThreads), lds, s, a);            \
+    else DMXQ_LAUNCH((bfp_smallinner_kernel<D_, A_, F_, 1>), dim3((unsigned)tiles), dim3(kSiThreads), lds, s, a);                     \
+  } while (0)
 #define DMXQ_SI(D_)                                                                                                                   \
   do {                                                                                                                                \
     const bool single = bfp_single_rounding_ok<D_>(wl);                                                                               \
-    if (single) { if (asym) DMXQ_LAUNCH((bfp_smallinner_kernel<D_, true, 2>), dim3((unsigned)tiles), dim3(kSiThreads), lds, s, a);    \
-                  else DMXQ_LAUNCH((bfp_smallinner_kernel<D_, false, 2>), dim3((unsigned)tiles), dim3(kSiThreads), lds, s, a); }      \
-    else { if (asym) DMXQ_LAUNCH((bfp_smallinner_kernel<D_, true, 1>), dim3((unsigned)tiles), dim3(kSiThreads), lds, s, a);           \
-           else DMXQ_LAUNCH((bfp_smallinner_kernel<D_, false, 1>), dim3((unsigned)tiles), dim3(kSiThreads), lds, s, a); }             \
+    if (single) { if (asym) DMXQ_SI2(D_, true, 2); else DMXQ_SI2(D_, false, 2); }                                                     \
+    else { if (asym) DMXQ_SI2(D_, true, 1); else DMXQ_SI2(D_, false, 1); }                                                            \
   } while (0)
   if (dtype_in == DMXQ_BF16) DMXQ_SI(DMXQ_BF16); else DMXQ_SI(DMXQ_F16);
 #undef DMXQ_SI
+#undef DMXQ_SI2
   return launch_status();
 }

@@ -93,6 +93,10 @@ def main():
         lambda i: L.dmxq_bfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, 1, R, C, 64, 8, 2, 1, 0, sp), k, n * 4)
     run("bfp_qdq bf16 block_dim=1 of [R/64,64,C] B=16",
         lambda i: L.dmxq_bfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, R // 64, 64, C, 16, 8, 2, 1, 0, sp), k, n * 4)
+    run("bfp_qdq bf16 conv weight [512,512,3,3] along in-channels B=64 (4.7 MB: launch-bound; LDS sub-slab kernel)",
+        lambda i: L.dmxq_bfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, 512, 512, 9, 64, 8, 2, 1, 0, sp), k, 512 * 512 * 9 * 4)
+    run("bfp_qdq bf16 feature map [64,2048,7,7] along channels B=64 (LDS sub-slab kernel)",
+        lambda i: L.dmxq_bfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, 64, 2048, 49, 64, 8, 2, 1, 0, sp), k, 64 * 2048 * 49 * 4)
     run("bfp_qdq bf16 rows ragged L=C-8 B=64 (generic path)",
         lambda i: L.dmxq_bfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, R, C - 8, 1, 64, 8, 2, 1, 0, sp), k, R * (C - 8) * 4)
     # ---------------------------------------------------------------- float / fixed / scale / gelu
