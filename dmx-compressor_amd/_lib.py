@@ -49,6 +49,7 @@ SIGNATURES = {
     "dmxq_unary": [_vp, _vp, _i32, _i32, _i64, _i32, _f32, _vp],
     "dmxq_rmsnorm": [_vp, _vp, _i32, _i32, _i64, _i64, _vp, _i32, _f32, _vp],
     "dmxq_rope": [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _vp],
+    "dmxq_rope_cast": [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "dmxq_softmax": [_vp, _vp, _i32, _i32, _i64, _i64, _f32, _vp],
     "dmxq_layernorm": [_vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _i32, _f32, _vp],
 }

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -488,6 +488,31 @@ def rope(x, cos, sin, unsqueeze_dim: int = 1):
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     check(rc, "dmxq_rope")
+    return out
+
+
+def rope_cast(x, cos, sin, unsqueeze_dim: int = 1, cast_x=None, cast_cos=None, cast_sin=None, cast_out=None):
+    """One operand of an ApplyRotaryPosEmb module with its casts in one launch: cast_out(rope(cast_x(x), cast_cos(cos), cast_sin(sin)));
+    casts are FloatingPoint formats (nearest, signed) or None = SAME.  None when not fusable."""
+    import ctypes
+    xc = _prep(x, "rope_cast")
+    if xc.dim() != 4 or cos.dim() != 3 or sin.dim() != 3 or unsqueeze_dim not in (1, 2) or cos.dtype != xc.dtype or sin.dtype != xc.dtype:
+        return None
+    c, s = _prep(cos, "rope_cast"), _prep(sin, "rope_cast")
+    B, n1, n2, D = xc.shape
+    if tuple(c.shape) != (B, n2 if unsqueeze_dim == 1 else n1, D) or s.shape != c.shape:
+        return None
+    structs = []
+    for f in (cast_x, cast_cos, cast_sin, cast_out):
+        if f is not None and (f.rounding != "nearest" or f.unsigned):
+            return None
+        structs.append(None if f is None else _lib.FloatFmt(int(f.mantissa), int(f.exponent), int(f.bias), int(bool(f.flush_subnormal))))
+    ptrs = [ctypes.cast(ctypes.pointer(st), ctypes.c_void_p) if st is not None else None for st in structs]
+    out = torch.empty_like(xc)
+    rc = lib().dmxq_rope_cast(ptr(xc), ptr(c), ptr(s), ptr(out), dtype_code(xc.dtype), B, n1, n2, D, int(unsqueeze_dim == 1), *ptrs, stream_of(xc))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    check(rc, "dmxq_rope_cast")
     return out
 
 

@@ -418,4 +418,29 @@ inline bool valid_rounding(int r) { return r >= 0 && r <= 3; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // dtype / rounding dispatch: calls f(std::integral_constant...) style via macros kept local to each .hip file
+// ---------------------------------------------------------------------------------------------------------------------------
+// Range-only casts of bf16 words (elementwise.hip float_range_bf16_kernel, dmxq_binary_cast, dmxq_rope_cast): a FloatingPoint
+// format that keeps at least bf16's 7 mantissa bits only clamps the magnitude (Inf / NaN included: the reference reserves no codes
+// for them) and flushes what lies below its smallest normal value -- done on both halves of a dword at once.
+struct Range16 { uint32_t limit2, minb2; };  // both halves of a dword: clamp limit and smallest-normal threshold (bf16 bit patterns)
+__device__ __forceinline__ uint32_t range16_word(uint32_t w, const Range16& r) {
+  const u16x2 a = __builtin_bit_cast(u16x2, w & 0x7FFF7FFFu);
+  const u16x2 cl = __builtin_elementwise_min(a, __builtin_bit_cast(u16x2, r.limit2));
+  const uint32_t res = (w & 0x80008000u) | __builtin_bit_cast(uint32_t, cl);
+  // per half: keep iff |x| bits >= minb (saturating subtract -> 0 / non-zero -> 0 / 0xFFFF)
+  const u16x2 d = __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(a, (u16x2){1, 1}), __builtin_bit_cast(u16x2, r.minb2));
+  const u16x2 keep = __builtin_elementwise_min(d, (u16x2){1, 1}) * (u16x2){0xFFFF, 0xFFFF};
+  return res & __builtin_bit_cast(uint32_t, keep);
+}
+inline bool range16_of(const dmxq_float_fmt* f, Range16* r) {  // false: this format is not a range-only cast of bf16 values
+  if (!f || f->exp_bits == 0) { *r = Range16{0xFFFFFFFFu, 0u}; return true; }  // SAME: identity
+  if (f->exp_bits < 1 || f->exp_bits > 8 || f->man_bits < 7 || f->man_bits > 22 || !f->flush_subnormal) return false;
+  const int min_exp = -(f->exp_bias - 1), max_e = (1 << (f->exp_bits - 1)) + 127;
+  if (min_exp < -126 || min_exp > 127) return false;
+  const uint32_t limit = max_e >= 255 ? 0xFFFFu : (f->man_bits > 7 ? (uint32_t)(max_e + 1) << 7 : ((uint32_t)max_e << 7) | 0x7Fu);
+  const uint32_t minb = (uint32_t)(127 + min_exp) << 7;
+  *r = Range16{limit | (limit << 16), minb | (minb << 16)};
+  return true;
+}
+
 }  // namespace dmxq

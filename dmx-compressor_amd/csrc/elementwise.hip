@@ -550,16 +550,6 @@ using namespace dmxq;
 //     cast.py:306) to the bf16 word (max_e + 1) << 7 when man > 7 -- i.e. min_u16(|x| bits, limit) -- Inf and NaN included
 //     (the reference reserves no Inf / NaN codes: they saturate too).
 // 3.5 VALU operations per element instead of ~18, so the op streams like a copy; tile geometry by size as for BFP (rows_plan).
-struct Range16 { uint32_t limit2, minb2; };  // both halves of a dword: clamp limit and smallest-normal threshold (bf16 bit patterns)
-__device__ __forceinline__ uint32_t range16_word(uint32_t w, const Range16& r) {
-  const u16x2 a = __builtin_bit_cast(u16x2, w & 0x7FFF7FFFu);
-  const u16x2 cl = __builtin_elementwise_min(a, __builtin_bit_cast(u16x2, r.limit2));
-  const uint32_t res = (w & 0x80008000u) | __builtin_bit_cast(uint32_t, cl);
-  // per half: keep iff |x| bits >= minb (saturating subtract -> 0 / non-zero -> 0 / 0xFFFF)
-  const u16x2 d = __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(a, (u16x2){1, 1}), __builtin_bit_cast(u16x2, r.minb2));
-  const u16x2 keep = __builtin_elementwise_min(d, (u16x2){1, 1}) * (u16x2){0xFFFF, 0xFFFF};
-  return res & __builtin_bit_cast(uint32_t, keep);
-}
 template <int T, int U>
 __global__ __launch_bounds__(T) void float_range_bf16_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t n_vec, Range16 r) {
   constexpr int64_t TILE = (int64_t)T * U;
@@ -646,16 +636,6 @@ extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype
 // range-only (the FLOAT16-style formats of the BASIC rules: range16_word above).  Replaces the four launches of a ResAdd / Mul
 // DmxModule (modeling/nn/core.py:228-264: two input casts, the torch op, the output cast): 6 B/element instead of 18.
 // The op itself is torch's: fp32 arithmetic on the widened operands, one RNE rounding to bf16.
-static bool range16_of(const dmxq_float_fmt* f, Range16* r) {  // false: this format is not a range-only cast of bf16 values
-  if (!f || f->exp_bits == 0) { *r = Range16{0xFFFFFFFFu, 0u}; return true; }  // SAME: identity
-  if (f->exp_bits < 1 || f->exp_bits > 8 || f->man_bits < 7 || f->man_bits > 22 || !f->flush_subnormal) return false;
-  const int min_exp = -(f->exp_bias - 1), max_e = (1 << (f->exp_bits - 1)) + 127;
-  if (min_exp < -126 || min_exp > 127) return false;
-  const uint32_t limit = max_e >= 255 ? 0xFFFFu : (f->man_bits > 7 ? (uint32_t)(max_e + 1) << 7 : ((uint32_t)max_e << 7) | 0x7Fu);
-  const uint32_t minb = (uint32_t)(127 + min_exp) << 7;
-  *r = Range16{limit | (limit << 16), minb | (minb << 16)};
-  return true;
-}
 struct BinArgs { const void* a; const void* b; void* out; int64_t n_vec; Range16 ra, rb, ro; };
 template <int OP, int T, int U>
 __global__ __launch_bounds__(T) void binary_range_bf16_kernel(const BinArgs g) {

@@ -25,7 +25,8 @@ template <int DT>
 __global__ __launch_bounds__(kThreads) void rope_kernel(const void* __restrict__ x, const void* __restrict__ cs,
                                                        const void* __restrict__ sn, void* __restrict__ out, int64_t n_vec,
                                                        int vpr /*vectors per row*/, FastDiv31 f_vpr, FastDiv31 f_n2, FastDiv31 f_n1,
-                                                       int n1, int n2, int over_dim1) {
+                                                       int n1, int n2, int over_dim1, Range16 rgx, Range16 rgc, Range16 rgs,
+                                                       Range16 rgo) {
   constexpr int EPL = 16 / Elem<DT>::bytes;
   const int half = vpr / 2;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
@@ -39,8 +40,16 @@ __global__ __launch_bounds__(kThreads) void rope_kernel(const void* __restrict__
     const u32x4 rx = load_raw16<true>(x, v * 16), rp = *(const u32x4*)((const char*)x + pv * 16);
     const u32x4 rc = *(const u32x4*)((const char*)cs + ((int64_t)crow * vpr + vc) * 16);
     const u32x4 rs = *(const u32x4*)((const char*)sn + ((int64_t)crow * vpr + vc) * 16);
+    u32x4 cx = rx, cp = rp, cc = rc, cs2 = rs;
+    if constexpr (DT == DMXQ_BF16) {  // the module's input casts (dmxq_rope_cast: range-only formats; identity ranges for dmxq_rope)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        cx[j] = range16_word(rx[j], rgx); cp[j] = range16_word(rp[j], rgx);
+        cc[j] = range16_word(rc[j], rgc); cs2[j] = range16_word(rs[j], rgs);
+      }
+    }
     float xv[EPL], pvv[EPL], c[EPL], s[EPL], y[EPL];
-    widen<DT, EPL>(rx, xv); widen<DT, EPL>(rp, pvv); widen<DT, EPL>(rc, c); widen<DT, EPL>(rs, s);
+    widen<DT, EPL>(cx, xv); widen<DT, EPL>(cp, pvv); widen<DT, EPL>(cc, c); widen<DT, EPL>(cs2, s);
 #pragma unroll
     for (int k = 0; k < EPL; k++) {
       const float rot = lo ? -pvv[k] : pvv[k];
@@ -48,7 +57,12 @@ __global__ __launch_bounds__(kThreads) void rope_kernel(const void* __restrict__
       const float t2 = rnd_dt<DT>(rot * s[k]);
       y[k] = t1 + t2;   // rounded to DT by the store
     }
-    store_out<DT, EPL, true>((char*)out + v * 16, pack_vec<DT, EPL>(y));
+    OutVec<DT, EPL> o = pack_vec<DT, EPL>(y);
+    if constexpr (DT == DMXQ_BF16) {  // ... and its output cast
+#pragma unroll
+      for (int j = 0; j < 4; j++) o.w[j] = range16_word(o.w[j], rgo);
+    }
+    store_out<DT, EPL, true>((char*)out + v * 16, o);
   }
 }
 
@@ -56,8 +70,9 @@ __global__ __launch_bounds__(kThreads) void rope_kernel(const void* __restrict__
 
 using namespace dmxq;
 
-extern "C" int dmxq_rope(const void* x, const void* cos_tab, const void* sin_tab, void* out, int dtype, int64_t B, int64_t n1,
-                         int64_t n2, int64_t D, int broadcast_over_dim1, void* stream) {
+static int rope_launch(const void* x, const void* cos_tab, const void* sin_tab, void* out, int dtype, int64_t B, int64_t n1, int64_t n2,
+                       int64_t D, int broadcast_over_dim1, const Range16& rgx, const Range16& rgc, const Range16& rgs, const Range16& rgo,
+                       void* stream) {
   if (!valid_dtype(dtype) || B < 0 || n1 < 0 || n2 < 0 || D < 0) return DMXQ_ERR_BAD_ARG;
   const int64_t n = B * n1 * n2 * D;
   if (n == 0) return DMXQ_OK;
@@ -72,8 +87,25 @@ extern "C" int dmxq_rope(const void* x, const void* cos_tab, const void* sin_tab
   hipStream_t s = (hipStream_t)stream;
   const int grid = grid_for((n_vec + 1) / 2);
 #define DMXQ_ROPE(D_) DMXQ_LAUNCH(rope_kernel<D_>, dim3(grid), dim3(kThreads), 0, s, x, cos_tab, sin_tab, out, n_vec, vpr, make_fastdiv31(vpr), \
-                                  make_fastdiv31(n2), make_fastdiv31(n1), (int)n1, (int)n2, broadcast_over_dim1 ? 1 : 0)
+                                  make_fastdiv31(n2), make_fastdiv31(n1), (int)n1, (int)n2, broadcast_over_dim1 ? 1 : 0, rgx, rgc, rgs, rgo)
   if (dtype == DMXQ_F32) DMXQ_ROPE(DMXQ_F32); else if (dtype == DMXQ_F16) DMXQ_ROPE(DMXQ_F16); else DMXQ_ROPE(DMXQ_BF16);
 #undef DMXQ_ROPE
   return launch_status();
+}
+
+extern "C" int dmxq_rope(const void* x, const void* cos_tab, const void* sin_tab, void* out, int dtype, int64_t B, int64_t n1,
+                         int64_t n2, int64_t D, int broadcast_over_dim1, void* stream) {
+  const Range16 id{0xFFFFFFFFu, 0u};
+  return rope_launch(x, cos_tab, sin_tab, out, dtype, B, n1, n2, D, broadcast_over_dim1, id, id, id, id, stream);
+}
+
+// One operand (q or k) of an ApplyRotaryPosEmb DmxModule with its casts: out = cast_out(rope(cast_x(x), cast_cos(cos), cast_sin(sin))).
+// bf16 tensors and range-only formats only (DMXQ_ERR_UNSUPPORTED otherwise), see dmxq_binary_cast.
+extern "C" int dmxq_rope_cast(const void* x, const void* cos_tab, const void* sin_tab, void* out, int dtype, int64_t B, int64_t n1,
+                              int64_t n2, int64_t D, int broadcast_over_dim1, const dmxq_float_fmt* cast_x, const dmxq_float_fmt* cast_cos,
+                              const dmxq_float_fmt* cast_sin, const dmxq_float_fmt* cast_out, void* stream) {
+  Range16 rx, rc, rs, ro;
+  if (dtype != DMXQ_BF16 || !range16_of(cast_x, &rx) || !range16_of(cast_cos, &rc) || !range16_of(cast_sin, &rs) || !range16_of(cast_out, &ro))
+    return valid_dtype(dtype) ? DMXQ_ERR_UNSUPPORTED : DMXQ_ERR_BAD_ARG;
+  return rope_launch(x, cos_tab, sin_tab, out, dtype, B, n1, n2, D, broadcast_over_dim1, rx, rc, rs, ro, stream);
 }

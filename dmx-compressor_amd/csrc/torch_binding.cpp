@@ -512,6 +512,25 @@ Tensor rope(const Tensor& x, const Tensor& cos_t, const Tensor& sin_t, int64_t u
                   l.stream), "dmxq_rope");
   return out;
 }
+Tensor rope_cast(const Tensor& x, const Tensor& cos_t, const Tensor& sin_t, int64_t unsqueeze_dim, at::IntArrayRef cast_x, at::IntArrayRef cast_cos,
+                 at::IntArrayRef cast_sin, at::IntArrayRef cast_out) {
+  const Tensor xc = prep(x, "rope_cast");
+  TORCH_CHECK_NOT_IMPLEMENTED(xc.dim() == 4 && cos_t.dim() == 3 && sin_t.dim() == 3 && (unsqueeze_dim == 1 || unsqueeze_dim == 2),
+                              "rope_cast: expects x [B, n1, n2, D], cos / sin [B, S, D], unsqueeze_dim 1 or 2");
+  TORCH_CHECK_NOT_IMPLEMENTED(cos_t.scalar_type() == xc.scalar_type() && sin_t.scalar_type() == xc.scalar_type(), "rope_cast: one dtype");
+  const Tensor c = prep(cos_t, "rope_cast"), sn = prep(sin_t, "rope_cast");
+  const int64_t B = xc.size(0), n1 = xc.size(1), n2 = xc.size(2), D = xc.size(3), S = unsqueeze_dim == 1 ? n2 : n1;
+  TORCH_CHECK_NOT_IMPLEMENTED(c.size(0) == B && c.size(1) == S && c.size(2) == D && sn.sizes() == c.sizes(), "rope_cast: cos / sin shape");
+  Tensor out = at::empty_like(xc);
+  dmxq_float_fmt fx, fc, fs, fo;
+  Launch l(xc);
+  check(dmxq_rope_cast(xc.data_ptr(), c.data_ptr(), sn.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), B, n1, n2, D, unsqueeze_dim == 1,
+                       fmt_of(cast_x, &fx), fmt_of(cast_cos, &fc), fmt_of(cast_sin, &fs), fmt_of(cast_out, &fo), l.stream), "dmxq_rope_cast");
+  return out;
+}
+Tensor rope_cast_meta(const Tensor& x, const Tensor&, const Tensor&, int64_t, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef) {
+  return at::empty_like(x, x.options().memory_format(at::MemoryFormat::Contiguous));
+}
 Tensor rope_meta(const Tensor& x, const Tensor&, const Tensor&, int64_t) { return at::empty_like(x, x.options().memory_format(at::MemoryFormat::Contiguous)); }
 
 Tensor softmax(const Tensor& x, double clamp_min, OptDtype out_dtype) {  // over the contiguous last dim
@@ -576,6 +595,7 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("scale_channels(Tensor x, Tensor scale, int ch_axis, bool divide, ScalarType? out_dtype=None) -> Tensor");
   m.def("unary(Tensor x, int kind, float param=0.0, ScalarType? out_dtype=None) -> Tensor");
   m.def("rope(Tensor x, Tensor cos, Tensor sin, int unsqueeze_dim=1) -> Tensor");
+  m.def("rope_cast(Tensor x, Tensor cos, Tensor sin, int unsqueeze_dim, int[] cast_x, int[] cast_cos, int[] cast_sin, int[] cast_out) -> Tensor");
   m.def("softmax(Tensor x, float clamp_min, ScalarType? out_dtype=None) -> Tensor");
   m.def("norm(Tensor x, int cols, Tensor? weight, Tensor? bias, float eps, int kind, ScalarType? out_dtype=None) -> Tensor");
 }
@@ -585,7 +605,7 @@ TORCH_LIBRARY(dmxq, m) {
 #define DMXQ_FOR_ALL(X, m) \
   X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, input_hypernet); X(m, binary_cast); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
   X(m, float_qdq); X(m, fixed_qdq); X(m, fixed_qdq_multi); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
-  X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, rope); X(m, softmax); X(m, norm)
+  X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, rope); X(m, rope_cast); X(m, softmax); X(m, norm)
 
 // "CUDA" is the dispatch key of HIP tensors in a ROCm build of PyTorch
 TORCH_LIBRARY_IMPL(dmxq, CUDA, m) { DMXQ_FOR_ALL(DMXQ_IMPL, m); }

@@ -631,6 +631,34 @@ class ApplyRotaryPosEmb(DmxModule):
     def _forward(self, q, k, cos, sin, unsqueeze_dim=1):
         return self.approx_forward((q, k, cos, sin, unsqueeze_dim))
 
+    fuse_rope = True
+
+    def _fused_forward(self, q, k=None, cos=None, sin=None, unsqueeze_dim=1, *args, **kwargs):
+        """Four input casts, the exact function (about six torch kernels per operand) and two output casts as TWO launches
+        (dmxq_rope_cast for q and for k) when everything is bf16 and every cast is range-only; else the general path."""
+        ts = (q, k, cos, sin)
+        if (not self.fuse_rope or args or kwargs or any(not isinstance(t, torch.Tensor) for t in ts) or any(t.dtype != torch.bfloat16 for t in ts)
+                or not q.is_cuda or q.dim() != 4 or k.dim() != 4 or unsqueeze_dim not in (1, 2)
+                or self.smoothquant is not None and self.smoothquant._flag("enabled")
+                or torch.is_grad_enabled() and any(t.requires_grad for t in ts) or torch.compiler.is_compiling()
+                or not isinstance(self.approximator.function, NoApproximation)):
+            return None
+        ics, ocs = list(self.input_casts.values()), list(self.output_casts.values())
+        if len(ics) != 4 or len(ocs) != 2:
+            return None
+        fmts = []
+        for c in ics + ocs:
+            ok, f = _range_only_format(c, q.dtype)
+            if not ok:
+                return None
+            fmts.append(f)
+        from . import ops
+        qe = ops.rope_cast(q.detach(), cos.detach(), sin.detach(), unsqueeze_dim, fmts[0], fmts[2], fmts[3], fmts[4])
+        if qe is None:
+            return None
+        ke = ops.rope_cast(k.detach(), cos.detach(), sin.detach(), unsqueeze_dim, fmts[1], fmts[2], fmts[3], fmts[5])
+        return None if ke is None else (qe, ke)
+
 
 class RMSNorm(DmxModule, torch.nn.RMSNorm):
     """torch_modules.py:1144-1170"""

@@ -216,6 +216,14 @@ enum { DMXQ_BINARY_ADD = 0, DMXQ_BINARY_MUL = 1 };
 int dmxq_binary_cast(const void* a, const void* b, void* out, int dtype, int64_t n, int op, const dmxq_float_fmt* cast_a,
                      const dmxq_float_fmt* cast_b, const dmxq_float_fmt* cast_out, void* stream);
 
+/* One operand (q or k) of an ApplyRotaryPosEmb DmxModule (modeling/nn/custom_modules.py:142-194) with the module's casts:
+ * out = cast_out(rope(cast_x(x), cast_cos(cos), cast_sin(sin))), rope as dmxq_rope below (torch's op-by-op arithmetic in the
+ * tensor dtype).  Replaces, per operand, three input casts, the ~6 torch kernels of the exact function and the output cast.
+ * bf16 tensors, range-only formats (see dmxq_binary_cast); DMXQ_ERR_UNSUPPORTED otherwise. */
+int dmxq_rope_cast(const void* x, const void* cos_tab, const void* sin_tab, void* out, int dtype, int64_t B, int64_t n1, int64_t n2,
+                   int64_t D, int broadcast_over_dim1, const dmxq_float_fmt* cast_x, const dmxq_float_fmt* cast_cos,
+                   const dmxq_float_fmt* cast_sin, const dmxq_float_fmt* cast_out, void* stream);
+
 /* Approximator-slot ops.  The reference evaluates the exact torch.nn.functional op and then overwrites it with a
  * vsimd approximation that lives in a private package (functional/approximate.py:9-14, 300-327); with vsimd
  * absent (the public reference) the exact function is the result, and that is what these compute, in fp32.

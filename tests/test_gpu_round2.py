@@ -439,3 +439,22 @@ def test_rope_module_under_basic_rules(dmx, cuda):
         f16 = dmx.CastTo(format=dmx.format.FLOAT16)
         eq, ek = dmx.nn.ApplyRotaryPosEmb._rope(f16(q), f16(k), f16(cos), f16(sin), 1)
     assert bits_equal(yq, f16(eq)) == 0 and bits_equal(yk, f16(ek)) == 0
+    # ... and that forward was TWO launches (dmxq_rope_cast per operand), identical to the general path on Llama-3-8B head shapes,
+    # both unsqueeze dims, with values the casts saturate / flush
+    from _data import mismatches_nan_aware
+    for ud, qs, ks in ((1, (2, 32, 40, 128), (2, 8, 40, 128)), (2, (2, 40, 32, 128), (2, 40, 8, 128))):
+        q = (make("heavy", qs, seed=8) * 2).to(torch.bfloat16)
+        k = (make("heavy", ks, seed=9) * 2).to(torch.bfloat16)
+        q.view(-1)[:6] = torch.tensor([float("inf"), float("-inf"), float("nan"), 7e4, 3e-5, -0.0]).to(torch.bfloat16)
+        ang = make("normal", (2, 40, 128), seed=10) * 3
+        cos, sin = torch.cos(ang).to(torch.bfloat16).to(cuda), torch.sin(ang).to(torch.bfloat16).to(cuda)
+        q, k = q.to(cuda), k.to(cuda)
+        with torch.no_grad():
+            m.fuse_rope = True
+            assert m._fused_forward(q, k, cos, sin, ud) is not None
+            fq, fk = m(q, k, cos, sin, ud)
+            m.fuse_rope = False
+            gq, gk = m(q, k, cos, sin, ud)
+        assert mismatches_nan_aware(fq, gq) == 0 and mismatches_nan_aware(fk, gk) == 0, ud
+    m.fuse_rope = True
+    assert m._fused_forward(q.float(), k.float(), cos.float(), sin.float(), 1) is None        # float32: the general path
