@@ -432,13 +432,30 @@ __device__ __forceinline__ uint32_t range16_word(uint32_t w, const Range16& r) {
   const u16x2 keep = __builtin_elementwise_min(d, (u16x2){1, 1}) * (u16x2){0xFFFF, 0xFFFF};
   return res & __builtin_bit_cast(uint32_t, keep);
 }
-inline bool range16_of(const dmxq_float_fmt* f, Range16* r) {  // false: this format is not a range-only cast of bf16 values
+// false: this format is not a range-only cast of `dtype` values.  The reference's largest exponent is 2^(exp_bits-1) whatever the
+// bias (quant_cpu.cpp:359-402 through numerical/format.py:166-167), so its "FP16" saturates at 2^16 (2 - 2^-10), not at 65504.
+inline bool range16_of(const dmxq_float_fmt* f, int dtype, Range16* r) {
+  if (dtype != DMXQ_BF16 && dtype != DMXQ_F16) return false;
   if (!f || f->exp_bits == 0) { *r = Range16{0xFFFFFFFFu, 0u}; return true; }  // SAME: identity
-  if (f->exp_bits < 1 || f->exp_bits > 8 || f->man_bits < 7 || f->man_bits > 22 || !f->flush_subnormal) return false;
-  const int min_exp = -(f->exp_bias - 1), max_e = (1 << (f->exp_bits - 1)) + 127;
-  if (min_exp < -126 || min_exp > 127) return false;
-  const uint32_t limit = max_e >= 255 ? 0xFFFFu : (f->man_bits > 7 ? (uint32_t)(max_e + 1) << 7 : ((uint32_t)max_e << 7) | 0x7Fu);
-  const uint32_t minb = (uint32_t)(127 + min_exp) << 7;
+  const int dman = dtype == DMXQ_BF16 ? 7 : 10;
+  if (f->exp_bits < 1 || f->exp_bits > 8 || f->man_bits < dman || f->man_bits > 22 || !f->flush_subnormal) return false;
+  const int min_exp = -(f->exp_bias - 1), max_u = 1 << (f->exp_bits - 1);  // unbiased exponents of the smallest / largest binade
+  uint32_t limit, minb;
+  if (dtype == DMXQ_BF16) {
+    if (min_exp < -126 || min_exp > 127) return false;
+    const int max_e = max_u + 127;
+    // |x| bits above the largest binade are replaced by bf16(max_val): (max_e + 1) << 7 when man > 7 (max_val = 2^max_u (2 - 2^-man)
+    // rounds up), (max_e << 7) | 0x7F when man == 7; max_e = 255: no limit at all
+    limit = max_e >= 255 ? 0xFFFFu : (f->man_bits > 7 ? (uint32_t)(max_e + 1) << 7 : ((uint32_t)max_e << 7) | 0x7Fu);
+    minb = (uint32_t)(127 + min_exp) << 7;   // bits of 2^min_exp: below it the value is flushed to +0
+  } else {
+    if (min_exp > 15) return false;
+    // fp16 words: max_val >= 65520 rounds to Inf in the tensor dtype (finite fp16 values are never clamped, NaN becomes +-Inf)
+    if (max_u >= 16 || (max_u == 15 && f->man_bits > 10)) limit = 0x7C00u;
+    else limit = f->man_bits > 10 ? (uint32_t)(max_u + 1 + 15) << 10 : ((uint32_t)(max_u + 15) << 10) | 0x3FFu;
+    if (max_u + 15 < 1) return false;
+    minb = min_exp >= -14 ? (uint32_t)(min_exp + 15) << 10 : (min_exp >= -24 ? 1u << (min_exp + 24) : 1u);  // normal / subnormal bits of 2^min_exp
+  }
   *r = Range16{limit | (limit << 16), minb | (minb << 16)};
   return true;
 }

@@ -637,7 +637,7 @@ extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype
 // DmxModule (modeling/nn/core.py:228-264: two input casts, the torch op, the output cast): 6 B/element instead of 18.
 // The op itself is torch's: fp32 arithmetic on the widened operands, one RNE rounding to bf16.
 struct BinArgs { const void* a; const void* b; void* out; int64_t n_vec; Range16 ra, rb, ro; };
-template <int OP, int T, int U>
+template <int DT, int OP, int T, int U>
 __global__ __launch_bounds__(T) void binary_range_bf16_kernel(const BinArgs g) {
   constexpr int64_t TILE = (int64_t)T * U;
   const int64_t base = (int64_t)blockIdx.x * TILE + threadIdx.x;
@@ -654,9 +654,11 @@ __global__ __launch_bounds__(T) void binary_range_bf16_kernel(const BinArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const uint32_t wa = range16_word(ra[u][j], g.ra), wb = range16_word(rb[u][j], g.rb);
-      const float a0 = u2f(wa << 16), a1 = u2f(wa & 0xFFFF0000u), b0 = u2f(wb << 16), b1 = u2f(wb & 0xFFFF0000u);
+      float a0, a1, b0, b1;
+      if (DT == DMXQ_BF16) { a0 = u2f(wa << 16); a1 = u2f(wa & 0xFFFF0000u); b0 = u2f(wb << 16); b1 = u2f(wb & 0xFFFF0000u); }
+      else { a0 = half_lo(wa); a1 = half_hi(wa); b0 = half_lo(wb); b1 = half_hi(wb); }
       const float c0 = OP == 0 ? a0 + b0 : a0 * b0, c1 = OP == 0 ? a1 + b1 : a1 * b1;
-      ra[u][j] = range16_word(pack2<DMXQ_BF16>(c0, c1), g.ro);
+      ra[u][j] = range16_word(pack2<DT>(c0, c1), g.ro);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -673,15 +675,20 @@ extern "C" int dmxq_binary_cast(const void* a, const void* b, void* out, int dty
   if (n == 0) return DMXQ_OK;
   if (!a || !b || !out) return DMXQ_ERR_BAD_ARG;
   BinArgs g{a, b, out, n / 8, {}, {}, {}};
-  if (dtype != DMXQ_BF16 || n % 8 != 0 || !aligned16(a) || !aligned16(b) || !aligned16(out) || !range16_of(cast_a, &g.ra) ||
-      !range16_of(cast_b, &g.rb) || !range16_of(cast_out, &g.ro))
+  if (n % 8 != 0 || !aligned16(a) || !aligned16(b) || !aligned16(out) || !range16_of(cast_a, dtype, &g.ra) ||
+      !range16_of(cast_b, dtype, &g.rb) || !range16_of(cast_out, dtype, &g.ro))
     return DMXQ_ERR_UNSUPPORTED;
   constexpr int T = 256, U = 4;
   const int64_t tiles = (g.n_vec + T * U - 1) / (T * U);
   if (tiles > 0x7FFFFFFF) return DMXQ_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  if (op == DMXQ_BINARY_ADD) DMXQ_LAUNCH((binary_range_bf16_kernel<0, T, U>), dim3((unsigned)tiles), dim3(T), 0, s, g);
-  else DMXQ_LAUNCH((binary_range_bf16_kernel<1, T, U>), dim3((unsigned)tiles), dim3(T), 0, s, g);
+  if (dtype == DMXQ_BF16) {
+    if (op == DMXQ_BINARY_ADD) DMXQ_LAUNCH((binary_range_bf16_kernel<DMXQ_BF16, 0, T, U>), dim3((unsigned)tiles), dim3(T), 0, s, g);
+    else DMXQ_LAUNCH((binary_range_bf16_kernel<DMXQ_BF16, 1, T, U>), dim3((unsigned)tiles), dim3(T), 0, s, g);
+  } else {
+    if (op == DMXQ_BINARY_ADD) DMXQ_LAUNCH((binary_range_bf16_kernel<DMXQ_F16, 0, T, U>), dim3((unsigned)tiles), dim3(T), 0, s, g);
+    else DMXQ_LAUNCH((binary_range_bf16_kernel<DMXQ_F16, 1, T, U>), dim3((unsigned)tiles), dim3(T), 0, s, g);
+  }
   return launch_status();
 }
 

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kThreads) void rope_kernel(const void* __restrict__
     const u32x4 rc = *(const u32x4*)((const char*)cs + ((int64_t)crow * vpr + vc) * 16);
     const u32x4 rs = *(const u32x4*)((const char*)sn + ((int64_t)crow * vpr + vc) * 16);
     u32x4 cx = rx, cp = rp, cc = rc, cs2 = rs;
-    if constexpr (DT == DMXQ_BF16) {  // the module's input casts (dmxq_rope_cast: range-only formats; identity ranges for dmxq_rope)
+    if constexpr (DT != DMXQ_F32) {  // the module's input casts (dmxq_rope_cast: range-only formats; identity ranges for dmxq_rope)
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         cx[j] = range16_word(rx[j], rgx); cp[j] = range16_word(rp[j], rgx);
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kThreads) void rope_kernel(const void* __restrict__
       y[k] = t1 + t2;   // rounded to DT by the store
     }
     OutVec<DT, EPL> o = pack_vec<DT, EPL>(y);
-    if constexpr (DT == DMXQ_BF16) {  // ... and its output cast
+    if constexpr (DT != DMXQ_F32) {  // ... and its output cast
 #pragma unroll
       for (int j = 0; j < 4; j++) o.w[j] = range16_word(o.w[j], rgo);
     }
@@ -105,7 +105,7 @@ extern "C" int dmxq_rope_cast(const void* x, const void* cos_tab, const void* si
                               int64_t n2, int64_t D, int broadcast_over_dim1, const dmxq_float_fmt* cast_x, const dmxq_float_fmt* cast_cos,
                               const dmxq_float_fmt* cast_sin, const dmxq_float_fmt* cast_out, void* stream) {
   Range16 rx, rc, rs, ro;
-  if (dtype != DMXQ_BF16 || !range16_of(cast_x, &rx) || !range16_of(cast_cos, &rc) || !range16_of(cast_sin, &rs) || !range16_of(cast_out, &ro))
+  if (!range16_of(cast_x, dtype, &rx) || !range16_of(cast_cos, dtype, &rc) || !range16_of(cast_sin, dtype, &rs) || !range16_of(cast_out, dtype, &ro))
     return valid_dtype(dtype) ? DMXQ_ERR_UNSUPPORTED : DMXQ_ERR_BAD_ARG;
   return rope_launch(x, cos_tab, sin_tab, out, dtype, B, n1, n2, D, broadcast_over_dim1, rx, rc, rs, ro, stream);
 }

@@ -485,7 +485,7 @@ class _BinaryElementwise(DmxModule):
 
     def _fused_forward(self, a, b=None, *args, **kwargs):
         if (not self.fuse_binary or args or kwargs or not isinstance(a, torch.Tensor) or not isinstance(b, torch.Tensor)
-                or a.shape != b.shape or a.dtype != b.dtype or a.dtype != torch.bfloat16 or a.device != b.device or not a.is_cuda
+                or a.shape != b.shape or a.dtype != b.dtype or a.dtype not in (torch.bfloat16, torch.float16) or a.device != b.device or not a.is_cuda
                 or self.smoothquant is not None and self.smoothquant._flag("enabled")
                 or torch.is_grad_enabled() and (a.requires_grad or b.requires_grad) or torch.compiler.is_compiling()
                 or not isinstance(self.approximator.function, NoApproximation)):
@@ -637,7 +637,7 @@ class ApplyRotaryPosEmb(DmxModule):
         """Four input casts, the exact function (about six torch kernels per operand) and two output casts as TWO launches
         (dmxq_rope_cast for q and for k) when everything is bf16 and every cast is range-only; else the general path."""
         ts = (q, k, cos, sin)
-        if (not self.fuse_rope or args or kwargs or any(not isinstance(t, torch.Tensor) for t in ts) or any(t.dtype != torch.bfloat16 for t in ts)
+        if (not self.fuse_rope or args or kwargs or any(not isinstance(t, torch.Tensor) for t in ts) or q.dtype not in (torch.bfloat16, torch.float16) or any(t.dtype != q.dtype for t in ts)
                 or not q.is_cuda or q.dim() != 4 or k.dim() != 4 or unsqueeze_dim not in (1, 2)
                 or self.smoothquant is not None and self.smoothquant._flag("enabled")
                 or torch.is_grad_enabled() and any(t.requires_grad for t in ts) or torch.compiler.is_compiling()

@@ -209,8 +209,8 @@ int dmxq_input_hypernet(const void* x, int dtype_x, const float* sq_scale, void*
  * launches of modeling/nn/core.py:228-264 for such a module (CastToDict.forward on both inputs, numerical/cast.py:59-86; the op;
  * the output cast): 6 B/element instead of 18.  A cast is described by its FloatingPoint format (numerical/format.py:174-233,
  * nearest rounding, signed); NULL or exp_bits == 0 = SAME.  Fused only when every cast is RANGE-ONLY for the tensor dtype (bf16
- * tensors, man_bits >= 7, subnormals flushed: the FLOAT16-style formats of the BASIC rules); anything else returns
- * DMXQ_ERR_UNSUPPORTED and the caller runs the unfused ops.  Bit-identical to that chain. */
+ * tensors with man_bits >= 7, fp16 tensors with man_bits >= 10; subnormals flushed: the FLOAT16-style formats of the BASIC rules);
+ * anything else returns DMXQ_ERR_UNSUPPORTED and the caller runs the unfused ops.  Bit-identical to that chain; a / b may alias out. */
 typedef struct { int man_bits, exp_bits, exp_bias, flush_subnormal; } dmxq_float_fmt;
 enum { DMXQ_BINARY_ADD = 0, DMXQ_BINARY_MUL = 1 };
 int dmxq_binary_cast(const void* a, const void* b, void* out, int dtype, int64_t n, int op, const dmxq_float_fmt* cast_a,
@@ -219,7 +219,7 @@ int dmxq_binary_cast(const void* a, const void* b, void* out, int dtype, int64_t
 /* One operand (q or k) of an ApplyRotaryPosEmb DmxModule (modeling/nn/custom_modules.py:142-194) with the module's casts:
  * out = cast_out(rope(cast_x(x), cast_cos(cos), cast_sin(sin))), rope as dmxq_rope below (torch's op-by-op arithmetic in the
  * tensor dtype).  Replaces, per operand, three input casts, the ~6 torch kernels of the exact function and the output cast.
- * bf16 tensors, range-only formats (see dmxq_binary_cast); DMXQ_ERR_UNSUPPORTED otherwise. */
+ * 16-bit tensors, range-only formats (see dmxq_binary_cast); DMXQ_ERR_UNSUPPORTED otherwise. */
 int dmxq_rope_cast(const void* x, const void* cos_tab, const void* sin_tab, void* out, int dtype, int64_t B, int64_t n1, int64_t n2,
                    int64_t D, int broadcast_over_dim1, const dmxq_float_fmt* cast_x, const dmxq_float_fmt* cast_cos,
                    const dmxq_float_fmt* cast_sin, const dmxq_float_fmt* cast_out, void* stream);
