@@ -451,7 +451,8 @@ inline bool range16_of(const dmxq_float_fmt* f, int dtype, Range16* r) {
   } else {
     if (min_exp > 15) return false;
     // fp16 words: max_val >= 65520 rounds to Inf in the tensor dtype (finite fp16 values are never clamped, NaN becomes +-Inf)
-    if (max_u >= 16 || (max_u == 15 && f->man_bits > 10)) limit = 0x7C00u;
+    if (max_u >= 128) limit = 0xFFFFu;  // exp_bits = 8: nothing exceeds the largest binade, Inf and NaN pass through
+    else if (max_u >= 16 || (max_u == 15 && f->man_bits > 10)) limit = 0x7C00u;
     else limit = f->man_bits > 10 ? (uint32_t)(max_u + 1 + 15) << 10 : ((uint32_t)(max_u + 15) << 10) | 0x3FFu;
     if (max_u + 15 < 1) return false;
     minb = min_exp >= -14 ? (uint32_t)(min_exp + 15) << 10 : (min_exp >= -24 ? 1u << (min_exp + 24) : 1u);  // normal / subnormal bits of 2^min_exp

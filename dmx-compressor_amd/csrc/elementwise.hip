@@ -612,19 +612,13 @@ extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype
   if (!in || !out) return DMXQ_ERR_BAD_ARG;
   const FloatFmt f{man_bits, exp_bits, exp_bias, flush_subnormal ? 1 : 0, unsigned_abs ? 1 : 0, rounding, seed};
   hipStream_t s = (hipStream_t)stream;
-  // bf16 -> bf16, nearest, at least bf16's 7 mantissa bits kept, subnormals flushed, signed: the packed range-only kernel
-  {
-    const int min_exp = -(exp_bias - 1), max_e = (1 << (exp_bits - 1)) + 127;
-    if (dtype_in == DMXQ_BF16 && dtype_out == DMXQ_BF16 && rounding == DMXQ_ROUND_NEAREST && man_bits >= 7 && flush_subnormal &&
-        !unsigned_abs && n % 8 == 0 && aligned16(in) && aligned16(out) && min_exp >= -126 && min_exp <= 127) {
-      // |x| bits of every value whose exponent field exceeds max_e are replaced by bf16(max_val): (max_e + 1) << 7 when man > 7
-      // (max_val = 2^(max_e-127) (2 - 2^-man) rounds up), (max_e << 7) | 0x7F when man == 7; max_e = 255: no limit at all
-      const uint32_t limit = max_e >= 255 ? 0xFFFFu : (man_bits > 7 ? (uint32_t)(max_e + 1) << 7 : ((uint32_t)max_e << 7) | 0x7Fu);
-      const uint32_t minb = (uint32_t)(127 + min_exp) << 7;   // bf16 bits of 2^min_exp: below it the value is flushed to +0
-      // keep iff a >= minb  <=>  sat(sat(a + 1) - minb) != 0
-      const Range16 r{limit | (limit << 16), minb | (minb << 16)};
-      return launch_float_range_bf16(in, out, n / 8, r, s);
-    }
+  // 16-bit -> the same 16-bit dtype, nearest, at least the dtype's own mantissa bits kept, subnormals flushed, signed: the packed
+  // range-only kernel (common.hpp range16_of decides and builds the two thresholds)
+  if (dtype_in == dtype_out && dtype_in != DMXQ_F32 && rounding == DMXQ_ROUND_NEAREST && !unsigned_abs && n % 8 == 0 && aligned16(in) &&
+      aligned16(out)) {
+    const dmxq_float_fmt ff{man_bits, exp_bits, exp_bias, flush_subnormal ? 1 : 0};
+    Range16 r;
+    if (range16_of(&ff, dtype_in, &r)) return launch_float_range_bf16(in, out, n / 8, r, s);
   }
   if (rounding == DMXQ_ROUND_NEAREST) return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<DMXQ_ROUND_NEAREST>{f, make_float_fast(f.man, f.exp_bits, f.bias)}, s);
   return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<kRuntimeRounding>{f, make_float_fast(f.man, f.exp_bits, f.bias)}, s);

@@ -39,6 +39,21 @@ def test_float_qdq_stochastic_matches_oracle_stream(dmx, cuda, oracle, rounding)
     assert bits_equal(got, oracle.float_quantize(x, 3, 4, 7, False, rounding, 42)) == 0
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_float_qdq_every_16_bit_pattern(dmx, cuda, oracle, dtype):
+    """EXHAUSTIVE: all 65536 bit patterns of the tensor dtype (every NaN payload, both infinities, every subnormal) through the
+    formats that take the packed range-only kernel (common.hpp range16_of) and through ones that do not, against the oracle on the
+    widened value followed by CastTo's `.to(dtype)`; any NaN == any NaN."""
+    from _data import mismatches_nan_aware
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    x = bits.view(dtype).repeat(2)     # 131072 elements: whole 16-byte vectors, two tiles
+    for man, exp, bias, flush in ((10, 5, 15, True), (7, 8, 127, True), (10, 4, 7, True), (12, 5, 15, True), (22, 8, 127, True), (10, 5, 15, False),
+                                  (3, 4, 7, True), (7, 5, 15, True), (10, 8, 127, True), (10, 3, 3, True), (11, 2, 1, True)):
+        want = oracle.float_quantize(x.float(), man, exp, bias, flush).to(dtype)
+        got = dmx.ops.float_qdq(x.to(cuda), man, exp, bias, flush)
+        assert got.dtype == dtype and mismatches_nan_aware(got.cpu(), want) == 0, (dtype, man, exp, bias, flush)
+
+
 def test_float_unsigned_and_bypass(dmx, cuda, oracle):
     x = make("normal", (1000,), seed=1)
     f = dmx.Format.from_shorthand("FP[0|4|4,7](FN)")
