@@ -193,7 +193,7 @@ extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_o
       if (ru != DMXQ_ERR_UNSUPPORTED) return ru;
     }
   }
-  if (inner > 1 && inner <= 64) {  // a few elements between the members of a block: sub-slabs through the LDS (bfp_smallinner.hip)
+  if (inner > 1 && inner < 64) {  // a few elements between the members of a block: sub-slabs through the LDS (bfp_smallinner.hip)
     const int rc = dmxq_internal_bfp_smallinner(in, out, dtype_in, dtype_out, outer, L, inner, block_size, precision, rounding, symmetric,
                                                 stream);
     if (rc != DMXQ_ERR_UNSUPPORTED) return rc;
