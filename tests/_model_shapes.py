@@ -55,6 +55,15 @@ def _boundary(stages, tag, m, device, inputs, out_shape, dtype, out_scale=4.0):
             stages.append((f"{tag}/in{i + 1}", t.detach().cpu().contiguous()))
         pre = stage_input(f"{tag}/pre", out_shape, dtype, out_scale).to(device)
         stages.append((f"{tag}/out", m.output_casts(pre, output=True).detach().cpu().contiguous()))
+        # this repo's mirror only: a binary module that fuses its whole forward (dmxq_binary_cast) == its general path, at this shape
+        if hasattr(m, "fuse_binary") and len(inputs) == 2 and inputs[0].shape == inputs[1].shape:
+            a, b = inputs[0].to(device), inputs[1].to(device)
+            if m._fused_forward(a, b) is not None:
+                y_f = m(a, b)
+                m.fuse_binary = False
+                y_u = m(a, b)
+                m.fuse_binary = True
+                assert digest(y_f.cpu().contiguous()) == digest(y_u.cpu().contiguous()), f"{tag}: fused binary module"
 
 
 def _linear_stages(stages, tag, m, device, x, dtype, out_features):
@@ -66,6 +75,11 @@ def _linear_stages(stages, tag, m, device, x, dtype, out_features):
             stages.append((f"{tag}/sq_in", xin.detach().cpu().contiguous()))
         cin, _, _ = m.input_casts(xin)
         stages.append((f"{tag}/in", cin.detach().cpu().contiguous()))
+        # this repo's mirror only: the fused activation path (dmxq_input_hypernet), when the configuration takes it, must give the
+        # very tensor whose digest is compared with the reference's
+        fused = m._fused_input(x.to(device)) if hasattr(m, "_fused_input") and getattr(m, "smoothquant", None) is not None else None
+        if fused is not None:
+            assert fused.dtype == cin.dtype and digest(fused.detach().cpu().contiguous()) == digest(cin.detach().cpu().contiguous()), f"{tag}: fused input path"
         stages.append((f"{tag}/w", m._weight.detach().cpu().contiguous()))
         if m.bias is not None:
             stages.append((f"{tag}/b", m._bias.detach().cpu().contiguous()))
