@@ -52,9 +52,17 @@ def test_no_cpu_fallback(dmx):
     x = torch.randn(4, 16)
     for call in (lambda: dmx.ops.bfp_qdq(x, 8, 16), lambda: dmx.ops.float_qdq(x, 10, 5, 15, True),
                  lambda: dmx.ops.fixed_qdq(x, 8, 0), lambda: dmx.ops.nm_mask(x, 2, 4),
-                 lambda: dmx.CastTo(format="BFP[8|8]{16}(SN)")(x), lambda: dmx.ops.gelu(x)):
+                 lambda: dmx.CastTo(format="BFP[8|8]{16}(SN)")(x), lambda: dmx.ops.gelu(x),
+                 lambda: dmx.ops.input_hypernet(x, torch.ones(16), 8, 16), lambda: dmx.ops.binary_cast(x, x, "add"),
+                 lambda: dmx.ops.rope_cast(x.view(1, 1, 4, 16), torch.ones(1, 4, 16), torch.ones(1, 4, 16)),
+                 lambda: dmx.ops.weight_hypernet(x, 8, 16)):
         with pytest.raises(dmx.DmxqError):
             call()
+    # the fused module paths never catch that: a CPU tensor goes to the general path and fails there, loudly
+    m = dmx.nn.ResAdd()
+    m.configure(dict(input_formats=["FP[1|5|10,15](FN)"] * 2, output_formats=["FP[1|5|10,15](FN)"]))
+    with pytest.raises(dmx.DmxqError):
+        m(x.to(torch.bfloat16), x.to(torch.bfloat16))
 
 
 SHORTHANDS = ["SAME", "XP[8,0](CSN)", "XP[4,0](CSN)", "XP[8,+4](C_N)", "XP[16,-2](_SS)", "FP[1|5|10,15](FN)",
