@@ -32,6 +32,7 @@ SIGNATURES = {
     "dmxq_weight_hypernet": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_input_hypernet": [_vp, _i32, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_binary_cast": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
+    "dmxq_relu_cast": [_vp, _vp, _i32, _i64, _vp, _vp, _vp],
     "dmxq_float_qdq": [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _u64, _vp],
     "dmxq_fixed_qdq": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _u64, _vp],
     "dmxq_fixed_qdq_multi": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _u64, _vp],

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -488,6 +488,25 @@ def rope(x, cos, sin, unsqueeze_dim: int = 1):
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     check(rc, "dmxq_rope")
+    return out
+
+
+def relu_cast(x, cast_in=None, cast_out=None):
+    """A ReLU DmxModule in one launch: cast_out(relu(cast_in(x))); casts are FloatingPoint formats (nearest, signed) or None = SAME.
+    None when not fusable."""
+    import ctypes
+    xc = _prep(x, "relu_cast")
+    structs = []
+    for f in (cast_in, cast_out):
+        if f is not None and (f.rounding != "nearest" or f.unsigned):
+            return None
+        structs.append(None if f is None else _lib.FloatFmt(int(f.mantissa), int(f.exponent), int(f.bias), int(bool(f.flush_subnormal))))
+    ptrs = [ctypes.cast(ctypes.pointer(st), ctypes.c_void_p) if st is not None else None for st in structs]
+    out = torch.empty_like(xc)
+    rc = lib().dmxq_relu_cast(ptr(xc), ptr(out), dtype_code(xc.dtype), xc.numel(), *ptrs, stream_of(xc))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    check(rc, "dmxq_relu_cast")
     return out
 
 

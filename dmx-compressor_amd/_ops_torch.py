@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import DmxqError, ROUNDING_CODE, require_gpu
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -358,6 +358,19 @@ def rope(x, cos, sin, unsqueeze_dim: int = 1):
     require_gpu(x, "rope")
     try:
         return _ops.rope(x, cos, sin, unsqueeze_dim)
+    except NotImplementedError:
+        return None
+
+
+def relu_cast(x, cast_in=None, cast_out=None):
+    """A ReLU DmxModule in one launch: cast_out(relu(cast_in(x))); casts are FloatingPoint formats (nearest, signed) or None = SAME.
+    None when not fusable."""
+    require_gpu(x, "relu_cast")
+    for f in (cast_in, cast_out):
+        if f is not None and (f.rounding != "nearest" or f.unsigned):
+            return None
+    try:
+        return _ops.relu_cast(x, _fmt4(cast_in), _fmt4(cast_out))
     except NotImplementedError:
         return None
 

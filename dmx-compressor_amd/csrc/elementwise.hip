@@ -686,6 +686,52 @@ extern "C" int dmxq_binary_cast(const void* a, const void* b, void* out, int dty
   return launch_status();
 }
 
+
+// A ReLU DmxModule in one pass (dmxq_relu_cast): out = cast_out(relu(cast_in(x))) on 16-bit tensors with range-only casts, all on
+// the packed words.  relu = at::clamp_min(x, 0): negative values (not -0.0, not NaN) become +0.0, everything else passes.
+__device__ __forceinline__ uint32_t relu16_word(uint32_t w, uint32_t inf_bits2) {
+  const u16x2 mag = __builtin_bit_cast(u16x2, w & 0x7FFF7FFFu);
+  // per half: zero iff sign set and 0 < mag <= Inf  <=>  keep iff sign clear, or mag == 0, or mag > Inf (NaN)
+  const u16x2 sgn = __builtin_bit_cast(u16x2, (w >> 15) & 0x00010001u);                                  // 1 where negative
+  const u16x2 nonzero = __builtin_elementwise_min(mag, (u16x2){1, 1});                                   // 1 where mag != 0
+  const u16x2 notnan = (u16x2){1, 1} - __builtin_elementwise_min(__builtin_elementwise_sub_sat(mag, __builtin_bit_cast(u16x2, inf_bits2)), (u16x2){1, 1});
+  const u16x2 kill = sgn * nonzero * notnan;                                                              // 1 where the half becomes +0
+  const u16x2 keep = ((u16x2){1, 1} - kill) * (u16x2){0xFFFF, 0xFFFF};
+  return w & __builtin_bit_cast(uint32_t, keep);
+}
+struct ReluArgs { const void* in; void* out; int64_t n_vec; Range16 ri, ro; uint32_t inf2; };
+template <int T, int U>
+__global__ __launch_bounds__(T) void relu_range16_kernel(const ReluArgs g) {
+  const int64_t base = (int64_t)blockIdx.x * ((int64_t)T * U) + threadIdx.x;
+  u32x4 r[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) r[u] = load_raw16<true>(g.in, (base + u * T < g.n_vec ? base + u * T : g.n_vec - 1) * 16);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; u++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) r[u][j] = range16_word(relu16_word(range16_word(r[u][j], g.ri), g.inf2), g.ro);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; u++)
+    if (base + u * T < g.n_vec) __builtin_nontemporal_store(r[u], (u32x4*)((char*)g.out + (base + u * T) * 16));
+}
+
+extern "C" int dmxq_relu_cast(const void* in, void* out, int dtype, int64_t n, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out,
+                              void* stream) {
+  if (!valid_dtype(dtype) || n < 0) return DMXQ_ERR_BAD_ARG;
+  if (n == 0) return DMXQ_OK;
+  if (!in || !out) return DMXQ_ERR_BAD_ARG;
+  ReluArgs g{in, out, n / 8, {}, {}, dtype == DMXQ_BF16 ? 0x7F807F80u : 0x7C007C00u};
+  if (n % 8 != 0 || !aligned16(in) || !aligned16(out) || !range16_of(cast_in, dtype, &g.ri) || !range16_of(cast_out, dtype, &g.ro))
+    return DMXQ_ERR_UNSUPPORTED;
+  constexpr int T = 256, U = 8;
+  const int64_t tiles = (g.n_vec + T * U - 1) / (T * U);
+  if (tiles > 0x7FFFFFFF) return DMXQ_ERR_UNSUPPORTED;
+  DMXQ_LAUNCH((relu_range16_kernel<T, U>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, g);
+  return launch_status();
+}
+
 #endif  // part 1a
 #if DMXQ_EW(2)
 extern "C" int dmxq_fixed_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t C,

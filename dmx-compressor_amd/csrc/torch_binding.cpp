@@ -234,6 +234,17 @@ Tensor binary_cast_meta(const Tensor& a, const Tensor&, int64_t, at::IntArrayRef
   return empty_like_shape(a, a.scalar_type());
 }
 
+Tensor relu_cast(const Tensor& x, at::IntArrayRef cast_in, at::IntArrayRef cast_out) {
+  const Tensor xc = prep(x, "relu_cast");
+  Tensor out = empty_like_shape(xc, xc.scalar_type());
+  dmxq_float_fmt fi, fo;
+  Launch l(xc);
+  check(dmxq_relu_cast(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), xc.numel(), fmt_of(cast_in, &fi), fmt_of(cast_out, &fo), l.stream),
+        "dmxq_relu_cast");
+  return out;
+}
+Tensor relu_cast_meta(const Tensor& x, at::IntArrayRef, at::IntArrayRef) { return empty_like_shape(x, x.scalar_type()); }
+
 Tensor sbfp_qdq(const Tensor& x, int64_t precision, int64_t block_size, int64_t sman, int64_t sexp, int64_t sbias, bool sflush,
                 bool clamp, bool symmetric, int64_t block_dim, OptDtype out_dtype) {
   const Tensor xc = prep(x, "sbfp_qdq");
@@ -579,6 +590,7 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("weight_hypernet(Tensor w, int precision, int block_size, bool symmetric, Tensor? score, int K, int M, Tensor? sq_scale, ScalarType? out_dtype=None) -> Tensor");
   m.def("input_hypernet(Tensor x, Tensor sq_scale, int precision, int block_size, bool symmetric) -> Tensor");
   m.def("binary_cast(Tensor a, Tensor b, int op, int[] cast_a, int[] cast_b, int[] cast_out) -> Tensor");
+  m.def("relu_cast(Tensor x, int[] cast_in, int[] cast_out) -> Tensor");
   m.def("sbfp_qdq(Tensor x, int precision, int block_size, int scaler_man, int scaler_exp, int scaler_bias, bool scaler_flush, bool clamp, bool symmetric, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
   m.def("mxfp_qdq(Tensor x, int man, int exp, int block_size, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
   m.def("float_qdq(Tensor x, int man, int exp, int bias, bool flush_subnormal, bool unsigned_abs=False, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");
@@ -603,7 +615,7 @@ TORCH_LIBRARY(dmxq, m) {
 #define DMXQ_IMPL(m, name) m.impl(#name, &name)
 #define DMXQ_META(m, name) m.impl(#name, &name##_meta)
 #define DMXQ_FOR_ALL(X, m) \
-  X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, input_hypernet); X(m, binary_cast); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
+  X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, input_hypernet); X(m, binary_cast); X(m, relu_cast); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
   X(m, float_qdq); X(m, fixed_qdq); X(m, fixed_qdq_multi); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
   X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, rope); X(m, rope_cast); X(m, softmax); X(m, norm)
 

@@ -680,6 +680,24 @@ class ReLU(DmxModule, torch.nn.ReLU):
     def _forward(self, _input):
         return F.relu(_input)
 
+    fuse_relu = True
+
+    def _fused_forward(self, x, *args, **kwargs):
+        """input cast -> F.relu -> output cast as ONE launch (dmxq_relu_cast) on a 16-bit tensor with range-only casts"""
+        if (not self.fuse_relu or args or kwargs or not isinstance(x, torch.Tensor) or x.dtype not in (torch.bfloat16, torch.float16)
+                or not x.is_cuda or self.smoothquant is not None and self.smoothquant._flag("enabled")
+                or torch.is_grad_enabled() and x.requires_grad or torch.compiler.is_compiling()
+                or not isinstance(self.approximator.function, NoApproximation)):
+            return None
+        ics, ocs = list(self.input_casts.values()), list(self.output_casts.values())
+        if len(ics) != 1 or len(ocs) != 1:
+            return None
+        (ok_i, fi), (ok_o, fo) = _range_only_format(ics[0], x.dtype), _range_only_format(ocs[0], x.dtype)
+        if not (ok_i and ok_o):
+            return None
+        from . import ops
+        return ops.relu_cast(x.detach(), fi, fo)
+
 
 class MaxPool2d(DmxModule, torch.nn.MaxPool2d):
     def __init__(self, *a, **kw):

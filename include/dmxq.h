@@ -216,6 +216,12 @@ enum { DMXQ_BINARY_ADD = 0, DMXQ_BINARY_MUL = 1 };
 int dmxq_binary_cast(const void* a, const void* b, void* out, int dtype, int64_t n, int op, const dmxq_float_fmt* cast_a,
                      const dmxq_float_fmt* cast_b, const dmxq_float_fmt* cast_out, void* stream);
 
+/* A ReLU DmxModule (modeling/nn/torch_modules.py ReLU through core.py:228-264: input cast, F.relu, output cast) in one pass on
+ * 16-bit tensors with range-only casts (see dmxq_binary_cast): out = cast_out(clamp_min(cast_in(x), 0)).  4 B/element instead of
+ * 12 over three launches.  DMXQ_ERR_UNSUPPORTED otherwise. */
+int dmxq_relu_cast(const void* in, void* out, int dtype, int64_t n, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out,
+                   void* stream);
+
 /* One operand (q or k) of an ApplyRotaryPosEmb DmxModule (modeling/nn/custom_modules.py:142-194) with the module's casts:
  * out = cast_out(rope(cast_x(x), cast_cos(cos), cast_sin(sin))), rope as dmxq_rope below (torch's op-by-op arithmetic in the
  * tensor dtype).  Replaces, per operand, three input casts, the ~6 torch kernels of the exact function and the output cast.
