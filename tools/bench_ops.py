@@ -151,6 +151,8 @@ def main():
                    L.dmxq_float_qdq(vp(xs[(i + 1) % k].data_ptr()), vp(ys[(i + 1) % k].data_ptr()), _lib.BF16, _lib.BF16, n, 10, 5, 15, 1, 0, 2, 0, sp),
                    torch.add(ys[i], ys[(i + 1) % k], out=ys[(i + 2) % k]),
                    L.dmxq_float_qdq(vp(ys[(i + 2) % k].data_ptr()), vp(ys[(i + 3) % k].data_ptr()), _lib.BF16, _lib.BF16, n, 10, 5, 15, 1, 0, 2, 0, sp)), k, n * 6)
+    run("relu_cast ReLU module: FLOAT16 input and output casts, bf16 (one launch, 4 B/elem; 3 launches unfused)",
+        lambda i: L.dmxq_relu_cast(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, n, pf, pf, sp), k, n * 4)
     ws = torch.empty(L.dmxq_topk_workspace_bytes(n) // 8 + 1, dtype=torch.int64, device=dev)
     run("topk_sparsify TOPK{0.5} fp32 score, bf16 x -> bf16 y (radix select + apply; 4 score reads)",
         lambda i: L.dmxq_topk_mask(vp(ss[i % k2].data_ptr()), _lib.F32, vp(xs[i].data_ptr()), _lib.BF16, None, 0, vp(ys[i].data_ptr()), _lib.BF16, n, n // 2, vp(ws.data_ptr()), sp), k2, n * 8)
