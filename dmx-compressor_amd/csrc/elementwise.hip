@@ -550,8 +550,29 @@ using namespace dmxq;
 //     cast.py:306) to the bf16 word (max_e + 1) << 7 when man > 7 -- i.e. min_u16(|x| bits, limit) -- Inf and NaN included
 //     (the reference reserves no Inf / NaN codes: they saturate too).
 // 3.5 VALU operations per element instead of ~18, so the op streams like a copy; tile geometry by size as for BFP (rows_plan).
-template <int T, int U>
-__global__ __launch_bounds__(T) void float_range_bf16_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t n_vec, Range16 r) {
+__device__ __forceinline__ uint32_t relu16_word(uint32_t w, uint32_t inf_m1_2 /* Inf bits - 1 in both halves */) {
+  typedef short i16x2 __attribute__((ext_vector_type(2)));
+  const u16x2 mag = __builtin_bit_cast(u16x2, w & 0x7FFF7FFFu);
+  // a half is zeroed iff it is negative and 0 < mag <= Inf (not -0.0, not NaN):  t = mag - 1 wraps to 0xFFFF for mag = 0
+  const u16x2 t = mag - (u16x2){1, 1};
+  const u16x2 d = __builtin_elementwise_sub_sat(t, __builtin_bit_cast(u16x2, inf_m1_2));                 // 0 iff 1 <= mag <= Inf
+  const u16x2 in_range = __builtin_elementwise_min(d, (u16x2){1, 1}) - (u16x2){1, 1};                    // 0xFFFF iff in range
+  const u16x2 neg = __builtin_bit_cast(u16x2, __builtin_bit_cast(i16x2, w) >> (i16x2){15, 15});          // 0xFFFF iff sign set
+  return w & ~__builtin_bit_cast(uint32_t, neg & in_range);
+}
+// RELU: cast_out(relu(cast_in(w))) with r = the input cast's range and ro the output cast's (dmxq_relu_cast); else the cast alone
+struct ReluExtra { Range16 ro; uint32_t inf2; };
+// RELU: 0 = the cast alone, 1 = cast_out(relu(cast_in(w))), 2 = relu(cast_in(w)) (same format on both sides: no second cast)
+template <int RELU>
+__device__ __forceinline__ uint32_t range_or_relu(uint32_t w, const Range16& r, const ReluExtra& x) {
+  const uint32_t c = range16_word(w, r);
+  if (RELU == 0) return c;
+  const uint32_t q = relu16_word(c, x.inf2);
+  return RELU == 1 ? range16_word(q, x.ro) : q;
+}
+template <int T, int U, int RELU = 0>
+__global__ __launch_bounds__(T) void float_range_bf16_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t n_vec, Range16 r,
+                                                            ReluExtra rx) {
   constexpr int64_t TILE = (int64_t)T * U;
   const int64_t n_tiles = (n_vec + TILE - 1) / TILE;
   const uint32_t lane = threadIdx.x * 16u;
@@ -567,7 +588,7 @@ __global__ __launch_bounds__(T) void float_range_bf16_kernel(const void* __restr
 #pragma unroll
       for (int u = 0; u < U; u++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) raw[u][j] = range16_word(raw[u][j], r);
+        for (int j = 0; j < 4; j++) raw[u][j] = range_or_relu<RELU>(raw[u][j], r, rx);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -578,7 +599,7 @@ __global__ __launch_bounds__(T) void float_range_bf16_kernel(const void* __restr
         if (v < n_vec) {
           u32x4 w = load_raw16<true>(src + u * (T * 16), lane);
 #pragma unroll
-          for (int j = 0; j < 4; j++) w[j] = range16_word(w[j], r);
+          for (int j = 0; j < 4; j++) w[j] = range_or_relu<RELU>(w[j], r, rx);
           __builtin_nontemporal_store(w, (u32x4*)(dst + u * (T * 16) + lane));
         }
       }
@@ -586,10 +607,11 @@ __global__ __launch_bounds__(T) void float_range_bf16_kernel(const void* __restr
   }
 }
 
-static int launch_float_range_bf16(const void* in, void* out, int64_t n_vec, const Range16& r, hipStream_t s) {
+template <int RELU = 0>
+static int launch_float_range_bf16(const void* in, void* out, int64_t n_vec, const Range16& r, hipStream_t s, const ReluExtra& rx = ReluExtra{}) {
   const RowsPlan pl = rows_plan(n_vec, true);
   const unsigned grid = (unsigned)(pl.tiles < (1 << 20) ? pl.tiles : (1 << 20));
-#define DMXQ_RG(T_, U_) DMXQ_LAUNCH((float_range_bf16_kernel<T_, U_>), dim3(grid), dim3(T_), 0, s, in, out, n_vec, r)
+#define DMXQ_RG(T_, U_) DMXQ_LAUNCH((float_range_bf16_kernel<T_, U_, RELU>), dim3(grid), dim3(T_), 0, s, in, out, n_vec, r, rx)
   switch (pl.id) {
     case 0: DMXQ_RG(512, 1); break;
     case 1: DMXQ_RG(128, 2); break;
@@ -689,47 +711,19 @@ extern "C" int dmxq_binary_cast(const void* a, const void* b, void* out, int dty
 
 // A ReLU DmxModule in one pass (dmxq_relu_cast): out = cast_out(relu(cast_in(x))) on 16-bit tensors with range-only casts, all on
 // the packed words.  relu = at::clamp_min(x, 0): negative values (not -0.0, not NaN) become +0.0, everything else passes.
-__device__ __forceinline__ uint32_t relu16_word(uint32_t w, uint32_t inf_bits2) {
-  const u16x2 mag = __builtin_bit_cast(u16x2, w & 0x7FFF7FFFu);
-  // per half: zero iff sign set and 0 < mag <= Inf  <=>  keep iff sign clear, or mag == 0, or mag > Inf (NaN)
-  const u16x2 sgn = __builtin_bit_cast(u16x2, (w >> 15) & 0x00010001u);                                  // 1 where negative
-  const u16x2 nonzero = __builtin_elementwise_min(mag, (u16x2){1, 1});                                   // 1 where mag != 0
-  const u16x2 notnan = (u16x2){1, 1} - __builtin_elementwise_min(__builtin_elementwise_sub_sat(mag, __builtin_bit_cast(u16x2, inf_bits2)), (u16x2){1, 1});
-  const u16x2 kill = sgn * nonzero * notnan;                                                              // 1 where the half becomes +0
-  const u16x2 keep = ((u16x2){1, 1} - kill) * (u16x2){0xFFFF, 0xFFFF};
-  return w & __builtin_bit_cast(uint32_t, keep);
-}
-struct ReluArgs { const void* in; void* out; int64_t n_vec; Range16 ri, ro; uint32_t inf2; };
-template <int T, int U>
-__global__ __launch_bounds__(T) void relu_range16_kernel(const ReluArgs g) {
-  const int64_t base = (int64_t)blockIdx.x * ((int64_t)T * U) + threadIdx.x;
-  u32x4 r[U];
-#pragma unroll
-  for (int u = 0; u < U; u++) r[u] = load_raw16<true>(g.in, (base + u * T < g.n_vec ? base + u * T : g.n_vec - 1) * 16);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int u = 0; u < U; u++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) r[u][j] = range16_word(relu16_word(range16_word(r[u][j], g.ri), g.inf2), g.ro);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int u = 0; u < U; u++)
-    if (base + u * T < g.n_vec) __builtin_nontemporal_store(r[u], (u32x4*)((char*)g.out + (base + u * T) * 16));
-}
-
 extern "C" int dmxq_relu_cast(const void* in, void* out, int dtype, int64_t n, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out,
                               void* stream) {
   if (!valid_dtype(dtype) || n < 0) return DMXQ_ERR_BAD_ARG;
   if (n == 0) return DMXQ_OK;
   if (!in || !out) return DMXQ_ERR_BAD_ARG;
-  ReluArgs g{in, out, n / 8, {}, {}, dtype == DMXQ_BF16 ? 0x7F807F80u : 0x7C007C00u};
-  if (n % 8 != 0 || !aligned16(in) || !aligned16(out) || !range16_of(cast_in, dtype, &g.ri) || !range16_of(cast_out, dtype, &g.ro))
+  Range16 ri;
+  ReluExtra rx{{}, dtype == DMXQ_BF16 ? 0x7F7F7F7Fu : 0x7BFF7BFFu};
+  if (n % 8 != 0 || !aligned16(in) || !aligned16(out) || !range16_of(cast_in, dtype, &ri) || !range16_of(cast_out, dtype, &rx.ro))
     return DMXQ_ERR_UNSUPPORTED;
-  constexpr int T = 256, U = 8;
-  const int64_t tiles = (g.n_vec + T * U - 1) / (T * U);
-  if (tiles > 0x7FFFFFFF) return DMXQ_ERR_UNSUPPORTED;
-  DMXQ_LAUNCH((relu_range16_kernel<T, U>), dim3((unsigned)tiles), dim3(T), 0, (hipStream_t)stream, g);
-  return launch_status();
+  // the same format on both sides (the BASIC rules): relu of an already cast value needs no second cast -- an in-range value stays
+  // in range, zeros and the clamped NaN / Inf pass relu unchanged or become +0
+  if (rx.ro.limit2 == ri.limit2 && rx.ro.minb2 == ri.minb2) return launch_float_range_bf16<2>(in, out, n / 8, ri, (hipStream_t)stream, rx);
+  return launch_float_range_bf16<1>(in, out, n / 8, ri, (hipStream_t)stream, rx);  // the tile plans of the plain range cast
 }
 
 #endif  // part 1a
