@@ -64,8 +64,16 @@ __device__ __forceinline__ void hypernet_rows_body(const HnArgs& a) {
   constexpr int T1 = DIVIDE ? DMXQ_F32 : ((M == 0) ? DTW : ((DTW == DMXQ_F32 || DTS == DMXQ_F32 || DTW != DTS) ? DMXQ_F32 : DTW));
   const int lpb = LPBC > 0 ? LPBC : __builtin_amdgcn_readfirstlane(a.lpb);
   constexpr int UN = 4;  // units in flight per lane: all their loads are issued before the first one is ranked
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t u0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; u0 < a.n_units; u0 += UN * stride) {
+  // workgroup-CONTIGUOUS tiles of kThreads x UN units (a grid-strided assignment, unit r of a lane a whole grid apart, cost the
+  // hot kernel ~15 %: bfp_rows.hpp)
+  // -- with a mask (two or three streams per unit): 2:4 + BFP 23.1 -> 22.5 us, the Llama-3-8B layer of bench.py 63 -> 69 %; the dense
+  // scale + BFP path measured 5 % SLOWER that way (13.7 -> 14.4 us) and keeps the strided assignment.
+  constexpr bool kContig = M != 0;
+  const int64_t stride = kContig ? (int64_t)kThreads : (int64_t)gridDim.x * kThreads;
+  for (int64_t k = 0;; k++) {
+    const int64_t u0 = kContig ? ((int64_t)blockIdx.x + k * gridDim.x) * ((int64_t)kThreads * UN) + threadIdx.x
+                               : (int64_t)blockIdx.x * kThreads + threadIdx.x + k * UN * stride;
+    if (u0 >= a.n_units) break;  // (whole waves leave together: n_units is a multiple of the lanes of a block)
     float xa[UN][8], sa[M != 0 ? UN : 1][8], sva[HAS_SCALE ? UN : 1][8];
 #pragma unroll
     for (int r = 0; r < UN; r++) {
