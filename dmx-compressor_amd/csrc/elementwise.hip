@@ -673,7 +673,8 @@ __global__ __launch_bounds__(T) void binary_range_bf16_kernel(const BinArgs g) {
       float a0, a1, b0, b1;
       if (DT == DMXQ_BF16) { a0 = u2f(wa << 16); a1 = u2f(wa & 0xFFFF0000u); b0 = u2f(wb << 16); b1 = u2f(wb & 0xFFFF0000u); }
       else { a0 = half_lo(wa); a1 = half_hi(wa); b0 = half_lo(wb); b1 = half_hi(wb); }
-      const float c0 = OP == 0 ? a0 + b0 : a0 * b0, c1 = OP == 0 ? a1 + b1 : a1 * b1;
+      float c0 = OP == 0 ? a0 + b0 : a0 * b0, c1 = OP == 0 ? a1 + b1 : a1 * b1;
+      if (DT == DMXQ_BF16) { c0 = c0 != c0 ? u2f(0x7FC00000u) : c0; c1 = c1 != c1 ? u2f(0x7FC00000u) : c1; }  // c10::BFloat16: every NaN -> +0x7FC0
       ra[u][j] = range16_word(pack2<DT>(c0, c1), g.ro);
     }
   }
@@ -685,6 +686,94 @@ __global__ __launch_bounds__(T) void binary_range_bf16_kernel(const BinArgs g) {
   }
 }
 
+// The general form of the fused modules: ANY nearest-rounding FloatingPoint cast (incl. ones that round: FLOAT16 on a float32
+// tensor, 8-bit floats on a bf16 one) on ANY tensor dtype.  Per element: widen, cast_a / cast_b (magic-add form of floatq.hpp with
+// the bit-level form for what it does not cover), CastTo's `.to(dtype)`, the op in fp32 rounded once to the dtype, cast_out and
+// its `.to(dtype)`.  OP 0 add, 1 mul, 2 relu (b unused).  3 casts ~ 50 VALU per element: still under the memory time of a float32
+// tensor (12 B/element), about level with it for 16-bit ones.
+struct CastG { FloatFmt f; FloatFast k; int active; };
+static bool castg_of(const dmxq_float_fmt* f, CastG* c) {  // false: not a format the kernels take
+  if (!f || f->exp_bits == 0) { c->active = 0; c->f = FloatFmt{}; c->k = FloatFast{}; return true; }
+  if (f->exp_bits < 1 || f->exp_bits > 8 || f->man_bits < 0 || f->man_bits > 22) return false;
+  c->f = FloatFmt{f->man_bits, f->exp_bits, f->exp_bias, f->flush_subnormal ? 1 : 0, 0, DMXQ_ROUND_NEAREST, 0ull};
+  c->k = make_float_fast(f->man_bits, f->exp_bits, f->exp_bias);
+  c->active = 1;
+  return true;
+}
+template <int DT>
+__device__ __forceinline__ float castg_dt(float x) {  // CastTo's `.to(physical dtype)` / torch's rounding of an op's fp32 result
+  // c10::BFloat16 turns EVERY NaN into +0x7FC0 (c10/util/BFloat16.h round_to_nearest_even), c10::Half keeps the sign: it matters
+  // here because a following cast without NaN codes saturates a NaN to sign | max_val
+  if (DT == DMXQ_BF16) return x != x ? u2f(0x7FC00000u) : (float)(__bf16)x;
+  if (DT == DMXQ_F16) return (float)(_Float16)opaque(x);
+  return x;
+}
+template <int DT, int N>
+__device__ __forceinline__ void castg_vec(float (&x)[N], const CastG& c) {
+  if (!c.active) return;  // (wave-uniform, once per vector)
+  bool ok = c.k.usable != 0;
+  float q[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) { ok = ok && float_fast_ok(x[j], c.k); q[j] = float_q1_fast(x[j], c.k, c.f.flush != 0, false); }
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ull, 0)) {
+#pragma unroll
+    for (int j = 0; j < N; j++)
+      if (!c.k.usable || !float_fast_ok(x[j], c.k)) q[j] = float_q1<DMXQ_ROUND_NEAREST>(x[j], c.f, 0u);
+  }
+#pragma unroll
+  for (int j = 0; j < N; j++) x[j] = castg_dt<DT>(q[j]);
+}
+struct GenArgs { const void* a; const void* b; void* out; int64_t n_vec; CastG ca, cb, co; };
+template <int DT, int OP, int T, int U>
+__global__ __launch_bounds__(T) void fused_cast_generic_kernel(const GenArgs g) {
+  constexpr int EPL = 16 / Elem<DT>::bytes;
+  const int64_t base = (int64_t)blockIdx.x * ((int64_t)T * U) + threadIdx.x;
+  u32x4 ra[U], rb[OP == 2 ? 1 : U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int64_t v = base + u * T < g.n_vec ? base + u * T : g.n_vec - 1;  // clamped: unconditional loads
+    ra[u] = load_raw16<true>(g.a, v * 16);
+    if (OP != 2) rb[u] = load_raw16<true>(g.b, v * 16);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    float x[EPL], y[EPL], c[EPL];
+    widen<DT, EPL>(ra[u], x);
+    castg_vec<DT, EPL>(x, g.ca);
+    if (OP != 2) {
+      widen<DT, EPL>(rb[OP == 2 ? 0 : u], y);
+      castg_vec<DT, EPL>(y, g.cb);
+    }
+#pragma unroll
+    for (int j = 0; j < EPL; j++)
+      c[j] = castg_dt<DT>(OP == 0 ? x[j] + y[j] : (OP == 1 ? x[j] * y[j] : (x[j] < 0.0f ? 0.0f : x[j])));  // clamp_min(x, 0): -0.0 and NaN pass
+    castg_vec<DT, EPL>(c, g.co);
+    const OutVec<DT, EPL> o = pack_vec<DT, EPL>(c);
+#pragma unroll
+    for (int j = 0; j < 4; j++) ra[u][j] = o.w[j];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++)
+    if (base + u * T < g.n_vec) __builtin_nontemporal_store(ra[u], (u32x4*)((char*)g.out + (base + u * T) * 16));
+}
+template <int OP>
+static int launch_fused_generic(const void* a, const void* b, void* out, int dtype, int64_t n, const dmxq_float_fmt* fa, const dmxq_float_fmt* fb,
+                                const dmxq_float_fmt* fo, hipStream_t s) {
+  const int epl = dtype == DMXQ_F32 ? 4 : 8;
+  GenArgs g{a, b, out, n / epl, {}, {}, {}};
+  if (n % epl != 0 || !aligned16(a) || (OP != 2 && !aligned16(b)) || !aligned16(out) || !castg_of(fa, &g.ca) || !castg_of(fb, &g.cb) || !castg_of(fo, &g.co))
+    return DMXQ_ERR_UNSUPPORTED;
+  constexpr int T = 256, U = 2;
+  const int64_t tiles = (g.n_vec + T * U - 1) / (T * U);
+  if (tiles > 0x7FFFFFFF) return DMXQ_ERR_UNSUPPORTED;
+  if (dtype == DMXQ_F32) DMXQ_LAUNCH((fused_cast_generic_kernel<DMXQ_F32, OP, T, U>), dim3((unsigned)tiles), dim3(T), 0, s, g);
+  else if (dtype == DMXQ_F16) DMXQ_LAUNCH((fused_cast_generic_kernel<DMXQ_F16, OP, T, U>), dim3((unsigned)tiles), dim3(T), 0, s, g);
+  else DMXQ_LAUNCH((fused_cast_generic_kernel<DMXQ_BF16, OP, T, U>), dim3((unsigned)tiles), dim3(T), 0, s, g);
+  return launch_status();
+}
+
 extern "C" int dmxq_binary_cast(const void* a, const void* b, void* out, int dtype, int64_t n, int op, const dmxq_float_fmt* cast_a,
                                 const dmxq_float_fmt* cast_b, const dmxq_float_fmt* cast_out, void* stream) {
   if (!valid_dtype(dtype) || n < 0 || (op != DMXQ_BINARY_ADD && op != DMXQ_BINARY_MUL)) return DMXQ_ERR_BAD_ARG;
@@ -692,8 +781,9 @@ extern "C" int dmxq_binary_cast(const void* a, const void* b, void* out, int dty
   if (!a || !b || !out) return DMXQ_ERR_BAD_ARG;
   BinArgs g{a, b, out, n / 8, {}, {}, {}};
   if (n % 8 != 0 || !aligned16(a) || !aligned16(b) || !aligned16(out) || !range16_of(cast_a, dtype, &g.ra) ||
-      !range16_of(cast_b, dtype, &g.rb) || !range16_of(cast_out, dtype, &g.ro))
-    return DMXQ_ERR_UNSUPPORTED;
+      !range16_of(cast_b, dtype, &g.rb) || !range16_of(cast_out, dtype, &g.ro))  // not range-only: the general form
+    return op == DMXQ_BINARY_ADD ? launch_fused_generic<0>(a, b, out, dtype, n, cast_a, cast_b, cast_out, (hipStream_t)stream)
+                                 : launch_fused_generic<1>(a, b, out, dtype, n, cast_a, cast_b, cast_out, (hipStream_t)stream);
   constexpr int T = 256, U = 2;  // measured: 256x2 17.9 us, 256x4 18.3, 512x8 19.3 (three streams: small tiles interleave best)
   const int64_t tiles = (g.n_vec + T * U - 1) / (T * U);
   if (tiles > 0x7FFFFFFF) return DMXQ_ERR_UNSUPPORTED;
@@ -719,7 +809,7 @@ extern "C" int dmxq_relu_cast(const void* in, void* out, int dtype, int64_t n, c
   Range16 ri;
   ReluExtra rx{{}, dtype == DMXQ_BF16 ? 0x7F7F7F7Fu : 0x7BFF7BFFu};
   if (n % 8 != 0 || !aligned16(in) || !aligned16(out) || !range16_of(cast_in, dtype, &ri) || !range16_of(cast_out, dtype, &rx.ro))
-    return DMXQ_ERR_UNSUPPORTED;
+    return launch_fused_generic<2>(in, nullptr, out, dtype, n, cast_in, nullptr, cast_out, (hipStream_t)stream);  // the general form
   // the same format on both sides (the BASIC rules): relu of an already cast value needs no second cast -- an in-range value stays
   // in range, zeros and the clamped NaN / Inf pass relu unchanged or become +0
   if (rx.ro.limit2 == ri.limit2 && rx.ro.minb2 == ri.minb2) return launch_float_range_bf16<2>(in, out, n / 8, ri, (hipStream_t)stream, rx);

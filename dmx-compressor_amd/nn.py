@@ -473,19 +473,26 @@ def _range_only_format(cast, dtype):
         return (not cast.pre_transform), None
     if (not isinstance(fmt, FloatingPoint) or cast.pre_transform or not cast._flag("fake_quant_enabled") or cast._flag("observer_enabled")):
         return False, None
+    rep = repr(fmt)
+    # format.py:209-212: the dtype's own format passes the tensor through untouched (no flush, NaN stays NaN) -- SAME for the kernel
+    if (dtype == torch.float32 and rep == "FP[1|8|23,127](_N)") or (dtype == torch.float16 and rep == "FP[1|5|10,15](_N)"):
+        return True, None
+    if fmt.mantissa == 23:
+        return False, None
     return True, fmt
 
 
 class _BinaryElementwise(DmxModule):
     """ResAdd / Mul: two cast inputs, one elementwise op, one cast output (torch_modules.py:36-80).  In inference on same-shape
-    16-bit tensors whose three casts are range-only (the BASIC rules on a bf16 model) the whole module is ONE launch
-    (dmxq_binary_cast: 6 B/element instead of 18 over four launches); otherwise the general DmxModule.forward."""
+    tensors whose three casts are SAME or nearest-rounding FloatingPoint formats the whole module is ONE launch (dmxq_binary_cast:
+    a third of the traffic of the four launches; range-only casts of 16-bit tensors -- the BASIC rules on a bf16 model -- on packed
+    words); otherwise the general DmxModule.forward."""
     _op = "add"
     fuse_binary = True
 
     def _fused_forward(self, a, b=None, *args, **kwargs):
         if (not self.fuse_binary or args or kwargs or not isinstance(a, torch.Tensor) or not isinstance(b, torch.Tensor)
-                or a.shape != b.shape or a.dtype != b.dtype or a.dtype not in (torch.bfloat16, torch.float16) or a.device != b.device or not a.is_cuda
+                or a.shape != b.shape or a.dtype != b.dtype or a.dtype not in (torch.bfloat16, torch.float16, torch.float32) or a.device != b.device or not a.is_cuda
                 or self.smoothquant is not None and self.smoothquant._flag("enabled")
                 or torch.is_grad_enabled() and (a.requires_grad or b.requires_grad) or torch.compiler.is_compiling()
                 or not isinstance(self.approximator.function, NoApproximation)):
@@ -684,7 +691,7 @@ class ReLU(DmxModule, torch.nn.ReLU):
 
     def _fused_forward(self, x, *args, **kwargs):
         """input cast -> F.relu -> output cast as ONE launch (dmxq_relu_cast) on a 16-bit tensor with range-only casts"""
-        if (not self.fuse_relu or args or kwargs or not isinstance(x, torch.Tensor) or x.dtype not in (torch.bfloat16, torch.float16)
+        if (not self.fuse_relu or args or kwargs or not isinstance(x, torch.Tensor) or x.dtype not in (torch.bfloat16, torch.float16, torch.float32)
                 or not x.is_cuda or self.smoothquant is not None and self.smoothquant._flag("enabled")
                 or torch.is_grad_enabled() and x.requires_grad or torch.compiler.is_compiling()
                 or not isinstance(self.approximator.function, NoApproximation)):

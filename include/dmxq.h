@@ -208,17 +208,19 @@ int dmxq_input_hypernet(const void* x, int dtype_x, const float* sq_scale, void*
  * evaluated as torch does (fp32 arithmetic on the widened operands, one RNE rounding to the tensor dtype).  Replaces the four
  * launches of modeling/nn/core.py:228-264 for such a module (CastToDict.forward on both inputs, numerical/cast.py:59-86; the op;
  * the output cast): 6 B/element instead of 18.  A cast is described by its FloatingPoint format (numerical/format.py:174-233,
- * nearest rounding, signed); NULL or exp_bits == 0 = SAME.  Fused only when every cast is RANGE-ONLY for the tensor dtype (bf16
- * tensors with man_bits >= 7, fp16 tensors with man_bits >= 10; subnormals flushed: the FLOAT16-style formats of the BASIC rules);
- * anything else returns DMXQ_ERR_UNSUPPORTED and the caller runs the unfused ops.  Bit-identical to that chain; a / b may alias out. */
+ * nearest rounding, signed, man_bits <= 22); NULL or exp_bits == 0 = SAME.  Two forms: when every cast is RANGE-ONLY for a 16-bit
+ * tensor dtype (bf16 with man_bits >= 7, fp16 with man_bits >= 10; subnormals flushed: the FLOAT16-style formats of the BASIC rules)
+ * everything happens on the packed 16-bit words; otherwise (casts that round, float32 tensors) per element in fp32 with the
+ * arithmetic of dmxq_float_qdq.  DMXQ_ERR_UNSUPPORTED: n not a whole number of 16-byte vectors, unaligned pointers (the caller runs
+ * the unfused ops).  Bit-identical to that chain; a / b may alias out.  (The host mirror maps the reference's pass-through of a
+ * dtype's own format, numerical/format.py:209-212, to SAME before calling.) */
 typedef struct { int man_bits, exp_bits, exp_bias, flush_subnormal; } dmxq_float_fmt;
 enum { DMXQ_BINARY_ADD = 0, DMXQ_BINARY_MUL = 1 };
 int dmxq_binary_cast(const void* a, const void* b, void* out, int dtype, int64_t n, int op, const dmxq_float_fmt* cast_a,
                      const dmxq_float_fmt* cast_b, const dmxq_float_fmt* cast_out, void* stream);
 
 /* A ReLU DmxModule (modeling/nn/torch_modules.py ReLU through core.py:228-264: input cast, F.relu, output cast) in one pass on
- * 16-bit tensors with range-only casts (see dmxq_binary_cast): out = cast_out(clamp_min(cast_in(x), 0)).  4 B/element instead of
- * 12 over three launches.  DMXQ_ERR_UNSUPPORTED otherwise. */
+ * the two forms of dmxq_binary_cast: out = cast_out(clamp_min(cast_in(x), 0)).  A third of the traffic of the three launches. */
 int dmxq_relu_cast(const void* in, void* out, int dtype, int64_t n, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out,
                    void* stream);
 
