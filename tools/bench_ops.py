@@ -151,6 +151,15 @@ def main():
                    L.dmxq_float_qdq(vp(xs[(i + 1) % k].data_ptr()), vp(ys[(i + 1) % k].data_ptr()), _lib.BF16, _lib.BF16, n, 10, 5, 15, 1, 0, 2, 0, sp),
                    torch.add(ys[i], ys[(i + 1) % k], out=ys[(i + 2) % k]),
                    L.dmxq_float_qdq(vp(ys[(i + 2) % k].data_ptr()), vp(ys[(i + 3) % k].data_ptr()), _lib.BF16, _lib.BF16, n, 10, 5, 15, 1, 0, 2, 0, sp)), k, n * 6)
+    f32a = [torch.randn(R, C, device=dev) for _ in range(6)]
+    f32o = [torch.empty(R, C, device=dev) for _ in range(6)]
+    run("binary_cast ResAdd on float32 tensors, three FLOAT16 casts (general form: one launch, 12 B/elem)",
+        lambda i: L.dmxq_binary_cast(vp(f32a[i % 6].data_ptr()), vp(f32a[(i + 1) % 6].data_ptr()), vp(f32o[i % 6].data_ptr()), _lib.F32, n, 0, pf, pf, pf, sp), 6, n * 12)
+    run("  the four launches it replaces (3 x float_qdq FLOAT16 fp32 + torch add)",
+        lambda i: (L.dmxq_float_qdq(vp(f32a[i % 6].data_ptr()), vp(f32o[i % 6].data_ptr()), _lib.F32, _lib.F32, n, 10, 5, 15, 1, 0, 2, 0, sp),
+                   L.dmxq_float_qdq(vp(f32a[(i + 1) % 6].data_ptr()), vp(f32o[(i + 1) % 6].data_ptr()), _lib.F32, _lib.F32, n, 10, 5, 15, 1, 0, 2, 0, sp),
+                   torch.add(f32o[i % 6], f32o[(i + 1) % 6], out=f32o[(i + 2) % 6]),
+                   L.dmxq_float_qdq(vp(f32o[(i + 2) % 6].data_ptr()), vp(f32o[(i + 3) % 6].data_ptr()), _lib.F32, _lib.F32, n, 10, 5, 15, 1, 0, 2, 0, sp)), 6, n * 12)
     run("relu_cast ReLU module: FLOAT16 input and output casts, bf16 (one launch, 4 B/elem; 3 launches unfused)",
         lambda i: L.dmxq_relu_cast(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, n, pf, pf, sp), k, n * 4)
     ws = torch.empty(L.dmxq_topk_workspace_bytes(n) // 8 + 1, dtype=torch.int64, device=dev)
