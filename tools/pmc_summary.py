@@ -39,7 +39,7 @@ def main():
     dur = load_durations(sys.argv[1])
     print(f"{'kernel':70s} {'n':>4s} {'us':>8s} {'read MB':>9s} {'write MB':>9s} {'VALU act%':>9s} {'wait%':>7s} {'VALU/wave':>10s} {'VMEM rd/wave':>12s}")
     for k in sorted(sq, key=lambda k: -mean(dur.get(k, [0]))):
-        if not k.startswith(("void dmxq", "dmxq")):
+        if not (k.startswith(("void dmxq", "dmxq")) or any(t in k for t in ("binary_range_bf16_kernel", "fused_cast_generic_kernel", "float_range_bf16_kernel"))):
             continue
         c = sq[k]
         wc = mean(c.get("SQ_WAVE_CYCLES", []))
