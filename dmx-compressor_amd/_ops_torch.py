@@ -98,7 +98,8 @@ def bfp_qdq(x, precision: int, block_size: int, block_dim: int = -1, symmetric: 
     """BlockFloatingPoint Q->DQ of a whole tensor in one launch (numerical/format.py:304-343 semantics).
     Blocks run along `block_dim`; output has x's shape, contiguous, dtype `out_dtype` (default x.dtype)."""
     require_gpu(x, "bfp_qdq")
-    return _ops.bfp_qdq(x, precision, block_size, block_dim, symmetric, ROUNDING_CODE[rounding], out_dtype, _seed_arg(seed, rounding))
+    op = _ops.bfp_qdq if (x.requires_grad and torch.is_grad_enabled()) else _ops.bfp_qdq_nograd   # (the STE wrapper costs ~2.5 us per call)
+    return op(x, precision, block_size, block_dim, symmetric, ROUNDING_CODE[rounding], out_dtype, _seed_arg(seed, rounding))
 
 
 def block_quantize(a2d, wl: int, symmetric: bool = True, rounding: str = "nearest", seed: Optional[int] = None):
@@ -192,7 +193,8 @@ def float_qdq(x, man: int, exp: int, bias: int, flush_subnormal: bool, unsigned:
               rounding: str = "nearest", out_dtype: Optional[torch.dtype] = None, seed: Optional[int] = None):
     """Low-bit float Q->DQ (quant/quant_function.py:120-152 semantics), one launch."""
     require_gpu(x, "float_qdq")
-    return _ops.float_qdq(x, man, exp, bias, flush_subnormal, unsigned, ROUNDING_CODE[rounding], out_dtype, _seed_arg(seed, rounding))
+    op = _ops.float_qdq if (x.requires_grad and torch.is_grad_enabled()) else _ops.float_qdq_nograd
+    return op(x, man, exp, bias, flush_subnormal, unsigned, ROUNDING_CODE[rounding], out_dtype, _seed_arg(seed, rounding))
 
 
 def fixed_qdq(x, precision: int, fraction: int, clamp: bool = True, symmetric: bool = True, rounding: str = "nearest",
@@ -203,7 +205,8 @@ def fixed_qdq(x, precision: int, fraction: int, clamp: bool = True, symmetric: b
     scale None: bare FixedPoint.cast.  ch_axis None: per-tensor scale; else per-channel (group_size None) or
     per-group slabs of `group_size` channels."""
     require_gpu(x, "fixed_qdq")
-    return _ops.fixed_qdq(x, precision, fraction, clamp, symmetric, ROUNDING_CODE[rounding], scale, zero_point, ch_axis,
+    op = _ops.fixed_qdq if (x.requires_grad and torch.is_grad_enabled()) else _ops.fixed_qdq_nograd
+    return op(x, precision, fraction, clamp, symmetric, ROUNDING_CODE[rounding], scale, zero_point, ch_axis,
                           group_size or None, out_dtype, _seed_arg(seed, rounding))
 
 

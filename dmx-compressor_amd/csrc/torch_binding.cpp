@@ -583,6 +583,7 @@ Tensor norm_meta(const Tensor& x, int64_t, const OptTensor&, const OptTensor&, d
 
 TORCH_LIBRARY(dmxq, m) {
   m.def("bfp_qdq(Tensor x, int precision, int block_size, int block_dim=-1, bool symmetric=True, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");
+  m.def("bfp_qdq_nograd(Tensor x, int precision, int block_size, int block_dim=-1, bool symmetric=True, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");  // the same kernel without the Python STE autograd wrapper (2.5 us per call)
   m.def("block_quantize(Tensor a, int wl, bool symmetric, int rounding, int seed=0) -> Tensor");
   m.def("bfp_qdq_multi(Tensor[] xs, int precision, int block_size, int block_dim=-1, bool symmetric=True, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor[]");
   m.def("bfp_pack(Tensor x, int precision, int block_size, bool symmetric=True) -> (Tensor, Tensor)");
@@ -594,7 +595,9 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("sbfp_qdq(Tensor x, int precision, int block_size, int scaler_man, int scaler_exp, int scaler_bias, bool scaler_flush, bool clamp, bool symmetric, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
   m.def("mxfp_qdq(Tensor x, int man, int exp, int block_size, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
   m.def("float_qdq(Tensor x, int man, int exp, int bias, bool flush_subnormal, bool unsigned_abs=False, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");
+  m.def("float_qdq_nograd(Tensor x, int man, int exp, int bias, bool flush_subnormal, bool unsigned_abs=False, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");  // the same kernel without the Python STE autograd wrapper (2.5 us per call)
   m.def("fixed_qdq(Tensor x, int precision, int fraction, bool clamp, bool symmetric, int rounding, Tensor? scale, Tensor? zero_point, int? ch_axis, int? group_size, ScalarType? out_dtype=None, int seed=0) -> Tensor");
+  m.def("fixed_qdq_nograd(Tensor x, int precision, int fraction, bool clamp, bool symmetric, int rounding, Tensor? scale, Tensor? zero_point, int? ch_axis, int? group_size, ScalarType? out_dtype=None, int seed=0) -> Tensor");  // the same kernel without the Python STE autograd wrapper (2.5 us per call)
   m.def("fixed_qdq_multi(Tensor[] xs, int precision, int fraction, bool clamp, bool symmetric, int rounding, Tensor[] scales, Tensor[] zero_points, int group_size, ScalarType? out_dtype=None, int seed=0) -> Tensor[]");
   m.def("nm_mask(Tensor score, Tensor? x, int K, int M, int block_dim, bool want_mask, bool want_y, ScalarType? mask_dtype=None, ScalarType? y_dtype=None) -> (Tensor, Tensor)");
   m.def("topk_mask(Tensor score, Tensor? x, int n_zero, bool want_mask, bool want_y, ScalarType? mask_dtype=None, ScalarType? y_dtype=None) -> (Tensor, Tensor)");
@@ -620,5 +623,11 @@ TORCH_LIBRARY(dmxq, m) {
   X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, rope); X(m, rope_cast); X(m, softmax); X(m, norm)
 
 // "CUDA" is the dispatch key of HIP tensors in a ROCm build of PyTorch
-TORCH_LIBRARY_IMPL(dmxq, CUDA, m) { DMXQ_FOR_ALL(DMXQ_IMPL, m); }
-TORCH_LIBRARY_IMPL(dmxq, Meta, m) { DMXQ_FOR_ALL(DMXQ_META, m); }
+TORCH_LIBRARY_IMPL(dmxq, CUDA, m) {
+  DMXQ_FOR_ALL(DMXQ_IMPL, m);
+  m.impl("bfp_qdq_nograd", &bfp_qdq); m.impl("float_qdq_nograd", &float_qdq); m.impl("fixed_qdq_nograd", &fixed_qdq);
+}
+TORCH_LIBRARY_IMPL(dmxq, Meta, m) {
+  DMXQ_FOR_ALL(DMXQ_META, m);
+  m.impl("bfp_qdq_nograd", &bfp_qdq_meta); m.impl("float_qdq_nograd", &float_qdq_meta); m.impl("fixed_qdq_nograd", &fixed_qdq_meta);
+}

@@ -152,6 +152,8 @@ def test_host_overhead_of_one_cast_call(dmx, cuda):
     cargs = (ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), lib.BF16, lib.BF16, 64, 256, 1, 16, 8, lib.ROUND_NEAREST, 1, 0, lib.stream_of(x))
     for name, fn in (("C ABI dmxq_bfp_qdq alone (prebuilt ctypes arguments, no allocation)", lambda: L.dmxq_bfp_qdq(*cargs)),
                      ("torch.ops.dmxq.bfp_qdq", lambda: raw(x, 8, 16, -1, True, 2, None, 0)),
+                     ("torch.ops.dmxq.bfp_qdq_nograd (no STE autograd wrapper: what ops.bfp_qdq calls when no gradient is needed)",
+                      lambda: torch.ops.dmxq.bfp_qdq_nograd.default(x, 8, 16, -1, True, 2, None, 0)),
                      ("ops.bfp_qdq (torch binding)", lambda: dmx.ops.bfp_qdq(x, 8, 16)),
                      ("ops.bfp_qdq (ctypes binding)", lambda: _ops_ctypes.bfp_qdq(x, 8, 16)), ("CastTo.forward", lambda: c(x))):
         with torch.no_grad():
