@@ -123,6 +123,8 @@ def test_torch_compile_fullgraph_of_a_basic_linear(dmx, cuda, backend):
     """the reference's export path traces its CastTo through custom ops (fx/transform.py:133-178); here the whole BASIC
     Linear forward (input BFP cast, fused weight path, bias cast, F.linear, FLOAT16 output cast) must trace as ONE graph
     through torch.ops.dmxq with fake tensors -- no graph break, no fallback -- and give the eager result."""
+    if dmx.ops.BINDING != "torch":
+        pytest.skip("the ctypes binding cannot be traced (the torch extension is the default)")
     lin = dmx.nn.Linear(256, 128).to(cuda).to(torch.bfloat16)
     for r in dmx.config_rules.BASIC:
         if isinstance(lin, r.module_types):
