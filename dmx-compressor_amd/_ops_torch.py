@@ -178,14 +178,15 @@ def sbfp_qdq(x, precision: int, block_size: int, scaler_man: int, scaler_exp: in
              out_dtype: Optional[torch.dtype] = None):
     """ScaledBlockFloatingPoint Q->DQ (numerical/format.py:453-479), one launch."""
     require_gpu(x, "sbfp_qdq")
-    return _ops.sbfp_qdq(x, precision, block_size, scaler_man, scaler_exp, scaler_bias, scaler_flush, clamp, symmetric, block_dim,
-                         out_dtype)
+    op = _ops.sbfp_qdq if (x.requires_grad and torch.is_grad_enabled()) else _ops.sbfp_qdq_nograd
+    return op(x, precision, block_size, scaler_man, scaler_exp, scaler_bias, scaler_flush, clamp, symmetric, block_dim, out_dtype)
 
 
 def mxfp_qdq(x, man: int, exp: int, block_size: int, block_dim: int = -1, out_dtype: Optional[torch.dtype] = None):
     """MXFP Q->DQ (numerical/format.py:545-564), one launch."""
     require_gpu(x, "mxfp_qdq")
-    return _ops.mxfp_qdq(x, man, exp, block_size, block_dim, out_dtype)
+    op = _ops.mxfp_qdq if (x.requires_grad and torch.is_grad_enabled()) else _ops.mxfp_qdq_nograd
+    return op(x, man, exp, block_size, block_dim, out_dtype)
 
 
 # ---------------------------------------------------------------------------------------------------- element formats

@@ -593,7 +593,9 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("binary_cast(Tensor a, Tensor b, int op, int[] cast_a, int[] cast_b, int[] cast_out) -> Tensor");
   m.def("relu_cast(Tensor x, int[] cast_in, int[] cast_out) -> Tensor");
   m.def("sbfp_qdq(Tensor x, int precision, int block_size, int scaler_man, int scaler_exp, int scaler_bias, bool scaler_flush, bool clamp, bool symmetric, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
+  m.def("sbfp_qdq_nograd(Tensor x, int precision, int block_size, int scaler_man, int scaler_exp, int scaler_bias, bool scaler_flush, bool clamp, bool symmetric, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
   m.def("mxfp_qdq(Tensor x, int man, int exp, int block_size, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
+  m.def("mxfp_qdq_nograd(Tensor x, int man, int exp, int block_size, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
   m.def("float_qdq(Tensor x, int man, int exp, int bias, bool flush_subnormal, bool unsigned_abs=False, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");
   m.def("float_qdq_nograd(Tensor x, int man, int exp, int bias, bool flush_subnormal, bool unsigned_abs=False, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");  // the same kernel without the Python STE autograd wrapper (2.5 us per call)
   m.def("fixed_qdq(Tensor x, int precision, int fraction, bool clamp, bool symmetric, int rounding, Tensor? scale, Tensor? zero_point, int? ch_axis, int? group_size, ScalarType? out_dtype=None, int seed=0) -> Tensor");
@@ -626,8 +628,10 @@ TORCH_LIBRARY(dmxq, m) {
 TORCH_LIBRARY_IMPL(dmxq, CUDA, m) {
   DMXQ_FOR_ALL(DMXQ_IMPL, m);
   m.impl("bfp_qdq_nograd", &bfp_qdq); m.impl("float_qdq_nograd", &float_qdq); m.impl("fixed_qdq_nograd", &fixed_qdq);
+  m.impl("sbfp_qdq_nograd", &sbfp_qdq); m.impl("mxfp_qdq_nograd", &mxfp_qdq);
 }
 TORCH_LIBRARY_IMPL(dmxq, Meta, m) {
   DMXQ_FOR_ALL(DMXQ_META, m);
   m.impl("bfp_qdq_nograd", &bfp_qdq_meta); m.impl("float_qdq_nograd", &float_qdq_meta); m.impl("fixed_qdq_nograd", &fixed_qdq_meta);
+  m.impl("sbfp_qdq_nograd", &sbfp_qdq_meta); m.impl("mxfp_qdq_nograd", &mxfp_qdq_meta);
 }
