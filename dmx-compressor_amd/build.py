@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # per-source header dependencies (a change to the BFP tile code does not rebuild the elementwise kernels)
     extra = {"bfp.hip": ["bfp_math.hpp", "bfp_rows.hpp"], "bfp_cols.hip": ["bfp_math.hpp"], "bfp_urows.hip": ["bfp_math.hpp"], "bfp_smallinner.hip": ["bfp_math.hpp"],
              "bfp_pack.hip": ["bfp_math.hpp"], "hypernet.hip": ["bfp_math.hpp"], "blockfmt.hip": ["bfp_math.hpp", "floatq.hpp", "stream.hpp"],
-             "elementwise.hip": ["floatq.hpp", "stream.hpp"], "unary.hip": ["stream.hpp"]}
+             "elementwise.hip": ["floatq.hpp", "stream.hpp"], "unary.hip": ["stream.hpp"], "rope.hip": ["floatq.hpp"]}
     hipcc = _hipcc()
 
     def compile_one(spec):

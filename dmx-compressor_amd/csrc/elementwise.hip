@@ -11,42 +11,7 @@
 namespace dmxq {
 
 // ------------------------------------------------------------------------------------------------- float
-struct FloatFmt {
-  int man, exp_bits, bias, flush, unsigned_abs, rounding;
-  uint64_t seed;
-};
-
-// quant_cpu.cpp:359-402 for one element (oracle/oracle.c float_q1)
-template <int RND>
-__device__ __forceinline__ float float_q1(float a, const FloatFmt& f, uint32_t rnd) {
-  const uint32_t target = f2u(a);
-  const int target_exp = (int)((target & 0x7FFFFFFFu) >> 23) - 127;
-  const int min_exp = -(f.bias - 1);
-  float q;
-  if (target_exp < min_exp) {
-    if (f.flush) {
-      q = 0.0f;
-    } else {
-      // subnormal of the simulated format: add +-2^min_exp so the kept mantissa bits line up with the
-      // subnormal quantum, round, subtract (never saturates)
-      const float shift = u2f(((uint32_t)(127 + min_exp) << 23) | (target & 0x80000000u));
-      const float val = a + shift;
-      q = u2f(round_bitwise<RND>(f2u(val), f.man, f.rounding, rnd)) - shift;
-    }
-  } else {
-    uint32_t qb = round_bitwise<RND>(target, f.man, f.rounding, rnd);
-    // bit_helper.cpp:4-22 clip_exponent: saturate (with the INPUT's sign) at 2^(2^(e-1)) * (2 - 2^-m);
-    // no inf/nan codes are reserved
-    const int max_e = (1 << (f.exp_bits - 1)) + 127;
-    if (qb != 0u && (int)((qb & 0x7FFFFFFFu) >> 23) > max_e) {
-      const uint32_t max_man = (0x007FFFFFu >> (23 - f.man)) << (23 - f.man);
-      qb = (target & 0x80000000u) | ((uint32_t)max_e << 23) | max_man;
-    }
-    q = u2f(qb);
-  }
-  return f.unsigned_abs ? fabsf(q) : q;
-}
-
+// (FloatFmt, float_q1 and the per-element cast of the fused modules: floatq.hpp)
 // ------------------------------------------------------------------------------------------------- fixed
 struct FixedFmt {
   int sigma, clamp, rounding;
@@ -691,38 +656,6 @@ __global__ __launch_bounds__(T) void binary_range_bf16_kernel(const BinArgs g) {
 // the bit-level form for what it does not cover), CastTo's `.to(dtype)`, the op in fp32 rounded once to the dtype, cast_out and
 // its `.to(dtype)`.  OP 0 add, 1 mul, 2 relu (b unused).  3 casts ~ 50 VALU per element: still under the memory time of a float32
 // tensor (12 B/element), about level with it for 16-bit ones.
-struct CastG { FloatFmt f; FloatFast k; int active; };
-static bool castg_of(const dmxq_float_fmt* f, CastG* c) {  // false: not a format the kernels take
-  if (!f || f->exp_bits == 0) { c->active = 0; c->f = FloatFmt{}; c->k = FloatFast{}; return true; }
-  if (f->exp_bits < 1 || f->exp_bits > 8 || f->man_bits < 0 || f->man_bits > 22) return false;
-  c->f = FloatFmt{f->man_bits, f->exp_bits, f->exp_bias, f->flush_subnormal ? 1 : 0, 0, DMXQ_ROUND_NEAREST, 0ull};
-  c->k = make_float_fast(f->man_bits, f->exp_bits, f->exp_bias);
-  c->active = 1;
-  return true;
-}
-template <int DT>
-__device__ __forceinline__ float castg_dt(float x) {  // CastTo's `.to(physical dtype)` / torch's rounding of an op's fp32 result
-  // c10::BFloat16 turns EVERY NaN into +0x7FC0 (c10/util/BFloat16.h round_to_nearest_even), c10::Half keeps the sign: it matters
-  // here because a following cast without NaN codes saturates a NaN to sign | max_val
-  if (DT == DMXQ_BF16) return x != x ? u2f(0x7FC00000u) : (float)(__bf16)x;
-  if (DT == DMXQ_F16) return (float)(_Float16)opaque(x);
-  return x;
-}
-template <int DT, int N>
-__device__ __forceinline__ void castg_vec(float (&x)[N], const CastG& c) {
-  if (!c.active) return;  // (wave-uniform, once per vector)
-  bool ok = c.k.usable != 0;
-  float q[N];
-#pragma unroll
-  for (int j = 0; j < N; j++) { ok = ok && float_fast_ok(x[j], c.k); q[j] = float_q1_fast(x[j], c.k, c.f.flush != 0, false); }
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ull, 0)) {
-#pragma unroll
-    for (int j = 0; j < N; j++)
-      if (!c.k.usable || !float_fast_ok(x[j], c.k)) q[j] = float_q1<DMXQ_ROUND_NEAREST>(x[j], c.f, 0u);
-  }
-#pragma unroll
-  for (int j = 0; j < N; j++) x[j] = castg_dt<DT>(q[j]);
-}
 struct GenArgs { const void* a; const void* b; void* out; int64_t n_vec; CastG ca, cb, co; };
 template <int DT, int OP, int T, int U>
 __global__ __launch_bounds__(T) void fused_cast_generic_kernel(const GenArgs g) {

@@ -10,7 +10,7 @@
 // One lane owns 8 (16-bit) or 4 (fp32) consecutive d of one row and also loads the partner vector at d +- D/2 (a second
 // read of x, served by L2: the two halves of a row are 128-256 bytes apart): algorithmic traffic = x in + x out (+ the
 // cos / sin tables once per head).
-#include "common.hpp"
+#include "floatq.hpp"
 
 namespace dmxq {
 
@@ -21,12 +21,15 @@ __device__ __forceinline__ float rnd_dt(float v) {
   return v;
 }
 
-template <int DT>
+// GEN: the module's casts in their general (rounding) form, per element in fp32 (floatq.hpp castg_vec), for float32 tensors and formats
+// that are not range-only; the Range16 arguments are then identities
+struct RopeCasts { CastG x, c, s, o; };
+template <int DT, bool GEN = false>
 __global__ __launch_bounds__(kThreads) void rope_kernel(const void* __restrict__ x, const void* __restrict__ cs,
                                                        const void* __restrict__ sn, void* __restrict__ out, int64_t n_vec,
                                                        int vpr /*vectors per row*/, FastDiv31 f_vpr, FastDiv31 f_n2, FastDiv31 f_n1,
                                                        int n1, int n2, int over_dim1, Range16 rgx, Range16 rgc, Range16 rgs,
-                                                       Range16 rgo) {
+                                                       Range16 rgo, RopeCasts gc) {
   constexpr int EPL = 16 / Elem<DT>::bytes;
   const int half = vpr / 2;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
@@ -50,13 +53,15 @@ __global__ __launch_bounds__(kThreads) void rope_kernel(const void* __restrict__
     }
     float xv[EPL], pvv[EPL], c[EPL], s[EPL], y[EPL];
     widen<DT, EPL>(cx, xv); widen<DT, EPL>(cp, pvv); widen<DT, EPL>(cc, c); widen<DT, EPL>(cs2, s);
+    if constexpr (GEN) { castg_vec<DT, EPL>(xv, gc.x); castg_vec<DT, EPL>(pvv, gc.x); castg_vec<DT, EPL>(c, gc.c); castg_vec<DT, EPL>(s, gc.s); }
 #pragma unroll
     for (int k = 0; k < EPL; k++) {
       const float rot = lo ? -pvv[k] : pvv[k];
       const float t1 = rnd_dt<DT>(xv[k] * c[k]);
       const float t2 = rnd_dt<DT>(rot * s[k]);
-      y[k] = t1 + t2;   // rounded to DT by the store
+      y[k] = GEN ? castg_dt<DT>(t1 + t2) : t1 + t2;   // rounded to DT by the store (GEN: before the output cast)
     }
+    if constexpr (GEN) castg_vec<DT, EPL>(y, gc.o);
     OutVec<DT, EPL> o = pack_vec<DT, EPL>(y);
     if constexpr (DT != DMXQ_F32) {  // ... and its output cast
 #pragma unroll
@@ -72,7 +77,7 @@ using namespace dmxq;
 
 static int rope_launch(const void* x, const void* cos_tab, const void* sin_tab, void* out, int dtype, int64_t B, int64_t n1, int64_t n2,
                        int64_t D, int broadcast_over_dim1, const Range16& rgx, const Range16& rgc, const Range16& rgs, const Range16& rgo,
-                       void* stream) {
+                       void* stream, const RopeCasts* gen = nullptr) {
   if (!valid_dtype(dtype) || B < 0 || n1 < 0 || n2 < 0 || D < 0) return DMXQ_ERR_BAD_ARG;
   const int64_t n = B * n1 * n2 * D;
   if (n == 0) return DMXQ_OK;
@@ -86,9 +91,11 @@ static int rope_launch(const void* x, const void* cos_tab, const void* sin_tab, 
   const int64_t n_vec = n / epl;
   hipStream_t s = (hipStream_t)stream;
   const int grid = grid_for((n_vec + 1) / 2);
-#define DMXQ_ROPE(D_) DMXQ_LAUNCH(rope_kernel<D_>, dim3(grid), dim3(kThreads), 0, s, x, cos_tab, sin_tab, out, n_vec, vpr, make_fastdiv31(vpr), \
-                                  make_fastdiv31(n2), make_fastdiv31(n1), (int)n1, (int)n2, broadcast_over_dim1 ? 1 : 0, rgx, rgc, rgs, rgo)
-  if (dtype == DMXQ_F32) DMXQ_ROPE(DMXQ_F32); else if (dtype == DMXQ_F16) DMXQ_ROPE(DMXQ_F16); else DMXQ_ROPE(DMXQ_BF16);
+  const RopeCasts none{};
+#define DMXQ_ROPE(D_, G_) DMXQ_LAUNCH((rope_kernel<D_, G_>), dim3(grid), dim3(kThreads), 0, s, x, cos_tab, sin_tab, out, n_vec, vpr, make_fastdiv31(vpr), \
+                                  make_fastdiv31(n2), make_fastdiv31(n1), (int)n1, (int)n2, broadcast_over_dim1 ? 1 : 0, rgx, rgc, rgs, rgo, gen ? *gen : none)
+  if (gen) { if (dtype == DMXQ_F32) DMXQ_ROPE(DMXQ_F32, true); else if (dtype == DMXQ_F16) DMXQ_ROPE(DMXQ_F16, true); else DMXQ_ROPE(DMXQ_BF16, true); }
+  else { if (dtype == DMXQ_F32) DMXQ_ROPE(DMXQ_F32, false); else if (dtype == DMXQ_F16) DMXQ_ROPE(DMXQ_F16, false); else DMXQ_ROPE(DMXQ_BF16, false); }
 #undef DMXQ_ROPE
   return launch_status();
 }
@@ -105,7 +112,12 @@ extern "C" int dmxq_rope_cast(const void* x, const void* cos_tab, const void* si
                               int64_t n2, int64_t D, int broadcast_over_dim1, const dmxq_float_fmt* cast_x, const dmxq_float_fmt* cast_cos,
                               const dmxq_float_fmt* cast_sin, const dmxq_float_fmt* cast_out, void* stream) {
   Range16 rx, rc, rs, ro;
-  if (!range16_of(cast_x, dtype, &rx) || !range16_of(cast_cos, dtype, &rc) || !range16_of(cast_sin, dtype, &rs) || !range16_of(cast_out, dtype, &ro))
-    return valid_dtype(dtype) ? DMXQ_ERR_UNSUPPORTED : DMXQ_ERR_BAD_ARG;
+  if (!valid_dtype(dtype)) return DMXQ_ERR_BAD_ARG;
+  if (!range16_of(cast_x, dtype, &rx) || !range16_of(cast_cos, dtype, &rc) || !range16_of(cast_sin, dtype, &rs) || !range16_of(cast_out, dtype, &ro)) {
+    RopeCasts g;  // not range-only (casts that round, float32 tensors): the general form
+    if (!castg_of(cast_x, &g.x) || !castg_of(cast_cos, &g.c) || !castg_of(cast_sin, &g.s) || !castg_of(cast_out, &g.o)) return DMXQ_ERR_UNSUPPORTED;
+    const Range16 id{0xFFFFFFFFu, 0u};
+    return rope_launch(x, cos_tab, sin_tab, out, dtype, B, n1, n2, D, broadcast_over_dim1, id, id, id, id, stream, &g);
+  }
   return rope_launch(x, cos_tab, sin_tab, out, dtype, B, n1, n2, D, broadcast_over_dim1, rx, rc, rs, ro, stream);
 }

@@ -642,9 +642,10 @@ class ApplyRotaryPosEmb(DmxModule):
 
     def _fused_forward(self, q, k=None, cos=None, sin=None, unsqueeze_dim=1, *args, **kwargs):
         """Four input casts, the exact function (about six torch kernels per operand) and two output casts as TWO launches
-        (dmxq_rope_cast for q and for k) when everything is bf16 and every cast is range-only; else the general path."""
+        (dmxq_rope_cast for q and for k) when the four tensors share one float dtype and every cast is SAME or a nearest-rounding
+        FloatingPoint format; else the general path."""
         ts = (q, k, cos, sin)
-        if (not self.fuse_rope or args or kwargs or any(not isinstance(t, torch.Tensor) for t in ts) or q.dtype not in (torch.bfloat16, torch.float16) or any(t.dtype != q.dtype for t in ts)
+        if (not self.fuse_rope or args or kwargs or any(not isinstance(t, torch.Tensor) for t in ts) or q.dtype not in (torch.bfloat16, torch.float16, torch.float32) or any(t.dtype != q.dtype for t in ts)
                 or not q.is_cuda or q.dim() != 4 or k.dim() != 4 or unsqueeze_dim not in (1, 2)
                 or self.smoothquant is not None and self.smoothquant._flag("enabled")
                 or torch.is_grad_enabled() and any(t.requires_grad for t in ts) or torch.compiler.is_compiling()

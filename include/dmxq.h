@@ -227,7 +227,7 @@ int dmxq_relu_cast(const void* in, void* out, int dtype, int64_t n, const dmxq_f
 /* One operand (q or k) of an ApplyRotaryPosEmb DmxModule (modeling/nn/custom_modules.py:142-194) with the module's casts:
  * out = cast_out(rope(cast_x(x), cast_cos(cos), cast_sin(sin))), rope as dmxq_rope below (torch's op-by-op arithmetic in the
  * tensor dtype).  Replaces, per operand, three input casts, the ~6 torch kernels of the exact function and the output cast.
- * 16-bit tensors, range-only formats (see dmxq_binary_cast); DMXQ_ERR_UNSUPPORTED otherwise. */
+ * The two forms of dmxq_binary_cast (range-only casts of 16-bit tensors on packed words; anything else per element in fp32). */
 int dmxq_rope_cast(const void* x, const void* cos_tab, const void* sin_tab, void* out, int dtype, int64_t B, int64_t n1, int64_t n2,
                    int64_t D, int broadcast_over_dim1, const dmxq_float_fmt* cast_x, const dmxq_float_fmt* cast_cos,
                    const dmxq_float_fmt* cast_sin, const dmxq_float_fmt* cast_out, void* stream);

@@ -461,4 +461,16 @@ def test_rope_module_under_basic_rules(dmx, cuda):
             gq, gk = m(q, k, cos, sin, ud)
         assert mismatches_nan_aware(fq, gq) == 0 and mismatches_nan_aware(fk, gk) == 0, ud
     m.fuse_rope = True
-    assert m._fused_forward(q.float(), k.float(), cos.float(), sin.float(), 1) is None        # float32: the general path
+    # the general form: float32 tensors (FLOAT16 casts round), and formats that round a bf16 value
+    for dt, fmts in ((torch.float32, ["FP[1|5|10,15](FN)"] * 6), (torch.bfloat16, ["FP[1|4|3,7](FN)", "FP[1|5|2,15](FN)", "SAME", "FP[1|4|3,7](_N)", "FP[1|5|10,15](FN)", "FP[1|4|3,7](FN)"])):
+        m.configure(dict(input_formats=fmts[:4], output_formats=fmts[4:]))
+        qq, kk, cc, ss = q.to(dt), k.to(dt), cos.to(dt), sin.to(dt)
+        with torch.no_grad():
+            assert m._fused_forward(qq, kk, cc, ss, 2) is not None, dt
+            fq, fk = m(qq, kk, cc, ss, 2)
+            m.fuse_rope = False
+            gq, gk = m(qq, kk, cc, ss, 2)
+            m.fuse_rope = True
+        assert fq.dtype == dt and mismatches_nan_aware(fq, gq) == 0 and mismatches_nan_aware(fk, gk) == 0, dt
+    m.configure(dict(input_formats=["FP[1|4|3,7](FS)"] + ["SAME"] * 3))
+    assert m._fused_forward(q, k, cos, sin, 2) is None                                          # stochastic rounding: the general path
