@@ -3,7 +3,12 @@
 group 16"), on a 4096x4096 bf16 tensor, and % of the MI355X HBM roofline.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|llama-shard] [--replays R]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N)
+  python bench.py --gpus 2|4|8 ...   starts its own N ranks: with no WORLD_SIZE in the environment the parent (which never
+                                     touches the GPU) runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+                                     --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>` as a CHILD process,
+                                     forwards rank 0's one JSON line and exits with the child's code
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+                                     the driver's form: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment
 
 Workloads (one process per GPU, no data-path collective: SURVEY.md §8e)
   c2 (default)   one "step" = one pass of the hot path (`dmxq_bfp_qdq`, ONE kernel launch through the C ABI) over this
@@ -73,7 +78,34 @@ def parse():
     ap.add_argument("--no-check", action="store_true", help="skip the gather + whole-tensor equality check")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--preroll", type=int, default=0, help="untimed launches queued right in front of each HIP-event region")
+    ap.add_argument("--no-resident", action="store_true",
+                    help="skip the cache-resident loop (one 64 MiB buffer pair, served by the Infinity Cache): a rocprofv3 "
+                         "kernel-trace of the run then holds rotating-buffer launches only")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks through torch.distributed.run even for --gpus 1 (exercises the self-launch path)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`bench.py --gpus N` without a launcher: run the N ranks as a CHILD `torch.distributed.run` and relay its output.
+    Called before anything in this process touches HIP (importing torch does not), and as a child process, never an exec:
+    a process that has initialised the GPU must not be replaced on this pool, and this way the rule cannot be broken by a
+    later edit either."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    for ln in p.stdout:   # rank 0's JSON line (and anything else the ranks print) as it comes
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    sys.exit(p.wait())
 
 
 def synth(seed, rows, cols, device):
@@ -258,18 +290,24 @@ class Workload:
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        have = torch.cuda.device_count()   # does not initialise HIP on this image
+        if args.gpus > have:
+            print(f"bench.py --gpus {args.gpus}: this box has {have} GPU(s)", file=sys.stderr)
+            sys.exit(2)
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        args.gpus = world   # under a launcher the environment is authoritative
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:   # also for a 1-rank launch: the same RCCL code path as N > 1
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
@@ -358,7 +396,7 @@ def main():
 
     # cache-resident rate (one buffer pair, 64 MiB < 256 MiB Infinity Cache): always on record, never `value`
     resident = None
-    if args.workload in ("c2", "replica"):
+    if args.workload in ("c2", "replica") and not args.no_resident:
         with torch.cuda.stream(stream):
             for _ in range(50):
                 wl.launch(0, sp)

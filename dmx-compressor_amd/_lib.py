@@ -9,12 +9,12 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("DMXQ_LIB_PATH") or os.path.join(_HERE, "lib", "libdmxq.so")  # (override: A/B runs of two builds)
+LIB_PATH = os.environ.get("DMXQ_LIB_PATH") or os.path.join(_HERE, "lib", "libdmxq.so")  # (override: A/B runs of two builds; DMXQ_BINDING=ctypes only, ops.py refuses it otherwise)
 
 F32, F16, BF16 = 0, 1, 2
 ROUND_UP, ROUND_DOWN, ROUND_NEAREST, ROUND_STOCHASTIC = 0, 1, 2, 3
 ROUNDING_CODE = {"up": ROUND_UP, "down": ROUND_DOWN, "nearest": ROUND_NEAREST, "stochastic": ROUND_STOCHASTIC}
-OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_LAUNCH = 0, 1, 2, 3
+OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_PENDING = 0, 1, 2, 3, 4
 
 _DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 

@@ -268,13 +268,16 @@ def fixed_qdq_multi(tensors, precision: int, fraction: int, clamp: bool, symmetr
     zps = [z.detach().to(device=dev, dtype=torch.int64).contiguous() for z in zero_points]
     gs = group_size or 1
     descs = (_lib.AffineDesc * len(xs))()
-    for d, x, o, s, z in zip(descs, xs, outs, scs, zps):
-        if s.numel() == 1:
+    for i, (d, x, o, s, z) in enumerate(zip(descs, xs, outs, scs, zps)):
+        # a one-entry scale means per-tensor ONLY when no group_size was asked for; with group_size set a weight needs
+        # ceil(C / group_size) entries like `fixed_qdq(ch_axis=0, group_size=...)` (an uncalibrated cast, scale = [1.0], must
+        # raise here too, not be folded with a per-tensor scale of 1)
+        outer, C, inner = split3(x.shape, 0) if x.dim() > 0 else (1, 1, 1)
+        need = -(-C // gs) if (group_size or s.numel() != 1) else 1
+        if s.numel() < need or z.numel() < need:
+            raise ValueError(f"fixed_qdq_multi: tensor {i} needs {need} scale/zero_point entries, got {s.numel()}/{z.numel()}")
+        if need == 1:
             outer, C, inner = 1, 1, x.numel()
-        else:
-            outer, C, inner = split3(x.shape, 0)
-            if s.numel() < -(-C // gs):
-                raise ValueError("fixed_qdq_multi: not enough scale entries")
         d.in_, d.out, d.scale, d.zero_point, d.outer, d.C, d.inner = x.data_ptr(), o.data_ptr(), s.data_ptr(), z.data_ptr(), outer, C, inner
     seed = _next_seed() if (seed is None and rounding == "stochastic") else (seed or 0)
     with torch.cuda.device(dev):

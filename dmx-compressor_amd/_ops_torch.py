@@ -221,7 +221,7 @@ def fixed_qdq_multi(tensors, precision: int, fraction: int, clamp: bool, symmetr
     for t in tensors:
         require_gpu(t, "fixed_qdq_multi")
     return list(_ops.fixed_qdq_multi(tensors, precision, fraction, clamp, symmetric, ROUNDING_CODE[rounding], list(scales),
-                                     list(zero_points), group_size or 1, out_dtype, _seed_arg(seed, rounding)))
+                                     list(zero_points), group_size or 0, out_dtype, _seed_arg(seed, rounding)))
 
 
 # ---------------------------------------------------------------------------------------------------- sparsity

@@ -38,19 +38,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s.split("#")[0]))]
-    common = [os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "dmxq.h"), os.path.abspath(__file__)]
-    # per-source header dependencies (a change to the BFP tile code does not rebuild the elementwise kernels)
-    extra = {"bfp.hip": ["bfp_math.hpp", "bfp_rows.hpp"], "bfp_cols.hip": ["bfp_math.hpp"], "bfp_urows.hip": ["bfp_math.hpp"], "bfp_smallinner.hip": ["bfp_math.hpp"],
-             "bfp_pack.hip": ["bfp_math.hpp"], "hypernet.hip": ["bfp_math.hpp"], "blockfmt.hip": ["bfp_math.hpp", "floatq.hpp", "stream.hpp"],
-             "elementwise.hip": ["floatq.hpp", "stream.hpp"], "unary.hip": ["stream.hpp"], "rope.hip": ["floatq.hpp"]}
     hipcc = _hipcc()
+
+    def deps_of(dfile):
+        """prerequisites hipcc recorded for the object (-MD -MF): the headers a source REALLY includes, no hand-kept table"""
+        try:
+            txt = open(dfile).read().replace("\\\n", " ")
+        except OSError:
+            return None
+        names = txt.split(":", 1)[1].split() if ":" in txt else []
+        return [n for n in names if not n.startswith(("/opt/", "/usr/"))]
 
     def compile_one(spec):
         src, _, part = spec.partition("#")
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", f"_p{part}.o" if part else ".o"))
-        if force or _stale(o, [s] + common + [os.path.join(CSRC, h) for h in extra.get(src, [])]):
-            cmd = [hipcc] + FLAGS + ([f"-DDMXQ_EW_PART={part}"] if part else []) + ["-c", s, "-o", o]
+        deps = deps_of(o + ".d")
+        if force or deps is None or any(not os.path.exists(d) for d in deps) or _stale(o, [s, os.path.abspath(__file__)] + deps):
+            cmd = [hipcc] + FLAGS + ([f"-DDMXQ_EW_PART={part}"] if part else []) + ["-MD", "-MF", o + ".d", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -395,7 +395,8 @@ inline FastDiv31 make_fastdiv31(int64_t d64) {
 // Launch-error scoping.  HIP keeps ONE "last error" per host thread, shared with every other HIP user of the thread
 // (torch, RCCL): hipGetLastError() alone would report -- and clear -- somebody else's earlier failure as ours.  So the
 // first launch of a call records whether an error was ALREADY pending (DMXQ_LAUNCH -> launch_pre), and launch_status()
-// only claims (and clears) an error that appeared since then; a foreign pending error is left untouched for its owner.
+// only claims (and clears) an error that appeared since then; a foreign pending error is left untouched for its owner, and
+// the call then returns DMXQ_ERR_PENDING (its launches cannot be verified) -- never DMXQ_OK.
 struct LaunchTls { bool armed = false; hipError_t pre = hipSuccess; };
 inline LaunchTls& launch_tls() { static thread_local LaunchTls t; return t; }
 inline void launch_pre() {
@@ -406,8 +407,15 @@ inline int launch_status() {
   LaunchTls& t = launch_tls();
   const bool foreign = t.armed && t.pre != hipSuccess;
   t.armed = false;
-  if (foreign) return DMXQ_OK;  // cannot tell ours from theirs; a failed launch stays visible through their check
-  if (hipPeekAtLastError() == hipSuccess) return DMXQ_OK;
+  const hipError_t post = hipPeekAtLastError();
+  if (foreign) {
+    // An error of another HIP user was pending before our first launch.  If the code changed, the new one is ours: claim it.
+    // If not, our launches cannot be verified (ours may have failed with the same code, or theirs masks it), and the caller's
+    // output may be uninitialised: never report OK.  The foreign error itself is left in place for its owner.
+    if (post != t.pre) { (void)hipGetLastError(); return DMXQ_ERR_LAUNCH; }
+    return DMXQ_ERR_PENDING;
+  }
+  if (post == hipSuccess) return DMXQ_OK;
   (void)hipGetLastError();
   return DMXQ_ERR_LAUNCH;
 }

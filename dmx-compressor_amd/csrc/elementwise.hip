@@ -867,6 +867,7 @@ extern "C" const char* dmxq_status_string(int status) {
     case DMXQ_ERR_BAD_ARG: return "bad argument";
     case DMXQ_ERR_UNSUPPORTED: return "unsupported parameter (undefined behaviour in the reference)";
     case DMXQ_ERR_LAUNCH: return "HIP kernel launch failed";
+    case DMXQ_ERR_PENDING: return "a pre-existing HIP error was pending on this thread before the call: launches not verified";
   }
   return "unknown status";
 }

@@ -331,11 +331,14 @@ std::vector<Tensor> fixed_qdq_multi(at::TensorList xs, int64_t precision, int64_
     outs.push_back(empty_like_shape(ins[i], out_dtype));
     scs.push_back(scales[i].detach().to(ins[i].device(), at::kFloat).contiguous());
     zps.push_back(zero_points[i].detach().to(ins[i].device(), at::kLong).contiguous());
-    const bool per_tensor = scs[i].numel() == 1;
-    const Split3 s = per_tensor ? Split3{1, 1, ins[i].numel()} : split3(ins[i], 0);
+    // group_size <= 0: none asked for (a one-entry scale then means per-tensor).  With a group_size a weight needs
+    // ceil(C / group_size) entries exactly like fixed_qdq(ch_axis = 0, group_size): an uncalibrated cast (scale = [1.0]) raises
     const int64_t gs = std::max<int64_t>(group_size, 1);
-    const int64_t need = per_tensor ? 1 : (s.L + gs - 1) / gs;
-    TORCH_CHECK_VALUE(scs[i].numel() >= need && zps[i].numel() >= need, "fixed_qdq_multi: tensor ", i, " needs ", need, " scale/zero_point entries");
+    Split3 s = ins[i].dim() > 0 ? split3(ins[i], 0) : Split3{1, 1, 1};
+    const int64_t need = (group_size > 0 || scs[i].numel() != 1) ? (s.L + gs - 1) / gs : 1;
+    TORCH_CHECK_VALUE(scs[i].numel() >= need && zps[i].numel() >= need, "fixed_qdq_multi: tensor ", i, " needs ", need,
+                      " scale/zero_point entries, got ", scs[i].numel(), "/", zps[i].numel());
+    if (need == 1) s = Split3{1, 1, ins[i].numel()};
     d[i] = dmxq_affine_desc{ins[i].data_ptr(), outs[i].data_ptr(), (const float*)scs[i].data_ptr(), (const int64_t*)zps[i].data_ptr(), s.outer, s.L, s.inner};
   }
   Launch l(ins[0]);

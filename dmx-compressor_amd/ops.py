@@ -20,6 +20,12 @@ if _binding == "ctypes":
     from ._ops_ctypes import __all__, _next_seed  # noqa: F401
     BINDING = "ctypes"
 elif _binding == "torch":
+    if os.environ.get("DMXQ_LIB_PATH"):
+        # dmxq_torch.so is linked against lib/libdmxq.so (rpath $ORIGIN): the override would only reach the ctypes handle, an A/B
+        # run would silently measure the stock build and two copies of the library (each with its own thread_local launch
+        # state) would be loaded
+        raise ImportError("DMXQ_LIB_PATH (an alternative libdmxq.so) only works with DMXQ_BINDING=ctypes: the torch extension "
+                          "resolves lib/libdmxq.so through its rpath")
     from ._ops_torch import *  # noqa: F401,F403
     from ._ops_torch import __all__, _next_seed  # noqa: F401
     BINDING = "torch"

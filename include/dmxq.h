@@ -34,7 +34,10 @@ typedef enum {
   DMXQ_OK = 0,
   DMXQ_ERR_BAD_ARG = 1,     /* null pointer, negative size, misaligned/invalid enum ... */
   DMXQ_ERR_UNSUPPORTED = 2, /* parameter outside what the reference defines (e.g. mantissa bits = 23: UB there) */
-  DMXQ_ERR_LAUNCH = 3       /* hipGetLastError() != hipSuccess after the launch */
+  DMXQ_ERR_LAUNCH = 3,      /* hipGetLastError() != hipSuccess after the launch */
+  DMXQ_ERR_PENDING = 4      /* a HIP error of ANOTHER user of this host thread was already pending before the call (HIP keeps one
+                               "last error" per thread): the launches were issued but cannot be verified, so the outputs must not be
+                               trusted; the foreign error is left in place for its owner to collect (hipGetLastError) */
 } dmxq_status;
 
 const char* dmxq_status_string(int status);
