@@ -102,9 +102,10 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
-    for ln in p.stdout:   # rank 0's JSON line (and anything else the ranks print) as it comes
-        sys.stdout.write(ln)
-        sys.stdout.flush()
+    for ln in p.stdout:   # rank 0's JSON line goes to stdout, anything else the ranks or RCCL print to stderr
+        out = sys.stdout if ln.lstrip().startswith("{") else sys.stderr
+        out.write(ln)
+        out.flush()
     sys.exit(p.wait())
 
 
@@ -310,7 +311,17 @@ def main():
     if "WORLD_SIZE" in os.environ:   # also for a 1-rank launch: the same RCCL code path as N > 1
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        # RCCL prints a version banner on STDOUT when its communicator comes up; rank 0's JSON line must stay alone there
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+            dist.barrier()                                  # (communicator creation is lazy without this)
+            torch.cuda.synchronize(dev)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     from dmx_compressor_amd import _lib
 

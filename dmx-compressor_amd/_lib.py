@@ -33,6 +33,10 @@ SIGNATURES = {
     "dmxq_input_hypernet": [_vp, _i32, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_binary_cast": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
     "dmxq_relu_cast": [_vp, _vp, _i32, _i64, _vp, _vp, _vp],
+    "dmxq_unary_cast": [_vp, _vp, _i32, _i64, _i32, _f32, _vp, _vp, _vp],
+    "dmxq_softmax_cast": [_vp, _vp, _i32, _i64, _i64, _f32, _vp, _vp, _vp],
+    "dmxq_layernorm_cast": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _f32, _vp, _vp, _vp],
+    "dmxq_rmsnorm_cast": [_vp, _vp, _i32, _i64, _i64, _vp, _f32, _vp, _vp, _vp],
     "dmxq_float_qdq": [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _u64, _vp],
     "dmxq_fixed_qdq": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _u64, _vp],
     "dmxq_fixed_qdq_multi": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _u64, _vp],

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -584,6 +584,82 @@ def rmsnorm(x, normalized_shape, weight=None, eps: Optional[float] = None, out_d
     check(lib().dmxq_rmsnorm(ptr(xc), ptr(out), dtype_code(xc.dtype), dtype_code(out.dtype), rows, cols, ptr(w),
                              dtype_code(w.dtype) if w is not None else 0, float(eps), stream_of(xc)), "dmxq_rmsnorm")
     return out
+
+
+# ---- an activation / normalisation DmxModule in one launch (include/dmxq.h dmxq_unary_cast ...): cast_out(f(cast_in(x)))
+_UNARY_KIND = {"gelu": 0, "gelu_tanh": 1, "silu": 2, "quick_gelu": 3, "exp": 4}
+
+
+def _cast_ptrs(*fmts):
+    """(pointers, keep-alive) for dmxq_float_fmt arguments, or None when a format is not one the fused kernels take"""
+    import ctypes
+    structs = []
+    for f in fmts:
+        if f is not None and (f.rounding != "nearest" or f.unsigned):
+            return None
+        structs.append(None if f is None else _lib.FloatFmt(int(f.mantissa), int(f.exponent), int(f.bias), int(bool(f.flush_subnormal))))
+    return [ctypes.cast(ctypes.pointer(st), ctypes.c_void_p) if st is not None else None for st in structs], structs
+
+
+def _fused_rc(rc, what, out):
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    check(rc, what)
+    return out
+
+
+def unary_cast(x, func: str, cast_in=None, cast_out=None):
+    """A GELU / SiLU / QuickGELU / Exp DmxModule in one launch; None when not fusable."""
+    xc = _prep(x, "unary_cast")
+    cp = _cast_ptrs(cast_in, cast_out)
+    if cp is None:
+        return None
+    out = torch.empty_like(xc)
+    rc = lib().dmxq_unary_cast(ptr(xc), ptr(out), dtype_code(xc.dtype), xc.numel(), _UNARY_KIND[func], 0.0, *cp[0], stream_of(xc))
+    return _fused_rc(rc, "dmxq_unary_cast", out)
+
+
+def softmax_cast(x, dim: int = -1, cast_in=None, cast_out=None, input_clamp: Optional[float] = None):
+    """A Softmax DmxModule in one launch (softmax over the LAST dim only); None when not fusable."""
+    xc = _prep(x, "softmax_cast")
+    cp = _cast_ptrs(cast_in, cast_out)
+    if cp is None or xc.dim() == 0 or dim % xc.dim() != xc.dim() - 1:
+        return None
+    cols = xc.shape[-1]
+    out = torch.empty_like(xc)
+    rc = lib().dmxq_softmax_cast(ptr(xc), ptr(out), dtype_code(xc.dtype), xc.numel() // max(cols, 1), cols,
+                                 float(input_clamp) if input_clamp is not None else -math.inf, *cp[0], stream_of(xc))
+    return _fused_rc(rc, "dmxq_softmax_cast", out)
+
+
+def _norm_cast(x, normalized_shape, weight, bias, eps, rms, cast_in, cast_out, what):
+    xc = _prep(x, what)
+    cp = _cast_ptrs(cast_in, cast_out)
+    cols = 1
+    for d in (normalized_shape if not isinstance(normalized_shape, int) else (normalized_shape,)):
+        cols *= d
+    w = weight.detach().contiguous() if weight is not None else None
+    b = bias.detach().contiguous() if bias is not None else None
+    if cp is None or any(t is not None and (t.dtype != xc.dtype or t.device != xc.device or t.numel() != cols) for t in (w, b)):
+        return None
+    out = torch.empty_like(xc)
+    rows = xc.numel() // max(cols, 1)
+    if rms:
+        rc = lib().dmxq_rmsnorm_cast(ptr(xc), ptr(out), dtype_code(xc.dtype), rows, cols, ptr(w), float(eps), *cp[0], stream_of(xc))
+    else:
+        rc = lib().dmxq_layernorm_cast(ptr(xc), ptr(out), dtype_code(xc.dtype), rows, cols, ptr(w), ptr(b), float(eps), *cp[0], stream_of(xc))
+    return _fused_rc(rc, "dmxq_rmsnorm_cast" if rms else "dmxq_layernorm_cast", out)
+
+
+def layernorm_cast(x, normalized_shape, weight=None, bias=None, eps: float = 1e-5, cast_in=None, cast_out=None):
+    """A LayerNorm DmxModule in one launch (weight / bias in x's dtype); None when not fusable."""
+    return _norm_cast(x, normalized_shape, weight, bias, eps, False, cast_in, cast_out, "layernorm_cast")
+
+
+def rmsnorm_cast(x, normalized_shape, weight=None, eps: Optional[float] = None, cast_in=None, cast_out=None):
+    """An RMSNorm DmxModule in one launch (eps None = torch.finfo(x.dtype).eps, as torch); None when not fusable."""
+    eps = torch.finfo(x.dtype).eps if eps is None else eps
+    return _norm_cast(x, normalized_shape, weight, None, eps, True, cast_in, cast_out, "rmsnorm_cast")
 
 
 def _on_tensor_device(fn):

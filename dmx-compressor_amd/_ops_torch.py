@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import DmxqError, ROUNDING_CODE, require_gpu
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -419,3 +419,57 @@ def rmsnorm(x, normalized_shape, weight=None, eps: Optional[float] = None, out_d
     require_gpu(x, "rmsnorm")
     eps = torch.finfo(x.dtype).eps if eps is None else eps
     return _ops.norm(x, _cols(normalized_shape), weight, None, float(eps), 1, out_dtype)
+
+
+# ---- an activation / normalisation DmxModule in one launch (include/dmxq.h dmxq_unary_cast ...): cast_out(f(cast_in(x)))
+_UNARY_KIND = {"gelu": UNARY_GELU, "gelu_tanh": UNARY_GELU_TANH, "silu": UNARY_SILU, "quick_gelu": UNARY_QUICK_GELU, "exp": UNARY_EXP}
+
+
+def _casts_ok(*fmts):
+    return all(f is None or (f.rounding == "nearest" and not f.unsigned) for f in fmts)
+
+
+def unary_cast(x, func: str, cast_in=None, cast_out=None):
+    """A GELU / SiLU / QuickGELU / Exp DmxModule in one launch; func in {"gelu", "gelu_tanh", "silu", "quick_gelu", "exp"};
+    casts are FloatingPoint formats (nearest, signed) or None = SAME.  None when not fusable (the caller runs the three steps)."""
+    require_gpu(x, "unary_cast")
+    if not _casts_ok(cast_in, cast_out):
+        return None
+    try:
+        return _ops.unary_cast(x, _UNARY_KIND[func], 0.0, _fmt4(cast_in), _fmt4(cast_out))
+    except NotImplementedError:
+        return None
+
+
+def softmax_cast(x, dim: int = -1, cast_in=None, cast_out=None, input_clamp: Optional[float] = None):
+    """A Softmax DmxModule in one launch (softmax over the LAST dim only).  None when not fusable."""
+    require_gpu(x, "softmax_cast")
+    if x.dim() == 0 or dim % x.dim() != x.dim() - 1 or not _casts_ok(cast_in, cast_out):
+        return None
+    try:
+        return _ops.softmax_cast(x, float(input_clamp) if input_clamp is not None else -math.inf, _fmt4(cast_in), _fmt4(cast_out))
+    except NotImplementedError:
+        return None
+
+
+def layernorm_cast(x, normalized_shape, weight=None, bias=None, eps: float = 1e-5, cast_in=None, cast_out=None):
+    """A LayerNorm DmxModule in one launch (weight / bias in x's dtype).  None when not fusable."""
+    require_gpu(x, "layernorm_cast")
+    if not _casts_ok(cast_in, cast_out):
+        return None
+    try:
+        return _ops.norm_cast(x, _cols(normalized_shape), weight, bias, float(eps), 0, _fmt4(cast_in), _fmt4(cast_out))
+    except NotImplementedError:
+        return None
+
+
+def rmsnorm_cast(x, normalized_shape, weight=None, eps: Optional[float] = None, cast_in=None, cast_out=None):
+    """An RMSNorm DmxModule in one launch (eps None = torch.finfo(x.dtype).eps, as torch).  None when not fusable."""
+    require_gpu(x, "rmsnorm_cast")
+    if not _casts_ok(cast_in, cast_out):
+        return None
+    eps = torch.finfo(x.dtype).eps if eps is None else eps
+    try:
+        return _ops.norm_cast(x, _cols(normalized_shape), weight, None, float(eps), 1, _fmt4(cast_in), _fmt4(cast_out))
+    except NotImplementedError:
+        return None

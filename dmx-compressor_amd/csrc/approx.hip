@@ -19,7 +19,9 @@
 #include <atomic>
 #include <math.h>
 
-#include "common.hpp"
+#include <type_traits>
+
+#include "floatq.hpp"
 
 namespace dmxq {
 
@@ -212,6 +214,55 @@ __device__ __forceinline__ RowVec<DT, EPL> row_load_tail(const void* p, int64_t 
   return r;
 }
 
+// The casts of a DmxModule around a row function (dmxq_softmax_cast / dmxq_layernorm_cast / dmxq_rmsnorm_cast): out =
+// cast_out(f(cast_in(x))) in one pass.  16-bit rows: both casts are range-only (common.hpp range16_of) and act on the packed words
+// right after the load / right before the store; float32 rows: any nearest-rounding FloatingPoint format, per element (floatq.hpp).
+struct RowCast { Range16 ri, ro; CastG gi, go; };
+struct NoRowCast {};
+template <bool CAST> using RowCastArg = std::conditional_t<CAST, RowCast, NoRowCast>;
+template <bool CAST, int DT, int EPL, class RC>
+__device__ __forceinline__ void rowcast_raw_in(RowVec<DT, EPL>& r, const RC& rc) {
+  if constexpr (CAST && DT != DMXQ_F32) {
+#pragma unroll
+    for (int j = 0; j < RowVec<DT, EPL>::kWords; j++) r.w[j] = range16_word(r.w[j], rc.ri);
+  }
+}
+template <bool CAST, int DT, int EPL, class RC>
+__device__ __forceinline__ void rowcast_x_in(float (&x)[EPL], const RC& rc) {
+  if constexpr (CAST && DT == DMXQ_F32) castg_vec<DT, EPL>(x, rc.gi);
+}
+// y (fp32 results of one lane-vector) -> the words that are stored: rounded once to the row dtype, then the output cast
+template <bool CAST, int DT, int EPL, class RC>
+__device__ __forceinline__ RowVec<DT, EPL> rowcast_pack_out(float (&y)[EPL], const RC& rc) {
+  RowVec<DT, EPL> r;
+  if constexpr (DT == DMXQ_F32) {
+    if constexpr (CAST) castg_vec<DT, EPL>(y, rc.go);
+#pragma unroll
+    for (int j = 0; j < EPL; j++) r.w[j] = f2u(y[j]);
+  } else {
+    if constexpr (CAST && DT == DMXQ_BF16) {  // c10::BFloat16: every NaN -> +0x7FC0 before a cast that saturates NaN to sign | max
+#pragma unroll
+      for (int j = 0; j < EPL; j++) y[j] = y[j] != y[j] ? u2f(0x7FC00000u) : y[j];
+    }
+#pragma unroll
+    for (int j = 0; j < EPL / 2; j++) {
+      r.w[j] = pack2<DT>(y[2 * j], y[2 * j + 1]);
+      if constexpr (CAST) r.w[j] = range16_word(r.w[j], rc.ro);
+    }
+  }
+  return r;
+}
+template <int DT, int EPL, bool UNAL = false>
+__device__ __forceinline__ void row_store_raw(void* p, int64_t e, const RowVec<DT, EPL>& r) {
+  char* a = (char*)p + e * Elem<DT>::bytes;
+  if constexpr (RowVec<DT, EPL>::kWords == 4) {
+    const u32x4 v = {r.w[0], r.w[1], r.w[2], r.w[3]};
+    if constexpr (UNAL) *(u32x4_a2*)a = v; else __builtin_nontemporal_store(v, (u32x4*)a);
+  } else {
+    __builtin_nontemporal_store(u32x2{r.w[0], r.w[1]}, (u32x2*)a);
+  }
+}
+
 // Sum / max over the LPR (64 or 32) adjacent lanes that own a row, every lane receiving the result.  Inside a row of 16 lanes: four
 // DPP steps (quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- VALU operand modifiers, no LDS); across the rows of 16: the four
 // row totals through v_readlane.  The SAME summation tree as an xor butterfly (so the same bits), which as `__shfl_xor` compiled
@@ -252,9 +303,9 @@ constexpr int rows_per_wave(int vpl, int epl) { return 32 / (vpl * epl) >= 4 ? 4
 // 16-bit outputs: exp(x - m) as v_exp_f32(fma(x, log2 e, -m log2 e)) and one reciprocal per row -- relative error
 // ~2^-21, far inside the output format's 2^-9 / 2^-12 half-ulp (the rounding of m log2 e scales numerator and
 // denominator alike and cancels); fp32 outputs keep expf and the per-element division.
-template <int DT, int EPL, int VPL, int LPR, bool RAG = false>
+template <int DT, int EPL, int VPL, int LPR, bool RAG = false, bool CAST = false>
 __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __restrict__ in, void* __restrict__ out,
-                                                               int64_t rows, int64_t cols, float clamp_min) {
+                                                               int64_t rows, int64_t cols, float clamp_min, const RowCastArg<CAST> rc) {
   constexpr int SUB = kWave / LPR;  // rows side by side in one wave
   constexpr int RPW = rows_per_wave(VPL, EPL);
   constexpr bool FAST = DT != DMXQ_F32;
@@ -290,7 +341,9 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
       m[j] = -INFINITY;
 #pragma unroll
       for (int i = 0; i < VPL; i++) {
+        rowcast_raw_in<CAST, DT, EPL>(raw[j][i], rc);
         row_widen<DT, EPL>(raw[j][i], x[j][i]);
+        rowcast_x_in<CAST, DT, EPL>(x[j][i], rc);
         if (has_clamp) {
 #pragma unroll
           for (int k = 0; k < EPL; k++) x[j][i][k] = fmaxf(x[j][i][k], clamp_min);
@@ -336,7 +389,11 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
             float y[EPL];
 #pragma unroll
             for (int k = 0; k < EPL; k++) y[k] = FAST ? x[j][i][k] * inv : x[j][i][k] / s[j];
-            if constexpr (!RAG) {
+            if constexpr (CAST) {
+              const RowVec<DT, EPL> o = rowcast_pack_out<CAST, DT, EPL>(y, rc);
+              if constexpr (!RAG) row_store_raw<DT, EPL>(out, r * cols + (int64_t)v * EPL, o);
+              else row_store_raw<DT, EPL, true>(out, r * cols + (v < nvf ? (int64_t)v * EPL : cols - EPL), o);
+            } else if constexpr (!RAG) {
               row_store<DT, EPL>(out, r * cols + (int64_t)v * EPL, y);
             } else {
               row_store_u<DT, EPL>(out, r * cols + (v < nvf ? (int64_t)v * EPL : cols - EPL), y);
@@ -351,10 +408,10 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
 // weight / bias (same dtype as the rows) are read ONCE per wave and kept across its rows: widened to fp32 for short
 // rows, packed for longer ones.  Per element: widen + add, subtract + fma, and (x - mean) * (rstd w) + b as
 // subtract + fma with rstd w formed once per (row, vector element).
-template <int DT, int EPL, int VPL, int LPR, bool RMS = false>
+template <int DT, int EPL, int VPL, int LPR, bool RMS = false, bool CAST = false>
 __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                                  int64_t rows, int64_t cols, const void* __restrict__ w,
-                                                                 const void* __restrict__ b, float eps) {
+                                                                 const void* __restrict__ b, float eps, const RowCastArg<CAST> rc) {
   constexpr int SUB = kWave / LPR;
   constexpr int RPW = rows_per_wave(VPL, EPL);
   constexpr bool HOIST_F32 = VPL * EPL <= 24, HOIST_RAW = !HOIST_F32 && VPL <= 8;
@@ -397,7 +454,9 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
       float s = 0.0f;
 #pragma unroll
       for (int i = 0; i < VPL; i++) {
+        rowcast_raw_in<CAST, DT, EPL>(raw[j][i], rc);
         row_widen<DT, EPL>(raw[j][i], x[j][i]);
+        rowcast_x_in<CAST, DT, EPL>(x[j][i], rc);
         float t = 0.0f;
 #pragma unroll
         for (int k = 0; k < EPL; k++) t += x[j][i][k];
@@ -441,7 +500,8 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
               const float d = x[j][i][k] - mean[j];
               y[k] = b ? __builtin_fmaf(d, g, HOIST_F32 ? bf[i][k] : bb[k]) : d * g;
             }
-            row_store<DT, EPL>(out, r * cols + (int64_t)v * EPL, y);
+            if constexpr (CAST) row_store_raw<DT, EPL>(out, r * cols + (int64_t)v * EPL, rowcast_pack_out<CAST, DT, EPL>(y, rc));
+            else row_store<DT, EPL>(out, r * cols + (int64_t)v * EPL, y);
           }
         }
       }
@@ -453,10 +513,10 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
 // thread), two workgroup reductions per row through a 4-entry LDS exchange, RPW rows per iteration to amortise the two
 // barriers, weight / bias hoisted (packed) out of the persistent row loop.  The wave kernel at this size would hold
 // 128+ values per lane and re-read weight and bias (as much data as the row itself) for every row.
-template <int DT, int EPL, int VPL, bool RMS = false>
+template <int DT, int EPL, int VPL, bool RMS = false, bool CAST = false>
 __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                                   int64_t rows, int64_t cols, const void* __restrict__ w,
-                                                                  const void* __restrict__ b, float eps) {
+                                                                  const void* __restrict__ b, float eps, const RowCastArg<CAST> rc) {
   constexpr int RPW = VPL * EPL <= 32 ? 2 : 1;
   constexpr int NW = kThreads / kWave;
   __shared__ float red[2][RPW][NW];
@@ -491,7 +551,9 @@ __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* _
       float s = 0.0f;
 #pragma unroll
       for (int i = 0; i < VPL; i++) {
+        rowcast_raw_in<CAST, DT, EPL>(raw[j][i], rc);
         row_widen<DT, EPL>(raw[j][i], x[j][i]);
+        rowcast_x_in<CAST, DT, EPL>(x[j][i], rc);
         if constexpr (!RMS) {
           float u = 0.0f;
 #pragma unroll
@@ -550,7 +612,8 @@ __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* _
               const float d = x[j][i][k] - mean[j];
               y[k] = b ? __builtin_fmaf(d, g, bb[k]) : d * g;
             }
-            row_store<DT, EPL>(out, (r0 + j) * cols + (int64_t)v * EPL, y);
+            if constexpr (CAST) row_store_raw<DT, EPL>(out, (r0 + j) * cols + (int64_t)v * EPL, rowcast_pack_out<CAST, DT, EPL>(y, rc));
+            else row_store<DT, EPL>(out, (r0 + j) * cols + (int64_t)v * EPL, y);
           }
         }
       }
@@ -608,8 +671,9 @@ static int resident_grid(K kernel, int64_t wanted) {
 
 static inline int row_grid(int64_t rows) { return (int)(rows < 256 * 16 ? (rows < 1 ? 1 : rows) : 256 * 16); }
 
-extern "C" int dmxq_softmax(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
-                            float input_clamp_min, void* stream) {
+template <bool CAST>
+static int softmax_dispatch(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
+                            float input_clamp_min, void* stream, const RowCastArg<CAST>& rc) {
   if (!valid_dtype(dtype_in) || !valid_dtype(dtype_out) || rows < 0 || cols < 0) return DMXQ_ERR_BAD_ARG;
   if (rows * cols == 0) return DMXQ_OK;
   if (!in || !out) return DMXQ_ERR_BAD_ARG;
@@ -633,15 +697,15 @@ extern "C" int dmxq_softmax(const void* in, void* out, int dtype_in, int dtype_o
     constexpr int per_wg = 4 * rows_per_wave(V_, E_) * (64 / (L_));                                                   \
     if constexpr ((E_) * Elem<D_>::bytes == 16) {                                                                     \
       if (rag) {                                                                                                      \
-        DMXQ_LAUNCH((softmax_wave_kernel<D_, E_, V_, L_, true>),                                               \
-                           dim3((unsigned)resident_grid(softmax_wave_kernel<D_, E_, V_, L_, true>, (rows + per_wg - 1) / per_wg)), \
-                           dim3(kThreads), 0, s, in, out, rows, cols, input_clamp_min);                               \
+        DMXQ_LAUNCH((softmax_wave_kernel<D_, E_, V_, L_, true, CAST>),                                         \
+                           dim3((unsigned)resident_grid(softmax_wave_kernel<D_, E_, V_, L_, true, CAST>, (rows + per_wg - 1) / per_wg)), \
+                           dim3(kThreads), 0, s, in, out, rows, cols, input_clamp_min, rc);                           \
         break;                                                                                                        \
       }                                                                                                               \
     }                                                                                                                 \
-      DMXQ_LAUNCH((softmax_wave_kernel<D_, E_, V_, L_, false>),                                                \
-                         dim3((unsigned)resident_grid(softmax_wave_kernel<D_, E_, V_, L_, false>, (rows + per_wg - 1) / per_wg)), \
-                         dim3(kThreads), 0, s, in, out, rows, cols, input_clamp_min);                                 \
+      DMXQ_LAUNCH((softmax_wave_kernel<D_, E_, V_, L_, false, CAST>),                                          \
+                         dim3((unsigned)resident_grid(softmax_wave_kernel<D_, E_, V_, L_, false, CAST>, (rows + per_wg - 1) / per_wg)), \
+                         dim3(kThreads), 0, s, in, out, rows, cols, input_clamp_min, rc);                             \
   } while (0)
 #define DMXQ_SM_V(D_, E_)                                                                            \
   do {                                                                                               \
@@ -661,6 +725,7 @@ extern "C" int dmxq_softmax(const void* in, void* out, int dtype_in, int dtype_o
 #undef DMXQ_SM
     return launch_status();
   }
+  if constexpr (CAST) return DMXQ_ERR_UNSUPPORTED;  // the fused-cast form exists for register-resident rows only
   const size_t scratch = (kThreads / kWave) * sizeof(float);
   if (cols <= kRowLdsFloats)
     DMXQ_LAUNCH(softmax_rows_kernel<true>, dim3(row_grid(rows)), dim3(kThreads), scratch + cols * sizeof(float), s,
@@ -671,9 +736,29 @@ extern "C" int dmxq_softmax(const void* in, void* out, int dtype_in, int dtype_o
   return launch_status();
 }
 
-template <bool RMS>
+extern "C" int dmxq_softmax(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
+                            float input_clamp_min, void* stream) {
+  return softmax_dispatch<false>(in, out, dtype_in, dtype_out, rows, cols, input_clamp_min, stream, NoRowCast{});
+}
+
+// the two casts of a module around a row function: false = not a combination the fused kernels take
+static bool rowcast_of(int dtype, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, RowCast* rc) {
+  *rc = RowCast{};
+  if (dtype == DMXQ_F32) return castg_of(cast_in, &rc->gi) && castg_of(cast_out, &rc->go);
+  return range16_of(cast_in, dtype, &rc->ri) && range16_of(cast_out, dtype, &rc->ro);
+}
+
+extern "C" int dmxq_softmax_cast(const void* in, void* out, int dtype, int64_t rows, int64_t cols, float input_clamp_min,
+                                 const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* stream) {
+  RowCast rc;
+  if (!valid_dtype(dtype)) return DMXQ_ERR_BAD_ARG;
+  if (!rowcast_of(dtype, cast_in, cast_out, &rc)) return DMXQ_ERR_UNSUPPORTED;
+  return softmax_dispatch<true>(in, out, dtype, dtype, rows, cols, input_clamp_min, stream, rc);
+}
+
+template <bool RMS, bool CAST = false>
 static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
-                         const void* weight, const void* bias, int dtype_wb, float eps, void* stream) {
+                         const void* weight, const void* bias, int dtype_wb, float eps, void* stream, const RowCastArg<CAST>& rc = {}) {
   if (!valid_dtype(dtype_in) || !valid_dtype(dtype_out) || rows < 0 || cols < 0) return DMXQ_ERR_BAD_ARG;
   if ((weight || bias) && !valid_dtype(dtype_wb)) return DMXQ_ERR_BAD_ARG;
   if (rows * cols == 0) return DMXQ_OK;
@@ -688,9 +773,9 @@ static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out,
 #define DMXQ_LNB(D_, E_, V_)                                                                                          \
   do {                                                                                                                \
     constexpr int rpw = (V_) * (E_) <= 32 ? 2 : 1;                                                                    \
-    DMXQ_LAUNCH((layernorm_block_kernel<D_, E_, V_, RMS>),                                                          \
-                       dim3((unsigned)resident_grid(layernorm_block_kernel<D_, E_, V_, RMS>, (rows + rpw - 1) / rpw)),     \
-                       dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps);                                 \
+    DMXQ_LAUNCH((layernorm_block_kernel<D_, E_, V_, RMS, CAST>),                                                    \
+                       dim3((unsigned)resident_grid(layernorm_block_kernel<D_, E_, V_, RMS, CAST>, (rows + rpw - 1) / rpw)), \
+                       dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps, rc);                             \
   } while (0)
 #define DMXQ_LNB_V(D_, E_)                                                                                            \
   do {                                                                                                                \
@@ -712,9 +797,9 @@ static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out,
 #define DMXQ_LN(D_, E_, V_, L_)                                                                                       \
   do {                                                                                                                \
     constexpr int per_wg = 4 * rows_per_wave(V_, E_) * (64 / (L_));                                                   \
-    DMXQ_LAUNCH((layernorm_wave_kernel<D_, E_, V_, L_, RMS>),                                                       \
-                       dim3((unsigned)resident_grid(layernorm_wave_kernel<D_, E_, V_, L_, RMS>, (rows + per_wg - 1) / per_wg)), \
-                       dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps);                                 \
+    DMXQ_LAUNCH((layernorm_wave_kernel<D_, E_, V_, L_, RMS, CAST>),                                                 \
+                       dim3((unsigned)resident_grid(layernorm_wave_kernel<D_, E_, V_, L_, RMS, CAST>, (rows + per_wg - 1) / per_wg)), \
+                       dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps, rc);                             \
   } while (0)
 #define DMXQ_LN_V(D_, E_)                                                                            \
   do {                                                                                               \
@@ -734,6 +819,7 @@ static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out,
 #undef DMXQ_LN
     return launch_status();
   }
+  if constexpr (CAST) return DMXQ_ERR_UNSUPPORTED;  // the fused-cast form exists for register-resident rows only
   const size_t scratch = (kThreads / kWave) * sizeof(float);
   if (cols <= kRowLdsFloats)
     DMXQ_LAUNCH((layernorm_rows_kernel<true, RMS>), dim3(row_grid(rows)), dim3(kThreads), scratch + cols * sizeof(float),
@@ -755,4 +841,20 @@ extern "C" int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype
 extern "C" int dmxq_rmsnorm(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
                             const void* weight, int dtype_w, float eps, void* stream) {
   return norm_dispatch<true>(in, out, dtype_in, dtype_out, rows, cols, weight, nullptr, dtype_w, eps, stream);
+}
+
+// A LayerNorm / RMSNorm DmxModule in one pass: out = cast_out(norm(cast_in(x); weight, bias)), weight / bias in the row dtype.
+extern "C" int dmxq_layernorm_cast(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, const void* bias,
+                                   float eps, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* stream) {
+  RowCast rc;
+  if (!valid_dtype(dtype)) return DMXQ_ERR_BAD_ARG;
+  if (!rowcast_of(dtype, cast_in, cast_out, &rc)) return DMXQ_ERR_UNSUPPORTED;
+  return norm_dispatch<false, true>(in, out, dtype, dtype, rows, cols, weight, bias, dtype, eps, stream, rc);
+}
+extern "C" int dmxq_rmsnorm_cast(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, float eps,
+                                 const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* stream) {
+  RowCast rc;
+  if (!valid_dtype(dtype)) return DMXQ_ERR_BAD_ARG;
+  if (!rowcast_of(dtype, cast_in, cast_out, &rc)) return DMXQ_ERR_UNSUPPORTED;
+  return norm_dispatch<true, true>(in, out, dtype, dtype, rows, cols, weight, nullptr, dtype, eps, stream, rc);
 }

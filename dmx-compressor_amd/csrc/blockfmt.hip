@@ -85,12 +85,29 @@ struct MxfpBlock {
   __device__ __forceinline__ void setup(uint32_t maxbits, const MxfpFmt& f) {
     const float m = u2f(maxbits);
     zero = m == 0.0f;
-    // the reference evaluates 2^floor(log2 m) / 2^(2^(e-1)) in fp32 (format.py:551-555).  For a maximum with at most
-    // 11 significant bits (bf16 / fp16 inputs) log2f cannot round across an integer, so floor(log2 m) is m's exponent
-    // field and the scale is assembled from bits; fp32 inputs keep the libm form (known divergences).
-    const int eb = (int)(maxbits >> 23), se = eb - f.big_log2;
-    if (f.exact_exponent && eb >= 1 && eb <= 254 && se >= 1 && se <= 254) scale = u2f((uint32_t)se << 23);
-    else scale = exp2f(floorf(log2f(m))) / f.big;
+    // the reference evaluates 2^floor(log2 m) / 2^(2^(e-1)) in fp32 (format.py:551-555).  No libm: a float32 log2 within an ulp
+    // of the truth crosses an integer only for m = 2^v (1 - j 2^-24) with j <= jmax(v) (the rule and its proof sketch are in
+    // oracle/oracle.c oracle_floor_log2f; checked against torch.log2 for every exponent, fixtures tests/golden/boundaries.npz);
+    // a maximum with at most 11 significant bits (bf16 / fp16 inputs) has j >= 2^13 and never does.
+    int eb = (int)(maxbits >> 23);
+    if (eb >= 1 && eb <= 254) {
+      const uint32_t man = maxbits & 0x007FFFFFu;
+      const int v = eb - 126;  // floor(log2 m) + 1
+      if (!f.exact_exponent && man != 0u && v != 0) {
+        const uint32_t a = (uint32_t)(v < 0 ? -v : v), j = 0x00800000u - man;
+        const int c = 31 - __builtin_clz(a);
+        const int g = (v > 0 && (a & (a - 1u)) == 0u) ? 25 - c : 24 - c;  // 17 .. 25
+        // jmax = floor(2^24 (1 - 2^(-2^-g))): 88 44 22 11 | 5 2 1 | 0 0, as bytes of two constants
+        const uint32_t jmax = g <= 20 ? ((0x0B162C58u >> (8 * (g - 17))) & 0xFFu) : (g <= 23 ? ((0x00010205u >> (8 * (g - 21))) & 0xFFu) : 0u);
+        if (j <= jmax) eb += 1;
+      }
+      const int se = eb - f.big_log2;
+      if (eb == 255) scale = INFINITY;                      // 2^128: the reference's fp32 power overflows too
+      else if (se >= 1) scale = u2f((uint32_t)se << 23);
+      else scale = ldexpf(1.0f, se - 127);                  // a denormal (or zero) scale, exact
+    } else {
+      scale = exp2f(floorf(log2f(m))) / f.big;              // zero (see `zero`), denormal, Inf, NaN maxima
+    }
     const uint32_t sb = f2u(scale);
     pow2 = (sb & 0x007FFFFFu) == 0u && (sb >> 23) >= 1u && (sb >> 23) <= 253u;
     inv = u2f((254u - (sb >> 23)) << 23);

@@ -7,6 +7,7 @@
 // fp32 arithmetic, one RNE narrowing to the output dtype, 16-byte stores.  HBM-bound: 2+2 B/elem for 16-bit I/O.
 #include "floatq.hpp"
 #include "stream.hpp"
+#include "unary_ops.hpp"
 
 namespace dmxq {
 
@@ -342,50 +343,6 @@ struct ScaleOp {
         if (k + 1 < N && it.next(cm)) s = scale[it.g];
       }
     }
-  }
-};
-
-// torch.nn.functional.gelu, erf and tanh forms (approximator slot, see approx.hip).
-// FAST (16-bit outputs only): the libm calls are replaced by short closed forms whose error (< 8e-7 absolute on the
-// result for |x| <= 10, exact saturation beyond) is far inside the output format's half-ulp:
-//   erf form : with z = |x| / sqrt 2, erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2), t = 1 / (1 + p z)
-//              (Abramowitz-Stegun 7.1.26, |error| < 1.5e-7), gelu = x >= 0 ? x - x erfc / 2 : x erfc / 2 -- the erfc form
-//              keeps RELATIVE accuracy in the negative tail, where 1 + erf cancels;
-//   tanh form: x (1 + tanh u) / 2 = x / (1 + exp(-2u)).
-// TANH is a template parameter, not a kernel argument: as a run-time flag it was a scalar branch around EVERY element (16 per
-// pair of vectors), which kept the compiler from interleaving the elements' rcp / exp chains
-template <bool FAST, bool TANH>
-struct GeluOp {
-  static constexpr bool kHeavy = true;
-  static constexpr int kTileUnroll = 2;
-  __device__ __forceinline__ void apply_one(float x, float& y, int64_t) const {
-    if (TANH) {
-      const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-      const float u = k0 * (x + k1 * x * x * x);
-      if (FAST) {  // x (1 + tanh u) / 2 = x / (1 + exp(-2u)): no cancellation in the negative tail
-        y = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -2.8853900817779268f));
-      } else {
-        y = 0.5f * x * (1.0f + tanhf(u));
-      }
-    } else if (FAST) {
-      const float z = fabsf(x) * 0.7071067811865476f;
-      const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-      float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
-      p = __builtin_fmaf(t, p, 1.421413741f);
-      p = __builtin_fmaf(t, p, -0.284496736f);
-      p = __builtin_fmaf(t, p, 0.254829592f);
-      const float erfc = p * t * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
-      const float g = 0.5f * x * erfc;
-      y = x > 0.0f ? x - g : g;  // (x = -0: g = -0, as torch)
-      if (x != x) y = x;
-    } else {
-      y = 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
-    }
-  }
-  template <int N>
-  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
-#pragma unroll
-    for (int k = 0; k < N; k++) apply_one(x[k], y[k], e0 + k);
   }
 };
 

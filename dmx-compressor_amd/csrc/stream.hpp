@@ -39,6 +39,12 @@ struct OpPrep<OP, std::void_t<typename OP::Prep>> {
 template <class OP, class = void> struct OpTilePrep { static constexpr bool value = false; };
 template <class OP> struct OpTilePrep<OP, std::void_t<decltype(OP::kTilePrep)>> { static constexpr bool value = OP::kTilePrep; };
 
+// Optional raw-word hooks (act_cast.hip): an OP with `static constexpr bool kRawHooks = true` sees every 16-byte input vector
+// before it is widened (raw_in) and every packed output vector before it is stored (raw_out) -- the range-only casts of 16-bit
+// tensors act on the packed words (common.hpp range16_word), two elements per operation.
+template <class OP, class = void> struct OpRawHooks { static constexpr bool value = false; };
+template <class OP> struct OpRawHooks<OP, std::void_t<decltype(OP::kRawHooks)>> { static constexpr bool value = OP::kRawHooks; };
+
 template <int DTI, int DTO, int UNROLL, int THREADS, class OP, bool UNAL = false>
 __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                         int64_t n, OP op) {
@@ -66,9 +72,11 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict_
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
           float x[EPL], y[EPL];
+          if constexpr (OpRawHooks<OP>::value) op.raw_in(raw[u]);
           widen<DTI, EPL>(raw[u], x);
           OpPrep<OP>::apply(op, x, y, (v0 + (int64_t)u * THREADS) * EPL, prep_of(u));
           o[u] = pack_vec<DTO, EPL>(y);
+          if constexpr (OpRawHooks<OP>::value) op.raw_out(o[u]);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -91,11 +99,14 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict_
       for (int u = 0; u < UNROLL; u++) {
         const int64_t vi = v0 + (int64_t)u * THREADS;
         if (vi < n_vec) {
-          const u32x4 raw = load_raw16<true, uint32_t, UNAL>(src + u * (THREADS * 16), lane_in);
+          u32x4 raw = load_raw16<true, uint32_t, UNAL>(src + u * (THREADS * 16), lane_in);
           float x[EPL], y[EPL];
+          if constexpr (OpRawHooks<OP>::value) op.raw_in(raw);
           widen<DTI, EPL>(raw, x);
           op.apply_vec(x, y, vi * EPL);
-          store_out<DTO, EPL, true, UNAL>(dst + u * (THREADS * OVB) + lane_out, pack_vec<DTO, EPL>(y));
+          OutVec<DTO, EPL> o1 = pack_vec<DTO, EPL>(y);
+          if constexpr (OpRawHooks<OP>::value) op.raw_out(o1);
+          store_out<DTO, EPL, true, UNAL>(dst + u * (THREADS * OVB) + lane_out, o1);
         }
       }
     }

@@ -582,6 +582,57 @@ Tensor norm_meta(const Tensor& x, int64_t, const OptTensor&, const OptTensor&, d
   return empty_like_shape(x, out_dtype);
 }
 
+// ---- an activation / normalisation module in one launch: cast_out(f(cast_in(x)))  (include/dmxq.h dmxq_unary_cast ...)
+Tensor unary_cast(const Tensor& x, int64_t kind, double param, at::IntArrayRef cast_in, at::IntArrayRef cast_out) {
+  const Tensor xc = prep(x, "unary_cast");
+  Tensor out = empty_like_shape(xc, xc.scalar_type());
+  dmxq_float_fmt fi, fo;
+  Launch l(xc);
+  check(dmxq_unary_cast(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), xc.numel(), (int)kind, (float)param, fmt_of(cast_in, &fi),
+                        fmt_of(cast_out, &fo), l.stream), "dmxq_unary_cast");
+  return out;
+}
+Tensor unary_cast_meta(const Tensor& x, int64_t, double, at::IntArrayRef, at::IntArrayRef) { return empty_like_shape(x, x.scalar_type()); }
+
+Tensor softmax_cast(const Tensor& x, double clamp_min, at::IntArrayRef cast_in, at::IntArrayRef cast_out) {  // over the contiguous last dim
+  const Tensor xc = prep(x, "softmax_cast");
+  const int64_t cols = xc.dim() ? xc.size(-1) : 1;
+  const int64_t rows = cols ? xc.numel() / cols : 0;
+  Tensor out = empty_like_shape(xc, xc.scalar_type());
+  dmxq_float_fmt fi, fo;
+  Launch l(xc);
+  check(dmxq_softmax_cast(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), rows, cols, (float)clamp_min, fmt_of(cast_in, &fi),
+                          fmt_of(cast_out, &fo), l.stream), "dmxq_softmax_cast");
+  return out;
+}
+Tensor softmax_cast_meta(const Tensor& x, double, at::IntArrayRef, at::IntArrayRef) { return empty_like_shape(x, x.scalar_type()); }
+
+Tensor norm_cast(const Tensor& x, int64_t cols, const OptTensor& weight, const OptTensor& bias, double eps, int64_t kind, at::IntArrayRef cast_in,
+                 at::IntArrayRef cast_out) {
+  const Tensor xc = prep(x, "norm_cast");
+  const int64_t rows = cols ? xc.numel() / cols : 0;
+  Tensor w, b;
+  if (weight.has_value() && weight->defined()) w = weight->detach().contiguous();
+  if (bias.has_value() && bias->defined()) b = bias->detach().contiguous();
+  TORCH_CHECK_NOT_IMPLEMENTED((!w.defined() || (w.scalar_type() == xc.scalar_type() && w.device() == xc.device() && w.numel() == cols)) &&
+                              (!b.defined() || (b.scalar_type() == xc.scalar_type() && b.device() == xc.device() && b.numel() == cols)),
+                              "norm_cast: weight / bias must be in the row dtype, on the row's device, one per column");
+  Tensor out = empty_like_shape(xc, xc.scalar_type());
+  dmxq_float_fmt fi, fo;
+  Launch l(xc);
+  if (kind == 0)
+    check(dmxq_layernorm_cast(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), rows, cols, w.defined() ? w.data_ptr() : nullptr,
+                              b.defined() ? b.data_ptr() : nullptr, (float)eps, fmt_of(cast_in, &fi), fmt_of(cast_out, &fo), l.stream),
+          "dmxq_layernorm_cast");
+  else
+    check(dmxq_rmsnorm_cast(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), rows, cols, w.defined() ? w.data_ptr() : nullptr, (float)eps,
+                            fmt_of(cast_in, &fi), fmt_of(cast_out, &fo), l.stream), "dmxq_rmsnorm_cast");
+  return out;
+}
+Tensor norm_cast_meta(const Tensor& x, int64_t, const OptTensor&, const OptTensor&, double, int64_t, at::IntArrayRef, at::IntArrayRef) {
+  return empty_like_shape(x, x.scalar_type());
+}
+
 }  // namespace
 
 TORCH_LIBRARY(dmxq, m) {
@@ -618,6 +669,9 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("rope_cast(Tensor x, Tensor cos, Tensor sin, int unsqueeze_dim, int[] cast_x, int[] cast_cos, int[] cast_sin, int[] cast_out) -> Tensor");
   m.def("softmax(Tensor x, float clamp_min, ScalarType? out_dtype=None) -> Tensor");
   m.def("norm(Tensor x, int cols, Tensor? weight, Tensor? bias, float eps, int kind, ScalarType? out_dtype=None) -> Tensor");
+  m.def("unary_cast(Tensor x, int kind, float param, int[] cast_in, int[] cast_out) -> Tensor");
+  m.def("softmax_cast(Tensor x, float clamp_min, int[] cast_in, int[] cast_out) -> Tensor");
+  m.def("norm_cast(Tensor x, int cols, Tensor? weight, Tensor? bias, float eps, int kind, int[] cast_in, int[] cast_out) -> Tensor");
 }
 
 #define DMXQ_IMPL(m, name) m.impl(#name, &name)
@@ -625,7 +679,8 @@ TORCH_LIBRARY(dmxq, m) {
 #define DMXQ_FOR_ALL(X, m) \
   X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, input_hypernet); X(m, binary_cast); X(m, relu_cast); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
   X(m, float_qdq); X(m, fixed_qdq); X(m, fixed_qdq_multi); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
-  X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, rope); X(m, rope_cast); X(m, softmax); X(m, norm)
+  X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, rope); X(m, rope_cast); X(m, softmax); X(m, norm); \
+  X(m, unary_cast); X(m, softmax_cast); X(m, norm_cast)
 
 // "CUDA" is the dispatch key of HIP tensors in a ROCm build of PyTorch
 TORCH_LIBRARY_IMPL(dmxq, CUDA, m) {

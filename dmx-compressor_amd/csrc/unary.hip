@@ -14,62 +14,9 @@
 #include <math.h>
 
 #include "stream.hpp"
+#include "unary_ops.hpp"
 
 namespace dmxq {
-
-template <int DT>
-__device__ __forceinline__ float round_dt(float v) {  // RNE to DT and back (exact for fp32)
-  if (DT == DMXQ_BF16) return (float)(__bf16)v;
-  if (DT == DMXQ_F16) return (float)(_Float16)opaque(v);
-  return v;
-}
-
-// FAST: 16-bit outputs -- v_exp_f32 + v_rcp_f32 (relative error ~2^-21, far inside the 2^-9 / 2^-12 half-ulp of the
-// output format); fp32 outputs keep expf and the IEEE division.
-template <bool FAST>
-__device__ __forceinline__ float sigmoid_mul(float x, float t) {  // x * sigmoid(t)
-  if (FAST) {
-    const float d = 1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f);
-    // v_rcp_f32 flushes a denormal RESULT to zero (1 / d for d > 2^126): the far negative tail, where the true value
-    // x / d is still a normal number (silu(-88) = -5.3e-37), takes the IEEE division instead (rare: t < -87)
-    return d > 8.5e37f ? x / d : x * __builtin_amdgcn_rcpf(d);
-  }
-  return x / (1.0f + expf(-t));
-}
-
-template <int KIND, int DTI, bool FAST>
-struct UnaryOp {
-  static constexpr bool kHeavy = true;
-  static constexpr int kTileUnroll = KIND == DMXQ_UNARY_SILU ? 8 : (KIND == DMXQ_UNARY_QUICK_GELU ? 2 : 4);  // stream.hpp
-  float param;
-  __device__ __forceinline__ void apply_one(float x, float& y, int64_t) const {
-    if (KIND == DMXQ_UNARY_SILU) {
-      y = sigmoid_mul<FAST>(x, x);
-    } else if (KIND == DMXQ_UNARY_EXP) {
-      y = FAST ? __builtin_amdgcn_exp2f(x * 1.4426950408889634f) : expf(x);
-    } else if (KIND == DMXQ_UNARY_QUICK_GELU) {
-      const float t = round_dt<DTI>(1.702f * x);
-      float s;
-      if (FAST && DTI != DMXQ_F32) {
-        const float d = 1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f);
-        s = d > 8.5e37f ? 1.0f / d : __builtin_amdgcn_rcpf(d);  // (v_rcp_f32 flushes denormal results: see sigmoid_mul)
-      } else {
-        s = 1.0f / (1.0f + expf(-t));
-      }
-      s = round_dt<DTI>(s);
-      y = x * s;
-    } else {  // DMXQ_UNARY_SILU_EXPERIMENTAL: relu(half(x)) * scale, the product rounded to half by the store
-      const float h = round_dt<DMXQ_F16>(x);
-      const float r = h < 0.0f ? 0.0f : h;  // at::relu == clamp_min(0): NaN stays NaN, -0.0 stays -0.0 (max(-0, +0) keeps the first)
-      y = r * param;
-    }
-  }
-  template <int N>
-  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
-#pragma unroll
-    for (int k = 0; k < N; k++) apply_one(x[k], y[k], e0 + k);
-  }
-};
 
 template <int KIND>
 static int launch_unary(const void* in, void* out, int dti, int dto, int64_t n, float param, hipStream_t s) {

@@ -1,0 +1,116 @@
+// csrc/unary_ops.hpp -- the per-element functions of the approximator slot as OPs of the streaming skeleton (stream.hpp):
+// GELU (erf / tanh), SILU, QUICK_GELU, EXP and the reference's `experimental.silu`.  Shared by elementwise.hip (dmxq_gelu),
+// unary.hip (dmxq_unary) and act_cast.hip (dmxq_unary_cast: the same functions between a module's two casts).
+#pragma once
+#include <math.h>
+
+#include "common.hpp"
+
+namespace dmxq {
+
+// torch.nn.functional.gelu, erf and tanh forms (approximator slot, see approx.hip).
+// FAST (16-bit outputs only): the libm calls are replaced by short closed forms whose error (< 8e-7 absolute on the
+// result for |x| <= 10, exact saturation beyond) is far inside the output format's half-ulp:
+//   erf form : with z = |x| / sqrt 2, erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2), t = 1 / (1 + p z)
+//              (Abramowitz-Stegun 7.1.26, |error| < 1.5e-7), gelu = x >= 0 ? x - x erfc / 2 : x erfc / 2 -- the erfc form
+//              keeps RELATIVE accuracy in the negative tail, where 1 + erf cancels;
+//   tanh form: x (1 + tanh u) / 2 = x / (1 + exp(-2u)).
+// TANH is a template parameter, not a kernel argument: as a run-time flag it was a scalar branch around EVERY element (16 per
+// pair of vectors), which kept the compiler from interleaving the elements' rcp / exp chains
+template <bool FAST, bool TANH>
+struct GeluOp {
+  static constexpr bool kHeavy = true;
+  static constexpr int kTileUnroll = 2;
+  __device__ __forceinline__ void apply_one(float x, float& y, int64_t) const {
+    if (TANH) {
+      const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+      const float u = k0 * (x + k1 * x * x * x);
+      if (FAST) {  // x (1 + tanh u) / 2 = x / (1 + exp(-2u)): no cancellation in the negative tail
+        y = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -2.8853900817779268f));
+      } else {
+        y = 0.5f * x * (1.0f + tanhf(u));
+      }
+    } else if (FAST) {
+      const float z = fabsf(x) * 0.7071067811865476f;
+      const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+      float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+      p = __builtin_fmaf(t, p, 1.421413741f);
+      p = __builtin_fmaf(t, p, -0.284496736f);
+      p = __builtin_fmaf(t, p, 0.254829592f);
+      const float erfc = p * t * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+      const float g = 0.5f * x * erfc;
+      y = x > 0.0f ? x - g : g;  // (x = -0: g = -0, as torch)
+      if (!(x < INFINITY)) y = x;  // NaN, and +inf (inf - inf 0 otherwise); -inf keeps g = -inf 0 = NaN, as torch's 0.5 x (1 + erf)
+    } else {
+      y = 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+    }
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
+#pragma unroll
+    for (int k = 0; k < N; k++) apply_one(x[k], y[k], e0 + k);
+  }
+};
+
+template <int DT>
+__device__ __forceinline__ float round_dt(float v) {  // RNE to DT and back (exact for fp32)
+  if (DT == DMXQ_BF16) return (float)(__bf16)v;
+  if (DT == DMXQ_F16) return (float)(_Float16)opaque(v);
+  return v;
+}
+
+// FAST: 16-bit outputs -- v_exp_f32 + v_rcp_f32 (relative error ~2^-21, far inside the 2^-9 / 2^-12 half-ulp of the
+// output format); fp32 outputs keep expf and the IEEE division.
+template <bool FAST>
+__device__ __forceinline__ float sigmoid_mul(float x, float t) {  // x * sigmoid(t)
+  if (FAST) {
+    const float d = 1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f);
+    // v_rcp_f32 flushes a denormal RESULT to zero (1 / d for d > 2^126): the far negative tail, where the true value
+    // x / d is still a normal number (silu(-88) = -5.3e-37), takes the IEEE division instead (rare: t < -87)
+    return d > 8.5e37f ? x / d : x * __builtin_amdgcn_rcpf(d);
+  }
+  return x / (1.0f + expf(-t));
+}
+
+template <int KIND, int DTI, bool FAST>
+struct UnaryOp {
+  static constexpr bool kHeavy = true;
+  static constexpr int kTileUnroll = KIND == DMXQ_UNARY_SILU ? 8 : (KIND == DMXQ_UNARY_QUICK_GELU ? 2 : 4);  // stream.hpp
+  float param;
+  __device__ __forceinline__ void apply_one(float x, float& y, int64_t) const {
+    if (KIND == DMXQ_UNARY_SILU) {
+      y = sigmoid_mul<FAST>(x, x);
+    } else if (KIND == DMXQ_UNARY_EXP) {
+      if (FAST) {
+        // v_exp_f32 flushes denormal RESULTS: below 2^-126 the argument is raised by 64 and the result scaled back (exact)
+        const float t = x * 1.4426950408889634f;
+        const bool tiny = t < -126.0f;
+        y = __builtin_amdgcn_exp2f(tiny ? t + 64.0f : t) * (tiny ? 5.421010862427522e-20f : 1.0f);
+      } else {
+        y = expf(x);
+      }
+    } else if (KIND == DMXQ_UNARY_QUICK_GELU) {
+      const float t = round_dt<DTI>(1.702f * x);
+      float s;
+      if (FAST && DTI != DMXQ_F32) {
+        const float d = 1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f);
+        s = d > 8.5e37f ? 1.0f / d : __builtin_amdgcn_rcpf(d);  // (v_rcp_f32 flushes denormal results: see sigmoid_mul)
+      } else {
+        s = 1.0f / (1.0f + expf(-t));
+      }
+      s = round_dt<DTI>(s);
+      y = x * s;
+    } else {  // DMXQ_UNARY_SILU_EXPERIMENTAL: relu(half(x)) * scale, the product rounded to half by the store
+      const float h = round_dt<DMXQ_F16>(x);
+      const float r = h < 0.0f ? 0.0f : h;  // at::relu == clamp_min(0): NaN stays NaN, -0.0 stays -0.0 (max(-0, +0) keeps the first)
+      y = r * param;
+    }
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
+#pragma unroll
+    for (int k = 0; k < N; k++) apply_one(x[k], y[k], e0 + k);
+  }
+};
+
+}  // namespace dmxq

@@ -350,6 +350,60 @@ class DmxModule(torch.nn.Module):
         take the general path.  Results must be bit-identical to the general path."""
         return None
 
+    #: run an activation / normalisation module (input cast -> function -> output cast) as ONE launch (dmxq_unary_cast,
+    #: dmxq_softmax_cast, dmxq_layernorm_cast, dmxq_rmsnorm_cast) when the configuration allows; see `_act_casts`
+    fuse_activation = True
+
+    def _act_casts(self, x, func_id):
+        """(input format, output format, approximator wrapper params) when this module's forward may run as ONE launch of this
+        library's kernel for `func_id`, else None: inference only, one float tensor on the GPU, no SmoothQuant, one input and one
+        output cast that are SAME or nearest-rounding FloatingPoint formats, and an approximator that is NONE or
+        `func_id[dmxq]` (the exact function on these kernels -- then the input clamp of the Softmax wrapper applies)."""
+        if (not self.fuse_activation or not isinstance(x, torch.Tensor) or x.dtype not in (torch.bfloat16, torch.float16, torch.float32)
+                or not x.is_cuda or x.numel() == 0 or self.smoothquant is not None and self.smoothquant._flag("enabled")
+                or torch.is_grad_enabled() and x.requires_grad or torch.compiler.is_compiling()):
+            return None
+        fn, wp = self.approximator.function, {}
+        if not isinstance(fn, NoApproximation):
+            if getattr(fn, "algorithm", None) != "dmxq" or fn.func_id != func_id or fn.extra_params:
+                return None
+            wp = fn.wrapper_params
+        ics, ocs = list(self.input_casts.values()), list(self.output_casts.values())
+        if len(ics) != 1 or len(ocs) != 1:
+            return None
+        (ok_i, fi), (ok_o, fo) = _range_only_format(ics[0], x.dtype), _range_only_format(ocs[0], x.dtype)
+        return (fi, fo, wp) if ok_i and ok_o else None
+
+    def _plain_param(self, name, dtype):
+        """the parameter `name` when the module hands it to the function UNCHANGED (every stage of its hypernet a no-op) and it is
+        of dtype `dtype`; False when a cast / sparsifier / SmoothQuant applies (the fused norm kernels take raw parameters)"""
+        p = getattr(self, name, None)
+        if p is None:
+            return None
+        if p.dtype != dtype or not p.is_cuda or torch.is_grad_enabled() and p.requires_grad:  # (autograd needs torch's own function)
+            return False
+        casts = [self.bias_cast] if name == "bias" else [self.weight_cast, self.weight_storage_cast]
+        for c in casts:
+            if c is not None and not (isinstance(c.format, Same) and not c.pre_transform):
+                return False
+        if name == "weight":
+            if self.weight_sparsifier is not None and not isinstance(self.weight_sparsifier.sparseness, Dense):
+                return False
+            if self.smoothquant is not None and not self.smoothquant._flag("fused_to_weight") and self.smoothquant._flag("enabled"):
+                return False
+        return p.detach()
+
+    def _fused_unary(self, x, func_id, func, args, kwargs):
+        """input cast -> per-element function -> output cast as ONE launch (dmxq_unary_cast), or None"""
+        c = None if (args or kwargs) else self._act_casts(x, func_id)
+        if c is None or c[2]:
+            return None
+        from . import ops
+        out = ops.unary_cast(x.detach(), func, c[0], c[1])
+        if out is not None:
+            self.approximation_error = None
+        return out
+
     def forward(self, input, *args, **kwargs):
         whole = self._fused_forward(input, *args, **kwargs)
         if whole is not None:
@@ -385,6 +439,15 @@ class DmxModule(torch.nn.Module):
         return self.approximator(*inputs, *approx_args, **approx_kwargs)
 
     def approx_forward(self, inputs, *args, **kwargs):
+        fn = self.approximator.function
+        if (getattr(fn, "algorithm", None) == "dmxq" and not torch.compiler.is_compiling()
+                and not (torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (*inputs, *args)))):
+            # `[dmxq]` IS the exact function, evaluated by this library's kernels: in inference there is nothing to overwrite, so
+            # torch's own evaluation (whose only other use is the autograd graph) is skipped; `approximation_error` would be the
+            # rounding difference between two evaluations of the same function and is not formed
+            self.approximation_error = None
+            with torch.no_grad():
+                return self.approximator_wrapper(inputs, args, kwargs, **fn.wrapper_params)
         _output = self.functional_forward(*inputs, *args, **kwargs)
         if not isinstance(self.approximator.function, NoApproximation):
             with torch.no_grad():
@@ -547,6 +610,17 @@ class Softmax(DmxModule, torch.nn.Softmax):
     def _forward(self, _input):
         return self.approx_forward((_input,), dim=self.dim)
 
+    def _fused_forward(self, x, *args, **kwargs):
+        """input cast -> softmax over the last dim -> output cast as ONE launch (dmxq_softmax_cast)"""
+        c = None if (args or kwargs) else self._act_casts(x, "SOFTMAX")
+        if c is None or self.dim is None or x.dim() == 0 or self.dim % x.dim() != x.dim() - 1:
+            return None
+        from . import ops
+        out = ops.softmax_cast(x.detach(), -1, c[0], c[1], c[2].get("input_clamp"))
+        if out is not None:
+            self.approximation_error = None
+        return out
+
 
 class LayerNorm(DmxModule, torch.nn.LayerNorm):
     def __init__(self, normalized_shape, eps: float = 1e-5, elementwise_affine: bool = True):
@@ -557,6 +631,20 @@ class LayerNorm(DmxModule, torch.nn.LayerNorm):
     def _forward(self, _input):
         return self.approx_forward((_input,), self.normalized_shape, self._weight_ro, self._bias_ro, self.eps)
 
+    def _fused_forward(self, x, *args, **kwargs):
+        """input cast -> layer_norm -> output cast as ONE launch (dmxq_layernorm_cast); weight and bias as they are (SAME casts)"""
+        c = None if (args or kwargs) else self._act_casts(x, "LAYER_NORM")
+        if c is None or c[2]:
+            return None
+        w, b = self._plain_param("weight", x.dtype), self._plain_param("bias", x.dtype)
+        if w is False or b is False:
+            return None
+        from . import ops
+        out = ops.layernorm_cast(x.detach(), self.normalized_shape, w, b, self.eps, c[0], c[1])
+        if out is not None:
+            self.approximation_error = None
+        return out
+
 
 class GELU(DmxModule, torch.nn.GELU):
     def __init__(self, approximate: str = "none"):
@@ -566,6 +654,9 @@ class GELU(DmxModule, torch.nn.GELU):
 
     def _forward(self, _input):
         return self.approx_forward((_input,), approximate=self.approximate)
+
+    def _fused_forward(self, x, *args, **kwargs):
+        return self._fused_unary(x, "GELU", "gelu_tanh" if self.approximate == "tanh" else "gelu", args, kwargs)
 
 
 class SiLU(DmxModule, torch.nn.SiLU):
@@ -579,6 +670,9 @@ class SiLU(DmxModule, torch.nn.SiLU):
     def _forward(self, _input):
         return self.approx_forward((_input,))
 
+    def _fused_forward(self, x, *args, **kwargs):
+        return self._fused_unary(x, "SILU", "silu", args, kwargs)
+
 
 class QuickGELU(DmxModule):
     """custom_modules.py:112-117: transformers' QuickGELUActivation, `x * sigmoid(1.702 * x)` in the input dtype"""
@@ -591,6 +685,9 @@ class QuickGELU(DmxModule):
     def _forward(self, _input):
         return self.approx_forward((_input,))
 
+    def _fused_forward(self, x, *args, **kwargs):
+        return self._fused_unary(x, "QUICK_GELU", "quick_gelu", args, kwargs)
+
 
 class Exp(DmxModule):
     """torch_modules.py:236-242 (no approximator slot in the reference: plain torch.exp between the casts)"""
@@ -601,6 +698,9 @@ class Exp(DmxModule):
 
     def _forward(self, _input):
         return torch.exp(_input)
+
+    def _fused_forward(self, x, *args, **kwargs):
+        return self._fused_unary(x, "EXP", "exp", args, kwargs)
 
 
 class Mul(_BinaryElementwise):
@@ -678,6 +778,20 @@ class RMSNorm(DmxModule, torch.nn.RMSNorm):
 
     def _forward(self, _input):
         return self.approx_forward((_input,), self.normalized_shape, self._weight_ro, self.eps)
+
+    def _fused_forward(self, x, *args, **kwargs):
+        """input cast -> rms_norm -> output cast as ONE launch (dmxq_rmsnorm_cast); the weight as it is (SAME cast)"""
+        c = None if (args or kwargs) else self._act_casts(x, "RMS_NORM")
+        if c is None or c[2]:
+            return None
+        w = self._plain_param("weight", x.dtype)
+        if w is False:
+            return None
+        from . import ops
+        out = ops.rmsnorm_cast(x.detach(), self.normalized_shape, w, self.eps, c[0], c[1])
+        if out is not None:
+            self.approximation_error = None
+        return out
 
 
 class ReLU(DmxModule, torch.nn.ReLU):

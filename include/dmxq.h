@@ -266,6 +266,29 @@ int dmxq_softmax(const void* in, void* out, int dtype_in, int dtype_out, int64_t
 int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
                    const void* weight, const void* bias, int dtype_wb, float eps, void* stream);
 
+/* An activation-function or normalisation DmxModule in ONE pass: out = cast_out(f(cast_in(x))), x and out of one dtype.
+ * Replaces the three launches of modeling/nn/core.py:228-264 for the modules whose `_forward` is one of these functions
+ * (torch_modules.py GELU / SiLU :1559-1576 / Exp :236-242, custom_modules.py:112-117 QuickGELU, Softmax :989-998, LayerNorm
+ * :1062-1082, RMSNorm :1144-1170; both casts are FLOAT16 in BASIC mode, src/dmx/compressor/__init__.py:360-455): input CastTo,
+ * the exact torch function (functional/approximate.py:300-304 with vsimd absent), output CastTo -- 4 B/element for a 16-bit
+ * tensor instead of 12.  The casts are the bit-exact casts of dmxq_float_qdq with CastTo's `.to(dtype)` after each (formats as
+ * in dmxq_binary_cast: NULL or exp_bits == 0 = SAME); f is evaluated in fp32 on the cast input and rounded once to the tensor
+ * dtype, as torch evaluates it (QUICK_GELU: in the tensor dtype).  The function is floating point: out == cast_out(v) for a v
+ * within 1 ulp of the tensor dtype (16-bit tensors) of the correctly rounded f(cast_in(x)); float32 tensors: within the ulps of
+ * the unfused functions before the output cast.
+ * DMXQ_ERR_UNSUPPORTED (the caller runs the three launches): 16-bit tensors with a cast that is not range-only for the dtype
+ * (bf16: man_bits >= 7, fp16: man_bits >= 10, subnormals flushed); unaligned pointers; n not a whole number of 16-byte
+ * vectors; rows that do not take the register-resident row kernels (longer than 1024 lane-vectors, or -- norms -- not a
+ * multiple of 4 elements); weight / bias are in the row dtype.  kind: DMXQ_UNARY_GELU .. DMXQ_UNARY_EXP. */
+int dmxq_unary_cast(const void* in, void* out, int dtype, int64_t n, int kind, float param, const dmxq_float_fmt* cast_in,
+                    const dmxq_float_fmt* cast_out, void* stream);
+int dmxq_softmax_cast(const void* in, void* out, int dtype, int64_t rows, int64_t cols, float input_clamp_min,
+                      const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* stream);
+int dmxq_layernorm_cast(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, const void* bias,
+                        float eps, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* stream);
+int dmxq_rmsnorm_cast(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, float eps,
+                      const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* stream);
+
 /* APPLY_LLAMA_ROPE: x_embed = (x * cos) + (rotate_half(x) * sin), evaluated in the tensor dtype like torch does (every
  * product and the sum rounded to the dtype: bit-identical to torch's CPU result).  Replaces: modeling/nn/custom_modules.py:
  * 142-172 ApplyRotaryPosEmbBase.forward for ONE of q / k (call it twice).  x, out: [B, n1, n2, D] contiguous, out != x;

@@ -291,6 +291,35 @@ int oracle_sbfp_qdq(const float* in, float* out, int64_t rows, int64_t L, int64_
   return 0;
 }
 
+/* floor(log2f(m)) as the reference gets it from `torch.floor(torch.log2(chunk_max))` (numerical/format.py:551-553) for a
+ * normal finite fp32 m, WITHOUT calling a libm.  log2(m) is irrational unless m is a power of two, and a float32 log2 within
+ * an ulp of the truth (Sleef in torch, glibc here, ocml on the device) can only be pushed across an INTEGER when m lies just
+ * below a power of two: m = 2^v (1 - j 2^-24).  Then log2 m = v - j 2^-24 / ln 2 (1 + ...), and its float32 rounding is v
+ * itself -- so the floor comes out one too high -- exactly when that distance is under half the gap between v and the float32
+ * below it:  gap = ulp(|v|), halved when v is a positive power of two.  With g = -log2(gap / 2) that is j <= jmax[g] =
+ * floor(2^24 (1 - 2^(-2^-g))).  oracle/gen_golden_r3.py checks this rule against torch.log2 itself for EVERY exponent and every
+ * j <= 256 (and 2 M random maxima) and records reference MXFP casts of such blocks (tests/golden/boundaries.npz). */
+int oracle_floor_log2f(float m) {
+  const uint32_t b = f2u(m) & 0x7FFFFFFFu;
+  const int eb = (int)(b >> 23);
+  if (eb < 1 || eb > 254) return (int)floorf(log2f(m)); /* zero / denormal / Inf / NaN: not the rule's domain */
+  const uint32_t man = b & 0x007FFFFFu;
+  int fl = eb - 127;
+  if (man != 0u) {
+    const int v = fl + 1;
+    const uint32_t j = 0x00800000u - man; /* m = 2^v (1 - j 2^-24) */
+    if (v != 0) {
+      const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+      int c = 0;
+      while ((a >> (c + 1)) != 0u) c++; /* floor(log2 |v|) */
+      const int g = (v > 0 && (a & (a - 1u)) == 0u) ? 25 - c : 24 - c; /* 17 .. 25 */
+      static const uint32_t jmax[9] = {88u, 44u, 22u, 11u, 5u, 2u, 1u, 0u, 0u}; /* g = 17 .. 25 */
+      if (j <= jmax[g - 17]) fl += 1;
+    }
+  }
+  return fl;
+}
+
 /* numerical/format.py:545-564 MXFP.cast (intended layout: blocks along the last dim; the reference's
  * cat(dim=block_dim) slip is not reproduced).  Per block: scale = 2^floor(log2(max|x|)) / 2^(2^(e-1));
  * y = float_quantize(x / scale, man, exp, bias = 2^(e-1)-1, no flush) * scale.
@@ -308,7 +337,7 @@ int oracle_mxfp_qdq(const float* in, float* out, int64_t rows, int64_t L, int64_
       float m = 0.0f;
       for (int64_t i = 0; i < len; i++) { float a = fabsf(x[i]); if (a > m || isnan(a)) m = a; }
       if (m == 0.0f) { for (int64_t i = 0; i < len; i++) y[i] = x[i] * 0.0f; continue; }
-      const float scale = powf(2.0f, floorf(log2f(m))) / big;
+      const float scale = powf(2.0f, (float)oracle_floor_log2f(m)) / big;
       for (int64_t i = 0; i < len; i++) y[i] = float_q1(x[i] / scale, man, exp_bits, bias, 0, R_NEAREST, 0u) * scale;
     }
   return 0;

@@ -102,3 +102,35 @@ def err_in_ulps(got: torch.Tensor, truth64: torch.Tensor, dtype, floor=None) -> 
     ulp = torch.exp2(torch.floor(torch.log2(mag))) * _EPS[dtype]
     e = ((g - t).abs() / ulp)[ok]
     return float(e.max()) if e.numel() else 0.0
+
+
+def ulp_of(t64: torch.Tensor, dtype, floor=None) -> torch.Tensor:
+    """unit in the last place of `dtype` at |t64| (never below the smallest normal's; 0 where t64 is not finite)"""
+    mag = t64.abs()
+    if floor is not None:
+        mag = torch.maximum(mag, floor.detach().cpu().double().abs())
+    fin = torch.isfinite(mag)
+    mag = torch.where(fin, mag, torch.ones_like(mag)).clamp_min(_TINY[dtype])
+    return torch.where(fin, torch.exp2(torch.floor(torch.log2(mag))) * _EPS[dtype], torch.zeros_like(mag))
+
+
+def outside_cast_bracket(got: torch.Tensor, truth64: torch.Tensor, cast_out, dtype, n_ulp: float = 1.0, floor=None) -> int:
+    """Number of elements that violate the contract of the fused cast modules (include/dmxq.h dmxq_unary_cast ...):
+        got == cast_out(v)  for some v within n_ulp ulps (of the tensor dtype) of the float64 truth.
+    cast_out (a dtype -> same-dtype CPU function: the ORACLE's bit-exact cast followed by `.to(dtype)`) is monotone, so this is
+    checked as  cast_out(truth - n ulp) <= got <= cast_out(truth + n ulp)  -- exact at saturation and flush thresholds, where
+    a last-place difference before the cast legitimately decides between two far-apart results.  NaN truth: got must be what
+    cast_out makes of a NaN (NaN, or +-max for formats without NaN codes), compared by magnitude."""
+    g = got.detach().cpu().double()
+    t = truth64.detach().cpu().double()
+    u = ulp_of(t, dtype, floor) * n_ulp
+    nan = torch.isnan(t)
+    tz = torch.where(nan, torch.zeros_like(t), t)
+    lo = cast_out((tz - u).to(dtype)).double()
+    hi = cast_out((tz + u).to(dtype)).double()
+    bad = ~((g >= lo) & (g <= hi)) & ~nan
+    if bool(nan.any()):
+        want = cast_out(t.to(dtype)).double()
+        both_nan = torch.isnan(want) & torch.isnan(g)
+        bad = bad | (nan & ~both_nan & ~(g.abs() == want.abs()))
+    return int(bad.sum())

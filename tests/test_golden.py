@@ -217,6 +217,66 @@ def test_composite_block_format_fixtures(backend, dmx, oracle):
 
 
 @pytest.mark.parametrize("backend", backends(), indirect=True)
+def test_boundaries_mxfp_maxima_just_below_powers_of_two(backend, dmx, oracle):
+    """MXFP.cast (format.py:545-564) scales a block by 2^floor(log2 max) with a FLOAT32 log2 (:551-553), which rounds to the
+    integer v for a maximum 2^v (1 - j 2^-24) with small j -- the scale is then twice the "exact" one.  1534 such blocks
+    (59 exponents x 26 distances j = 1 .. 96; an exact floor would get 448 of them wrong) cast by the reference itself
+    (oracle/gen_golden_r3.py, which also checks the closed rule of oracle_floor_log2f against torch.log2 for every float32
+    exponent): oracle and kernel must reproduce every bit."""
+    g = load("boundaries.npz")
+    x = tensor(g["mx_x"], torch.float32)
+    hip = isinstance(backend, HipBackend)
+    for i, sh in enumerate([str(s) for s in g["mx_sh"]]):
+        f = dmx.Format.from_shorthand(sh)
+        if hip:
+            y = dmx.CastTo(format=f)(x.to(backend.dev))
+        else:
+            y = oracle.mxfp_cast(x, f.element_format.mantissa, f.element_format.exponent, f.block_size)
+        assert mism(y, g[f"mx_y{i}"], torch.float32) == 0, sh
+    if hip:  # the same blocks inside longer rows (several blocks per lane group), and as bf16 (the exponent-field path: never rounds up)
+        xl = x.reshape(-1, 8 * 26)
+        f = dmx.Format.from_shorthand("MXFP8[E4M3]{8}")
+        assert mism(dmx.CastTo(format=f)(xl.to(backend.dev)).reshape(x.shape), g["mx_y0"], torch.float32) == 0
+        xb = x.to(torch.bfloat16)
+        want = oracle.mxfp_cast(xb, 3, 4, 8).to(torch.bfloat16)
+        got = dmx.CastTo(format=f)(xb.to(backend.dev)).cpu()
+        assert int(((got.view(torch.int16) != want.view(torch.int16)) & ~(torch.isnan(got.float()) & torch.isnan(want.float()))).sum()) == 0
+
+
+@pytest.mark.parametrize("backend", backends(), indirect=True)
+def test_boundaries_asymmetric_bfp_with_planted_nonfinite_and_denormal_blocks(backend, dmx):
+    """`BFP[p|8]{16}(_N)` (format.py:304-372) on tensors with planted Inf / NaN / denormal-maximum blocks, against the reference's
+    own output.  The reference's post-pass rebuilds a whole [rows, 16] chunk from integers iff ANY row of the
+    chunk holds an edge code (format.py:362-370): a block whose maximum is Inf / NaN then becomes `ldexp(int(NaN), ..)` garbage
+    instead of NaN, and a -0.0 result (which only a block with a DENORMAL maximum can produce) becomes +0.0.  Blocks are independent
+    here.  Asserted: (1) bit-equality with the reference on every element outside those two sets -- in particular
+    on every finite block, edge codes and all-zero blocks included; (2) inside a poisoned block this library returns exactly what
+    its SYMMETRIC format returns for that block; (3) in denormal-maximum blocks only the sign of zeros may differ; (4) the
+    differing set is exactly as large as recorded when the fixture was made (64 = 4 blocks x 16; 15 zero signs, float32 only)."""
+    g = load("boundaries.npz")
+    for nm, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        x = tensor(g[f"asym_x_{nm}"], dt)
+        xf = x.float().reshape(48, 4, 16)
+        poisoned = ~torch.isfinite(xf).all(-1, keepdim=True).expand_as(xf).reshape(48, 64)
+        den = (xf.abs().amax(-1, keepdim=True) < 2.0 ** -126).expand_as(xf).reshape(48, 64)
+        assert int(poisoned.sum()) == 64
+        for i, sh in enumerate([str(s) for s in g["asym_sh"]]):
+            f = dmx.Format.from_shorthand(sh)
+            got = backend.bfp(x, f.precision, f.block_size, -1, False, dt).cpu()
+            sym = backend.bfp(x, f.precision, f.block_size, -1, True, dt).cpu()
+            want = tensor(g[f"asym_y{i}_{nm}"], dt)
+            it = T_BITS[dt]
+            nan2 = torch.isnan(got.float()) & torch.isnan(want.float())
+            diff = (got.view(it) != want.view(it)) & ~nan2
+            zero_sign = den & (got.float() == 0) & (want.float() == 0)
+            assert int((diff & ~poisoned & ~zero_sign).sum()) == 0, (sh, nm)                       # (1)
+            same_as_sym = (got.view(it) == sym.view(it)) | (torch.isnan(got.float()) & torch.isnan(sym.float()))
+            assert bool(same_as_sym[poisoned].all()), (sh, nm)                                      # (2)
+            assert bool(((got.float() == want.float()) | nan2 | poisoned)[den].all()), (sh, nm)     # (3)
+            assert int((diff & poisoned).sum()) == 64 and int((diff & zero_sign).sum()) == (15 if dt == torch.float32 else 0), (sh, nm)  # (4)
+
+
+@pytest.mark.parametrize("backend", backends(), indirect=True)
 def test_nm_mask_fixtures(backend):
     g = load("nm_mask.npz")
     n = 0

@@ -207,6 +207,39 @@ def main():
     w = torch.ones(cols2, device=dev, dtype=torch.bfloat16)
     run("layernorm bf16 rows of 768",
         lambda i: L.dmxq_layernorm(vp(xl[i].data_ptr()), vp(yl[i].data_ptr()), _lib.BF16, _lib.BF16, rows2, cols2, vp(w.data_ptr()), vp(w.data_ptr()), _lib.BF16, ctypes.c_float(1e-5), sp), 14, rows2 * cols2 * 4)
+    # ---------------------------------------------------------------- activation / normalisation MODULES in one launch (row a9)
+    # cast_in -> f -> cast_out with the BASIC rules' FLOAT16 casts; next to each, the three launches it replaces (this library's two
+    # casts around torch's own GPU function), both at the fused kernel's algorithmic bytes (in + out)
+    F = torch.nn.functional
+    fq = lambda a, o, dt, m: L.dmxq_float_qdq(vp(a.data_ptr()), vp(o.data_ptr()), dt, dt, m, 10, 5, 15, 1, 0, 2, 0, sp)
+    for kind, nm, tf in ((0, "gelu", lambda a, o: torch.nn.functional.gelu(a)), (2, "silu", lambda a, o: torch.nn.functional.silu(a))):
+        run(f"unary_cast {nm} module: FLOAT16 -> {nm} -> FLOAT16, bf16 (one launch, 4 B/elem)",
+            lambda i: L.dmxq_unary_cast(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, n, kind, ctypes.c_float(0.0), pf, pf, sp), k, n * 4)
+        run(f"  the three launches it replaces (float_qdq, torch {nm}, float_qdq)",
+            lambda i: (fq(xs[i], ys[i], _lib.BF16, n), ys[(i + 1) % k].copy_(tf(ys[i], None)), fq(ys[(i + 1) % k], ys[i], _lib.BF16, n)), k, n * 4)
+    run("unary_cast gelu module on float32 tensors (general form, 8 B/elem)",
+        lambda i: L.dmxq_unary_cast(vp(f32a[i % 6].data_ptr()), vp(f32o[i % 6].data_ptr()), _lib.F32, n, 0, ctypes.c_float(0.0), pf, pf, sp), 6, n * 8)
+    run("  the three launches it replaces (float_qdq fp32, torch gelu, float_qdq fp32)",
+        lambda i: (fq(f32a[i % 6], f32o[i % 6], _lib.F32, n), f32o[(i + 1) % 6].copy_(F.gelu(f32o[i % 6])), fq(f32o[(i + 1) % 6], f32o[i % 6], _lib.F32, n)), 6, n * 8)
+    run("softmax_cast module bf16 rows of 1500: FLOAT16 -> softmax -> FLOAT16 (one launch)",
+        lambda i: L.dmxq_softmax_cast(vp(xr[i].data_ptr()), vp(yr[i].data_ptr()), _lib.BF16, rows, cols, ctypes.c_float(-math.inf), pf, pf, sp), 10, rows * cols * 4)
+    run("  the three launches it replaces (float_qdq, torch softmax, float_qdq)",
+        lambda i: (fq(xr[i], yr[i], _lib.BF16, rows * cols), yr[(i + 1) % 10].copy_(torch.softmax(yr[i], -1)), fq(yr[(i + 1) % 10], yr[i], _lib.BF16, rows * cols)), 10, rows * cols * 4)
+    xr32 = [torch.randn(rows, cols, device=dev) for _ in range(5)]
+    yr32 = [torch.empty_like(t) for t in xr32]
+    run("softmax_cast module float32 rows of 1500 (Whisper attention, general form, 8 B/elem)",
+        lambda i: L.dmxq_softmax_cast(vp(xr32[i].data_ptr()), vp(yr32[i].data_ptr()), _lib.F32, rows, cols, ctypes.c_float(-math.inf), pf, pf, sp), 5, rows * cols * 8)
+    run("  the three launches it replaces (float_qdq fp32, torch softmax, float_qdq fp32)",
+        lambda i: (fq(xr32[i], yr32[i], _lib.F32, rows * cols), yr32[(i + 1) % 5].copy_(torch.softmax(yr32[i], -1)), fq(yr32[(i + 1) % 5], yr32[i], _lib.F32, rows * cols)), 5, rows * cols * 8)
+    del xr32, yr32
+    run("layernorm_cast module bf16 rows of 768 (one launch)",
+        lambda i: L.dmxq_layernorm_cast(vp(xl[i].data_ptr()), vp(yl[i].data_ptr()), _lib.BF16, rows2, cols2, vp(w.data_ptr()), vp(w.data_ptr()), ctypes.c_float(1e-5), pf, pf, sp), 14, rows2 * cols2 * 4)
+    run("  the three launches it replaces (float_qdq, torch layer_norm, float_qdq)",
+        lambda i: (fq(xl[i], yl[i], _lib.BF16, rows2 * cols2), yl[(i + 1) % 14].copy_(F.layer_norm(yl[i], (cols2,), w, w, 1e-5)), fq(yl[(i + 1) % 14], yl[i], _lib.BF16, rows2 * cols2)), 14, rows2 * cols2 * 4)
+    run("rmsnorm_cast module bf16 rows of 4096 (Llama hidden, one launch)",
+        lambda i: L.dmxq_rmsnorm_cast(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, R, C, vp(wr.data_ptr()), ctypes.c_float(1e-5), pf, pf, sp), k, n * 4)
+    run("  the three launches it replaces (float_qdq, torch rms_norm, float_qdq)",
+        lambda i: (fq(xs[i], ys[i], _lib.BF16, n), ys[(i + 1) % k].copy_(F.rms_norm(ys[i], (C,), wr, 1e-5)), fq(ys[(i + 1) % k], ys[i], _lib.BF16, n)), k, n * 4)
     if args.json:
         json.dump(results, open(args.json, "w"), indent=1)
 

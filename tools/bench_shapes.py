@@ -12,7 +12,7 @@ import torch  # noqa: E402
 
 from dmx_compressor_amd import _lib  # noqa: E402
 
-SHAPES = [(4096, 4096), (14336, 4096), (4096, 14336), (1024, 4096), (128256, 4096), (16384, 4096), (2048, 14336), (768, 768),
+SHAPES = [(2048, 4096), (3072, 4096), (4096, 4096), (4100, 4096), (4608, 4096), (5000, 4096), (6144, 4096), (8192, 4096), (10240, 4096), (14336, 4096), (4096, 14336), (1024, 4096), (128256, 4096), (16384, 4096), (2048, 14336), (768, 768),
           (3072, 768), (768, 3072), (50272, 768), (12 * 1500, 1500), (1500, 768), (64, 4096), (120, 400)]
 
 

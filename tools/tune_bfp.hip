@@ -64,9 +64,17 @@ int main(int argc, char** argv) {
     int g = (GRID) > 0 ? (GRID) : (int)((n_vec + (int64_t)T * U - 1) / ((int64_t)T * U)); \
     hipLaunchKernelGGL((copy_kernel<U, M, T>), dim3(g), dim3(T), 0, q, i, o, n_vec); }, {}})
   // G0 = exact grid.  M bits: 1 nt-load, 2 nt-store, 4 sc1-store, 8 sc0-store (copy: 4 = workgroup-contiguous tiles; bfp is always tiled)
+  if (getenv("TUNE_SET") && std::string(getenv("TUNE_SET")) == "sweep") {
+    // tile-plan continuity (round 3): the one-round shapes against the multi-round 512x2 just above the 32 MiB headline size
+    ADD_COPY(2, 7, 512, 0); ADD_COPY(16, 7, 512, 0);
+    ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPG(4, 3, 512, 0, 2, 4); ADD_BFPG(8, 3, 512, 0, 2, 8); ADD_BFPG(16, 3, 512, 0, 2, 16);
+    ADD_BFPG(2, 3, 256, 0, 2, 2); ADD_BFPG(4, 3, 256, 0, 2, 4); ADD_BFPG(8, 3, 256, 0, 2, 8);
+    ADD_BFPG(16, 3, 512, 256, 2, 16); ADD_BFPG(8, 3, 512, 512, 2, 8); ADD_BFPG(8, 3, 512, 256, 2, 8);  // persistent: 1 or 2 workgroups per CU looping over tiles
+  } else {
   ADD_COPY(16, 7, 512, 0);
   ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPL(16, 3, 512, 0, 2, 16, 2); ADD_BFPG(16, 3, 256, 0, 2, 16); ADD_BFPL(16, 3, 256, 0, 2, 16, 2);
   ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPL(2, 3, 512, 0, 2, 2, 2); ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPL(16, 3, 512, 0, 2, 16, 2);
+  }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto& v : vs) for (int i = 0; i < 10; i++) v.run(in[i % NBUF], out[i % NBUF], st);
   CK(hipStreamSynchronize(st));
