@@ -3,6 +3,7 @@
 group 16"), on a 4096x4096 bf16 tensor, and % of the MI355X HBM roofline.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|llama-shard] [--replays R]
+  python bench.py --workload layer --model opt125m|llama|whisper    one configured model layer end to end (tools/bench_layer.py)
   python bench.py --gpus 2|4|8 ...   starts its own N ranks: with no WORLD_SIZE in the environment the parent (which never
                                      touches the GPU) runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
                                      --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>` as a CHILD process,
@@ -64,7 +65,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", choices=["c2", "replica", "llama-shard"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "replica", "llama-shard", "layer"], default="c2")
+    ap.add_argument("--model", choices=["opt125m", "llama", "whisper"], default="llama",
+                    help="--workload layer: which configured layer (BASELINE.json configs 3 / 4 / 5), see tools/bench_layer.py")
+    ap.add_argument("--layer-modes", default="live,folded,unfused", help="--workload layer: which variants to time")
     ap.add_argument("--op", choices=["hypernet", "bfp"], default="hypernet", help="llama-shard only")
     ap.add_argument("--replays", type=int, default=15, help="timed replays of the K-step graph (median reported)")
     ap.add_argument("--nbuf", type=int, default=20, help="c2: distinct in/out buffer pairs (20 x 64 MiB = 1.25 GiB)")
@@ -297,6 +301,17 @@ def main():
             print(f"bench.py --gpus {args.gpus}: this box has {have} GPU(s)", file=sys.stderr)
             sys.exit(2)
         self_launch(args)
+    if args.workload == "layer":   # one configured model layer end to end (tools/bench_layer.py); single GPU, its own JSON line
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("bench_layer", os.path.join(ROOT, "tools", "bench_layer.py"))
+        bl = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bl)
+        if not torch.cuda.is_available():
+            print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
+            sys.exit(2)
+        steps = args.steps if args.steps != 2000 else 20
+        print(json.dumps(bl.run(args.model, steps, min(args.warmup, 10), modes=tuple(args.layer_modes.split(",")))), flush=True)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

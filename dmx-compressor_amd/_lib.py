@@ -30,6 +30,7 @@ SIGNATURES = {
     "dmxq_bfp_pack": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_bfp_unpack": [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp],
     "dmxq_weight_hypernet": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
+    "dmxq_weight_hypernet_strided": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_input_hypernet": [_vp, _i32, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_binary_cast": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
     "dmxq_relu_cast": [_vp, _vp, _i32, _i64, _vp, _vp, _vp],

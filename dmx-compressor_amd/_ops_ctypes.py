@@ -124,11 +124,12 @@ def bfp_unpack(mant, exps, precision: int, block_size: int, out_dtype: torch.dty
 
 
 def weight_hypernet(w, precision: int, block_size: int, symmetric: bool = True, score=None, K: int = 0, M: int = 0,
-                    sq_scale=None, out_dtype: Optional[torch.dtype] = None):
-    """Fused N:M mask -> SmoothQuant scale -> BFP Q->DQ over a weight blocked along its last dim (one launch).
+                    sq_scale=None, out_dtype: Optional[torch.dtype] = None, block_dim: int = -1):
+    """Fused N:M mask -> SmoothQuant scale -> BFP Q->DQ over a weight (one launch), everything along `block_dim`: the last dim
+    (Linear) or any other (conv weights along in-channels: dmxq_weight_hypernet_strided).
     Returns None when the geometry / dtype combination is not fusable (the caller runs the unfused chain)."""
     wc = _prep(w, "weight_hypernet")
-    L = wc.shape[-1] if wc.dim() else 1
+    outer, L, inner = split3(wc.shape, block_dim) if wc.dim() else (1, 1, 1)
     rows = wc.numel() // max(L, 1)
     sc = _prep(score, "weight_hypernet") if (score is not None and M) else None
     if sc is not None and sc.shape != wc.shape:
@@ -139,9 +140,14 @@ def weight_hypernet(w, precision: int, block_size: int, symmetric: bool = True, 
     sq = sq_scale.detach().to(device=wc.device, dtype=torch.float32).contiguous() if sq_scale is not None else None
     if sq is not None and sq.numel() != L:
         return None
-    rc = lib().dmxq_weight_hypernet(ptr(wc), dtype_code(wc.dtype), ptr(sc), dtype_code(sc.dtype) if sc is not None else 0,
-                                    K, M if sc is not None else 0, ptr(sq), ptr(out), dtype_code(od), rows, L, block_size,
-                                    precision, int(symmetric), stream_of(wc))
+    if inner != 1:
+        rc = lib().dmxq_weight_hypernet_strided(ptr(wc), dtype_code(wc.dtype), ptr(sc), dtype_code(sc.dtype) if sc is not None else 0,
+                                                K, M if sc is not None else 0, ptr(sq), ptr(out), dtype_code(od), outer, L, inner,
+                                                block_size, precision, int(symmetric), stream_of(wc))
+    else:
+        rc = lib().dmxq_weight_hypernet(ptr(wc), dtype_code(wc.dtype), ptr(sc), dtype_code(sc.dtype) if sc is not None else 0,
+                                        K, M if sc is not None else 0, ptr(sq), ptr(out), dtype_code(od), rows, L, block_size,
+                                        precision, int(symmetric), stream_of(wc))
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     check(rc, "dmxq_weight_hypernet")

@@ -135,13 +135,14 @@ def bfp_unpack(mant, exps, precision: int, block_size: int, out_dtype: torch.dty
 
 
 def weight_hypernet(w, precision: int, block_size: int, symmetric: bool = True, score=None, K: int = 0, M: int = 0,
-                    sq_scale=None, out_dtype: Optional[torch.dtype] = None):
-    """Fused N:M mask -> SmoothQuant scale -> BFP Q->DQ over a weight blocked along its last dim (one launch).
+                    sq_scale=None, out_dtype: Optional[torch.dtype] = None, block_dim: int = -1):
+    """Fused N:M mask -> SmoothQuant scale -> BFP Q->DQ over a weight (one launch), everything along `block_dim`: the last dim
+    (Linear) or any other (conv weights along in-channels: dmxq_weight_hypernet_strided).
     Returns None when the geometry / dtype combination is not fusable (the caller runs the unfused chain)."""
     require_gpu(w, "weight_hypernet")
     try:
         return _ops.weight_hypernet(w, precision, block_size, symmetric, score if M else None, K, M if score is not None else 0,
-                                    sq_scale, out_dtype)
+                                    sq_scale, out_dtype, block_dim)
     except NotImplementedError:
         return None
 

@@ -250,6 +250,85 @@ __global__ __launch_bounds__(kInThreads) void input_rows_kernel(InArgs a) {
 #undef DMXQ_IN
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The weight chain for layouts whose blocked dimension is NOT the contiguous one (dmxq_weight_hypernet_strided): w = [outer, L,
+// inner] with N:M groups, SmoothQuant channels and BFP blocks all along L -- Conv1d / Conv2d weights [out, in, k...] with block_dim = 1
+// (modeling/nn/torch_modules.py:582-585, 674-677).  These tensors are small (Whisper conv2 [768,768,3]: 7 MB of fp32; LeNet conv2:
+// 2400 elements) and the call is launch-bound, so the kernel is the plain statement of the chain: one lane per (outer, block, inner
+// position) walks its <= B rows twice -- the block maximum of the masked, scaled values, then the codes -- adjacent lanes on adjacent
+// inner positions.  Any block size and a ragged last block (torch.split), runtime dtypes, the dtype flow of the header comment.
+struct HsArgs {
+  const void* w; const void* score; const float* scale; void* out;
+  int64_t outer, L, inner, nblk;   // nblk = ceil(L / B)
+  int B, K, M, wl, dtw, dts, dto, t1;
+};
+__device__ __forceinline__ float round_rt(int dt, float v) {
+  if (dt == DMXQ_BF16) return round_to<DMXQ_BF16>(v);
+  if (dt == DMXQ_F16) return round_to<DMXQ_F16>(v);
+  return v;
+}
+// rows [j0, j0 + 8) of a lane's block after mask and scale, as T1 values (rows past `len` are 0: they cannot raise a maximum)
+__device__ __forceinline__ void hs_rows8(const HsArgs& a, int64_t base, int64_t c0, int j0, int len, float (&v)[8]) {
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const bool in = j0 + j < len;
+    v[j] = in ? load_rt(a.w, a.dtw, base + (int64_t)(j0 + j) * a.inner) : 0.0f;
+    s[j] = (in && a.M) ? load_rt(a.score, a.dts, base + (int64_t)(j0 + j) * a.inner) : 0.0f;
+  }
+  if (a.M) {  // ranks inside the groups of M rows (M in {2, 4, 8} divides 8 and the block size)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int g0 = j & ~(a.M - 1);
+      const int32_t kj = hn_sort_key(s[j]);
+      int rank = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int32_t ki = hn_sort_key(s[i]);
+        const bool same_group = i >= g0 && i < g0 + a.M && i != j;
+        rank += (same_group && (ki < kj || (ki == kj && i < j))) ? 1 : 0;
+      }
+      v[j] = v[j] * (rank >= a.M - a.K ? 1.0f : 0.0f);  // a real multiply: -w * 0 = -0 (sparse.py:300)
+    }
+  }
+  if (a.scale) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int64_t c = c0 + j0 + j < a.L ? c0 + j0 + j : a.L - 1;
+      v[j] = round_rt(a.t1, v[j] * a.scale[c]);   // scale_weight's `.to(wgt.dtype)`
+    }
+  }
+}
+template <bool ASYM>
+__global__ __launch_bounds__(kThreads) void hypernet_strided_kernel(const HsArgs a) {
+  const int64_t n = a.outer * a.nblk * a.inner;
+  for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < n; t += (int64_t)gridDim.x * kThreads) {
+    const int64_t q = t / a.inner, i = t - q * a.inner, o = q / a.nblk, b = q - o * a.nblk;
+    const int64_t c0 = b * a.B;
+    const int len = (int)(a.L - c0 < a.B ? a.L - c0 : a.B);
+    const int64_t base = (o * a.L + c0) * a.inner + i;
+    uint32_t mb = 0u;
+    for (int j0 = 0; j0 < len; j0 += 8) {
+      float v[8];
+      hs_rows8(a, base, c0, j0, len, v);
+#pragma unroll
+      for (int j = 0; j < 8; j++) mb = max(mb, f2u(v[j]) & 0x7FFFFFFFu);  // integer max of |x| patterns: NaN propagates like torch.max
+    }
+    const BfpBlockParams p = bfp_block_params<ASYM, false>(mb, a.wl);
+    for (int j0 = 0; j0 < len; j0 += 8) {
+      float v[8];
+      hs_rows8(a, base, c0, j0, len, v);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (j0 + j < len) {
+          const float y = round_rt(a.t1, bfp_q1<DMXQ_ROUND_NEAREST, ASYM>(v[j], p, a.wl, DMXQ_ROUND_NEAREST, 0u));  // CastTo's `.to(physical dtype)`
+          store_rt(a.out, a.dto, base + (int64_t)(j0 + j) * a.inner, y);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace dmxq
 
 using namespace dmxq;
@@ -341,5 +420,26 @@ extern "C" int dmxq_input_hypernet(const void* x, int dtype_x, const float* sq_s
 #define DMXQ_IH(W_) DMXQ_LAUNCH((hypernet_rows_kernel<W_, W_, DMXQ_F32, 0, true, true, true>), dim3(grid), dim3(kThreads), 0, s, a)
   if (dtype_x == DMXQ_BF16) DMXQ_IH(DMXQ_BF16); else if (dtype_x == DMXQ_F16) DMXQ_IH(DMXQ_F16); else DMXQ_IH(DMXQ_F32);
 #undef DMXQ_IH
+  return launch_status();
+}
+
+// The chain of dmxq_weight_hypernet for [outer, L, inner] layouts (conv weights blocked along in-channels): see hypernet_strided_kernel.
+extern "C" int dmxq_weight_hypernet_strided(const void* w, int dtype_w, const void* score, int dtype_score, int K, int M,
+                                            const float* sq_scale, void* out, int dtype_out, int64_t outer, int64_t L, int64_t inner,
+                                            int64_t block_size, int precision, int symmetric, void* stream) {
+  if (!valid_dtype(dtype_w) || !valid_dtype(dtype_out) || outer < 0 || L < 0 || inner < 1 || block_size < 1) return DMXQ_ERR_BAD_ARG;
+  if (M != 0 && (!score || !valid_dtype(dtype_score) || K < 1 || K > M)) return DMXQ_ERR_BAD_ARG;
+  const int64_t B = block_size;
+  if (!(M == 0 || M == 2 || M == 4 || M == 8) || B < 2 || B > (1 << 20) || (M && (B % M != 0 || L % M != 0)) || precision < 2 || precision > 22)
+    return DMXQ_ERR_UNSUPPORTED;
+  if (outer * L * inner == 0) return DMXQ_OK;
+  if (!w || !out) return DMXQ_ERR_BAD_ARG;
+  // T1: dtype after the mask multiply = torch's promotion of (w, score); the weight's own dtype without a mask
+  const int t1 = M == 0 ? dtype_w : ((dtype_w == DMXQ_F32 || dtype_score == DMXQ_F32 || dtype_w != dtype_score) ? DMXQ_F32 : dtype_w);
+  const int64_t nblk = (L + B - 1) / B;
+  const HsArgs a{w, M ? score : nullptr, sq_scale, out, outer, L, inner, nblk, (int)B, K, M, precision, dtype_w, M ? dtype_score : dtype_w, dtype_out, t1};
+  const int grid = grid_for(outer * nblk * inner);
+  if (symmetric) DMXQ_LAUNCH(hypernet_strided_kernel<false>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
+  else DMXQ_LAUNCH(hypernet_strided_kernel<true>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, a);
   return launch_status();
 }

@@ -171,7 +171,7 @@ at::ScalarType hypernet_dtype(const Tensor& w, const OptTensor& score, int64_t M
   return out_dtype.value_or(masked ? at::promote_types(w.scalar_type(), score->scalar_type()) : w.scalar_type());
 }
 Tensor weight_hypernet(const Tensor& w, int64_t precision, int64_t block_size, bool symmetric, const OptTensor& score, int64_t K,
-                       int64_t M, const OptTensor& sq_scale, OptDtype out_dtype) {
+                       int64_t M, const OptTensor& sq_scale, OptDtype out_dtype, int64_t block_dim) {
   const Tensor wc = prep(w, "weight_hypernet");
   const bool masked = score.has_value() && score->defined() && M != 0;
   Tensor sc, sq;
@@ -179,7 +179,8 @@ Tensor weight_hypernet(const Tensor& w, int64_t precision, int64_t block_size, b
     sc = prep(*score, "weight_hypernet");
     TORCH_CHECK_NOT_IMPLEMENTED(sc.sizes() == wc.sizes(), "weight_hypernet: score and weight shapes differ");
   }
-  const int64_t L = wc.dim() ? wc.size(-1) : 1;
+  const Split3 s3 = split3(wc, wc.dim() ? block_dim : -1);
+  const int64_t L = s3.L;
   const int64_t rows = L ? wc.numel() / L : 0;
   if (sq_scale.has_value() && sq_scale->defined()) {
     sq = sq_scale->detach().to(wc.device(), at::kFloat).contiguous();
@@ -187,6 +188,13 @@ Tensor weight_hypernet(const Tensor& w, int64_t precision, int64_t block_size, b
   }
   Tensor out = empty_like_shape(wc, hypernet_dtype(wc, score, M, out_dtype));
   Launch l(wc);
+  if (s3.inner != 1) {  // blocks / groups / channels along a non-contiguous dim (conv weights): the strided form
+    check(dmxq_weight_hypernet_strided(wc.data_ptr(), dt_code(wc.scalar_type()), masked ? sc.data_ptr() : nullptr,
+                                       masked ? dt_code(sc.scalar_type()) : 0, (int)K, masked ? (int)M : 0,
+                                       sq.defined() ? (const float*)sq.data_ptr() : nullptr, out.data_ptr(), dt_code(out.scalar_type()),
+                                       s3.outer, L, s3.inner, block_size, (int)precision, symmetric, l.stream), "dmxq_weight_hypernet_strided");
+    return out;
+  }
   check(dmxq_weight_hypernet(wc.data_ptr(), dt_code(wc.scalar_type()), masked ? sc.data_ptr() : nullptr,
                              masked ? dt_code(sc.scalar_type()) : 0, (int)K, masked ? (int)M : 0,
                              sq.defined() ? (const float*)sq.data_ptr() : nullptr, out.data_ptr(), dt_code(out.scalar_type()), rows, L,
@@ -194,7 +202,7 @@ Tensor weight_hypernet(const Tensor& w, int64_t precision, int64_t block_size, b
   return out;
 }
 Tensor weight_hypernet_meta(const Tensor& w, int64_t, int64_t, bool, const OptTensor& score, int64_t, int64_t M, const OptTensor&,
-                            OptDtype out_dtype) {
+                            OptDtype out_dtype, int64_t) {
   return empty_like_shape(w, hypernet_dtype(w, score, M, out_dtype));
 }
 
@@ -642,7 +650,7 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("bfp_qdq_multi(Tensor[] xs, int precision, int block_size, int block_dim=-1, bool symmetric=True, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor[]");
   m.def("bfp_pack(Tensor x, int precision, int block_size, bool symmetric=True) -> (Tensor, Tensor)");
   m.def("bfp_unpack(Tensor mant, Tensor exps, int precision, int block_size, ScalarType out_dtype) -> Tensor");
-  m.def("weight_hypernet(Tensor w, int precision, int block_size, bool symmetric, Tensor? score, int K, int M, Tensor? sq_scale, ScalarType? out_dtype=None) -> Tensor");
+  m.def("weight_hypernet(Tensor w, int precision, int block_size, bool symmetric, Tensor? score, int K, int M, Tensor? sq_scale, ScalarType? out_dtype=None, int block_dim=-1) -> Tensor");
   m.def("input_hypernet(Tensor x, Tensor sq_scale, int precision, int block_size, bool symmetric) -> Tensor");
   m.def("binary_cast(Tensor a, Tensor b, int op, int[] cast_a, int[] cast_b, int[] cast_out) -> Tensor");
   m.def("relu_cast(Tensor x, int[] cast_in, int[] cast_out) -> Tensor");

@@ -186,32 +186,41 @@ class DmxModule(torch.nn.Module):
 
     def _fused_weight(self, _w):
         """mask -> SmoothQuant scale -> BFP in ONE launch, or None when this configuration must take the chain:
-        inference only (no autograd through the fused op), everything along the last dim (Linear layout),
-        BlockTopK or Dense sparseness, SAME storage format, plain BFP weight format with nearest rounding."""
+        inference only (no autograd through the fused op), mask groups, SmoothQuant channels and BFP blocks all along ONE dim -- the
+        last (Linear layout: the tiled kernel) or any other (Conv1d / Conv2d weights along in-channels, torch_modules.py:582-585,
+        674-677: dmxq_weight_hypernet_strided) --, BlockTopK or Dense sparseness, SAME storage format, plain BFP weight format with
+        nearest rounding."""
         from .format import BlockFloatingPoint
         from .sparse import BlockTopK
-        if not self.fuse_weight_hypernet or self.weight_cast is None or torch.is_grad_enabled() and _w.requires_grad:
+        if not self.fuse_weight_hypernet or self.weight_cast is None or _w.dim() == 0 or torch.is_grad_enabled() and _w.requires_grad:
             return None
         wc, st = self.weight_cast, self.weight_storage_cast
         fmt = wc.format
-        if (not isinstance(fmt, BlockFloatingPoint) or fmt.rounding != "nearest" or fmt.block_size < 8 or wc.pre_transform
-                or wc.block_dim not in (-1, _w.dim() - 1) or not wc._flag("fake_quant_enabled") or wc._flag("observer_enabled")):
+        nd = _w.dim()
+        if (not isinstance(fmt, BlockFloatingPoint) or fmt.rounding != "nearest" or wc.pre_transform or not -nd <= wc.block_dim < nd
+                or not wc._flag("fake_quant_enabled") or wc._flag("observer_enabled")):
+            return None
+        bd = wc.block_dim % nd
+        last = bd == nd - 1
+        if fmt.block_size < (8 if last else 2):
             return None
         if st is not None and not (isinstance(st.format, Same) and not st.pre_transform):
             return None
         sp, score, K, M = self.weight_sparsifier, None, 0, 0
         if sp is not None and not isinstance(sp.sparseness, Dense):
-            if not isinstance(sp.sparseness, BlockTopK) or sp.sparseness.block_dim not in (-1, _w.dim() - 1) or sp.plastic \
-                    or sp.score.shape != _w.shape or self.training:
+            if not isinstance(sp.sparseness, BlockTopK) or not -nd <= sp.sparseness.block_dim < nd or sp.sparseness.block_dim % nd != bd \
+                    or sp.plastic or sp.score.shape != _w.shape or self.training:
                 return None
             score, K, M = sp.score.detach(), sp.sparseness.K, sp.sparseness.block_size
         sq = None
         if self.smoothquant is not None and not self.smoothquant._flag("fused_to_weight") and self.smoothquant._flag("enabled"):
-            if self.smoothquant.win_ch_axis not in (-1, _w.dim() - 1):
+            if not -nd <= self.smoothquant.win_ch_axis < nd or self.smoothquant.win_ch_axis % nd != bd:
                 return None
             sq = self.smoothquant.scale
+        if not last and score is None and sq is None:
+            return None  # a plain cast along another dim: the chain IS one launch (dmxq_bfp_qdq: the column / sub-slab kernels)
         from . import ops
-        y = ops.weight_hypernet(_w.detach(), fmt.precision, fmt.block_size, fmt.symmetric, score, K, M, sq)
+        y = ops.weight_hypernet(_w.detach(), fmt.precision, fmt.block_size, fmt.symmetric, score, K, M, sq, block_dim=bd)
         if y is not None and sp is not None and M:
             sp.mask = None  # not materialised on the fused path
         return y

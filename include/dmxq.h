@@ -197,6 +197,16 @@ int dmxq_weight_hypernet(const void* w, int dtype_w, const void* score, int dtyp
                          const float* sq_scale, void* out, int dtype_out, int64_t rows, int64_t L, int64_t block_size,
                          int precision, int symmetric, void* stream);
 
+/* The same chain for layouts whose blocked dimension is not the contiguous one: w viewed as [outer, L, inner] with the N:M groups,
+ * the SmoothQuant channels and the BFP blocks all along L (stride inner) -- Conv1d / Conv2d weights [out, in, k...], whose weight
+ * cast, sparsifier and SmoothQuant axis are dim 1 (modeling/nn/torch_modules.py:582-585, 674-677; the chain is
+ * modeling/nn/core.py:178-198 as above).  Any block size >= 2 and a ragged last block (torch.split); M in {0, 2, 4, 8} dividing
+ * block_size; every dtype combination.  Bit-identical to the unfused chain.  These weights are small: the call is launch-bound and
+ * the point is one launch instead of three. */
+int dmxq_weight_hypernet_strided(const void* w, int dtype_w, const void* score, int dtype_score, int K, int M,
+                                 const float* sq_scale, void* out, int dtype_out, int64_t outer, int64_t L, int64_t inner,
+                                 int64_t block_size, int precision, int symmetric, void* stream);
+
 /* The activation twin of the fused weight path: SmoothQuant input scaling -> BFP input cast in one pass over x[rows, L]
  * (channels and blocks along the contiguous last dim).  out = BFP_QDQ(x / sq_scale[c]); the quotient is an IEEE fp32 division
  * and stays fp32 -- torch's promotion of (input dtype, fp32 scale), i.e. what `a / scale` returns in

@@ -1,0 +1,161 @@
+"""-m gpu, round 3: the weight chain of a conv layer as one launch (dmxq_weight_hypernet_strided), the multi-tensor fold's scale
+check, DMXQ_ERR_PENDING."""
+import ctypes
+
+import pytest
+import torch
+
+from _data import bits_equal, make
+
+pytestmark = pytest.mark.gpu
+BF16, F32, F16 = torch.bfloat16, torch.float32, torch.float16
+
+# (constructor, weight shape, N:M shorthand along dim 1): Whisper-small conv1 / conv2, LeNet-5 conv2, a ResNet-style 3x3
+CONVS = [
+    ("whisper conv1 [768,80,3]", lambda nn: nn.Conv1d(80, 768, 3, padding=1), (768, 80, 3), "BTOPK{2:4,1}(U)"),
+    ("whisper conv2 [768,768,3]", lambda nn: nn.Conv1d(768, 768, 3, stride=2, padding=1), (768, 768, 3), "BTOPK{4:8,1}(U)"),
+    ("lenet conv2 [16,6,5,5]", lambda nn: nn.Conv2d(6, 16, 5), (16, 6, 5, 5), "BTOPK{1:2,1}(U)"),
+    ("resnet 3x3 [64,128,3,3]", lambda nn: nn.Conv2d(128, 64, 3, padding=1), (64, 128, 3, 3), "BTOPK{2:4,1}(U)"),
+]
+
+
+@pytest.mark.parametrize("wdt", [F32, BF16, F16])
+@pytest.mark.parametrize("tag,ctor,shape,nm", CONVS, ids=[c[0] for c in CONVS])
+def test_conv_weight_chain_is_one_launch_and_equals_the_unfused_chain(dmx, cuda, oracle, wdt, tag, ctor, shape, nm):
+    """modeling/nn/core.py:178-198 for Conv1d / Conv2d (weight cast, sparsifier and SmoothQuant all along dim 1,
+    torch_modules.py:582-585, 674-677): sparsifier -> smoothquant.scale_weight -> weight_cast in ONE launch, bit-identical to the
+    three-op chain of this library (which the LeNet / model-shape fixtures pin to the reference), and to the ORACLE composed the way
+    the reference composes the steps -- for {mask, no mask} x {scale, no scale} x symmetric / asymmetric formats, ragged last
+    blocks (80 = 64 + 16 in-channels, 6 < 64) included."""
+    C = shape[1]
+    for fmt in ("BFP[8|8]{64}(SN)", "BFP[8|8]{16}(_N)", "BFP[4|8]{2}(SN)"):
+        B = int(fmt.split("{")[1].split("}")[0])
+        for use_mask in (False, True):
+            if use_mask and B % int(nm.split(":")[1].split(",")[0]) != 0:
+                continue
+            for use_sq in (False, True):
+                if not use_mask and not use_sq:
+                    continue   # a plain cast is already one launch (and `_fused_weight` says so by returning None)
+                m = ctor(dmx.nn).to(wdt)
+                w = (make("heavy", shape, seed=31).clamp(-50, 50) * 0.1).to(wdt)
+                m.weight.data = w.clone()
+                m = m.to(cuda).eval()
+                m.configure(dict(weight_format=fmt))
+                score = None
+                if use_mask:
+                    m.configure(dict(weight_sparseness=nm))
+                    m.fuse_weight_hypernet = False
+                    with torch.no_grad():
+                        m._weight                                      # materialise the lazy score
+                    score = make("normal", shape, seed=32).abs()
+                    score.reshape(-1)[::7] = score.reshape(-1)[1::7][: score.reshape(-1)[::7].numel()]   # ties inside groups
+                    m.weight_sparsifier.score.data = score.to(cuda)
+                scale = None
+                if use_sq:
+                    scale = (torch.rand(C, generator=torch.Generator().manual_seed(1)) * 4 + 0.25)
+                    m.smoothquant.scale = scale.to(cuda)
+                    m.smoothquant.enable()
+                with torch.no_grad():
+                    m.fuse_weight_hypernet = False
+                    chain = m._weight
+                    m.fuse_weight_hypernet = True
+                    assert m._fused_weight(m.weight) is not None, (tag, fmt, use_mask, use_sq)
+                    fused = m._weight
+                assert fused.dtype == chain.dtype and bits_equal(fused, chain) == 0, (tag, fmt, use_mask, use_sq)
+                # the oracle, composed like the reference: x * mask (promoted dtype) -> (x * scale).to(dtype) -> BFP cast -> .to(dtype)
+                f = dmx.Format.from_shorthand(fmt)
+                t = w
+                if use_mask:
+                    K, M = int(nm.split("{")[1].split(":")[0]), int(nm.split(":")[1].split(",")[0])
+                    t = oracle.sparsify(t, score, K, M, 1)
+                if use_sq:
+                    t = (t * scale.view(1, -1, *([1] * (len(shape) - 2)))).to(t.dtype)
+                want = oracle.bfp_cast(t, f.precision, f.block_size, 1, f.symmetric).to(t.dtype)
+                assert want.dtype == fused.dtype and bits_equal(fused.cpu(), want.contiguous()) == 0, (tag, fmt, use_mask, use_sq, "oracle")
+    # a plain BASIC conv (no mask, no scale): nothing to fuse, the chain is the single cast launch
+    m = ctor(dmx.nn).to(cuda)
+    m.configure(dict(weight_format="BFP[8|8]{64}(SN)"))
+    with torch.no_grad():
+        assert m._fused_weight(m.weight) is None and m._weight.shape == shape
+
+
+def test_conv_forward_with_fused_weight_path(dmx, cuda):
+    """the module's forward consumes the fused weight (same result as with the chain), Whisper conv2 shape"""
+    m = dmx.nn.Conv1d(768, 768, 3, stride=2, padding=1).to(cuda).eval()
+    dmx.configure_model(m, *dmx.config_rules.BASIC)
+    m.configure(dict(weight_sparseness="BTOPK{4:8,1}(U)"))
+    x = make("normal", (1, 768, 300), seed=5).to(cuda)
+    with torch.no_grad():
+        m.fuse_weight_hypernet = False
+        m(x)                                                            # materialises the score
+        y_chain = m(x)
+        m.fuse_weight_hypernet = True
+        assert m._fused_weight(m.weight) is not None
+        y_fused = m(x)
+    assert torch.equal(y_chain, y_fused)
+
+
+def test_fold_refuses_an_uncalibrated_group_quantised_weight_like_the_per_module_path(dmx, cuda):
+    """`fixed_qdq_multi` took any one-entry scale as per-tensor even with a group_size, so
+    `fold_weights_and_biases` silently rounded an UNCALIBRATED group-quantised weight (scale = [1.0]) to integers; the per-module
+    path raises ValueError (need N scale entries).  Both raise now; a calibrated model still folds, bit-identically."""
+    hp = dmx.nn.DmxModuleQuantizerCalibrationHyperparams(weight=dmx.nn.DmxQuantizerCalibrationHyperparams(
+        observer_cls=dmx.MinMaxObserver, qscheme_to_overload=torch.per_tensor_symmetric, group_size=128, ch_axis=0))
+
+    def model():
+        seq = torch.nn.Sequential(dmx.nn.Linear(256, 512), dmx.nn.Linear(512, 256)).to(cuda)
+        for mod in seq:
+            mod.configure(dict(weight_format="XP[8,0](CSN)"))
+        return seq
+
+    seq = model()
+    for mod in seq:                                   # group_size set on the cast, but never calibrated: scale is still [1.0]
+        mod.weight_cast.group_size, mod.weight_cast.ch_axis = 128, 0
+    w0 = [mod.weight.detach().clone() for mod in seq]
+    with pytest.raises(ValueError):
+        with torch.no_grad():
+            seq[0]._weight                            # the per-module path
+    with pytest.raises(ValueError):
+        dmx.nn.fold_weights_and_biases(seq)           # ... and the batched fold
+    assert all(torch.equal(mod.weight.detach(), w) for mod, w in zip(seq, w0)), "a refused fold must leave the weights alone"
+    with pytest.raises(ValueError):
+        dmx.ops.fixed_qdq_multi([w0[0]], 8, 0, True, True, [torch.ones(1, device=cuda)], [torch.zeros(1, dtype=torch.int64, device=cuda)], group_size=128)
+    # one group covering every channel is legal with one entry (C <= group_size), and so is a per-tensor scale without a group_size
+    small = torch.randn(64, 32, device=cuda)
+    a = dmx.ops.fixed_qdq_multi([small], 8, 0, True, True, [torch.full((1,), 0.05, device=cuda)], [torch.zeros(1, dtype=torch.int64, device=cuda)], group_size=128)[0]
+    b = dmx.ops.fixed_qdq_multi([small], 8, 0, True, True, [torch.full((1,), 0.05, device=cuda)], [torch.zeros(1, dtype=torch.int64, device=cuda)])[0]
+    c = dmx.ops.fixed_qdq(small, 8, 0, True, True, scale=torch.full((1,), 0.05, device=cuda), zero_point=torch.zeros(1, dtype=torch.int64, device=cuda))
+    assert torch.equal(a, c) and torch.equal(b, c)
+    # calibrated: folds, and equals module-by-module folding
+    seq, ref = model(), model()
+    for s_mod, r_mod in zip(seq, ref):
+        r_mod.load_state_dict(s_mod.state_dict())
+        for mod in (s_mod, r_mod):
+            with mod.calibrating_quantizers(hp), torch.no_grad():
+                mod._weight
+    dmx.nn.fold_weights_and_biases(seq)
+    for mod in ref:
+        mod.fold_weight_and_bias()
+    assert all(torch.equal(a.weight, b.weight) for a, b in zip(seq, ref))
+
+
+def test_pending_foreign_hip_error_is_reported_not_swallowed(dmx, cuda):
+    """with another HIP user's error pending on the thread, a call used to return DMXQ_OK without verifying its
+    launches.  Now: DMXQ_ERR_PENDING (4), the foreign error left in place for its owner."""
+    from dmx_compressor_amd import _lib
+    L = _lib.lib()
+    hip = ctypes.CDLL("libamdhip64.so")
+    x = torch.randn(64, 64, device=cuda, dtype=BF16)
+    y = torch.empty_like(x)
+    args = (ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), _lib.BF16, _lib.BF16, 64, 64, 1, 16, 8, 2, 1, 0, None)
+    torch.cuda.synchronize()
+    assert L.dmxq_bfp_qdq(*args) == 0
+    hip.hipGetLastError()                                            # clean slate
+    assert hip.hipMemcpy(None, None, 16, 99) != 0                    # somebody else's failing call: sets the thread's last error
+    assert hip.hipPeekAtLastError() != 0
+    rc = L.dmxq_bfp_qdq(*args)
+    assert rc == _lib.ERR_PENDING == 4 and b"pre-existing" in L.dmxq_status_string(rc)
+    assert hip.hipPeekAtLastError() != 0                              # still there for its owner
+    hip.hipGetLastError()                                             # ... who collects it
+    assert L.dmxq_bfp_qdq(*args) == 0
+    torch.cuda.synchronize()
