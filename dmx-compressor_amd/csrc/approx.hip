@@ -303,12 +303,15 @@ constexpr int rows_per_wave(int vpl, int epl) { return 32 / (vpl * epl) >= 4 ? 4
 // 16-bit outputs: exp(x - m) as v_exp_f32(fma(x, log2 e, -m log2 e)) and one reciprocal per row -- relative error
 // ~2^-21, far inside the output format's 2^-9 / 2^-12 half-ulp (the rounding of m log2 e scales numerator and
 // denominator alike and cancels); fp32 outputs keep expf and the per-element division.
-template <int DT, int EPL, int VPL, int LPR, bool RAG = false, bool CAST = false>
+// FAST32: float32 rows behind an output cast that keeps <= 16 mantissa bits (a module's FLOAT16 output cast): the v_exp / one
+// reciprocal per row forms of the 16-bit rows (relative error ~2^-21, invisible at 2^-17) instead of the compensated expf and a
+// division per element -- those make the fp32 kernel VALU-bound (Whisper's [12,1500,1500] attention: 58 us -> see profiles/r03_*)
+template <int DT, int EPL, int VPL, int LPR, bool RAG = false, bool CAST = false, bool FAST32 = false>
 __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                                int64_t rows, int64_t cols, float clamp_min, const RowCastArg<CAST> rc) {
   constexpr int SUB = kWave / LPR;  // rows side by side in one wave
   constexpr int RPW = rows_per_wave(VPL, EPL);
-  constexpr bool FAST = DT != DMXQ_F32;
+  constexpr bool FAST = DT != DMXQ_F32 || FAST32;
   const int lane = threadIdx.x & (kWave - 1), sub = lane / LPR, sl = lane & (LPR - 1);
   const int64_t wave = (int64_t)blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave;
   const int64_t n_waves = (int64_t)gridDim.x * (kThreads / kWave);
@@ -692,6 +695,8 @@ static int softmax_dispatch(const void* in, void* out, int dtype_in, int dtype_o
     if (half_vec) rag = false;
     int lpr, vpl;
     wave_shape(half_vec ? cols / 4 : (cols + full - 1) / full, &lpr, &vpl);
+    bool fast32 = false;
+    if constexpr (CAST) fast32 = !rag && rc.go.active && rc.go.f.man <= 16;
 #define DMXQ_SM(D_, E_, V_, L_)                                                                                       \
   do {                                                                                                                \
     constexpr int per_wg = 4 * rows_per_wave(V_, E_) * (64 / (L_));                                                   \
@@ -699,6 +704,14 @@ static int softmax_dispatch(const void* in, void* out, int dtype_in, int dtype_o
       if (rag) {                                                                                                      \
         DMXQ_LAUNCH((softmax_wave_kernel<D_, E_, V_, L_, true, CAST>),                                         \
                            dim3((unsigned)resident_grid(softmax_wave_kernel<D_, E_, V_, L_, true, CAST>, (rows + per_wg - 1) / per_wg)), \
+                           dim3(kThreads), 0, s, in, out, rows, cols, input_clamp_min, rc);                           \
+        break;                                                                                                        \
+      }                                                                                                               \
+    }                                                                                                                 \
+    if constexpr (CAST && (D_) == DMXQ_F32) {                                                                         \
+      if (fast32) {                                                                                                   \
+        DMXQ_LAUNCH((softmax_wave_kernel<D_, E_, V_, L_, false, CAST, true>),                                  \
+                           dim3((unsigned)resident_grid(softmax_wave_kernel<D_, E_, V_, L_, false, CAST, true>, (rows + per_wg - 1) / per_wg)), \
                            dim3(kThreads), 0, s, in, out, rows, cols, input_clamp_min, rc);                           \
         break;                                                                                                        \
       }                                                                                                               \

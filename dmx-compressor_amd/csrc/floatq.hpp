@@ -99,12 +99,39 @@ __device__ __forceinline__ float float_q1(float a, const FloatFmt& f, uint32_t r
   return f.unsigned_abs ? fabsf(q) : q;
 }
 
-struct CastG { FloatFmt f; FloatFast k; int active; };
+// Formats that FLUSH their subnormals (FLOAT16, BFLOAT16 of the BASIC rules) on finite inputs, on the magnitude bits: round to
+// `man` bits half-to-even (add half - 1 + kept LSB, mask: quant_cpu.cpp:211-237 -- the carry may ripple into the exponent),
+// saturate at sign | max_e | max_man (a rounded pattern above it has an exponent above max_e, bit_helper.cpp:4-22), and +0 where
+// the INPUT's exponent is below the smallest normal one (quant_cpu.cpp:372-376 decides on the input).  8 integer operations per
+// element instead of the ~17 of the magic-add form; Inf / NaN inputs (and man = 0, whose tie rule reads the exponent's lowest
+// bit) keep the bit-level form through the caller's wave-uniform fallback.
+struct FlushFast { uint32_t half_m1, mask, lim_bits, min_bits; int sh, usable; };
+inline FlushFast make_flush_fast(int man, int exp_bits, int bias, int flush) {
+  FlushFast k{};
+  const int min_exp = -(bias - 1), max_e = (1 << (exp_bits - 1)) + 127;
+  k.usable = (flush && man >= 1 && man <= 22 && min_exp >= -126 && min_exp <= 127) ? 1 : 0;
+  k.sh = 23 - man;
+  k.mask = (1u << (23 - man)) - 1u;
+  k.half_m1 = (1u << (22 - man)) - 1u;
+  k.lim_bits = max_e >= 255 ? 0x7F800000u : (((uint32_t)max_e << 23) | ((0x007FFFFFu >> (23 - man)) << (23 - man)));  // max_e = 255: a finite input can at most round up to Inf
+  k.min_bits = (uint32_t)(127 + (k.usable ? min_exp : 0)) << 23;
+  return k;
+}
+__device__ __forceinline__ float float_q1_flush(float a, const FlushFast& k) {
+  const uint32_t u = f2u(a), m = u & 0x7FFFFFFFu;
+  uint32_t r = (m + k.half_m1 + ((m >> k.sh) & 1u)) & ~k.mask;
+  r = r < k.lim_bits ? r : k.lim_bits;
+  r |= u & 0x80000000u;
+  return u2f(m < k.min_bits ? 0u : r);
+}
+
+struct CastG { FloatFmt f; FloatFast k; FlushFast ff; int active; };
 inline bool castg_of(const dmxq_float_fmt* f, CastG* c) {  // false: not a format the kernels take
-  if (!f || f->exp_bits == 0) { c->active = 0; c->f = FloatFmt{}; c->k = FloatFast{}; return true; }
+  if (!f || f->exp_bits == 0) { c->active = 0; c->f = FloatFmt{}; c->k = FloatFast{}; c->ff = FlushFast{}; return true; }
   if (f->exp_bits < 1 || f->exp_bits > 8 || f->man_bits < 0 || f->man_bits > 22) return false;
   c->f = FloatFmt{f->man_bits, f->exp_bits, f->exp_bias, f->flush_subnormal ? 1 : 0, 0, DMXQ_ROUND_NEAREST, 0ull};
   c->k = make_float_fast(f->man_bits, f->exp_bits, f->exp_bias);
+  c->ff = make_flush_fast(f->man_bits, f->exp_bits, f->exp_bias, f->flush_subnormal ? 1 : 0);
   c->active = 1;
   return true;
 }
@@ -119,6 +146,20 @@ __device__ __forceinline__ float castg_dt(float x) {  // CastTo's `.to(physical 
 template <int DT, int N>
 __device__ __forceinline__ void castg_vec(float (&x)[N], const CastG& c) {
   if (!c.active) return;  // (wave-uniform, once per vector)
+  if (c.ff.usable) {      // flush formats: the integer form, finite inputs
+    bool fin = true;
+    float q[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) { fin = fin && (f2u(x[j]) & 0x7F800000u) != 0x7F800000u; q[j] = float_q1_flush(x[j], c.ff); }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fin) != 0ull, 0)) {
+#pragma unroll
+      for (int j = 0; j < N; j++)
+        if ((f2u(x[j]) & 0x7F800000u) == 0x7F800000u) q[j] = float_q1<DMXQ_ROUND_NEAREST>(x[j], c.f, 0u);
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) x[j] = castg_dt<DT>(q[j]);
+    return;
+  }
   bool ok = c.k.usable != 0;
   float q[N];
 #pragma unroll

@@ -184,7 +184,7 @@ class DmxModule(torch.nn.Module):
     #: use the single-kernel weight path (csrc/hypernet.hip) when the configuration allows it; results are bit-identical
     fuse_weight_hypernet = True
 
-    def _fused_weight(self, _w):
+    def _fused_weight(self, _w, out_dtype=None):
         """mask -> SmoothQuant scale -> BFP in ONE launch, or None when this configuration must take the chain:
         inference only (no autograd through the fused op), mask groups, SmoothQuant channels and BFP blocks all along ONE dim -- the
         last (Linear layout: the tiled kernel) or any other (Conv1d / Conv2d weights along in-channels, torch_modules.py:582-585,
@@ -220,15 +220,28 @@ class DmxModule(torch.nn.Module):
         if not last and score is None and sq is None:
             return None  # a plain cast along another dim: the chain IS one launch (dmxq_bfp_qdq: the column / sub-slab kernels)
         from . import ops
-        y = ops.weight_hypernet(_w.detach(), fmt.precision, fmt.block_size, fmt.symmetric, score, K, M, sq, block_dim=bd)
+        if out_dtype is not None and last:
+            # the tiled kernel is instantiated for these (weight, score, output) dtypes (csrc/hypernet.hip); anything else keeps the chain's
+            # own dtype and the consumer converts.  Decided HERE, statically: under torch.compile the op is traced through its meta
+            # kernel, which cannot refuse a combination.
+            sd = score.dtype if score is not None else _w.dtype
+            ok = {(torch.bfloat16, torch.float32): (torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16): (torch.bfloat16,),
+                  (torch.float16, torch.float32): (torch.float16, torch.float32), (torch.float16, torch.float16): (torch.float16,),
+                  (torch.float32, torch.float32): (torch.float32,)}.get((_w.dtype, sd), ())
+            if out_dtype not in ok:
+                out_dtype = None
+        y = ops.weight_hypernet(_w.detach(), fmt.precision, fmt.block_size, fmt.symmetric, score, K, M, sq, out_dtype=out_dtype, block_dim=bd)
         if y is not None and sp is not None and M:
             sp.mask = None  # not materialised on the fused path
         return y
 
     @property
     def weight_hypernet(self):
-        def _weight_hypernet(_w):
-            fused = self._fused_weight(_w)
+        def _weight_hypernet(_w, out_dtype=None):
+            """out_dtype: the dtype the CONSUMER converts the result to anyway (Linear: `_weight.to(_input.dtype)`, torch_modules.py:
+            347-350) -- the fused kernel then rounds to it directly (the chain's dtype is torch's promotion of weight and score dtypes:
+            float32 for a bf16 weight with an N:M score Parameter, i.e. a 4 B/element store and a separate conversion pass)"""
+            fused = self._fused_weight(_w, out_dtype)
             if fused is not None:
                 return fused
             if self.weight_sparsifier is not None:
@@ -486,7 +499,7 @@ class Linear(DmxModule, torch.nn.Linear):
 
     def _forward(self, _input):
         if isinstance(self.accum_format, Same):  # torch_modules.py:346-350
-            _weight = self._weight_ro.to(_input.dtype)
+            _weight = self.weight_hypernet(self.weight, _input.dtype).to(_input.dtype)
             _bias = self._bias_ro  # (a property: one cast launch per evaluation)
             return F.linear(_input, _weight, None if _bias is None else _bias.to(_input.dtype))
         _weight = self._weight_ro

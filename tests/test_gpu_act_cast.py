@@ -137,7 +137,7 @@ def test_row_function_cast_contract(dmx, cuda, oracle, dtype):
             cin = _cpu_cast(oracle, fi)(x)
             got = dmx.ops.softmax_cast(x.to(cuda), -1, fi, fo)
             if got is not None:
-                bad = outside_cast_bracket(got, F.softmax(cin.double(), -1), cast_o, dtype, _n_ulp({torch.float32: 8}, dtype, None))
+                bad = outside_cast_bracket(got, F.softmax(cin.double(), -1), cast_o, dtype, _n_ulp({torch.float32: 8}, dtype, fo))
                 assert bad == 0, ("softmax", dtype, cols, rows, ci, co, bad)
             else:  # rows longer than 1024 lane-vectors are not register resident
                 assert cols > 1024 * (4 if dtype == torch.float32 else 8), ("softmax not fused", dtype, cols)
@@ -238,7 +238,7 @@ def test_softmax_and_norm_modules_run_the_fused_kernels(dmx, cuda, oracle, dtype
     it = torch.int16 if dtype != torch.float32 else torch.int32
     assert torch.equal(y.view(it), dmx.ops.softmax_cast(x, -1, fi, fo).view(it))
     cin = _cpu_cast(oracle, fi)(x.cpu())
-    assert outside_cast_bracket(y, F.softmax(cin.double(), -1), _cpu_cast(oracle, fo), dtype, _n_ulp({torch.float32: 8}, dtype, None)) == 0
+    assert outside_cast_bracket(y, F.softmax(cin.double(), -1), _cpu_cast(oracle, fo), dtype, _n_ulp({torch.float32: 8}, dtype, fo)) == 0
     sm2 = _basic(dmx, nn.Softmax(dim=1)).to(cuda)        # not the last dim: the general path
     assert sm2._fused_forward(x) is None and sm2(x).shape == x.shape
     for cols, ctor, kind in ((768, lambda: nn.LayerNorm(768), "ln"), (4096, lambda: nn.RMSNorm(4096, eps=1e-5), "rms")):
@@ -334,7 +334,7 @@ def test_model_shape_activation_stages(dmx, cuda, oracle, tag, dtype, shape, kin
         truth, floor = f64(cin, dtype), None if floor_fn is None else floor_fn(cin)
         n = _n_ulp(tol, dtype, fo)
     elif kind == "softmax":
-        truth, n = F.softmax(cin.double(), -1), _n_ulp({torch.float32: 8}, dtype, None)
+        truth, n = F.softmax(cin.double(), -1), _n_ulp({torch.float32: 8}, dtype, fo)
     elif kind == "layernorm":
         truth, floor = _ln_truth(cin, cols, m.weight.detach().cpu(), m.bias.detach().cpu(), m.eps)
         n = _n_ulp({torch.float32: 3}, dtype, None)

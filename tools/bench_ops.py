@@ -216,30 +216,40 @@ def main():
         run(f"unary_cast {nm} module: FLOAT16 -> {nm} -> FLOAT16, bf16 (one launch, 4 B/elem)",
             lambda i: L.dmxq_unary_cast(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, n, kind, ctypes.c_float(0.0), pf, pf, sp), k, n * 4)
         run(f"  the three launches it replaces (float_qdq, torch {nm}, float_qdq)",
-            lambda i: (fq(xs[i], ys[i], _lib.BF16, n), ys[(i + 1) % k].copy_(tf(ys[i], None)), fq(ys[(i + 1) % k], ys[i], _lib.BF16, n)), k, n * 4)
+            lambda i: (fq(xs[i], ys[i], _lib.BF16, n), fq(tf(ys[i], None), ys[(i + 1) % k], _lib.BF16, n)), k, n * 4)
     run("unary_cast gelu module on float32 tensors (general form, 8 B/elem)",
         lambda i: L.dmxq_unary_cast(vp(f32a[i % 6].data_ptr()), vp(f32o[i % 6].data_ptr()), _lib.F32, n, 0, ctypes.c_float(0.0), pf, pf, sp), 6, n * 8)
     run("  the three launches it replaces (float_qdq fp32, torch gelu, float_qdq fp32)",
-        lambda i: (fq(f32a[i % 6], f32o[i % 6], _lib.F32, n), f32o[(i + 1) % 6].copy_(F.gelu(f32o[i % 6])), fq(f32o[(i + 1) % 6], f32o[i % 6], _lib.F32, n)), 6, n * 8)
+        lambda i: (fq(f32a[i % 6], f32o[i % 6], _lib.F32, n), fq(F.gelu(f32o[i % 6]), f32o[(i + 1) % 6], _lib.F32, n)), 6, n * 8)
     run("softmax_cast module bf16 rows of 1500: FLOAT16 -> softmax -> FLOAT16 (one launch)",
         lambda i: L.dmxq_softmax_cast(vp(xr[i].data_ptr()), vp(yr[i].data_ptr()), _lib.BF16, rows, cols, ctypes.c_float(-math.inf), pf, pf, sp), 10, rows * cols * 4)
     run("  the three launches it replaces (float_qdq, torch softmax, float_qdq)",
-        lambda i: (fq(xr[i], yr[i], _lib.BF16, rows * cols), yr[(i + 1) % 10].copy_(torch.softmax(yr[i], -1)), fq(yr[(i + 1) % 10], yr[i], _lib.BF16, rows * cols)), 10, rows * cols * 4)
+        lambda i: (fq(xr[i], yr[i], _lib.BF16, rows * cols), fq(torch.softmax(yr[i], -1), yr[(i + 1) % 10], _lib.BF16, rows * cols)), 10, rows * cols * 4)
     xr32 = [torch.randn(rows, cols, device=dev) for _ in range(5)]
     yr32 = [torch.empty_like(t) for t in xr32]
     run("softmax_cast module float32 rows of 1500 (Whisper attention, general form, 8 B/elem)",
         lambda i: L.dmxq_softmax_cast(vp(xr32[i].data_ptr()), vp(yr32[i].data_ptr()), _lib.F32, rows, cols, ctypes.c_float(-math.inf), pf, pf, sp), 5, rows * cols * 8)
     run("  the three launches it replaces (float_qdq fp32, torch softmax, float_qdq fp32)",
-        lambda i: (fq(xr32[i], yr32[i], _lib.F32, rows * cols), yr32[(i + 1) % 5].copy_(torch.softmax(yr32[i], -1)), fq(yr32[(i + 1) % 5], yr32[i], _lib.F32, rows * cols)), 5, rows * cols * 8)
+        lambda i: (fq(xr32[i], yr32[i], _lib.F32, rows * cols), fq(torch.softmax(yr32[i], -1), yr32[(i + 1) % 5], _lib.F32, rows * cols)), 5, rows * cols * 8)
+    run("bfp_qdq float32 rows of 1500, B=64 (ragged last block: Whisper attention probabilities)",
+        lambda i: L.dmxq_bfp_qdq(vp(xr32[i].data_ptr()), vp(yr32[i].data_ptr()), _lib.F32, _lib.F32, rows, cols, 1, 64, 8, 2, 1, 0, sp), 5, rows * cols * 8)
     del xr32, yr32
+    run("float_qdq float32 FP16(FN) [BASIC activation cast of a float32 model]",
+        lambda i: fq(f32a[i % 6], f32o[i % 6], _lib.F32, n), 6, n * 8)
+    xl32 = [torch.randn(rows2, cols2, device=dev) for _ in range(8)]
+    yl32 = [torch.empty_like(t) for t in xl32]
+    w32 = torch.ones(cols2, device=dev)
+    run("layernorm_cast module float32 rows of 768 (opt-125m / Whisper, general form, 8 B/elem)",
+        lambda i: L.dmxq_layernorm_cast(vp(xl32[i].data_ptr()), vp(yl32[i].data_ptr()), _lib.F32, rows2, cols2, vp(w32.data_ptr()), vp(w32.data_ptr()), ctypes.c_float(1e-5), pf, pf, sp), 8, rows2 * cols2 * 8)
+    del xl32, yl32
     run("layernorm_cast module bf16 rows of 768 (one launch)",
         lambda i: L.dmxq_layernorm_cast(vp(xl[i].data_ptr()), vp(yl[i].data_ptr()), _lib.BF16, rows2, cols2, vp(w.data_ptr()), vp(w.data_ptr()), ctypes.c_float(1e-5), pf, pf, sp), 14, rows2 * cols2 * 4)
     run("  the three launches it replaces (float_qdq, torch layer_norm, float_qdq)",
-        lambda i: (fq(xl[i], yl[i], _lib.BF16, rows2 * cols2), yl[(i + 1) % 14].copy_(F.layer_norm(yl[i], (cols2,), w, w, 1e-5)), fq(yl[(i + 1) % 14], yl[i], _lib.BF16, rows2 * cols2)), 14, rows2 * cols2 * 4)
+        lambda i: (fq(xl[i], yl[i], _lib.BF16, rows2 * cols2), fq(F.layer_norm(yl[i], (cols2,), w, w, 1e-5), yl[(i + 1) % 14], _lib.BF16, rows2 * cols2)), 14, rows2 * cols2 * 4)
     run("rmsnorm_cast module bf16 rows of 4096 (Llama hidden, one launch)",
         lambda i: L.dmxq_rmsnorm_cast(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, R, C, vp(wr.data_ptr()), ctypes.c_float(1e-5), pf, pf, sp), k, n * 4)
     run("  the three launches it replaces (float_qdq, torch rms_norm, float_qdq)",
-        lambda i: (fq(xs[i], ys[i], _lib.BF16, n), ys[(i + 1) % k].copy_(F.rms_norm(ys[i], (C,), wr, 1e-5)), fq(ys[(i + 1) % k], ys[i], _lib.BF16, n)), k, n * 4)
+        lambda i: (fq(xs[i], ys[i], _lib.BF16, n), fq(F.rms_norm(ys[i], (C,), wr, 1e-5), ys[(i + 1) % k], _lib.BF16, n)), k, n * 4)
     if args.json:
         json.dump(results, open(args.json, "w"), indent=1)
 
