@@ -50,11 +50,9 @@ struct CastedOp {
       base.apply_vec(xc, y, e0);
       castg_vec<DT, N>(y, go);
     } else {
+      // (a NaN result keeps the sign the hardware gives it: torch's CPU bf16 conversion makes every NaN positive, its GPU one does
+      // not, and a cast without NaN codes then saturates to +-max accordingly -- the magnitude is the contract here)
       base.apply_vec(x, y, e0);
-      if (DT == DMXQ_BF16) {  // c10::BFloat16: every NaN -> +0x7FC0 (it matters: a cast without NaN codes saturates it to sign | max)
-#pragma unroll
-        for (int k = 0; k < N; k++) y[k] = y[k] != y[k] ? u2f(0x7FC00000u) : y[k];
-      }
     }
   }
   __device__ __forceinline__ void apply_one(float, float&, int64_t) const {}  // (n % EPL == 0 is required: no scalar tail)
@@ -69,7 +67,9 @@ static int launch_casted(const void* in, void* out, int64_t n, const BASE& base,
 
 // accurate libm forms only where an fp32 result can be seen: float32 tensors whose output cast keeps more than 16 mantissa bits
 template <int KIND>
-static int launch_unary_cast(const void* in, void* out, int dtype, int64_t n, float param, const ActCasts& c, bool fast32, hipStream_t s) {
+static int launch_unary_cast(const void* in, void* out, int dtype, int64_t n, float param, const ActCasts& c, bool fast32, bool notail, hipStream_t s) {
+  if (notail && dtype == DMXQ_BF16) return launch_casted<UnaryOp<KIND, DMXQ_BF16, true, true>, DMXQ_BF16>(in, out, n, {param}, c, s);
+  if (notail && dtype == DMXQ_F16) return launch_casted<UnaryOp<KIND, DMXQ_F16, true, true>, DMXQ_F16>(in, out, n, {param}, c, s);
   if (dtype == DMXQ_BF16) return launch_casted<UnaryOp<KIND, DMXQ_BF16, true>, DMXQ_BF16>(in, out, n, {param}, c, s);
   if (dtype == DMXQ_F16) return launch_casted<UnaryOp<KIND, DMXQ_F16, true>, DMXQ_F16>(in, out, n, {param}, c, s);
   if (fast32) return launch_casted<UnaryOp<KIND, DMXQ_F32, true>, DMXQ_F32>(in, out, n, {param}, c, s);
@@ -104,11 +104,14 @@ extern "C" int dmxq_unary_cast(const void* in, void* out, int dtype, int64_t n, 
     return DMXQ_ERR_UNSUPPORTED;
   }
   hipStream_t s = (hipStream_t)stream;
+  // the far tail of silu / quick_gelu (|result| < 1e-35) needs no exact last bits when the output cast flushes it: a 16-bit tensor
+  // whose output cast has a smallest normal value of 2^-100 or more
+  const bool notail = dtype != DMXQ_F32 && cast_out && cast_out->exp_bits != 0 && cast_out->flush_subnormal && -(cast_out->exp_bias - 1) >= -100;
   switch (kind) {
     case DMXQ_UNARY_GELU: return launch_gelu_cast<false>(in, out, dtype, n, c, fast32, s);
     case DMXQ_UNARY_GELU_TANH: return launch_gelu_cast<true>(in, out, dtype, n, c, fast32, s);
-    case DMXQ_UNARY_SILU: return launch_unary_cast<DMXQ_UNARY_SILU>(in, out, dtype, n, param, c, fast32, s);
-    case DMXQ_UNARY_QUICK_GELU: return launch_unary_cast<DMXQ_UNARY_QUICK_GELU>(in, out, dtype, n, param, c, fast32, s);
-    default: return launch_unary_cast<DMXQ_UNARY_EXP>(in, out, dtype, n, param, c, fast32, s);
+    case DMXQ_UNARY_SILU: return launch_unary_cast<DMXQ_UNARY_SILU>(in, out, dtype, n, param, c, fast32, notail, s);
+    case DMXQ_UNARY_QUICK_GELU: return launch_unary_cast<DMXQ_UNARY_QUICK_GELU>(in, out, dtype, n, param, c, fast32, notail, s);
+    default: return launch_unary_cast<DMXQ_UNARY_EXP>(in, out, dtype, n, param, c, fast32, false, s);
   }
 }

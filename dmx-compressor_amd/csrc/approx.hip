@@ -240,10 +240,7 @@ __device__ __forceinline__ RowVec<DT, EPL> rowcast_pack_out(float (&y)[EPL], con
 #pragma unroll
     for (int j = 0; j < EPL; j++) r.w[j] = f2u(y[j]);
   } else {
-    if constexpr (CAST && DT == DMXQ_BF16) {  // c10::BFloat16: every NaN -> +0x7FC0 before a cast that saturates NaN to sign | max
-#pragma unroll
-      for (int j = 0; j < EPL; j++) y[j] = y[j] != y[j] ? u2f(0x7FC00000u) : y[j];
-    }
+    // (a NaN result keeps the hardware's sign: see act_cast.hip)
 #pragma unroll
     for (int j = 0; j < EPL / 2; j++) {
       r.w[j] = pack2<DT>(y[2 * j], y[2 * j + 1]);
@@ -319,8 +316,12 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
   const int nv = nvf + (tail ? 1 : 0);
   const int i_tail = nvf / LPR;  // the per-lane slot that holds a row's partial vector
   const bool has_clamp = clamp_min > -INFINITY;  // torch.clamp(x, min=input_clamp) (torch_modules.py:989-994)
-  for (int64_t r0 = wave * (RPW * SUB); r0 < rows; r0 += n_waves * (RPW * SUB)) {
-    RowVec<DT, EPL> raw[RPW][VPL];
+  // PREFETCH (aligned rows with few vectors per lane): the NEXT iteration's rows are requested before the current ones are
+  // reduced, see layernorm_wave_kernel.  (Not for RAG rows: their overlapped last vectors make a row's stores touch bytes that a
+  // neighbouring lane of the SAME row loads -- fine within an iteration, where all loads precede the stores -- and in-place calls
+  // must keep that order.)
+  constexpr bool PREFETCH = false;  // measured slower on every shape, see layernorm_wave_kernel
+  auto load_rows = [&](int64_t r0, RowVec<DT, EPL> (&dst)[RPW][VPL]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
       const int64_t r = r0 + j * SUB + sub;
@@ -332,11 +333,21 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
           // the partial last vector of a row is read (and written) as the EPL elements that END at the row end: its first
           // `back` elements repeat the previous lane's last ones -- left out of the row sum below, stored twice with the same
           // value -- so a ragged row has no element-wise access (all of a row's loads precede its stores in this wave: in-place safe)
-          raw[j][i] = row_load_u<DT, EPL>(in, base + (v < nvf ? (int64_t)v * EPL : cols - EPL));
+          dst[j][i] = row_load_u<DT, EPL>(in, base + (v < nvf ? (int64_t)v * EPL : cols - EPL));
         } else {
-          raw[j][i] = row_load<DT, EPL>(in, base + (int64_t)(v < nvf ? v : nvf - 1) * EPL);
+          dst[j][i] = row_load<DT, EPL>(in, base + (int64_t)(v < nvf ? v : nvf - 1) * EPL);
         }
       }
+    }
+  };
+  RowVec<DT, EPL> raw[RPW][VPL], nxt[PREFETCH ? RPW : 1][PREFETCH ? VPL : 1];
+  if constexpr (PREFETCH) load_rows(wave * (RPW * SUB), raw);
+  for (int64_t r0 = wave * (RPW * SUB); r0 < rows; r0 += n_waves * (RPW * SUB)) {
+    if constexpr (PREFETCH) {
+      load_rows(r0 + n_waves * (RPW * SUB), nxt);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      load_rows(r0, raw);
     }
     float x[RPW][VPL][EPL], m[RPW], s[RPW];
 #pragma unroll
@@ -405,6 +416,12 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
         }
       }
     }
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int j = 0; j < RPW; j++)
+#pragma unroll
+        for (int i = 0; i < VPL; i++) raw[j][i] = nxt[j][i];
+    }
   }
 }
 
@@ -439,8 +456,13 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
       }
     }
   }
-  for (int64_t r0 = wave * (RPW * SUB); r0 < rows; r0 += n_waves * (RPW * SUB)) {
-    RowVec<DT, EPL> raw[RPW][VPL];
+  // PREFETCH (measured in round 3, OFF): short rows keep few bytes in flight per lane (768 bf16 elements: 3 vectors = 48 B), so a wave
+  // could request the rows of its NEXT iteration before it reduces the current ones.  It was SLOWER on every shape of
+  // tools/bench_rows.py -- layernorm 24000x768 16.1 -> 17.1 us, 65536x256 13.6 -> 15.5, softmax 18000x1500 21.6 -> 23.5 (profiles/
+  // r03_row_prefetch.txt): the extra live registers cost more occupancy than the deeper queue per wave buys.  The code path stays
+  // (compiled out) as the record of the experiment.
+  constexpr bool PREFETCH = false;
+  auto load_rows = [&](int64_t r0, RowVec<DT, EPL> (&dst)[RPW][VPL]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
       const int64_t r = r0 + j * SUB + sub;
@@ -448,8 +470,18 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
 #pragma unroll
       for (int i = 0; i < VPL; i++) {
         const int v = i * LPR + sl;
-        raw[j][i] = row_load<DT, EPL>(in, base + (int64_t)(v < nv ? v : nv - 1) * EPL);
+        dst[j][i] = row_load<DT, EPL>(in, base + (int64_t)(v < nv ? v : nv - 1) * EPL);
       }
+    }
+  };
+  RowVec<DT, EPL> raw[RPW][VPL], nxt[PREFETCH ? RPW : 1][PREFETCH ? VPL : 1];
+  if constexpr (PREFETCH) load_rows(wave * (RPW * SUB), raw);
+  for (int64_t r0 = wave * (RPW * SUB); r0 < rows; r0 += n_waves * (RPW * SUB)) {
+    if constexpr (PREFETCH) {
+      load_rows(r0 + n_waves * (RPW * SUB), nxt);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      load_rows(r0, raw);
     }
     float x[RPW][VPL][EPL], mean[RPW], rstd[RPW];
 #pragma unroll
@@ -508,6 +540,12 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
           }
         }
       }
+    }
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int j = 0; j < RPW; j++)
+#pragma unroll
+        for (int i = 0; i < VPL; i++) raw[j][i] = nxt[j][i];
     }
   }
 }
@@ -674,6 +712,13 @@ static int resident_grid(K kernel, int64_t wanted) {
 
 static inline int row_grid(int64_t rows) { return (int)(rows < 256 * 16 ? (rows < 1 ? 1 : rows) : 256 * 16); }
 
+// This file is compiled TWICE (build.py: -DDMXQ_EW_PART=1 / 2): softmax and the norms are ~150 kernel instantiations each.
+#ifndef DMXQ_EW_PART
+#define DMXQ_EW_PART 0
+#endif
+#define DMXQ_AP(P_) (DMXQ_EW_PART == 0 || DMXQ_EW_PART == (P_))
+
+#if DMXQ_AP(1)
 template <bool CAST>
 static int softmax_dispatch(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
                             float input_clamp_min, void* stream, const RowCastArg<CAST>& rc) {
@@ -754,6 +799,8 @@ extern "C" int dmxq_softmax(const void* in, void* out, int dtype_in, int dtype_o
   return softmax_dispatch<false>(in, out, dtype_in, dtype_out, rows, cols, input_clamp_min, stream, NoRowCast{});
 }
 
+#endif  // part 1 (softmax)
+
 // the two casts of a module around a row function: false = not a combination the fused kernels take
 static bool rowcast_of(int dtype, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, RowCast* rc) {
   *rc = RowCast{};
@@ -761,6 +808,7 @@ static bool rowcast_of(int dtype, const dmxq_float_fmt* cast_in, const dmxq_floa
   return range16_of(cast_in, dtype, &rc->ri) && range16_of(cast_out, dtype, &rc->ro);
 }
 
+#if DMXQ_AP(1)
 extern "C" int dmxq_softmax_cast(const void* in, void* out, int dtype, int64_t rows, int64_t cols, float input_clamp_min,
                                  const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* stream) {
   RowCast rc;
@@ -769,6 +817,9 @@ extern "C" int dmxq_softmax_cast(const void* in, void* out, int dtype, int64_t r
   return softmax_dispatch<true>(in, out, dtype, dtype, rows, cols, input_clamp_min, stream, rc);
 }
 
+#endif  // part 1
+
+#if DMXQ_AP(2)
 template <bool RMS, bool CAST = false>
 static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
                          const void* weight, const void* bias, int dtype_wb, float eps, void* stream, const RowCastArg<CAST>& rc = {}) {
@@ -780,6 +831,8 @@ static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out,
   const bool same = dtype_in == dtype_out && ((!weight && !bias) || dtype_wb == dtype_in);
   const int epl = same ? wave_epl(dtype_in, cols, in, out, weight, bias) : 0;
   const int full_epl = dtype_in == DMXQ_F32 ? 4 : 8;
+  // (round 3: the wave kernel at 512 vectors per row -- one wave per 4096-element bf16 row, 8 vectors per lane -- measured 15.6 us against
+  // this kernel's 13.4 us on 4096 x 4096)
   if (epl == full_epl && cols / epl > 256 && cols / epl <= 8 * kThreads) {  // long rows: workgroup per row
     const int64_t nv = cols / epl;
     const int vpl = (int)((nv + kThreads - 1) / kThreads);
@@ -871,3 +924,4 @@ extern "C" int dmxq_rmsnorm_cast(const void* in, void* out, int dtype, int64_t r
   if (!rowcast_of(dtype, cast_in, cast_out, &rc)) return DMXQ_ERR_UNSUPPORTED;
   return norm_dispatch<true, true>(in, out, dtype, dtype, rows, cols, weight, nullptr, dtype, eps, stream, rc);
 }
+#endif  // part 2 (norms)

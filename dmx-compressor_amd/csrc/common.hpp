@@ -340,6 +340,37 @@ __device__ __forceinline__ float div_for_clamped_int(float n, const Recip& c) {
   return __builtin_amdgcn_classf(q0, 0x001 | 0x002 | 0x004 | 0x200) ? q0 : q;  // sNaN, qNaN, -inf, +inf
 }
 
+// The affine integer cast  (clamp(rne'(x / d + z)) - z) * d  of N elements that share ONE scale (a vector inside a quantisation
+// group), two elements per instruction through the packed fp32 pipe: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 carry the
+// reciprocal quotient of div_for_clamped_int, the + z, the (a + 0.5f) - 0.5f rounding helper (sim_helper.cpp:14-21 in its fp32
+// form) and the dequantisation; v_rndne and the clamp (one v_med3) stay per element: ~7.5 VALU per element instead of ~13
+// (the kernel's time followed its VALU count, profiles/r02_pmc_second_tier.txt).  Same values bit for bit as the per-element form
+// for every FINITE quotient; a lane whose q0 is Inf / NaN (where the correction step and v_med3 are wrong: NaN must stay NaN)
+// reports `special` and the caller redoes its vector per element behind one cold wave-uniform branch.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int N>
+__device__ __forceinline__ bool affine_int_pairs(const float (&x)[N], float (&y)[N], float d, float rs, float z, float t_min, float t_max) {
+  static_assert(N % 2 == 0, "pairs");
+  bool special = false;
+#pragma unroll
+  for (int k = 0; k < N; k += 2) {
+    const f32x2 n2 = {x[k], x[k + 1]};
+    const f32x2 q0 = n2 * rs;
+    const f32x2 t = __builtin_elementwise_fma((f32x2){d, d}, q0, -n2);    // -(r): r = n - d q0, exact
+    const f32x2 q = __builtin_elementwise_fma(-t, (f32x2){rs, rs}, q0);
+    special = special || __builtin_amdgcn_classf(q0.x, 0x001 | 0x002 | 0x004 | 0x200) || __builtin_amdgcn_classf(q0.y, 0x001 | 0x002 | 0x004 | 0x200);
+    f32x2 u = q + z;
+    u = (u + 0.5f) - 0.5f;
+    f32x2 v;
+    v.x = __builtin_amdgcn_fmed3f(__builtin_rintf(u.x), t_min, t_max);
+    v.y = __builtin_amdgcn_fmed3f(__builtin_rintf(u.y), t_min, t_max);
+    const f32x2 o = (v - z) * d;
+    y[k] = o.x;
+    y[k + 1] = o.y;
+  }
+  return special;
+}
+
 // a value the program knows to be the same in every lane, moved to scalar registers (what follows it -- index arithmetic,
 // table loads -- then runs on the scalar unit / as s_load)
 __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
@@ -430,21 +461,24 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Range-only casts of bf16 words (elementwise.hip float_range_bf16_kernel, dmxq_binary_cast, dmxq_rope_cast): a FloatingPoint
 // format that keeps at least bf16's 7 mantissa bits only clamps the magnitude (Inf / NaN included: the reference reserves no codes
 // for them) and flushes what lies below its smallest normal value -- done on both halves of a dword at once.
-struct Range16 { uint32_t limit2, minb2; };  // both halves of a dword: clamp limit and smallest-normal threshold (bf16 bit patterns)
+typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
+struct Range16 { uint32_t limit2, minb2; };  // both halves of a dword: clamp limit, and (smallest-normal threshold - 1) as int16 (bit patterns of the 16-bit dtype)
 __device__ __forceinline__ uint32_t range16_word(uint32_t w, const Range16& r) {
-  const u16x2 a = __builtin_bit_cast(u16x2, w & 0x7FFF7FFFu);
-  const u16x2 cl = __builtin_elementwise_min(a, __builtin_bit_cast(u16x2, r.limit2));
+  const uint32_t aw = w & 0x7FFF7FFFu;
+  const u16x2 cl = __builtin_elementwise_min(__builtin_bit_cast(u16x2, aw), __builtin_bit_cast(u16x2, r.limit2));
   const uint32_t res = (w & 0x80008000u) | __builtin_bit_cast(uint32_t, cl);
-  // per half: keep iff |x| bits >= minb (saturating subtract -> 0 / non-zero -> 0 / 0xFFFF)
-  const u16x2 d = __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(a, (u16x2){1, 1}), __builtin_bit_cast(u16x2, r.minb2));
-  const u16x2 keep = __builtin_elementwise_min(d, (u16x2){1, 1}) * (u16x2){0xFFFF, 0xFFFF};
+  // per half: keep iff |x| bits >= minb  <=>  (minb - 1) - |x| < 0 as int16 (both below 2^15: no overflow) -> arithmetic shift = mask.
+  // v_and, v_pk_min_u16, v_and, v_pk_sub_i16, v_pk_ashrrev_i16, v_bitop3: 6 operations per dword (the saturating-subtract form
+  // compiled to two 16-bit compares, two selects and a permute: 10)
+  const i16x2 t = __builtin_bit_cast(i16x2, r.minb2) - __builtin_bit_cast(i16x2, aw);
+  const i16x2 keep = t >> (i16x2){15, 15};
   return res & __builtin_bit_cast(uint32_t, keep);
 }
 // false: this format is not a range-only cast of `dtype` values.  The reference's largest exponent is 2^(exp_bits-1) whatever the
 // bias (quant_cpu.cpp:359-402 through numerical/format.py:166-167), so its "FP16" saturates at 2^16 (2 - 2^-10), not at 65504.
 inline bool range16_of(const dmxq_float_fmt* f, int dtype, Range16* r) {
   if (dtype != DMXQ_BF16 && dtype != DMXQ_F16) return false;
-  if (!f || f->exp_bits == 0) { *r = Range16{0xFFFFFFFFu, 0u}; return true; }  // SAME: identity
+  if (!f || f->exp_bits == 0) { *r = Range16{0xFFFFFFFFu, 0xFFFFFFFFu}; return true; }  // SAME: identity (no limit, threshold 0)
   const int dman = dtype == DMXQ_BF16 ? 7 : 10;
   if (f->exp_bits < 1 || f->exp_bits > 8 || f->man_bits < dman || f->man_bits > 22 || !f->flush_subnormal) return false;
   const int min_exp = -(f->exp_bias - 1), max_u = 1 << (f->exp_bits - 1);  // unbiased exponents of the smallest / largest binade
@@ -465,7 +499,8 @@ inline bool range16_of(const dmxq_float_fmt* f, int dtype, Range16* r) {
     if (max_u + 15 < 1) return false;
     minb = min_exp >= -14 ? (uint32_t)(min_exp + 15) << 10 : (min_exp >= -24 ? 1u << (min_exp + 24) : 1u);  // normal / subnormal bits of 2^min_exp
   }
-  *r = Range16{limit | (limit << 16), minb | (minb << 16)};
+  const uint32_t m1 = (minb - 1u) & 0xFFFFu;
+  *r = Range16{limit | (limit << 16), m1 | (m1 << 16)};
   return true;
 }
 

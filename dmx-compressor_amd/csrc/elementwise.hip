@@ -108,7 +108,7 @@ template <int MODE, bool SIMPLE = false>
 struct FixedOp {
   static constexpr bool kHeavy = true;
   // clamped integer formats: no affine = ~6 VALU per element (one round of 512 x 16 tiles: 11.6 vs 12.7 us), with a scale 256 x 8
-  static constexpr int kTileUnroll = !SIMPLE ? 4 : (MODE == kNone ? 16 : 8);
+  static constexpr int kTileUnroll = !SIMPLE ? 4 : (MODE == kNone ? 16 : 8);  // (round 3: one round of 512 x 16 tiles with a per-group scale measured 16.7 us against 14.0 us for 256 x 8)
   FixedFmt f;
   ChannelMap cm;
   const float* scale;
@@ -203,7 +203,8 @@ struct FixedOp {
       const int64_t left = cm.C - it.g * cm.group_size;
       const int64_t run = (left < cm.group_size ? left : cm.group_size) * cm.inner;
       if (it.r * cm.inner + it.i + len > run) return false;
-      g = it.g;
+      g = uniform_i64(it.g);  // (the index arithmetic above ran on the vector unit: back to scalar registers, so that the two table
+                              // reads are s_load and not two more vector loads queued in front of the tile's own)
     }
     p.sc = scale[g];
     p.z = (float)zp[g];
@@ -222,8 +223,19 @@ struct FixedOp {
       // with a cold IEEE redo -- 15.0 vs 15.3 us, INT8 group_size 128 on 4096 x 4096 bf16 -- the opposite of the BFP kernels)
       if (SIMPLE && MODE != kNone && __builtin_amdgcn_ballot_w64(!recip_ok(sc)) == 0ull) {
         const float rs = 1.0f / sc;
+        if constexpr (N % 2 == 0) {
+          // pairs through the packed fp32 pipe (common.hpp affine_int_pairs); lanes holding an Inf / NaN quotient redo theirs
+          const bool special = affine_int_pairs<N>(x, y, sc, rs, z, f.t_min, f.t_max);
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {
+            if (special) {
 #pragma unroll
-        for (int k = 0; k < N; k++) y[k] = q<true>(x[k], sc, z, e0 + k, rs);
+              for (int k = 0; k < N; k++) y[k] = q<true>(x[k], sc, z, e0 + k, rs);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < N; k++) y[k] = q<true>(x[k], sc, z, e0 + k, rs);
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < N; k++) y[k] = q(x[k], sc, z, e0 + k);
@@ -308,7 +320,7 @@ struct ScaleOp {
       const int64_t left = cm.C - it.g * cm.group_size;
       const int64_t run = (left < cm.group_size ? left : cm.group_size) * cm.inner;
       if (it.r * cm.inner + it.i + len > run) return false;
-      g = it.g;
+      g = uniform_i64(it.g);
     }
     p.s = scale[g];
     return true;

@@ -63,8 +63,14 @@ __global__ __launch_bounds__(kFmThreads) void fixed_multi_kernel(const FixedMult
     widen<DTI, EPL>(raw[u], x);
     const float rs = 1.0f / sc[u];
     if (__builtin_amdgcn_ballot_w64(!recip_ok(sc[u])) == 0ull) {
+      // pairs through the packed fp32 pipe (common.hpp affine_int_pairs); lanes holding an Inf / NaN quotient redo theirs
+      const bool special = affine_int_pairs<EPL>(x, y, sc[u], rs, z[u], a.t_min, a.t_max);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0ull, 0)) {
+        if (special) {
 #pragma unroll
-      for (int j = 0; j < EPL; j++) y[j] = fixed_simple_q(x[j], sc[u], z[u], rs, true, a.t_min, a.t_max);
+          for (int j = 0; j < EPL; j++) y[j] = fixed_simple_q(x[j], sc[u], z[u], rs, true, a.t_min, a.t_max);
+        }
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < EPL; j++) y[j] = fixed_simple_q(x[j], sc[u], z[u], rs, false, a.t_min, a.t_max);

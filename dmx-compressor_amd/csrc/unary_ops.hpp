@@ -61,10 +61,14 @@ __device__ __forceinline__ float round_dt(float v) {  // RNE to DT and back (exa
 
 // FAST: 16-bit outputs -- v_exp_f32 + v_rcp_f32 (relative error ~2^-21, far inside the 2^-9 / 2^-12 half-ulp of the
 // output format); fp32 outputs keep expf and the IEEE division.
-template <bool FAST>
+// NOTAIL: the caller's output cast flushes everything below ~1e-30 to +0, which is where the far negative tail (t < -87) lands
+// whatever its last bits: x * rcp(d) = -0 there and the per-element branch around the IEEE division (five scalar instructions
+// and their wait states per element) goes away.
+template <bool FAST, bool NOTAIL = false>
 __device__ __forceinline__ float sigmoid_mul(float x, float t) {  // x * sigmoid(t)
   if (FAST) {
     const float d = 1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f);
+    if (NOTAIL) return x * __builtin_amdgcn_rcpf(d);
     // v_rcp_f32 flushes a denormal RESULT to zero (1 / d for d > 2^126): the far negative tail, where the true value
     // x / d is still a normal number (silu(-88) = -5.3e-37), takes the IEEE division instead (rare: t < -87)
     return d > 8.5e37f ? x / d : x * __builtin_amdgcn_rcpf(d);
@@ -72,14 +76,14 @@ __device__ __forceinline__ float sigmoid_mul(float x, float t) {  // x * sigmoid
   return x / (1.0f + expf(-t));
 }
 
-template <int KIND, int DTI, bool FAST>
+template <int KIND, int DTI, bool FAST, bool NOTAIL = false>
 struct UnaryOp {
   static constexpr bool kHeavy = true;
   static constexpr int kTileUnroll = KIND == DMXQ_UNARY_SILU ? 8 : (KIND == DMXQ_UNARY_QUICK_GELU ? 2 : 4);  // stream.hpp
   float param;
   __device__ __forceinline__ void apply_one(float x, float& y, int64_t) const {
     if (KIND == DMXQ_UNARY_SILU) {
-      y = sigmoid_mul<FAST>(x, x);
+      y = sigmoid_mul<FAST, NOTAIL>(x, x);
     } else if (KIND == DMXQ_UNARY_EXP) {
       if (FAST) {
         // v_exp_f32 flushes denormal RESULTS: below 2^-126 the argument is raised by 64 and the result scaled back (exact)
@@ -94,7 +98,7 @@ struct UnaryOp {
       float s;
       if (FAST && DTI != DMXQ_F32) {
         const float d = 1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f);
-        s = d > 8.5e37f ? 1.0f / d : __builtin_amdgcn_rcpf(d);  // (v_rcp_f32 flushes denormal results: see sigmoid_mul)
+        s = (!NOTAIL && d > 8.5e37f) ? 1.0f / d : __builtin_amdgcn_rcpf(d);  // (v_rcp_f32 flushes denormal results: see sigmoid_mul)
       } else {
         s = 1.0f / (1.0f + expf(-t));
       }

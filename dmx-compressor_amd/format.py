@@ -148,16 +148,27 @@ class FloatingPoint(Format):
         self.mantissa, self.exponent, self.bias = mantissa, exponent, bias
         self.flush_subnormal, self.unsigned, self.rounding = flush_subnormal, unsigned, rounding
 
+    def native_of(self):
+        """torch.float32 for FP[1|8|23,127](_N), torch.float16 for FP[1|5|10,15](_N) (the two formats the reference passes through
+        untouched when the tensor already has that dtype, format.py:209-212), else None.  Field compares: this sits on the hot path
+        of every cast call and building the shorthand string costs more than the kernel launch it guards."""
+        if self.flush_subnormal or self.unsigned or self.rounding != "nearest":
+            return None
+        if self.mantissa == 23 and self.exponent == 8 and self.bias == 127:
+            return torch.float32
+        if self.mantissa == 10 and self.exponent == 5 and self.bias == 15:
+            return torch.float16
+        return None
+
     def cast(self, x, block_dim: int = -1, out_dtype=torch.float32):
-        rep = repr(self)
+        native = self.native_of()
         # format.py:209-212: native formats pass the input tensor object through untouched
-        if (x.dtype == torch.float32 and rep == "FP[1|8|23,127](_N)") or (
-                x.dtype == torch.float16 and rep == "FP[1|5|10,15](_N)"):
+        if native is not None and x.dtype == native:
             return x
         if self.mantissa == 23:
-            if rep == "FP[1|8|23,127](_N)":  # FLOAT32 applied to a 16-bit tensor: exact widening (reference: UB)
+            if native == torch.float32:  # FLOAT32 applied to a 16-bit tensor: exact widening (reference: UB)
                 return x.to(out_dtype or torch.float32)
-            raise NotImplementedError(f"{rep}: a 23-bit mantissa through float_quantize is undefined in the reference")
+            raise NotImplementedError(f"{self!r}: a 23-bit mantissa through float_quantize is undefined in the reference")
         # the extra fp16 subnormal flush of format.py:222-232 is implied by flush_subnormal on this path
         return ops.float_qdq(x, self.mantissa, self.exponent, self.bias, self.flush_subnormal, self.unsigned,
                              self.rounding, out_dtype=out_dtype)

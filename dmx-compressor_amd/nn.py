@@ -27,7 +27,7 @@ from .sparse import Dense, Sparsify
 
 __all__ = ["DmxModule", "DmxQuantizerCalibrationHyperparams", "DmxModuleQuantizerCalibrationHyperparams",
            "DmxModuleSmoothQuantHyperparams", "Linear", "Conv1d", "Conv2d", "ResAdd", "ActActMatMul", "Softmax", "LayerNorm", "GELU", "ReLU", "SiLU", "QuickGELU", "Exp", "Mul", "RMSNorm", "ApplyRotaryPosEmb",
-           "MaxPool2d", "AvgPool2d", "Embedding", "DmxConfigRule", "configure_model", "fold_weights_and_biases"]
+           "MaxPool2d", "AvgPool2d", "Embedding", "DmxConfigRule", "configure_model", "fold_weights_and_biases", "GraphedForward"]
 
 
 class _LazySparsify(Sparsify):
@@ -558,9 +558,8 @@ def _range_only_format(cast, dtype):
         return (not cast.pre_transform), None
     if (not isinstance(fmt, FloatingPoint) or cast.pre_transform or not cast._flag("fake_quant_enabled") or cast._flag("observer_enabled")):
         return False, None
-    rep = repr(fmt)
     # format.py:209-212: the dtype's own format passes the tensor through untouched (no flush, NaN stays NaN) -- SAME for the kernel
-    if (dtype == torch.float32 and rep == "FP[1|8|23,127](_N)") or (dtype == torch.float16 and rep == "FP[1|5|10,15](_N)"):
+    if fmt.native_of() == dtype:
         return True, None
     if fmt.mantissa == 23:
         return False, None
@@ -937,6 +936,49 @@ def fold_weights_and_biases(model: torch.nn.Module) -> torch.nn.Module:
             if isinstance(m, DmxModule):
                 m.fold_weight_and_bias()
     return model
+
+
+class GraphedForward:
+    """A configured model's inference forward as ONE hipGraph replay.
+
+    Small layers are HOST-bound in eager mode: an opt-125m decoder layer under the BASIC rules is ~60 launches of a few microseconds
+    each, and Python + dispatcher + hipLaunchKernel cost more than the kernels (775 us eager vs 258 us of GPU time per forward,
+    profiles/r03_layer_opt125m.json).  Every launch of this library goes to torch's current stream with no host synchronisation
+    (DESIGN.md §6.7), so a forward can be captured once and replayed:
+
+        g = GraphedForward(model, example_x)          # warm-up forwards on a side stream, then capture
+        y = g(x)                                       # copies x into the static input, replays, returns the static output
+
+    Static shapes and dtypes (one graph per input signature); the returned tensors are the graph's own buffers and are
+    overwritten by the next call -- clone what must outlive it.  Inference only (captured under torch.no_grad); calibration
+    (observers, SmoothQuant `calibrating`) and stochastic rounding with an implicit seed must be done before capture."""
+
+    def __init__(self, model: torch.nn.Module, *example_inputs: torch.Tensor, warmup: int = 3):
+        if not example_inputs or not all(isinstance(t, torch.Tensor) and t.is_cuda for t in example_inputs):
+            raise ValueError("GraphedForward: tensor inputs on the GPU required")
+        self.model = model
+        self.static_in = [t.detach().clone() for t in example_inputs]
+        dev = self.static_in[0].device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.no_grad(), torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):   # lazily created state (scores, allocator pools, rocBLAS workspaces) before the capture
+                model(*self.static_in)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side):
+                self.static_out = model(*self.static_in)
+        torch.cuda.current_stream(dev).wait_stream(side)
+
+    def __call__(self, *inputs: torch.Tensor):
+        if len(inputs) != len(self.static_in):
+            raise ValueError(f"GraphedForward: captured with {len(self.static_in)} inputs, called with {len(inputs)}")
+        for dst, src in zip(self.static_in, inputs):
+            if src.shape != dst.shape or src.dtype != dst.dtype or src.device != dst.device:
+                raise ValueError(f"GraphedForward: captured for {tuple(dst.shape)} {dst.dtype} on {dst.device}, got {tuple(src.shape)} {src.dtype} on {src.device}")
+            dst.copy_(src)
+        self.graph.replay()
+        return self.static_out
 
 
 def configure_model(model: torch.nn.Module, *rules: DmxConfigRule):

@@ -159,3 +159,30 @@ def test_pending_foreign_hip_error_is_reported_not_swallowed(dmx, cuda):
     hip.hipGetLastError()                                             # ... who collects it
     assert L.dmxq_bfp_qdq(*args) == 0
     torch.cuda.synchronize()
+
+
+def test_graphed_forward_replays_a_configured_layer(dmx, cuda):
+    """nn.GraphedForward: an opt-125m-sized block under the BASIC rules captured once and replayed -- same bits as the eager forward,
+    new inputs picked up through the static buffer, shape changes refused."""
+    nn = dmx.nn
+
+    class Block(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ln, self.fc1, self.act, self.fc2, self.res = nn.LayerNorm(256), nn.Linear(256, 1024), nn.GELU(), nn.Linear(1024, 256), nn.ResAdd()
+
+        def forward(self, x):
+            return self.res(self.fc2(self.act(self.fc1(self.ln(x)))), x)
+
+    torch.manual_seed(0)
+    m = Block().to(cuda).eval()
+    dmx.configure_model(m, *dmx.config_rules.BASIC)
+    x1, x2 = make("normal", (4, 64, 256), seed=1).to(cuda), make("normal", (4, 64, 256), seed=2).to(cuda)
+    with torch.no_grad():
+        e1, e2 = m(x1), m(x2)
+    g = nn.GraphedForward(m, x1)
+    y1 = g(x1).clone()
+    y2 = g(x2).clone()
+    assert torch.equal(y1, e1) and torch.equal(y2, e2) and not torch.equal(y1, y2)
+    with pytest.raises(ValueError):
+        g(x1[:2])

@@ -127,8 +127,10 @@ def main():
             lambda i: L.dmxq_nm_mask(vp(ss[i].data_ptr()), _lib.F32, None, 0, vp(yf[i].data_ptr()), _lib.F32, None, 0, R, C, 1, K_, M_, sp), k2, n * 8)
         run(f"nm_sparsify {K_}:{M_} fp32 score, bf16 x -> bf16 y (fused apply)",
             lambda i: L.dmxq_nm_mask(vp(ss[i].data_ptr()), _lib.F32, vp(xs[i].data_ptr()), _lib.BF16, None, 0, vp(ys[i].data_ptr()), _lib.BF16, R, C, 1, K_, M_, sp), k2, n * 8)
-    run("nm_sparsify 2:4 bf16 score(|w|) -> bf16 y",
-        lambda i: L.dmxq_nm_mask(vp(xs[i].data_ptr()), _lib.BF16, vp(xs[i].data_ptr()), _lib.BF16, None, 0, vp(ys[i].data_ptr()), _lib.BF16, R, C, 1, 2, 4, sp), k, n * 4)
+    # a |w| score is its own tensor (Sparsify's score_func materialises it, sparse.py:287-294): score + x + y = 6 B/element.  (Rounds 1-2
+    # passed the SAME buffer as score and x and counted 4 B/element: the second read was an L2 hit and the row read 56 %.)
+    run("nm_sparsify 2:4 bf16 score(|w|), bf16 x -> bf16 y (6 B/elem)",
+        lambda i: L.dmxq_nm_mask(vp(xs[(i + 1) % k].data_ptr()), _lib.BF16, vp(xs[i].data_ptr()), _lib.BF16, None, 0, vp(ys[i].data_ptr()), _lib.BF16, R, C, 1, 2, 4, sp), k, n * 6)
     # ---------------------------------------------------------------- fused weight hypernet (mask -> scale -> BFP)
     sq = (torch.rand(C, device=dev) + 0.5)
     run("weight_hypernet 2:4 mask + BFP16_64, bf16 w, fp32 score -> bf16 (vs 3 unfused passes)",
