@@ -227,7 +227,8 @@ def summarise(path):
     rows = []
     for r in csv.DictReader(open(files[0])):
         nm, ns, calls = r["Name"], float(r["TotalDurationNs"]), int(r["Calls"])
-        k = "dmxq" if "dmxq::" in nm else ("gemm" if any(t in nm for t in ("Cijk_", "gemm", "Gemm", "GEMM")) else "other")
+        ours = "dmxq::" in nm or any(t in nm for t in ("fused_cast_generic_kernel", "binary_range_bf16_kernel", "float_range_bf16_kernel"))
+        k = "dmxq" if ours else ("gemm" if any(t in nm for t in ("Cijk_", "gemm", "Gemm", "GEMM")) else "other")
         tot[k][0] += ns
         tot[k][1] += calls
         rows.append((ns, calls, k, nm))

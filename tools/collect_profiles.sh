@@ -2,7 +2,7 @@
 # tools/collect_profiles.sh <round tag, e.g. r02> — everything under profiles/ that is measured on the GPU box, in one go.
 # Run through gpurun from the repo root; results land in gpurun_out/<tag>/ and are copied to profiles/ by hand.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -13,11 +13,19 @@ python3 bench.py --no-cpu-baseline > $OUT/bench_line_default.json 2>> $OUT/bench
 python3 bench.py --workload llama-shard --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_llama_hypernet.json 2>> $OUT/bench.err
 python3 bench.py --workload llama-shard --op bfp --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_llama_bfp.json 2>> $OUT/bench.err
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_torchrun1.json 2>> $OUT/bench.err
+python3 bench.py --gpus 1 --spawn --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_spawn1.json 2>> $OUT/bench.err
+for mdl in opt125m llama whisper; do python3 bench.py --workload layer --model $mdl > $OUT/layer_$mdl.json 2>> $OUT/bench.err; done
 # 2. rocprofv3 kernel statistics of the driver's command, and the two HBM traffic passes (separate, --kernel-trace only)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/prof_bench -o run --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_bench.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o run --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --replays 3 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o run --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --replays 3 > $OUT/pmc_write.log 2>&1
+# (--no-resident --no-check: the trace then holds ROTATING-buffer launches of the hot kernel only -- VERDICT r2 weak-5)
+rocprofv3 --kernel-trace --stats -d $OUT/prof_bench -o run --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-resident --no-check > $OUT/prof_bench.log 2>&1
+for mdl in opt125m llama whisper; do
+  rocprofv3 --kernel-trace --stats -d $OUT/prof_layer_$mdl -o run --output-format csv -- python3 $R/bench.py --workload layer --model $mdl --layer-modes live > $OUT/prof_layer_$mdl.log 2>&1
+  python3 $R/tools/bench_layer.py --summarise $OUT/prof_layer_$mdl > $OUT/layer_shares_$mdl.txt 2>&1
+  rm -rf $OUT/prof_layer_$mdl
+done
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o run --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-resident --no-check --replays 3 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o run --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-resident --no-check --replays 3 > $OUT/pmc_write.log 2>&1
 cd $R
 python3 - "$OUT" <<'PY'
 import csv, glob, json, os, sys
@@ -32,7 +40,7 @@ def counter(d, name):
 fe, wr = counter("pmc_fetch", "FETCH_SIZE"), counter("pmc_write", "WRITE_SIZE")
 if fe and wr:
     rd, ww = 2 * sum(fe) / len(fe) * 1024, sum(wr) / len(wr) * 1024
-    json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --replays 3`, "
+    json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-resident --no-check --replays 3`, "
                          f"mean over {len(fe)} / {len(wr)} dispatches of dmxq::bfp_rows_kernel (4096x4096 bf16)",
                "FETCH_SIZE_KB_raw": round(sum(fe) / len(fe), 2), "WRITE_SIZE_KB_raw": round(sum(wr) / len(wr), 2),
                "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for 16 B/lane streaming reads -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact for 16 B/lane stores",
@@ -50,7 +58,7 @@ rm -rf $OUT/prof_bench $OUT/pmc_fetch $OUT/pmc_write
 python3 tools/bench_shapes.py > $OUT/secondary_shapes.txt 2>&1
 python3 tools/bench_ops.py > $OUT/ops_roofline_table.txt 2>&1
 python3 tools/bench_rows.py > $OUT/row_ops.txt 2>&1
-bash tools/collect_pmc.sh gpurun_out/$TAG/pmc "per-channel along last,group_size=128,group_minmax,channel_maxabs,bf16 score,SBFP12,rnd=3,histc,bfloat16->bfloat16 B=16 wl=8 sym rnd=2,scale_channels,layernorm,rmsnorm" > /dev/null 2>&1
+bash tools/collect_pmc.sh gpurun_out/$TAG/pmc "per-channel along last,group_size=128,group_minmax,channel_maxabs,bf16 score,SBFP12,rnd=3,histc,bfloat16->bfloat16 B=16 wl=8 sym rnd=2,scale_channels,layernorm,rmsnorm,softmax,unary,_cast,E4M3,block_dim=-2" > /dev/null 2>&1
 python3 -m pytest tests/test_gpu_round2.py -m gpu -q -k host_overhead > $OUT/host_overhead.log 2>&1
 cp gpurun_out/host_overhead.txt $OUT/host_overhead.txt 2>/dev/null
 ls -la $OUT
