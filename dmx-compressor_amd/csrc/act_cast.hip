@@ -26,7 +26,7 @@ namespace dmxq {
 template <class BASE, int DT>
 struct CastedOp {
   static constexpr bool kHeavy = true;
-  static constexpr int kTileUnroll = BASE::kTileUnroll;
+  static constexpr int kTileUnroll = DT == DMXQ_F32 ? BASE::kTileUnrollF32 : BASE::kTileUnroll;
   static constexpr bool kRawHooks = DT != DMXQ_F32;
   BASE base;
   Range16 ri, ro;  // 16-bit tensors

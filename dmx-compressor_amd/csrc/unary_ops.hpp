@@ -20,7 +20,10 @@ namespace dmxq {
 template <bool FAST, bool TANH>
 struct GeluOp {
   static constexpr bool kHeavy = true;
-  static constexpr int kTileUnroll = 2;
+  // tile geometry (stream.hpp), measured on 4096 x 4096 in round 3 after the arithmetic moved to the packed pipe: bf16 256 x 8 13.2 us vs
+  // 256 x 2 13.9; the float32 module form (act_cast.hip, 4 elements per vector) 256 x 2 25.3 us vs 256 x 8 27.5
+  static constexpr int kTileUnroll = FAST ? 8 : 2;
+  static constexpr int kTileUnrollF32 = 2;
   __device__ __forceinline__ void apply_one(float x, float& y, int64_t) const {
     if (TANH) {
       const float k0 = 0.7978845608028654f, k1 = 0.044715f;
@@ -45,10 +48,50 @@ struct GeluOp {
       y = 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
     }
   }
+  // FAST, two elements per instruction through the packed fp32 pipe (v_pk_mul / v_pk_fma / v_pk_add_f32: these kernels are bound by
+  // VALU issue, ~4 cycles per wave instruction, not by HBM -- profiles/r03_pmc_second_tier.txt): 11.5 instead of ~22 VALU per element.
+  //   erf form : gelu = x Phi(x), Phi = x > 0 ? 1 - h : h with h = erfc(|x| / sqrt 2) / 2 -- the select sits on Phi, so +inf gives
+  //              inf * 1, -inf gives -inf * 0 = NaN (as torch's 0.5 x (1 + erf)), -0 gives -0 * 0.5 and NaN propagates, with no
+  //              special cases; relative accuracy in the negative tail as before (h is formed without cancellation);
+  //   tanh form: x / (1 + exp(-2u)), u = k0 x (1 + k1 x^2).
+  __device__ __forceinline__ f32x2 apply_pair(f32x2 x) const {
+    if (TANH) {
+      const f32x2 x2 = x * x;
+      const f32x2 w = __builtin_elementwise_fma(x2, (f32x2){0.044715f, 0.044715f}, (f32x2){1.0f, 1.0f}) * x;   // x (1 + k1 x^2)
+      const f32x2 a = w * (0.7978845608028654f * -2.8853900817779268f);                                          // -2 u log2 e
+      f32x2 d = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+      d = d + 1.0f;
+      const f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+      return x * r;
+    }
+    const f32x2 ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
+    const f32x2 z = ax * 0.7071067811865476f;
+    const f32x2 den = __builtin_elementwise_fma(z, (f32x2){0.3275911f, 0.3275911f}, (f32x2){1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    f32x2 p = __builtin_elementwise_fma(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(t, p, (f32x2){1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(t, p, (f32x2){-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(t, p, (f32x2){0.254829592f, 0.254829592f});
+    const f32x2 a = (z * z) * -1.4426950408889634f;
+    const f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    const f32x2 h = ((p * t) * e) * 0.5f;            // erfc / 2
+    const f32x2 g = 1.0f - h;
+    const f32x2 phi = {x.x > 0.0f ? g.x : h.x, x.y > 0.0f ? g.y : h.y};
+    return x * phi;
+  }
   template <int N>
   __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
+    if constexpr (FAST && N % 2 == 0) {
 #pragma unroll
-    for (int k = 0; k < N; k++) apply_one(x[k], y[k], e0 + k);
+      for (int k = 0; k < N; k += 2) {
+        const f32x2 r = apply_pair((f32x2){x[k], x[k + 1]});
+        y[k] = r.x;
+        y[k + 1] = r.y;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; k++) apply_one(x[k], y[k], e0 + k);
+    }
   }
 };
 
@@ -80,6 +123,7 @@ template <int KIND, int DTI, bool FAST, bool NOTAIL = false>
 struct UnaryOp {
   static constexpr bool kHeavy = true;
   static constexpr int kTileUnroll = KIND == DMXQ_UNARY_SILU ? 8 : (KIND == DMXQ_UNARY_QUICK_GELU ? 2 : 4);  // stream.hpp
+  static constexpr int kTileUnrollF32 = kTileUnroll;
   float param;
   __device__ __forceinline__ void apply_one(float x, float& y, int64_t) const {
     if (KIND == DMXQ_UNARY_SILU) {
@@ -112,8 +156,22 @@ struct UnaryOp {
   }
   template <int N>
   __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
+    if constexpr (KIND == DMXQ_UNARY_SILU && FAST && NOTAIL && N % 2 == 0) {
+      // x / (1 + exp(-x)) on pairs (packed fp32 pipe: GeluOp::apply_pair): 3.5 VALU per element
 #pragma unroll
-    for (int k = 0; k < N; k++) apply_one(x[k], y[k], e0 + k);
+      for (int k = 0; k < N; k += 2) {
+        const f32x2 v = {x[k], x[k + 1]};
+        const f32x2 a = v * -1.4426950408889634f;
+        f32x2 d = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+        d = d + 1.0f;
+        const f32x2 r = v * (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        y[k] = r.x;
+        y[k + 1] = r.y;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; k++) apply_one(x[k], y[k], e0 + k);
+    }
   }
 };
 

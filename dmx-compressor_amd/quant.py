@@ -65,7 +65,25 @@ def _mk(rounding):
     )
 
 
+def _fixed_mask(a, wl, fl, symmetric, rounding):
+    """fixed_point_quantize_{nearest,stochastic}_mask (quant_cpu.cpp:86-126, exported at :424-440): (clamped result, uint8 mask of the
+    elements the clamp changed).  Unreachable from the reference's Python wrappers, part of the pybind seam: composed here from the
+    clamped and the unclamped cast (the same random draws for both through one explicit seed) and two compares against
+    sim_helper.cpp:5-12's limits -- two launches of dmxq_fixed_qdq plus torch's compare kernels, not a hot path."""
+    _check_native_input(a, "fixed_point_quantize_mask")
+    seed = ops._next_seed() if rounding == "stochastic" else 0
+    o = ops.fixed_qdq(a, wl, fl, True, symmetric, rounding, seed=seed)
+    u = ops.fixed_qdq(a, wl, fl, False, symmetric, rounding, seed=seed)
+    t_min = -(2.0 ** (wl - fl - 1))
+    t_max = -t_min - 2.0 ** (-fl)
+    if symmetric:
+        t_min += 2.0 ** (-fl)
+    return o, ((u > t_max) | (u < t_min)).to(torch.uint8)
+
+
 quant_hip = SimpleNamespace()
+quant_hip.fixed_point_quantize_nearest_mask = lambda a, wl, fl, symmetric: _fixed_mask(a, wl, fl, symmetric, "nearest")
+quant_hip.fixed_point_quantize_stochastic_mask = lambda a, wl, fl, symmetric: _fixed_mask(a, wl, fl, symmetric, "stochastic")
 for _r in ("nearest", "stochastic", "down", "up"):
     _f = _mk(_r)
     setattr(quant_hip, f"block_quantize_{_r}", _f["block"])

