@@ -186,3 +186,34 @@ def test_graphed_forward_replays_a_configured_layer(dmx, cuda):
     assert torch.equal(y1, e1) and torch.equal(y2, e2) and not torch.equal(y1, y2)
     with pytest.raises(ValueError):
         g(x1[:2])
+
+
+def test_round3_entry_points_through_both_bindings(dmx, cuda):
+    """the round-3 entry points (fused activation / normalisation modules, the strided weight chain) return identical bits through
+    the torch extension and the ctypes binding -- the same C ABI behind both"""
+    from dmx_compressor_amd import _ops_ctypes as C
+    from dmx_compressor_amd import _ops_torch as T
+    f16, b16 = dmx.Format.from_shorthand("FP[1|5|10,15](FN)"), dmx.Format.from_shorthand("FP[1|8|7,127](FN)")
+    x = (make("normal", (96, 512), seed=1) * 3).to(BF16).to(cuda)
+    xf = (make("heavy", (64, 384), seed=2)).clamp(-1e4, 1e4).to(cuda)
+    w = torch.randn(512, device=cuda).to(BF16)
+    wf = torch.randn(384, device=cuda)
+    conv = (make("normal", (32, 24, 3, 3), seed=3) * 0.1).to(cuda)
+    score = make("normal", (32, 24, 3, 3), seed=4).abs().to(cuda)
+    sq = (torch.rand(24, device=cuda) + 0.5)
+    cases = [
+        lambda o: o.unary_cast(x, "gelu", f16, f16), lambda o: o.unary_cast(x, "silu", f16, None), lambda o: o.unary_cast(xf, "quick_gelu", b16, f16),
+        lambda o: o.unary_cast(xf, "exp", None, f16), lambda o: o.unary_cast(x, "gelu_tanh", None, None),
+        lambda o: o.softmax_cast(x, -1, f16, f16), lambda o: o.softmax_cast(xf, -1, f16, f16, input_clamp=-2.0),
+        lambda o: o.layernorm_cast(x, 512, w, w, 1e-5, f16, f16), lambda o: o.layernorm_cast(xf, 384, wf, None, 1e-5, f16, b16),
+        lambda o: o.rmsnorm_cast(x, 512, w, 1e-6, f16, f16), lambda o: o.rmsnorm_cast(xf, 384, None, None, None, f16),
+        lambda o: o.weight_hypernet(conv, 8, 16, True, score, 2, 4, sq, block_dim=1), lambda o: o.weight_hypernet(conv.to(BF16), 4, 8, False, None, 0, 0, sq, block_dim=1),
+    ]
+    for i, f in enumerate(cases):
+        a, b = f(C), f(T)
+        assert a is not None and b is not None, i
+        assert a.dtype == b.dtype and a.shape == b.shape and bits_equal(a, b) == 0, f"case {i}"
+    # not fusable -> None from both (a rounding cast on a 16-bit tensor; softmax over another dim)
+    e4m3 = dmx.Format.from_shorthand("FP[1|4|3,7](_N)")
+    for o in (C, T):
+        assert o.unary_cast(x, "gelu", e4m3, f16) is None and o.softmax_cast(x, 0, f16, f16) is None
