@@ -64,7 +64,19 @@ int main(int argc, char** argv) {
     int g = (GRID) > 0 ? (GRID) : (int)((n_vec + (int64_t)T * U - 1) / ((int64_t)T * U)); \
     hipLaunchKernelGGL((copy_kernel<U, M, T>), dim3(g), dim3(T), 0, q, i, o, n_vec); }, {}})
   // G0 = exact grid.  M bits: 1 nt-load, 2 nt-store, 4 sc1-store, 8 sc0-store (copy: 4 = workgroup-contiguous tiles; bfp is always tiled)
-  if (getenv("TUNE_SET") && std::string(getenv("TUNE_SET")) == "sweep") {
+#define ADD_BFPB(ASYM_, LPB_, LPBC_) vs.push_back({"bfp  512x16 " #ASYM_ " lpb" #LPB_ " lpbc" #LPBC_, [=](const void* i, void* o, hipStream_t q) { \
+    int g = (int)((n_vec + (int64_t)512 * 16 - 1) / ((int64_t)512 * 16)); \
+    hipLaunchKernelGGL((bfp_rows_kernel<DMXQ_BF16, DMXQ_BF16, DMXQ_ROUND_NEAREST, ASYM_, 16, 3, 512, 2, 16, 16, LPBC_>), dim3(g), dim3(512), 0, q, i, o, n_vec, LPB_, 8, 2, 0ull); }, {}})
+  if (getenv("TUNE_SET") && std::string(getenv("TUNE_SET")) == "blocks") {
+    // round 3: block size 64 / 128 (8 / 16 lanes per block), symmetric vs asymmetric, lane count compile-time vs run-time
+    ADD_COPY(16, 7, 512, 0);
+    ADD_BFPB(false, 2, 0); ADD_BFPB(false, 8, 0); ADD_BFPB(true, 8, 0); ADD_BFPB(false, 16, 0); ADD_BFPB(true, 16, 0); ADD_BFPB(false, 4, 0);
+    ADD_BFPB(false, 8, 8); ADD_BFPB(true, 8, 8); ADD_BFPB(false, 2, 2); ADD_BFPB(true, 2, 0);
+  } else if (getenv("TUNE_SET") && std::string(getenv("TUNE_SET")) == "small") {
+    ADD_COPY(2, 7, 512, 0); ADD_COPY(4, 7, 512, 0);
+    ADD_BFPG(1, 3, 512, 0, 2, 1); ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPG(3, 3, 512, 0, 2, 3); ADD_BFPG(4, 3, 512, 0, 2, 4); ADD_BFPG(6, 3, 512, 0, 2, 6); ADD_BFPG(8, 3, 512, 0, 2, 8);
+    ADD_BFPG(2, 3, 128, 0, 2, 2); ADD_BFPG(1, 3, 256, 0, 2, 1); ADD_BFPG(2, 3, 256, 0, 2, 2); ADD_BFPG(4, 3, 256, 0, 2, 4); ADD_BFPG(8, 3, 256, 0, 2, 8);
+  } else if (getenv("TUNE_SET") && std::string(getenv("TUNE_SET")) == "sweep") {
     // tile-plan continuity (round 3): the one-round shapes against the multi-round 512x2 just above the 32 MiB headline size
     ADD_COPY(2, 7, 512, 0); ADD_COPY(16, 7, 512, 0);
     ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPG(4, 3, 512, 0, 2, 4); ADD_BFPG(8, 3, 512, 0, 2, 8); ADD_BFPG(16, 3, 512, 0, 2, 16);
