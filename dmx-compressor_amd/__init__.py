@@ -72,9 +72,10 @@ def _rule_sets():
     `dmx_compressor_amd.nn`.  Each row: module types -> (input formats, weight, bias, output formats)."""
     f = format
     S, F16, B64 = f.SAME, f.FLOAT16, f.BFP16_64
-    conv_like = (nn.Conv1d, nn.Conv2d)
-    act_like = (nn.Softmax, nn.LayerNorm, nn.GELU, nn.ReLU, nn.SiLU, nn.QuickGELU, nn.RMSNorm, nn.Exp)
-    pools = (nn.MaxPool2d, nn.AvgPool2d)
+    conv_like = (nn.Conv1d, nn.Conv2d, nn.ConvTranspose2d)
+    act_like = (nn.Softmax, nn.LayerNorm, nn.GELU, nn.ReLU, nn.SiLU, nn.QuickGELU, nn.RMSNorm, nn.Exp, nn.ReLU6, nn.Tanh, nn.NewGELU,
+                nn.FastGELU, nn.BloomGELU, nn.ClippedGELU, nn.BatchNorm2d, nn.GroupNorm)
+    pools = (nn.MaxPool2d, nn.AvgPool2d, nn.AdaptiveAvgPool2d)
 
     def wb(inp, w, b, out):
         return dict(input_formats=[inp], weight_format=w, bias_format=b, output_formats=[out])

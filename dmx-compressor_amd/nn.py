@@ -27,7 +27,9 @@ from .sparse import Dense, Sparsify
 
 __all__ = ["DmxModule", "DmxQuantizerCalibrationHyperparams", "DmxModuleQuantizerCalibrationHyperparams",
            "DmxModuleSmoothQuantHyperparams", "Linear", "Conv1d", "Conv2d", "ResAdd", "ActActMatMul", "Softmax", "LayerNorm", "GELU", "ReLU", "SiLU", "QuickGELU", "Exp", "Mul", "RMSNorm", "ApplyRotaryPosEmb",
-           "MaxPool2d", "AvgPool2d", "Embedding", "DmxConfigRule", "configure_model", "fold_weights_and_biases", "GraphedForward"]
+           "MaxPool2d", "AvgPool2d", "Embedding", "ReLU6", "Tanh", "Dropout", "NewGELU", "FastGELU", "BloomGELU", "ClippedGELU", "AdaptiveAvgPool2d",
+           "BatchNorm2d", "GroupNorm", "ConvTranspose2d", "BAddBMM", "ScaledDotProductAttention", "DmxConfigRule", "configure_model",
+           "fold_weights_and_biases", "GraphedForward"]
 
 
 class _LazySparsify(Sparsify):
@@ -840,6 +842,200 @@ class ReLU(DmxModule, torch.nn.ReLU):
             return None
         from . import ops
         return ops.relu_cast(x.detach(), fi, fo)
+
+
+# ---- the remaining module types of modeling/nn/torch_modules.py and custom_modules.py (round 3): each is torch's own op between this
+# library's casts (the general DmxModule.forward), so that a model built for the reference's module set configures and runs here.
+class ReLU6(DmxModule, torch.nn.ReLU6):
+    """torch_modules.py:1501-1557"""
+
+    def __init__(self, inplace: bool = False):
+        torch.nn.ReLU6.__init__(self, inplace=False)
+        self._dmx_init()
+        self.functional_forward = F.relu6
+
+    def _forward(self, _input):
+        return self.approx_forward((_input,))
+
+
+class Tanh(DmxModule, torch.nn.Tanh):
+    """torch_modules.py:1619-1673"""
+
+    def __init__(self):
+        torch.nn.Tanh.__init__(self)
+        self._dmx_init()
+        self.functional_forward = torch.tanh
+
+    def _forward(self, _input):
+        return self.approx_forward((_input,))
+
+
+class Dropout(DmxModule, torch.nn.Dropout):
+    """torch_modules.py:1379-1440: F.dropout(x, p, training, inplace) between the casts (identity in eval mode)"""
+
+    def __init__(self, p: float = 0.5, inplace: bool = False):
+        torch.nn.Dropout.__init__(self, p=p, inplace=False)
+        self._dmx_init()
+        self.functional_forward = lambda x: F.dropout(x, self.p, self.training, False)
+
+    def _forward(self, _input, *args, **kwargs):
+        return self.approx_forward((_input,))
+
+
+class _GELUVariant(DmxModule):
+    """custom_modules.py:96-140 (GELUBase subclasses over transformers' activation classes): the formulas of transformers.activations,
+    evaluated in the input dtype by torch like the originals"""
+
+    def __init__(self):
+        torch.nn.Module.__init__(self)
+        self._dmx_init()
+        self.functional_forward = self._f
+
+    def _forward(self, _input):
+        return self.approx_forward((_input,))
+
+
+class NewGELU(_GELUVariant):
+    @staticmethod
+    def _f(x):  # NewGELUActivation
+        return 0.5 * x * (1.0 + torch.tanh(0.7978845608028654 * (x + 0.044715 * torch.pow(x, 3.0))))
+
+
+class FastGELU(_GELUVariant):
+    @staticmethod
+    def _f(x):  # FastGELUActivation
+        return 0.5 * x * (1.0 + torch.tanh(x * 0.7978845608 * (1.0 + 0.044715 * x * x)))
+
+
+class BloomGELU(_GELUVariant):
+    @staticmethod
+    def _f(x):  # transformers.models.bloom.modeling_bloom.BloomGelu (inference form)
+        return x * 0.5 * (1.0 + torch.tanh(0.79788456 * x * (1 + 0.044715 * x * x)))
+
+
+class ClippedGELU(_GELUVariant):
+    def __init__(self, min: float = -10.0, max: float = 10.0):
+        self.min, self.max = min, max
+        super().__init__()
+
+    def _f(self, x):  # ClippedGELUActivation
+        return torch.clip(F.gelu(x), self.min, self.max)
+
+
+class AdaptiveAvgPool2d(DmxModule, torch.nn.AdaptiveAvgPool2d):
+    """torch_modules.py:829-865"""
+
+    def __init__(self, output_size):
+        torch.nn.AdaptiveAvgPool2d.__init__(self, output_size)
+        self._dmx_init()
+
+    def _forward(self, _input):
+        return torch.nn.AdaptiveAvgPool2d.forward(self, _input)
+
+
+class BatchNorm2d(DmxModule, torch.nn.BatchNorm2d):
+    """torch_modules.py:1222-1308: F.batch_norm with the cast weight / bias and the running statistics"""
+
+    def __init__(self, num_features, eps: float = 1e-5, momentum: float = 0.1, affine: bool = True, track_running_stats: bool = True):
+        torch.nn.BatchNorm2d.__init__(self, num_features, eps=eps, momentum=momentum, affine=affine, track_running_stats=track_running_stats)
+        self._dmx_init()
+
+    def _forward(self, _input):
+        self._check_input_dim(_input)
+        eaf = 0.0 if self.momentum is None else self.momentum
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked = self.num_batches_tracked + 1
+            eaf = 1.0 / float(self.num_batches_tracked) if self.momentum is None else self.momentum
+        bn_training = True if self.training else (self.running_mean is None and self.running_var is None)
+        use_stats = not self.training or self.track_running_stats
+        return F.batch_norm(_input, self.running_mean if use_stats else None, self.running_var if use_stats else None,
+                            self._weight_ro if self.weight is not None else None, self._bias_ro, bn_training, eaf, self.eps)
+
+
+class GroupNorm(DmxModule, torch.nn.GroupNorm):
+    """torch_modules.py:1310-1377"""
+
+    def __init__(self, num_groups: int, num_channels: int, eps: float = 1e-5, affine: bool = True):
+        torch.nn.GroupNorm.__init__(self, num_groups, num_channels, eps=eps, affine=affine)
+        self._dmx_init()
+
+    def _forward(self, _input):
+        _weight = self._weight_ro if self.weight is not None else None
+        if _weight is not None:
+            _input = _input.to(_weight.dtype)
+        return F.group_norm(_input, self.num_groups, _weight, self._bias_ro, self.eps)
+
+
+class ConvTranspose2d(_ConvNd, torch.nn.ConvTranspose2d):
+    """torch_modules.py:716-827 (input and weight blocked along dim 1, like Conv2d)"""
+
+    def __init__(self, *a, **kw):
+        torch.nn.ConvTranspose2d.__init__(self, *a, **kw)
+        self._conv_init()
+
+    def _forward(self, _input, output_size=None):
+        if self.padding_mode != "zeros":
+            raise ValueError("Only `zeros` padding mode is supported for ConvTranspose2d")
+        output_padding = self._output_padding(_input, output_size, self.stride, self.padding, self.kernel_size, 2, self.dilation)
+        _weight = self._weight_ro
+        _convolution = self.accum_cast(F.conv_transpose2d(_input.to(_weight.dtype), _weight, None, self.stride, self.padding, output_padding,
+                                                          self.groups, self.dilation))
+        if self.bias is not None:
+            return torch.add(_convolution, self._bias_ro.unsqueeze(-1).unsqueeze(-1))
+        return _convolution
+
+
+class BAddBMM(DmxModule):
+    """torch_modules.py:267-312: torch.baddbmm(input, batch1, batch2) with batch2 blocked along dim -2"""
+
+    def __init__(self):
+        torch.nn.Module.__init__(self)
+        self._dmx_init(input_names=("input_cast", "batch1_cast", "batch2_cast"))
+        self.input_casts.input_cast.block_dim = -1
+        self.input_casts.batch1_cast.block_dim = -1
+        self.input_casts.batch2_cast.block_dim = -2
+
+    def _forward(self, input, batch1, batch2, **kwargs):
+        return torch.baddbmm(input, batch1, batch2, **kwargs)
+
+
+class ScaledDotProductAttention(DmxModule):
+    """torch_modules.py:108-192: a COMPOUND module -- F.scaled_dot_product_attention spelled out with ResAdd / ActActMatMul / Mul / Softmax /
+    Dropout submodules, each with its own casts (so every fused path above applies inside it)"""
+    is_compound = True
+
+    def __init__(self, dropout_p: float = 0.0):
+        torch.nn.Module.__init__(self)
+        self._dmx_init(input_names=("query_states_cast", "key_states_cast", "value_states_cast", "attn_mask_cast"))
+        for c in self.input_casts.values():
+            c.block_dim = -1
+        self.resadd, self.actmatmul, self.softmax = ResAdd(), ActActMatMul(), Softmax(dim=-1)
+        self.dropout, self.mul = Dropout(p=dropout_p), Mul()
+
+    def forward(self, query, key, value, attn_mask=None, is_causal=False, scale=None, enable_gqa=False):
+        import math
+        L, S = query.size(-2), key.size(-2)
+        scale_factor = torch.tensor(1 / math.sqrt(query.size(-1)), dtype=torch.float16) if scale is None else scale
+        attn_bias = torch.zeros(L, S, dtype=query.dtype).to(query.device)
+        if is_causal:
+            assert attn_mask is None
+            attn_bias.masked_fill_(torch.ones(L, S, dtype=torch.bool, device=query.device).tril(diagonal=0).logical_not(), -10000.0)
+        if attn_mask is not None:
+            if attn_mask.dtype == torch.bool:
+                attn_bias.masked_fill_(attn_mask.logical_not(), -10000.0)
+            else:
+                attn_bias = self.resadd(attn_bias, attn_mask)
+        if enable_gqa:
+            key = key.repeat_interleave(query.size(-3) // key.size(-3), -3)
+            value = value.repeat_interleave(query.size(-3) // value.size(-3), -3)
+        attn_weight = self.actmatmul(query, key.transpose(-2, -1))
+        attn_weight = self.resadd(attn_weight, attn_bias)
+        if not isinstance(scale_factor, torch.Tensor):
+            scale_factor = torch.tensor(float(scale_factor), dtype=attn_weight.dtype)
+        attn_weight = self.mul(attn_weight, scale_factor.to(attn_weight.device))
+        attn_weight = self.softmax(attn_weight)
+        attn_weight = self.dropout(attn_weight)
+        return self.actmatmul(attn_weight, value)
 
 
 class MaxPool2d(DmxModule, torch.nn.MaxPool2d):

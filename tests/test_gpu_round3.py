@@ -217,3 +217,54 @@ def test_round3_entry_points_through_both_bindings(dmx, cuda):
     e4m3 = dmx.Format.from_shorthand("FP[1|4|3,7](_N)")
     for o in (C, T):
         assert o.unary_cast(x, "gelu", e4m3, f16) is None and o.softmax_cast(x, 0, f16, f16) is None
+
+
+def test_remaining_module_types_are_the_torch_op_between_the_casts(dmx, cuda):
+    """ReLU6 / Tanh / Dropout / GELU variants / AdaptiveAvgPool2d / BatchNorm2d / GroupNorm / ConvTranspose2d / BAddBMM under the BASIC rules ==
+    input cast(s) -> torch's op -> output cast, composed by hand from this library's cast ops (which the fixtures pin to the reference);
+    ScaledDotProductAttention (compound) against the same composition of its submodules (modeling/nn/torch_modules.py:108-192)."""
+    nn, ops, F = dmx.nn, dmx.ops, torch.nn.functional
+    f16 = dmx.format.FLOAT16
+    cast = lambda t: f16.cast(t, out_dtype=t.dtype)
+    bfp = lambda t, dim=-1: ops.bfp_qdq(t, 8, 64, dim, True, out_dtype=t.dtype)
+    x = (make("normal", (4, 16, 12, 12), seed=1) * 3).to(cuda)
+    with torch.no_grad():
+        for m, f in ((nn.ReLU6(), F.relu6), (nn.Tanh(), torch.tanh), (nn.Dropout(0.3).eval(), lambda t: t), (nn.NewGELU(), nn.NewGELU._f),
+                     (nn.FastGELU(), nn.FastGELU._f), (nn.BloomGELU(), nn.BloomGELU._f), (nn.ClippedGELU(-1.0, 2.0), lambda t: torch.clip(F.gelu(t), -1.0, 2.0)),
+                     (nn.AdaptiveAvgPool2d(3), lambda t: F.adaptive_avg_pool2d(t, 3))):
+            m = m.to(cuda)
+            dmx.configure_model(m, *dmx.config_rules.BASIC)
+            want = f(cast(x)) if isinstance(m, nn.Dropout) else cast(f(cast(x)))   # (Dropout has no rule in the reference: SAME)
+            if isinstance(m, nn.Dropout):
+                want = x.clone()
+            assert torch.equal(m(x), want), type(m).__name__
+        bn = nn.BatchNorm2d(16).to(cuda).eval()
+        bn.running_mean.copy_(torch.randn(16)); bn.running_var.copy_(torch.rand(16) + 0.5); bn.weight.data.normal_(1, 0.1); bn.bias.data.normal_(0, 0.1)
+        dmx.configure_model(bn, *dmx.config_rules.BASIC)
+        assert torch.equal(bn(x), cast(F.batch_norm(cast(x), bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.1, bn.eps)))
+        gn = nn.GroupNorm(4, 16).to(cuda)
+        gn.weight.data.normal_(1, 0.1); gn.bias.data.normal_(0, 0.1)
+        dmx.configure_model(gn, *dmx.config_rules.BASIC)
+        assert torch.equal(gn(x), cast(F.group_norm(cast(x), 4, gn.weight, gn.bias, gn.eps)))
+        ct = nn.ConvTranspose2d(16, 8, 3, stride=2).to(cuda)
+        dmx.configure_model(ct, *dmx.config_rules.BASIC)
+        w = bfp(ct.weight.detach(), 1)
+        b = ops.float_qdq(ct.bias.detach(), 22, 8, 127, False)            # BFP32_1 = float_quantize(man = 22)
+        want = cast(F.conv_transpose2d(bfp(x, 1), w, None, ct.stride, ct.padding, (0, 0), 1, ct.dilation) + b.unsqueeze(-1).unsqueeze(-1))
+        assert torch.equal(ct(x), want)
+        bb = nn.BAddBMM().to(cuda)
+        i, b1, b2 = torch.randn(3, 5, 7, device=cuda), torch.randn(3, 5, 64, device=cuda), torch.randn(3, 64, 7, device=cuda)
+        bb.configure(dict(input_formats=[dmx.format.SAME, dmx.format.BFP16_64, dmx.format.BFP16_64], output_formats=[f16]))
+        assert torch.equal(bb(i, b1, b2), cast(torch.baddbmm(i, bfp(b1), bfp(b2, -2))))
+        # compound attention: its five submodules take the rules; result == the same chain spelled out with the configured submodules
+        sdpa = nn.ScaledDotProductAttention().to(cuda)
+        dmx.configure_model(sdpa, *dmx.config_rules.BASIC)
+        q, k, v = (torch.randn(2, 4, 64, 64, device=cuda) for _ in range(3))
+        got = sdpa(q, k, v, is_causal=True)
+        bias = torch.zeros(64, 64, device=cuda).masked_fill_(torch.ones(64, 64, dtype=torch.bool, device=cuda).tril().logical_not(), -10000.0)
+        a = sdpa.actmatmul(q, k.transpose(-2, -1))
+        a = sdpa.mul(sdpa.resadd(a, bias), torch.tensor(1 / 8.0, dtype=torch.float16, device=cuda))
+        want = sdpa.actmatmul(sdpa.dropout(sdpa.softmax(a)), v)
+        assert torch.equal(got, want) and got.shape == (2, 4, 64, 64)
+        ref = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+        assert (got - ref).abs().max() < 0.05 * ref.abs().max()              # (and it IS attention, up to the BASIC formats' precision)
