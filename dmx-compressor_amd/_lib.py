@@ -46,6 +46,7 @@ SIGNATURES = {
     "dmxq_topk_mask": [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp],
     "dmxq_bernoulli_mask": [_vp, _vp, _i32, _i32, _i64, _u64, _vp],
     "dmxq_group_minmax": [_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
+    "dmxq_group_minmax_accumulate": [_vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp],
     "dmxq_qparams": [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp],
     "dmxq_histc": [_vp, _i32, _i64, _i64, _f32, _f32, _vp, _vp],
     "dmxq_channel_maxabs": [_vp, _i32, _i64, _i64, _i64, _vp, _vp],

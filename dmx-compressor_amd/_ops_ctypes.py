@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "group_minmax_accumulate", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -377,6 +377,19 @@ def group_minmax(x, ch_axis: int, group_size: int):
     check(lib().dmxq_group_minmax(ptr(xc), dtype_code(xc.dtype), outer, C, inner, group_size, ptr(mn), ptr(mx),
                                   stream_of(xc)), "dmxq_group_minmax")
     return mn, mx
+
+
+def group_minmax_accumulate(x, ch_axis: int, group_size: int, mn, mx):
+    """running min / max of slabs of `group_size` channels updated IN PLACE by one launch (dmxq_group_minmax_accumulate)"""
+    xc = _prep(x, "group_minmax_accumulate")
+    outer, C, inner = split3(xc.shape, ch_axis)
+    gs = max(int(group_size), 1)
+    G = -(-C // gs)
+    for t in (mn, mx):
+        if not (t.is_cuda and t.device == xc.device and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == G):
+            raise RuntimeError(f"group_minmax_accumulate: running min / max must be contiguous float32 tensors of {G} entries on the input's device")
+    check(lib().dmxq_group_minmax_accumulate(ptr(xc), dtype_code(xc.dtype), outer, C, inner, gs, ptr(mn), ptr(mx), stream_of(xc)),
+          "dmxq_group_minmax_accumulate")
 
 
 def qparams(mn, mx, qmin: int, qmax: int, symmetric_qscheme: bool):

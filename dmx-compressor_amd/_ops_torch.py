@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import DmxqError, ROUNDING_CODE, require_gpu
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "group_minmax_accumulate", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -281,6 +281,13 @@ def group_minmax(x, ch_axis: int, group_size: int):
     """Per-group (slabs of `group_size` channels along ch_axis) min and max: two float32 [G] tensors."""
     require_gpu(x, "group_minmax")
     return _ops.group_minmax(x, ch_axis, group_size)
+
+
+def group_minmax_accumulate(x, ch_axis: int, group_size: int, mn, mx):
+    """running min / max of slabs of `group_size` channels updated IN PLACE by one launch: mn = min(mn, min(x)), mx = max(mx, max(x))
+    (MinMaxObserver.forward as a whole, observer.py:173-193).  mn / mx: contiguous float32 GPU tensors of ceil(C / group_size) entries."""
+    require_gpu(x, "group_minmax_accumulate")
+    _ops.group_minmax_accumulate(x, ch_axis, group_size, mn, mx)
 
 
 def qparams(mn, mx, qmin: int, qmax: int, symmetric_qscheme: bool):

@@ -175,6 +175,53 @@ __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const 
   }
 }
 
+// outer == 1 (a weight's row slabs along dim 0, or the whole tensor as one group): the vectors of group g are ONE contiguous run, so a
+// workgroup takes workgroup-contiguous tiles of 512 x 16 vectors with all 16 loads of a lane in flight -- the shape that reads fastest
+// in tools/tune_reduce (profiles/r02_tune_reduce.txt: 7.3 us for 32 MiB against 8.8 us with 1024-thread workgroups and 4 loads in
+// flight, grid-strided) -- and no 64-bit index arithmetic per vector.  One round for a 32 MiB tensor (256 workgroups).
+constexpr int kFlatThreads = 512;
+template <int DT> struct FlatUnroll { static constexpr int value = DT == DMXQ_F32 ? 8 : 16; };  // 256 bytes in flight per lane either way
+template <int DT>
+__global__ __launch_bounds__(kFlatThreads) void group_minmax_flat_kernel(const void* __restrict__ in, int64_t C, int64_t inner, int64_t gs,
+                                                                        float* mn, float* mx) {
+  constexpr int T = kFlatThreads, U = FlatUnroll<DT>::value;
+  const int64_t g = blockIdx.y;
+  const int64_t c0 = g * gs;
+  const int64_t lenv = ((C - c0 < gs) ? (C - c0) : gs) * inner / 8;  // vectors of this group
+  const int64_t v0 = c0 * inner / 8;
+  float lo = INFINITY, hi = -INFINITY;
+  for (int64_t b = (int64_t)blockIdx.x * (T * U); b < lenv; b += (int64_t)gridDim.x * (T * U)) {
+    Raw8<DT> raw[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t v = b + (int64_t)u * T + threadIdx.x;
+      raw[u] = load8_raw<DT>(in, (v0 + (v < lenv ? v : lenv - 1)) * 8);  // clamped: a repeated vector cannot change a min / max
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      float v[8];
+      widen8<DT>(raw[u], v);
+#pragma unroll
+      for (int k = 0; k < 8; k++) { lo = fminf(lo, v[k]); hi = fmaxf(hi, v[k]); }
+    }
+  }
+  lo = wave_min(lo);
+  hi = wave_max(hi);
+  __shared__ float s_lo[T / kWave], s_hi[T / kWave];
+  const int w = threadIdx.x / kWave;
+  if ((threadIdx.x & (kWave - 1)) == 0) { s_lo[w] = lo; s_hi[w] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 1; i < T / kWave; i++) { lo = fminf(lo, s_lo[i]); hi = fmaxf(hi, s_hi[i]); }
+    if (lo <= hi) {
+      atomic_min_f32(&mn[g], lo);
+      atomic_max_f32(&mx[g], hi);
+    }
+  }
+}
+
 // vectorised twin of channel_maxabs_kernel: a workgroup covers a strip of 64 x 8 = 512 consecutive columns of the
 // (C x inner) plane; a lane owns 8 columns, the 4 waves take different rows (4 row loads in flight each), their
 // partial maxima are combined through LDS and ONE wave issues the integer atomics.
@@ -338,15 +385,17 @@ __global__ void hist_to_float_kernel(uint32_t* counts, int bins) {
 
 using namespace dmxq;
 
-extern "C" int dmxq_group_minmax(const void* in, int dtype_in, int64_t outer, int64_t C, int64_t inner,
-                                 int64_t group_size, float* mn, float* mx, void* stream) {
+// FILL: mn / mx are initialised to +inf / -inf by a first launch (dmxq_group_minmax); without it the kernel's atomics fold this
+// tensor's extrema INTO the values already there (dmxq_group_minmax_accumulate: a running min / max updated in ONE launch)
+static int group_minmax_impl(const void* in, int dtype_in, int64_t outer, int64_t C, int64_t inner, int64_t group_size, float* mn, float* mx,
+                             void* stream, bool fill) {
   if (!valid_dtype(dtype_in) || outer < 0 || C < 0 || inner < 0 || group_size < 1) return DMXQ_ERR_BAD_ARG;
   if (C == 0) return DMXQ_OK;
   if (!mn || !mx) return DMXQ_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int64_t G = (C + group_size - 1) / group_size;
   if (G > 65535) return DMXQ_ERR_UNSUPPORTED;
-  DMXQ_LAUNCH(fill2_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, mn, INFINITY, mx, -INFINITY, G);
+  if (fill) DMXQ_LAUNCH(fill2_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, mn, INFINITY, mx, -INFINITY, G);
   if (outer * inner > 0) {
     if (!in) return DMXQ_ERR_BAD_ARG;
     const int64_t per_group = outer * group_size * inner;
@@ -356,7 +405,16 @@ extern "C" int dmxq_group_minmax(const void* in, int dtype_in, int64_t outer, in
     if (splits < 1) splits = 1;
     // every run [(o*C + g*gs) * inner, + len*inner) starts 16-byte aligned and is a whole number of 8-element vectors
     const bool vec = aligned16(in) && (group_size * inner) % 8 == 0 && (C * inner) % 8 == 0;
-    if (vec) {
+    if (vec && outer == 1) {
+      const int64_t tile = (int64_t)kFlatThreads * (dtype_in == DMXQ_F32 ? 8 : 16);
+      int64_t sv = (per_group / 8 + tile - 1) / tile;
+      const int64_t capv = (512 + G - 1) / G;
+      if (sv > capv) sv = capv;
+      if (sv < 1) sv = 1;
+#define DMXQ_MF(D_) DMXQ_LAUNCH(group_minmax_flat_kernel<D_>, dim3((unsigned)sv, (unsigned)G), dim3(kFlatThreads), 0, s, in, C, inner, group_size, mn, mx)
+      if (dtype_in == DMXQ_F32) DMXQ_MF(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_MF(DMXQ_F16); else DMXQ_MF(DMXQ_BF16);
+#undef DMXQ_MF
+    } else if (vec) {
       int64_t sv = (per_group / 8 + kMinmaxThreads * 8 - 1) / (kMinmaxThreads * 8);  // ~8 vectors per lane
       const int64_t capv = (512 + G - 1) / G;  // ~512 workgroups of 1024 threads in total
       if (sv > capv) sv = capv;
@@ -369,6 +427,15 @@ extern "C" int dmxq_group_minmax(const void* in, int dtype_in, int64_t outer, in
                          outer, C, inner, group_size, mn, mx);
   }
   return launch_status();
+}
+
+extern "C" int dmxq_group_minmax(const void* in, int dtype_in, int64_t outer, int64_t C, int64_t inner,
+                                 int64_t group_size, float* mn, float* mx, void* stream) {
+  return group_minmax_impl(in, dtype_in, outer, C, inner, group_size, mn, mx, stream, true);
+}
+extern "C" int dmxq_group_minmax_accumulate(const void* in, int dtype_in, int64_t outer, int64_t C, int64_t inner,
+                                            int64_t group_size, float* mn, float* mx, void* stream) {
+  return group_minmax_impl(in, dtype_in, outer, C, inner, group_size, mn, mx, stream, false);
 }
 
 extern "C" int dmxq_qparams(const float* mn, const float* mx, int64_t n_groups, int qmin, int qmax,

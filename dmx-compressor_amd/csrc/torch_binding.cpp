@@ -448,6 +448,20 @@ std::tuple<Tensor, Tensor> group_minmax_meta(const Tensor& x, int64_t ch_axis, i
   return {at::empty({G}, x.options().dtype(at::kFloat)), at::empty({G}, x.options().dtype(at::kFloat))};
 }
 
+// running min / max updated in place, one launch (dmxq_group_minmax_accumulate); returns nothing new: mn / mx ARE the state
+void group_minmax_accumulate(const Tensor& x, int64_t ch_axis, int64_t group_size, Tensor mn, Tensor mx) {
+  const Tensor xc = prep(x, "group_minmax_accumulate");
+  const Split3 s = split3(xc, ch_axis);
+  const int64_t gs = std::max<int64_t>(group_size, 1), G = (s.L + gs - 1) / gs;
+  TORCH_CHECK(mn.is_cuda() && mx.is_cuda() && mn.device() == xc.device() && mx.device() == xc.device() && mn.scalar_type() == at::kFloat &&
+              mx.scalar_type() == at::kFloat && mn.is_contiguous() && mx.is_contiguous() && mn.numel() == G && mx.numel() == G,
+              "group_minmax_accumulate: running min / max must be contiguous float32 tensors of ", G, " entries on the input's device");
+  Launch l(xc);
+  check(dmxq_group_minmax_accumulate(xc.data_ptr(), dt_code(xc.scalar_type()), s.outer, s.L, s.inner, gs, (float*)mn.data_ptr(),
+                                     (float*)mx.data_ptr(), l.stream), "dmxq_group_minmax_accumulate");
+}
+void group_minmax_accumulate_meta(const Tensor&, int64_t, int64_t, Tensor, Tensor) {}
+
 std::tuple<Tensor, Tensor> qparams(const Tensor& mn, const Tensor& mx, int64_t qmin, int64_t qmax, bool symmetric) {
   TORCH_CHECK(mn.is_cuda(), "qparams: tensors must be on the GPU (no CPU fallback)");
   const Tensor a = mn.to(at::kFloat).contiguous(), b = mx.to(at::kFloat).contiguous();
@@ -667,6 +681,7 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("topk_mask(Tensor score, Tensor? x, int n_zero, bool want_mask, bool want_y, ScalarType? mask_dtype=None, ScalarType? y_dtype=None) -> (Tensor, Tensor)");
   m.def("bernoulli_mask(Tensor score, int seed, ScalarType? mask_dtype=None) -> Tensor");
   m.def("group_minmax(Tensor x, int ch_axis, int group_size) -> (Tensor, Tensor)");
+  m.def("group_minmax_accumulate(Tensor x, int ch_axis, int group_size, Tensor(a!) mn, Tensor(b!) mx) -> ()");
   m.def("qparams(Tensor mn, Tensor mx, int qmin, int qmax, bool symmetric_qscheme) -> (Tensor, Tensor)");
   m.def("histc(Tensor x, int bins, float lo, float hi) -> Tensor");
   m.def("channel_maxabs(Tensor x, int ch_axis) -> Tensor");
@@ -688,7 +703,7 @@ TORCH_LIBRARY(dmxq, m) {
   X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, input_hypernet); X(m, binary_cast); X(m, relu_cast); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
   X(m, float_qdq); X(m, fixed_qdq); X(m, fixed_qdq_multi); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
   X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, rope); X(m, rope_cast); X(m, softmax); X(m, norm); \
-  X(m, unary_cast); X(m, softmax_cast); X(m, norm_cast)
+  X(m, unary_cast); X(m, softmax_cast); X(m, norm_cast); X(m, group_minmax_accumulate)
 
 // "CUDA" is the dispatch key of HIP tensors in a ROCm build of PyTorch
 TORCH_LIBRARY_IMPL(dmxq, CUDA, m) {

@@ -63,6 +63,19 @@ class MinMaxObserver(ObserverBase):
         if x.numel() == 0:
             return x
         xd = x.detach()
+        # the running state has this observation's shape already (every call after the first): ONE launch folds the tensor's extrema
+        # into it (dmxq_group_minmax_accumulate) -- reduction and `min_val = torch.min(x_min, min_val)` together, no fill launch
+        if group_size or self.qscheme in _PER_CHANNEL:
+            view, axis, gs = xd, self.ch_axis, (group_size or 1)
+            n_groups = -(-xd.shape[self.ch_axis] // gs) if xd.dim() else 1
+            shape = (n_groups,)
+        else:
+            view, axis, gs, shape = xd.reshape(1, -1), 0, 1, ()
+        if (self.min_val.shape == shape and self.min_val.is_cuda and self.min_val.device == xd.device and self.min_val.dtype == torch.float32
+                and self.max_val.shape == shape and self.max_val.device == xd.device and self.max_val.dtype == torch.float32
+                and self.min_val.is_contiguous() and self.max_val.is_contiguous() and not torch.compiler.is_compiling()):
+            ops.group_minmax_accumulate(view, axis, gs, self.min_val.view(-1), self.max_val.view(-1))
+            return x
         if group_size:                       # slabs along ch_axis (cast.py:200-204 torch.split)
             mn, mx = ops.group_minmax(xd, self.ch_axis, group_size)
         elif self.qscheme in _PER_CHANNEL:   # one group per channel

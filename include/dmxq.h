@@ -162,6 +162,14 @@ int dmxq_bernoulli_mask(const void* score, void* mask_out, int dtype_score, int 
 int dmxq_group_minmax(const void* in, int dtype_in, int64_t outer, int64_t C, int64_t inner, int64_t group_size,
                       float* mn, float* mx, void* stream);
 
+/* The same reduction folded INTO running values: mn[g] = min(mn[g], min over group g), mx[g] = max(mx[g], max over group g), in ONE
+ * launch (no initialising launch: mn / mx must hold valid values, +inf / -inf before the first observation).  Replaces
+ * numerical/observer.py:173-193 MinMaxObserver.forward as a whole -- the two reductions AND `min_val = torch.min(x_min, min_val)` /
+ * `max_val = torch.max(...)` (4 launches with dmxq_group_minmax, ~10 per group in the reference).  Exact and order-independent (integer
+ * atomics on the float bit patterns). */
+int dmxq_group_minmax_accumulate(const void* in, int dtype_in, int64_t outer, int64_t C, int64_t inner, int64_t group_size,
+                                 float* mn, float* mx, void* stream);
+
 /* (min,max) -> (scale, zero_point).  Replaces numerical/observer.py:59-115 _calculate_qparams. */
 int dmxq_qparams(const float* mn, const float* mx, int64_t n_groups, int qmin, int qmax, int symmetric_qscheme,
                  float* scale, int64_t* zero_point, void* stream);

@@ -268,3 +268,37 @@ def test_remaining_module_types_are_the_torch_op_between_the_casts(dmx, cuda):
         assert torch.equal(got, want) and got.shape == (2, 4, 64, 64)
         ref = F.scaled_dot_product_attention(q, k, v, is_causal=True)
         assert (got - ref).abs().max() < 0.05 * ref.abs().max()              # (and it IS attention, up to the BASIC formats' precision)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16, F16])
+def test_minmax_accumulate_equals_reduce_then_min_max(dmx, cuda, oracle, dtype):
+    """dmxq_group_minmax_accumulate: the running min / max of a MinMaxObserver updated in ONE launch == group_minmax followed by
+    torch.minimum / torch.maximum with the previous state (observer.py:173-193), exactly, over three batches; per group, per channel,
+    per tensor; and the observer itself takes that path from its second observation on (same qparams as the oracle's)."""
+    xs = [make("heavy", (256, 96), seed=40 + i, dtype=dtype).clamp(-1e4, 1e4) for i in range(3)]
+    for ch_axis, gs in ((0, 32), (0, 1), (-1, 8), (0, 256)):
+        G = -(-xs[0].shape[ch_axis] // gs)
+        mn = torch.full((G,), float("inf"), device=cuda)
+        mx = torch.full((G,), float("-inf"), device=cuda)
+        rmn, rmx = mn.clone(), mx.clone()
+        for x in xs:
+            dmx.ops.group_minmax_accumulate(x.to(cuda), ch_axis, gs, mn, mx)
+            a, b = dmx.ops.group_minmax(x.to(cuda), ch_axis, gs)
+            rmn, rmx = torch.minimum(rmn, a), torch.maximum(rmx, b)
+            assert torch.equal(mn, rmn) and torch.equal(mx, rmx), (ch_axis, gs)
+        omn, omx = oracle.group_minmax(torch.cat(xs, dim=1 if ch_axis == 0 else 0), ch_axis, gs)
+        assert torch.equal(mn.cpu(), omn) and torch.equal(mx.cpu(), omx)
+    for qs, gsz in ((torch.per_tensor_symmetric, None), (torch.per_channel_affine, None), (torch.per_tensor_affine, 64)):
+        obs = dmx.MinMaxObserver(qscheme=qs, ch_axis=0).to(cuda)
+        for x in xs:
+            obs(x.to(cuda), gsz)
+        allx = torch.cat(xs, dim=1)
+        if gsz:
+            omn, omx = oracle.group_minmax(allx, 0, gsz)
+        elif qs == torch.per_channel_affine:
+            omn, omx = oracle.group_minmax(allx, 0, 1)
+        else:
+            omn, omx = oracle.group_minmax(allx.reshape(1, -1), 0, 1)
+        assert torch.equal(obs.min_val.reshape(-1).cpu(), omn) and torch.equal(obs.max_val.reshape(-1).cpu(), omx), (qs, gsz)
+    with pytest.raises(RuntimeError):
+        dmx.ops.group_minmax_accumulate(xs[0].to(cuda), 0, 32, torch.zeros(3, device=cuda), torch.zeros(3, device=cuda))

@@ -189,6 +189,11 @@ def main():
     mx = torch.empty(R, device=dev)
     run("group_minmax bf16 group_size=128 along dim0",
         lambda i: L.dmxq_group_minmax(vp(xs[i].data_ptr()), _lib.BF16, 1, R, C, 128, vp(mn.data_ptr()), vp(mx.data_ptr()), sp), k, n * 2)
+    mn.fill_(float("inf")); mx.fill_(float("-inf"))
+    run("group_minmax_accumulate bf16 group_size=128 (a MinMaxObserver step in ONE launch: reduction + running min / max)",
+        lambda i: L.dmxq_group_minmax_accumulate(vp(xs[i].data_ptr()), _lib.BF16, 1, R, C, 128, vp(mn.data_ptr()), vp(mx.data_ptr()), sp), k, n * 2)
+    run("group_minmax_accumulate bf16 per-tensor",
+        lambda i: L.dmxq_group_minmax_accumulate(vp(xs[i].data_ptr()), _lib.BF16, 1, 1, n, 1, vp(mn.data_ptr()), vp(mx.data_ptr()), sp), k, n * 2)
     run("group_minmax bf16 per-tensor",
         lambda i: L.dmxq_group_minmax(vp(xs[i].data_ptr()), _lib.BF16, 1, 1, n, 1, vp(mn.data_ptr()), vp(mx.data_ptr()), sp), k, n * 2)
     ma = torch.empty(C, device=dev)
