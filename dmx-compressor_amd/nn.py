@@ -77,8 +77,14 @@ class DmxModuleSmoothQuantHyperparams:
 def _shares_storage(a, b) -> bool:
     if not (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor)):
         return False
-    if torch.compiler.is_compiling():  # storages have no addresses while tracing with fake tensors: identity only
-        return a is b
+    if torch.compiler.is_compiling():
+        # storages have no addresses while tracing with fake tensors: identity, and the view relation (`_base`) -- an all-SAME module
+        # whose `_forward` hands back a VIEW of its input or parameter (x.view(...), x[..., :k], .t()) must still be cloned at the
+        # boundary like the reference's Same.cast does
+        if a is b:
+            return True
+        ba, bb = getattr(a, "_base", None), getattr(b, "_base", None)
+        return (ba is not None and (ba is b or ba is bb)) or (bb is not None and bb is a)
     return a.device == b.device and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.numel() > 0
 
 

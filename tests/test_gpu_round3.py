@@ -302,3 +302,30 @@ def test_minmax_accumulate_equals_reduce_then_min_max(dmx, cuda, oracle, dtype):
         assert torch.equal(obs.min_val.reshape(-1).cpu(), omn) and torch.equal(obs.max_val.reshape(-1).cpu(), omx), (qs, gsz)
     with pytest.raises(RuntimeError):
         dmx.ops.group_minmax_accumulate(xs[0].to(cuda), 0, 32, torch.zeros(3, device=cuda), torch.zeros(3, device=cuda))
+
+
+def test_all_same_module_returning_a_view_is_cloned_under_torch_compile(dmx, cuda):
+    """in a compiled graph storages have no addresses, and the boundary check used to see only `out is input`; an
+    all-SAME module whose _forward returns a VIEW of its input escaped un-cloned, so a caller's in-place op on the result wrote
+    through to the input (the reference's Same.cast always clones).  The view relation is followed now."""
+    class Slice(dmx.nn.DmxModule):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self._dmx_init()
+
+        def _forward(self, _input):
+            return _input[:, :8]
+
+    m = Slice().to(cuda)
+
+    def f(x):
+        y = m(x)
+        y.add_(1.0)          # must not reach x
+        return y
+
+    x = torch.zeros(4, 16, device=cuda)
+    eager = f(x)
+    assert float(x.abs().max()) == 0.0 and float(eager.min()) == 1.0
+    x2 = torch.zeros(4, 16, device=cuda)
+    out = torch.compile(f, backend="aot_eager", fullgraph=True)(x2)
+    assert float(x2.abs().max()) == 0.0 and float(out.min()) == 1.0
