@@ -56,12 +56,29 @@ struct FloatOp {
   static constexpr int kTileUnroll = 8;  // 256 x 4 13.5 us, 256 x 8 12.1 us)
   FloatFmt f;
   FloatFast k;
+  FlushFast ff;
   __device__ __forceinline__ void apply_one(float x, float& y, int64_t e) const {
     const bool stoch = (RND == kRuntimeRounding) && f.rounding == DMXQ_ROUND_STOCHASTIC;
     y = float_q1<RND>(x, f, stoch ? rnd_bits(f.seed, (uint64_t)e) : 0u);
   }
   template <int N>
   __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
+    if (RND == DMXQ_ROUND_NEAREST && ff.usable) {
+      // formats that flush their subnormals (FLOAT16 / BFLOAT16 of the BASIC rules): 8 integer operations per element on the magnitude
+      // bits (floatq.hpp float_q1_flush); Inf / NaN inputs redone with the bit-level form behind one cold wave-uniform branch
+      bool fin = true;
+#pragma unroll
+      for (int j = 0; j < N; j++) {
+        fin = fin && (f2u(x[j]) & 0x7F800000u) != 0x7F800000u;
+        y[j] = float_q1_flush(x[j], ff);
+      }
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fin) != 0ull, 0)) {
+#pragma unroll
+        for (int j = 0; j < N; j++)
+          if ((f2u(x[j]) & 0x7F800000u) == 0x7F800000u) apply_one(x[j], y[j], e0 + j);
+      }
+      return;
+    }
     if (RND == DMXQ_ROUND_NEAREST && k.usable) {
       // the branch-free form for every element, unconditionally; the (rare) elements it does not cover -- Inf, NaN, exponents
       // too large for the magic constant -- are redone with the bit-level form behind ONE cold wave-uniform branch, so that the
@@ -576,8 +593,10 @@ extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype
     Range16 r;
     if (range16_of(&ff, dtype_in, &r)) return launch_float_range_bf16(in, out, n / 8, r, s);
   }
-  if (rounding == DMXQ_ROUND_NEAREST) return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<DMXQ_ROUND_NEAREST>{f, make_float_fast(f.man, f.exp_bits, f.bias)}, s);
-  return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<kRuntimeRounding>{f, make_float_fast(f.man, f.exp_bits, f.bias)}, s);
+  // (the integer flush form does not apply the final abs of sign-less formats: those keep the magic-add form)
+  const FlushFast ff = make_flush_fast(f.man, f.exp_bits, f.bias, f.flush && !f.unsigned_abs);
+  if (rounding == DMXQ_ROUND_NEAREST) return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<DMXQ_ROUND_NEAREST>{f, make_float_fast(f.man, f.exp_bits, f.bias), ff}, s);
+  return dispatch_stream(in, out, dtype_in, dtype_out, n, FloatOp<kRuntimeRounding>{f, make_float_fast(f.man, f.exp_bits, f.bias), FlushFast{}}, s);
 }
 
 
