@@ -5,7 +5,7 @@ scale, per output dtype: maximum distance in ulps 
   * the HIP kernels of this repo, and
   * torch's own CPU result in the tensor's dtype -- what the reference computes (functional/approximate.py:300-304) --
 so that "within 1 ulp of the stated format" is checked against the truth rather than against another rounded
-implementation.  Writes a table to stdout (committed as profiles/r02_accuracy_table.txt)."""
+implementation.  Writes a table to stdout (committed as profiles/r03_accuracy_table.txt; round 3 adds the fused modules)."""
 import os
 import sys
 
@@ -63,5 +63,56 @@ def main():
         row(f"smoothquant scale, alpha = {alpha}", torch.float32, d.ops.smoothquant_scale(a.to(dev), b.to(dev), alpha), cpu, truth)
 
 
+def fused_modules():
+    """Round 3: the activation / normalisation MODULES as one launch (cast_in -> f -> cast_out, BASIC rules: FLOAT16 casts) against
+    the float64 truth pushed through the same casts (this library's bit-exact cast kernels), in ulps of the TENSOR dtype (float32 tensors: of the output cast's 10-bit format), next to the
+    unfused module (this library's casts around torch's GPU function); and how many elements the two paths disagree on."""
+    nn = d.nn
+    f16 = d.format.FLOAT16
+    cast = lambda t: f16.cast(t, out_dtype=t.dtype)
+    print()
+    print(f"{'fused module, FLOAT16 casts (inputs)':46s} {'dtype':9s} {'fused max ulp':>13s} {'unfused max ulp':>15s} {'fused != unfused':>17s}   (vs cast(round(f64 truth(cast(x)))))")
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        x = (make("normal", (1 << 20,), seed=11) * 4.0).to(dt).to(dev)
+        r15 = (make("normal", (512, 1500), seed=12) * 3.0).to(dt).to(dev)
+        r768 = (make("normal", (1024, 768), seed=13) * 2.0 + 0.3).to(dt).to(dev)
+        r4096 = (make("normal", (256, 4096), seed=14) * 2.0 + 0.3).to(dt).to(dev)
+        w768, b768 = (1.0 + 0.1 * make("normal", (768,), seed=3)).to(dt).to(dev), (0.1 * make("normal", (768,), seed=4)).to(dt).to(dev)
+        w4096 = (1.0 + 0.1 * make("normal", (4096,), seed=5)).to(dt).to(dev)
+
+        def ln_floor(c, w, b):
+            cd = c.double()
+            mu, rstd = cd.mean(-1, keepdim=True), (cd.var(-1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+            return (cd.abs().amax(-1, keepdim=True) + mu.abs()) * rstd * w.double().abs() + b.double().abs()
+
+        cases = [
+            ("GELU, N(0,16)", nn.GELU(), x, lambda c: F.gelu(c.double()), lambda c: c.double().abs() / 2),
+            ("SiLU, N(0,16)", nn.SiLU(), x, lambda c: F.silu(c.double()), None),
+            ("Exp, N(0,16) clamped to +-10", nn.Exp(), x.clamp(-10, 10), lambda c: torch.exp(c.double()), None),
+            ("Softmax rows of 1500, N(0,9)", nn.Softmax(dim=-1), r15, lambda c: torch.softmax(c.double(), -1), None),
+            ("LayerNorm rows of 768, affine", nn.LayerNorm(768), r768, lambda c: F.layer_norm(c.double(), (768,), w768.double(), b768.double(), 1e-5), lambda c: ln_floor(c, w768, b768)),
+            ("RMSNorm rows of 4096, weight", nn.RMSNorm(4096, eps=1e-5), r4096, lambda c: F.rms_norm(c.double(), (4096,), w4096.double(), 1e-5), None),
+        ]
+        for name, m, inp, f64, floor_fn in cases:
+            m = m.to(dev).to(dt)
+            d.configure_model(m, *d.config_rules.BASIC)
+            with torch.no_grad():
+                if isinstance(m, nn.LayerNorm):
+                    m.weight.copy_(w768); m.bias.copy_(b768)
+                if isinstance(m, nn.RMSNorm):
+                    m.weight.copy_(w4096)
+                fused = m(inp)
+                m.fuse_activation = False
+                unfused = m(inp)
+                c = cast(inp)
+                truth = cast(f64(c).to(dt))           # cast_out(round_D(truth)): the value both paths approximate
+            fl = None if floor_fn is None else floor_fn(c)
+            unit = dt if dt != torch.float32 else torch.float16   # float32 tensors: ulps of the OUTPUT CAST's format (10 mantissa bits)
+            a, b = err_in_ulps(fused, truth.double(), unit, fl), err_in_ulps(unfused, truth.double(), unit, fl)
+            diff = float((fused.float() != unfused.float()).float().mean()) * 100
+            print(f"{name:46s} {str(dt).replace('torch.', ''):9s} {a:13.2f} {b:15.2f} {diff:16.3f}%", flush=True)
+
+
 if __name__ == "__main__":
     main()
+    fused_modules()
