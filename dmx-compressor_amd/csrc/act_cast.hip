@@ -26,7 +26,8 @@ namespace dmxq {
 template <class BASE, int DT>
 struct CastedOp {
   static constexpr bool kHeavy = true;
-  static constexpr int kTileUnroll = DT == DMXQ_F32 ? BASE::kTileUnrollF32 : BASE::kTileUnroll;
+  static constexpr int kTileUnroll = DT == DMXQ_F32 ? BASE::kTileUnrollF32 : BASE::kCastUnroll;  // (stream.hpp: geometry for 20-32 MiB tensors)
+  static constexpr int kTileThreads = DT == DMXQ_F32 ? 256 : BASE::kCastThreads;
   static constexpr bool kRawHooks = DT != DMXQ_F32;
   BASE base;
   Range16 ri, ro;  // 16-bit tensors

@@ -303,11 +303,11 @@ constexpr int rows_per_wave(int vpl, int epl) { return 32 / (vpl * epl) >= 4 ? 4
 // FAST32: float32 rows behind an output cast that keeps <= 16 mantissa bits (a module's FLOAT16 output cast): the v_exp / one
 // reciprocal per row forms of the 16-bit rows (relative error ~2^-21, invisible at 2^-17) instead of the compensated expf and a
 // division per element -- those make the fp32 kernel VALU-bound (Whisper's [12,1500,1500] attention: 58 us -> see profiles/r03_*)
-template <int DT, int EPL, int VPL, int LPR, bool RAG = false, bool CAST = false, bool FAST32 = false>
+template <int DT, int EPL, int VPL, int LPR, bool RAG = false, bool CAST = false, bool FAST32 = false, int RPWO = 0>
 __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                                int64_t rows, int64_t cols, float clamp_min, const RowCastArg<CAST> rc) {
   constexpr int SUB = kWave / LPR;  // rows side by side in one wave
-  constexpr int RPW = rows_per_wave(VPL, EPL);
+  constexpr int RPW = RPWO ? RPWO : rows_per_wave(VPL, EPL);  // (RPWO: tools/tune_rows only)
   constexpr bool FAST = DT != DMXQ_F32 || FAST32;
   const int lane = threadIdx.x & (kWave - 1), sub = lane / LPR, sl = lane & (LPR - 1);
   const int64_t wave = (int64_t)blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave;
@@ -428,13 +428,13 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
 // weight / bias (same dtype as the rows) are read ONCE per wave and kept across its rows: widened to fp32 for short
 // rows, packed for longer ones.  Per element: widen + add, subtract + fma, and (x - mean) * (rstd w) + b as
 // subtract + fma with rstd w formed once per (row, vector element).
-template <int DT, int EPL, int VPL, int LPR, bool RMS = false, bool CAST = false>
+template <int DT, int EPL, int VPL, int LPR, bool RMS = false, bool CAST = false, int RPWO = 0, int HOISTO = 0>
 __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                                  int64_t rows, int64_t cols, const void* __restrict__ w,
                                                                  const void* __restrict__ b, float eps, const RowCastArg<CAST> rc) {
   constexpr int SUB = kWave / LPR;
-  constexpr int RPW = rows_per_wave(VPL, EPL);
-  constexpr bool HOIST_F32 = VPL * EPL <= 24, HOIST_RAW = !HOIST_F32 && VPL <= 8;
+  constexpr int RPW = RPWO ? RPWO : rows_per_wave(VPL, EPL);
+  constexpr bool HOIST_F32 = HOISTO == 0 && VPL * EPL <= 24, HOIST_RAW = HOISTO != 2 && !HOIST_F32 && VPL <= 8;  // (HOISTO: tools/tune_rows only)
   const int lane = threadIdx.x & (kWave - 1), sub = lane / LPR, sl = lane & (LPR - 1);
   const int64_t wave = (int64_t)blockIdx.x * (kThreads / kWave) + threadIdx.x / kWave;
   const int64_t n_waves = (int64_t)gridDim.x * (kThreads / kWave);
@@ -554,11 +554,11 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
 // thread), two workgroup reductions per row through a 4-entry LDS exchange, RPW rows per iteration to amortise the two
 // barriers, weight / bias hoisted (packed) out of the persistent row loop.  The wave kernel at this size would hold
 // 128+ values per lane and re-read weight and bias (as much data as the row itself) for every row.
-template <int DT, int EPL, int VPL, bool RMS = false, bool CAST = false>
+template <int DT, int EPL, int VPL, bool RMS = false, bool CAST = false, int RPWO = 0>
 __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                                   int64_t rows, int64_t cols, const void* __restrict__ w,
                                                                   const void* __restrict__ b, float eps, const RowCastArg<CAST> rc) {
-  constexpr int RPW = VPL * EPL <= 32 ? 2 : 1;
+  constexpr int RPW = RPWO ? RPWO : (VPL * EPL <= 32 ? 2 : 1);
   constexpr int NW = kThreads / kWave;
   __shared__ float red[2][RPW][NW];
   const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
@@ -710,6 +710,12 @@ static int resident_grid(K kernel, int64_t wanted) {
   return (int)(wanted < cap ? (wanted < 1 ? 1 : wanted) : cap);
 }
 
+// one pass per workgroup (the kernels still loop, for grids beyond the limit).  Round 3 (tools/tune_rows -> profiles/r03_tune_rows.txt):
+// softmax rows of 1500 bf16, persistent grid vs one pass: 14.1 vs 13.7 us on 32 MiB, 52.0 vs 46.6 us on 128 MiB, equal below 16 MiB --
+// a softmax wave has no per-wave setup to amortise.  (LayerNorm's wave kernel has: weight and bias, hoisted and widened once per
+// wave; it stays persistent: 14.4 vs 17.2 us for one pass on 21845 x 768.)
+static inline unsigned one_pass_grid(int64_t wanted) { return (unsigned)(wanted < 1 ? 1 : (wanted > 0x7FFFFFFF ? 0x7FFFFFFF : wanted)); }
+
 static inline int row_grid(int64_t rows) { return (int)(rows < 256 * 16 ? (rows < 1 ? 1 : rows) : 256 * 16); }
 
 // This file is compiled TWICE (build.py: -DDMXQ_EW_PART=1 / 2): softmax and the norms are ~150 kernel instantiations each.
@@ -748,7 +754,7 @@ static int softmax_dispatch(const void* in, void* out, int dtype_in, int dtype_o
     if constexpr ((E_) * Elem<D_>::bytes == 16) {                                                                     \
       if (rag) {                                                                                                      \
         DMXQ_LAUNCH((softmax_wave_kernel<D_, E_, V_, L_, true, CAST>),                                         \
-                           dim3((unsigned)resident_grid(softmax_wave_kernel<D_, E_, V_, L_, true, CAST>, (rows + per_wg - 1) / per_wg)), \
+                           dim3((unsigned)one_pass_grid((rows + per_wg - 1) / per_wg)), \
                            dim3(kThreads), 0, s, in, out, rows, cols, input_clamp_min, rc);                           \
         break;                                                                                                        \
       }                                                                                                               \
@@ -756,13 +762,13 @@ static int softmax_dispatch(const void* in, void* out, int dtype_in, int dtype_o
     if constexpr (CAST && (D_) == DMXQ_F32) {                                                                         \
       if (fast32) {                                                                                                   \
         DMXQ_LAUNCH((softmax_wave_kernel<D_, E_, V_, L_, false, CAST, true>),                                  \
-                           dim3((unsigned)resident_grid(softmax_wave_kernel<D_, E_, V_, L_, false, CAST, true>, (rows + per_wg - 1) / per_wg)), \
+                           dim3((unsigned)one_pass_grid((rows + per_wg - 1) / per_wg)), \
                            dim3(kThreads), 0, s, in, out, rows, cols, input_clamp_min, rc);                           \
         break;                                                                                                        \
       }                                                                                                               \
     }                                                                                                                 \
       DMXQ_LAUNCH((softmax_wave_kernel<D_, E_, V_, L_, false, CAST>),                                          \
-                         dim3((unsigned)resident_grid(softmax_wave_kernel<D_, E_, V_, L_, false, CAST>, (rows + per_wg - 1) / per_wg)), \
+                         dim3((unsigned)one_pass_grid((rows + per_wg - 1) / per_wg)), \
                          dim3(kThreads), 0, s, in, out, rows, cols, input_clamp_min, rc);                             \
   } while (0)
 #define DMXQ_SM_V(D_, E_)                                                                            \
@@ -836,9 +842,23 @@ static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out,
   if (epl == full_epl && cols / epl > 256 && cols / epl <= 8 * kThreads) {  // long rows: workgroup per row
     const int64_t nv = cols / epl;
     const int vpl = (int)((nv + kThreads - 1) / kThreads);
+    // rows per workgroup iteration (round 3, tools/tune_rows -> profiles/r03_tune_rows.txt, RMSNorm / LayerNorm rows of 4096 bf16): 2, on a
+    // persistent grid (2560 / 3072 x 4096: 8.2 / 9.9 us against 9.3 / 10.8 us for one pass per workgroup) -- except tensors of 26-32 MiB,
+    // which fit the chip in ONE round of workgroups when each lane keeps ~16 vectors in flight: 8 rows per workgroup, one pass, 10.9 /
+    // 11.5 us against 11.9 / 13.2 us on 3584 / 4096 x 4096 (RMSNorm 63 -> 72 % of the roofline; LayerNorm 13.7 -> 12.3 us).  The fused
+    // module form (CAST) gains 2 % at most from it and keeps the one geometry.
+    const int64_t bytes = rows * cols * (dtype_in == DMXQ_F32 ? 4 : 2);
+    const bool mid = bytes > ((int64_t)26 << 20) && bytes <= ((int64_t)32 << 20);
 #define DMXQ_LNB(D_, E_, V_)                                                                                          \
   do {                                                                                                                \
-    constexpr int rpw = (V_) * (E_) <= 32 ? 2 : 1;                                                                    \
+    constexpr int rpw = (V_) * (E_) <= 32 ? 2 : 1, rpw_mid = 16 / (V_) >= 8 ? 8 : (16 / (V_) >= 4 ? 4 : 2);            \
+    if constexpr (!CAST && rpw_mid != rpw) {                                                                          \
+      if (mid) {                                                                                                      \
+        DMXQ_LAUNCH((layernorm_block_kernel<D_, E_, V_, RMS, CAST, rpw_mid>), dim3(one_pass_grid((rows + rpw_mid - 1) / rpw_mid)),   \
+                    dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps, rc);                                \
+        break;                                                                                                        \
+      }                                                                                                               \
+    }                                                                                                                 \
     DMXQ_LAUNCH((layernorm_block_kernel<D_, E_, V_, RMS, CAST>),                                                    \
                        dim3((unsigned)resident_grid(layernorm_block_kernel<D_, E_, V_, RMS, CAST>, (rows + rpw - 1) / rpw)), \
                        dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps, rc);                             \

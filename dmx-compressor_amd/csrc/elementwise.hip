@@ -52,8 +52,9 @@ __device__ __forceinline__ float rnd_unit(uint64_t seed, uint64_t idx) {
 // (streaming skeleton, geometry and the channel walker: stream.hpp)
 template <int RND>
 struct FloatOp {
-  static constexpr bool kHeavy = true;  // 13 (nearest) to ~25 VALU ops per element: stagger workgroups (stream.hpp; the one-round 512 x 16 tiling measured 14.4 us,
-  static constexpr int kTileUnroll = 8;  // 256 x 4 13.5 us, 256 x 8 12.1 us)
+  static constexpr bool kHeavy = true;  // 13 (nearest) to ~25 VALU ops per element
+  // 20-32 MiB tensors (stream.hpp): E4M3 on 3072 / 3584 / 4096 x 4096 bf16: 64 x 8 9.7 / 11.1 / 11.9 us, 256 x 8 9.5 / 12.4 / 12.8; any x 16 spills
+  static constexpr int kTileUnroll = 8, kTileThreads = RND == DMXQ_ROUND_NEAREST ? 64 : 256;
   FloatFmt f;
   FloatFast k;
   FlushFast ff;
@@ -124,8 +125,9 @@ static inline int pick_mode(int64_t C, int64_t inner, int64_t group_size, int ep
 template <int MODE, bool SIMPLE = false>
 struct FixedOp {
   static constexpr bool kHeavy = true;
-  // clamped integer formats: no affine = ~6 VALU per element (one round of 512 x 16 tiles: 11.6 vs 12.7 us), with a scale 256 x 8
-  static constexpr int kTileUnroll = !SIMPLE ? 4 : (MODE == kNone ? 16 : 8);  // (round 3: one round of 512 x 16 tiles with a per-group scale measured 16.7 us against 14.0 us for 256 x 8)
+  // 20-32 MiB tensors (stream.hpp), clamped integer formats, 3072 / 3584 / 4096 x 4096 bf16: no affine 64 x 16 8.5 / 9.9 / 11.1 us (256 x 8
+  // 9.9 / 11.8 / 13.7); per-group scale 128 x 16 11.1 / 11.6 / 12.4 us (256 x 8 10.9 / 13.9 / 14.9; 512 x 16 12.2 / 12.9 / 13.7)
+  static constexpr int kTileUnroll = !SIMPLE ? 4 : 16, kTileThreads = !SIMPLE ? 256 : (MODE == kNone ? 64 : 128);
   FixedFmt f;
   ChannelMap cm;
   const float* scale;
@@ -156,44 +158,75 @@ struct FixedOp {
     }
     y = q(x, sc, z, e);
   }
-  // lastdim_kernel interface (per-channel along the contiguous dim): the N channels of a lane stay in registers
-  template <int N> struct ChanParams { float sc[N], z[N], rs[N]; bool fast; };
+  // lastdim_kernel interface (per-channel along the contiguous dim): the N channels of a lane stay in registers, as PAIRS for the
+  // packed fp32 pipe (scale, reciprocal, zero point: 3 N registers)
+  template <int N> struct ChanParams { f32x2 d[N / 2], rs[N / 2], z[N / 2]; bool fast; };
+  template <int N> struct RawParams { f32x4 sc[N / 4]; i64x2 zp[N / 2]; };
+  // the table reads only (the kernel issues them, then its data loads, and only then make_params: nothing waits on a load before
+  // the last one is in flight)
   template <int N>
-  __device__ __forceinline__ ChanParams<N> load_params(int64_t c0) const {
+  __device__ __forceinline__ RawParams<N> fetch_params(int64_t c0) const {
+    static_assert(N % 4 == 0, "vectors of 4 or 8 channels");
+    RawParams<N> r;
+#pragma unroll
+    for (int k = 0; k < N / 4; k++) r.sc[k] = *(const f32x4*)(scale + c0 + 4 * k);
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) r.zp[k] = *(const i64x2*)(zp + c0 + 2 * k);
+    return r;
+  }
+  // (float)(int64): one v_cvt when the value fits 32 bits (every real zero point), the long conversion otherwise
+  static __device__ __forceinline__ float zp_float(int64_t v) {
+    return (int64_t)(int32_t)v == v ? (float)(int32_t)v : (float)v;
+  }
+  template <int N>
+  __device__ __forceinline__ ChanParams<N> make_params(const RawParams<N>& r) const {
     ChanParams<N> p;
-#pragma unroll
-    for (int k = 0; k < N; k += 4) {
-      const f32x4 t = *(const f32x4*)(scale + c0 + k);
-      p.sc[k] = t.x; p.sc[k + 1] = t.y; p.sc[k + 2] = t.z; p.sc[k + 3] = t.w;
-    }
-#pragma unroll
-    for (int k = 0; k < N; k += 2) {
-      const i64x2 t = *(const i64x2*)(zp + c0 + k);
-      p.z[k] = (float)t.x; p.z[k + 1] = (float)t.y;
-    }
-    // reciprocals of the lane's N channel scales, once per column strip (the lanes then walk down the rows)
     bool ok = SIMPLE;
 #pragma unroll
-    for (int k = 0; k < N; k++) { p.rs[k] = 1.0f / p.sc[k]; ok = ok && recip_ok(p.sc[k]); }
+    for (int k = 0; k < N / 2; k++) {
+      const f32x4 t = r.sc[k / 2];
+      p.d[k] = (k % 2 == 0) ? (f32x2){t.x, t.y} : (f32x2){t.z, t.w};
+      p.z[k] = (f32x2){zp_float(r.zp[k].x), zp_float(r.zp[k].y)};
+      // reciprocals of the lane's N channel scales, once per workgroup
+      p.rs[k] = (f32x2){1.0f / p.d[k].x, 1.0f / p.d[k].y};
+      ok = ok && recip_ok(p.d[k].x) && recip_ok(p.d[k].y);
+    }
     p.fast = ok;  // per lane: every one of its N scales has an exact-enough reciprocal
     return p;
   }
   template <int N>
   __device__ __forceinline__ void apply_chan(const float (&x)[N], const ChanParams<N>& p, float (&y)[N], int64_t e0) const {
     if (SIMPLE) {
-      // reciprocal form unconditionally (straight-line code); lanes holding a scale outside its range redo theirs with the
-      // IEEE division behind one cold branch (as bfp_rows.hpp does for its literal path)
+      // the arithmetic of common.hpp affine_int_pairs with a (scale, reciprocal, zero point) PAIR per instruction: ~7.5 VALU per
+      // element, straight-line.  Lanes holding a scale outside the reciprocal's range, or an Inf / NaN quotient, redo their vector
+      // with the IEEE division behind one cold wave-uniform branch.
+      bool redo = !p.fast;
 #pragma unroll
-      for (int k = 0; k < N; k++) y[k] = q<true>(x[k], p.sc[k], p.z[k], e0 + k, p.rs[k]);
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(!p.fast) != 0ull, 0)) {
-        if (!p.fast) {
+      for (int k = 0; k < N; k += 2) {
+        const f32x2 d = p.d[k / 2], rs = p.rs[k / 2], z = p.z[k / 2];
+        const f32x2 n2 = {x[k], x[k + 1]};
+        const f32x2 q0 = n2 * rs;
+        const f32x2 t = __builtin_elementwise_fma(d, q0, -n2);  // -(r): r = n - d q0, exact
+        const f32x2 q = __builtin_elementwise_fma(-t, rs, q0);
+        redo = redo || __builtin_amdgcn_classf(q0.x, 0x001 | 0x002 | 0x004 | 0x200) || __builtin_amdgcn_classf(q0.y, 0x001 | 0x002 | 0x004 | 0x200);
+        f32x2 u = q + z;
+        u = (u + 0.5f) - 0.5f;
+        f32x2 v;
+        v.x = __builtin_amdgcn_fmed3f(__builtin_rintf(u.x), f.t_min, f.t_max);
+        v.y = __builtin_amdgcn_fmed3f(__builtin_rintf(u.y), f.t_min, f.t_max);
+        const f32x2 o = (v - z) * d;
+        y[k] = o.x;
+        y[k + 1] = o.y;
+      }
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo) != 0ull, 0)) {
+        if (redo) {
 #pragma unroll
-          for (int k = 0; k < N; k++) y[k] = q(x[k], p.sc[k], p.z[k], e0 + k);
+          for (int k = 0; k < N; k++) y[k] = q(x[k], p.d[k / 2][k % 2], p.z[k / 2][k % 2], e0 + k);
         }
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < N; k++) y[k] = q(x[k], p.sc[k], p.z[k], e0 + k);
+      for (int k = 0; k < N; k++) y[k] = q(x[k], p.d[k / 2][k % 2], p.z[k / 2][k % 2], e0 + k);
     }
   }
   // the vector's (scale, zero point) when it has a single one: fetched ahead of the arithmetic (stream.hpp OpPrep)
@@ -301,12 +334,20 @@ struct ScaleOp {
     y = DIVIDE ? x / s : x * s;
   }
   template <int N> struct ChanParams { float s[N]; };
+  template <int N> struct RawParams { f32x4 sc[N / 4]; };
   template <int N>
-  __device__ __forceinline__ ChanParams<N> load_params(int64_t c0) const {
+  __device__ __forceinline__ RawParams<N> fetch_params(int64_t c0) const {
+    RawParams<N> r;
+#pragma unroll
+    for (int k = 0; k < N / 4; k++) r.sc[k] = *(const f32x4*)(scale + c0 + 4 * k);
+    return r;
+  }
+  template <int N>
+  __device__ __forceinline__ ChanParams<N> make_params(const RawParams<N>& r) const {
     ChanParams<N> p;
 #pragma unroll
     for (int k = 0; k < N; k += 4) {
-      const f32x4 t = *(const f32x4*)(scale + c0 + k);
+      const f32x4 t = r.sc[k / 4];
       p.s[k] = t.x; p.s[k + 1] = t.y; p.s[k + 2] = t.z; p.s[k + 3] = t.w;
     }
     return p;
@@ -390,45 +431,63 @@ struct BernoulliOp {
 };
 
 // Per-channel parameters along the CONTIGUOUS dim (activations per hidden channel, SmoothQuant's input / weight
-// scaling): a lane keeps the parameters of its EPL channels in registers and walks down the rows, instead of
+// scaling): a lane keeps the parameters of its EPL channels in registers and handles RPI rows of them, instead of
 // re-reading the scale / zero-point tables (12 B per element, 3x the data itself) for every lane-vector.
-// Layout: lpr = min(cv, 256) lanes per row (cv = C / EPL vectors per row), rpp = 256 / lpr rows side by side in a
-// workgroup, column strips of 256 vectors (grid.y) when rows are longer; RPI row groups in flight per iteration.
-// RPI rows are in flight per lane and iteration: all their loads are issued first, every row is converted into registers,
-// then the stores go out as one burst (the schedule of bfp_rows.hpp).  The per-lane channel parameters (8 scales, 8 zero
-// points = 96 B, plus 8 reciprocals) cost more than a row's data (16 B in, 16 B out), so a workgroup must own MANY rows:
-// RPI = 8 and a grid of about four workgroups per CU (round 1 ran 4 rows per workgroup: the setup was most of the work,
-// 43 % of roofline for per-channel INT8).
-template <int DTI, int DTO, class OP, int RPI>
-__global__ __launch_bounds__(kThreads) void lastdim_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t rows,
-                                                          int64_t C, int cv, int lpr, int rpp, OP op) {
+// Layout: lpr = min(cv, THREADS) lanes per row (cv = C / EPL vectors per row), rpp = THREADS / lpr rows side by side in a
+// workgroup, column strips of THREADS vectors (grid.y) when rows are longer; a workgroup owns rpp * RPI rows, ONE pass.
+// Schedule (round 3, tools/tune_lastdim -> profiles/r03_tune_lastdim.txt): table reads, then all RPI data loads, and only then the
+// parameter arithmetic (8 reciprocals, int64 -> float) -- rounds 1-2 finished the parameters first, i.e. a full L2 round trip plus
+// ~350 VALU before the first HBM request of a workgroup (48 % of roofline for per-channel INT8).  Every row is converted into
+// registers, then the stores go out as one burst (the schedule of bfp_rows.hpp).  One pass per workgroup and 16 rows in flight
+// measured best throughout: looping workgroups (2-16 passes) lost 10-50 %.
+template <int DTI, int DTO, class OP, int THREADS, int RPI>
+__global__ __launch_bounds__(THREADS) void lastdim_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t rows,
+                                                         int64_t C, int cv, int lpr, int rpp, OP op) {
   constexpr int EPL = 16 / Elem<DTI>::bytes, OVB = EPL * Elem<DTO>::bytes;
   const int t = threadIdx.x;
   const int sub = t / lpr, sl = t - sub * lpr;
   const int cb = blockIdx.y * lpr + sl;
   const bool active = sub < rpp && cb < cv;
   const int cbc = cb < cv ? cb : cv - 1;
-  const auto p = op.template load_params<EPL>((int64_t)cbc * EPL);
   const int subc = sub < rpp ? sub : rpp - 1;
-  const int64_t step = (int64_t)gridDim.x * rpp * RPI;
-  for (int64_t r0 = (int64_t)blockIdx.x * rpp * RPI; r0 < rows; r0 += step) {
-    u32x4 raw[RPI];
+  const int64_t r0 = (int64_t)blockIdx.x * rpp * RPI;
+  const auto pr = op.template fetch_params<EPL>((int64_t)cbc * EPL);
+  // whole workgroups (all but the last along the rows): a scalar base per row group + one 32-bit lane offset, no per-load address
+  // arithmetic between the loads; the last one clamps its rows (unconditional loads) and predicates its stores
+  const bool whole = r0 + (int64_t)rpp * RPI <= rows;  // wave-uniform
+  const uint32_t lane_v = (uint32_t)subc * (uint32_t)cv + (uint32_t)cbc;
+  u32x4 raw[RPI];
+  if (whole) {
+    const char* src = (const char*)in + r0 * cv * 16;
+#pragma unroll
+    for (int j = 0; j < RPI; j++) raw[j] = load_raw16<true, uint32_t>(src + (int64_t)j * rpp * cv * 16, lane_v * 16u);
+  } else {
 #pragma unroll
     for (int j = 0; j < RPI; j++) {
       const int64_t r = r0 + (int64_t)j * rpp + subc;
-      raw[j] = load_raw16<true>(in, ((r < rows ? r : rows - 1) * cv + cbc) * 16);  // clamped: unconditional loads
+      raw[j] = load_raw16<true>(in, ((r < rows ? r : rows - 1) * cv + cbc) * 16);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    OutVec<DTO, EPL> o[RPI];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const auto p = op.template make_params<EPL>(pr);
+  __builtin_amdgcn_sched_barrier(0);
+  OutVec<DTO, EPL> o[RPI];
 #pragma unroll
-    for (int j = 0; j < RPI; j++) {
-      const int64_t r = r0 + (int64_t)j * rpp + sub;
-      float x[EPL], y[EPL];
-      widen<DTI, EPL>(raw[j], x);
-      op.apply_chan(x, p, y, r * C + (int64_t)cb * EPL);
-      o[j] = pack_vec<DTO, EPL>(y);
-      __builtin_amdgcn_sched_barrier(0);
+  for (int j = 0; j < RPI; j++) {
+    const int64_t r = r0 + (int64_t)j * rpp + sub;
+    float x[EPL], y[EPL];
+    widen<DTI, EPL>(raw[j], x);
+    op.apply_chan(x, p, y, r * C + (int64_t)cb * EPL);
+    o[j] = pack_vec<DTO, EPL>(y);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (whole) {
+    char* dst = (char*)out + r0 * cv * OVB;
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < RPI; j++) store_out<DTO, EPL, true>(dst + (int64_t)j * rpp * cv * OVB + lane_v * (uint32_t)OVB, o[j]);
     }
+  } else {
 #pragma unroll
     for (int j = 0; j < RPI; j++) {
       const int64_t r = r0 + (int64_t)j * rpp + sub;
@@ -437,30 +496,39 @@ __global__ __launch_bounds__(kThreads) void lastdim_kernel(const void* __restric
   }
 }
 
+// Geometry of one lastdim launch: THREADS lanes per workgroup, RPI rows per lane, gx workgroups along the rows
+struct LastdimPlan { int threads, rpi; int64_t gx; int cv, lpr, rpp, strips; };
+static inline bool lastdim_plan(int dti, int64_t rows, int64_t C, LastdimPlan* pl) {
+  const int epl = dti == DMXQ_F32 ? 4 : 8;
+  if (C % epl != 0 || C / epl > 0x7FFFFFFF || rows < 1) return false;
+  const int cv = (int)(C / epl);
+  const int threads = kThreads;
+  const int lpr = cv < threads ? cv : threads, rpp = threads / lpr;
+  const int strips = (cv + lpr - 1) / lpr;
+  if (strips > 65535 || (int64_t)rpp * cv * 32 > 0xFFFFFFFFll) return false;  // (32-bit lane offsets: a row group < 4 GiB in either dtype)
+  // rows per lane: as many (16, 8, 4) as still leave two workgroups per CU
+  int rpi = 16;
+  while (rpi > 4 && ((rows + (int64_t)rpp * rpi - 1) / ((int64_t)rpp * rpi)) * strips < 512) rpi >>= 1;
+  const int64_t gx = (rows + (int64_t)rpp * rpi - 1) / ((int64_t)rpp * rpi);
+  if (gx > 0x7FFFFFFF) return false;
+  *pl = LastdimPlan{threads, rpi, gx, cv, lpr, rpp, strips};
+  return true;
+}
+
 // DMXQ_ERR_UNSUPPORTED: not applicable (caller keeps the streaming kernel)
 template <class OP>
 static int launch_lastdim(const void* in, void* out, int dti, int dto, int64_t rows, int64_t C, const OP& op, hipStream_t s) {
-  const int epl = dti == DMXQ_F32 ? 4 : 8;
-  if (C % epl != 0 || !aligned16(in) || !aligned16(out) || C / epl > 0x7FFFFFFF || rows < 1) return DMXQ_ERR_UNSUPPORTED;
-  const int cv = (int)(C / epl), lpr = cv < kThreads ? cv : kThreads, rpp = kThreads / lpr;
-  const int strips = (cv + lpr - 1) / lpr;
-  if (strips > 65535) return DMXQ_ERR_UNSUPPORTED;
-  // rows in flight per lane: 8 when there are enough rows to fill ~4 workgroups per CU with them, else 4
-  const bool big = rows >= (int64_t)rpp * 8 * ((1024 + strips - 1) / strips);
-  const int rpi = big ? 8 : 4;
-  int64_t gx = (rows + (int64_t)rpp * rpi - 1) / ((int64_t)rpp * rpi);
-  const int64_t cap = (2048 + strips - 1) / strips;
-  if (gx > cap) gx = cap;
-  if (gx < 1) gx = 1;
-#define DMXQ_LD(I_, O_)                                                                                               \
-  if (dti == I_ && dto == O_) {                                                                                       \
-    if (big)                                                                                                          \
-      DMXQ_LAUNCH((lastdim_kernel<I_, O_, OP, 8>), dim3((unsigned)gx, (unsigned)strips), dim3(kThreads), 0, s, in, out, \
-                  rows, C, cv, lpr, rpp, op);                                                                         \
-    else                                                                                                              \
-      DMXQ_LAUNCH((lastdim_kernel<I_, O_, OP, 4>), dim3((unsigned)gx, (unsigned)strips), dim3(kThreads), 0, s, in, out, \
-                  rows, C, cv, lpr, rpp, op);                                                                         \
-    return launch_status();                                                                                           \
+  LastdimPlan pl;
+  if (!aligned16(in) || !aligned16(out) || !lastdim_plan(dti, rows, C, &pl)) return DMXQ_ERR_UNSUPPORTED;
+#define DMXQ_LDK(I_, O_, T_, R_)                                                                                            \
+  DMXQ_LAUNCH((lastdim_kernel<I_, O_, OP, T_, R_>), dim3((unsigned)pl.gx, (unsigned)pl.strips), dim3(T_), 0, s, in, out, rows, C, \
+              pl.cv, pl.lpr, pl.rpp, op)
+#define DMXQ_LD(I_, O_)                                        \
+  if (dti == I_ && dto == O_) {                                \
+    if (pl.rpi == 16) DMXQ_LDK(I_, O_, kThreads, 16);          \
+    else if (pl.rpi == 8) DMXQ_LDK(I_, O_, kThreads, 8);       \
+    else DMXQ_LDK(I_, O_, kThreads, 4);                        \
+    return launch_status();                                    \
   }
   DMXQ_LD(DMXQ_BF16, DMXQ_BF16)
   DMXQ_LD(DMXQ_F16, DMXQ_F16)
@@ -468,6 +536,7 @@ static int launch_lastdim(const void* in, void* out, int dti, int dto, int64_t r
   DMXQ_LD(DMXQ_BF16, DMXQ_F32)
   DMXQ_LD(DMXQ_F16, DMXQ_F32)
 #undef DMXQ_LD
+#undef DMXQ_LDK
   return DMXQ_ERR_UNSUPPORTED;
 }
 

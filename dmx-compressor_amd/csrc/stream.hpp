@@ -120,16 +120,19 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict_
   }
 }
 
-// Geometry.  Small tensors: 256 x 1 tiles (many workgroups).  Big ones (>= 256 workgroups of 256 x 4 vectors): the op says
-// how many 16-byte vectors a lane keeps in flight, by how much arithmetic it carries per element -- measured on 4096 x 4096
-// bf16 (profiles/r02_stream_geometry.txt, one box, all eight geometries per op):
-//   kTileUnroll 16  almost no arithmetic (INT8 without affine, scale multiply): ONE round of 512 x 16 tiles, one workgroup per CU,
-//                   when the tensor is 224-256 such tiles (11.6 us vs 12.7 us); otherwise 256 x 8
-//   kTileUnroll 8   light (minifloat cast, silu, INT8 with a per-group scale): 256 x 8   (E4M3 12.1 vs 13.5 us, silu 11.4 vs 12.7 us)
-//   kTileUnroll 4   default for kHeavy ops
-//   kTileUnroll 2   VALU-heavy (erf gelu, quick_gelu's dtype chain, the composite block formats): 256 x 2 -- or 512 x 2 with
-//                   kTileThreads 512 (SBFP: 17.4 vs 18.3 us) -- so that several workgroups per CU interleave their compute with
-//                   each other's memory phases
+// Geometry: workgroup-contiguous tiles of THREADS x UNROLL 16-byte vectors, one tile per workgroup.  Round 3 measured every op of the
+// library over 15 geometries and 13 tensor sizes with the kernels themselves (tools/tune_stream -> profiles/r03_tune_stream.txt).
+// What holds for ALL of them, light or VALU-heavy, is the rule by tensor size -- keep the whole tensor in flight in ONE round of
+// resident workgroups while that is possible, with as few loads per lane as that takes:
+//     <=  2 MiB of input   256 x 1
+//     <= 12 MiB            256 x 2      (silu on 8 MiB: 4.4 us; the 256 x 8 tiles of round 2 took 7.0)
+//     <= 20 MiB            256 x 4
+//     <= 32 MiB            the op's own geometry, kTileThreads x kTileUnroll (default 256 x 4 for kHeavy ops, 256 x 16 otherwise): here
+//                          the ops differ by how much arithmetic sits between the load burst and the store burst -- e.g. INT8 without a
+//                          scale 64 x 16, with a per-group scale 128 x 16, minifloat cast 64 x 8, silu 256 x 8, the fused GELU module
+//                          512 x 4, the fused SiLU module 512 x 16 (4096 x 4096 bf16: 11.1 / 12.4 / 11.9 / 11.4 / 13.7 / 11.7 us)
+//     beyond               256 x 2: several rounds per CU are needed anyway, and small tiles whose workgroups drift apart (reads of one
+//                          overlapping writes of another) measured best for every op (77 % of 8 TB/s at 112 MiB)
 template <class OP, class = void> struct OpHeavy { static constexpr bool value = false; };
 template <class OP> struct OpHeavy<OP, decltype((void)OP::kHeavy)> { static constexpr bool value = OP::kHeavy; };
 template <class OP, class = void> struct OpTileUnroll { static constexpr int value = OpHeavy<OP>::value ? 4 : 16; };
@@ -140,9 +143,10 @@ template <class OP> struct OpTileThreads<OP, decltype((void)OP::kTileThreads)> {
 template <int DTI, int DTO, class OP>
 static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hipStream_t s) {
   constexpr int EPL = 16 / Elem<DTI>::bytes;
-  constexpr int UB = (Elem<DTO>::bytes > Elem<DTI>::bytes) ? 8 : 16;
-  constexpr int TU = OpTileUnroll<OP>::value, TT = OpTileThreads<OP>::value;
+  constexpr int UB = (Elem<DTO>::bytes > Elem<DTI>::bytes) ? 8 : 16;  // (a widening output doubles the registers a vector holds)
+  constexpr int TT = OpTileThreads<OP>::value, TU = OpTileUnroll<OP>::value < UB ? OpTileUnroll<OP>::value : UB;
   static_assert(TU == 16 || TU == 8 || TU == 4 || TU == 2, "kTileUnroll");
+  static_assert(TT == 64 || TT == 128 || TT == 256 || TT == 512, "kTileThreads");
   const int64_t n_vec = n / EPL;
   if (!aligned16(in) || !aligned16(out)) {  // views that start mid-allocation: same schedule on unaligned 16-byte accesses
     int64_t tiles = (n_vec + (int64_t)256 * 4 - 1) / ((int64_t)256 * 4);
@@ -158,12 +162,11 @@ static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hip
     if (tiles > (1 << 20)) tiles = 1 << 20;                                                                       \
     DMXQ_LAUNCH((stream_kernel<DTI, DTO, U_, T_, OP>), dim3((unsigned)tiles), dim3(T_), 0, s, in, out, n, op); \
   } while (0)
-  if (n_vec < (int64_t)256 * 256 * 4) DMXQ_STREAM(256, 1);
-  else if constexpr (TU == 16) {
-    const int64_t big_tiles = (n_vec + (int64_t)512 * UB - 1) / ((int64_t)512 * UB);
-    if (big_tiles <= 256 && big_tiles >= 224) DMXQ_STREAM(512, UB);  // one full round
-    else DMXQ_STREAM(256, 8);
-  } else DMXQ_STREAM(TT, TU);
+  if (n_vec <= ((int64_t)1 << 17)) DMXQ_STREAM(256, 1);
+  else if (n_vec <= ((int64_t)3 << 18)) DMXQ_STREAM(256, 2);
+  else if (n_vec <= ((int64_t)5 << 18)) DMXQ_STREAM(256, 4);
+  else if (n_vec <= ((int64_t)1 << 21)) DMXQ_STREAM(TT, TU);
+  else DMXQ_STREAM(256, 2);
 #undef DMXQ_STREAM
   return launch_status();
 }
