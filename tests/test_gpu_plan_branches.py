@@ -1,0 +1,170 @@
+"""-m gpu: every launch-geometry branch of the size-dependent plans computes the same values.
+
+Round 3 made the tile geometry of the flat-stream kernels a function of the tensor size (csrc/stream.hpp launch_stream: 256 x 1 up
+to 2 MiB, 256 x 2 up to 12 MiB, 256 x 4 up to 20 MiB, the op's own geometry up to 32 MiB -- 64 x 16, 128 x 16, 64 x 8, 512 x 4, 512 x 16 ...
+-- and 256 x 2 beyond), gave the per-channel kernel along the contiguous dim 4 / 8 / 16 rows per lane by size (csrc/elementwise.hip
+lastdim_plan), the norm workgroup kernel 8 rows per pass for 26-32 MiB tensors and softmax one pass per workgroup (csrc/approx.hip).
+The oracle-parity tests run at small sizes (the 256 x 1 branch) and at 4096 x 4096; this file closes the gap with a size-independent
+property of these ops: they are per element (or per row / per block / per quantisation group), so the result on a big tensor must
+equal, bit for bit, the results on its row slabs -- each small enough to take the 256 x 1 branch the oracle tests pin.  Sizes are chosen to hit every
+branch, including a tensor one row past the 32 MiB boundary and row counts that leave partial tiles."""
+import pytest
+import torch
+
+from _data import bits_equal, make
+
+pytestmark = pytest.mark.gpu
+BF16, F32, F16 = torch.bfloat16, torch.float32, torch.float16
+
+# rows of a [rows, 4096] 16-bit tensor (float32: [rows, 2048], the same bytes): 2.3 MiB (256 x 2), 12.5 MiB (256 x 4), 20.3 MiB and 32 MiB
+# (the op's own geometry), 32.8 MiB and 48 MiB (256 x 2 again)
+ROWS = [300, 1600, 2600, 4096, 4200, 6144]
+SLAB = 128  # rows per reference slab: 1 MiB -> the 256 x 1 branch; a multiple of every group / block size used below
+
+
+def _input(rows, dtype, seed):
+    cols = 2048 if dtype == F32 else 4096
+    x = make("heavy", (rows, cols), seed=seed, dtype=torch.float32).clamp(-3e4, 3e4)
+    x.view(-1)[:: 4099] = 0.0
+    x.view(-1)[5:: 8191] = -0.0
+    return x.to(dtype)
+
+
+def _slabs(fn, x, per_slab_args=None):
+    outs = []
+    for i, r0 in enumerate(range(0, x.shape[0], SLAB)):
+        xs = x[r0:r0 + SLAB].contiguous()
+        outs.append(fn(xs, i) if per_slab_args else fn(xs))
+    return torch.cat(outs, 0)
+
+
+def _check(tag, whole, parts):
+    bad = bits_equal(whole, parts)
+    assert bad == 0, f"{tag}: {bad} elements differ between the whole-tensor launch and its 128-row slabs"
+
+
+@pytest.mark.parametrize("rows", ROWS)
+@pytest.mark.parametrize("dtype", [BF16, F16, F32], ids=["bf16", "f16", "f32"])
+def test_per_element_casts_and_functions(dmx, cuda, rows, dtype):
+    ops = dmx.ops
+    x = _input(rows, dtype, seed=rows).to(cuda)
+    fp16 = dmx.Format.from_shorthand("FP[1|5|10,15](FN)")
+    cases = {
+        "float_qdq E4M3": lambda t: ops.float_qdq(t, 3, 4, 7, False),
+        "float_qdq FP16(FN)": lambda t: ops.float_qdq(t, 10, 5, 15, True),
+        "float_qdq E5M2 stochastic-free up": lambda t: ops.float_qdq(t, 2, 5, 15, False, rounding="up"),
+        "fixed_qdq INT8": lambda t: ops.fixed_qdq(t, 8, 0),
+        "fixed_qdq XP[8,4] unclamped": lambda t: ops.fixed_qdq(t, 8, 4, clamp=False),
+        "gelu": lambda t: ops.gelu(t),
+        "gelu tanh": lambda t: ops.gelu(t, approximate="tanh"),
+        "silu": lambda t: ops.silu(t),
+        "quick_gelu": lambda t: ops.quick_gelu(t),
+        "unary_cast gelu FLOAT16": lambda t: ops.unary_cast(t, "gelu", fp16, fp16),
+        "unary_cast silu FLOAT16": lambda t: ops.unary_cast(t, "silu", fp16, fp16),
+        "unary_cast quick_gelu FLOAT16": lambda t: ops.unary_cast(t, "quick_gelu", fp16, fp16),
+        "relu_cast FLOAT16": lambda t: ops.relu_cast(t, fp16, fp16),
+    }
+    for tag, fn in cases.items():
+        whole = fn(x)
+        assert whole is not None, tag
+        _check(f"{tag} {dtype} rows={rows}", whole, _slabs(fn, x))
+
+
+@pytest.mark.parametrize("rows", ROWS)
+@pytest.mark.parametrize("dtype", [BF16, F32], ids=["bf16", "f32"])
+def test_affine_integer_casts(dmx, cuda, rows, dtype):
+    """INT8 with a scale per group of 128 rows (stream kernel, one scale per tile), per row (stream kernel, channel walker), per
+    column (lastdim kernel: 4 / 8 / 16 rows per lane by size) and SmoothQuant's per-column divide / multiply."""
+    ops = dmx.ops
+    x = _input(rows, dtype, seed=7 * rows).to(cuda)
+    cols = x.shape[1]
+    g = torch.Generator().manual_seed(rows)
+    n_groups = -(-rows // 128)
+    sc_g = (torch.rand(n_groups, generator=g) * 0.2 + 0.01).to(cuda)
+    zp_g = torch.randint(-5, 6, (n_groups,), generator=g).to(cuda)
+    sc_r = (torch.rand(rows, generator=g) * 0.2 + 0.01).to(cuda)
+    zp_r = torch.randint(-5, 6, (rows,), generator=g).to(cuda)
+    sc_c = (torch.rand(cols, generator=g) * 0.2 + 0.01)
+    sc_c[3] = 3e-7            # outside the reciprocal form's range: the lane redoes its vector with the IEEE division
+    sc_c[cols - 1] = 2.5e6
+    sc_c = sc_c.to(cuda)
+    zp_c = torch.randint(-5, 6, (cols,), generator=g).to(cuda)
+
+    whole = ops.fixed_qdq(x, 8, 0, scale=sc_g, zero_point=zp_g, ch_axis=0, group_size=128)
+    parts = _slabs(lambda t, i: ops.fixed_qdq(t, 8, 0, scale=sc_g[i:i + 1], zero_point=zp_g[i:i + 1], ch_axis=0, group_size=128), x, True)
+    _check(f"INT8 group 128 {dtype} rows={rows}", whole, parts)
+
+    whole = ops.fixed_qdq(x, 8, 0, scale=sc_r, zero_point=zp_r, ch_axis=0)
+    parts = _slabs(lambda t, i: ops.fixed_qdq(t, 8, 0, scale=sc_r[i * SLAB:(i + 1) * SLAB], zero_point=zp_r[i * SLAB:(i + 1) * SLAB], ch_axis=0), x, True)
+    _check(f"INT8 per row {dtype} rows={rows}", whole, parts)
+
+    whole = ops.fixed_qdq(x, 8, 0, scale=sc_c, zero_point=zp_c, ch_axis=1)
+    _check(f"INT8 per column {dtype} rows={rows}", whole, _slabs(lambda t: ops.fixed_qdq(t, 8, 0, scale=sc_c, zero_point=zp_c, ch_axis=1), x))
+    # ... against the per-element definition as well (cast.py:278-296 on the GPU's own torch ops; IEEE division): the lastdim kernel is new
+    xf = x.float()
+    q = torch.clamp(torch.round((xf / sc_c + zp_c) + 0.5 - 0.5), -127, 127)   # (symmetric=True: [-127, 127])
+    # (sim_helper's (a + 0.5) - 0.5 pre-step equals torch.round's half-even except where the fp32 add rounds; compare loosely here,
+    #  the bit-exact statement is the slab identity above plus the small-size oracle tests)
+    ref = ((q - zp_c) * sc_c).to(dtype)
+    assert bool(((whole.float() - ref.float()).abs() <= sc_c * 1.6).all())
+
+    for divide in (True, False):
+        whole = ops.scale_channels(x, sc_c, 1, divide)
+        _check(f"scale_channels divide={divide} {dtype} rows={rows}", whole, _slabs(lambda t: ops.scale_channels(t, sc_c, 1, divide), x))
+
+
+@pytest.mark.parametrize("rows", ROWS)
+def test_block_formats(dmx, cuda, rows):
+    ops = dmx.ops
+    x = _input(rows, BF16, seed=11 * rows).to(cuda)
+    cases = {
+        "MXFP8[E4M3]{32}": lambda t: ops.mxfp_qdq(t, 3, 4, 32),
+        "MXFP4[E2M1]{32}": lambda t: ops.mxfp_qdq(t, 1, 2, 32),
+        "SBFP12_16": lambda t: ops.sbfp_qdq(t, 4, 16, 4, 4, 7, False),
+        "BFP[8|8]{16}": lambda t: ops.bfp_qdq(t, 8, 16),
+        "BFP[8|8]{64} asym": lambda t: ops.bfp_qdq(t, 8, 64, symmetric=False),
+        "BFP[8|8]{64} along rows": lambda t: ops.bfp_qdq(t, 8, 64, block_dim=0),
+    }
+    for tag, fn in cases.items():
+        _check(f"{tag} rows={rows}", fn(x), _slabs(fn, x))
+
+
+@pytest.mark.parametrize("rows", [1600, 3584, 4096, 4200])
+@pytest.mark.parametrize("dtype", [BF16, F32], ids=["bf16", "f32"])
+def test_row_functions(dmx, cuda, rows, dtype):
+    """RMSNorm / LayerNorm rows of 4096 16-bit elements (workgroup-per-row kernel: 2 rows per iteration on a persistent grid, 8 rows per
+    pass at 26-32 MiB), rows of 768 (wave kernel) and softmax rows of 1500 (one pass per workgroup), plain and as fused modules."""
+    ops = dmx.ops
+    fp16 = dmx.Format.from_shorthand("FP[1|5|10,15](FN)")
+    x = (_input(rows, dtype, seed=13 * rows).float().clamp(-30, 30)).to(dtype).to(cuda)
+    cols = x.shape[1]
+    w = (torch.rand(cols, generator=torch.Generator().manual_seed(1)) + 0.5).to(dtype).to(cuda)
+    b = (torch.rand(cols, generator=torch.Generator().manual_seed(2)) - 0.5).to(dtype).to(cuda)
+    cases = {
+        "rmsnorm": lambda t: ops.rmsnorm(t, cols, w, 1e-6),
+        "layernorm": lambda t: ops.layernorm(t, cols, w, b),
+        "rmsnorm_cast": lambda t: ops.rmsnorm_cast(t, cols, w, 1e-6, fp16, fp16),
+        "layernorm_cast": lambda t: ops.layernorm_cast(t, cols, w, b, 1e-5, fp16, fp16),
+        "softmax": lambda t: ops.softmax(t),
+    }
+    for tag, fn in cases.items():
+        whole = fn(x)
+        assert whole is not None, tag
+        _check(f"{tag} {dtype} {rows}x{cols}", whole, _slabs(fn, x))
+    # short rows: the same elements viewed as rows of 768 / 1500
+    n = x.numel()
+    for c, names in ((768, ("layernorm", "layernorm_cast")), (1500, ("softmax", "softmax_cast"))):
+        r = n // c
+        y = x.view(-1)[: r * c].view(r, c)
+        wc, bc = w[:c].contiguous(), b[:c].contiguous()
+        fns = {
+            "layernorm": lambda t: ops.layernorm(t, c, wc, bc),
+            "layernorm_cast": lambda t: ops.layernorm_cast(t, c, wc, bc, 1e-5, fp16, fp16),
+            "softmax": lambda t: ops.softmax(t),
+            "softmax_cast": lambda t: ops.softmax_cast(t, -1, fp16, fp16),
+        }
+        for nm in names:
+            whole = fns[nm](y)
+            assert whole is not None, nm
+            parts = torch.cat([fns[nm](y[r0:r0 + 512].contiguous()) for r0 in range(0, r, 512)], 0)
+            _check(f"{nm} {dtype} {r}x{c}", whole, parts)

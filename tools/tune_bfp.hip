@@ -73,6 +73,12 @@ int main(int argc, char** argv) {
     ADD_BFPB(false, 2, 0); ADD_BFPB(false, 8, 0); ADD_BFPB(true, 8, 0); ADD_BFPB(false, 16, 0); ADD_BFPB(true, 16, 0); ADD_BFPB(false, 4, 0);
     ADD_BFPB(false, 8, 8); ADD_BFPB(true, 8, 8); ADD_BFPB(false, 2, 2); ADD_BFPB(true, 2, 0);
     if (getenv("TUNE_WIDE")) { ADD_BFPG(8, 3, 1024, 0, 2, 8); ADD_BFPG(16, 3, 1024, 0, 2, 16); ADD_BFPG(32, 3, 256, 0, 2, 32); ADD_BFPG(16, 3, 512, 0, 2, 8); ADD_BFPG(16, 3, 512, 0, 2, 4); }
+  } else if (getenv("TUNE_SET") && std::string(getenv("TUNE_SET")) == "wg") {
+    // round 3: workgroup size at 16 (and 8) vectors per lane -- the flat-stream ops preferred 64 .. 256 lanes at the headline size
+    ADD_COPY(16, 7, 512, 0); ADD_COPY(16, 7, 256, 0); ADD_COPY(16, 7, 128, 0); ADD_COPY(16, 7, 64, 0);
+    ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPG(16, 3, 256, 0, 2, 16); ADD_BFPG(16, 3, 128, 0, 2, 16); ADD_BFPG(16, 3, 64, 0, 2, 16);
+    ADD_BFPG(8, 3, 512, 0, 2, 8); ADD_BFPG(8, 3, 256, 0, 2, 8); ADD_BFPG(8, 3, 128, 0, 2, 8); ADD_BFPG(8, 3, 64, 0, 2, 8);
+    ADD_BFPG(32, 3, 128, 0, 2, 32); ADD_BFPG(32, 3, 64, 0, 2, 32); ADD_BFPG(4, 3, 256, 0, 2, 4); ADD_BFPG(4, 3, 512, 0, 2, 4); ADD_BFPG(2, 3, 512, 0, 2, 2);
   } else if (getenv("TUNE_SET") && std::string(getenv("TUNE_SET")) == "small") {
     ADD_COPY(2, 7, 512, 0); ADD_COPY(4, 7, 512, 0);
     ADD_BFPG(1, 3, 512, 0, 2, 1); ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPG(3, 3, 512, 0, 2, 3); ADD_BFPG(4, 3, 512, 0, 2, 4); ADD_BFPG(6, 3, 512, 0, 2, 6); ADD_BFPG(8, 3, 512, 0, 2, 8);
