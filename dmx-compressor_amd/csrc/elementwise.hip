@@ -7,6 +7,7 @@
 // fp32 arithmetic, one RNE narrowing to the output dtype, 16-byte stores.  HBM-bound: 2+2 B/elem for 16-bit I/O.
 #include "floatq.hpp"
 #include "stream.hpp"
+#include "lastdim.hpp"
 #include "unary_ops.hpp"
 
 namespace dmxq {
@@ -429,116 +430,6 @@ struct BernoulliOp {
     for (int k = 0; k < N; k++) apply_one(x[k], y[k], e0 + k);
   }
 };
-
-// Per-channel parameters along the CONTIGUOUS dim (activations per hidden channel, SmoothQuant's input / weight
-// scaling): a lane keeps the parameters of its EPL channels in registers and handles RPI rows of them, instead of
-// re-reading the scale / zero-point tables (12 B per element, 3x the data itself) for every lane-vector.
-// Layout: lpr = min(cv, THREADS) lanes per row (cv = C / EPL vectors per row), rpp = THREADS / lpr rows side by side in a
-// workgroup, column strips of THREADS vectors (grid.y) when rows are longer; a workgroup owns rpp * RPI rows, ONE pass.
-// Schedule (round 3, tools/tune_lastdim -> profiles/r03_tune_lastdim.txt): table reads, then all RPI data loads, and only then the
-// parameter arithmetic (8 reciprocals, int64 -> float) -- rounds 1-2 finished the parameters first, i.e. a full L2 round trip plus
-// ~350 VALU before the first HBM request of a workgroup (48 % of roofline for per-channel INT8).  Every row is converted into
-// registers, then the stores go out as one burst (the schedule of bfp_rows.hpp).  One pass per workgroup and 16 rows in flight
-// measured best throughout: looping workgroups (2-16 passes) lost 10-50 %.
-template <int DTI, int DTO, class OP, int THREADS, int RPI>
-__global__ __launch_bounds__(THREADS) void lastdim_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t rows,
-                                                         int64_t C, int cv, int lpr, int rpp, OP op) {
-  constexpr int EPL = 16 / Elem<DTI>::bytes, OVB = EPL * Elem<DTO>::bytes;
-  const int t = threadIdx.x;
-  const int sub = t / lpr, sl = t - sub * lpr;
-  const int cb = blockIdx.y * lpr + sl;
-  const bool active = sub < rpp && cb < cv;
-  const int cbc = cb < cv ? cb : cv - 1;
-  const int subc = sub < rpp ? sub : rpp - 1;
-  const int64_t r0 = (int64_t)blockIdx.x * rpp * RPI;
-  const auto pr = op.template fetch_params<EPL>((int64_t)cbc * EPL);
-  // whole workgroups (all but the last along the rows): a scalar base per row group + one 32-bit lane offset, no per-load address
-  // arithmetic between the loads; the last one clamps its rows (unconditional loads) and predicates its stores
-  const bool whole = r0 + (int64_t)rpp * RPI <= rows;  // wave-uniform
-  const uint32_t lane_v = (uint32_t)subc * (uint32_t)cv + (uint32_t)cbc;
-  u32x4 raw[RPI];
-  if (whole) {
-    const char* src = (const char*)in + r0 * cv * 16;
-#pragma unroll
-    for (int j = 0; j < RPI; j++) raw[j] = load_raw16<true, uint32_t>(src + (int64_t)j * rpp * cv * 16, lane_v * 16u);
-  } else {
-#pragma unroll
-    for (int j = 0; j < RPI; j++) {
-      const int64_t r = r0 + (int64_t)j * rpp + subc;
-      raw[j] = load_raw16<true>(in, ((r < rows ? r : rows - 1) * cv + cbc) * 16);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  const auto p = op.template make_params<EPL>(pr);
-  __builtin_amdgcn_sched_barrier(0);
-  OutVec<DTO, EPL> o[RPI];
-#pragma unroll
-  for (int j = 0; j < RPI; j++) {
-    const int64_t r = r0 + (int64_t)j * rpp + sub;
-    float x[EPL], y[EPL];
-    widen<DTI, EPL>(raw[j], x);
-    op.apply_chan(x, p, y, r * C + (int64_t)cb * EPL);
-    o[j] = pack_vec<DTO, EPL>(y);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (whole) {
-    char* dst = (char*)out + r0 * cv * OVB;
-    if (active) {
-#pragma unroll
-      for (int j = 0; j < RPI; j++) store_out<DTO, EPL, true>(dst + (int64_t)j * rpp * cv * OVB + lane_v * (uint32_t)OVB, o[j]);
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < RPI; j++) {
-      const int64_t r = r0 + (int64_t)j * rpp + sub;
-      if (active && r < rows) store_out<DTO, EPL, true>((char*)out + (r * cv + cb) * OVB, o[j]);
-    }
-  }
-}
-
-// Geometry of one lastdim launch: THREADS lanes per workgroup, RPI rows per lane, gx workgroups along the rows
-struct LastdimPlan { int threads, rpi; int64_t gx; int cv, lpr, rpp, strips; };
-static inline bool lastdim_plan(int dti, int64_t rows, int64_t C, LastdimPlan* pl) {
-  const int epl = dti == DMXQ_F32 ? 4 : 8;
-  if (C % epl != 0 || C / epl > 0x7FFFFFFF || rows < 1) return false;
-  const int cv = (int)(C / epl);
-  const int threads = kThreads;
-  const int lpr = cv < threads ? cv : threads, rpp = threads / lpr;
-  const int strips = (cv + lpr - 1) / lpr;
-  if (strips > 65535 || (int64_t)rpp * cv * 32 > 0xFFFFFFFFll) return false;  // (32-bit lane offsets: a row group < 4 GiB in either dtype)
-  // rows per lane: as many (16, 8, 4) as still leave two workgroups per CU
-  int rpi = 16;
-  while (rpi > 4 && ((rows + (int64_t)rpp * rpi - 1) / ((int64_t)rpp * rpi)) * strips < 512) rpi >>= 1;
-  const int64_t gx = (rows + (int64_t)rpp * rpi - 1) / ((int64_t)rpp * rpi);
-  if (gx > 0x7FFFFFFF) return false;
-  *pl = LastdimPlan{threads, rpi, gx, cv, lpr, rpp, strips};
-  return true;
-}
-
-// DMXQ_ERR_UNSUPPORTED: not applicable (caller keeps the streaming kernel)
-template <class OP>
-static int launch_lastdim(const void* in, void* out, int dti, int dto, int64_t rows, int64_t C, const OP& op, hipStream_t s) {
-  LastdimPlan pl;
-  if (!aligned16(in) || !aligned16(out) || !lastdim_plan(dti, rows, C, &pl)) return DMXQ_ERR_UNSUPPORTED;
-#define DMXQ_LDK(I_, O_, T_, R_)                                                                                            \
-  DMXQ_LAUNCH((lastdim_kernel<I_, O_, OP, T_, R_>), dim3((unsigned)pl.gx, (unsigned)pl.strips), dim3(T_), 0, s, in, out, rows, C, \
-              pl.cv, pl.lpr, pl.rpp, op)
-#define DMXQ_LD(I_, O_)                                        \
-  if (dti == I_ && dto == O_) {                                \
-    if (pl.rpi == 16) DMXQ_LDK(I_, O_, kThreads, 16);          \
-    else if (pl.rpi == 8) DMXQ_LDK(I_, O_, kThreads, 8);       \
-    else DMXQ_LDK(I_, O_, kThreads, 4);                        \
-    return launch_status();                                    \
-  }
-  DMXQ_LD(DMXQ_BF16, DMXQ_BF16)
-  DMXQ_LD(DMXQ_F16, DMXQ_F16)
-  DMXQ_LD(DMXQ_F32, DMXQ_F32)
-  DMXQ_LD(DMXQ_BF16, DMXQ_F32)
-  DMXQ_LD(DMXQ_F16, DMXQ_F32)
-#undef DMXQ_LD
-#undef DMXQ_LDK
-  return DMXQ_ERR_UNSUPPORTED;
-}
 
 static inline ChannelMap make_channel_map(int64_t C, int64_t inner, int64_t group_size, int64_t n) {
   const int64_t c = C < 1 ? 1 : C, in = inner < 1 ? 1 : inner;

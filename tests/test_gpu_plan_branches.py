@@ -129,6 +129,30 @@ def test_block_formats(dmx, cuda, rows):
         _check(f"{tag} rows={rows}", fn(x), _slabs(fn, x))
 
 
+@pytest.mark.parametrize("rows", [40, 300, 1600, 4096, 4200])
+@pytest.mark.parametrize("dtype", [BF16, F16, F32], ids=["bf16", "f16", "f32"])
+def test_dense_smoothquant_weight_path(dmx, cuda, rows, dtype):
+    """w * s[column] -> BFP in one launch (csrc/hypernet.hip HnLastOp on the lastdim kernel: 4 / 8 / 16 rows per lane by size) == the two
+    library ops it fuses (scale_channels, then bfp_qdq: both pinned to the oracle / the reference elsewhere), and == its own row slabs;
+    symmetric and asymmetric codes, block sizes with 2, 8 and 64 lanes per block, a widening output."""
+    ops = dmx.ops
+    x = _input(rows, dtype, seed=17 * rows).to(cuda)
+    cols = x.shape[1]
+    sc = (torch.rand(cols, generator=torch.Generator().manual_seed(rows)) * 4 + 0.25).to(cuda)
+    for B, sym, out_dtype in ((64, True, None), (16, False, None), (512 if dtype != F32 else 256, True, None), (64, True, F32)):
+        if out_dtype == dtype:
+            continue
+        fn = lambda t: ops.weight_hypernet(t, 8, B, sym, sq_scale=sc, out_dtype=out_dtype)
+        whole = fn(x)
+        assert whole is not None, (B, sym, out_dtype)
+        scaled = ops.scale_channels(x, sc, 1, False)             # w * s, rounded to the weight dtype
+        chain = ops.bfp_qdq(scaled, 8, B, symmetric=sym)
+        if out_dtype is not None:
+            chain = chain.to(out_dtype)
+        _check(f"dense SQ + BFP{B} sym={sym} {dtype}->{out_dtype} rows={rows} vs the two-op chain", whole, chain)
+        _check(f"dense SQ + BFP{B} sym={sym} {dtype}->{out_dtype} rows={rows} vs slabs", whole, _slabs(fn, x))
+
+
 @pytest.mark.parametrize("rows", [1600, 3584, 4096, 4200])
 @pytest.mark.parametrize("dtype", [BF16, F32], ids=["bf16", "f32"])
 def test_row_functions(dmx, cuda, rows, dtype):
