@@ -295,6 +295,7 @@ __device__ __forceinline__ float seg_max(float v) {
 }
 // row slots per wave iteration: about 32 fp32 values per lane (occupancy beats bytes in flight per wave here: 64 was
 // 1-4 % slower on every shape of tools/bench_rows.py)
+constexpr bool kRowEarlyLoads = false;  // layernorm_wave_kernel: next rows requested before this iteration's stores (measured slower, see there)
 constexpr int rows_per_wave(int vpl, int epl) { return 32 / (vpl * epl) >= 4 ? 4 : (32 / (vpl * epl) >= 2 ? 2 : 1); }
 
 // 16-bit outputs: exp(x - m) as v_exp_f32(fma(x, log2 e, -m log2 e)) and one reciprocal per row -- relative error
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
 // weight / bias (same dtype as the rows) are read ONCE per wave and kept across its rows: widened to fp32 for short
 // rows, packed for longer ones.  Per element: widen + add, subtract + fma, and (x - mean) * (rstd w) + b as
 // subtract + fma with rstd w formed once per (row, vector element).
-template <int DT, int EPL, int VPL, int LPR, bool RMS = false, bool CAST = false, int RPWO = 0, int HOISTO = 0>
+template <int DT, int EPL, int VPL, int LPR, bool RMS = false, bool CAST = false, int RPWO = 0, int HOISTO = 0, int PFO = -1>
 __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                                  int64_t rows, int64_t cols, const void* __restrict__ w,
                                                                  const void* __restrict__ b, float eps, const RowCastArg<CAST> rc) {
@@ -456,12 +457,13 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
       }
     }
   }
-  // PREFETCH (measured in round 3, OFF): short rows keep few bytes in flight per lane (768 bf16 elements: 3 vectors = 48 B), so a wave
-  // could request the rows of its NEXT iteration before it reduces the current ones.  It was SLOWER on every shape of
-  // tools/bench_rows.py -- layernorm 24000x768 16.1 -> 17.1 us, 65536x256 13.6 -> 15.5, softmax 18000x1500 21.6 -> 23.5 (profiles/
-  // r03_row_prefetch.txt): the extra live registers cost more occupancy than the deeper queue per wave buys.  The code path stays
-  // (compiled out) as the record of the experiment.
-  constexpr bool PREFETCH = false;
+  // EARLY (measured in round 3, OFF): request the rows of the NEXT iteration as soon as the current ones are widened -- into the same raw
+  // registers, dead by then -- i.e. before this iteration's reductions and stores (a wave's loads and stores retire in order through
+  // one counter, so the plain loop's wait for the next rows also waits for the previous stores).  SLOWER: 21845 x 768 bf16 14.4 -> 16.1 us,
+  // the fused module 14.7 -> 17.1, 128 MiB 45.5 -> 47.7 (tools/tune_rows, profiles/r03_tune_rows.txt); so was an earlier form with a second
+  // register set, issued at the loop top (profiles/r03_row_prefetch.txt).  What these rows lack at 32 MiB is not queue depth per wave:
+  // the same kernel reaches 74 % of the roofline at 128 MiB.  The code path stays (compiled out) as the record of the experiment.
+  constexpr bool EARLY = PFO < 0 ? kRowEarlyLoads : PFO != 0;
   auto load_rows = [&](int64_t r0, RowVec<DT, EPL> (&dst)[RPW][VPL]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
@@ -474,15 +476,11 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
       }
     }
   };
-  RowVec<DT, EPL> raw[RPW][VPL], nxt[PREFETCH ? RPW : 1][PREFETCH ? VPL : 1];
-  if constexpr (PREFETCH) load_rows(wave * (RPW * SUB), raw);
-  for (int64_t r0 = wave * (RPW * SUB); r0 < rows; r0 += n_waves * (RPW * SUB)) {
-    if constexpr (PREFETCH) {
-      load_rows(r0 + n_waves * (RPW * SUB), nxt);
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      load_rows(r0, raw);
-    }
+  RowVec<DT, EPL> raw[RPW][VPL];
+  const int64_t r_step = n_waves * (RPW * SUB);
+  if constexpr (EARLY) load_rows(wave * (RPW * SUB), raw);
+  for (int64_t r0 = wave * (RPW * SUB); r0 < rows; r0 += r_step) {
+    if constexpr (!EARLY) load_rows(r0, raw);
     float x[RPW][VPL][EPL], mean[RPW], rstd[RPW];
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
@@ -498,6 +496,11 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
         s += (i * LPR + sl < nv) ? t : 0.0f;
       }
       mean[j] = s;
+    }
+    if constexpr (EARLY) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_rows(r0 + r_step, raw);  // (rows past the end re-read the last row: unconditional loads, never stored)
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int j = 0; j < RPW; j++) mean[j] = RMS ? 0.0f : seg_sum<LPR>(mean[j]) * inv_n;  // RMSNorm: no centring
@@ -540,12 +543,6 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
           }
         }
       }
-    }
-    if constexpr (PREFETCH) {
-#pragma unroll
-      for (int j = 0; j < RPW; j++)
-#pragma unroll
-        for (int i = 0; i < VPL; i++) raw[j][i] = nxt[j][i];
     }
   }
 }

@@ -76,6 +76,10 @@ int main(int argc, char** argv) {
     const unsigned g = GRID_OF(k, want, MODE); const RowCastArg<CASTV> a = pick_cast<CASTV>(rc); \
     vs.push_back({std::string(CASTV ? "ln768_m" : "ln768  ") + " rpw" #RPW " grid" #MODE " hoist" #H, [=](const void* i, void* o, hipStream_t q) { \
       hipLaunchKernelGGL(k, dim3(g), dim3(kThreads), 0, q, i, o, rows768, (int64_t)768, (const void*)d_w, (const void*)d_b, 1e-5f, a); }, {}}); }
+#define ADD_LNP(CASTV, RPW, MODE, H, PF) { auto k = layernorm_wave_kernel<DMXQ_BF16, 8, 3, 32, false, CASTV, RPW, H, PF>; const int64_t want = (rows768 + 4 * RPW * 2 - 1) / (4 * RPW * 2); \
+    const unsigned g = GRID_OF(k, want, MODE); const RowCastArg<CASTV> a = pick_cast<CASTV>(rc); \
+    vs.push_back({std::string(CASTV ? "ln768_m" : "ln768  ") + " rpw" #RPW " grid" #MODE " hoist" #H " early" #PF, [=](const void* i, void* o, hipStream_t q) { \
+      hipLaunchKernelGGL(k, dim3(g), dim3(kThreads), 0, q, i, o, rows768, (int64_t)768, (const void*)d_w, (const void*)d_b, 1e-5f, a); }, {}}); }
 #define ADD_LNB(CASTV, RPW, MODE) { auto k = layernorm_block_kernel<DMXQ_BF16, 8, 2, false, CASTV, RPW>; const int64_t want = (rows4096 + RPW - 1) / RPW; \
     const unsigned g = GRID_OF(k, want, MODE); const RowCastArg<CASTV> a = pick_cast<CASTV>(rc); \
     vs.push_back({std::string(CASTV ? "ln4k_m " : "ln4k   ") + " rpw" #RPW " grid" #MODE, [=](const void* i, void* o, hipStream_t q) { \
@@ -90,6 +94,8 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(k, dim3(g), dim3(kThreads), 0, q, i, o, rows1500, (int64_t)1500, -INFINITY, a); }, {}}); }
 #define ADD_GRIDS(M, C, R) M(C, R, 0) M(C, R, 1) M(C, R, 2)
   ADD_COPY(512, 16); ADD_COPY(256, 16); ADD_COPY(512, 2);
+  ADD_LNP(false, 1, 0, 0, 0) ADD_LNP(false, 1, 0, 0, 1) ADD_LNP(false, 2, 0, 0, 0) ADD_LNP(false, 2, 0, 0, 1) ADD_LNP(false, 1, 0, 1, 0) ADD_LNP(false, 1, 0, 1, 1) ADD_LNP(false, 2, 0, 1, 1) ADD_LNP(false, 4, 0, 0, 1)
+  ADD_LNP(true, 1, 0, 0, 0) ADD_LNP(true, 1, 0, 0, 1) ADD_LNP(true, 1, 0, 1, 1) ADD_LNP(true, 2, 0, 0, 1)
   ADD_LNH(false, 1, 0, 1) ADD_LNH(false, 1, 1, 1) ADD_LNH(false, 2, 0, 1) ADD_LNH(false, 2, 1, 1) ADD_LNH(false, 1, 0, 2) ADD_LNH(false, 1, 1, 2) ADD_LNH(false, 2, 0, 2) ADD_LNH(false, 2, 1, 2)
   ADD_LNH(true, 1, 0, 1) ADD_LNH(true, 1, 1, 1) ADD_LNH(true, 2, 0, 1) ADD_LNH(true, 1, 0, 2) ADD_LNH(true, 1, 1, 2)
   ADD_GRIDS(ADD_LN, false, 1) ADD_GRIDS(ADD_LN, false, 2) ADD_GRIDS(ADD_LN, false, 4) ADD_GRIDS(ADD_LN, false, 8)
