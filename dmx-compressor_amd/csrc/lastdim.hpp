@@ -79,7 +79,7 @@ __global__ __launch_bounds__(THREADS) void lastdim_kernel(const void* __restrict
 
 // Geometry of one lastdim launch: THREADS lanes per workgroup, RPI rows per lane, gx workgroups along the rows
 struct LastdimPlan { int threads, rpi; int64_t gx; int cv, lpr, rpp, strips; };
-static inline bool lastdim_plan(int dti, int64_t rows, int64_t C, LastdimPlan* pl) {
+static inline bool lastdim_plan(int dti, int dto, int64_t rows, int64_t C, LastdimPlan* pl) {
   const int epl = dti == DMXQ_F32 ? 4 : 8;
   if (C % epl != 0 || C / epl > 0x7FFFFFFF || rows < 1) return false;
   const int cv = (int)(C / epl);
@@ -88,7 +88,9 @@ static inline bool lastdim_plan(int dti, int64_t rows, int64_t C, LastdimPlan* p
   const int strips = (cv + lpr - 1) / lpr;
   if (strips > 65535 || (int64_t)rpp * cv * 32 > 0xFFFFFFFFll) return false;  // (32-bit lane offsets: a row group < 4 GiB in either dtype)
   // rows per lane: as many (16, 8, 4) as still leave two workgroups per CU
-  int rpi = 16;
+  // (a widening output -- 32 bytes per lane, two half-line stores -- keeps 8: with 16 the partial lines of a row group no longer merge
+  //  before they leave the L2, 95 MB written for 67 MB of output and 34.0 instead of 30.3 us, bf16 -> float32 x / s on 4096 x 4096)
+  int rpi = (dto == DMXQ_F32 && dti != DMXQ_F32) ? 8 : 16;
   while (rpi > 4 && ((rows + (int64_t)rpp * rpi - 1) / ((int64_t)rpp * rpi)) * strips < 512) rpi >>= 1;
   const int64_t gx = (rows + (int64_t)rpp * rpi - 1) / ((int64_t)rpp * rpi);
   if (gx > 0x7FFFFFFF) return false;
@@ -100,7 +102,7 @@ static inline bool lastdim_plan(int dti, int64_t rows, int64_t C, LastdimPlan* p
 template <int DTI, int DTO, class OP>
 static int launch_lastdim_typed(const void* in, void* out, int64_t rows, int64_t C, const OP& op, hipStream_t s) {
   LastdimPlan pl;
-  if (!aligned16(in) || !aligned16(out) || !lastdim_plan(DTI, rows, C, &pl)) return DMXQ_ERR_UNSUPPORTED;
+  if (!aligned16(in) || !aligned16(out) || !lastdim_plan(DTI, DTO, rows, C, &pl)) return DMXQ_ERR_UNSUPPORTED;
 #define DMXQ_LDK(R_)                                                                                                          \
   DMXQ_LAUNCH((lastdim_kernel<DTI, DTO, OP, kThreads, R_>), dim3((unsigned)pl.gx, (unsigned)pl.strips), dim3(kThreads), 0, s, in, out, rows, C, \
               pl.cv, pl.lpr, pl.rpp, op)
