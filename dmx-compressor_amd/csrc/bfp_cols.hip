@@ -7,9 +7,9 @@
 // inner dimension (16 B per lane, so a wave reads whole 1 KiB / 512 B / 256 B row segments), and each lane walks
 // down the B rows of its block keeping the column tile in REGISTERS: one pass, every element read once and
 // written once, all B row-loads of a lane in flight at once.
-//   RPL = rows per lane (<= 32: 128 data VGPRs), RS = row split: the B = RPL*RS rows of a block are shared by RS
-//   lane groups of 64/RS lanes (B = 64 -> two half-waves of 32 rows each); per-column maxima are combined across
-//   the groups with lane permutes.  Every COLUMN is its own block, so a lane carries EPL block maxima.
+//   RPL = rows per lane (<= 32: 128 data VGPRs), RS = row split: the B = RPL*RS rows of a block are shared by RS lane groups of 64/RS
+//   lanes (B = 64 -> two half-waves of 32 rows each, or eight groups of 8 lanes with 8 rows each: launch_cols); per-column maxima are
+//   combined across the groups with lane permutes.  Every COLUMN is its own block, so a lane carries EPL block maxima.
 // Arithmetic is bfp_math.hpp (magic-add nearest-even with the literal path as wave-uniform fallback).
 #include "bfp_math.hpp"
 
@@ -19,6 +19,8 @@ template <int RS>
 __device__ __forceinline__ uint32_t split_max_u32(uint32_t m) {
   if (RS >= 2) m = max(m, (uint32_t)__shfl_xor((int)m, 32));
   if (RS >= 4) m = max(m, (uint32_t)__shfl_xor((int)m, 16));
+  if (RS >= 8) m = max(m, (uint32_t)__shfl_xor((int)m, 8));
+  if (RS >= 16) m = max(m, (uint32_t)__shfl_xor((int)m, 4));
   return m;
 }
 
@@ -186,11 +188,21 @@ template <int DTI, int DTO, int RND, bool ASYM>
 static int launch_cols(const void* in, void* out, int64_t outer, int64_t L, int64_t inner, int64_t B, int wl,
                        int rounding, uint64_t seed, bool unal, hipStream_t s) {
 #define DMXQ_G(RPL_, RS_) return launch_cols_geom<DTI, DTO, RND, ASYM, RPL_, RS_>(in, out, outer, L, inner, wl, rounding, seed, unal, s)
+  // B = 64 on rows that are whole 128-byte lines (round 3): 8 rows per lane, the 8 row groups of a block side by side in the wave, instead of
+  // 32 rows per lane in two half-waves.  A lane's serial share -- its loads, then rows x 8 elements of arithmetic -- is what a small
+  // tensor waits for, and the attention operands this path serves ARE small (Llama V [1, 32, 128, 128] bf16: 8.5 -> 4.6 us, Whisper
+  // [12, 1500, 64] float32: 7.3 -> 4.4 us, opt-125m [24, 128, 64]: 6.3 -> 3.6 us per launch inside a graph); 134 MB of them: 53 -> 46 us
+  // (64 -> 73 %); [64, 256, 56, 56] along channels 44 -> 37 us.  A row group then reads 128 contiguous bytes per row: rows that are NOT whole
+  // lines (28 x 28, 14 x 14 maps) straddle two lines per piece and measured 14-24 % slower that way, so they keep the wide groups; so do the
+  // other block sizes (B = 16 as 8 x 2 instead of 16 x 1: 11.7 -> 13.1 us on 32 MiB).  4 rows per lane: equal on small tensors, 15 % slower
+  // on the big one.  (tools/bench_conv_shapes.py, profiles/r03_conv_shapes.txt)
   switch (B) {
     case 8: DMXQ_G(8, 1);
     case 16: DMXQ_G(16, 1);
     case 32: DMXQ_G(32, 1);
-    case 64: DMXQ_G(32, 2);
+    case 64:
+      if (!unal && (inner * (int64_t)Elem<DTI>::bytes) % 128 == 0) DMXQ_G(8, 8);
+      DMXQ_G(32, 2);
     case 128: DMXQ_G(32, 4);
   }
 #undef DMXQ_G
