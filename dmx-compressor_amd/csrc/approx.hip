@@ -442,19 +442,14 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
   const int nv = (int)(cols / EPL);
   const float inv_n = 1.0f / (float)cols;
   float wf[HOIST_F32 ? VPL : 1][EPL], bf[HOIST_F32 ? VPL : 1][EPL];
-  RowVec<DT, EPL> wr[HOIST_RAW ? VPL : 1], br[HOIST_RAW ? VPL : 1];
-  if (HOIST_F32 || HOIST_RAW) {
+  RowVec<DT, EPL> wr[(HOIST_F32 || HOIST_RAW) ? VPL : 1], br[(HOIST_F32 || HOIST_RAW) ? VPL : 1];
+  if (HOIST_F32 || HOIST_RAW) {  // the raw reads only: their conversion waits until the wave's first rows are requested too (below)
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
       const int v = i * LPR + sl;
       const int64_t c = (int64_t)(v < nv ? v : nv - 1) * EPL;
-      if (HOIST_F32) {
-        if (w) row_widen<DT, EPL>(row_load_keep<DT, EPL>(w, c), wf[i]);
-        if (b) row_widen<DT, EPL>(row_load_keep<DT, EPL>(b, c), bf[i]);
-      } else {
-        if (w) wr[i] = row_load_keep<DT, EPL>(w, c);
-        if (b) br[i] = row_load_keep<DT, EPL>(b, c);
-      }
+      if (w) wr[i] = row_load_keep<DT, EPL>(w, c);
+      if (b) br[i] = row_load_keep<DT, EPL>(b, c);
     }
   }
   // EARLY (measured in round 3, OFF): request the rows of the NEXT iteration as soon as the current ones are widened -- into the same raw
@@ -477,10 +472,21 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
     }
   };
   RowVec<DT, EPL> raw[RPW][VPL];
-  const int64_t r_step = n_waves * (RPW * SUB);
-  if constexpr (EARLY) load_rows(wave * (RPW * SUB), raw);
-  for (int64_t r0 = wave * (RPW * SUB); r0 < rows; r0 += r_step) {
-    if constexpr (!EARLY) load_rows(r0, raw);
+  const int64_t r_step = n_waves * (RPW * SUB), r_first = wave * (RPW * SUB);
+  // the wave's FIRST rows are requested before anything waits on the weight / bias reads (round 3: the widening of the hoisted
+  // parameters used to sit between their loads and the first row loads -- a full memory round trip before a wave's first row request,
+  // which is most of the run time of a small tensor: every wave of a [256, 768] activation makes exactly one iteration)
+  load_rows(r_first, raw);
+  __builtin_amdgcn_sched_barrier(0);
+  if (HOIST_F32) {
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+      if (w) row_widen<DT, EPL>(wr[i], wf[i]);
+      if (b) row_widen<DT, EPL>(br[i], bf[i]);
+    }
+  }
+  for (int64_t r0 = r_first; r0 < rows; r0 += r_step) {
+    if constexpr (!EARLY) { if (r0 != r_first) load_rows(r0, raw); }
     float x[RPW][VPL][EPL], mean[RPW], rstd[RPW];
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
