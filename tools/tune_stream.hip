@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
   const CastedOp<GeluOp<true, false>, DMXQ_BF16> gelum{gelu, ac.ri, ac.ro, ac.gi, ac.go};
   const CastedOp<UnaryOp<DMXQ_UNARY_SILU, DMXQ_BF16, true, true>, DMXQ_BF16> silum{{1.0f}, ac.ri, ac.ro, ac.gi, ac.go};
   // composite block formats (blockfmt.hip): MXFP8[E4M3]{32} (4 lanes per block), SBFP12_16 (2 lanes per block)
-  const MxfpFmt mxf{3, 4, 7, (float)ldexp(1.0, 8), make_float_fast(3, 4, 7), 8, 1};
+  const MxfpFmt mxf{3, 4, 7, (float)ldexp(1.0, 8), make_float_fast(3, 4, 7), 8, 1, 1};
   const BlockOp<MxfpFmt, MxfpBlock> mxfp{mxf, 4};
   const SbfpFmt sbf{4, 1, -7.0f, 7.0f, 7.0f, 4, 4, 7, 0};
   const BlockOp<SbfpFmt, SbfpBlock> sbfp{sbf, 2};
