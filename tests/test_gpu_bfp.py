@@ -57,7 +57,9 @@ def test_odd_block_sizes_and_ragged_tails(dmx, cuda, oracle, B, dtype):
 @pytest.mark.parametrize("B", [16, 64, 5])
 def test_block_dim_layouts(dmx, cuda, oracle, dim, B):
     # conv activations / weights block along dim 1, attention multipliers along -2
-    for shape in [(2, 32, 5, 5), (3, 6, 5, 5), (2, 1, 32, 32), (4, 64, 48)]:
+    # (the last three: rows of whole 128-byte lines -- B = 64 then runs 8 rows per lane in 8 row groups, csrc/bfp_cols.hip launch_cols --
+    #  with ragged last blocks: L = 100, 70)
+    for shape in [(2, 32, 5, 5), (3, 6, 5, 5), (2, 1, 32, 32), (4, 64, 48), (3, 100, 64), (2, 2, 128, 128), (2, 70, 192)]:
         if dim >= len(shape):
             continue
         x = make("normal", shape, seed=dim + 10, dtype=torch.bfloat16)
