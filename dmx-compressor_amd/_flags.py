@@ -12,6 +12,16 @@ Code that pokes a buffer directly must call `refresh_flags()` afterwards; `load_
 
 class HostFlags:
     _flag_names = ()
+    #: zero-dim float buffers mirrored the same way (SmoothQuant's `migration_strength`, `scale_min`: read with `float(...)` in every
+    #: calibration / dynamic forward -- a device->host copy and a stream drain each once the module is on the GPU, and not capturable)
+    _scalar_names = ()
+
+    def _set_scalar(self, name: str, value: float) -> None:
+        getattr(self, name).fill_(float(value))
+        self.__dict__["_h_" + name] = float(value)
+
+    def _scalar(self, name: str) -> float:
+        return self.__dict__["_h_" + name]
 
     def _set_flag(self, name: str, value) -> None:
         getattr(self, name)[0] = 1 if value else 0
@@ -23,6 +33,8 @@ class HostFlags:
     def refresh_flags(self) -> None:
         for n in self._flag_names:
             self.__dict__["_h_" + n] = int(getattr(self, n)[0])
+        for n in self._scalar_names:
+            self.__dict__["_h_" + n] = float(getattr(self, n))
 
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)

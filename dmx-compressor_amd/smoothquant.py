@@ -45,6 +45,7 @@ def _scale(x, scale, ch_axis, divide, out_dtype):
 
 class ActivationWeightSmoothQuant(HostFlags, torch.nn.Module):
     _flag_names = ("enabled", "dynamic", "fused_to_weight")
+    _scalar_names = ("migration_strength", "scale_min")
 
     def __init__(self, ch_axis: int, win_ch_axis: int, migration_strength: float = 0.5,
                  scale_format: Union[str, Format] = "SAME", dynamic: bool = False, scale_min: float = 1e-5):
@@ -79,11 +80,12 @@ class ActivationWeightSmoothQuant(HostFlags, torch.nn.Module):
 
     def set_migration_strength(self, migration_strength: float):
         assert 0 <= migration_strength <= 1, "migration strength should be between 0 and 1"
-        self.migration_strength.fill_(float(migration_strength))
+        self._set_scalar("migration_strength", migration_strength)
 
     # -------------------------------------------------------------- calibration
     def compute_scale(self, inp_maxabs: torch.Tensor, wgt_maxabs: torch.Tensor) -> None:
-        s = ops.smoothquant_scale(inp_maxabs, wgt_maxabs, float(self.migration_strength), float(self.scale_min))
+        # (host mirrors of the two scalar buffers: `float(buffer)` would copy from the device and drain the stream, per Linear per forward)
+        s = ops.smoothquant_scale(inp_maxabs, wgt_maxabs, self._scalar("migration_strength"), self._scalar("scale_min"))
         self.scale = self.scale_cast(s)
 
     def forward(self, inp: torch.Tensor, wgt: torch.Tensor) -> None:
@@ -110,5 +112,5 @@ class ActivationWeightSmoothQuant(HostFlags, torch.nn.Module):
         self._set_flag("fused_to_weight", True)
 
     def extra_repr(self) -> str:
-        return (f"migration_strength = {self.migration_strength.item()}, ch_axis = {self.ch_axis}, win_ch_axis = "
+        return (f"migration_strength = {self._scalar('migration_strength')}, ch_axis = {self.ch_axis}, win_ch_axis = "
                 f"{self.win_ch_axis}, scale_format = {self.scale_cast.format}, dynamic = {bool(self.dynamic.item())}")

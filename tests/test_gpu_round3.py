@@ -329,3 +329,32 @@ def test_all_same_module_returning_a_view_is_cloned_under_torch_compile(dmx, cud
     x2 = torch.zeros(4, 16, device=cuda)
     out = torch.compile(f, backend="aot_eager", fullgraph=True)(x2)
     assert float(x2.abs().max()) == 0.0 and float(out.min()) == 1.0
+
+
+def test_smoothquant_calibration_and_dynamic_forwards_do_not_synchronise(dmx, cuda):
+    """The calibration / dynamic SmoothQuant forward (smoothquant.py:518-535: both channel maxima and the scale, every call) reads its
+    two scalar buffers (`migration_strength`, `scale_min`) from host mirrors: no device->host copy, so the forward neither drains the
+    stream nor breaks a hipGraph capture.  The values used are the buffers' (also after set_migration_strength / load_state_dict)."""
+    torch.manual_seed(0)
+    m = dmx.nn.Linear(256, 128).to(cuda).eval()
+    m.configure(dict(input_formats=["BFP[8|8]{64}(SN)"], weight_format="BFP[8|8]{64}(SN)"))
+    x = torch.randn(32, 256, device=cuda)
+    m.smoothquant.set_migration_strength(0.8)
+    m.smoothquant.set_dynamic(True)
+    m.smoothquant.enable()
+    with torch.no_grad():
+        m(x)                                             # warm-up: allocations, kernel loads
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            y = m(x)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+    a, w = x.abs().amax(0), m.weight.detach().abs().amax(0)
+    ref = (a.pow(torch.tensor(0.8, device=cuda)) / w.pow(1 - torch.tensor(0.8, device=cuda))).clamp(min=1e-5)
+    assert torch.allclose(m.smoothquant.scale, ref, rtol=1e-6, atol=0.0)
+    assert torch.isfinite(y).all()
+    # a buffer poked directly (or loaded from a state dict: `_load_from_state_dict` calls refresh_flags) is picked up by refresh_flags
+    m.smoothquant.migration_strength.fill_(0.3)
+    m.smoothquant.refresh_flags()
+    assert m.smoothquant._scalar("migration_strength") == float(torch.tensor(0.3, dtype=torch.float32))
