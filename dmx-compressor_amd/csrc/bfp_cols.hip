@@ -45,6 +45,8 @@ __device__ __forceinline__ void accumulate_absmax(const u32x4& v, uint32_t (&mb)
   }
 }
 
+struct ColsIdx { FastDiv31 f_cvec, f_nblk, f_ctiles; int small; };  // host-made magic numbers for the unit decomposition
+
 // UNAL: rows (inner elements) that are not whole aligned 16-byte vectors -- 14x14 or 7x7 feature maps, views that start
 // mid-allocation.  Accesses are 16 bytes at element alignment (common.hpp load_raw16 / store_out UNAL), and the last,
 // partial vector of a row is replaced by the vector that ENDS at the row end: every column is its own block, so the
@@ -52,7 +54,7 @@ __device__ __forceinline__ void accumulate_absmax(const u32x4& v, uint32_t (&mb)
 template <int DTI, int DTO, int RND, bool ASYM, int RPL, int RS, int FAST, bool UNAL = false>
 __global__ __launch_bounds__(kThreads) void bfp_cols_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                            int64_t outer, int64_t L, int64_t inner, int wl,
-                                                           int rounding, uint64_t seed) {
+                                                           int rounding, uint64_t seed, const ColsIdx ix) {
   constexpr int EPL = 16 / Elem<DTI>::bytes;
   constexpr int B = RPL * RS;
   constexpr int LPR = kWave / RS;  // lanes per row segment
@@ -76,18 +78,35 @@ __global__ __launch_bounds__(kThreads) void bfp_cols_kernel(const void* __restri
   for (int64_t unit = wave_id; unit < units; unit += n_waves) {
     int64_t o, blk, cv;
     bool col_ok;
+    // (unit -> (outer, block, column tile): magic-number divisions when everything fits 31 bits -- three 64-bit divisions here were ~450
+    //  VALU operations in front of a unit's first load, as many as its 8 rows x 8 elements of arithmetic: tools/isa_prologue.py)
     if (packed) {
       const int64_t g = unit * LPR + lig;
       col_ok = g < total_cv;
       const int64_t gc = col_ok ? g : total_cv - 1;
-      const int64_t ob = gc / cvec;
-      cv = gc - ob * cvec;
-      o = ob / nblk;
-      blk = ob - o * nblk;
+      if (ix.small) {
+        const uint32_t ob = ix.f_cvec.div((uint32_t)gc), o32 = ix.f_nblk.div(ob);
+        cv = (uint32_t)gc - ob * (uint32_t)cvec;
+        o = o32;
+        blk = ob - o32 * (uint32_t)nblk;
+      } else {
+        const int64_t ob = gc / cvec;
+        cv = gc - ob * cvec;
+        o = ob / nblk;
+        blk = ob - o * nblk;
+      }
     } else {
-      const int64_t ct = unit % ctiles;
-      blk = (unit / ctiles) % nblk;
-      o = unit / (ctiles * nblk);
+      int64_t ct;
+      if (ix.small) {
+        const uint32_t q = ix.f_ctiles.div((uint32_t)unit), o32 = ix.f_nblk.div(q);
+        ct = (uint32_t)unit - q * (uint32_t)ctiles;
+        o = o32;
+        blk = q - o32 * (uint32_t)nblk;
+      } else {
+        ct = unit % ctiles;
+        blk = (unit / ctiles) % nblk;
+        o = unit / (ctiles * nblk);
+      }
       cv = ct * LPR + lig;                                // this lane's column vector
       col_ok = cv < cvec;
     }
@@ -159,14 +178,16 @@ static int launch_cols_geom(const void* in, void* out, int64_t outer, int64_t L,
   if (grid < 1) grid = 1;
   if (grid > (1 << 20)) grid = 1 << 20;
   const int fast = (RND == DMXQ_ROUND_NEAREST && wl <= 20) ? (bfp_single_rounding_ok<DTI>(wl) ? 2 : 1) : 0;
+  const int64_t total = outer * nblk * (cvec * 2 <= LPR ? cvec : ctiles * LPR);
+  const ColsIdx ix{make_fastdiv31(cvec), make_fastdiv31(nblk), make_fastdiv31(ctiles), (total < ((int64_t)1 << 31) && units * LPR < ((int64_t)1 << 31)) ? 1 : 0};
 #define DMXQ_COLS(F_)                                                                                             \
   do {                                                                                                            \
     if (unal)                                                                                                     \
       DMXQ_LAUNCH((bfp_cols_kernel<DTI, DTO, RND, ASYM, RPL, RS, F_, true>), dim3((unsigned)grid), dim3(kThreads), 0, \
-                         s, in, out, outer, L, inner, wl, rounding, seed);                                        \
+                         s, in, out, outer, L, inner, wl, rounding, seed, ix);                                    \
     else                                                                                                          \
       DMXQ_LAUNCH((bfp_cols_kernel<DTI, DTO, RND, ASYM, RPL, RS, F_, false>), dim3((unsigned)grid), dim3(kThreads), 0, \
-                         s, in, out, outer, L, inner, wl, rounding, seed);                                        \
+                         s, in, out, outer, L, inner, wl, rounding, seed, ix);                                    \
   } while (0)
   // instantiate only what can run: the literal path for the runtime-rounding build; magic-add (double / single
   // rounding) for nearest-even.  (nearest with wl > 20 is routed to the runtime-rounding build by the caller.)
