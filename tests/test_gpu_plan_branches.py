@@ -192,3 +192,37 @@ def test_row_functions(dmx, cuda, rows, dtype):
             assert whole is not None, nm
             parts = torch.cat([fns[nm](y[r0:r0 + 512].contiguous()) for r0 in range(0, r, 512)], 0)
             _check(f"{nm} {dtype} {r}x{c}", whole, parts)
+
+
+def test_per_channel_kernel_equals_the_channel_walker_on_random_shapes(dmx, cuda):
+    """The per-channel-along-the-last-dim kernel (csrc/lastdim.hpp: column strips, several rows side by side in a workgroup when rows are
+    short, 4 / 8 / 16 rows per lane, a clamped tail workgroup) against the flat-stream kernel's channel walker, which the same call takes
+    when the scale table is not 16-byte aligned (elementwise.hip pick_mode): 60 random [rows, C] shapes, C any multiple of the lane
+    vector, bf16 / fp16 / float32, INT8 with zero points, INT4 symmetric, and SmoothQuant's divide / multiply -- bit for bit."""
+    ops = dmx.ops
+    g = torch.Generator().manual_seed(2024)
+    for it in range(60):
+        dtype = (BF16, F16, F32)[it % 3]
+        epl = 4 if dtype == F32 else 8
+        C = int(torch.randint(1, 700, (1,), generator=g)) * epl
+        rows = int(torch.randint(1, 3000, (1,), generator=g))
+        x = (make("heavy", (rows, C), seed=it, dtype=torch.float32).clamp(-1e4, 1e4)).to(dtype).to(cuda)
+        buf = (torch.rand(C + 4, generator=g) * 0.3 + 0.01).to(cuda)
+        zbuf = torch.randint(-7, 8, (C + 2,), generator=g).to(cuda)
+        sc_al, sc_un = buf[4:].clone(), buf[1:C + 1]        # same values; the second view starts 4 bytes into the allocation
+        sc_un.copy_(sc_al)
+        zp_al, zp_un = zbuf[2:].clone(), zbuf[1:C + 1]      # int64: 8 bytes into the allocation
+        zp_un.copy_(zp_al)
+        assert sc_al.data_ptr() % 16 == 0 and sc_un.data_ptr() % 16 != 0
+        for prec in (8, 4):
+            a = ops.fixed_qdq(x, prec, 0, scale=sc_al, zero_point=zp_al, ch_axis=1)
+            b = ops.fixed_qdq(x, prec, 0, scale=sc_un, zero_point=zp_un, ch_axis=1)
+            _check(f"INT{prec} per column {dtype} [{rows}, {C}]", a, b)
+        for divide in (True, False):
+            a = ops.scale_channels(x, sc_al, 1, divide)
+            b = ops.scale_channels(x, sc_un, 1, divide)
+            _check(f"scale_channels divide={divide} {dtype} [{rows}, {C}]", a, b)
+        if dtype != F32:
+            a = ops.scale_channels(x, sc_al, 1, True, out_dtype=F32)
+            b = ops.scale_channels(x, sc_un, 1, True, out_dtype=F32)
+            _check(f"scale_channels -> float32 {dtype} [{rows}, {C}]", a, b)
