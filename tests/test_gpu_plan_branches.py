@@ -226,3 +226,22 @@ def test_per_channel_kernel_equals_the_channel_walker_on_random_shapes(dmx, cuda
             a = ops.scale_channels(x, sc_al, 1, True, out_dtype=F32)
             b = ops.scale_channels(x, sc_un, 1, True, out_dtype=F32)
             _check(f"scale_channels -> float32 {dtype} [{rows}, {C}]", a, b)
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32], ids=["bf16", "f32"])
+def test_dense_smoothquant_weight_path_on_narrow_rows(dmx, cuda, dtype):
+    """Rows shorter than a workgroup (several rows side by side, lanes left over when 256 is not a multiple of the row's vectors) and
+    blocks of 2 .. 32 lanes: w * s -> BFP on the lastdim kernel == scale_channels then bfp_qdq, bit for bit."""
+    ops = dmx.ops
+    for cols, Bs in ((768, (16, 64, 256)), (1536, (64, 512)), (192, (8, 64)), (64, (16, 64)), (4160, (64,))):
+        for rows in (1, 7, 333, 2050):
+            x = make("heavy", (rows, cols), seed=rows + cols, dtype=torch.float32).clamp(-3e4, 3e4).to(dtype).to(cuda)
+            sc = (torch.rand(cols, generator=torch.Generator().manual_seed(cols)) * 4 + 0.25).to(cuda)
+            for B in Bs:
+                if dtype == F32 and B > 256:
+                    continue
+                for sym in (True, False):
+                    whole = ops.weight_hypernet(x, 8, B, sym, sq_scale=sc)
+                    assert whole is not None, (cols, B)
+                    chain = ops.bfp_qdq(ops.scale_channels(x, sc, 1, False), 8, B, symmetric=sym)
+                    _check(f"dense SQ + BFP{B} sym={sym} {dtype} [{rows}, {cols}]", whole, chain)
