@@ -36,6 +36,7 @@ SIGNATURES = {
     "dmxq_relu_cast": [_vp, _vp, _i32, _i64, _vp, _vp, _vp],
     "dmxq_unary_cast": [_vp, _vp, _i32, _i64, _i32, _f32, _vp, _vp, _vp],
     "dmxq_softmax_cast": [_vp, _vp, _i32, _i64, _i64, _f32, _vp, _vp, _vp],
+    "dmxq_softmax_cast_bfp": [_vp, _vp, _i32, _i64, _i64, _f32, _vp, _vp, _i64, _i32, _vp],
     "dmxq_layernorm_cast": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _f32, _vp, _vp, _vp],
     "dmxq_rmsnorm_cast": [_vp, _vp, _i32, _i64, _i64, _vp, _f32, _vp, _vp, _vp],
     "dmxq_float_qdq": [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _u64, _vp],

@@ -638,16 +638,21 @@ def unary_cast(x, func: str, cast_in=None, cast_out=None):
     return _fused_rc(rc, "dmxq_unary_cast", out)
 
 
-def softmax_cast(x, dim: int = -1, cast_in=None, cast_out=None, input_clamp: Optional[float] = None):
-    """A Softmax DmxModule in one launch (softmax over the LAST dim only); None when not fusable."""
+def softmax_cast(x, dim: int = -1, cast_in=None, cast_out=None, input_clamp: Optional[float] = None, then_bfp=None):
+    """A Softmax DmxModule in one launch (softmax over the LAST dim only); then_bfp = (precision, block_size): the consumer's BFP input
+    cast applied to the result in the same launch; None when not fusable."""
     xc = _prep(x, "softmax_cast")
     cp = _cast_ptrs(cast_in, cast_out)
     if cp is None or xc.dim() == 0 or dim % xc.dim() != xc.dim() - 1:
         return None
     cols = xc.shape[-1]
     out = torch.empty_like(xc)
-    rc = lib().dmxq_softmax_cast(ptr(xc), ptr(out), dtype_code(xc.dtype), xc.numel() // max(cols, 1), cols,
-                                 float(input_clamp) if input_clamp is not None else -math.inf, *cp[0], stream_of(xc))
+    clamp = float(input_clamp) if input_clamp is not None else -math.inf
+    if then_bfp:
+        rc = lib().dmxq_softmax_cast_bfp(ptr(xc), ptr(out), dtype_code(xc.dtype), xc.numel() // max(cols, 1), cols, clamp, *cp[0],
+                                         int(then_bfp[1]), int(then_bfp[0]), stream_of(xc))
+        return _fused_rc(rc, "dmxq_softmax_cast_bfp", out)
+    rc = lib().dmxq_softmax_cast(ptr(xc), ptr(out), dtype_code(xc.dtype), xc.numel() // max(cols, 1), cols, clamp, *cp[0], stream_of(xc))
     return _fused_rc(rc, "dmxq_softmax_cast", out)
 
 

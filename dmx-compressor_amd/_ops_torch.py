@@ -449,13 +449,15 @@ def unary_cast(x, func: str, cast_in=None, cast_out=None):
         return None
 
 
-def softmax_cast(x, dim: int = -1, cast_in=None, cast_out=None, input_clamp: Optional[float] = None):
-    """A Softmax DmxModule in one launch (softmax over the LAST dim only).  None when not fusable."""
+def softmax_cast(x, dim: int = -1, cast_in=None, cast_out=None, input_clamp: Optional[float] = None, then_bfp=None):
+    """A Softmax DmxModule in one launch (softmax over the LAST dim only).  then_bfp = (precision, block_size): the consumer's BFP input
+    cast (symmetric, nearest, along the same dim) applied to the result in the same launch.  None when not fusable."""
     require_gpu(x, "softmax_cast")
     if x.dim() == 0 or dim % x.dim() != x.dim() - 1 or not _casts_ok(cast_in, cast_out):
         return None
     try:
-        return _ops.softmax_cast(x, float(input_clamp) if input_clamp is not None else -math.inf, _fmt4(cast_in), _fmt4(cast_out))
+        return _ops.softmax_cast(x, float(input_clamp) if input_clamp is not None else -math.inf, _fmt4(cast_in), _fmt4(cast_out),
+                                 int(then_bfp[1]) if then_bfp else 0, int(then_bfp[0]) if then_bfp else 0)
     except NotImplementedError:
         return None
 

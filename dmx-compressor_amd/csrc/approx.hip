@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "floatq.hpp"
+#include "bfp_math.hpp"
 
 namespace dmxq {
 
@@ -217,7 +218,7 @@ __device__ __forceinline__ RowVec<DT, EPL> row_load_tail(const void* p, int64_t 
 // The casts of a DmxModule around a row function (dmxq_softmax_cast / dmxq_layernorm_cast / dmxq_rmsnorm_cast): out =
 // cast_out(f(cast_in(x))) in one pass.  16-bit rows: both casts are range-only (common.hpp range16_of) and act on the packed words
 // right after the load / right before the store; float32 rows: any nearest-rounding FloatingPoint format, per element (floatq.hpp).
-struct RowCast { Range16 ri, ro; CastG gi, go; };
+struct RowCast { Range16 ri, ro; CastG gi, go; int bfp_B = 0, bfp_wl = 0, bfp_lpb = 0; };  // bfp_*: the CONSUMER's BFP input cast, dmxq_softmax_cast_bfp
 struct NoRowCast {};
 template <bool CAST> using RowCastArg = std::conditional_t<CAST, RowCast, NoRowCast>;
 template <bool CAST, int DT, int EPL, class RC>
@@ -304,7 +305,7 @@ constexpr int rows_per_wave(int vpl, int epl) { return 32 / (vpl * epl) >= 4 ? 4
 // FAST32: float32 rows behind an output cast that keeps <= 16 mantissa bits (a module's FLOAT16 output cast): the v_exp / one
 // reciprocal per row forms of the 16-bit rows (relative error ~2^-21, invisible at 2^-17) instead of the compensated expf and a
 // division per element -- those make the fp32 kernel VALU-bound (Whisper's [12,1500,1500] attention: 58 us -> see profiles/r03_*)
-template <int DT, int EPL, int VPL, int LPR, bool RAG = false, bool CAST = false, bool FAST32 = false, int RPWO = 0>
+template <int DT, int EPL, int VPL, int LPR, bool RAG = false, bool CAST = false, bool FAST32 = false, int RPWO = 0, bool BFPOUT = false>
 __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                                int64_t rows, int64_t cols, float clamp_min, const RowCastArg<CAST> rc) {
   constexpr int SUB = kWave / LPR;  // rows side by side in one wave
@@ -392,6 +393,47 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
     }
 #pragma unroll
     for (int j = 0; j < RPW; j++) s[j] = seg_sum<LPR>(s[j]);
+    if constexpr (BFPOUT) {
+      // dmxq_softmax_cast_bfp: the probabilities go straight into the NEXT module's BFP input cast (blocks of B along the row = lpb
+      // adjacent lanes of one slot i: LPR % lpb == 0, so a block never straddles slots; a ragged last block is simply shorter).  Every
+      // lane runs the block-maximum DPP steps -- rows past the end were loaded clamped, slots past the row end contribute 0 -- and only
+      // the store is predicated.  Same arithmetic as dmxq_bfp_qdq on the stored module output (bfp_math.hpp), so bit-identical to
+      // the two launches.
+      static_assert(!BFPOUT || (CAST && !RAG), "fused BFP epilogue: cast form, whole vectors");
+      const int lpb = __builtin_amdgcn_readfirstlane(rc.bfp_lpb), wl = __builtin_amdgcn_readfirstlane(rc.bfp_wl);
+#pragma unroll
+      for (int j = 0; j < RPW; j++) {
+        const int64_t r = r0 + j * SUB + sub;
+        const float inv = 1.0f / s[j];
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+          const int v = i * LPR + sl;
+          float y[EPL], z[EPL], q[EPL];
+#pragma unroll
+          for (int k = 0; k < EPL; k++) y[k] = FAST ? x[j][i][k] * inv : x[j][i][k] / s[j];
+          const RowVec<DT, EPL> o = rowcast_pack_out<CAST, DT, EPL>(y, rc);  // what the softmax module returns
+          row_widen<DT, EPL>(o, z);
+          uint32_t mb = 0u;
+#pragma unroll
+          for (int k = 0; k < EPL; k++) mb = max(mb, f2u(z[k]) & 0x7FFFFFFFu);
+          mb = group_max_u32(v < nv ? mb : 0u, lpb);
+          const bool fast_ok = bfp_fast_ok(mb, wl);
+          {
+            const BfpBlockParams bp = bfp_block_params<false, true>(mb, wl);
+#pragma unroll
+            for (int k = 0; k < EPL; k++) q[k] = bfp_q1_fast<false, false>(z[k], bp);
+          }
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast_ok) != 0ull, 0)) {
+            if (!fast_ok) {
+              const BfpBlockParams bp = bfp_block_params<false, false>(mb, wl);
+#pragma unroll
+              for (int k = 0; k < EPL; k++) q[k] = bfp_q1<DMXQ_ROUND_NEAREST, false>(z[k], bp, wl, DMXQ_ROUND_NEAREST, 0u);
+            }
+          }
+          if (v < nv && r < rows) row_store<DT, EPL>(out, r * cols + (int64_t)v * EPL, q);  // CastTo's `.to(dtype)`: one RNE rounding
+        }
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
       const int64_t r = r0 + j * SUB + sub;
@@ -416,6 +458,7 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
           }
         }
       }
+    }
     }
     if constexpr (PREFETCH) {
 #pragma unroll
@@ -763,6 +806,21 @@ static int softmax_dispatch(const void* in, void* out, int dtype_in, int dtype_o
 #define DMXQ_SM(D_, E_, V_, L_)                                                                                       \
   do {                                                                                                                \
     constexpr int per_wg = 4 * rows_per_wave(V_, E_) * (64 / (L_));                                                   \
+    if constexpr (CAST) {                                                                                             \
+      if (rc.bfp_B) { /* dmxq_softmax_cast_bfp: blocks of B elements = lpb adjacent lanes of one slot */               \
+        const int lpb = rc.bfp_B / (E_);                                                                              \
+        if (rag || rc.bfp_B % (E_) != 0 || lpb < 1 || (lpb & (lpb - 1)) != 0 || lpb > (L_)) return DMXQ_ERR_UNSUPPORTED; \
+        RowCast rb = rc;                                                                                              \
+        rb.bfp_lpb = lpb;                                                                                             \
+        if ((D_) == DMXQ_F32 && fast32)                                                                               \
+          DMXQ_LAUNCH((softmax_wave_kernel<D_, E_, V_, L_, false, CAST, (D_) == DMXQ_F32, 0, true>),                  \
+                      dim3(one_pass_grid((rows + per_wg - 1) / per_wg)), dim3(kThreads), 0, s, in, out, rows, cols, input_clamp_min, rb); \
+        else                                                                                                          \
+          DMXQ_LAUNCH((softmax_wave_kernel<D_, E_, V_, L_, false, CAST, false, 0, true>),                             \
+                      dim3(one_pass_grid((rows + per_wg - 1) / per_wg)), dim3(kThreads), 0, s, in, out, rows, cols, input_clamp_min, rb); \
+        break;                                                                                                        \
+      }                                                                                                               \
+    }                                                                                                                 \
     if constexpr ((E_) * Elem<D_>::bytes == 16) {                                                                     \
       if (rag) {                                                                                                      \
         DMXQ_LAUNCH((softmax_wave_kernel<D_, E_, V_, L_, true, CAST>),                                         \
@@ -832,6 +890,25 @@ extern "C" int dmxq_softmax_cast(const void* in, void* out, int dtype, int64_t r
   RowCast rc;
   if (!valid_dtype(dtype)) return DMXQ_ERR_BAD_ARG;
   if (!rowcast_of(dtype, cast_in, cast_out, &rc)) return DMXQ_ERR_UNSUPPORTED;
+  return softmax_dispatch<true>(in, out, dtype, dtype, rows, cols, input_clamp_min, stream, rc);
+}
+
+// ... and with the NEXT module's BFP input cast applied to the result (modeling/nn/core.py:228-264 of the consumer: `input_casts` of the
+// ActActMatMul / Linear that takes the probabilities, numerical/format.py:304-343): out = BFP_QDQ(cast_out(softmax(cast_in(x)))) along
+// the rows, symmetric, nearest -- the pass over the [heads, S, S] probabilities that the consumer's cast would make (108 MB each way
+// for Whisper-small) disappears.  Bit-identical to dmxq_softmax_cast followed by dmxq_bfp_qdq.  DMXQ_ERR_UNSUPPORTED when the rows
+// are not whole lane-vectors or the block size does not map onto whole lanes (the caller runs the two launches).
+extern "C" int dmxq_softmax_cast_bfp(const void* in, void* out, int dtype, int64_t rows, int64_t cols, float input_clamp_min,
+                                     const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, int64_t block_size, int precision,
+                                     void* stream) {
+  RowCast rc;
+  if (!valid_dtype(dtype) || block_size < 1) return DMXQ_ERR_BAD_ARG;
+  if (precision < 2 || precision > 20 || block_size > 512) return DMXQ_ERR_UNSUPPORTED;
+  if (!rowcast_of(dtype, cast_in, cast_out, &rc)) return DMXQ_ERR_UNSUPPORTED;
+  rc.bfp_B = (int)block_size;
+  rc.bfp_wl = precision;
+  const int full = dtype == DMXQ_F32 ? 4 : 8;
+  if (rows * cols != 0 && !(cols >= full && (cols + full - 1) / full <= 64 * 16)) return DMXQ_ERR_UNSUPPORTED;  // (register-resident rows only)
   return softmax_dispatch<true>(in, out, dtype, dtype, rows, cols, input_clamp_min, stream, rc);
 }
 

@@ -616,18 +616,23 @@ Tensor unary_cast(const Tensor& x, int64_t kind, double param, at::IntArrayRef c
 }
 Tensor unary_cast_meta(const Tensor& x, int64_t, double, at::IntArrayRef, at::IntArrayRef) { return empty_like_shape(x, x.scalar_type()); }
 
-Tensor softmax_cast(const Tensor& x, double clamp_min, at::IntArrayRef cast_in, at::IntArrayRef cast_out) {  // over the contiguous last dim
+Tensor softmax_cast(const Tensor& x, double clamp_min, at::IntArrayRef cast_in, at::IntArrayRef cast_out, int64_t bfp_block,
+                    int64_t bfp_precision) {  // over the contiguous last dim; bfp_block > 0: the consumer's BFP input cast applied too
   const Tensor xc = prep(x, "softmax_cast");
   const int64_t cols = xc.dim() ? xc.size(-1) : 1;
   const int64_t rows = cols ? xc.numel() / cols : 0;
   Tensor out = empty_like_shape(xc, xc.scalar_type());
   dmxq_float_fmt fi, fo;
   Launch l(xc);
-  check(dmxq_softmax_cast(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), rows, cols, (float)clamp_min, fmt_of(cast_in, &fi),
-                          fmt_of(cast_out, &fo), l.stream), "dmxq_softmax_cast");
+  if (bfp_block > 0)
+    check(dmxq_softmax_cast_bfp(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), rows, cols, (float)clamp_min, fmt_of(cast_in, &fi),
+                                fmt_of(cast_out, &fo), bfp_block, (int)bfp_precision, l.stream), "dmxq_softmax_cast_bfp");
+  else
+    check(dmxq_softmax_cast(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), rows, cols, (float)clamp_min, fmt_of(cast_in, &fi),
+                            fmt_of(cast_out, &fo), l.stream), "dmxq_softmax_cast");
   return out;
 }
-Tensor softmax_cast_meta(const Tensor& x, double, at::IntArrayRef, at::IntArrayRef) { return empty_like_shape(x, x.scalar_type()); }
+Tensor softmax_cast_meta(const Tensor& x, double, at::IntArrayRef, at::IntArrayRef, int64_t, int64_t) { return empty_like_shape(x, x.scalar_type()); }
 
 Tensor norm_cast(const Tensor& x, int64_t cols, const OptTensor& weight, const OptTensor& bias, double eps, int64_t kind, at::IntArrayRef cast_in,
                  at::IntArrayRef cast_out) {
@@ -693,7 +698,7 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("softmax(Tensor x, float clamp_min, ScalarType? out_dtype=None) -> Tensor");
   m.def("norm(Tensor x, int cols, Tensor? weight, Tensor? bias, float eps, int kind, ScalarType? out_dtype=None) -> Tensor");
   m.def("unary_cast(Tensor x, int kind, float param, int[] cast_in, int[] cast_out) -> Tensor");
-  m.def("softmax_cast(Tensor x, float clamp_min, int[] cast_in, int[] cast_out) -> Tensor");
+  m.def("softmax_cast(Tensor x, float clamp_min, int[] cast_in, int[] cast_out, int bfp_block=0, int bfp_precision=0) -> Tensor");
   m.def("norm_cast(Tensor x, int cols, Tensor? weight, Tensor? bias, float eps, int kind, int[] cast_in, int[] cast_out) -> Tensor");
 }
 

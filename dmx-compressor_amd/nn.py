@@ -29,7 +29,7 @@ __all__ = ["DmxModule", "DmxQuantizerCalibrationHyperparams", "DmxModuleQuantize
            "DmxModuleSmoothQuantHyperparams", "Linear", "Conv1d", "Conv2d", "ResAdd", "ActActMatMul", "Softmax", "LayerNorm", "GELU", "ReLU", "SiLU", "QuickGELU", "Exp", "Mul", "RMSNorm", "ApplyRotaryPosEmb",
            "MaxPool2d", "AvgPool2d", "Embedding", "ReLU6", "Tanh", "Dropout", "NewGELU", "FastGELU", "BloomGELU", "ClippedGELU", "AdaptiveAvgPool2d",
            "BatchNorm2d", "GroupNorm", "ConvTranspose2d", "BAddBMM", "ScaledDotProductAttention", "DmxConfigRule", "configure_model",
-           "fold_weights_and_biases", "GraphedForward"]
+           "fold_weights_and_biases", "GraphedForward", "link_consumer"]
 
 
 class _LazySparsify(Sparsify):
@@ -375,6 +375,10 @@ class DmxModule(torch.nn.Module):
         from . import ops
         return ops.input_hypernet(x.detach(), sq.scale, fmt.precision, fmt.block_size, fmt.symmetric)
 
+    def _first_input_cast(self):
+        ic = self.input_casts
+        return ic[next(iter(ic.keys()))] if len(ic) else None
+
     def _fused_forward(self, input, *args, **kwargs):
         """A module whose whole forward (input casts -> op -> output cast) exists as ONE kernel returns its result here, or None to
         take the general path.  Results must be bit-identical to the general path."""
@@ -448,6 +452,10 @@ class DmxModule(torch.nn.Module):
                 input = self.smoothquant.scale_input(input)
         if fused is not None:
             _input, args, kwargs = self.input_casts(fused, *args, first_done=True, **kwargs)
+        elif (not torch.compiler.is_compiling() and getattr(input, "_dmx_precast", None) is not None
+              and input._dmx_precast is self._first_input_cast()):
+            # the producer already applied THIS module's first input cast in its own launch (nn.link_consumer)
+            _input, args, kwargs = self.input_casts(input, *args, first_done=True, **kwargs)
         else:
             _input, args, kwargs = self.input_casts(input, *args, **kwargs)
         _output = self._forward(_input, *args, **kwargs)
@@ -645,10 +653,34 @@ class Softmax(DmxModule, torch.nn.Softmax):
         if c is None or self.dim is None or x.dim() == 0 or self.dim % x.dim() != x.dim() - 1:
             return None
         from . import ops
+        nc = self._linked_bfp_cast(x)
+        if nc is not None:
+            out = ops.softmax_cast(x.detach(), -1, c[0], c[1], c[2].get("input_clamp"), then_bfp=(nc.format.precision, nc.format.block_size))
+            if out is not None:
+                out._dmx_precast = nc      # the consumer's forward recognises ITS cast object and skips it (DmxModule.forward)
+                self.approximation_error = None
+                return out
         out = ops.softmax_cast(x.detach(), -1, c[0], c[1], c[2].get("input_clamp"))
         if out is not None:
             self.approximation_error = None
         return out
+
+    #: apply the linked consumer's BFP input cast in the softmax launch (dmxq_softmax_cast_bfp); see `link_consumer`
+    fuse_next_cast = True
+
+    def _linked_bfp_cast(self, x):
+        """the consumer's input cast when it can ride in this module's launch: a live link, inference, a plain BFP format (symmetric,
+        nearest) along the softmax dim, fake-quantising and not observing, no pre-transform"""
+        from .format import BlockFloatingPoint
+        consumer = self.__dict__.get("_next_consumer") if self.fuse_next_cast else None   # set by nn.link_consumer
+        nc = consumer._first_input_cast() if consumer is not None else None
+        if nc is None or torch.compiler.is_compiling() or torch.is_grad_enabled() and x.requires_grad:
+            return None
+        fmt = nc.format
+        if (not isinstance(fmt, BlockFloatingPoint) or fmt.rounding != "nearest" or not fmt.symmetric or nc.pre_transform
+                or nc.block_dim not in (-1, x.dim() - 1) or not nc._flag("fake_quant_enabled") or nc._flag("observer_enabled")):
+            return None
+        return nc
 
 
 class LayerNorm(DmxModule, torch.nn.LayerNorm):
@@ -1005,6 +1037,10 @@ class BAddBMM(DmxModule):
         return torch.baddbmm(input, batch1, batch2, **kwargs)
 
 
+def _all_same_casts(m) -> bool:
+    return all(isinstance(c.format, Same) and not c.pre_transform for c in list(m.input_casts.values()) + list(m.output_casts.values()))
+
+
 class ScaledDotProductAttention(DmxModule):
     """torch_modules.py:108-192: a COMPOUND module -- F.scaled_dot_product_attention spelled out with ResAdd / ActActMatMul / Mul / Softmax /
     Dropout submodules, each with its own casts (so every fused path above applies inside it)"""
@@ -1017,6 +1053,7 @@ class ScaledDotProductAttention(DmxModule):
             c.block_dim = -1
         self.resadd, self.actmatmul, self.softmax = ResAdd(), ActActMatMul(), Softmax(dim=-1)
         self.dropout, self.mul = Dropout(p=dropout_p), Mul()
+        link_consumer(self.softmax, self.actmatmul)   # probabilities -> (identity dropout) -> `attn_weight @ value`: see forward
 
     def forward(self, query, key, value, attn_mask=None, is_causal=False, scale=None, enable_gqa=False):
         import math
@@ -1039,8 +1076,20 @@ class ScaledDotProductAttention(DmxModule):
         if not isinstance(scale_factor, torch.Tensor):
             scale_factor = torch.tensor(float(scale_factor), dtype=attn_weight.dtype)
         attn_weight = self.mul(attn_weight, scale_factor.to(attn_weight.device))
-        attn_weight = self.softmax(attn_weight)
-        attn_weight = self.dropout(attn_weight)
+        # softmax -> (dropout) -> matmul inside ONE compound module: when the dropout is the identity (inference, SAME casts) the
+        # probabilities have exactly one consumer, and the softmax launch applies the matmul's input cast too (link_consumer)
+        identity_dropout = (not self.training or self.dropout.p == 0.0) and _all_same_casts(self.dropout)
+        if identity_dropout:
+            attn_weight = self.softmax(attn_weight)           # (linked to self.actmatmul in __init__)
+            if torch.compiler.is_compiling() or getattr(attn_weight, "_dmx_precast", None) is None:
+                attn_weight = self.dropout(attn_weight)       # not fused after all: the reference's call sequence
+        else:
+            self.softmax.__dict__["fuse_next_cast"] = False   # an active dropout sits between the two: no fusion for this call
+            try:
+                attn_weight = self.softmax(attn_weight)
+            finally:
+                del self.softmax.__dict__["fuse_next_cast"]
+            attn_weight = self.dropout(attn_weight)
         return self.actmatmul(attn_weight, value)
 
 
@@ -1071,6 +1120,24 @@ class Embedding(DmxModule, torch.nn.Embedding):
         _output = F.embedding(input, self._weight_ro, self.padding_idx, self.max_norm, self.norm_type,
                               self.scale_grad_by_freq, self.sparse)
         return self.output_casts(_output, output=True)
+
+
+def link_consumer(producer: "DmxModule", consumer: "DmxModule") -> None:
+    """Declare that `consumer` is the ONLY user of `producer`'s output and takes it as its first input (HF attention: the Softmax whose
+    probabilities go -- through an inactive dropout -- into the `attn_probs @ value` ActActMatMul).  The producer may then apply the
+    consumer's first input cast in its own launch (Softmax: dmxq_softmax_cast_bfp, one pass over the [heads, S, S] probabilities
+    instead of two) and the consumer skips it; the result is bit-identical.  The link is by object: reconfiguring either module's
+    formats is picked up at the next forward, and anything the fused kernel does not cover falls back to the two launches.  Do NOT
+    link when something else reads the producer's output (e.g. `output_attentions=True`): it would see the BFP-cast values.
+    `unlink`: link_consumer(producer, None)."""
+    if consumer is None:
+        producer.__dict__.pop("_next_consumer", None)
+        return
+    if consumer._first_input_cast() is None:
+        raise ValueError("the consumer has no input cast to link")
+    # a plain attribute (not a registered submodule: no extra state_dict keys), held strongly so that copy.deepcopy / pickle of the
+    # model keep the pair together
+    producer.__dict__["_next_consumer"] = consumer
 
 
 # ---------------------------------------------------------------------------------------------------- rules

@@ -302,6 +302,13 @@ int dmxq_unary_cast(const void* in, void* out, int dtype, int64_t n, int kind, f
                     const dmxq_float_fmt* cast_out, void* stream);
 int dmxq_softmax_cast(const void* in, void* out, int dtype, int64_t rows, int64_t cols, float input_clamp_min,
                       const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* stream);
+/* ... followed by the NEXT module's BFP input cast of the result (the `input_casts` entry of the ActActMatMul / Linear that consumes the
+ * probabilities: modeling/nn/core.py:228-264, numerical/format.py:304-343, blocks of `block_size` along the rows, symmetric, nearest):
+ * out = BFP_QDQ(cast_out(softmax(cast_in(x)))) in ONE pass, bit-identical to dmxq_softmax_cast followed by dmxq_bfp_qdq(.., block_size,
+ * precision, nearest, symmetric).  The consumer then skips that cast.  DMXQ_ERR_UNSUPPORTED: as dmxq_softmax_cast, or rows that are not
+ * whole lane-vectors, or a block size that is not 2^k lane-vectors (16-byte vectors; 8-byte ones for 16-bit rows of 4 k elements). */
+int dmxq_softmax_cast_bfp(const void* in, void* out, int dtype, int64_t rows, int64_t cols, float input_clamp_min,
+                          const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, int64_t block_size, int precision, void* stream);
 int dmxq_layernorm_cast(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, const void* bias,
                         float eps, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* stream);
 int dmxq_rmsnorm_cast(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, float eps,

@@ -341,3 +341,76 @@ def test_model_shape_activation_stages(dmx, cuda, oracle, tag, dtype, shape, kin
     else:
         truth, n = _rms_truth(cin, cols, m.weight.detach().cpu(), m.eps), _n_ulp({torch.float32: 4}, dtype, None)
     assert outside_cast_bracket(y, truth, _cpu_cast(oracle, fo), dtype, n, floor) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "f16", "f32"])
+def test_softmax_cast_then_bfp_equals_the_two_launches(dmx, cuda, dtype):
+    """dmxq_softmax_cast_bfp: the consumer's BFP input cast applied in the softmax module's launch == dmxq_softmax_cast followed by
+    dmxq_bfp_qdq, bit for bit (both pinned elsewhere: the module contract above, the BFP cast against the reference) -- attention
+    shapes with whole and ragged last blocks, 16- and 8-byte lane-vectors, rows shorter than a block, several rows per wave, both
+    bindings' front ends; shapes the fused form does not take return None."""
+    ops = dmx.ops
+    f16 = _fmt(dmx, "FLOAT16")
+    shapes = [(12, 100, 1500), (3, 7, 128), (2, 5, 64), (4, 33, 2048), (2, 9, 200), (1, 4, 4096), (5, 32), (2, 3, 24)]
+    for shape in shapes:
+        x = (make("normal", shape, seed=sum(shape), dtype=torch.float32) * 3).to(dtype).to(cuda)
+        for cin, cout in ((f16, f16), (None, f16), (None, None)):
+            for B, wl in ((64, 8), (16, 8), (32, 4), (128, 8)):
+                fused = ops.softmax_cast(x, -1, cin, cout, then_bfp=(wl, B))
+                two = ops.softmax_cast(x, -1, cin, cout)
+                if two is None:
+                    assert fused is None
+                    continue
+                want = ops.bfp_qdq(two, wl, B)
+                if fused is None:
+                    # not fusable: the row is not whole lane-vectors, or B is not a power-of-two number of them
+                    epl = 4 if dtype == torch.float32 else 8
+                    assert shape[-1] % 4 != 0 or (B // epl) * epl != B or shape[-1] % epl != 0 and (dtype == torch.float32 or B % 4 != 0), (shape, B)
+                    continue
+                bad = int((fused.view(torch.int32 if dtype == torch.float32 else torch.int16) != want.view(torch.int32 if dtype == torch.float32 else torch.int16)).sum())
+                assert bad == 0, f"{shape} {dtype} B={B} wl={wl} casts=({cin}, {cout}): {bad} elements differ"
+
+
+def test_linked_softmax_feeds_the_matmul_without_a_second_pass(dmx, cuda):
+    """nn.link_consumer / the compound ScaledDotProductAttention: the Softmax launch applies the `probs @ value` ActActMatMul's input
+    cast, the matmul skips it, results identical to the unlinked modules; reconfiguring the consumer's format is picked up; an active
+    dropout or a format the fused kernel does not take fall back to the reference's call sequence."""
+    nn = dmx.nn
+    torch.manual_seed(0)
+    for dtype in (torch.bfloat16, torch.float32):
+        sm, pv = nn.Softmax(dim=-1).to(cuda).eval(), nn.ActActMatMul().to(cuda).eval()
+        dmx.configure_model(torch.nn.ModuleList([sm, pv]), *dmx.config_rules.BASIC)
+        s = (torch.randn(2, 4, 96, 128, device=cuda) * 2).to(dtype)
+        v = torch.randn(2, 4, 128, 64, device=cuda).to(dtype)
+        with torch.no_grad():
+            want = pv(sm(s), v)
+            nn.link_consumer(sm, pv)
+            p = sm(s)
+            assert getattr(p, "_dmx_precast", None) is pv._first_input_cast()
+            got = pv(p, v)
+            assert torch.equal(got, want)
+            pv.configure(dict(input_formats=["BFP[4|8]{32}(SN)", "BFP[8|8]{64}(SN)"]))       # picked up at the next forward
+            want2 = pv(_unlinked(sm, s), v)
+            assert torch.equal(pv(sm(s), v), want2)
+            pv.configure(dict(input_formats=["BFP[8|8]{64}(_N)", "BFP[8|8]{64}(SN)"]))       # asymmetric: not fused, still right
+            p = sm(s)
+            assert getattr(p, "_dmx_precast", None) is None
+            nn.link_consumer(sm, None)
+        # the compound module
+        att = nn.ScaledDotProductAttention().to(cuda).eval()
+        dmx.configure_model(att, *dmx.config_rules.BASIC)
+        q, k = (torch.randn(2, 4, 96, 64, device=cuda)).to(dtype), (torch.randn(2, 4, 128, 64, device=cuda)).to(dtype)
+        with torch.no_grad():
+            got = att(q, k, v)
+            att.softmax.fuse_next_cast = False
+            want = att(q, k, v)
+            att.softmax.fuse_next_cast = True
+        assert torch.equal(got, want)
+
+
+def _unlinked(sm, s):
+    sm.fuse_next_cast = False
+    try:
+        return sm(s)
+    finally:
+        sm.fuse_next_cast = True

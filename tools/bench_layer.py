@@ -100,6 +100,9 @@ def build_layer(name, dev):
                 p.copy_(torch.randn_like(p) * 0.1 + 1.0)
     m = m.to(dev).to(dt).eval()
     d.configure_model(m, *d.config_rules.BASIC)
+    # the probabilities have ONE consumer (no dropout in inference, attention weights not returned): the softmax launch may apply the
+    # `p @ v` matmul's input cast too (nn.link_consumer; switched with the other fusions by set_fusions)
+    nn.link_consumer(m.softmax, m.pv)
     lin = [mod for mod in m.modules() if isinstance(mod, nn.Linear)]
     x = (torch.randn(c["B"], c["S"], H, device=dev) * 1.5).to(dt)
     extra = ()
@@ -130,7 +133,7 @@ def build_layer(name, dev):
     return m, x, extra
 
 
-FUSE_FLAGS = ("fuse_weight_hypernet", "fuse_input_hypernet", "fuse_binary", "fuse_relu", "fuse_rope", "fuse_activation")
+FUSE_FLAGS = ("fuse_weight_hypernet", "fuse_input_hypernet", "fuse_binary", "fuse_relu", "fuse_rope", "fuse_activation", "fuse_next_cast")
 
 
 def set_fusions(m, on):

@@ -240,6 +240,11 @@ def main():
         lambda i: (fq(xr32[i], yr32[i], _lib.F32, rows * cols), fq(torch.softmax(yr32[i], -1), yr32[(i + 1) % 5], _lib.F32, rows * cols)), 5, rows * cols * 8)
     run("bfp_qdq float32 rows of 1500, B=64 (ragged last block: Whisper attention probabilities)",
         lambda i: L.dmxq_bfp_qdq(vp(xr32[i].data_ptr()), vp(yr32[i].data_ptr()), _lib.F32, _lib.F32, rows, cols, 1, 64, 8, 2, 1, 0, sp), 5, rows * cols * 8)
+    run("softmax_cast_bfp float32 rows of 1500: the softmax module AND the consumer's BFP16_64 input cast in one launch (8 B/elem)",
+        lambda i: L.dmxq_softmax_cast_bfp(vp(xr32[i].data_ptr()), vp(yr32[i].data_ptr()), _lib.F32, rows, cols, ctypes.c_float(-math.inf), pf, pf, 64, 8, sp), 5, rows * cols * 8)
+    run("  the two launches it replaces (softmax_cast, then bfp_qdq of the probabilities: 16 B/elem)",
+        lambda i: (L.dmxq_softmax_cast(vp(xr32[i].data_ptr()), vp(yr32[i].data_ptr()), _lib.F32, rows, cols, ctypes.c_float(-math.inf), pf, pf, sp),
+                   L.dmxq_bfp_qdq(vp(yr32[i].data_ptr()), vp(yr32[(i + 1) % 5].data_ptr()), _lib.F32, _lib.F32, rows, cols, 1, 64, 8, 2, 1, 0, sp)), 5, rows * cols * 8)
     del xr32, yr32
     run("float_qdq float32 FP16(FN) [BASIC activation cast of a float32 model]",
         lambda i: fq(f32a[i % 6], f32o[i % 6], _lib.F32, n), 6, n * 8)
