@@ -39,6 +39,8 @@ SIGNATURES = {
     "dmxq_softmax_cast_bfp": [_vp, _vp, _i32, _i64, _i64, _f32, _vp, _vp, _i64, _i32, _vp],
     "dmxq_layernorm_cast": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _f32, _vp, _vp, _vp],
     "dmxq_rmsnorm_cast": [_vp, _vp, _i32, _i64, _i64, _vp, _f32, _vp, _vp, _vp],
+    "dmxq_layernorm_cast_bfp": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _f32, _vp, _vp, _i64, _i32, _vp],
+    "dmxq_rmsnorm_cast_bfp": [_vp, _vp, _i32, _i64, _i64, _vp, _f32, _vp, _vp, _i64, _i32, _vp],
     "dmxq_float_qdq": [_vp, _vp, _i32, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _u64, _vp],
     "dmxq_fixed_qdq": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _u64, _vp],
     "dmxq_fixed_qdq_multi": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _u64, _vp],

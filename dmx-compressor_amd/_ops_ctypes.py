@@ -656,7 +656,7 @@ def softmax_cast(x, dim: int = -1, cast_in=None, cast_out=None, input_clamp: Opt
     return _fused_rc(rc, "dmxq_softmax_cast", out)
 
 
-def _norm_cast(x, normalized_shape, weight, bias, eps, rms, cast_in, cast_out, what):
+def _norm_cast(x, normalized_shape, weight, bias, eps, rms, cast_in, cast_out, what, then_bfp=None):
     xc = _prep(x, what)
     cp = _cast_ptrs(cast_in, cast_out)
     cols = 1
@@ -668,6 +668,13 @@ def _norm_cast(x, normalized_shape, weight, bias, eps, rms, cast_in, cast_out, w
         return None
     out = torch.empty_like(xc)
     rows = xc.numel() // max(cols, 1)
+    if then_bfp:
+        bb, bp = int(then_bfp[1]), int(then_bfp[0])
+        if rms:
+            rc = lib().dmxq_rmsnorm_cast_bfp(ptr(xc), ptr(out), dtype_code(xc.dtype), rows, cols, ptr(w), float(eps), *cp[0], bb, bp, stream_of(xc))
+        else:
+            rc = lib().dmxq_layernorm_cast_bfp(ptr(xc), ptr(out), dtype_code(xc.dtype), rows, cols, ptr(w), ptr(b), float(eps), *cp[0], bb, bp, stream_of(xc))
+        return _fused_rc(rc, "dmxq_rmsnorm_cast_bfp" if rms else "dmxq_layernorm_cast_bfp", out)
     if rms:
         rc = lib().dmxq_rmsnorm_cast(ptr(xc), ptr(out), dtype_code(xc.dtype), rows, cols, ptr(w), float(eps), *cp[0], stream_of(xc))
     else:
@@ -675,15 +682,16 @@ def _norm_cast(x, normalized_shape, weight, bias, eps, rms, cast_in, cast_out, w
     return _fused_rc(rc, "dmxq_rmsnorm_cast" if rms else "dmxq_layernorm_cast", out)
 
 
-def layernorm_cast(x, normalized_shape, weight=None, bias=None, eps: float = 1e-5, cast_in=None, cast_out=None):
-    """A LayerNorm DmxModule in one launch (weight / bias in x's dtype); None when not fusable."""
-    return _norm_cast(x, normalized_shape, weight, bias, eps, False, cast_in, cast_out, "layernorm_cast")
+def layernorm_cast(x, normalized_shape, weight=None, bias=None, eps: float = 1e-5, cast_in=None, cast_out=None, then_bfp=None):
+    """A LayerNorm DmxModule in one launch (weight / bias in x's dtype); then_bfp = (precision, block_size): the consumers' BFP input
+    cast in the same launch; None when not fusable."""
+    return _norm_cast(x, normalized_shape, weight, bias, eps, False, cast_in, cast_out, "layernorm_cast", then_bfp)
 
 
-def rmsnorm_cast(x, normalized_shape, weight=None, eps: Optional[float] = None, cast_in=None, cast_out=None):
-    """An RMSNorm DmxModule in one launch (eps None = torch.finfo(x.dtype).eps, as torch); None when not fusable."""
+def rmsnorm_cast(x, normalized_shape, weight=None, eps: Optional[float] = None, cast_in=None, cast_out=None, then_bfp=None):
+    """An RMSNorm DmxModule in one launch (eps None = torch.finfo(x.dtype).eps, as torch); then_bfp as layernorm_cast; None when not fusable."""
     eps = torch.finfo(x.dtype).eps if eps is None else eps
-    return _norm_cast(x, normalized_shape, weight, None, eps, True, cast_in, cast_out, "rmsnorm_cast")
+    return _norm_cast(x, normalized_shape, weight, None, eps, True, cast_in, cast_out, "rmsnorm_cast", then_bfp)
 
 
 def _on_tensor_device(fn):

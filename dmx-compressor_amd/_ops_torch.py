@@ -462,24 +462,28 @@ def softmax_cast(x, dim: int = -1, cast_in=None, cast_out=None, input_clamp: Opt
         return None
 
 
-def layernorm_cast(x, normalized_shape, weight=None, bias=None, eps: float = 1e-5, cast_in=None, cast_out=None):
-    """A LayerNorm DmxModule in one launch (weight / bias in x's dtype).  None when not fusable."""
+def layernorm_cast(x, normalized_shape, weight=None, bias=None, eps: float = 1e-5, cast_in=None, cast_out=None, then_bfp=None):
+    """A LayerNorm DmxModule in one launch (weight / bias in x's dtype); then_bfp = (precision, block_size): the consumers' BFP input
+    cast (symmetric, nearest, along the rows) applied in the same launch.  None when not fusable."""
     require_gpu(x, "layernorm_cast")
     if not _casts_ok(cast_in, cast_out):
         return None
     try:
-        return _ops.norm_cast(x, _cols(normalized_shape), weight, bias, float(eps), 0, _fmt4(cast_in), _fmt4(cast_out))
+        return _ops.norm_cast(x, _cols(normalized_shape), weight, bias, float(eps), 0, _fmt4(cast_in), _fmt4(cast_out),
+                              int(then_bfp[1]) if then_bfp else 0, int(then_bfp[0]) if then_bfp else 0)
     except NotImplementedError:
         return None
 
 
-def rmsnorm_cast(x, normalized_shape, weight=None, eps: Optional[float] = None, cast_in=None, cast_out=None):
-    """An RMSNorm DmxModule in one launch (eps None = torch.finfo(x.dtype).eps, as torch).  None when not fusable."""
+def rmsnorm_cast(x, normalized_shape, weight=None, eps: Optional[float] = None, cast_in=None, cast_out=None, then_bfp=None):
+    """An RMSNorm DmxModule in one launch (eps None = torch.finfo(x.dtype).eps, as torch); then_bfp as layernorm_cast.  None when not
+    fusable."""
     require_gpu(x, "rmsnorm_cast")
     if not _casts_ok(cast_in, cast_out):
         return None
     eps = torch.finfo(x.dtype).eps if eps is None else eps
     try:
-        return _ops.norm_cast(x, _cols(normalized_shape), weight, None, float(eps), 1, _fmt4(cast_in), _fmt4(cast_out))
+        return _ops.norm_cast(x, _cols(normalized_shape), weight, None, float(eps), 1, _fmt4(cast_in), _fmt4(cast_out),
+                              int(then_bfp[1]) if then_bfp else 0, int(then_bfp[0]) if then_bfp else 0)
     except NotImplementedError:
         return None

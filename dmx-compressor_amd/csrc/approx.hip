@@ -261,6 +261,33 @@ __device__ __forceinline__ void row_store_raw(void* p, int64_t e, const RowVec<D
   }
 }
 
+// The CONSUMER's BFP input cast applied to one lane-vector of a module's result (dmxq_*_cast_bfp): `o` is what the module returns
+// (output cast applied, rounded to the row dtype); the block maximum runs over lpb adjacent lanes -- EVERY lane of the wave must call
+// this (`valid` = the slot lies inside the row; invalid slots contribute 0) --, then the magic-add arithmetic of bfp_math.hpp with
+// its cold literal redo.  q: the values to store (row_store rounds them to the row dtype: CastTo's `.to(dtype)`).
+template <int DT, int EPL>
+__device__ __forceinline__ void bfp_epilogue(const RowVec<DT, EPL>& o, bool valid, int lpb, int wl, float (&q)[EPL]) {
+  float z[EPL];
+  row_widen<DT, EPL>(o, z);
+  uint32_t mb = 0u;
+#pragma unroll
+  for (int k = 0; k < EPL; k++) mb = max(mb, f2u(z[k]) & 0x7FFFFFFFu);
+  mb = group_max_u32(valid ? mb : 0u, lpb);
+  const bool fast_ok = bfp_fast_ok(mb, wl);
+  {
+    const BfpBlockParams bp = bfp_block_params<false, true>(mb, wl);
+#pragma unroll
+    for (int k = 0; k < EPL; k++) q[k] = bfp_q1_fast<false, false>(z[k], bp);
+  }
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast_ok) != 0ull, 0)) {
+    if (!fast_ok) {
+      const BfpBlockParams bp = bfp_block_params<false, false>(mb, wl);
+#pragma unroll
+      for (int k = 0; k < EPL; k++) q[k] = bfp_q1<DMXQ_ROUND_NEAREST, false>(z[k], bp, wl, DMXQ_ROUND_NEAREST, 0u);
+    }
+  }
+}
+
 // Sum / max over the LPR (64 or 32) adjacent lanes that own a row, every lane receiving the result.  Inside a row of 16 lanes: four
 // DPP steps (quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- VALU operand modifiers, no LDS); across the rows of 16: the four
 // row totals through v_readlane.  The SAME summation tree as an xor butterfly (so the same bits), which as `__shfl_xor` compiled
@@ -408,28 +435,10 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
           const int v = i * LPR + sl;
-          float y[EPL], z[EPL], q[EPL];
+          float y[EPL], q[EPL];
 #pragma unroll
           for (int k = 0; k < EPL; k++) y[k] = FAST ? x[j][i][k] * inv : x[j][i][k] / s[j];
-          const RowVec<DT, EPL> o = rowcast_pack_out<CAST, DT, EPL>(y, rc);  // what the softmax module returns
-          row_widen<DT, EPL>(o, z);
-          uint32_t mb = 0u;
-#pragma unroll
-          for (int k = 0; k < EPL; k++) mb = max(mb, f2u(z[k]) & 0x7FFFFFFFu);
-          mb = group_max_u32(v < nv ? mb : 0u, lpb);
-          const bool fast_ok = bfp_fast_ok(mb, wl);
-          {
-            const BfpBlockParams bp = bfp_block_params<false, true>(mb, wl);
-#pragma unroll
-            for (int k = 0; k < EPL; k++) q[k] = bfp_q1_fast<false, false>(z[k], bp);
-          }
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast_ok) != 0ull, 0)) {
-            if (!fast_ok) {
-              const BfpBlockParams bp = bfp_block_params<false, false>(mb, wl);
-#pragma unroll
-              for (int k = 0; k < EPL; k++) q[k] = bfp_q1<DMXQ_ROUND_NEAREST, false>(z[k], bp, wl, DMXQ_ROUND_NEAREST, 0u);
-            }
-          }
+          bfp_epilogue<DT, EPL>(rowcast_pack_out<CAST, DT, EPL>(y, rc), v < nv, lpb, wl, q);
           if (v < nv && r < rows) row_store<DT, EPL>(out, r * cols + (int64_t)v * EPL, q);  // CastTo's `.to(dtype)`: one RNE rounding
         }
       }
@@ -472,7 +481,7 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
 // weight / bias (same dtype as the rows) are read ONCE per wave and kept across its rows: widened to fp32 for short
 // rows, packed for longer ones.  Per element: widen + add, subtract + fma, and (x - mean) * (rstd w) + b as
 // subtract + fma with rstd w formed once per (row, vector element).
-template <int DT, int EPL, int VPL, int LPR, bool RMS = false, bool CAST = false, int RPWO = 0, int HOISTO = 0, int PFO = -1>
+template <int DT, int EPL, int VPL, int LPR, bool RMS = false, bool CAST = false, int RPWO = 0, int HOISTO = 0, int PFO = -1, bool BFPOUT = false>
 __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                                  int64_t rows, int64_t cols, const void* __restrict__ w,
                                                                  const void* __restrict__ b, float eps, const RowCastArg<CAST> rc) {
@@ -567,6 +576,35 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
     }
 #pragma unroll
     for (int j = 0; j < RPW; j++) rstd[j] = 1.0f / sqrtf(seg_sum<LPR>(rstd[j]) * inv_n + eps);  // biased variance, as F.layer_norm
+    if constexpr (BFPOUT) {
+      // dmxq_layernorm_cast_bfp / dmxq_rmsnorm_cast_bfp: the consumers' BFP input cast on the module's result (bfp_epilogue: every lane
+      // takes part, only the store is predicated)
+      static_assert(!BFPOUT || CAST, "fused BFP epilogue: cast form");
+      const int lpb = __builtin_amdgcn_readfirstlane(rc.bfp_lpb), wl = __builtin_amdgcn_readfirstlane(rc.bfp_wl);
+#pragma unroll
+      for (int i = 0; i < VPL; i++) {
+        const int v = i * LPR + sl, vc = v < nv ? v : nv - 1;
+        float ww[EPL], bb[EPL];
+        if (!HOIST_F32) {
+          if (w) row_widen<DT, EPL>(HOIST_RAW ? wr[i] : row_load_keep<DT, EPL>(w, (int64_t)vc * EPL), ww);
+          if (b) row_widen<DT, EPL>(HOIST_RAW ? br[i] : row_load_keep<DT, EPL>(b, (int64_t)vc * EPL), bb);
+        }
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+          const int64_t r = r0 + j * SUB + sub;
+          float y[EPL], q[EPL];
+#pragma unroll
+          for (int k = 0; k < EPL; k++) {
+            const float g = w ? rstd[j] * (HOIST_F32 ? wf[i][k] : ww[k]) : rstd[j];
+            const float d = x[j][i][k] - mean[j];
+            y[k] = b ? __builtin_fmaf(d, g, HOIST_F32 ? bf[i][k] : bb[k]) : d * g;
+          }
+          bfp_epilogue<DT, EPL>(rowcast_pack_out<CAST, DT, EPL>(y, rc), v < nv, lpb, wl, q);
+          if (v < nv && r < rows) row_store<DT, EPL>(out, r * cols + (int64_t)v * EPL, q);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
       const int v = i * LPR + sl;
@@ -600,7 +638,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
 // thread), two workgroup reductions per row through a 4-entry LDS exchange, RPW rows per iteration to amortise the two
 // barriers, weight / bias hoisted (packed) out of the persistent row loop.  The wave kernel at this size would hold
 // 128+ values per lane and re-read weight and bias (as much data as the row itself) for every row.
-template <int DT, int EPL, int VPL, bool RMS = false, bool CAST = false, int RPWO = 0, bool ONE_PASS = false>
+template <int DT, int EPL, int VPL, bool RMS = false, bool CAST = false, int RPWO = 0, bool ONE_PASS = false, bool BFPOUT = false>
 __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                                   int64_t rows, int64_t cols, const void* __restrict__ w,
                                                                   const void* __restrict__ b, float eps, const RowCastArg<CAST> rc) {
@@ -685,6 +723,30 @@ __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* _
 #pragma unroll
       for (int k = 1; k < NW; k++) q += red[qb][j][k];
       rstd[j] = 1.0f / sqrtf(q * inv_n + eps);  // biased variance, as F.layer_norm
+    }
+    if constexpr (BFPOUT) {
+      static_assert(!BFPOUT || CAST, "fused BFP epilogue: cast form");
+      const int lpb = __builtin_amdgcn_readfirstlane(rc.bfp_lpb), wl = __builtin_amdgcn_readfirstlane(rc.bfp_wl);
+#pragma unroll
+      for (int i = 0; i < VPL; i++) {
+        const int v = i * kThreads + t;
+        float ww[EPL], bb[EPL];
+        if (w) row_widen<DT, EPL>(wr[i], ww);   // (loaded clamped: valid for every lane)
+        if (b) row_widen<DT, EPL>(br[i], bb);
+#pragma unroll
+        for (int j = 0; j < RPW; j++) {
+          float y[EPL], q[EPL];
+#pragma unroll
+          for (int k = 0; k < EPL; k++) {
+            const float g = w ? rstd[j] * ww[k] : rstd[j];
+            const float d = x[j][i][k] - mean[j];
+            y[k] = b ? __builtin_fmaf(d, g, bb[k]) : d * g;
+          }
+          bfp_epilogue<DT, EPL>(rowcast_pack_out<CAST, DT, EPL>(y, rc), v < nv, lpb, wl, q);
+          if (v < nv && r0 + j < rows) row_store<DT, EPL>(out, (r0 + j) * cols + (int64_t)v * EPL, q);
+        }
+      }
+      return;
     }
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
@@ -941,6 +1003,18 @@ static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out,
 #define DMXQ_LNB(D_, E_, V_)                                                                                          \
   do {                                                                                                                \
     constexpr int rpw = (V_) * (E_) <= 32 ? 2 : 1, rpw_mid = 16 / (V_) >= 8 ? 8 : (16 / (V_) >= 4 ? 4 : 2);            \
+    if constexpr (CAST) {                                                                                             \
+      if (rc.bfp_B) { /* dmxq_*norm_cast_bfp: blocks of B elements = lpb adjacent lanes */                              \
+        const int lpb = rc.bfp_B / (E_);                                                                              \
+        if (rc.bfp_B % (E_) != 0 || lpb < 1 || (lpb & (lpb - 1)) != 0 || lpb > 64) return DMXQ_ERR_UNSUPPORTED;        \
+        RowCast rb = rc;                                                                                              \
+        rb.bfp_lpb = lpb;                                                                                             \
+        DMXQ_LAUNCH((layernorm_block_kernel<D_, E_, V_, RMS, CAST, 0, false, true>),                                \
+                    dim3((unsigned)resident_grid(layernorm_block_kernel<D_, E_, V_, RMS, CAST, 0, false, true>, (rows + rpw - 1) / rpw)), \
+                    dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps, rb);                                \
+        break;                                                                                                        \
+      }                                                                                                               \
+    }                                                                                                                 \
     if constexpr (!CAST && rpw_mid != rpw) {                                                                          \
       if (mid) {                                                                                                      \
         DMXQ_LAUNCH((layernorm_block_kernel<D_, E_, V_, RMS, CAST, rpw_mid, true>), dim3(one_pass_grid((rows + rpw_mid - 1) / rpw_mid)),   \
@@ -972,6 +1046,18 @@ static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out,
 #define DMXQ_LN(D_, E_, V_, L_)                                                                                       \
   do {                                                                                                                \
     constexpr int per_wg = 4 * rows_per_wave(V_, E_) * (64 / (L_));                                                   \
+    if constexpr (CAST) {                                                                                             \
+      if (rc.bfp_B) {                                                                                                 \
+        const int lpb = rc.bfp_B / (E_);                                                                              \
+        if (rc.bfp_B % (E_) != 0 || lpb < 1 || (lpb & (lpb - 1)) != 0 || lpb > (L_)) return DMXQ_ERR_UNSUPPORTED;      \
+        RowCast rb = rc;                                                                                              \
+        rb.bfp_lpb = lpb;                                                                                             \
+        DMXQ_LAUNCH((layernorm_wave_kernel<D_, E_, V_, L_, RMS, CAST, 0, 0, -1, true>),                             \
+                    dim3((unsigned)resident_grid(layernorm_wave_kernel<D_, E_, V_, L_, RMS, CAST, 0, 0, -1, true>, (rows + per_wg - 1) / per_wg)), \
+                    dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps, rb);                                \
+        break;                                                                                                        \
+      }                                                                                                               \
+    }                                                                                                                 \
     DMXQ_LAUNCH((layernorm_wave_kernel<D_, E_, V_, L_, RMS, CAST>),                                                 \
                        dim3((unsigned)resident_grid(layernorm_wave_kernel<D_, E_, V_, L_, RMS, CAST>, (rows + per_wg - 1) / per_wg)), \
                        dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps, rc);                             \
@@ -1031,6 +1117,31 @@ extern "C" int dmxq_rmsnorm_cast(const void* in, void* out, int dtype, int64_t r
   RowCast rc;
   if (!valid_dtype(dtype)) return DMXQ_ERR_BAD_ARG;
   if (!rowcast_of(dtype, cast_in, cast_out, &rc)) return DMXQ_ERR_UNSUPPORTED;
+  return norm_dispatch<true, true>(in, out, dtype, dtype, rows, cols, weight, nullptr, dtype, eps, stream, rc);
+}
+// ... and with the BFP input cast of the modules that consume the result (the q / k / v or gate / up Linears after a pre-attention /
+// pre-MLP norm: identical `input_casts` formats, modeling/nn/core.py:228-264) applied in the same launch; bit-identical to
+// dmxq_layernorm_cast / dmxq_rmsnorm_cast followed by dmxq_bfp_qdq(.., block_size, precision, nearest, symmetric).
+extern "C" int dmxq_layernorm_cast_bfp(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, const void* bias,
+                                       float eps, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, int64_t block_size,
+                                       int precision, void* stream) {
+  RowCast rc;
+  if (!valid_dtype(dtype) || block_size < 1) return DMXQ_ERR_BAD_ARG;
+  if (precision < 2 || precision > 20 || block_size > 512) return DMXQ_ERR_UNSUPPORTED;
+  if (!rowcast_of(dtype, cast_in, cast_out, &rc)) return DMXQ_ERR_UNSUPPORTED;
+  rc.bfp_B = (int)block_size;
+  rc.bfp_wl = precision;
+  return norm_dispatch<false, true>(in, out, dtype, dtype, rows, cols, weight, bias, dtype, eps, stream, rc);
+}
+extern "C" int dmxq_rmsnorm_cast_bfp(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, float eps,
+                                     const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, int64_t block_size, int precision,
+                                     void* stream) {
+  RowCast rc;
+  if (!valid_dtype(dtype) || block_size < 1) return DMXQ_ERR_BAD_ARG;
+  if (precision < 2 || precision > 20 || block_size > 512) return DMXQ_ERR_UNSUPPORTED;
+  if (!rowcast_of(dtype, cast_in, cast_out, &rc)) return DMXQ_ERR_UNSUPPORTED;
+  rc.bfp_B = (int)block_size;
+  rc.bfp_wl = precision;
   return norm_dispatch<true, true>(in, out, dtype, dtype, rows, cols, weight, nullptr, dtype, eps, stream, rc);
 }
 #endif  // part 2 (norms)

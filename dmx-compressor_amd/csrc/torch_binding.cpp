@@ -635,7 +635,7 @@ Tensor softmax_cast(const Tensor& x, double clamp_min, at::IntArrayRef cast_in, 
 Tensor softmax_cast_meta(const Tensor& x, double, at::IntArrayRef, at::IntArrayRef, int64_t, int64_t) { return empty_like_shape(x, x.scalar_type()); }
 
 Tensor norm_cast(const Tensor& x, int64_t cols, const OptTensor& weight, const OptTensor& bias, double eps, int64_t kind, at::IntArrayRef cast_in,
-                 at::IntArrayRef cast_out) {
+                 at::IntArrayRef cast_out, int64_t bfp_block, int64_t bfp_precision) {  // bfp_block > 0: the consumers' BFP input cast too
   const Tensor xc = prep(x, "norm_cast");
   const int64_t rows = cols ? xc.numel() / cols : 0;
   Tensor w, b;
@@ -647,7 +647,15 @@ Tensor norm_cast(const Tensor& x, int64_t cols, const OptTensor& weight, const O
   Tensor out = empty_like_shape(xc, xc.scalar_type());
   dmxq_float_fmt fi, fo;
   Launch l(xc);
-  if (kind == 0)
+  if (bfp_block > 0 && kind == 0)
+    check(dmxq_layernorm_cast_bfp(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), rows, cols, w.defined() ? w.data_ptr() : nullptr,
+                                  b.defined() ? b.data_ptr() : nullptr, (float)eps, fmt_of(cast_in, &fi), fmt_of(cast_out, &fo), bfp_block,
+                                  (int)bfp_precision, l.stream), "dmxq_layernorm_cast_bfp");
+  else if (bfp_block > 0)
+    check(dmxq_rmsnorm_cast_bfp(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), rows, cols, w.defined() ? w.data_ptr() : nullptr,
+                                (float)eps, fmt_of(cast_in, &fi), fmt_of(cast_out, &fo), bfp_block, (int)bfp_precision, l.stream),
+          "dmxq_rmsnorm_cast_bfp");
+  else if (kind == 0)
     check(dmxq_layernorm_cast(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), rows, cols, w.defined() ? w.data_ptr() : nullptr,
                               b.defined() ? b.data_ptr() : nullptr, (float)eps, fmt_of(cast_in, &fi), fmt_of(cast_out, &fo), l.stream),
           "dmxq_layernorm_cast");
@@ -656,7 +664,7 @@ Tensor norm_cast(const Tensor& x, int64_t cols, const OptTensor& weight, const O
                             fmt_of(cast_in, &fi), fmt_of(cast_out, &fo), l.stream), "dmxq_rmsnorm_cast");
   return out;
 }
-Tensor norm_cast_meta(const Tensor& x, int64_t, const OptTensor&, const OptTensor&, double, int64_t, at::IntArrayRef, at::IntArrayRef) {
+Tensor norm_cast_meta(const Tensor& x, int64_t, const OptTensor&, const OptTensor&, double, int64_t, at::IntArrayRef, at::IntArrayRef, int64_t, int64_t) {
   return empty_like_shape(x, x.scalar_type());
 }
 
@@ -699,7 +707,7 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("norm(Tensor x, int cols, Tensor? weight, Tensor? bias, float eps, int kind, ScalarType? out_dtype=None) -> Tensor");
   m.def("unary_cast(Tensor x, int kind, float param, int[] cast_in, int[] cast_out) -> Tensor");
   m.def("softmax_cast(Tensor x, float clamp_min, int[] cast_in, int[] cast_out, int bfp_block=0, int bfp_precision=0) -> Tensor");
-  m.def("norm_cast(Tensor x, int cols, Tensor? weight, Tensor? bias, float eps, int kind, int[] cast_in, int[] cast_out) -> Tensor");
+  m.def("norm_cast(Tensor x, int cols, Tensor? weight, Tensor? bias, float eps, int kind, int[] cast_in, int[] cast_out, int bfp_block=0, int bfp_precision=0) -> Tensor");
 }
 
 #define DMXQ_IMPL(m, name) m.impl(#name, &name)

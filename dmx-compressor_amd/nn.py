@@ -379,6 +379,34 @@ class DmxModule(torch.nn.Module):
         ic = self.input_casts
         return ic[next(iter(ic.keys()))] if len(ic) else None
 
+    #: apply the linked consumers' BFP input cast in this module's launch (dmxq_softmax_cast_bfp, dmxq_layernorm_cast_bfp,
+    #: dmxq_rmsnorm_cast_bfp); see `link_consumer`
+    fuse_next_cast = True
+
+    def _linked_bfp_cast(self, x):
+        """the consumers' (common) first input cast when it can ride in this module's launch: a live link (nn.link_consumer), inference,
+        every consumer with the SAME plain BFP format (symmetric, nearest, along this module's last dim), fake-quantising and not
+        observing, no pre-transform, and no SmoothQuant scaling in front of it.  Returns (casts, format) or None."""
+        from .format import BlockFloatingPoint
+        consumers = self.__dict__.get("_next_consumers") if self.fuse_next_cast else None
+        if not consumers or torch.compiler.is_compiling() or torch.is_grad_enabled() and x.requires_grad:
+            return None
+        casts, fmt0 = [], None
+        for c in consumers:
+            nc = c._first_input_cast()
+            sq = getattr(c, "smoothquant", None)
+            if nc is None or (sq is not None and (sq._flag("enabled") or sq._flag("dynamic") or sq.calibrating)):
+                return None
+            fmt = nc.format
+            if (not isinstance(fmt, BlockFloatingPoint) or fmt.rounding != "nearest" or not fmt.symmetric or nc.pre_transform
+                    or nc.block_dim not in (-1, x.dim() - 1) or not nc._flag("fake_quant_enabled") or nc._flag("observer_enabled")):
+                return None
+            if fmt0 is not None and (fmt.precision != fmt0.precision or fmt.block_size != fmt0.block_size):
+                return None
+            fmt0 = fmt
+            casts.append(nc)
+        return tuple(casts), fmt0
+
     def _fused_forward(self, input, *args, **kwargs):
         """A module whose whole forward (input casts -> op -> output cast) exists as ONE kernel returns its result here, or None to
         take the general path.  Results must be bit-identical to the general path."""
@@ -453,7 +481,7 @@ class DmxModule(torch.nn.Module):
         if fused is not None:
             _input, args, kwargs = self.input_casts(fused, *args, first_done=True, **kwargs)
         elif (not torch.compiler.is_compiling() and getattr(input, "_dmx_precast", None) is not None
-              and input._dmx_precast is self._first_input_cast()):
+              and any(c is self._first_input_cast() for c in input._dmx_precast)):
             # the producer already applied THIS module's first input cast in its own launch (nn.link_consumer)
             _input, args, kwargs = self.input_casts(input, *args, first_done=True, **kwargs)
         else:
@@ -655,9 +683,9 @@ class Softmax(DmxModule, torch.nn.Softmax):
         from . import ops
         nc = self._linked_bfp_cast(x)
         if nc is not None:
-            out = ops.softmax_cast(x.detach(), -1, c[0], c[1], c[2].get("input_clamp"), then_bfp=(nc.format.precision, nc.format.block_size))
+            out = ops.softmax_cast(x.detach(), -1, c[0], c[1], c[2].get("input_clamp"), then_bfp=(nc[1].precision, nc[1].block_size))
             if out is not None:
-                out._dmx_precast = nc      # the consumer's forward recognises ITS cast object and skips it (DmxModule.forward)
+                out._dmx_precast = nc[0]   # a consumer's forward recognises ITS cast object among these and skips it (DmxModule.forward)
                 self.approximation_error = None
                 return out
         out = ops.softmax_cast(x.detach(), -1, c[0], c[1], c[2].get("input_clamp"))
@@ -665,22 +693,6 @@ class Softmax(DmxModule, torch.nn.Softmax):
             self.approximation_error = None
         return out
 
-    #: apply the linked consumer's BFP input cast in the softmax launch (dmxq_softmax_cast_bfp); see `link_consumer`
-    fuse_next_cast = True
-
-    def _linked_bfp_cast(self, x):
-        """the consumer's input cast when it can ride in this module's launch: a live link, inference, a plain BFP format (symmetric,
-        nearest) along the softmax dim, fake-quantising and not observing, no pre-transform"""
-        from .format import BlockFloatingPoint
-        consumer = self.__dict__.get("_next_consumer") if self.fuse_next_cast else None   # set by nn.link_consumer
-        nc = consumer._first_input_cast() if consumer is not None else None
-        if nc is None or torch.compiler.is_compiling() or torch.is_grad_enabled() and x.requires_grad:
-            return None
-        fmt = nc.format
-        if (not isinstance(fmt, BlockFloatingPoint) or fmt.rounding != "nearest" or not fmt.symmetric or nc.pre_transform
-                or nc.block_dim not in (-1, x.dim() - 1) or not nc._flag("fake_quant_enabled") or nc._flag("observer_enabled")):
-            return None
-        return nc
 
 
 class LayerNorm(DmxModule, torch.nn.LayerNorm):
@@ -701,6 +713,13 @@ class LayerNorm(DmxModule, torch.nn.LayerNorm):
         if w is False or b is False:
             return None
         from . import ops
+        nc = self._linked_bfp_cast(x) if len(self.normalized_shape) == 1 else None
+        if nc is not None:   # the consumers' BFP input cast in the same launch (nn.link_consumer)
+            out = ops.layernorm_cast(x.detach(), self.normalized_shape, w, b, self.eps, c[0], c[1], then_bfp=(nc[1].precision, nc[1].block_size))
+            if out is not None:
+                out._dmx_precast = nc[0]
+                self.approximation_error = None
+                return out
         out = ops.layernorm_cast(x.detach(), self.normalized_shape, w, b, self.eps, c[0], c[1])
         if out is not None:
             self.approximation_error = None
@@ -849,6 +868,13 @@ class RMSNorm(DmxModule, torch.nn.RMSNorm):
         if w is False:
             return None
         from . import ops
+        nc = self._linked_bfp_cast(x) if len(self.normalized_shape) == 1 else None
+        if nc is not None:   # the consumers' BFP input cast in the same launch (nn.link_consumer)
+            out = ops.rmsnorm_cast(x.detach(), self.normalized_shape, w, self.eps, c[0], c[1], then_bfp=(nc[1].precision, nc[1].block_size))
+            if out is not None:
+                out._dmx_precast = nc[0]
+                self.approximation_error = None
+                return out
         out = ops.rmsnorm_cast(x.detach(), self.normalized_shape, w, self.eps, c[0], c[1])
         if out is not None:
             self.approximation_error = None
@@ -1122,22 +1148,25 @@ class Embedding(DmxModule, torch.nn.Embedding):
         return self.output_casts(_output, output=True)
 
 
-def link_consumer(producer: "DmxModule", consumer: "DmxModule") -> None:
-    """Declare that `consumer` is the ONLY user of `producer`'s output and takes it as its first input (HF attention: the Softmax whose
-    probabilities go -- through an inactive dropout -- into the `attn_probs @ value` ActActMatMul).  The producer may then apply the
-    consumer's first input cast in its own launch (Softmax: dmxq_softmax_cast_bfp, one pass over the [heads, S, S] probabilities
-    instead of two) and the consumer skips it; the result is bit-identical.  The link is by object: reconfiguring either module's
-    formats is picked up at the next forward, and anything the fused kernel does not cover falls back to the two launches.  Do NOT
-    link when something else reads the producer's output (e.g. `output_attentions=True`): it would see the BFP-cast values.
-    `unlink`: link_consumer(producer, None)."""
-    if consumer is None:
-        producer.__dict__.pop("_next_consumer", None)
+def link_consumer(producer: "DmxModule", *consumers: "DmxModule") -> None:
+    """Declare that `consumers` are the ONLY users of `producer`'s output and take it as their first input: the Softmax whose
+    probabilities go -- through an inactive dropout -- into the `attn_probs @ value` ActActMatMul; the pre-attention norm whose result
+    feeds the q / k / v Linears (gate / up, fc1 after the pre-MLP norm).  The producer (Softmax, LayerNorm, RMSNorm) may then apply the
+    consumers' first input cast -- the same BFP format for all of them -- in its own launch (dmxq_softmax_cast_bfp,
+    dmxq_layernorm_cast_bfp, dmxq_rmsnorm_cast_bfp: one pass over the activation instead of 1 + len(consumers)) and the consumers skip
+    theirs; results are bit-identical.  The link is by object: reconfiguring a module's formats or switching on SmoothQuant is picked up at
+    the next forward, and whatever the fused kernels do not cover falls back to separate launches.  Do NOT link when anything else reads
+    the producer's output (`output_attentions=True`, a residual taken AFTER the norm): it would see the BFP-cast values.
+    Unlink: link_consumer(producer) or link_consumer(producer, None)."""
+    consumers = tuple(c for c in consumers if c is not None)
+    if not consumers:
+        producer.__dict__.pop("_next_consumers", None)
         return
-    if consumer._first_input_cast() is None:
-        raise ValueError("the consumer has no input cast to link")
-    # a plain attribute (not a registered submodule: no extra state_dict keys), held strongly so that copy.deepcopy / pickle of the
-    # model keep the pair together
-    producer.__dict__["_next_consumer"] = consumer
+    if any(c._first_input_cast() is None for c in consumers):
+        raise ValueError("a consumer has no input cast to link")
+    # a plain attribute (not registered submodules: no extra state_dict keys), held strongly so that copy.deepcopy / pickle of the model
+    # keep the modules together
+    producer.__dict__["_next_consumers"] = consumers
 
 
 # ---------------------------------------------------------------------------------------------------- rules

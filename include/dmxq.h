@@ -313,6 +313,14 @@ int dmxq_layernorm_cast(const void* in, void* out, int dtype, int64_t rows, int6
                         float eps, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* stream);
 int dmxq_rmsnorm_cast(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, float eps,
                       const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* stream);
+/* The norm modules followed by the (identical) BFP input casts of the modules that consume the result -- the q / k / v Linears after a
+ * pre-attention norm, gate / up (fc1) after a pre-MLP norm: `input_casts` of modeling/nn/core.py:228-264 -- in ONE launch, as
+ * dmxq_softmax_cast_bfp: out = BFP_QDQ(cast_out(norm(cast_in(x)))), bit-identical to the module's launch followed by dmxq_bfp_qdq. */
+int dmxq_layernorm_cast_bfp(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, const void* bias,
+                            float eps, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, int64_t block_size, int precision,
+                            void* stream);
+int dmxq_rmsnorm_cast_bfp(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, float eps,
+                          const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, int64_t block_size, int precision, void* stream);
 
 /* APPLY_LLAMA_ROPE: x_embed = (x * cos) + (rotate_half(x) * sin), evaluated in the tensor dtype like torch does (every
  * product and the sum rounded to the dtype: bit-identical to torch's CPU result).  Replaces: modeling/nn/custom_modules.py:

@@ -386,7 +386,7 @@ def test_linked_softmax_feeds_the_matmul_without_a_second_pass(dmx, cuda):
             want = pv(sm(s), v)
             nn.link_consumer(sm, pv)
             p = sm(s)
-            assert getattr(p, "_dmx_precast", None) is pv._first_input_cast()
+            assert getattr(p, "_dmx_precast", None) == (pv._first_input_cast(),)
             got = pv(p, v)
             assert torch.equal(got, want)
             pv.configure(dict(input_formats=["BFP[4|8]{32}(SN)", "BFP[8|8]{64}(SN)"]))       # picked up at the next forward
@@ -414,3 +414,62 @@ def _unlinked(sm, s):
         return sm(s)
     finally:
         sm.fuse_next_cast = True
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "f16", "f32"])
+def test_norm_cast_then_bfp_equals_the_two_launches(dmx, cuda, dtype):
+    """dmxq_layernorm_cast_bfp / dmxq_rmsnorm_cast_bfp == the module's launch followed by dmxq_bfp_qdq, bit for bit: rows on the wave kernel
+    (32 / 64 lanes per row, several rows per wave), on the workgroup kernel (4096, 8192), with a ragged last block, with and without
+    weight / bias."""
+    ops = dmx.ops
+    f16 = _fmt(dmx, "FLOAT16")
+    int_t = torch.int32 if dtype == torch.float32 else torch.int16
+    for rows, cols in ((50, 768), (7, 256), (33, 1024), (5, 4096), (3, 8192), (9, 1504), (4, 64), (2, 3072)):
+        x = (make("normal", (rows, cols), seed=rows + cols, dtype=torch.float32) * 2 + 0.3).to(dtype).to(cuda)
+        w = (torch.rand(cols, generator=torch.Generator().manual_seed(1)) + 0.5).to(dtype).to(cuda)
+        b = (torch.rand(cols, generator=torch.Generator().manual_seed(2)) - 0.5).to(dtype).to(cuda)
+        for B, wl in ((64, 8), (16, 8), (128, 6)):
+            for name, fused_fn, plain_fn in (
+                    ("layernorm", lambda t: ops.layernorm_cast(t, cols, w, b, 1e-5, f16, f16, then_bfp=(wl, B)), lambda t: ops.layernorm_cast(t, cols, w, b, 1e-5, f16, f16)),
+                    ("layernorm no affine", lambda t: ops.layernorm_cast(t, cols, None, None, 1e-5, None, f16, then_bfp=(wl, B)), lambda t: ops.layernorm_cast(t, cols, None, None, 1e-5, None, f16)),
+                    ("rmsnorm", lambda t: ops.rmsnorm_cast(t, cols, w, 1e-6, f16, f16, then_bfp=(wl, B)), lambda t: ops.rmsnorm_cast(t, cols, w, 1e-6, f16, f16))):
+                two = plain_fn(x)
+                fused = fused_fn(x)
+                if two is None or fused is None:
+                    assert fused is None
+                    continue
+                want = ops.bfp_qdq(two, wl, B)
+                bad = int((fused.view(int_t) != want.view(int_t)).sum())
+                assert bad == 0, f"{name} {dtype} [{rows}, {cols}] B={B} wl={wl}: {bad} elements differ"
+
+
+def test_linked_norm_feeds_several_linears_with_one_cast(dmx, cuda):
+    """nn.link_consumer(norm, q, k, v): the norm launch applies the three Linears' (identical) BFP input cast, each Linear skips its own;
+    outputs identical to the unlinked modules.  A consumer with SmoothQuant scaling switched on, or consumers whose formats differ, are
+    not fused (and still right)."""
+    nn = dmx.nn
+    torch.manual_seed(1)
+    for dtype, Norm in ((torch.bfloat16, lambda: nn.RMSNorm(512, eps=1e-5)), (torch.float32, lambda: nn.LayerNorm(512))):
+        norm = Norm().to(cuda).to(dtype).eval()
+        lins = [nn.Linear(512, 256).to(cuda).to(dtype).eval() for _ in range(3)]
+        dmx.configure_model(torch.nn.ModuleList([norm] + lins), *dmx.config_rules.BASIC)
+        x = torch.randn(4, 40, 512, device=cuda).to(dtype)
+        with torch.no_grad():
+            want = [l(norm(x)) for l in lins]
+            nn.link_consumer(norm, *lins)
+            h = norm(x)
+            assert getattr(h, "_dmx_precast", None) == tuple(l._first_input_cast() for l in lins)
+            got = [l(h) for l in lins]
+            assert all(torch.equal(a, b) for a, b in zip(got, want))
+            lins[1].configure(dict(input_formats=["BFP[8|8]{32}(SN)"]))          # formats differ now: no fused cast
+            h = norm(x)
+            assert getattr(h, "_dmx_precast", None) is None
+            lins[1].configure(dict(input_formats=["BFP[8|8]{64}(SN)"]))
+            lins[2].smoothquant.scale = (torch.rand(512, device=cuda) + 0.5)
+            lins[2].smoothquant.enable()                                          # x / s in front of that cast: no fused cast
+            h = norm(x)
+            assert getattr(h, "_dmx_precast", None) is None
+            lins[2].smoothquant.disable()
+            assert getattr(norm(x), "_dmx_precast", None) is not None
+            nn.link_consumer(norm)
+            assert getattr(norm(x), "_dmx_precast", None) is None

@@ -103,6 +103,9 @@ def build_layer(name, dev):
     # the probabilities have ONE consumer (no dropout in inference, attention weights not returned): the softmax launch may apply the
     # `p @ v` matmul's input cast too (nn.link_consumer; switched with the other fusions by set_fusions)
     nn.link_consumer(m.softmax, m.pv)
+    # ... and the pre-norms feed nothing but the projections (the residual branches off BEFORE the norm)
+    nn.link_consumer(m.norm1, m.q_proj, m.k_proj, m.v_proj)
+    nn.link_consumer(m.norm2, *((m.gate_proj, m.up_proj) if c["gated"] else (m.fc1,)))
     lin = [mod for mod in m.modules() if isinstance(mod, nn.Linear)]
     x = (torch.randn(c["B"], c["S"], H, device=dev) * 1.5).to(dt)
     extra = ()
