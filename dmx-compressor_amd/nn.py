@@ -29,7 +29,7 @@ __all__ = ["DmxModule", "DmxQuantizerCalibrationHyperparams", "DmxModuleQuantize
            "DmxModuleSmoothQuantHyperparams", "Linear", "Conv1d", "Conv2d", "ResAdd", "ActActMatMul", "Softmax", "LayerNorm", "GELU", "ReLU", "SiLU", "QuickGELU", "Exp", "Mul", "RMSNorm", "ApplyRotaryPosEmb",
            "MaxPool2d", "AvgPool2d", "Embedding", "ReLU6", "Tanh", "Dropout", "NewGELU", "FastGELU", "BloomGELU", "ClippedGELU", "AdaptiveAvgPool2d",
            "BatchNorm2d", "GroupNorm", "ConvTranspose2d", "BAddBMM", "ScaledDotProductAttention", "DmxConfigRule", "configure_model",
-           "fold_weights_and_biases", "GraphedForward", "link_consumer"]
+           "fold_weights_and_biases", "GraphedForward", "link_consumer", "link_consumers_from_fx", "DmxTracer"]
 
 
 class _LazySparsify(Sparsify):
@@ -1167,6 +1167,57 @@ def link_consumer(producer: "DmxModule", *consumers: "DmxModule") -> None:
     # a plain attribute (not registered submodules: no extra state_dict keys), held strongly so that copy.deepcopy / pickle of the model
     # keep the modules together
     producer.__dict__["_next_consumers"] = consumers
+
+
+def link_consumers_from_fx(gm) -> int:
+    """Set `link_consumer` for every producer of a traced model whose users allow it: `gm` is a torch.fx.GraphModule in which DmxModules
+    are leaf `call_module` nodes (what the reference's transform produces: modeling/model.py).  For each Softmax / LayerNorm / RMSNorm
+    node, follow its value through dropouts that are the identity in inference (p == 0 or eval mode, SAME casts); if EVERY remaining
+    user is a `call_module` of a DmxModule that takes the value as its FIRST positional argument (and the value is not a graph output),
+    link the producer to those modules.  Returns the number of producers linked.  (`DmxTracer` below traces a plain nn.Module that way.)"""
+    import torch.fx as fx
+    mods = dict(gm.named_modules())
+    linked = 0
+
+    def is_identity_dropout(n):
+        m = mods.get(n.target) if n.op == "call_module" else None
+        return isinstance(m, Dropout) and (not m.training or m.p == 0.0) and _all_same_casts(m)
+
+    for node in gm.graph.nodes:
+        prod = mods.get(node.target) if node.op == "call_module" else None
+        if not isinstance(prod, (Softmax, LayerNorm, RMSNorm)):
+            continue
+        frontier, consumers, ok = [node], [], True
+        while frontier and ok:
+            n = frontier.pop()
+            for u in n.users:
+                if u.op == "output":
+                    ok = False
+                elif is_identity_dropout(u) and u.args and u.args[0] is n:
+                    frontier.append(u)
+                else:
+                    m = mods.get(u.target) if u.op == "call_module" else None
+                    if isinstance(m, DmxModule) and u.args and u.args[0] is n and sum(1 for a in list(u.args) + list(u.kwargs.values()) if a is n) == 1:
+                        consumers.append(m)
+                    else:
+                        ok = False
+        if ok and consumers:
+            link_consumer(prod, *dict.fromkeys(consumers))
+            linked += 1
+        else:
+            link_consumer(prod)
+    return linked
+
+
+def DmxTracer():
+    """a torch.fx.Tracer that keeps every DmxModule a leaf (the granularity of the reference's transformed graphs)"""
+    import torch.fx as fx
+
+    class _T(fx.Tracer):
+        def is_leaf_module(self, m, qualname):
+            return isinstance(m, DmxModule) or super().is_leaf_module(m, qualname)
+
+    return _T()
 
 
 # ---------------------------------------------------------------------------------------------------- rules

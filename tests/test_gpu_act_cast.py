@@ -473,3 +473,44 @@ def test_linked_norm_feeds_several_linears_with_one_cast(dmx, cuda):
             assert getattr(norm(x), "_dmx_precast", None) is not None
             nn.link_consumer(norm)
             assert getattr(norm(x), "_dmx_precast", None) is None
+
+
+def test_links_derived_from_an_fx_graph(dmx, cuda):
+    """nn.link_consumers_from_fx on a traced pre-norm attention block: norm -> q / k / v (one cast), softmax -> dropout (identity) ->
+    `p @ v`; a softmax whose probabilities are ALSO returned is left alone; results equal the unlinked model."""
+    import torch.fx as fx
+    nn = dmx.nn
+
+    class Block(torch.nn.Module):
+        def __init__(self, return_probs):
+            super().__init__()
+            self.norm = nn.LayerNorm(256)
+            self.q, self.k, self.v, self.o = (nn.Linear(256, 256) for _ in range(4))
+            self.qk, self.pv, self.softmax, self.drop, self.res = nn.ActActMatMul(), nn.ActActMatMul(), nn.Softmax(dim=-1), nn.Dropout(0.1), nn.ResAdd()
+            self.return_probs = return_probs
+
+        def forward(self, x):
+            h = self.norm(x)
+            q, k, v = self.q(h), self.k(h), self.v(h)
+            p = self.drop(self.softmax(self.qk(q, k.transpose(-1, -2))))
+            y = self.res(self.o(self.pv(p, v)), x)
+            return (y, p) if self.return_probs else y
+
+    torch.manual_seed(3)
+    x = torch.randn(2, 64, 256, device=cuda)
+    for return_probs in (False, True):
+        m = Block(return_probs).to(cuda).eval()
+        dmx.configure_model(m, *dmx.config_rules.BASIC)
+        with torch.no_grad():
+            want = m(x)
+        gm = fx.GraphModule(m, nn.DmxTracer().trace(m))
+        n = nn.link_consumers_from_fx(gm)
+        assert n == (1 if return_probs else 2)
+        assert m.norm.__dict__["_next_consumers"] == (m.q, m.k, m.v)
+        assert ("_next_consumers" in m.softmax.__dict__) == (not return_probs)
+        with torch.no_grad():
+            got = gm(x)
+        if return_probs:
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        else:
+            assert torch.equal(got, want)
