@@ -383,6 +383,33 @@ class DmxModule(torch.nn.Module):
     #: dmxq_rmsnorm_cast_bfp); see `link_consumer`
     fuse_next_cast = True
 
+    def _output_cast_absorbed(self, y) -> bool:
+        """True when this module's (single) output cast may be skipped because every linked consumer (nn.link_consumer) applies the same
+        nearest-rounding FloatingPoint format to the value as its first input cast: F(F(y)) == F(y) for such a cast (round to a grid,
+        saturate, flush -- also through CastTo's `.to(dtype)` after each), so the consumer's result is unchanged.  Not while either cast
+        observes (calibration must see the data it would see), has a pre-transform, or is switched off."""
+        from .format import FloatingPoint
+        consumers = self.__dict__.get("_next_consumers") if self.fuse_next_cast else None
+        if not consumers or not isinstance(y, torch.Tensor) or len(self.output_casts) != 1 or torch.compiler.is_compiling() \
+                or torch.is_grad_enabled() and y.requires_grad:
+            return False
+        oc = self.output_casts[next(iter(self.output_casts.keys()))]
+        f = oc.format
+        if (not isinstance(f, FloatingPoint) or f.rounding != "nearest" or f.unsigned or oc.pre_transform
+                or not oc._flag("fake_quant_enabled") or oc._flag("observer_enabled")):
+            return False
+        for c in consumers:
+            nc = c._first_input_cast()
+            sq = getattr(c, "smoothquant", None)
+            if nc is None or (sq is not None and (sq._flag("enabled") or sq._flag("dynamic") or sq.calibrating)):
+                return False
+            g = nc.format
+            if (not isinstance(g, FloatingPoint) or g.rounding != "nearest" or g.unsigned or nc.pre_transform
+                    or not nc._flag("fake_quant_enabled") or nc._flag("observer_enabled")
+                    or (g.mantissa, g.exponent, g.bias, bool(g.flush_subnormal)) != (f.mantissa, f.exponent, f.bias, bool(f.flush_subnormal))):
+                return False
+        return True
+
     def _linked_bfp_cast(self, x):
         """the consumers' (common) first input cast when it can ride in this module's launch: a live link (nn.link_consumer), inference,
         every consumer with the SAME plain BFP format (symmetric, nearest, along this module's last dim), fake-quantising and not
@@ -487,7 +514,9 @@ class DmxModule(torch.nn.Module):
         else:
             _input, args, kwargs = self.input_casts(input, *args, **kwargs)
         _output = self._forward(_input, *args, **kwargs)
-        output = self.output_casts(_output, output=True)
+        # (a GEMM-bearing module's output cast is a launch of its own; when the linked consumer applies the SAME cast to this value as
+        #  its first input cast -- inside its fused kernel -- the cast here is redundant: FloatingPoint casts are projections)
+        output = _output if self._output_cast_absorbed(_output) else self.output_casts(_output, output=True)
         if self.align_boundary_dtype:
             output = (type(output)(a.to(_dtype) for a in output) if isinstance(output, (tuple, list)) else output.to(_dtype))
         # module boundary: the reference's SAME casts clone, so its result never aliases an input (a caller may run
@@ -1154,7 +1183,9 @@ def link_consumer(producer: "DmxModule", *consumers: "DmxModule") -> None:
     feeds the q / k / v Linears (gate / up, fc1 after the pre-MLP norm).  The producer (Softmax, LayerNorm, RMSNorm) may then apply the
     consumers' first input cast -- the same BFP format for all of them -- in its own launch (dmxq_softmax_cast_bfp,
     dmxq_layernorm_cast_bfp, dmxq_rmsnorm_cast_bfp: one pass over the activation instead of 1 + len(consumers)) and the consumers skip
-    theirs; results are bit-identical.  The link is by object: reconfiguring a module's formats or switching on SmoothQuant is picked up at
+    theirs; results are bit-identical.  A GEMM-bearing producer (Linear, ActActMatMul, Conv) uses the link the other way round: its
+    output cast -- a launch of its own -- is skipped when the consumer applies the same FloatingPoint cast to the value as its first
+    input cast (`_output_cast_absorbed`: o_proj -> ResAdd, fc1 -> GELU, `q @ k^T` -> Softmax).  The link is by object: reconfiguring a module's formats or switching on SmoothQuant is picked up at
     the next forward, and whatever the fused kernels do not cover falls back to separate launches.  Do NOT link when anything else reads
     the producer's output (`output_attentions=True`, a residual taken AFTER the norm): it would see the BFP-cast values.
     Unlink: link_consumer(producer) or link_consumer(producer, None)."""
@@ -1171,8 +1202,8 @@ def link_consumer(producer: "DmxModule", *consumers: "DmxModule") -> None:
 
 def link_consumers_from_fx(gm) -> int:
     """Set `link_consumer` for every producer of a traced model whose users allow it: `gm` is a torch.fx.GraphModule in which DmxModules
-    are leaf `call_module` nodes (what the reference's transform produces: modeling/model.py).  For each Softmax / LayerNorm / RMSNorm
-    node, follow its value through dropouts that are the identity in inference (p == 0 or eval mode, SAME casts); if EVERY remaining
+    are leaf `call_module` nodes (what the reference's transform produces: modeling/model.py).  For each DmxModule node, follow its
+    value through dropouts that are the identity in inference (p == 0 or eval mode, SAME casts); if EVERY remaining
     user is a `call_module` of a DmxModule that takes the value as its FIRST positional argument (and the value is not a graph output),
     link the producer to those modules.  Returns the number of producers linked.  (`DmxTracer` below traces a plain nn.Module that way.)"""
     import torch.fx as fx
@@ -1185,7 +1216,7 @@ def link_consumers_from_fx(gm) -> int:
 
     for node in gm.graph.nodes:
         prod = mods.get(node.target) if node.op == "call_module" else None
-        if not isinstance(prod, (Softmax, LayerNorm, RMSNorm)):
+        if not isinstance(prod, DmxModule) or isinstance(prod, Dropout):
             continue
         frontier, consumers, ok = [node], [], True
         while frontier and ok:

@@ -504,13 +504,41 @@ def test_links_derived_from_an_fx_graph(dmx, cuda):
         with torch.no_grad():
             want = m(x)
         gm = fx.GraphModule(m, nn.DmxTracer().trace(m))
-        n = nn.link_consumers_from_fx(gm)
-        assert n == (1 if return_probs else 2)
+        nn.link_consumers_from_fx(gm)
         assert m.norm.__dict__["_next_consumers"] == (m.q, m.k, m.v)
         assert ("_next_consumers" in m.softmax.__dict__) == (not return_probs)
+        assert m.qk.__dict__["_next_consumers"] == (m.softmax,) and m.o.__dict__["_next_consumers"] == (m.res,)
+        assert "_next_consumers" not in m.v.__dict__ and "_next_consumers" not in m.k.__dict__   # second operand / through a transpose
+        assert m.qk._output_cast_absorbed(torch.empty(1, device=cuda)) and not m.q._output_cast_absorbed(torch.empty(1, device=cuda))
         with torch.no_grad():
             got = gm(x)
         if return_probs:
             assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
         else:
             assert torch.equal(got, want)
+
+
+def test_output_cast_absorbed_by_the_consumers_identical_input_cast(dmx, cuda):
+    """A Linear / ActActMatMul whose FLOAT16 output cast is followed by the linked consumer's FLOAT16 input cast skips its own launch:
+    same results (the cast is a projection), also for bf16 tensors (where `.to(bfloat16)` follows each cast) and saturating values;
+    not while the output cast observes, not when the formats differ."""
+    nn = dmx.nn
+    torch.manual_seed(5)
+    for dtype in (torch.float32, torch.bfloat16):
+        lin, act, mm, sm = nn.Linear(128, 256).to(cuda).to(dtype).eval(), nn.GELU().to(cuda).eval(), nn.ActActMatMul().to(cuda).eval(), nn.Softmax(dim=-1).to(cuda).eval()
+        dmx.configure_model(torch.nn.ModuleList([lin, act, mm, sm]), *dmx.config_rules.BASIC)
+        x = (torch.randn(3, 50, 128, device=cuda) * 40).to(dtype)
+        x[0, 0, :4] = torch.tensor([3e5, -3e5, 1e-6, -1e-7], device=cuda).to(dtype)      # beyond FLOAT16's range / below its flush threshold
+        lin.weight.data[:4, :4] = torch.eye(4, device=cuda).to(dtype) * 8
+        q, k = torch.randn(2, 4, 32, 64, device=cuda).to(dtype) * 30, torch.randn(2, 4, 64, 48, device=cuda).to(dtype) * 30
+        with torch.no_grad():
+            want_a, want_s = act(lin(x)), sm(mm(q, k))
+            nn.link_consumer(lin, act)
+            nn.link_consumer(mm, sm)
+            assert lin._output_cast_absorbed(x) and mm._output_cast_absorbed(x)
+            assert torch.equal(act(lin(x)), want_a) and torch.equal(sm(mm(q, k)), want_s)
+            act.configure(dict(input_formats=["FP[1|5|10,15](_N)"]))                       # no flush: a different cast
+            assert not lin._output_cast_absorbed(x) and torch.equal(act(lin(x)), act(_unlinked(lin, x)))
+            act.configure(dict(input_formats=["FP[1|5|10,15](FN)"]))
+            lin.output_casts[next(iter(lin.output_casts.keys()))]._set_flag("observer_enabled", True)
+            assert not lin._output_cast_absorbed(x)

@@ -106,6 +106,15 @@ def build_layer(name, dev):
     # ... and the pre-norms feed nothing but the projections (the residual branches off BEFORE the norm)
     nn.link_consumer(m.norm1, m.q_proj, m.k_proj, m.v_proj)
     nn.link_consumer(m.norm2, *((m.gate_proj, m.up_proj) if c["gated"] else (m.fc1,)))
+    # GEMM-bearing modules whose result has one consumer that takes it first: their FLOAT16 output cast is the consumer's input cast
+    nn.link_consumer(m.qk, m.softmax)
+    nn.link_consumer(m.o_proj, m.res1)
+    if c["gated"]:
+        nn.link_consumer(m.gate_proj, m.act)
+        nn.link_consumer(m.down_proj, m.res2)
+    else:
+        nn.link_consumer(m.fc1, m.act)
+        nn.link_consumer(m.fc2, m.res2)
     lin = [mod for mod in m.modules() if isinstance(mod, nn.Linear)]
     x = (torch.randn(c["B"], c["S"], H, device=dev) * 1.5).to(dt)
     extra = ()
