@@ -379,6 +379,11 @@ class DmxModule(torch.nn.Module):
         ic = self.input_casts
         return ic[next(iter(ic.keys()))] if len(ic) else None
 
+    def _input_cast_at(self, idx: int):
+        """the cast CastToDict.forward applies to the idx-th positional tensor argument"""
+        keys = list(self.input_casts.keys())
+        return self.input_casts[keys[idx]] if 0 <= idx < len(keys) else None
+
     #: apply the linked consumers' BFP input cast in this module's launch (dmxq_softmax_cast_bfp, dmxq_layernorm_cast_bfp,
     #: dmxq_rmsnorm_cast_bfp); see `link_consumer`
     fuse_next_cast = True
@@ -398,9 +403,9 @@ class DmxModule(torch.nn.Module):
         if (not isinstance(f, FloatingPoint) or f.rounding != "nearest" or f.unsigned or oc.pre_transform
                 or not oc._flag("fake_quant_enabled") or oc._flag("observer_enabled")):
             return False
-        for c in consumers:
-            nc = c._first_input_cast()
-            sq = getattr(c, "smoothquant", None)
+        for c, idx in consumers:
+            nc = c._input_cast_at(idx)
+            sq = getattr(c, "smoothquant", None) if idx == 0 else None
             if nc is None or (sq is not None and (sq._flag("enabled") or sq._flag("dynamic") or sq.calibrating)):
                 return False
             g = nc.format
@@ -419,7 +424,9 @@ class DmxModule(torch.nn.Module):
         if not consumers or torch.compiler.is_compiling() or torch.is_grad_enabled() and x.requires_grad:
             return None
         casts, fmt0 = [], None
-        for c in consumers:
+        for c, idx in consumers:
+            if idx != 0:   # (the consumer-side skip exists for the first input only)
+                return None
             nc = c._first_input_cast()
             sq = getattr(c, "smoothquant", None)
             if nc is None or (sq is not None and (sq._flag("enabled") or sq._flag("dynamic") or sq.calibrating)):
@@ -1188,13 +1195,14 @@ def link_consumer(producer: "DmxModule", *consumers: "DmxModule") -> None:
     input cast (`_output_cast_absorbed`: o_proj -> ResAdd, fc1 -> GELU, `q @ k^T` -> Softmax).  The link is by object: reconfiguring a module's formats or switching on SmoothQuant is picked up at
     the next forward, and whatever the fused kernels do not cover falls back to separate launches.  Do NOT link when anything else reads
     the producer's output (`output_attentions=True`, a residual taken AFTER the norm): it would see the BFP-cast values.
-    Unlink: link_consumer(producer) or link_consumer(producer, None)."""
-    consumers = tuple(c for c in consumers if c is not None)
+    A consumer that takes the value as its k-th positional tensor (the `up` projection into `Mul(act(gate), up)`) is given as
+    `(module, k)`: only the redundant-output-cast form applies there.  Unlink: link_consumer(producer) or link_consumer(producer, None)."""
+    consumers = tuple((c if isinstance(c, tuple) else (c, 0)) for c in consumers if c is not None)
     if not consumers:
         producer.__dict__.pop("_next_consumers", None)
         return
-    if any(c._first_input_cast() is None for c in consumers):
-        raise ValueError("a consumer has no input cast to link")
+    if any(c._input_cast_at(i) is None for c, i in consumers):
+        raise ValueError("a consumer has no input cast at that position to link")
     # a plain attribute (not registered submodules: no extra state_dict keys), held strongly so that copy.deepcopy / pickle of the model
     # keep the modules together
     producer.__dict__["_next_consumers"] = consumers
@@ -1228,8 +1236,10 @@ def link_consumers_from_fx(gm) -> int:
                     frontier.append(u)
                 else:
                     m = mods.get(u.target) if u.op == "call_module" else None
-                    if isinstance(m, DmxModule) and u.args and u.args[0] is n and sum(1 for a in list(u.args) + list(u.kwargs.values()) if a is n) == 1:
-                        consumers.append(m)
+                    pos = [i for i, a in enumerate(u.args) if a is n]
+                    if (isinstance(m, DmxModule) and len(pos) == 1 and not any(a is n for a in u.kwargs.values())
+                            and all(isinstance(a, fx.Node) for a in u.args[:pos[0]])):   # (earlier args are tensors: the index counts tensors)
+                        consumers.append((m, pos[0]))
                     else:
                         ok = False
         if ok and consumers:

@@ -505,10 +505,10 @@ def test_links_derived_from_an_fx_graph(dmx, cuda):
             want = m(x)
         gm = fx.GraphModule(m, nn.DmxTracer().trace(m))
         nn.link_consumers_from_fx(gm)
-        assert m.norm.__dict__["_next_consumers"] == (m.q, m.k, m.v)
+        assert m.norm.__dict__["_next_consumers"] == ((m.q, 0), (m.k, 0), (m.v, 0))
         assert ("_next_consumers" in m.softmax.__dict__) == (not return_probs)
-        assert m.qk.__dict__["_next_consumers"] == (m.softmax,) and m.o.__dict__["_next_consumers"] == (m.res,)
-        assert "_next_consumers" not in m.v.__dict__ and "_next_consumers" not in m.k.__dict__   # second operand / through a transpose
+        assert m.qk.__dict__["_next_consumers"] == ((m.softmax, 0),) and m.o.__dict__["_next_consumers"] == ((m.res, 0),)
+        assert m.v.__dict__["_next_consumers"] == ((m.pv, 1),) and "_next_consumers" not in m.k.__dict__   # second operand; through a transpose
         assert m.qk._output_cast_absorbed(torch.empty(1, device=cuda)) and not m.q._output_cast_absorbed(torch.empty(1, device=cuda))
         with torch.no_grad():
             got = gm(x)

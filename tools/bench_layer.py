@@ -111,6 +111,7 @@ def build_layer(name, dev):
     nn.link_consumer(m.o_proj, m.res1)
     if c["gated"]:
         nn.link_consumer(m.gate_proj, m.act)
+        nn.link_consumer(m.up_proj, (m.mul, 1))
         nn.link_consumer(m.down_proj, m.res2)
     else:
         nn.link_consumer(m.fc1, m.act)
