@@ -63,6 +63,11 @@ class CastTo(HostFlags, torch.nn.Module):
     #: caller may mutate the result in place.  DmxModule switches this off on the casts it owns (their results are
     #: consumed inside the module) and re-establishes the no-alias guarantee once, at the module boundary (nn.py).
     copy_on_same = True
+    #: cast a transposed / permuted view IN ITS OWN LAYOUT: the kernels take contiguous tensors, so a dense permuted view is cast through
+    #: the permutation that makes it contiguous (the block dimension follows it) and the result is handed back with the input's strides,
+    #: instead of being copied to a contiguous tensor first.  Same values; set by modules whose `_forward` takes any strides
+    #: (ActActMatMul: q / k^T / v of an attention arrive as transposed views -- k^T blocked along -2 is k blocked along its LAST dim).
+    keep_layout = False
 
     def __init__(self, format="SAME", observer=DummyObserver, group_size=None, block_dim=-1,
                  qscheme=torch.per_tensor_affine, ch_axis=-1, **observer_kwargs):
@@ -206,6 +211,15 @@ class CastTo(HostFlags, torch.nn.Module):
                                  zero_point=self.zero_point, ch_axis=ch_axis, group_size=gs, out_dtype=out_dtype)
         if ste:
             return CastToFormat.apply(x, fmt, self.block_dim, out_dtype)
+        if self.keep_layout and x.dim() > 1 and not x.is_contiguous() and not torch.compiler.is_compiling():
+            order = sorted(range(x.dim()), key=lambda d: (-x.stride(d), d))
+            xp = x.permute(order)
+            if xp.is_contiguous():
+                y = fmt.cast(xp, order.index(self.block_dim % x.dim()), out_dtype=out_dtype)
+                inv = [0] * len(order)
+                for i, d in enumerate(order):
+                    inv[d] = i
+                return y.permute(inv)
         return fmt.cast(x, self.block_dim, out_dtype=out_dtype)
 
     def forward(self, x):

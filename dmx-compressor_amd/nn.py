@@ -692,6 +692,8 @@ class ActActMatMul(DmxModule):
         self._dmx_init(input_names=("input_cast", "multiplier_cast"))
         self.input_casts.input_cast.block_dim = -1      # torch_modules.py:197-204
         self.input_casts.multiplier_cast.block_dim = -2
+        for c in self.input_casts.values():             # torch.matmul takes any strides: no contiguous copy of q / k^T / v views
+            c.keep_layout = True
 
     def _forward(self, _input, multiplier):
         return torch.matmul(_input, multiplier)

@@ -358,3 +358,30 @@ def test_smoothquant_calibration_and_dynamic_forwards_do_not_synchronise(dmx, cu
     m.smoothquant.migration_strength.fill_(0.3)
     m.smoothquant.refresh_flags()
     assert m.smoothquant._scalar("migration_strength") == float(torch.tensor(0.3, dtype=torch.float32))
+
+
+def test_keep_layout_casts_a_permuted_view_without_a_copy(dmx, cuda):
+    """CastTo.keep_layout (set on ActActMatMul's input casts): a dense transposed / permuted view is cast through the permutation that makes
+    it contiguous, the block dimension following it -- same values as casting a contiguous copy, the input's strides on the result; views
+    that are not dense permutations (slices) take the copying path."""
+    torch.manual_seed(2)
+    base = torch.randn(2, 96, 4, 64, device=cuda)
+    views = {"[B,S,H,D] -> [B,H,S,D]": base.transpose(1, 2), "... -> k^T [B,H,D,S]": base.transpose(1, 2).transpose(-1, -2),
+             "permute(3,0,2,1)": base.permute(3, 0, 2, 1), "sliced (not dense)": base.transpose(1, 2)[:, :, ::2]}
+    for fmt in ("BFP[8|8]{64}(SN)", "BFP[8|8]{16}(_N)", "FP[1|5|10,15](FN)"):
+        for bd in (-1, -2):
+            c = dmx.CastTo(format=fmt, block_dim=bd).to(cuda)
+            for name, v in views.items():
+                for dtype in (torch.float32, torch.bfloat16):
+                    x = v.to(dtype) if dtype != torch.float32 else v
+                    if dtype != torch.float32 and "sliced" not in name:   # `.to` of a dense view keeps its strides
+                        assert x.stride() == v.stride()
+                    c.keep_layout = False
+                    want = c(x)
+                    c.keep_layout = True
+                    got = c(x)
+                    assert torch.equal(got, want), (fmt, bd, name, dtype)
+                    if "sliced" not in name and not x.is_contiguous():
+                        assert got.stride() == x.stride(), (name, got.stride(), x.stride())
+    mm = dmx.nn.ActActMatMul().to(cuda).eval()
+    assert all(c.keep_layout for c in mm.input_casts.values())
