@@ -1197,6 +1197,8 @@ def link_consumer(producer: "DmxModule", *consumers: "DmxModule") -> None:
     input cast (`_output_cast_absorbed`: o_proj -> ResAdd, fc1 -> GELU, `q @ k^T` -> Softmax).  The link is by object: reconfiguring a module's formats or switching on SmoothQuant is picked up at
     the next forward, and whatever the fused kernels do not cover falls back to separate launches.  Do NOT link when anything else reads
     the producer's output (`output_attentions=True`, a residual taken AFTER the norm): it would see the BFP-cast values.
+    REPLACING a linked module in the model (or rerouting the value) invalidates the declaration: link again (or run
+    `link_consumers_from_fx` again) after structural changes.
     A consumer that takes the value as its k-th positional tensor (the `up` projection into `Mul(act(gate), up)`) is given as
     `(module, k)`: only the redundant-output-cast form applies there.  Unlink: link_consumer(producer) or link_consumer(producer, None)."""
     consumers = tuple((c if isinstance(c, tuple) else (c, 0)) for c in consumers if c is not None)
