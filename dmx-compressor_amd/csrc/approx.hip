@@ -835,7 +835,8 @@ static inline unsigned one_pass_grid(int64_t wanted) { return (unsigned)(wanted 
 
 static inline int row_grid(int64_t rows) { return (int)(rows < 256 * 16 ? (rows < 1 ? 1 : rows) : 256 * 16); }
 
-// This file is compiled TWICE (build.py: -DDMXQ_EW_PART=1 / 2): softmax and the norms are ~150 kernel instantiations each.
+// This file is compiled FIVE times (build.py: -DDMXQ_EW_PART=1 .. 5): softmax, and the four (RMS, CAST) forms of the norms, ~70-150 kernel
+// instantiations each.
 #ifndef DMXQ_EW_PART
 #define DMXQ_EW_PART 0
 #endif
@@ -976,7 +977,7 @@ extern "C" int dmxq_softmax_cast_bfp(const void* in, void* out, int dtype, int64
 
 #endif  // part 1
 
-#if DMXQ_AP(2)
+#if DMXQ_AP(2) || DMXQ_AP(3) || DMXQ_AP(4) || DMXQ_AP(5)
 template <bool RMS, bool CAST = false>
 static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
                          const void* weight, const void* bias, int dtype_wb, float eps, void* stream, const RowCastArg<CAST>& rc = {}) {
@@ -1090,12 +1091,17 @@ static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out,
                        dtype_in, dtype_out, rows, cols, weight, bias, dtype_wb, eps);
   return launch_status();
 }
+#endif
 
+// (one object per (RMS, CAST) instantiation of norm_dispatch -- ~70-140 kernels each: build.py compiles parts 2-5 in parallel)
+#if DMXQ_AP(2)
 extern "C" int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype_out, int64_t rows, int64_t cols,
                               const void* weight, const void* bias, int dtype_wb, float eps, void* stream) {
   return norm_dispatch<false>(in, out, dtype_in, dtype_out, rows, cols, weight, bias, dtype_wb, eps, stream);
 }
 
+#endif
+#if DMXQ_AP(4)
 // RMSNorm (torch_modules.py:1144-1170 -> F.rms_norm): the same register-resident row kernels without the centring pass:
 // y = x * rsqrt(mean(x^2) + eps) * weight, fp32, one rounding.  (1 / sqrtf(.) here vs torch's rsqrt: both correctly
 // rounded to within an ulp of fp32, far inside the tolerance the tests state for 16-bit outputs.)
@@ -1104,7 +1110,9 @@ extern "C" int dmxq_rmsnorm(const void* in, void* out, int dtype_in, int dtype_o
   return norm_dispatch<true>(in, out, dtype_in, dtype_out, rows, cols, weight, nullptr, dtype_w, eps, stream);
 }
 
+#endif
 // A LayerNorm / RMSNorm DmxModule in one pass: out = cast_out(norm(cast_in(x); weight, bias)), weight / bias in the row dtype.
+#if DMXQ_AP(3)
 extern "C" int dmxq_layernorm_cast(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, const void* bias,
                                    float eps, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* stream) {
   RowCast rc;
@@ -1112,6 +1120,8 @@ extern "C" int dmxq_layernorm_cast(const void* in, void* out, int dtype, int64_t
   if (!rowcast_of(dtype, cast_in, cast_out, &rc)) return DMXQ_ERR_UNSUPPORTED;
   return norm_dispatch<false, true>(in, out, dtype, dtype, rows, cols, weight, bias, dtype, eps, stream, rc);
 }
+#endif
+#if DMXQ_AP(5)
 extern "C" int dmxq_rmsnorm_cast(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, float eps,
                                  const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* stream) {
   RowCast rc;
@@ -1119,9 +1129,11 @@ extern "C" int dmxq_rmsnorm_cast(const void* in, void* out, int dtype, int64_t r
   if (!rowcast_of(dtype, cast_in, cast_out, &rc)) return DMXQ_ERR_UNSUPPORTED;
   return norm_dispatch<true, true>(in, out, dtype, dtype, rows, cols, weight, nullptr, dtype, eps, stream, rc);
 }
+#endif
 // ... and with the BFP input cast of the modules that consume the result (the q / k / v or gate / up Linears after a pre-attention /
 // pre-MLP norm: identical `input_casts` formats, modeling/nn/core.py:228-264) applied in the same launch; bit-identical to
 // dmxq_layernorm_cast / dmxq_rmsnorm_cast followed by dmxq_bfp_qdq(.., block_size, precision, nearest, symmetric).
+#if DMXQ_AP(3)
 extern "C" int dmxq_layernorm_cast_bfp(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, const void* bias,
                                        float eps, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, int64_t block_size,
                                        int precision, void* stream) {
@@ -1133,6 +1145,8 @@ extern "C" int dmxq_layernorm_cast_bfp(const void* in, void* out, int dtype, int
   rc.bfp_wl = precision;
   return norm_dispatch<false, true>(in, out, dtype, dtype, rows, cols, weight, bias, dtype, eps, stream, rc);
 }
+#endif
+#if DMXQ_AP(5)
 extern "C" int dmxq_rmsnorm_cast_bfp(const void* in, void* out, int dtype, int64_t rows, int64_t cols, const void* weight, float eps,
                                      const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, int64_t block_size, int precision,
                                      void* stream) {
@@ -1144,4 +1158,4 @@ extern "C" int dmxq_rmsnorm_cast_bfp(const void* in, void* out, int dtype, int64
   rc.bfp_wl = precision;
   return norm_dispatch<true, true>(in, out, dtype, dtype, rows, cols, weight, nullptr, dtype, eps, stream, rc);
 }
-#endif  // part 2 (norms)
+#endif  // parts 2-5 (norms)
