@@ -52,7 +52,7 @@ __device__ __forceinline__ void pack_codes_literal(const float (&x)[EPL], uint32
 // rows of whole power-of-two blocks: a workgroup takes a contiguous tile of kPackThreads x kPackUnroll 16-byte vectors, all of a
 // lane's loads in flight before the first block maximum; the magic-add codes for every lane as straight-line code, the blocks
 // that form does not cover redone behind one cold branch (the structure of bfp_rows.hpp)
-constexpr int kPackThreads = 256, kPackUnroll = 8;
+constexpr int kPackThreads = 256, kPackUnroll = 4;  // (round 3, 4096 x 4096 bf16: 256 x 2 and 256 x 4 12.0 us, 256 x 8 12.8, 256 x 16 and 128 x 16 14.5)
 template <int DTI>
 __global__ __launch_bounds__(kPackThreads) void bfp_pack_rows_kernel(const void* __restrict__ in, int8_t* __restrict__ mant,
                                                                     uint8_t* __restrict__ exps, int64_t n_vec, int lpb_arg,
@@ -148,23 +148,28 @@ __global__ __launch_bounds__(kThreads) void bfp_unpack_kernel(const int8_t* __re
 // into 8 outputs (one or two 16-byte stores); the block index is a shift of the flat element index.
 // value = (code * 2^-(p-2)) * 2^(E-127): the first product is exact, the second rounds once (only a denormal result
 // rounds at all) -- the same value as the scalar kernel's ldexpf -- and cannot overflow.
+constexpr int kUnpackUnroll = 8;
 template <int DTO>
 __global__ __launch_bounds__(kThreads) void bfp_unpack_vec_kernel(const int8_t* __restrict__ mant,
                                                                  const uint8_t* __restrict__ exps, void* __restrict__ out,
                                                                  int64_t n_vec, int b_shift /*log2(B / 8)*/, int wl) {
   const float down = u2f((uint32_t)(127 - (wl - 2)) << 23);
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t v0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; v0 < n_vec; v0 += 4 * stride) {
-    u32x2 m[4];
-    uint32_t eb[4];
+  // workgroup-contiguous tiles of kThreads x kUnpackUnroll code vectors, one pass per workgroup, all loads first (round 3: the
+  // grid-strided 4-in-flight form measured 11.0 us on 4096 x 4096, 58 %)
+  constexpr int U = kUnpackUnroll;
+  const int64_t stride = kThreads;
+  {
+    const int64_t v0 = (int64_t)blockIdx.x * (kThreads * U) + threadIdx.x;
+    u32x2 m[U];
+    uint32_t eb[U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {
       const int64_t v = v0 + u * stride < n_vec ? v0 + u * stride : n_vec - 1;  // clamped: unconditional loads
       m[u] = __builtin_nontemporal_load((const u32x2*)(mant + v * 8));
       eb[u] = exps[v >> b_shift];
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {
       const int64_t v = v0 + u * stride;
       if (v < n_vec) {
         const float up = eb[u] == 255u ? u2f(0x7FC00000u) : u2f(eb[u] << 23);
@@ -227,7 +232,9 @@ extern "C" int dmxq_bfp_unpack(const int8_t* mant, const uint8_t* exps, void* ou
     const int64_t n_vec = rows * L / 8;
     int b_shift = 0;
     while (((int64_t)8 << b_shift) < B) b_shift++;
-    const int grid = grid_for((n_vec + 3) / 4);
+    const int64_t tiles = (n_vec + (int64_t)kThreads * kUnpackUnroll - 1) / ((int64_t)kThreads * kUnpackUnroll);
+    if (tiles > 0x7FFFFFFF) return DMXQ_ERR_UNSUPPORTED;
+    const unsigned grid = (unsigned)tiles;
     hipStream_t s = (hipStream_t)stream;
     if (dtype_out == DMXQ_F32) DMXQ_LAUNCH(bfp_unpack_vec_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision);
     else if (dtype_out == DMXQ_F16) DMXQ_LAUNCH(bfp_unpack_vec_kernel<DMXQ_F16>, dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision);
