@@ -172,9 +172,10 @@ def input_hypernet(x, sq_scale, precision: int, block_size: int, symmetric: bool
     return out
 
 
-def binary_cast(a, b, op: str, cast_a=None, cast_b=None, cast_out=None):
+def binary_cast(a, b, op: str, cast_a=None, cast_b=None, cast_out=None, then_bfp=None):
     """A binary DmxModule in one launch: cast_out(cast_a(a) op cast_b(b)), op in {"add", "mul"}; each cast is a FloatingPoint
-    format (nearest, signed) or None = SAME.  None when not fusable (the caller runs the casts and the op one by one)."""
+    format (nearest, signed) or None = SAME.  then_bfp = (precision, block_size): the consumer's BFP input cast along the last dim in the
+    same launch (dmxq_binary_cast_bfp).  None when not fusable (the caller runs the casts and the op one by one)."""
     ac, bc = _prep(a, "binary_cast"), _prep(b, "binary_cast")
     if ac.shape != bc.shape or ac.dtype != bc.dtype or ac.device != bc.device:
         return None
@@ -186,7 +187,13 @@ def binary_cast(a, b, op: str, cast_a=None, cast_b=None, cast_out=None):
     out = torch.empty_like(ac)
     import ctypes
     ptrs = [ctypes.cast(ctypes.pointer(st), ctypes.c_void_p) if st is not None else None for st in structs]
-    rc = lib().dmxq_binary_cast(ptr(ac), ptr(bc), ptr(out), dtype_code(ac.dtype), ac.numel(), {"add": 0, "mul": 1}[op], *ptrs, stream_of(ac))
+    if then_bfp:
+        if ac.dim() < 1 or ac.numel() == 0:
+            return None
+        rc = lib().dmxq_binary_cast_bfp(ptr(ac), ptr(bc), ptr(out), dtype_code(ac.dtype), ac.numel(), {"add": 0, "mul": 1}[op], *ptrs,
+                                        ac.shape[-1], int(then_bfp[1]), int(then_bfp[0]), stream_of(ac))
+    else:
+        rc = lib().dmxq_binary_cast(ptr(ac), ptr(bc), ptr(out), dtype_code(ac.dtype), ac.numel(), {"add": 0, "mul": 1}[op], *ptrs, stream_of(ac))
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     check(rc, "dmxq_binary_cast")
@@ -513,9 +520,9 @@ def rope(x, cos, sin, unsqueeze_dim: int = 1):
     return out
 
 
-def relu_cast(x, cast_in=None, cast_out=None):
-    """A ReLU DmxModule in one launch: cast_out(relu(cast_in(x))); casts are FloatingPoint formats (nearest, signed) or None = SAME.
-    None when not fusable."""
+def relu_cast(x, cast_in=None, cast_out=None, then_bfp=None):
+    """A ReLU DmxModule in one launch: cast_out(relu(cast_in(x))); casts are FloatingPoint formats (nearest, signed) or None = SAME;
+    then_bfp as binary_cast (dmxq_relu_cast_bfp).  None when not fusable."""
     import ctypes
     xc = _prep(x, "relu_cast")
     structs = []
@@ -525,7 +532,13 @@ def relu_cast(x, cast_in=None, cast_out=None):
         structs.append(None if f is None else _lib.FloatFmt(int(f.mantissa), int(f.exponent), int(f.bias), int(bool(f.flush_subnormal))))
     ptrs = [ctypes.cast(ctypes.pointer(st), ctypes.c_void_p) if st is not None else None for st in structs]
     out = torch.empty_like(xc)
-    rc = lib().dmxq_relu_cast(ptr(xc), ptr(out), dtype_code(xc.dtype), xc.numel(), *ptrs, stream_of(xc))
+    if then_bfp:
+        if xc.dim() < 1 or xc.numel() == 0:
+            return None
+        rc = lib().dmxq_relu_cast_bfp(ptr(xc), ptr(out), dtype_code(xc.dtype), xc.numel(), *ptrs, xc.shape[-1], int(then_bfp[1]), int(then_bfp[0]),
+                                      stream_of(xc))
+    else:
+        rc = lib().dmxq_relu_cast(ptr(xc), ptr(out), dtype_code(xc.dtype), xc.numel(), *ptrs, stream_of(xc))
     if rc == _lib.ERR_UNSUPPORTED:
         return None
     check(rc, "dmxq_relu_cast")

@@ -161,15 +161,17 @@ def _fmt4(f):
     return [] if f is None else [int(f.mantissa), int(f.exponent), int(f.bias), int(bool(f.flush_subnormal))]
 
 
-def binary_cast(a, b, op: str, cast_a=None, cast_b=None, cast_out=None):
+def binary_cast(a, b, op: str, cast_a=None, cast_b=None, cast_out=None, then_bfp=None):
     """A binary DmxModule in one launch: cast_out(cast_a(a) op cast_b(b)), op in {"add", "mul"}; each cast is a FloatingPoint
-    format (nearest, signed) or None = SAME.  None when not fusable (the caller runs the casts and the op one by one)."""
+    format (nearest, signed) or None = SAME.  then_bfp = (precision, block_size): the consumer's BFP input cast along the last dim in the
+    same launch (dmxq_binary_cast_bfp).  None when not fusable (the caller runs the casts and the op one by one)."""
     require_gpu(a, "binary_cast")
     for f in (cast_a, cast_b, cast_out):
         if f is not None and (f.rounding != "nearest" or f.unsigned):
             return None
     try:
-        return _ops.binary_cast(a, b, {"add": 0, "mul": 1}[op], _fmt4(cast_a), _fmt4(cast_b), _fmt4(cast_out))
+        return _ops.binary_cast(a, b, {"add": 0, "mul": 1}[op], _fmt4(cast_a), _fmt4(cast_b), _fmt4(cast_out),
+                                int(then_bfp[1]) if then_bfp else 0, int(then_bfp[0]) if then_bfp else 0)
     except NotImplementedError:
         return None
 
@@ -374,15 +376,15 @@ def rope(x, cos, sin, unsqueeze_dim: int = 1):
         return None
 
 
-def relu_cast(x, cast_in=None, cast_out=None):
-    """A ReLU DmxModule in one launch: cast_out(relu(cast_in(x))); casts are FloatingPoint formats (nearest, signed) or None = SAME.
-    None when not fusable."""
+def relu_cast(x, cast_in=None, cast_out=None, then_bfp=None):
+    """A ReLU DmxModule in one launch: cast_out(relu(cast_in(x))); casts are FloatingPoint formats (nearest, signed) or None = SAME;
+    then_bfp as binary_cast (dmxq_relu_cast_bfp).  None when not fusable."""
     require_gpu(x, "relu_cast")
     for f in (cast_in, cast_out):
         if f is not None and (f.rounding != "nearest" or f.unsigned):
             return None
     try:
-        return _ops.relu_cast(x, _fmt4(cast_in), _fmt4(cast_out))
+        return _ops.relu_cast(x, _fmt4(cast_in), _fmt4(cast_out), int(then_bfp[1]) if then_bfp else 0, int(then_bfp[0]) if then_bfp else 0)
     except NotImplementedError:
         return None
 

@@ -8,6 +8,7 @@
 #include "floatq.hpp"
 #include "stream.hpp"
 #include "lastdim.hpp"
+#include "bfp_math.hpp"
 #include "unary_ops.hpp"
 
 namespace dmxq {
@@ -565,30 +566,71 @@ extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype
 // range-only (the FLOAT16-style formats of the BASIC rules: range16_word above).  Replaces the four launches of a ResAdd / Mul
 // DmxModule (modeling/nn/core.py:228-264: two input casts, the torch op, the output cast): 6 B/element instead of 18.
 // The op itself is torch's: fp32 arithmetic on the widened operands, one RNE rounding to bf16.
-struct BinArgs { const void* a; const void* b; void* out; int64_t n_vec; Range16 ra, rb, ro; };
-template <int DT, int OP, int T, int U>
+// The BFP cast of the module that consumes the result (dmxq_binary_cast_bfp / dmxq_relu_cast_bfp), on one lane-vector of the module's
+// result in place: blocks of lpb adjacent lanes (DPP maximum; EVERY lane of the wave must call this), the arithmetic of bfp_math.hpp --
+// symmetric, nearest, the fast block path with the literal one behind a wave vote.
+template <int EPL>
+__device__ __forceinline__ void bfp_cast_lane_vector(float (&c)[EPL], int lpb, int wl) {
+  uint32_t mb = 0u;
+#pragma unroll
+  for (int j = 0; j < EPL; j++) mb = max(mb, f2u(c[j]) & 0x7FFFFFFFu);
+  mb = group_max_u32(mb, lpb);
+  const bool fast_ok = bfp_fast_ok(mb, wl);
+  float q[EPL];
+  {
+    const BfpBlockParams bp = bfp_block_params<false, true>(mb, wl);
+#pragma unroll
+    for (int j = 0; j < EPL; j++) q[j] = bfp_q1_fast<false, false>(c[j], bp);
+  }
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast_ok) != 0ull, 0)) {
+    if (!fast_ok) {
+      const BfpBlockParams bp = bfp_block_params<false, false>(mb, wl);
+#pragma unroll
+      for (int j = 0; j < EPL; j++) q[j] = bfp_q1<DMXQ_ROUND_NEAREST, false>(c[j], bp, wl, DMXQ_ROUND_NEAREST, 0u);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < EPL; j++) c[j] = q[j];
+}
+
+// OP 0 add, 1 mul, 2 relu (b unused; only with BFPOUT: the plain ReLU module is float_range_bf16_kernel<., ., 1>)
+struct BinArgs { const void* a; const void* b; void* out; int64_t n_vec; Range16 ra, rb, ro; int bfp_lpb = 0, bfp_wl = 0; };
+template <int DT, int OP, int T, int U, bool BFPOUT = false>
 __global__ __launch_bounds__(T) void binary_range_bf16_kernel(const BinArgs g) {
   constexpr int64_t TILE = (int64_t)T * U;
   const int64_t base = (int64_t)blockIdx.x * TILE + threadIdx.x;
-  u32x4 ra[U], rb[U];
+  u32x4 ra[U], rb[OP == 2 ? 1 : U];
 #pragma unroll
   for (int u = 0; u < U; u++) {
     const int64_t v = base + u * T < g.n_vec ? base + u * T : g.n_vec - 1;  // clamped: unconditional loads
     ra[u] = load_raw16<true>(g.a, v * 16);
-    rb[u] = load_raw16<true>(g.b, v * 16);
+    if (OP != 2) rb[u] = load_raw16<true>(g.b, v * 16);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int u = 0; u < U; u++) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const uint32_t wa = range16_word(ra[u][j], g.ra), wb = range16_word(rb[u][j], g.rb);
+      const uint32_t wa = range16_word(ra[u][j], g.ra), wb = OP == 2 ? 0u : range16_word(rb[OP == 2 ? 0 : u][j], g.rb);
       float a0, a1, b0, b1;
       if (DT == DMXQ_BF16) { a0 = u2f(wa << 16); a1 = u2f(wa & 0xFFFF0000u); b0 = u2f(wb << 16); b1 = u2f(wb & 0xFFFF0000u); }
       else { a0 = half_lo(wa); a1 = half_hi(wa); b0 = half_lo(wb); b1 = half_hi(wb); }
-      float c0 = OP == 0 ? a0 + b0 : a0 * b0, c1 = OP == 0 ? a1 + b1 : a1 * b1;
-      if (DT == DMXQ_BF16) { c0 = c0 != c0 ? u2f(0x7FC00000u) : c0; c1 = c1 != c1 ? u2f(0x7FC00000u) : c1; }  // c10::BFloat16: every NaN -> +0x7FC0
-      ra[u][j] = range16_word(pack2<DT>(c0, c1), g.ro);
+      float c0, c1;
+      if (OP == 2) {  // clamp_min(x, 0): -0.0 and NaN pass with their bits
+        ra[u][j] = range16_word((a0 < 0.0f ? 0u : (wa & 0xFFFFu)) | (a1 < 0.0f ? 0u : (wa & 0xFFFF0000u)), g.ro);
+      } else {
+        c0 = OP == 0 ? a0 + b0 : a0 * b0, c1 = OP == 0 ? a1 + b1 : a1 * b1;
+        if (DT == DMXQ_BF16) { c0 = c0 != c0 ? u2f(0x7FC00000u) : c0; c1 = c1 != c1 ? u2f(0x7FC00000u) : c1; }  // c10::BFloat16: every NaN -> +0x7FC0
+        ra[u][j] = range16_word(pack2<DT>(c0, c1), g.ro);
+      }
+    }
+    if constexpr (BFPOUT) {
+      float c[8];
+      widen<DT, 8>(ra[u], c);
+      bfp_cast_lane_vector<8>(c, __builtin_amdgcn_readfirstlane(g.bfp_lpb), __builtin_amdgcn_readfirstlane(g.bfp_wl));
+      const OutVec<DT, 8> o = pack_vec<DT, 8>(c);
+#pragma unroll
+      for (int j = 0; j < 4; j++) ra[u][j] = o.w[j];
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -604,8 +646,11 @@ __global__ __launch_bounds__(T) void binary_range_bf16_kernel(const BinArgs g) {
 // the bit-level form for what it does not cover), CastTo's `.to(dtype)`, the op in fp32 rounded once to the dtype, cast_out and
 // its `.to(dtype)`.  OP 0 add, 1 mul, 2 relu (b unused).  3 casts ~ 50 VALU per element: still under the memory time of a float32
 // tensor (12 B/element), about level with it for 16-bit ones.
-struct GenArgs { const void* a; const void* b; void* out; int64_t n_vec; CastG ca, cb, co; };
-template <int DT, int OP, int T, int U>
+struct GenArgs { const void* a; const void* b; void* out; int64_t n_vec; CastG ca, cb, co; int bfp_lpb = 0, bfp_wl = 0; };
+// BFPOUT (dmxq_binary_cast_bfp / dmxq_relu_cast_bfp): the input cast of the module that consumes the result -- BFP blocks of lpb adjacent
+// lane-vectors along the contiguous rows -- applied to the module's result before it is stored: every lane of the kernel already runs
+// unconditionally (clamped loads, predicated stores), so the DPP block maximum needs nothing else; arithmetic of bfp_math.hpp.
+template <int DT, int OP, int T, int U, bool BFPOUT = false>
 __global__ __launch_bounds__(T) void fused_cast_generic_kernel(const GenArgs g) {
   constexpr int EPL = 16 / Elem<DT>::bytes;
   const int64_t base = (int64_t)blockIdx.x * ((int64_t)T * U) + threadIdx.x;
@@ -630,6 +675,11 @@ __global__ __launch_bounds__(T) void fused_cast_generic_kernel(const GenArgs g) 
     for (int j = 0; j < EPL; j++)
       c[j] = castg_dt<DT>(OP == 0 ? x[j] + y[j] : (OP == 1 ? x[j] * y[j] : (x[j] < 0.0f ? 0.0f : x[j])));  // clamp_min(x, 0): -0.0 and NaN pass
     castg_vec<DT, EPL>(c, g.co);
+    if constexpr (BFPOUT) {
+#pragma unroll
+      for (int j = 0; j < EPL; j++) c[j] = castg_dt<DT>(c[j]);  // the module's result, in its dtype
+      bfp_cast_lane_vector<EPL>(c, __builtin_amdgcn_readfirstlane(g.bfp_lpb), __builtin_amdgcn_readfirstlane(g.bfp_wl));
+    }
     const OutVec<DT, EPL> o = pack_vec<DT, EPL>(c);
 #pragma unroll
     for (int j = 0; j < 4; j++) ra[u][j] = o.w[j];
@@ -639,9 +689,10 @@ __global__ __launch_bounds__(T) void fused_cast_generic_kernel(const GenArgs g) 
   for (int u = 0; u < U; u++)
     if (base + u * T < g.n_vec) __builtin_nontemporal_store(ra[u], (u32x4*)((char*)g.out + (base + u * T) * 16));
 }
+// bfp_block > 0: rows of `row_len` elements in whole blocks of bfp_block (the consumer's BFP input cast, symmetric, nearest)
 template <int OP>
 static int launch_fused_generic(const void* a, const void* b, void* out, int dtype, int64_t n, const dmxq_float_fmt* fa, const dmxq_float_fmt* fb,
-                                const dmxq_float_fmt* fo, hipStream_t s) {
+                                const dmxq_float_fmt* fo, hipStream_t s, int64_t row_len = 0, int64_t bfp_block = 0, int bfp_precision = 0) {
   const int epl = dtype == DMXQ_F32 ? 4 : 8;
   GenArgs g{a, b, out, n / epl, {}, {}, {}};
   if (n % epl != 0 || !aligned16(a) || (OP != 2 && !aligned16(b)) || !aligned16(out) || !castg_of(fa, &g.ca) || !castg_of(fb, &g.cb) || !castg_of(fo, &g.co))
@@ -649,6 +700,18 @@ static int launch_fused_generic(const void* a, const void* b, void* out, int dty
   constexpr int T = 256, U = 2;
   const int64_t tiles = (g.n_vec + T * U - 1) / (T * U);
   if (tiles > 0x7FFFFFFF) return DMXQ_ERR_UNSUPPORTED;
+  if (bfp_block > 0) {
+    const int64_t lpb = bfp_block / epl;
+    if (row_len < 1 || row_len % bfp_block != 0 || n % row_len != 0 || bfp_block % epl != 0 || lpb < 1 || lpb > 64 || (lpb & (lpb - 1)) != 0 ||
+        bfp_precision < 2 || bfp_precision > 20)
+      return DMXQ_ERR_UNSUPPORTED;
+    g.bfp_lpb = (int)lpb;
+    g.bfp_wl = bfp_precision;
+    if (dtype == DMXQ_F32) DMXQ_LAUNCH((fused_cast_generic_kernel<DMXQ_F32, OP, T, U, true>), dim3((unsigned)tiles), dim3(T), 0, s, g);
+    else if (dtype == DMXQ_F16) DMXQ_LAUNCH((fused_cast_generic_kernel<DMXQ_F16, OP, T, U, true>), dim3((unsigned)tiles), dim3(T), 0, s, g);
+    else DMXQ_LAUNCH((fused_cast_generic_kernel<DMXQ_BF16, OP, T, U, true>), dim3((unsigned)tiles), dim3(T), 0, s, g);
+    return launch_status();
+  }
   if (dtype == DMXQ_F32) DMXQ_LAUNCH((fused_cast_generic_kernel<DMXQ_F32, OP, T, U>), dim3((unsigned)tiles), dim3(T), 0, s, g);
   else if (dtype == DMXQ_F16) DMXQ_LAUNCH((fused_cast_generic_kernel<DMXQ_F16, OP, T, U>), dim3((unsigned)tiles), dim3(T), 0, s, g);
   else DMXQ_LAUNCH((fused_cast_generic_kernel<DMXQ_BF16, OP, T, U>), dim3((unsigned)tiles), dim3(T), 0, s, g);
@@ -695,6 +758,58 @@ extern "C" int dmxq_relu_cast(const void* in, void* out, int dtype, int64_t n, c
   // in range, zeros and the clamped NaN / Inf pass relu unchanged or become +0
   if (rx.ro.limit2 == ri.limit2 && rx.ro.minb2 == ri.minb2) return launch_float_range_bf16<2>(in, out, n / 8, ri, (hipStream_t)stream, rx);
   return launch_float_range_bf16<1>(in, out, n / 8, ri, (hipStream_t)stream, rx);  // the tile plans of the plain range cast
+}
+
+// 16-bit tensors whose casts are all range-only: the packed-word kernel with the BFP epilogue; kNotRangeOnly = take the general form
+constexpr int kNotRangeOnly = -1000;
+static int launch_range_bfp(int op, const void* a, const void* b, void* out, int dtype, int64_t n, const dmxq_float_fmt* cast_a, const dmxq_float_fmt* cast_b,
+                            const dmxq_float_fmt* cast_out, int64_t row_len, int64_t block_size, int precision, hipStream_t s) {
+  BinArgs g{a, b, out, n / 8, {}, {}, {}};
+  if (n % 8 != 0 || !aligned16(a) || !aligned16(b) || !aligned16(out) || !range16_of(cast_a, dtype, &g.ra) || !range16_of(cast_b, dtype, &g.rb) ||
+      !range16_of(cast_out, dtype, &g.ro))
+    return kNotRangeOnly;
+  const int64_t lpb = block_size / 8;
+  if (row_len < 1 || row_len % block_size != 0 || n % row_len != 0 || block_size % 8 != 0 || lpb < 1 || lpb > 64 || (lpb & (lpb - 1)) != 0 ||
+      precision < 2 || precision > 20)
+    return DMXQ_ERR_UNSUPPORTED;
+  g.bfp_lpb = (int)lpb;
+  g.bfp_wl = precision;
+  constexpr int T = 256, U = 2;
+  const int64_t tiles = (g.n_vec + T * U - 1) / (T * U);
+  if (tiles > 0x7FFFFFFF) return DMXQ_ERR_UNSUPPORTED;
+#define DMXQ_RB(DT_, OP_) DMXQ_LAUNCH((binary_range_bf16_kernel<DT_, OP_, T, U, true>), dim3((unsigned)tiles), dim3(T), 0, s, g)
+  if (dtype == DMXQ_BF16) { if (op == 0) DMXQ_RB(DMXQ_BF16, 0); else if (op == 1) DMXQ_RB(DMXQ_BF16, 1); else DMXQ_RB(DMXQ_BF16, 2); }
+  else { if (op == 0) DMXQ_RB(DMXQ_F16, 0); else if (op == 1) DMXQ_RB(DMXQ_F16, 1); else DMXQ_RB(DMXQ_F16, 2); }
+#undef DMXQ_RB
+  return launch_status();
+}
+
+// The same modules followed by the BFP input cast of the ONE module that consumes the result (Mul -> the down projection, ReLU -> fc2:
+// `input_casts` of modeling/nn/core.py:228-264; blocks of block_size along rows of row_len elements, symmetric, nearest) in one launch:
+// out = BFP_QDQ(module(x)), bit-identical to dmxq_binary_cast / dmxq_relu_cast followed by dmxq_bfp_qdq.  16-bit tensors with range-only casts on the packed words, anything else in the general form.
+extern "C" int dmxq_binary_cast_bfp(const void* a, const void* b, void* out, int dtype, int64_t n, int op, const dmxq_float_fmt* cast_a,
+                                    const dmxq_float_fmt* cast_b, const dmxq_float_fmt* cast_out, int64_t row_len, int64_t block_size,
+                                    int precision, void* stream) {
+  if (!valid_dtype(dtype) || n < 0 || (op != DMXQ_BINARY_ADD && op != DMXQ_BINARY_MUL) || block_size < 1) return DMXQ_ERR_BAD_ARG;
+  if (n == 0) return DMXQ_OK;
+  if (!a || !b || !out) return DMXQ_ERR_BAD_ARG;
+  if (dtype != DMXQ_F32) {
+    const int rc = launch_range_bfp(op == DMXQ_BINARY_ADD ? 0 : 1, a, b, out, dtype, n, cast_a, cast_b, cast_out, row_len, block_size, precision, (hipStream_t)stream);
+    if (rc != kNotRangeOnly) return rc;
+  }
+  return op == DMXQ_BINARY_ADD ? launch_fused_generic<0>(a, b, out, dtype, n, cast_a, cast_b, cast_out, (hipStream_t)stream, row_len, block_size, precision)
+                               : launch_fused_generic<1>(a, b, out, dtype, n, cast_a, cast_b, cast_out, (hipStream_t)stream, row_len, block_size, precision);
+}
+extern "C" int dmxq_relu_cast_bfp(const void* in, void* out, int dtype, int64_t n, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out,
+                                  int64_t row_len, int64_t block_size, int precision, void* stream) {
+  if (!valid_dtype(dtype) || n < 0 || block_size < 1) return DMXQ_ERR_BAD_ARG;
+  if (n == 0) return DMXQ_OK;
+  if (!in || !out) return DMXQ_ERR_BAD_ARG;
+  if (dtype != DMXQ_F32) {
+    const int rc = launch_range_bfp(2, in, in, out, dtype, n, cast_in, nullptr, cast_out, row_len, block_size, precision, (hipStream_t)stream);
+    if (rc != kNotRangeOnly) return rc;
+  }
+  return launch_fused_generic<2>(in, nullptr, out, dtype, n, cast_in, nullptr, cast_out, (hipStream_t)stream, row_len, block_size, precision);
 }
 
 #endif  // part 1a

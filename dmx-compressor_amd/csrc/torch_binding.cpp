@@ -227,31 +227,45 @@ static const dmxq_float_fmt* fmt_of(at::IntArrayRef v, dmxq_float_fmt* slot) {
   *slot = dmxq_float_fmt{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
   return slot;
 }
-Tensor binary_cast(const Tensor& a, const Tensor& b, int64_t op, at::IntArrayRef cast_a, at::IntArrayRef cast_b, at::IntArrayRef cast_out) {
+// bfp_block > 0: dmxq_binary_cast_bfp / dmxq_relu_cast_bfp (the consumer's BFP input cast along the last dim in the same launch)
+Tensor binary_cast(const Tensor& a, const Tensor& b, int64_t op, at::IntArrayRef cast_a, at::IntArrayRef cast_b, at::IntArrayRef cast_out,
+                   int64_t bfp_block, int64_t bfp_precision) {
   const Tensor ac = prep(a, "binary_cast"), bc = prep(b, "binary_cast");
   TORCH_CHECK_NOT_IMPLEMENTED(ac.sizes() == bc.sizes() && ac.scalar_type() == bc.scalar_type() && ac.device() == bc.device(),
                               "binary_cast: operands must share shape, dtype and device (no broadcasting)");
   Tensor out = empty_like_shape(ac, ac.scalar_type());
   dmxq_float_fmt fa, fb, fo;
   Launch l(ac);
+  if (bfp_block > 0) {
+    TORCH_CHECK_NOT_IMPLEMENTED(ac.dim() >= 1 && ac.numel() > 0, "binary_cast: the BFP cast needs a last dim");
+    check(dmxq_binary_cast_bfp(ac.data_ptr(), bc.data_ptr(), out.data_ptr(), dt_code(ac.scalar_type()), ac.numel(), (int)op, fmt_of(cast_a, &fa),
+                               fmt_of(cast_b, &fb), fmt_of(cast_out, &fo), ac.size(-1), bfp_block, (int)bfp_precision, l.stream), "dmxq_binary_cast_bfp");
+    return out;
+  }
   check(dmxq_binary_cast(ac.data_ptr(), bc.data_ptr(), out.data_ptr(), dt_code(ac.scalar_type()), ac.numel(), (int)op, fmt_of(cast_a, &fa),
                          fmt_of(cast_b, &fb), fmt_of(cast_out, &fo), l.stream), "dmxq_binary_cast");
   return out;
 }
-Tensor binary_cast_meta(const Tensor& a, const Tensor&, int64_t, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef) {
+Tensor binary_cast_meta(const Tensor& a, const Tensor&, int64_t, at::IntArrayRef, at::IntArrayRef, at::IntArrayRef, int64_t, int64_t) {
   return empty_like_shape(a, a.scalar_type());
 }
 
-Tensor relu_cast(const Tensor& x, at::IntArrayRef cast_in, at::IntArrayRef cast_out) {
+Tensor relu_cast(const Tensor& x, at::IntArrayRef cast_in, at::IntArrayRef cast_out, int64_t bfp_block, int64_t bfp_precision) {
   const Tensor xc = prep(x, "relu_cast");
   Tensor out = empty_like_shape(xc, xc.scalar_type());
   dmxq_float_fmt fi, fo;
   Launch l(xc);
+  if (bfp_block > 0) {
+    TORCH_CHECK_NOT_IMPLEMENTED(xc.dim() >= 1 && xc.numel() > 0, "relu_cast: the BFP cast needs a last dim");
+    check(dmxq_relu_cast_bfp(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), xc.numel(), fmt_of(cast_in, &fi), fmt_of(cast_out, &fo),
+                             xc.size(-1), bfp_block, (int)bfp_precision, l.stream), "dmxq_relu_cast_bfp");
+    return out;
+  }
   check(dmxq_relu_cast(xc.data_ptr(), out.data_ptr(), dt_code(xc.scalar_type()), xc.numel(), fmt_of(cast_in, &fi), fmt_of(cast_out, &fo), l.stream),
         "dmxq_relu_cast");
   return out;
 }
-Tensor relu_cast_meta(const Tensor& x, at::IntArrayRef, at::IntArrayRef) { return empty_like_shape(x, x.scalar_type()); }
+Tensor relu_cast_meta(const Tensor& x, at::IntArrayRef, at::IntArrayRef, int64_t, int64_t) { return empty_like_shape(x, x.scalar_type()); }
 
 Tensor sbfp_qdq(const Tensor& x, int64_t precision, int64_t block_size, int64_t sman, int64_t sexp, int64_t sbias, bool sflush,
                 bool clamp, bool symmetric, int64_t block_dim, OptDtype out_dtype) {
@@ -679,8 +693,8 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("bfp_unpack(Tensor mant, Tensor exps, int precision, int block_size, ScalarType out_dtype) -> Tensor");
   m.def("weight_hypernet(Tensor w, int precision, int block_size, bool symmetric, Tensor? score, int K, int M, Tensor? sq_scale, ScalarType? out_dtype=None, int block_dim=-1) -> Tensor");
   m.def("input_hypernet(Tensor x, Tensor sq_scale, int precision, int block_size, bool symmetric) -> Tensor");
-  m.def("binary_cast(Tensor a, Tensor b, int op, int[] cast_a, int[] cast_b, int[] cast_out) -> Tensor");
-  m.def("relu_cast(Tensor x, int[] cast_in, int[] cast_out) -> Tensor");
+  m.def("binary_cast(Tensor a, Tensor b, int op, int[] cast_a, int[] cast_b, int[] cast_out, int bfp_block=0, int bfp_precision=0) -> Tensor");
+  m.def("relu_cast(Tensor x, int[] cast_in, int[] cast_out, int bfp_block=0, int bfp_precision=0) -> Tensor");
   m.def("sbfp_qdq(Tensor x, int precision, int block_size, int scaler_man, int scaler_exp, int scaler_bias, bool scaler_flush, bool clamp, bool symmetric, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
   m.def("sbfp_qdq_nograd(Tensor x, int precision, int block_size, int scaler_man, int scaler_exp, int scaler_bias, bool scaler_flush, bool clamp, bool symmetric, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");
   m.def("mxfp_qdq(Tensor x, int man, int exp, int block_size, int block_dim=-1, ScalarType? out_dtype=None) -> Tensor");

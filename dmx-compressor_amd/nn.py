@@ -672,6 +672,12 @@ class _BinaryElementwise(DmxModule):
                 return None
             fmts.append(f)
         from . import ops
+        nc = self._linked_bfp_cast(a)
+        if nc is not None:   # the consumer's BFP input cast in this launch (dmxq_binary_cast_bfp); see Softmax._fused_forward
+            out = ops.binary_cast(a.detach(), b.detach(), self._op, *fmts, then_bfp=(nc[1].precision, nc[1].block_size))
+            if out is not None:
+                out._dmx_precast = nc[0]
+                return out
         return ops.binary_cast(a.detach(), b.detach(), self._op, *fmts)
 
 
@@ -943,6 +949,12 @@ class ReLU(DmxModule, torch.nn.ReLU):
         if not (ok_i and ok_o):
             return None
         from . import ops
+        nc = self._linked_bfp_cast(x)
+        if nc is not None:   # the consumer's BFP input cast in this launch (dmxq_relu_cast_bfp)
+            out = ops.relu_cast(x.detach(), fi, fo, then_bfp=(nc[1].precision, nc[1].block_size))
+            if out is not None:
+                out._dmx_precast = nc[0]
+                return out
         return ops.relu_cast(x.detach(), fi, fo)
 
 

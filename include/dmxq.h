@@ -245,6 +245,18 @@ int dmxq_binary_cast(const void* a, const void* b, void* out, int dtype, int64_t
 int dmxq_relu_cast(const void* in, void* out, int dtype, int64_t n, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out,
                    void* stream);
 
+/* dmxq_binary_cast / dmxq_relu_cast followed by the BFP input cast of the ONE module that consumes the result (a Mul feeding the down
+ * projection, a ReLU feeding fc2: each module casts its own input, modeling/nn/core.py:228-264 `input_casts`, so the producer's output
+ * is read back once more just to be cast) in the producer's launch: out = BFP_QDQ(module(...)) over blocks of `block_size` along
+ * contiguous rows of `row_len` elements (symmetric, nearest, `precision` mantissa bits), bit-identical to the two launches; the two
+ * forms of dmxq_binary_cast.  DMXQ_ERR_UNSUPPORTED (the caller runs the two launches): row_len not a whole number of
+ * blocks, block_size / (16 bytes of elements) not a power of two <= 64, and what dmxq_binary_cast does not take. */
+int dmxq_binary_cast_bfp(const void* a, const void* b, void* out, int dtype, int64_t n, int op, const dmxq_float_fmt* cast_a,
+                         const dmxq_float_fmt* cast_b, const dmxq_float_fmt* cast_out, int64_t row_len, int64_t block_size, int precision,
+                         void* stream);
+int dmxq_relu_cast_bfp(const void* in, void* out, int dtype, int64_t n, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out,
+                       int64_t row_len, int64_t block_size, int precision, void* stream);
+
 /* One operand (q or k) of an ApplyRotaryPosEmb DmxModule (modeling/nn/custom_modules.py:142-194) with the module's casts:
  * out = cast_out(rope(cast_x(x), cast_cos(cos), cast_sin(sin))), rope as dmxq_rope below (torch's op-by-op arithmetic in the
  * tensor dtype).  Replaces, per operand, three input casts, the ~6 torch kernels of the exact function and the output cast.

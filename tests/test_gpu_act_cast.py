@@ -542,3 +542,64 @@ def test_output_cast_absorbed_by_the_consumers_identical_input_cast(dmx, cuda):
             act.configure(dict(input_formats=["FP[1|5|10,15](FN)"]))
             lin.output_casts[next(iter(lin.output_casts.keys()))]._set_flag("observer_enabled", True)
             assert not lin._output_cast_absorbed(x)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "f16", "f32"])
+def test_binary_and_relu_cast_then_bfp_equal_the_two_launches(dmx, cuda, dtype):
+    """dmxq_binary_cast_bfp / dmxq_relu_cast_bfp: the consumer's BFP input cast in the Mul / ResAdd / ReLU module's launch == the module
+    launch followed by dmxq_bfp_qdq, bit for bit -- MLP shapes (whole tiles, a partial last tile, rows shorter than a workgroup's reach),
+    casts that round and casts that do not, blocks of 16..128, zero / denormal / huge blocks (the non-fast block path); rows that are
+    not whole blocks return None."""
+    ops = dmx.ops
+    f16, e4m3 = _fmt(dmx, "FLOAT16"), dmx.Format.from_shorthand("FP[1|4|3,7](FN)")
+    view = torch.int32 if dtype == torch.float32 else torch.int16
+    for shape in [(128, 14336), (256, 3072), (3, 50, 1024), (7, 192), (1, 64), (5, 3, 320), (2, 128)]:
+        a = (make("normal", shape, seed=sum(shape), dtype=torch.float32) * 3).to(dtype).to(cuda)
+        b = (make("normal", shape, seed=sum(shape) + 1, dtype=torch.float32) * 2).to(dtype).to(cuda)
+        a.view(-1)[:64] = 0                                           # an all-zero block
+        a.view(-1)[64:128] *= 1e-30 if dtype != torch.float16 else 1e-7   # a denormal-range block
+        if shape[-1] >= 256:
+            a.view(-1)[128:192] *= 1e30 if dtype != torch.float16 else 6e3
+        for casts in ((f16, f16, f16), (None, None, None), (e4m3, f16, None)):
+            for B, wl in ((64, 8), (16, 8), (32, 4), (128, 8)):
+                takes = shape[-1] % B == 0
+                for op in ("add", "mul"):
+                    fused = ops.binary_cast(a, b, op, *casts, then_bfp=(wl, B))
+                    two = ops.binary_cast(a, b, op, *casts)
+                    if two is None or not takes:
+                        assert fused is None, (shape, B, op)
+                        continue
+                    assert fused is not None, (shape, dtype, B, op, casts)
+                    want = ops.bfp_qdq(two, wl, B)
+                    assert int((fused.view(view) != want.view(view)).sum()) == 0, (shape, dtype, B, wl, op, casts)
+                fused, two = ops.relu_cast(a, casts[0], casts[2], then_bfp=(wl, B)), ops.relu_cast(a, casts[0], casts[2])
+                if two is None or not takes:
+                    assert fused is None
+                    continue
+                want = ops.bfp_qdq(two, wl, B)
+                assert fused is not None and int((fused.view(view) != want.view(view)).sum()) == 0, (shape, dtype, B, wl, casts)
+
+
+def test_linked_mul_and_relu_feed_a_linear_without_a_second_pass(dmx, cuda):
+    """nn.link_consumer(mul, down_proj) / (relu, fc2): the producer's launch applies the Linear's BFP input cast, the Linear skips its own;
+    outputs identical to the unlinked modules, fused only while the link is live and the formats allow."""
+    nn = dmx.nn
+    torch.manual_seed(7)
+    for dtype in (torch.bfloat16, torch.float32):
+        mul, relu, add = nn.Mul().to(cuda).eval(), nn.ReLU().to(cuda).eval(), nn.ResAdd().to(cuda).eval()
+        lin = nn.Linear(1024, 256).to(cuda).to(dtype).eval()
+        dmx.configure_model(torch.nn.ModuleList([mul, relu, add, lin]), *dmx.config_rules.BASIC)
+        a, b = (torch.randn(2, 60, 1024, device=cuda) * 3).to(dtype), (torch.randn(2, 60, 1024, device=cuda) * 2).to(dtype)
+        with torch.no_grad():
+            for prod, args in ((mul, (a, b)), (relu, (a,)), (add, (a, b))):
+                want = lin(prod(*args))
+                nn.link_consumer(prod, lin)
+                h = prod(*args)
+                assert getattr(h, "_dmx_precast", None) == (lin._first_input_cast(),), type(prod).__name__
+                assert torch.equal(lin(h), want)
+                lin.configure(dict(input_formats=["BFP[8|8]{64}(SS)"]))     # stochastic rounding: not the fused cast
+                assert getattr(prod(*args), "_dmx_precast", None) is None
+                lin.configure(dict(input_formats=["BFP[8|8]{64}(SN)"]))
+                nn.link_consumer(prod)
+                assert getattr(prod(*args), "_dmx_precast", None) is None
+                assert torch.equal(lin(prod(*args)), want)

@@ -113,9 +113,11 @@ def build_layer(name, dev):
         nn.link_consumer(m.gate_proj, m.act)
         nn.link_consumer(m.up_proj, (m.mul, 1))
         nn.link_consumer(m.down_proj, m.res2)
+        nn.link_consumer(m.mul, m.down_proj)   # ... and the gated product / the activation feed one projection: its BFP cast rides along
     else:
         nn.link_consumer(m.fc1, m.act)
         nn.link_consumer(m.fc2, m.res2)
+        nn.link_consumer(m.act, m.fc2)
     lin = [mod for mod in m.modules() if isinstance(mod, nn.Linear)]
     x = (torch.randn(c["B"], c["S"], H, device=dev) * 1.5).to(dt)
     extra = ()

@@ -64,6 +64,7 @@ def main():
     row("BFP16_64 input cast [256, 3072]", (t, 4 * h), F32, lambda x: ops.bfp_qdq(x, 8, 64))
     row("LayerNorm module [256, 768] (FLOAT16 casts)", (t, h), F32, lambda x: ops.layernorm_cast(x, h, w, w, 1e-5, F16, F16))
     row("ReLU module [256, 3072] (FLOAT16 casts)", (t, 4 * h), F32, lambda x: ops.relu_cast(x, F16, F16))
+    row("ReLU module + fc2's BFP16_64 input cast [256, 3072], one launch", (t, 4 * h), F32, lambda x: ops.relu_cast(x, F16, F16, then_bfp=(8, 64)))
     row("ResAdd module [256, 768] (FLOAT16 casts)", (t, h), F32, lambda x: ops.binary_cast(x, x, "add", F16, F16, F16))
     row("softmax module [24, 128, 128] (FLOAT16 casts)", (24, 128, 128), F32, lambda x: ops.softmax_cast(x, -1, F16, F16))
     row("BFP16_64 of the V operand [24, 128, 64] along dim -2", (24, 128, 64), F32, lambda x: ops.bfp_qdq(x, 8, 64, block_dim=-2))
@@ -80,6 +81,7 @@ def main():
     row("RMSNorm module [128, 4096] (FLOAT16 casts)", (t, h), BF16, lambda x: ops.rmsnorm_cast(x, h, w, 1e-5, F16, F16))
     row("SiLU module [128, 14336] (FLOAT16 casts)", (t, 14336), BF16, lambda x: ops.unary_cast(x, "silu", F16, F16))
     row("Mul module [128, 14336] (FLOAT16 casts)", (t, 14336), BF16, lambda x: ops.binary_cast(x, x, "mul", F16, F16, F16))
+    row("Mul module + down_proj's BFP16_64 input cast [128, 14336], one launch", (t, 14336), BF16, lambda x: ops.binary_cast(x, x, "mul", F16, F16, F16, then_bfp=(8, 64)))
     row("softmax module [32, 128, 128] (FLOAT16 casts)", (32, 128, 128), BF16, lambda x: ops.softmax_cast(x, -1, F16, F16))
     row("BFP16_64 of the V operand [32, 128, 128] along dim -2", (32, 128, 128), BF16, lambda x: ops.bfp_qdq(x, 8, 64, block_dim=-2))
     # ---- Whisper-small encoder layer, fp32, 1500 positions, hidden 768
