@@ -53,15 +53,22 @@ __device__ __forceinline__ void pack_codes_literal(const float (&x)[EPL], uint32
 // lane's loads in flight before the first block maximum; the magic-add codes for every lane as straight-line code, the blocks
 // that form does not cover redone behind one cold branch (the structure of bfp_rows.hpp)
 constexpr int kPackThreads = 256, kPackUnroll = 4;  // (round 3, 4096 x 4096 bf16: 256 x 2 and 256 x 4 12.0 us, 256 x 8 12.8, 256 x 16 and 128 x 16 14.5)
-template <int DTI>
-__global__ __launch_bounds__(kPackThreads) void bfp_pack_rows_kernel(const void* __restrict__ in, int8_t* __restrict__ mant,
+// VAR bit 0 (16-bit inputs, n_vec even, mant 16-byte aligned): 16-byte code stores -- neighbouring lanes swap the codes of two unroll
+//   slots (one DPP quad_perm each way), so the even lane stores vectors (v, v + 1) of slot 2k and the odd lane those of slot 2k + 1;
+// VAR bit 1 (exps 16-byte aligned): the tile's shared exponents (kPackThreads * kPackUnroll / lpb contiguous bytes) go through LDS and
+//   leave as 16-byte stores by the first lanes of the workgroup instead of one byte store per block.
+template <int DTI, int VAR, int T = kPackThreads, int U = kPackUnroll>
+__global__ __launch_bounds__(T) void bfp_pack_rows_kernel(const void* __restrict__ in, int8_t* __restrict__ mant,
                                                                     uint8_t* __restrict__ exps, int64_t n_vec, int lpb_arg,
                                                                     int lpb_log, int wl, int asym) {
   constexpr int EPL = 16 / Elem<DTI>::bytes;
-  constexpr int U = kPackUnroll, T = kPackThreads;
+  constexpr bool PAIR = (VAR & 1) != 0 && EPL == 8, LDSE = (VAR & 2) != 0;
+  static_assert(U % 2 == 0, "slots are stored in pairs");
+  __shared__ __attribute__((aligned(16))) uint8_t se[LDSE ? T * U : 16];
   const int lpb = __builtin_amdgcn_readfirstlane(lpb_arg);
   const int in_blk = threadIdx.x & (lpb - 1);  // v = threadIdx (mod lpb): tile bases and T are multiples of 64
-  const int64_t base = (int64_t)blockIdx.x * (T * U) + threadIdx.x;
+  const int64_t tile0 = (int64_t)blockIdx.x * (T * U);
+  const int64_t base = tile0 + threadIdx.x;
   u32x4 raw[U];
 #pragma unroll
   for (int u = 0; u < U; u++) {
@@ -71,6 +78,7 @@ __global__ __launch_bounds__(kPackThreads) void bfp_pack_rows_kernel(const void*
     raw[u] = load_raw16<true>(in, (v < n_vec ? v : n_vec - lpb + in_blk) * 16);
   }
   __builtin_amdgcn_sched_barrier(0);
+  uint32_t w[U][EPL / 4];
 #pragma unroll
   for (int u = 0; u < U; u++) {
     const int64_t v = base + u * T;
@@ -84,15 +92,43 @@ __global__ __launch_bounds__(kPackThreads) void bfp_pack_rows_kernel(const void*
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast) != 0ull, 0)) {
       if (!fast) pack_codes_literal<EPL>(x, mb, wl, asym, code);
     }
-    if (v < n_vec) {
-      uint32_t w[EPL / 4];
 #pragma unroll
-      for (int j = 0; j < EPL / 4; j++)
-        w[j] = ((uint32_t)code[4 * j] & 0xFFu) | (((uint32_t)code[4 * j + 1] & 0xFFu) << 8) |
-               (((uint32_t)code[4 * j + 2] & 0xFFu) << 16) | ((uint32_t)code[4 * j + 3] << 24);
-      if (EPL == 8) __builtin_nontemporal_store(u32x2{w[0], w[EPL / 4 - 1]}, (u32x2*)(mant + v * 8));
-      else __builtin_nontemporal_store(w[0], (uint32_t*)(mant + v * 4));
-      if (in_blk == 0) exps[v >> lpb_log] = (uint8_t)Eb;
+    for (int j = 0; j < EPL / 4; j++)
+      w[u][j] = ((uint32_t)code[4 * j] & 0xFFu) | (((uint32_t)code[4 * j + 1] & 0xFFu) << 8) |
+                (((uint32_t)code[4 * j + 2] & 0xFFu) << 16) | ((uint32_t)code[4 * j + 3] << 24);
+    if constexpr (!PAIR) {
+      if (v < n_vec) {
+        if (EPL == 8) __builtin_nontemporal_store(u32x2{w[u][0], w[u][EPL / 4 - 1]}, (u32x2*)(mant + v * 8));
+        else __builtin_nontemporal_store(w[u][0], (uint32_t*)(mant + v * 4));
+      }
+    }
+    if constexpr (LDSE) { if (in_blk == 0) se[(u * T + threadIdx.x) >> lpb_log] = (uint8_t)Eb; }
+    else { if (v < n_vec && in_blk == 0) exps[v >> lpb_log] = (uint8_t)Eb; }
+  }
+  if constexpr (PAIR) {
+    const bool odd = (threadIdx.x & 1) != 0;
+#pragma unroll
+    for (int u = 0; u < U; u += 2) {
+      // the even lane gives away its slot u + 1 codes, the odd lane its slot u codes
+      const uint32_t s0 = odd ? w[u][0] : w[u + 1][0], s1 = odd ? w[u][1] : w[u + 1][1];
+      const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);  // quad_perm [1, 0, 3, 2]
+      const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+      const u32x4 o = odd ? u32x4{r0, r1, w[u + 1][0], w[u + 1][1]} : u32x4{w[u][0], w[u][1], r0, r1};
+      const int64_t v = base + (odd ? (u + 1) * T - 1 : u * T);  // the even vector of the pair, in slot u (even lane) / u + 1 (odd lane)
+      if (v < n_vec) __builtin_nontemporal_store(o, (u32x4*)(mant + v * 8));  // (n_vec even: the pair is in or out as a whole)
+    }
+  }
+  if constexpr (LDSE) {
+    __syncthreads();
+    const int64_t blk0 = tile0 >> lpb_log, nblk = n_vec >> lpb_log;
+    const int cnt = (T * U) >> lpb_log;  // >= 16: lpb <= 64
+    const int i = threadIdx.x * 16;
+    if (i < cnt) {
+      if (blk0 + i + 16 <= nblk) {
+        __builtin_nontemporal_store(*(const u32x4*)(se + i), (u32x4*)(exps + blk0 + i));
+      } else {
+        for (int k = 0; k < 16 && blk0 + i + k < nblk; k++) exps[blk0 + i + k] = se[i + k];
+      }
     }
   }
 }
@@ -149,24 +185,51 @@ __global__ __launch_bounds__(kThreads) void bfp_unpack_kernel(const int8_t* __re
 // value = (code * 2^-(p-2)) * 2^(E-127): the first product is exact, the second rounds once (only a denormal result
 // rounds at all) -- the same value as the scalar kernel's ldexpf -- and cannot overflow.
 constexpr int kUnpackUnroll = 8;
-template <int DTO>
+// PAIR (n_vec even, mant 16-byte aligned): 16-byte code loads -- the even lane loads the codes of vectors (v, v + 1) of slot 2k, the odd
+// lane those of slot 2k + 1, and the two swap halves (one DPP quad_perm each way): the mirror image of bfp_pack_rows_kernel's stores
+template <int DTO, bool PAIR, int U = kUnpackUnroll>
 __global__ __launch_bounds__(kThreads) void bfp_unpack_vec_kernel(const int8_t* __restrict__ mant,
                                                                  const uint8_t* __restrict__ exps, void* __restrict__ out,
                                                                  int64_t n_vec, int b_shift /*log2(B / 8)*/, int wl) {
   const float down = u2f((uint32_t)(127 - (wl - 2)) << 23);
   // workgroup-contiguous tiles of kThreads x kUnpackUnroll code vectors, one pass per workgroup, all loads first (round 3: the
   // grid-strided 4-in-flight form measured 11.0 us on 4096 x 4096, 58 %)
-  constexpr int U = kUnpackUnroll;
+  static_assert(U % 2 == 0, "slots are loaded in pairs");
   const int64_t stride = kThreads;
   {
     const int64_t v0 = (int64_t)blockIdx.x * (kThreads * U) + threadIdx.x;
     u32x2 m[U];
     uint32_t eb[U];
+    if constexpr (PAIR) {
+      const bool odd = (threadIdx.x & 1) != 0;
+      u32x4 q[U / 2];
+#pragma unroll
+      for (int u = 0; u < U; u += 2) {
+        const int64_t p = v0 + (odd ? (u + 1) * stride - 1 : u * stride);  // the even vector of this lane's pair
+        q[u / 2] = __builtin_nontemporal_load((const u32x4*)(mant + (p < n_vec ? p : n_vec - 2) * 8));  // clamped: unconditional loads
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int64_t v = v0 + u * stride < n_vec ? v0 + u * stride : n_vec - 1;
+        eb[u] = exps[v >> b_shift];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u += 2) {
+        const u32x4 o = q[u / 2];
+        // the even lane gives away its second half (vector v + 1 of slot u), the odd lane its first (vector v - 1 of slot u + 1)
+        const uint32_t s0 = odd ? o[0] : o[2], s1 = odd ? o[1] : o[3];
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false);  // quad_perm [1, 0, 3, 2]
+        const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+        m[u] = odd ? u32x2{r0, r1} : u32x2{o[0], o[1]};
+        m[u + 1] = odd ? u32x2{o[2], o[3]} : u32x2{r0, r1};
+      }
+    } else {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int64_t v = v0 + u * stride < n_vec ? v0 + u * stride : n_vec - 1;  // clamped: unconditional loads
       m[u] = __builtin_nontemporal_load((const u32x2*)(mant + v * 8));
       eb[u] = exps[v >> b_shift];
+    }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -204,14 +267,22 @@ extern "C" int dmxq_bfp_pack(const void* in, int dtype_in, int8_t* mant, uint8_t
   const int asym = symmetric ? 0 : 1;
   if (L % B == 0 && pow2 && B >= epl && B <= 64 * epl && aligned16(in) && (reinterpret_cast<uintptr_t>(mant) & 7u) == 0) {
     const int64_t n_vec = n / epl;
-    const int64_t tiles = (n_vec + kPackThreads * kPackUnroll - 1) / (kPackThreads * kPackUnroll);
+    const bool small = n_vec <= (3 << 18);  // (tools/tune_pack.hip: up to 12 MiB of 16-bit input two vectors per lane, four beyond)
+    const int tile = kPackThreads * (small ? 2 : kPackUnroll);
+    const int64_t tiles = (n_vec + tile - 1) / tile;
     if (tiles > 0x7FFFFFFF) return DMXQ_ERR_UNSUPPORTED;
     const unsigned grid = (unsigned)tiles;
     int lpb_log = 0;
     while (((int64_t)epl << lpb_log) < B) lpb_log++;
-    if (dtype_in == DMXQ_F32) DMXQ_LAUNCH(bfp_pack_rows_kernel<DMXQ_F32>, dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
-    else if (dtype_in == DMXQ_F16) DMXQ_LAUNCH(bfp_pack_rows_kernel<DMXQ_F16>, dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
-    else DMXQ_LAUNCH(bfp_pack_rows_kernel<DMXQ_BF16>, dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
+    const bool pair = epl == 8 && n_vec % 2 == 0 && aligned16(mant), ldse = aligned16(exps);
+#define DMXQ_PK(DT_, V_) do { if (small) DMXQ_LAUNCH((bfp_pack_rows_kernel<DT_, V_, kPackThreads, 2>), dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym); \
+                              else DMXQ_LAUNCH((bfp_pack_rows_kernel<DT_, V_>), dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym); } while (0)
+#define DMXQ_PKV(DT_) do { if (pair && ldse) DMXQ_PK(DT_, 3); else if (pair) DMXQ_PK(DT_, 1); else if (ldse) DMXQ_PK(DT_, 2); else DMXQ_PK(DT_, 0); } while (0)
+    if (dtype_in == DMXQ_F32) { if (ldse) DMXQ_PK(DMXQ_F32, 2); else DMXQ_PK(DMXQ_F32, 0); }
+    else if (dtype_in == DMXQ_F16) DMXQ_PKV(DMXQ_F16);
+    else DMXQ_PKV(DMXQ_BF16);
+#undef DMXQ_PKV
+#undef DMXQ_PK
   } else {
     const int grid = grid_for(rows * ((L + B - 1) / B));
     if (dtype_in == DMXQ_F32) DMXQ_LAUNCH(bfp_pack_generic_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, in, mant, exps, rows, L, B, precision, asym);
@@ -232,13 +303,22 @@ extern "C" int dmxq_bfp_unpack(const int8_t* mant, const uint8_t* exps, void* ou
     const int64_t n_vec = rows * L / 8;
     int b_shift = 0;
     while (((int64_t)8 << b_shift) < B) b_shift++;
-    const int64_t tiles = (n_vec + (int64_t)kThreads * kUnpackUnroll - 1) / ((int64_t)kThreads * kUnpackUnroll);
+    // (tools/tune_pack.hip, bf16 out: up to 12 MiB of output 8-byte loads x 4 -- 3.5 us vs 3.8 on 1024 x 4096 --, up to 32 MiB 16-byte loads
+    // x 8 -- 8.9 us vs 9.7 on 4096 x 4096 --, beyond that 16-byte loads x 2: 33.2 us vs 34.1 on 8192 x 8192)
+    const bool pair = n_vec % 2 == 0 && aligned16(mant) && n_vec > (3 << 18);
+    const int unroll = n_vec <= (3 << 18) ? 4 : (n_vec <= (1 << 21) || !pair ? 8 : 2);
+    const int64_t tiles = (n_vec + (int64_t)kThreads * unroll - 1) / ((int64_t)kThreads * unroll);
     if (tiles > 0x7FFFFFFF) return DMXQ_ERR_UNSUPPORTED;
     const unsigned grid = (unsigned)tiles;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype_out == DMXQ_F32) DMXQ_LAUNCH(bfp_unpack_vec_kernel<DMXQ_F32>, dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision);
-    else if (dtype_out == DMXQ_F16) DMXQ_LAUNCH(bfp_unpack_vec_kernel<DMXQ_F16>, dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision);
-    else DMXQ_LAUNCH(bfp_unpack_vec_kernel<DMXQ_BF16>, dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision);
+#define DMXQ_UPK(DT_, P_, U_) DMXQ_LAUNCH((bfp_unpack_vec_kernel<DT_, P_, U_>), dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision)
+#define DMXQ_UP(DT_) do { if (unroll == 4) DMXQ_UPK(DT_, false, 4); else if (!pair) DMXQ_UPK(DT_, false, 8); else if (unroll == 8) DMXQ_UPK(DT_, true, 8); \
+                          else DMXQ_UPK(DT_, true, 2); } while (0)
+    if (dtype_out == DMXQ_F32) DMXQ_UP(DMXQ_F32);
+    else if (dtype_out == DMXQ_F16) DMXQ_UP(DMXQ_F16);
+    else DMXQ_UP(DMXQ_BF16);
+#undef DMXQ_UPK
+#undef DMXQ_UP
     return launch_status();
   }
   DMXQ_LAUNCH(bfp_unpack_kernel, dim3(grid_for(rows * L)), dim3(kThreads), 0, (hipStream_t)stream, mant, exps, out,

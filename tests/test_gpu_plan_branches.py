@@ -245,3 +245,32 @@ def test_dense_smoothquant_weight_path_on_narrow_rows(dmx, cuda, dtype):
                     assert whole is not None, (cols, B)
                     chain = ops.bfp_qdq(ops.scale_channels(x, sc, 1, False), 8, B, symmetric=sym)
                     _check(f"dense SQ + BFP{B} sym={sym} {dtype} [{rows}, {cols}]", whole, chain)
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32], ids=["bf16", "f32"])
+def test_packed_bfp_geometry_branches(dmx, cuda, dtype):
+    """bfp_pack / bfp_unpack choose their tile geometry and load / store width by size (csrc/bfp_pack.hip: two or four vectors per lane,
+    16-byte code stores through a neighbour-lane exchange when the vector count is even, exponents through LDS; unpack: 8-byte loads x 4,
+    16-byte loads x 8 up to 32 MiB of output, x 2 beyond, 8-byte loads x 8 when the vector count is odd): codes, exponents and unpacked
+    values of the whole tensor equal those of its 128-row slabs (small: the branch the oracle test pins), and the round trip equals the cast."""
+    ops = dmx.ops
+    cols = 4096
+    for rows, L, B in [(300, cols, 16), (1600, cols, 64), (4096, cols, 16), (4200, cols, 64), (1537, 4104, 8), (130, 4104, 8)]:
+        x = make("heavy", (rows, L), seed=rows, dtype=torch.float32).clamp(-3e4, 3e4)
+        x.view(-1)[:: 4099] = 0.0
+        x[1, :B] = 0.0
+        x = x.to(dtype).to(cuda)
+        m, e = ops.bfp_pack(x, 8, B, True)
+        ms, es = [], []
+        for r0 in range(0, rows, SLAB):
+            a, b = ops.bfp_pack(x[r0:r0 + SLAB].clone(), 8, B, True)
+            ms.append(a)
+            es.append(b)
+        assert torch.equal(m, torch.cat(ms, 0)) and torch.equal(e, torch.cat(es, 0)), (rows, L, B)
+        for od in (BF16, F32):
+            y = ops.bfp_unpack(m, e, 8, B, od)
+            ys = torch.cat([ops.bfp_unpack(m[r0:r0 + SLAB].clone(), e[r0:r0 + SLAB].clone(), 8, B, od) for r0 in range(0, rows, SLAB)], 0)
+            _check(f"bfp_unpack {rows}x{L} B={B} -> {od}", y, ys)
+        ok = ((e > 0) & (e < 255)).repeat_interleave(B, dim=-1)
+        y, q = ops.bfp_unpack(m, e, 8, B, torch.float32), ops.bfp_qdq(x, 8, B, out_dtype=torch.float32)
+        assert torch.equal(y[ok].view(torch.int32), q[ok].view(torch.int32)), (rows, L, B)
