@@ -62,8 +62,8 @@ __global__ __launch_bounds__(T) void bfp_pack_rows_kernel(const void* __restrict
                                                                     uint8_t* __restrict__ exps, int64_t n_vec, int lpb_arg,
                                                                     int lpb_log, int wl, int asym) {
   constexpr int EPL = 16 / Elem<DTI>::bytes;
-  constexpr bool PAIR = (VAR & 1) != 0 && EPL == 8, LDSE = (VAR & 2) != 0;
-  static_assert(U % 2 == 0, "slots are stored in pairs");
+  constexpr bool PAIR = (VAR & 1) != 0 && EPL == 8, QUAD = (VAR & 1) != 0 && EPL == 4, LDSE = (VAR & 2) != 0;
+  static_assert(U % 2 == 0 && (!QUAD || U % 4 == 0), "slots are stored in pairs (float32 inputs: in fours)");
   __shared__ __attribute__((aligned(16))) uint8_t se[LDSE ? T * U : 16];
   const int lpb = __builtin_amdgcn_readfirstlane(lpb_arg);
   const int in_blk = threadIdx.x & (lpb - 1);  // v = threadIdx (mod lpb): tile bases and T are multiples of 64
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(T) void bfp_pack_rows_kernel(const void* __restrict
     for (int j = 0; j < EPL / 4; j++)
       w[u][j] = ((uint32_t)code[4 * j] & 0xFFu) | (((uint32_t)code[4 * j + 1] & 0xFFu) << 8) |
                 (((uint32_t)code[4 * j + 2] & 0xFFu) << 16) | ((uint32_t)code[4 * j + 3] << 24);
-    if constexpr (!PAIR) {
+    if constexpr (!PAIR && !QUAD) {
       if (v < n_vec) {
         if (EPL == 8) __builtin_nontemporal_store(u32x2{w[u][0], w[u][EPL / 4 - 1]}, (u32x2*)(mant + v * 8));
         else __builtin_nontemporal_store(w[u][0], (uint32_t*)(mant + v * 4));
@@ -116,6 +116,30 @@ __global__ __launch_bounds__(T) void bfp_pack_rows_kernel(const void* __restrict
       const u32x4 o = odd ? u32x4{r0, r1, w[u + 1][0], w[u + 1][1]} : u32x4{w[u][0], w[u][1], r0, r1};
       const int64_t v = base + (odd ? (u + 1) * T - 1 : u * T);  // the even vector of the pair, in slot u (even lane) / u + 1 (odd lane)
       if (v < n_vec) __builtin_nontemporal_store(o, (u32x4*)(mant + v * 8));  // (n_vec even: the pair is in or out as a whole)
+    }
+  }
+  if constexpr (QUAD) {
+    // float32 inputs: 4 codes = one dword per lane and slot.  A 4 x 4 transpose inside each quad of lanes (two exchange steps: lanes
+    // xor 1, then lanes xor 2) leaves lane j of the quad with the dwords of all four lanes for slot 4k + j: one 16-byte store (n_vec % 4 == 0)
+    const bool b1 = (threadIdx.x & 1) != 0, b2 = (threadIdx.x & 2) != 0;
+#pragma unroll
+    for (int u = 0; u < U; u += 4) {
+      uint32_t p0[2], p1[2];  // after step 1: slot u + b1 (p0) and slot u + 2 + b1 (p1), each from lanes (2h, 2h + 1) of this half quad
+      {
+        const uint32_t sa = b1 ? w[u][0] : w[u + 1][0], sb = b1 ? w[u + 2][0] : w[u + 3][0];
+        const uint32_t ra = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sa, 0xB1, 0xF, 0xF, false);  // quad_perm [1, 0, 3, 2]
+        const uint32_t rb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sb, 0xB1, 0xF, 0xF, false);
+        p0[0] = b1 ? ra : w[u][0];      p0[1] = b1 ? w[u + 1][0] : ra;
+        p1[0] = b1 ? rb : w[u + 2][0];  p1[1] = b1 ? w[u + 3][0] : rb;
+      }
+      // step 2: the lower half quad gives away its p1, the upper its p0
+      const uint32_t s0 = b2 ? p0[0] : p1[0], s1 = b2 ? p0[1] : p1[1];
+      const uint32_t r0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, 0x4E, 0xF, 0xF, false);  // quad_perm [2, 3, 0, 1]
+      const uint32_t r1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, 0x4E, 0xF, 0xF, false);
+      const u32x4 o = b2 ? u32x4{r0, r1, p1[0], p1[1]} : u32x4{p0[0], p0[1], r0, r1};
+      const int j = threadIdx.x & 3;
+      const int64_t v = base - j + (int64_t)(u + j) * T;  // the first vector of the quad, in slot u + j
+      if (v < n_vec) __builtin_nontemporal_store(o, (u32x4*)(mant + v * 4));
     }
   }
   if constexpr (LDSE) {
@@ -278,7 +302,14 @@ extern "C" int dmxq_bfp_pack(const void* in, int dtype_in, int8_t* mant, uint8_t
 #define DMXQ_PK(DT_, V_) do { if (small) DMXQ_LAUNCH((bfp_pack_rows_kernel<DT_, V_, kPackThreads, 2>), dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym); \
                               else DMXQ_LAUNCH((bfp_pack_rows_kernel<DT_, V_>), dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym); } while (0)
 #define DMXQ_PKV(DT_) do { if (pair && ldse) DMXQ_PK(DT_, 3); else if (pair) DMXQ_PK(DT_, 1); else if (ldse) DMXQ_PK(DT_, 2); else DMXQ_PK(DT_, 0); } while (0)
-    if (dtype_in == DMXQ_F32) { if (ldse) DMXQ_PK(DMXQ_F32, 2); else DMXQ_PK(DMXQ_F32, 0); }
+    if (dtype_in == DMXQ_F32) {
+      // (16-byte code stores need four slots: the two-slot geometry of small tensors keeps 4-byte stores)
+      const bool quad = !small && n_vec % 4 == 0 && aligned16(mant);
+      if (quad && ldse) DMXQ_LAUNCH((bfp_pack_rows_kernel<DMXQ_F32, 3>), dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
+      else if (quad) DMXQ_LAUNCH((bfp_pack_rows_kernel<DMXQ_F32, 1>), dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
+      else if (ldse) DMXQ_PK(DMXQ_F32, 2);
+      else DMXQ_PK(DMXQ_F32, 0);
+    }
     else if (dtype_in == DMXQ_F16) DMXQ_PKV(DMXQ_F16);
     else DMXQ_PKV(DMXQ_BF16);
 #undef DMXQ_PKV

@@ -180,6 +180,10 @@ def main():
         lambda i: L.dmxq_bfp_pack(vp(xs[i].data_ptr()), _lib.BF16, vp(mant[i].data_ptr()), vp(exps[i].data_ptr()), R, C, 16, 8, 1, sp), k, n * 3 + n // 16)
     run("bfp_unpack int8 codes + uint8 exponents -> bf16, B=16",
         lambda i: L.dmxq_bfp_unpack(vp(mant[i].data_ptr()), vp(exps[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, R, C, 16, 8, sp), k, n * 3 + n // 16)
+    run("bfp_pack float32 -> int8 codes + uint8 exponents, B=64 (5 B/elem)",
+        lambda i: L.dmxq_bfp_pack(vp(f32a[i % 6].data_ptr()), _lib.F32, vp(mant[i % k].data_ptr()), vp(exps[i % k].data_ptr()), R, C, 64, 8, 1, sp), 6, n * 5 + n // 64)
+    run("bfp_unpack int8 codes + uint8 exponents -> float32, B=64",
+        lambda i: L.dmxq_bfp_unpack(vp(mant[i % k].data_ptr()), vp(exps[i % k].data_ptr()), vp(f32o[i % 6].data_ptr()), _lib.F32, R, C, 64, 8, sp), 6, n * 5 + n // 64)
     run("unary silu bf16", lambda i: L.dmxq_unary(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, n, 2, ctypes.c_float(0.0), sp), k, n * 4)
     run("unary quick_gelu bf16", lambda i: L.dmxq_unary(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, n, 3, ctypes.c_float(0.0), sp), k, n * 4)
     wr = torch.ones(C, device=dev, dtype=torch.bfloat16)
