@@ -274,6 +274,51 @@ __global__ __launch_bounds__(kThreads) void bfp_unpack_vec_kernel(const int8_t* 
   }
 }
 
+// float32 outputs: 8 codes become 32 bytes, and two 16-byte stores per lane at a 32-byte lane stride leave every store instruction with
+// half-used lines (measured 44 % of roofline whatever the unroll, tools/tune_pack.hip).  Here a wave takes 512 codes per slot as two
+// regions of 256: the even lane of a pair loads 8 bytes of region 0, the odd lane 8 bytes of region 1, they swap one dword (DPP
+// quad_perm), and lane l then holds dword l of BOTH regions -- 4 codes each -> two 16-byte stores, each instruction one contiguous KiB.
+// Same values as bfp_unpack_vec_kernel.  n_codes: a multiple of 8.
+template <int U>
+__global__ __launch_bounds__(kThreads) void bfp_unpack_f32_kernel(const int8_t* __restrict__ mant, const uint8_t* __restrict__ exps,
+                                                                 float* __restrict__ out, int64_t n_codes, int b_log /*log2 B*/, int wl) {
+  const float down = u2f((uint32_t)(127 - (wl - 2)) << 23);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool odd = (lane & 1) != 0;
+  const int64_t tile0 = (int64_t)blockIdx.x * (kThreads * U * 8);
+  u32x2 m[U];
+  uint32_t ea[U], eb[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int64_t chunk = tile0 + (int64_t)(u * kThreads + wave * 64) * 8;
+    const int64_t ld = chunk + (odd ? 256 : 0) + 8 * (lane >> 1);
+    m[u] = __builtin_nontemporal_load((const u32x2*)(mant + (ld + 8 <= n_codes ? ld : n_codes - 8)));  // clamped: unconditional loads
+    const int64_t ca = chunk + 4 * lane, cb = ca + 256;
+    ea[u] = exps[(ca < n_codes ? ca : n_codes - 1) >> b_log];
+    eb[u] = exps[(cb < n_codes ? cb : n_codes - 1) >> b_log];
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int64_t chunk = tile0 + (int64_t)(u * kThreads + wave * 64) * 8;
+    // even lane: has region-0 dwords (2i, 2i + 1), gives away the second; odd lane: has region-1 dwords (2i, 2i + 1), gives away the first
+    const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(odd ? m[u].x : m[u].y), 0xB1, 0xF, 0xF, false);  // quad_perm [1, 0, 3, 2]
+    const uint32_t wa = odd ? r : m[u].x, wb = odd ? m[u].y : r;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int64_t c0 = chunk + 4 * lane + 256 * h;
+      if (c0 < n_codes) {
+        const uint32_t e = h ? eb[u] : ea[u];
+        const uint32_t w = e == 0u ? 0u : (h ? wb : wa);  // zero / denormal block: +0 whatever the codes
+        const float up = e == 255u ? u2f(0x7FC00000u) : u2f(e << 23);
+        float y[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) y[k] = ((float)((int)(w << (24 - 8 * k)) >> 24) * down) * up;
+        __builtin_nontemporal_store(u32x4{f2u(y[0]), f2u(y[1]), f2u(y[2]), f2u(y[3])}, (u32x4*)(out + c0));
+      }
+    }
+  }
+}
+
 }  // namespace dmxq
 
 using namespace dmxq;
@@ -345,7 +390,12 @@ extern "C" int dmxq_bfp_unpack(const int8_t* mant, const uint8_t* exps, void* ou
 #define DMXQ_UPK(DT_, P_, U_) DMXQ_LAUNCH((bfp_unpack_vec_kernel<DT_, P_, U_>), dim3(grid), dim3(kThreads), 0, s, mant, exps, out, n_vec, b_shift, precision)
 #define DMXQ_UP(DT_) do { if (unroll == 4) DMXQ_UPK(DT_, false, 4); else if (!pair) DMXQ_UPK(DT_, false, 8); else if (unroll == 8) DMXQ_UPK(DT_, true, 8); \
                           else DMXQ_UPK(DT_, true, 2); } while (0)
-    if (dtype_out == DMXQ_F32) DMXQ_UP(DMXQ_F32);
+    if (dtype_out == DMXQ_F32) {
+      constexpr int UF = 2;
+      const int64_t ft = (n_vec + (int64_t)kThreads * UF - 1) / ((int64_t)kThreads * UF);
+      if (ft > 0x7FFFFFFF) return DMXQ_ERR_UNSUPPORTED;
+      DMXQ_LAUNCH((bfp_unpack_f32_kernel<UF>), dim3((unsigned)ft), dim3(kThreads), 0, s, mant, exps, (float*)out, n_vec * 8, b_shift + 3, precision);
+    }
     else if (dtype_out == DMXQ_F16) DMXQ_UP(DMXQ_F16);
     else DMXQ_UP(DMXQ_BF16);
 #undef DMXQ_UPK

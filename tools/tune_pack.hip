@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
   std::vector<uint16_t> h(n);
   uint64_t s = 88172645463325252ull;
   for (int64_t i = 0; i < n; i++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = (uint16_t)(((s >> 20) & 0x8FFF) | 0x3000) ^ (uint16_t)((s >> 40) & 0x0F00); }
-  for (int b = 0; b < NBUF; b++) { CK(hipMalloc(&in[b], n * 2)); CK(hipMalloc((void**)&mant[b], n)); CK(hipMalloc((void**)&exps[b], n / 8)); CK(hipMemcpy(in[b], h.data(), n * 2, hipMemcpyHostToDevice)); }
+  for (int b = 0; b < NBUF; b++) { CK(hipMalloc(&in[b], n * 4)); CK(hipMalloc((void**)&mant[b], n)); CK(hipMalloc((void**)&exps[b], n / 8)); CK(hipMemcpy(in[b], h.data(), n * 2, hipMemcpyHostToDevice)); }
   hipStream_t st; CK(hipStreamCreate(&st));
   std::vector<Variant> vs;
 #define ADDG(B_, V_, T_, U_) vs.push_back({"B=" #B_ " VAR " #V_ " " #T_ "x" #U_, [=](const void* i, int8_t* m, uint8_t* e, hipStream_t q) { \
@@ -39,7 +39,12 @@ int main(int argc, char** argv) {
   int bshift16 = 1, bshift64 = 3;
 #define ADDU(P_, U_) vs.push_back({"unpack B=16 " #P_ " x" #U_, [=](const void* i, int8_t* m, uint8_t* e, hipStream_t q) { \
     hipLaunchKernelGGL((bfp_unpack_vec_kernel<DMXQ_BF16, P_, U_>), dim3((unsigned)((n_vec + kThreads * U_ - 1) / (kThreads * U_))), dim3(kThreads), 0, q, m, e, (void*)i, n_vec, bshift16, 8); }, {}})
-  if (getenv("TUNE_UNPACK")) { vs.clear(); ADDU(false, 8); ADDU(true, 8); ADDU(false, 4); ADDU(true, 4); ADDU(true, 2); ADDU(true, 16); (void)bshift64; }
+#define ADDUF(P_, U_, BS_) vs.push_back({"unpack f32 bs" #BS_ " " #P_ " x" #U_, [=](const void* i, int8_t* m, uint8_t* e, hipStream_t q) { \
+    hipLaunchKernelGGL((bfp_unpack_vec_kernel<DMXQ_F32, P_, U_>), dim3((unsigned)((n_vec + kThreads * U_ - 1) / (kThreads * U_))), dim3(kThreads), 0, q, m, e, (void*)i, n_vec, BS_, 8); }, {}})
+#define ADDUR(U_, BL_) vs.push_back({"unpack f32 regions B=2^" #BL_ " x" #U_, [=](const void* i, int8_t* m, uint8_t* e, hipStream_t q) { \
+    hipLaunchKernelGGL((bfp_unpack_f32_kernel<U_>), dim3((unsigned)((n_vec + kThreads * U_ - 1) / (kThreads * U_))), dim3(kThreads), 0, q, m, e, (float*)i, n_vec * 8, BL_, 8); }, {}})
+  if (getenv("TUNE_UNPACK_F32")) { vs.clear(); ADDUR(1, 4); ADDUR(2, 4); ADDUR(4, 4); ADDUR(8, 4); ADDUR(2, 6); ADDUR(4, 6); ADDUF(false, 8, 1); ADDUF(true, 8, 1); ADDUF(false, 4, 1); ADDUF(true, 4, 1); ADDUF(false, 2, 1); ADDUF(true, 2, 1); ADDUF(true, 2, 3); ADDUF(true, 4, 3); ADDUF(true, 8, 3); }
+  else if (getenv("TUNE_UNPACK")) { vs.clear(); ADDU(false, 8); ADDU(true, 8); ADDU(false, 4); ADDU(true, 4); ADDU(true, 2); ADDU(true, 16); (void)bshift64; }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto& v : vs) for (int i = 0; i < 10; i++) v.run(in[i % NBUF], mant[i % NBUF], exps[i % NBUF], st);
   CK(hipStreamSynchronize(st));
@@ -57,7 +62,7 @@ int main(int argc, char** argv) {
   for (auto& v : vs) {
     std::sort(v.us.begin(), v.us.end());
     const float med = v.us[v.us.size() / 2];
-    const double bytes = 3.0 * n + (double)n / (v.name[0] == 'u' || v.name[2] == '1' ? 16 : 64);
+    const double bytes = (v.name.find("f32") != std::string::npos ? 5.0 : 3.0) * n + (double)n / (v.name[0] == 'u' || v.name[2] == '1' ? 16 : 64);
     printf("%-16s %9.2f %9.2f %8.1f%%\n", v.name.c_str(), v.us[0], med, 100.0 * bytes / (med * 1e-6) / 8e12);
   }
   return 0;
