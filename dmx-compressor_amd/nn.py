@@ -514,8 +514,7 @@ class DmxModule(torch.nn.Module):
                 input = self.smoothquant.scale_input(input)
         if fused is not None:
             _input, args, kwargs = self.input_casts(fused, *args, first_done=True, **kwargs)
-        elif (not torch.compiler.is_compiling() and getattr(input, "_dmx_precast", None) is not None
-              and any(c is self._first_input_cast() for c in input._dmx_precast)):
+        elif not torch.compiler.is_compiling() and any(c is self._first_input_cast() for c in _precast_of(input)):
             # the producer already applied THIS module's first input cast in its own launch (nn.link_consumer)
             _input, args, kwargs = self.input_casts(input, *args, first_done=True, **kwargs)
         else:
@@ -646,6 +645,20 @@ def _range_only_format(cast, dtype):
     return True, fmt
 
 
+def _tag_precast(out, casts):
+    """mark a producer's result as already holding its consumers' first input cast (nn.link_consumer): the consumers' cast OBJECTS and
+    the tensor's version counter -- an in-place change of the value afterwards voids the mark"""
+    out._dmx_precast = casts
+    out._dmx_precast_version = out._version
+
+
+def _precast_of(t):
+    casts = getattr(t, "_dmx_precast", None)
+    if casts is None or getattr(t, "_dmx_precast_version", -1) != t._version:
+        return ()
+    return casts
+
+
 class _BinaryElementwise(DmxModule):
     """ResAdd / Mul: two cast inputs, one elementwise op, one cast output (torch_modules.py:36-80).  In inference on same-shape
     tensors whose three casts are SAME or nearest-rounding FloatingPoint formats the whole module is ONE launch (dmxq_binary_cast:
@@ -676,7 +689,7 @@ class _BinaryElementwise(DmxModule):
         if nc is not None:   # the consumer's BFP input cast in this launch (dmxq_binary_cast_bfp); see Softmax._fused_forward
             out = ops.binary_cast(a.detach(), b.detach(), self._op, *fmts, then_bfp=(nc[1].precision, nc[1].block_size))
             if out is not None:
-                out._dmx_precast = nc[0]
+                _tag_precast(out, nc[0])
                 return out
         return ops.binary_cast(a.detach(), b.detach(), self._op, *fmts)
 
@@ -729,7 +742,7 @@ class Softmax(DmxModule, torch.nn.Softmax):
         if nc is not None:
             out = ops.softmax_cast(x.detach(), -1, c[0], c[1], c[2].get("input_clamp"), then_bfp=(nc[1].precision, nc[1].block_size))
             if out is not None:
-                out._dmx_precast = nc[0]   # a consumer's forward recognises ITS cast object among these and skips it (DmxModule.forward)
+                _tag_precast(out, nc[0])   # a consumer's forward recognises ITS cast object among these and skips it (DmxModule.forward)
                 self.approximation_error = None
                 return out
         out = ops.softmax_cast(x.detach(), -1, c[0], c[1], c[2].get("input_clamp"))
@@ -761,7 +774,7 @@ class LayerNorm(DmxModule, torch.nn.LayerNorm):
         if nc is not None:   # the consumers' BFP input cast in the same launch (nn.link_consumer)
             out = ops.layernorm_cast(x.detach(), self.normalized_shape, w, b, self.eps, c[0], c[1], then_bfp=(nc[1].precision, nc[1].block_size))
             if out is not None:
-                out._dmx_precast = nc[0]
+                _tag_precast(out, nc[0])
                 self.approximation_error = None
                 return out
         out = ops.layernorm_cast(x.detach(), self.normalized_shape, w, b, self.eps, c[0], c[1])
@@ -916,7 +929,7 @@ class RMSNorm(DmxModule, torch.nn.RMSNorm):
         if nc is not None:   # the consumers' BFP input cast in the same launch (nn.link_consumer)
             out = ops.rmsnorm_cast(x.detach(), self.normalized_shape, w, self.eps, c[0], c[1], then_bfp=(nc[1].precision, nc[1].block_size))
             if out is not None:
-                out._dmx_precast = nc[0]
+                _tag_precast(out, nc[0])
                 self.approximation_error = None
                 return out
         out = ops.rmsnorm_cast(x.detach(), self.normalized_shape, w, self.eps, c[0], c[1])
@@ -953,7 +966,7 @@ class ReLU(DmxModule, torch.nn.ReLU):
         if nc is not None:   # the consumer's BFP input cast in this launch (dmxq_relu_cast_bfp)
             out = ops.relu_cast(x.detach(), fi, fo, then_bfp=(nc[1].precision, nc[1].block_size))
             if out is not None:
-                out._dmx_precast = nc[0]
+                _tag_precast(out, nc[0])
                 return out
         return ops.relu_cast(x.detach(), fi, fo)
 

@@ -597,6 +597,9 @@ def test_linked_mul_and_relu_feed_a_linear_without_a_second_pass(dmx, cuda):
                 h = prod(*args)
                 assert getattr(h, "_dmx_precast", None) == (lin._first_input_cast(),), type(prod).__name__
                 assert torch.equal(lin(h), want)
+                h = prod(*args)
+                h.mul_(1.7)                                                  # changed in place after the producer returned it: the mark is void
+                assert torch.equal(lin(h), lin(h.clone()))
                 lin.configure(dict(input_formats=["BFP[8|8]{64}(SS)"]))     # stochastic rounding: not the fused cast
                 assert getattr(prod(*args), "_dmx_precast", None) is None
                 lin.configure(dict(input_formats=["BFP[8|8]{64}(SN)"]))
