@@ -166,6 +166,87 @@ static void launch_nm_vec(const NmArgs& a, int64_t n, hipStream_t s) {
                      a, n_units);
 }
 
+// float32 score -> float32 mask (BlockTopK.forward on a float32 weight's score: the standalone mask op), M in {2, 4, 8}.  In the
+// kernel above a lane owns 8 consecutive elements = 32 bytes of each float32 stream, i.e. two 16-byte accesses 32 bytes apart: every
+// load / store instruction of a wave touches half of each line it covers (59 % of roofline).  Here a lane owns ONE 16-byte vector per
+// slot -- whole groups for M <= 4; for M = 8 neighbouring lanes swap vectors of two slots (DPP quad_perm, as csrc/bfp_pack.hip), so the
+// even lane ranks the pair's group of slot 2k and the odd lane that of slot 2k + 1, and the mask bits travel back the same way --,
+// workgroup-contiguous one-pass tiles, all loads first.  n_vec % 2 == 0 for M = 8 (whole groups).
+template <int M, int UN>
+__global__ __launch_bounds__(kThreads) void nm_mask_f32_kernel(const float* __restrict__ score, float* __restrict__ mask, int64_t n_vec, int K) {
+  static_assert(M == 2 || M == 4 || M == 8, "groups of 2, 4 or 8");
+  static_assert(UN % 2 == 0, "slots are taken in pairs");
+  const int64_t base = (int64_t)blockIdx.x * (kThreads * UN) + threadIdx.x;
+  u32x4 raw[UN];
+#pragma unroll
+  for (int u = 0; u < UN; u++) {
+    const int64_t v = base + (int64_t)u * kThreads;
+    // clamped: unconditional loads (M = 8: the same position of the last pair, so that the exchange below moves defined data)
+    const int64_t vc = v < n_vec ? v : (M == 8 ? n_vec - 2 + (threadIdx.x & 1) : n_vec - 1);
+    raw[u] = load_raw16<true>(score, vc * 16);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const int thr = M - K;
+  auto rank_bits = [&](const int32_t (&key)[M]) __attribute__((always_inline)) -> uint32_t {
+    int rank[M];
+#pragma unroll
+    for (int i = 0; i < M; i++) rank[i] = 0;
+#pragma unroll
+    for (int i = 0; i < M; i++)
+#pragma unroll
+      for (int jj = 0; jj < i; jj++) {
+        const bool jj_first = key[jj] <= key[i];  // equal keys: the lower index sorts first
+        rank[i] += jj_first ? 1 : 0;
+        rank[jj] += jj_first ? 0 : 1;
+      }
+    uint32_t bits = 0u;
+#pragma unroll
+    for (int i = 0; i < M; i++) bits |= rank[i] >= thr ? (1u << i) : 0u;
+    return bits;
+  };
+  auto store_bits = [&](int64_t v, uint32_t b4) __attribute__((always_inline)) {
+    if (v < n_vec) {
+      const uint32_t one = 0x3F800000u;
+      __builtin_nontemporal_store(u32x4{(b4 & 1u) ? one : 0u, (b4 & 2u) ? one : 0u, (b4 & 4u) ? one : 0u, (b4 & 8u) ? one : 0u}, (u32x4*)(mask + v * 4));
+    }
+  };
+  if constexpr (M <= 4) {
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      uint32_t b4 = 0u;
+#pragma unroll
+      for (int g = 0; g < 4; g += M) {
+        int32_t key[M];
+#pragma unroll
+        for (int i = 0; i < M; i++) key[i] = sort_key(u2f(raw[u][g + i]));
+        b4 |= rank_bits(key) << g;
+      }
+      store_bits(base + (int64_t)u * kThreads, b4);
+    }
+  } else {
+    const bool odd = (threadIdx.x & 1) != 0;
+#pragma unroll
+    for (int u = 0; u < UN; u += 2) {
+      // the even lane gives away its slot u + 1 vector, the odd lane its slot u vector
+      u32x4 r;
+#pragma unroll
+      for (int j = 0; j < 4; j++) r[j] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(odd ? raw[u][j] : raw[u + 1][j]), 0xB1, 0xF, 0xF, false);
+      int32_t key[8];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        key[j] = sort_key(u2f(odd ? r[j] : raw[u][j]));              // first half of the group: the even lane's vector
+        key[4 + j] = sort_key(u2f(odd ? raw[u + 1][j] : r[j]));      // second half: the odd lane's
+      }
+      const uint32_t b8 = rank_bits(key);
+      // even lane: bits 0-3 are its own slot-u vector, bits 4-7 the odd lane's slot-u vector; odd lane: bits 0-3 the even lane's slot u + 1
+      // vector, bits 4-7 its own
+      const uint32_t back = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(odd ? (b8 & 0xFu) : (b8 >> 4)), 0xB1, 0xF, 0xF, false);
+      store_bits(base + (int64_t)u * kThreads, odd ? back : (b8 & 0xFu));
+      store_bits(base + (int64_t)(u + 1) * kThreads, odd ? (b8 >> 4) : back);
+    }
+  }
+}
+
 // any M <= 64: same rule with runtime loops (scores re-read instead of kept in registers)
 __global__ __launch_bounds__(kThreads) void nm_mask_anyM_kernel(NmArgs a, int M) {
   const int64_t ngrp = a.L / M;
@@ -217,6 +298,19 @@ extern "C" int dmxq_nm_mask(const void* score, int dtype_score, const void* x, i
   if (vec_ok && y_out && !mask_out) {
     const int rc = dmxq_internal_nm_sparsify_typed(score, dtype_score, x, dtype_x, y_out, dtype_y, n, K, M, stream);
     if (rc != DMXQ_ERR_UNSUPPORTED) return rc;
+  }
+  if (vec_ok && mask_out && !y_out && dtype_score == DMXQ_F32 && dtype_mask == DMXQ_F32 && M <= 8) {
+    constexpr int UN = 4;
+    const int64_t n_vec = n / 4;
+    const int64_t tiles = (n_vec + kThreads * UN - 1) / (kThreads * UN);
+    if (tiles <= 0x7FFFFFFF) {
+      switch (M) {
+        case 2: DMXQ_LAUNCH((nm_mask_f32_kernel<2, UN>), dim3((unsigned)tiles), dim3(kThreads), 0, s, (const float*)score, (float*)mask_out, n_vec, K); break;
+        case 4: DMXQ_LAUNCH((nm_mask_f32_kernel<4, UN>), dim3((unsigned)tiles), dim3(kThreads), 0, s, (const float*)score, (float*)mask_out, n_vec, K); break;
+        default: DMXQ_LAUNCH((nm_mask_f32_kernel<8, UN>), dim3((unsigned)tiles), dim3(kThreads), 0, s, (const float*)score, (float*)mask_out, n_vec, K); break;
+      }
+      return launch_status();
+    }
   }
   if (vec_ok) {
     switch (M) {

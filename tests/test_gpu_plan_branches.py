@@ -274,3 +274,24 @@ def test_packed_bfp_geometry_branches(dmx, cuda, dtype):
         ok = ((e > 0) & (e < 255)).repeat_interleave(B, dim=-1)
         y, q = ops.bfp_unpack(m, e, 8, B, torch.float32), ops.bfp_qdq(x, 8, B, out_dtype=torch.float32)
         assert torch.equal(y[ok].view(torch.int32), q[ok].view(torch.int32)), (rows, L, B)
+
+
+def test_float32_nm_mask_kernel_equals_the_general_vector_kernel(dmx, cuda):
+    """float32 score -> float32 mask takes its own kernel (csrc/nm_mask.hip nm_mask_f32_kernel: one 16-byte vector per lane and slot, M = 8
+    groups assembled by a neighbour-lane exchange); the same score with a bfloat16 mask takes the general vector kernel the oracle tests pin:
+    the masks must agree, with ties, +-0, NaN and Inf in the groups, on sizes with partial last tiles."""
+    ops = dmx.ops
+    for rows, cols in [(300, 4096), (4096, 4096), (5, 48), (1, 16), (1030, 1040)]:
+        s = make("heavy", (rows, cols), seed=rows + cols, dtype=torch.float32)
+        s.view(-1)[::7] = 0.0
+        s.view(-1)[3::11] = -0.0
+        s.view(-1)[5::13] = 1.5            # ties
+        s.view(-1)[1::97] = float("nan")
+        s.view(-1)[2::101] = float("inf")
+        s.view(-1)[4::103] = -float("inf")
+        s = s.to(cuda)
+        for K, M in [(1, 2), (2, 4), (1, 4), (3, 4), (4, 8), (2, 8), (7, 8), (8, 8)]:
+            m32 = ops.nm_mask(s, K, M)
+            m16 = ops.nm_mask(s, K, M, mask_dtype=torch.bfloat16)
+            assert m32.dtype == torch.float32 and torch.equal(m32, m16.float()), (rows, cols, K, M)
+            assert int(m32.sum()) == s.numel() // M * K
