@@ -21,10 +21,20 @@ namespace dmxq {
 // ~350 VALU before the first HBM request of a workgroup (48 % of roofline for per-channel INT8).  Every row is converted into
 // registers, then the stores go out as one burst (the schedule of bfp_rows.hpp).  One pass per workgroup and 16 rows in flight
 // measured best throughout: looping workgroups (2-16 passes) lost 10-50 %.
-template <int DTI, int DTO, class OP, int THREADS, int RPI>
+// IVB = input bytes per lane-vector: 16, or 8 for a 16-bit -> float32 launch of the per-element ops (launch_lastdim below): the lane then
+// owns 4 elements, loads 8 bytes and STORES 16 contiguous ones, so that every store instruction of a wave covers whole lines -- with 16-byte
+// loads a lane's 8 float32 results are two 16-byte stores 32 bytes apart, half-written lines per instruction (x / s, bf16 -> float32 on
+// 4096 x 4096: 30.3 us; the same finding as bfp_rows.hpp's IVB).
+template <int IVB>
+__device__ __forceinline__ u32x4 lastdim_load(const void* p, int64_t off) {
+  if constexpr (IVB == 16) return load_raw16<true>(p, off);
+  const u32x2 t = __builtin_nontemporal_load((const u32x2*)((const char*)p + off));
+  return u32x4{t.x, t.y, 0u, 0u};
+}
+template <int DTI, int DTO, class OP, int THREADS, int RPI, int IVB = 16>
 __global__ __launch_bounds__(THREADS) void lastdim_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t rows,
                                                          int64_t C, int cv, int lpr, int rpp, OP op) {
-  constexpr int EPL = 16 / Elem<DTI>::bytes, OVB = EPL * Elem<DTO>::bytes;
+  constexpr int EPL = IVB / Elem<DTI>::bytes, OVB = EPL * Elem<DTO>::bytes;
   const int t = threadIdx.x;
   const int sub = t / lpr, sl = t - sub * lpr;
   const int cb = blockIdx.y * lpr + sl;
@@ -39,14 +49,17 @@ __global__ __launch_bounds__(THREADS) void lastdim_kernel(const void* __restrict
   const uint32_t lane_v = (uint32_t)subc * (uint32_t)cv + (uint32_t)cbc;
   u32x4 raw[RPI];
   if (whole) {
-    const char* src = (const char*)in + r0 * cv * 16;
+    const char* src = (const char*)in + r0 * cv * IVB;
 #pragma unroll
-    for (int j = 0; j < RPI; j++) raw[j] = load_raw16<true, uint32_t>(src + (int64_t)j * rpp * cv * 16, lane_v * 16u);
+    for (int j = 0; j < RPI; j++) {
+      if constexpr (IVB == 16) raw[j] = load_raw16<true, uint32_t>(src + (int64_t)j * rpp * cv * 16, lane_v * 16u);
+      else raw[j] = lastdim_load<IVB>(src + (int64_t)j * rpp * cv * IVB, (int64_t)(lane_v * (uint32_t)IVB));
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < RPI; j++) {
       const int64_t r = r0 + (int64_t)j * rpp + subc;
-      raw[j] = load_raw16<true>(in, ((r < rows ? r : rows - 1) * cv + cbc) * 16);
+      raw[j] = lastdim_load<IVB>(in, ((r < rows ? r : rows - 1) * cv + cbc) * IVB);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -57,7 +70,14 @@ __global__ __launch_bounds__(THREADS) void lastdim_kernel(const void* __restrict
   for (int j = 0; j < RPI; j++) {
     const int64_t r = r0 + (int64_t)j * rpp + sub;
     float x[EPL], y[EPL];
-    widen<DTI, EPL>(raw[j], x);
+    if constexpr (IVB == 16) {
+      widen<DTI, EPL>(raw[j], x);
+    } else {
+      float xw[16 / Elem<DTI>::bytes];
+      widen<DTI, 16 / Elem<DTI>::bytes>(raw[j], xw);
+#pragma unroll
+      for (int k = 0; k < EPL; k++) x[k] = xw[k];
+    }
     op.apply_chan(x, p, y, r * C + (int64_t)cb * EPL);
     o[j] = pack_vec<DTO, EPL>(y);
     __builtin_amdgcn_sched_barrier(0);
@@ -79,8 +99,8 @@ __global__ __launch_bounds__(THREADS) void lastdim_kernel(const void* __restrict
 
 // Geometry of one lastdim launch: THREADS lanes per workgroup, RPI rows per lane, gx workgroups along the rows
 struct LastdimPlan { int threads, rpi; int64_t gx; int cv, lpr, rpp, strips; };
-static inline bool lastdim_plan(int dti, int dto, int64_t rows, int64_t C, LastdimPlan* pl) {
-  const int epl = dti == DMXQ_F32 ? 4 : 8;
+static inline bool lastdim_plan(int dti, int dto, int64_t rows, int64_t C, LastdimPlan* pl, int ivb = 16) {
+  const int epl = ivb / (dti == DMXQ_F32 ? 4 : 2);
   if (C % epl != 0 || C / epl > 0x7FFFFFFF || rows < 1) return false;
   const int cv = (int)(C / epl);
   const int threads = kThreads;
@@ -90,7 +110,7 @@ static inline bool lastdim_plan(int dti, int dto, int64_t rows, int64_t C, Lastd
   // rows per lane: as many (16, 8, 4) as still leave two workgroups per CU
   // (a widening output -- 32 bytes per lane, two half-line stores -- keeps 8: with 16 the partial lines of a row group no longer merge
   //  before they leave the L2, 95 MB written for 67 MB of output and 34.0 instead of 30.3 us, bf16 -> float32 x / s on 4096 x 4096)
-  int rpi = (dto == DMXQ_F32 && dti != DMXQ_F32) ? 8 : 16;
+  int rpi = (dto == DMXQ_F32 && dti != DMXQ_F32 && ivb == 16) ? 8 : 16;
   while (rpi > 4 && ((rows + (int64_t)rpp * rpi - 1) / ((int64_t)rpp * rpi)) * strips < 512) rpi >>= 1;
   const int64_t gx = (rows + (int64_t)rpp * rpi - 1) / ((int64_t)rpp * rpi);
   if (gx > 0x7FFFFFFF) return false;
@@ -99,12 +119,12 @@ static inline bool lastdim_plan(int dti, int dto, int64_t rows, int64_t C, Lastd
 }
 
 // DMXQ_ERR_UNSUPPORTED: not applicable (caller keeps its other kernel)
-template <int DTI, int DTO, class OP>
+template <int DTI, int DTO, class OP, int IVB = 16>
 static int launch_lastdim_typed(const void* in, void* out, int64_t rows, int64_t C, const OP& op, hipStream_t s) {
   LastdimPlan pl;
-  if (!aligned16(in) || !aligned16(out) || !lastdim_plan(DTI, DTO, rows, C, &pl)) return DMXQ_ERR_UNSUPPORTED;
+  if (!aligned16(in) || !aligned16(out) || !lastdim_plan(DTI, DTO, rows, C, &pl, IVB)) return DMXQ_ERR_UNSUPPORTED;
 #define DMXQ_LDK(R_)                                                                                                          \
-  DMXQ_LAUNCH((lastdim_kernel<DTI, DTO, OP, kThreads, R_>), dim3((unsigned)pl.gx, (unsigned)pl.strips), dim3(kThreads), 0, s, in, out, rows, C, \
+  DMXQ_LAUNCH((lastdim_kernel<DTI, DTO, OP, kThreads, R_, IVB>), dim3((unsigned)pl.gx, (unsigned)pl.strips), dim3(kThreads), 0, s, in, out, rows, C, \
               pl.cv, pl.lpr, pl.rpp, op)
   if (pl.rpi == 16) DMXQ_LDK(16);
   else if (pl.rpi == 8) DMXQ_LDK(8);
@@ -120,9 +140,10 @@ static int launch_lastdim(const void* in, void* out, int dti, int dto, int64_t r
   DMXQ_LD(DMXQ_BF16, DMXQ_BF16)
   DMXQ_LD(DMXQ_F16, DMXQ_F16)
   DMXQ_LD(DMXQ_F32, DMXQ_F32)
-  DMXQ_LD(DMXQ_BF16, DMXQ_F32)
-  DMXQ_LD(DMXQ_F16, DMXQ_F32)
 #undef DMXQ_LD
+  // 16-bit -> float32: 8-byte loads, 16-byte stores (see lastdim_kernel)
+  if (dti == DMXQ_BF16 && dto == DMXQ_F32) return launch_lastdim_typed<DMXQ_BF16, DMXQ_F32, OP, 8>(in, out, rows, C, op, s);
+  if (dti == DMXQ_F16 && dto == DMXQ_F32) return launch_lastdim_typed<DMXQ_F16, DMXQ_F32, OP, 8>(in, out, rows, C, op, s);
   return DMXQ_ERR_UNSUPPORTED;
 }
 

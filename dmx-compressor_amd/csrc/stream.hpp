@@ -45,17 +45,39 @@ template <class OP> struct OpTilePrep<OP, std::void_t<decltype(OP::kTilePrep)>> 
 template <class OP, class = void> struct OpRawHooks { static constexpr bool value = false; };
 template <class OP> struct OpRawHooks<OP, std::void_t<decltype(OP::kRawHooks)>> { static constexpr bool value = OP::kRawHooks; };
 
-template <int DTI, int DTO, int UNROLL, int THREADS, class OP, bool UNAL = false>
+// IVB = input bytes per lane-vector: 16, or 8 for aligned 16-bit -> float32 launches -- the lane then owns 4 elements and its results
+// are ONE 16-byte store, every store instruction of a wave covering whole lines (with 16-byte loads they are two 16-byte stores 32 bytes
+// apart: half-written lines per instruction, ~40 % of the bandwidth; bfp_rows.hpp, lastdim.hpp).
+template <int IVB, bool UNAL>
+__device__ __forceinline__ u32x4 stream_load(const char* p, uint32_t off) {
+  if constexpr (IVB == 16) return load_raw16<true, uint32_t, UNAL>(p, off);
+  const u32x2 t = __builtin_nontemporal_load((const u32x2*)(p + off));
+  return u32x4{t.x, t.y, 0u, 0u};
+}
+template <int DTI, int EPL>
+__device__ __forceinline__ void stream_widen(const u32x4& raw, float (&x)[EPL]) {
+  constexpr int FULL = 16 / Elem<DTI>::bytes;
+  if constexpr (EPL == FULL) {
+    widen<DTI, FULL>(raw, x);
+  } else {
+    float xw[FULL];
+    widen<DTI, FULL>(raw, xw);
+#pragma unroll
+    for (int k = 0; k < EPL; k++) x[k] = xw[k];
+  }
+}
+template <int DTI, int DTO, int UNROLL, int THREADS, class OP, bool UNAL = false, int IVB = 16>
 __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                         int64_t n, OP op) {
-  constexpr int EPL = 16 / Elem<DTI>::bytes;
+  static_assert(IVB == 16 || (IVB == 8 && !UNAL && !OpRawHooks<OP>::value), "8-byte input vectors: aligned tensors, no raw-word hooks");
+  constexpr int EPL = IVB / Elem<DTI>::bytes;
   constexpr int OVB = EPL * Elem<DTO>::bytes;
   constexpr int64_t TILE = (int64_t)THREADS * UNROLL;
   const int64_t n_vec = n / EPL;
   const int64_t n_tiles = (n_vec + TILE - 1) / TILE;
-  const uint32_t lane_in = threadIdx.x * 16u, lane_out = threadIdx.x * (uint32_t)OVB;
+  const uint32_t lane_in = threadIdx.x * (uint32_t)IVB, lane_out = threadIdx.x * (uint32_t)OVB;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const char* src = (const char*)in + tile * (TILE * 16);
+    const char* src = (const char*)in + tile * (TILE * IVB);
     char* dst = (char*)out + tile * (TILE * OVB);
     const int64_t v0 = tile * TILE + threadIdx.x;
     if ((tile + 1) * TILE <= n_vec) {
@@ -66,14 +88,14 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict_
         __builtin_amdgcn_sched_barrier(0);
         u32x4 raw[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) raw[u] = load_raw16<true, uint32_t, UNAL>(src + u * (THREADS * 16), lane_in);
+        for (int u = 0; u < UNROLL; u++) raw[u] = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
         __builtin_amdgcn_sched_barrier(0);
         OutVec<DTO, EPL> o[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
           float x[EPL], y[EPL];
           if constexpr (OpRawHooks<OP>::value) op.raw_in(raw[u]);
-          widen<DTI, EPL>(raw[u], x);
+          stream_widen<DTI, EPL>(raw[u], x);
           OpPrep<OP>::apply(op, x, y, (v0 + (int64_t)u * THREADS) * EPL, prep_of(u));
           o[u] = pack_vec<DTO, EPL>(y);
           if constexpr (OpRawHooks<OP>::value) op.raw_out(o[u]);
@@ -99,10 +121,10 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict_
       for (int u = 0; u < UNROLL; u++) {
         const int64_t vi = v0 + (int64_t)u * THREADS;
         if (vi < n_vec) {
-          u32x4 raw = load_raw16<true, uint32_t, UNAL>(src + u * (THREADS * 16), lane_in);
+          u32x4 raw = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
           float x[EPL], y[EPL];
           if constexpr (OpRawHooks<OP>::value) op.raw_in(raw);
-          widen<DTI, EPL>(raw, x);
+          stream_widen<DTI, EPL>(raw, x);
           op.apply_vec(x, y, vi * EPL);
           OutVec<DTO, EPL> o1 = pack_vec<DTO, EPL>(y);
           if constexpr (OpRawHooks<OP>::value) op.raw_out(o1);
@@ -142,8 +164,28 @@ template <class OP> struct OpTileThreads<OP, decltype((void)OP::kTileThreads)> {
 
 template <int DTI, int DTO, class OP>
 static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hipStream_t s) {
+  constexpr bool WIDE = Elem<DTO>::bytes > Elem<DTI>::bytes;
+  if constexpr (WIDE && !OpRawHooks<OP>::value) {
+    // 16-bit -> float32 on aligned tensors: lane-vectors of 4 elements (8 bytes in, 16 out), the geometry rule applied to the OUTPUT bytes
+    if (aligned16(in) && aligned16(out)) {
+      const int64_t nv = n / 4;
+#define DMXQ_STREAM8(T_, U_)                                                                                           \
+  do {                                                                                                                 \
+    int64_t tiles = (nv + (int64_t)(T_) * (U_) - 1) / ((int64_t)(T_) * (U_));                                          \
+    if (tiles < 1) tiles = 1;                                                                                          \
+    if (tiles > (1 << 20)) tiles = 1 << 20;                                                                            \
+    DMXQ_LAUNCH((stream_kernel<DTI, DTO, U_, T_, OP, false, 8>), dim3((unsigned)tiles), dim3(T_), 0, s, in, out, n, op); \
+  } while (0)
+      if (nv <= ((int64_t)1 << 17)) DMXQ_STREAM8(256, 1);
+      else if (nv <= ((int64_t)3 << 18)) DMXQ_STREAM8(256, 2);
+      else if (nv <= ((int64_t)1 << 21)) DMXQ_STREAM8(256, 4);
+      else DMXQ_STREAM8(256, 2);
+#undef DMXQ_STREAM8
+      return launch_status();
+    }
+  }
   constexpr int EPL = 16 / Elem<DTI>::bytes;
-  constexpr int UB = (Elem<DTO>::bytes > Elem<DTI>::bytes) ? 8 : 16;  // (a widening output doubles the registers a vector holds)
+  constexpr int UB = WIDE ? 8 : 16;  // (a widening output doubles the registers a vector holds)
   constexpr int TT = OpTileThreads<OP>::value, TU = OpTileUnroll<OP>::value < UB ? OpTileUnroll<OP>::value : UB;
   static_assert(TU == 16 || TU == 8 || TU == 4 || TU == 2, "kTileUnroll");
   static_assert(TT == 64 || TT == 128 || TT == 256 || TT == 512, "kTileThreads");

@@ -295,3 +295,32 @@ def test_float32_nm_mask_kernel_equals_the_general_vector_kernel(dmx, cuda):
             m16 = ops.nm_mask(s, K, M, mask_dtype=torch.bfloat16)
             assert m32.dtype == torch.float32 and torch.equal(m32, m16.float()), (rows, cols, K, M)
             assert int(m32.sum()) == s.numel() // M * K
+
+
+@pytest.mark.parametrize("rows", [300, 1600, 4096, 4200])
+@pytest.mark.parametrize("dtype", [BF16, F16], ids=["bf16", "f16"])
+def test_widening_outputs_take_the_same_values_on_every_geometry(dmx, cuda, rows, dtype):
+    """16-bit in, float32 out: the flat-stream and per-channel kernels give a lane 4 elements (8-byte loads, ONE 16-byte store: every
+    store instruction covers whole lines) instead of 8 -- csrc/stream.hpp / lastdim.hpp IVB.  Whole tensor == its 128-row slabs (the
+    small branch the oracle tests pin, tests/test_gpu_elementwise.py), and == the same-dtype result where that is exact."""
+    ops = dmx.ops
+    x = _input(rows, dtype, seed=rows + 1).to(cuda)
+    C = x.shape[1]
+    sc = (torch.rand(C, device=cuda) * 0.05 + 0.01)
+    zp = torch.randint(-3, 4, (C,), device=cuda, dtype=torch.int64)
+    sq = torch.rand(C, device=cuda) + 0.5
+    cases = {
+        "float_qdq E4M3 -> f32": lambda t: ops.float_qdq(t, 3, 4, 7, False, out_dtype=F32),
+        "float_qdq FP16(FN) -> f32": lambda t: ops.float_qdq(t, 10, 5, 15, True, out_dtype=F32),
+        "fixed_qdq INT8 -> f32": lambda t: ops.fixed_qdq(t, 8, 0, out_dtype=F32),
+        "fixed_qdq INT8 per channel (last dim) -> f32": lambda t: ops.fixed_qdq(t, 8, 0, scale=sc, zero_point=zp, ch_axis=-1, out_dtype=F32),
+        "scale_channels x / s -> f32": lambda t: ops.scale_channels(t, sq, -1, True, out_dtype=F32),
+        "scale_channels x * s -> f32": lambda t: ops.scale_channels(t, sq, -1, False, out_dtype=F32),
+    }
+    for tag, fn in cases.items():
+        whole = fn(x)
+        assert whole.dtype == F32
+        _check(f"{tag} {dtype} rows={rows}", whole, _slabs(fn, x))
+    # the casts' values are representable in the input dtype here: the float32 output is the same-dtype output widened
+    assert bits_equal(ops.float_qdq(x, 10, 5, 15, True, out_dtype=F32), ops.float_qdq(x, 10, 5, 15, True).float()) == 0
+    assert bits_equal(ops.scale_channels(x, sq, -1, True, out_dtype=F32), x.float() / sq) == 0

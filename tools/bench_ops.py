@@ -184,6 +184,10 @@ def main():
         lambda i: L.dmxq_bfp_pack(vp(f32a[i % 6].data_ptr()), _lib.F32, vp(mant[i % k].data_ptr()), vp(exps[i % k].data_ptr()), R, C, 64, 8, 1, sp), 6, n * 5 + n // 64)
     run("bfp_unpack int8 codes + uint8 exponents -> float32, B=64",
         lambda i: L.dmxq_bfp_unpack(vp(mant[i % k].data_ptr()), vp(exps[i % k].data_ptr()), vp(f32o[i % 6].data_ptr()), _lib.F32, R, C, 64, 8, sp), 6, n * 5 + n // 64)
+    run("scale_channels bf16 -> float32, x / s along last dim (the unfused SmoothQuant input scaling of a bf16 model; 6 B/elem)",
+        lambda i: L.dmxq_scale_channels(vp(xs[i].data_ptr()), vp(f32o[i % 6].data_ptr()), _lib.BF16, _lib.F32, R, C, 1, vp(scc.data_ptr()), 1, sp), 6, n * 6)
+    run("float_qdq bf16 -> float32 E4M3 (widening output; 6 B/elem)",
+        lambda i: L.dmxq_float_qdq(vp(xs[i].data_ptr()), vp(f32o[i % 6].data_ptr()), _lib.BF16, _lib.F32, n, 3, 4, 7, 0, 0, 2, 0, sp), 6, n * 6)
     run("unary silu bf16", lambda i: L.dmxq_unary(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, n, 2, ctypes.c_float(0.0), sp), k, n * 4)
     run("unary quick_gelu bf16", lambda i: L.dmxq_unary(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, n, 3, ctypes.c_float(0.0), sp), k, n * 4)
     wr = torch.ones(C, device=dev, dtype=torch.bfloat16)
