@@ -201,6 +201,7 @@ struct MxfpBlock {
 template <class FMT, class BLK>
 struct BlockOp {
   static constexpr bool kHeavy = true;
+  static constexpr bool kFixedVector = true;  // a block is lpb adjacent lanes of 16-byte vectors: no 8-byte-vector form for widening outputs
   static constexpr int kTileUnroll = FMT::kUnroll, kTileThreads = FMT::kThreads;  // stream.hpp, 20-32 MiB tensors: SBFP 128 x 4 (13.7 vs 15.0 us for 512 x 2), MXFP 256 x 8 (12.3 vs 13.5 us for 256 x 2, with the x-domain element cast)
   FMT f;
   int lpb;

@@ -162,10 +162,14 @@ template <class OP> struct OpTileUnroll<OP, decltype((void)OP::kTileUnroll)> { s
 template <class OP, class = void> struct OpTileThreads { static constexpr int value = 256; };
 template <class OP> struct OpTileThreads<OP, decltype((void)OP::kTileThreads)> { static constexpr int value = OP::kTileThreads; };
 
+// An OP whose arithmetic is tied to the 16-byte lane-vector (blocks = adjacent lanes: blockfmt.hip) says `kFixedVector = true`
+template <class OP, class = void> struct OpFixedVector { static constexpr bool value = false; };
+template <class OP> struct OpFixedVector<OP, std::void_t<decltype(OP::kFixedVector)>> { static constexpr bool value = OP::kFixedVector; };
+
 template <int DTI, int DTO, class OP>
 static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hipStream_t s) {
   constexpr bool WIDE = Elem<DTO>::bytes > Elem<DTI>::bytes;
-  if constexpr (WIDE && !OpRawHooks<OP>::value) {
+  if constexpr (WIDE && !OpRawHooks<OP>::value && !OpFixedVector<OP>::value) {
     // 16-bit -> float32 on aligned tensors: lane-vectors of 4 elements (8 bytes in, 16 out), the geometry rule applied to the OUTPUT bytes
     if (aligned16(in) && aligned16(out)) {
       const int64_t nv = n / 4;
