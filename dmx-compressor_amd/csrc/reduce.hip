@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kFlatThreads) void group_minmax_flat_kernel(const v
 // partial maxima are combined through LDS and ONE wave issues the integer atomics.
 constexpr int kMaxabsThreads = 1024;  // 16 waves over rows per column strip: parallelism without more atomics
 constexpr int kMaxabsRows = 8;        // rows in flight per lane
-template <int DT>
+template <int DT, int U = kMaxabsRows>
 __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(const void* __restrict__ in,
                                                                            int64_t outer, int64_t C, int64_t inner,
                                                                            float* out) {
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(cons
   // a workgroup takes W * U consecutive rows per pass: wave w rows w, w + W, ...; the U row loads of a lane are all in flight
   // before the first is consumed (tools/tune_reduce.hip: W16 x U8 = 9.4 us on 4096 x 4096 bf16 against 11.6 us with 4 loads per
   // batch and 16 row splits).  Rows past the end re-read the last row: harmless for a maximum.
-  constexpr int U = kMaxabsRows;
+  // (U < 8: activations of a few thousand rows -- fewer rows per workgroup, more workgroups; see dmxq_channel_maxabs)
   if (ok) {
     for (int64_t o = (int64_t)blockIdx.y * (W * U) + w; o < outer; o += (int64_t)gridDim.y * (W * U)) {
       Raw8<DT> raw[U];
@@ -463,16 +463,24 @@ extern "C" int dmxq_channel_maxabs(const void* in, int dtype_in, int64_t outer, 
     int64_t gy = kMaxBlocks / gx;
     if (gy < 1) gy = 1;
     if (gy > outer) gy = outer;
+    int rows_in_flight = kMaxabsRows;
     if (vec) {  // one pass of 16 waves x 8 rows per workgroup, at most 64 row splits (each costs one atomic per channel)
-      const int64_t rows_per_pass = (kMaxabsThreads / kWave) * kMaxabsRows;
+      // a [1500, 768] activation (SmoothQuant calibration of Whisper-small) is 2 x 12 workgroups that way, 24 of 256 CUs, 10.2 us:
+      // 4 / 2 rows per lane while that leaves the chip short of workgroups and stays within the 64 splits
+      while (rows_in_flight > 2 && gx * ((outer + (kMaxabsThreads / kWave) * rows_in_flight - 1) / ((kMaxabsThreads / kWave) * rows_in_flight)) < 256 &&
+             (outer + (kMaxabsThreads / kWave) * (rows_in_flight / 2) - 1) / ((kMaxabsThreads / kWave) * (rows_in_flight / 2)) <= 64)
+        rows_in_flight /= 2;
+      const int64_t rows_per_pass = (kMaxabsThreads / kWave) * rows_in_flight;
       gy = (outer + rows_per_pass - 1) / rows_per_pass;
       if (gy > 64) gy = 64;
     }
     if (gy > 65535) gy = 65535;
     if (vec)
-#define DMXQ_MA(D_) DMXQ_LAUNCH(channel_maxabs_vec_kernel<D_>, dim3((unsigned)gx, (unsigned)gy), dim3(kMaxabsThreads), 0, s, in, outer, C, inner, out)
+#define DMXQ_MAU(D_, U_) DMXQ_LAUNCH((channel_maxabs_vec_kernel<D_, U_>), dim3((unsigned)gx, (unsigned)gy), dim3(kMaxabsThreads), 0, s, in, outer, C, inner, out)
+#define DMXQ_MA(D_) do { if (rows_in_flight == 8) DMXQ_MAU(D_, 8); else if (rows_in_flight == 4) DMXQ_MAU(D_, 4); else DMXQ_MAU(D_, 2); } while (0)
     { if (dtype_in == DMXQ_F32) DMXQ_MA(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_MA(DMXQ_F16); else DMXQ_MA(DMXQ_BF16); }
 #undef DMXQ_MA
+#undef DMXQ_MAU
     else
       DMXQ_LAUNCH(channel_maxabs_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, s, in, dtype_in,
                          outer, C, inner, out);
