@@ -106,7 +106,7 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
     const RowsPlan pl = rows_plan(n_vec, (F_) != 4);                                               \
     if constexpr ((F_) != 4) {                                                                     \
       if (pl.id == 2) { DMXQ_ROWS(512, 4, F_); break; }                                            \
-      if (pl.id == 3) { DMXQ_ROWS(512, 6, F_); break; }                                            \
+      if (pl.id == 3) { DMXQ_ROWS(128, 8, F_); break; }                                            \
       if (pl.id == 4) { DMXQ_ROWS(512, 16, F_); break; }                                           \
     }                                                                                              \
     if (pl.id == 0) DMXQ_ROWS(512, 1, F_);                                                         \

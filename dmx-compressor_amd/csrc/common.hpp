@@ -385,7 +385,7 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
 //   * up to 32 MiB of input the best shape keeps the WHOLE tensor in flight in one round of <= 2 workgroups per CU
 //     (every CU reads its share, computes, writes it: the phases stay in lockstep and HBM sees pure read bursts
 //     followed by pure write bursts): 512x1 (<= 4 MiB), 128x2 (<= 12 MiB: many small workgroups ramp fastest),
-//     512x4 (<= 16 MiB), 512x6 (<= 24 MiB), 512x16 (<= 32 MiB: the 4096x4096 bf16 headline tensor, 256 tiles);
+//     512x4 (<= 16 MiB), 128x8 (<= 20 MiB), 512x16 (<= 32 MiB: the 4096x4096 bf16 headline tensor, 256 tiles);
 //   * beyond that several rounds per CU are needed anyway, and small 512x2 tiles (4 resident workgroups per CU that
 //     desynchronise, so reads of one overlap writes of another) win: 77-79 % of 8 TB/s vs 68-71 % for 512x16.
 struct RowsPlan { int id, threads, unroll; int64_t tiles; };
@@ -395,7 +395,9 @@ inline RowsPlan rows_plan(int64_t n_vec, bool allow_big) {
   if (n_vec <= ((int64_t)3 << 18)) return mk(1, 128, 2);
   if (allow_big) {  // (the any-rounding build would spill at many vectors per lane: it goes straight to 512x2)
     if (n_vec <= ((int64_t)1 << 20)) return mk(2, 512, 4);
-    if (n_vec <= ((int64_t)3 << 19)) return mk(3, 512, 6);
+    // (round 3, tools/tune_bfp TUNE_SET=wg -> profiles/r03_tune_bfp_mid.txt: 512x6 measured 10.4 us on 3072 x 4096 bf16 against 9.35 for
+    //  512x16 and ~9.5 on 2560 rows against 7.98 for 128x8: 60 % -> 67-69 % of the roofline at 20-24 MiB)
+    if (n_vec <= ((int64_t)5 << 18)) return mk(3, 128, 8);
     if (n_vec <= ((int64_t)1 << 21)) return mk(4, 512, 16);
   }
   return mk(5, 512, 2);

@@ -528,7 +528,7 @@ static int launch_float_range_bf16(const void* in, void* out, int64_t n_vec, con
     case 0: DMXQ_RG(512, 1); break;
     case 1: DMXQ_RG(128, 2); break;
     case 2: DMXQ_RG(512, 4); break;
-    case 3: DMXQ_RG(512, 6); break;
+    case 3: DMXQ_RG(512, 16); break;  // (the 16-20 MiB class of rows_plan: the copy-like range kernel keeps one geometry up to 32 MiB)
     case 4: DMXQ_RG(512, 16); break;
     default: DMXQ_RG(512, 2); break;
   }

@@ -324,3 +324,23 @@ def test_widening_outputs_take_the_same_values_on_every_geometry(dmx, cuda, rows
     # the casts' values are representable in the input dtype here: the float32 output is the same-dtype output widened
     assert bits_equal(ops.float_qdq(x, 10, 5, 15, True, out_dtype=F32), ops.float_qdq(x, 10, 5, 15, True).float()) == 0
     assert bits_equal(ops.scale_channels(x, sq, -1, True, out_dtype=F32), x.float() / sq) == 0
+
+
+@pytest.mark.parametrize("rows", [600, 1400, 2000, 2500, 3072, 4096, 4200])
+@pytest.mark.parametrize("dtype", [BF16, F32], ids=["bf16", "f32"])
+def test_hot_kernel_tile_plans(dmx, cuda, rows, dtype):
+    """every size class of csrc/common.hpp rows_plan (512x1, 128x2, 512x4, 128x8, 512x16, 512x2; float32 tensors reach the classes at half
+    the rows) for the hot BFP kernel, its widening / stochastic / asymmetric builds and the range-only FLOAT16 cast that shares the plan:
+    whole tensor == 128-row slabs."""
+    ops = dmx.ops
+    x = _input(rows, dtype, seed=7 * rows).to(cuda)
+    cases = {
+        "BFP[8|8]{16}": lambda t: ops.bfp_qdq(t, 8, 16),
+        "BFP[8|8]{64}": lambda t: ops.bfp_qdq(t, 8, 64),
+        "BFP[8|8]{64} asym": lambda t: ops.bfp_qdq(t, 8, 64, symmetric=False),
+        "BFP[8|8]{32} down": lambda t: ops.bfp_qdq(t, 8, 32, rounding="down"),
+        "BFP[8|8]{64} -> f32": lambda t: ops.bfp_qdq(t, 8, 64, out_dtype=F32),
+        "FLOAT16 cast": lambda t: ops.float_qdq(t, 10, 5, 15, True),
+    }
+    for tag, fn in cases.items():
+        _check(f"{tag} {dtype} rows={rows}", fn(x), _slabs(fn, x))
