@@ -112,9 +112,9 @@ def test_fixed_multi_opt125m_int8_group128_matches_oracle(dmx, cuda, oracle):
             assert bits_equal(y, want) == 0, (i, shapes[i])
 
 
-# every tile geometry of rows_plan (csrc/bfp.hip): 512x1, 128x2, 512x4, 512x6, 512x16, 512x2, each with a partial last tile
-GEOMETRY_ROWS = [(200, "512x1"), (511, "512x1"), (1000, "128x2"), (1535, "128x2"), (2000, "512x4"), (2900, "512x6"),
-                 (3071, "512x6"), (4096, "512x16"), (3900, "512x16"), (5000, "512x2")]
+# every tile geometry of rows_plan (csrc/common.hpp): 512x1, 128x2, 512x4, 128x8, 512x16, 512x2, each with a partial last tile
+GEOMETRY_ROWS = [(200, "512x1"), (511, "512x1"), (1000, "128x2"), (1535, "128x2"), (2000, "512x4"), (2300, "128x8"), (2559, "128x8"),
+                 (2900, "512x16"), (3071, "512x16"), (4096, "512x16"), (3900, "512x16"), (5000, "512x2")]
 
 
 @pytest.mark.parametrize("rows,geom", GEOMETRY_ROWS)
@@ -128,7 +128,7 @@ def test_bfp_every_tile_geometry_at_its_size(dmx, cuda, oracle, rows, geom):
     assert bits_equal(got, oracle.bfp_cast(x, 8, 16).to(torch.bfloat16)) == 0
 
 
-@pytest.mark.parametrize("rows", [1000, 2900, 4096, 5000])
+@pytest.mark.parametrize("rows", [1000, 2400, 2900, 4096, 5000])
 @pytest.mark.parametrize("dtype,out_dtype,rounding", [(torch.float32, None, "nearest"), (torch.bfloat16, torch.float32, "nearest"),
                                                       (torch.bfloat16, None, "down"), (torch.float16, None, "stochastic")])
 def test_bfp_tile_geometries_other_builds(dmx, cuda, oracle, rows, dtype, out_dtype, rounding):
