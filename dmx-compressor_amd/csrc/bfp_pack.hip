@@ -145,7 +145,7 @@ __global__ __launch_bounds__(T) void bfp_pack_rows_kernel(const void* __restrict
   if constexpr (LDSE) {
     __syncthreads();
     const int64_t blk0 = tile0 >> lpb_log, nblk = n_vec >> lpb_log;
-    const int cnt = (T * U) >> lpb_log;  // >= 16: lpb <= 64
+    const int cnt = (T * U) >> lpb_log;  // >= 16 (checked by the dispatcher)
     const int i = threadIdx.x * 16;
     if (i < cnt) {
       if (blk0 + i + 16 <= nblk) {
@@ -343,7 +343,8 @@ extern "C" int dmxq_bfp_pack(const void* in, int dtype_in, int8_t* mant, uint8_t
     const unsigned grid = (unsigned)tiles;
     int lpb_log = 0;
     while (((int64_t)epl << lpb_log) < B) lpb_log++;
-    const bool pair = epl == 8 && n_vec % 2 == 0 && aligned16(mant), ldse = aligned16(exps);
+    // (the LDS form writes a tile's exponents as whole 16-byte vectors: at least 16 blocks per tile -- not B = 64 lane-vectors on the two-slot tiles)
+    const bool pair = epl == 8 && n_vec % 2 == 0 && aligned16(mant), ldse = aligned16(exps) && (tile >> lpb_log) >= 16;
 #define DMXQ_PK(DT_, V_) do { if (small) DMXQ_LAUNCH((bfp_pack_rows_kernel<DT_, V_, kPackThreads, 2>), dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym); \
                               else DMXQ_LAUNCH((bfp_pack_rows_kernel<DT_, V_>), dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym); } while (0)
 #define DMXQ_PKV(DT_) do { if (pair && ldse) DMXQ_PK(DT_, 3); else if (pair) DMXQ_PK(DT_, 1); else if (ldse) DMXQ_PK(DT_, 2); else DMXQ_PK(DT_, 0); } while (0)

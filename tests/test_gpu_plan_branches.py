@@ -255,7 +255,8 @@ def test_packed_bfp_geometry_branches(dmx, cuda, dtype):
     values of the whole tensor equal those of its 128-row slabs (small: the branch the oracle test pins), and the round trip equals the cast."""
     ops = dmx.ops
     cols = 4096
-    for rows, L, B in [(300, cols, 16), (1600, cols, 64), (4096, cols, 16), (4200, cols, 64), (1537, 4104, 8), (130, 4104, 8)]:
+    for rows, L, B in [(300, cols, 16), (1600, cols, 64), (4096, cols, 16), (4200, cols, 64), (1537, 4104, 8), (130, 4104, 8), (300, cols, 512), (2000, cols, 512),
+                       (300, cols, 256)]:
         x = make("heavy", (rows, L), seed=rows, dtype=torch.float32).clamp(-3e4, 3e4)
         x.view(-1)[:: 4099] = 0.0
         x[1, :B] = 0.0
