@@ -17,18 +17,28 @@ namespace dmxq {
 // codes of one 16-byte input vector.  Nearest-even through the magic add of bfp_math.hpp (2): with t = fl(x + base),
 // fl(t + M) lies in M's binade, whose ulp is the quantum, and so does K = M + base: the INTEGER difference of the two
 // bit patterns is the code.  Clamp and asymmetric rule as bfp_q1_fast (double-rounding form, any input dtype).
-template <int EPL>
-__device__ __forceinline__ void pack_codes_fast(const float (&x)[EPL], uint32_t mb, int wl, int asym, int (&code)[EPL]) {
-  const BfpBlockParams p = bfp_block_params<true, true>(mb, wl);
+// SINGLE (16-bit inputs: bfp_single_rounding_ok, precision <= 8): one rounding, fl(x + K) already lies in K's binade -- the form of the
+// hot kernel (bfp_q1_fast<true>), where the asymmetric format is just an asymmetric clamp.  3 operations per element instead of 6.
+template <int EPL, bool SINGLE, bool ASYM>
+__device__ __forceinline__ void pack_codes_fast(const float (&x)[EPL], uint32_t mb, int wl, int (&code)[EPL]) {
+  const BfpBlockParams p = bfp_block_params<ASYM, true>(mb, wl);
   const int cmax = (1 << (wl - 1)) - 1;
   const uint32_t kb = f2u(p.K);
-  const float thr = asym ? p.thr : -INFINITY;  // symmetric: x <= -inf never holds for a finite block
 #pragma unroll
   for (int k = 0; k < EPL; k++) {
-    const int ci = (int)(f2u((x[k] + p.base) + p.M) - kb);
-    const int c = ci < -cmax ? -cmax : (ci > cmax ? cmax : ci);
-    code[k] = (x[k] <= thr) ? -cmax - 1 : c;
+    if constexpr (SINGLE) {
+      const int ci = (int)(f2u(x[k] + p.K) - kb);
+      code[k] = ci < (ASYM ? -cmax - 1 : -cmax) ? (ASYM ? -cmax - 1 : -cmax) : (ci > cmax ? cmax : ci);
+    } else {
+      const int ci = (int)(f2u((x[k] + p.base) + p.M) - kb);
+      const int c = ci < -cmax ? -cmax : (ci > cmax ? cmax : ci);
+      code[k] = (ASYM && x[k] <= p.thr) ? -cmax - 1 : c;
+    }
   }
+}
+// four codes (each within int8) -> one dword: two byte selections and an OR
+__device__ __forceinline__ uint32_t pack4_codes(int c0, int c1, int c2, int c3) {
+  return __builtin_amdgcn_perm((uint32_t)c1, (uint32_t)c0, 0x0c0c0400u) | __builtin_amdgcn_perm((uint32_t)c3, (uint32_t)c2, 0x04000c0cu);
 }
 // the literal form, for the blocks bfp_fast_ok does not cover and the zero / denormal / Inf / NaN maxima (all-zero codes)
 template <int EPL>
@@ -57,7 +67,7 @@ constexpr int kPackThreads = 256, kPackUnroll = 4;  // (round 3, 4096 x 4096 bf1
 //   slots (one DPP quad_perm each way), so the even lane stores vectors (v, v + 1) of slot 2k and the odd lane those of slot 2k + 1;
 // VAR bit 1 (exps 16-byte aligned): the tile's shared exponents (kPackThreads * kPackUnroll / lpb contiguous bytes) go through LDS and
 //   leave as 16-byte stores by the first lanes of the workgroup instead of one byte store per block.
-template <int DTI, int VAR, int T = kPackThreads, int U = kPackUnroll>
+template <int DTI, int VAR, int T = kPackThreads, int U = kPackUnroll, bool ASYM = false>
 __global__ __launch_bounds__(T) void bfp_pack_rows_kernel(const void* __restrict__ in, int8_t* __restrict__ mant,
                                                                     uint8_t* __restrict__ exps, int64_t n_vec, int lpb_arg,
                                                                     int lpb_log, int wl, int asym) {
@@ -88,14 +98,12 @@ __global__ __launch_bounds__(T) void bfp_pack_rows_kernel(const void* __restrict
     float x[EPL];
     widen<DTI, EPL>(raw[u], x);
     int code[EPL];
-    pack_codes_fast<EPL>(x, mb, wl, asym, code);
+    pack_codes_fast<EPL, DTI != DMXQ_F32, ASYM>(x, mb, wl, code);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast) != 0ull, 0)) {
       if (!fast) pack_codes_literal<EPL>(x, mb, wl, asym, code);
     }
 #pragma unroll
-    for (int j = 0; j < EPL / 4; j++)
-      w[u][j] = ((uint32_t)code[4 * j] & 0xFFu) | (((uint32_t)code[4 * j + 1] & 0xFFu) << 8) |
-                (((uint32_t)code[4 * j + 2] & 0xFFu) << 16) | ((uint32_t)code[4 * j + 3] << 24);
+    for (int j = 0; j < EPL / 4; j++) w[u][j] = pack4_codes(code[4 * j], code[4 * j + 1], code[4 * j + 2], code[4 * j + 3]);
     if constexpr (!PAIR && !QUAD) {
       if (v < n_vec) {
         if (EPL == 8) __builtin_nontemporal_store(u32x2{w[u][0], w[u][EPL / 4 - 1]}, (u32x2*)(mant + v * 8));
@@ -345,19 +353,22 @@ extern "C" int dmxq_bfp_pack(const void* in, int dtype_in, int8_t* mant, uint8_t
     while (((int64_t)epl << lpb_log) < B) lpb_log++;
     // (the LDS form writes a tile's exponents as whole 16-byte vectors: at least 16 blocks per tile -- not B = 64 lane-vectors on the two-slot tiles)
     const bool pair = epl == 8 && n_vec % 2 == 0 && aligned16(mant), ldse = aligned16(exps) && (tile >> lpb_log) >= 16;
-#define DMXQ_PK(DT_, V_) do { if (small) DMXQ_LAUNCH((bfp_pack_rows_kernel<DT_, V_, kPackThreads, 2>), dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym); \
-                              else DMXQ_LAUNCH((bfp_pack_rows_kernel<DT_, V_>), dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym); } while (0)
+#define DMXQ_PKL(DT_, V_, U_, A_) DMXQ_LAUNCH((bfp_pack_rows_kernel<DT_, V_, kPackThreads, U_, A_>), dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym)
+#define DMXQ_PKU(DT_, V_, U_) do { if (asym) DMXQ_PKL(DT_, V_, U_, true); else DMXQ_PKL(DT_, V_, U_, false); } while (0)
+#define DMXQ_PK(DT_, V_) do { if (small) DMXQ_PKU(DT_, V_, 2); else DMXQ_PKU(DT_, V_, kPackUnroll); } while (0)
 #define DMXQ_PKV(DT_) do { if (pair && ldse) DMXQ_PK(DT_, 3); else if (pair) DMXQ_PK(DT_, 1); else if (ldse) DMXQ_PK(DT_, 2); else DMXQ_PK(DT_, 0); } while (0)
     if (dtype_in == DMXQ_F32) {
       // (16-byte code stores need four slots: the two-slot geometry of small tensors keeps 4-byte stores)
       const bool quad = !small && n_vec % 4 == 0 && aligned16(mant);
-      if (quad && ldse) DMXQ_LAUNCH((bfp_pack_rows_kernel<DMXQ_F32, 3>), dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
-      else if (quad) DMXQ_LAUNCH((bfp_pack_rows_kernel<DMXQ_F32, 1>), dim3(grid), dim3(kPackThreads), 0, s, in, mant, exps, n_vec, (int)(B / epl), lpb_log, precision, asym);
+      if (quad && ldse) DMXQ_PKU(DMXQ_F32, 3, kPackUnroll);
+      else if (quad) DMXQ_PKU(DMXQ_F32, 1, kPackUnroll);
       else if (ldse) DMXQ_PK(DMXQ_F32, 2);
       else DMXQ_PK(DMXQ_F32, 0);
     }
     else if (dtype_in == DMXQ_F16) DMXQ_PKV(DMXQ_F16);
     else DMXQ_PKV(DMXQ_BF16);
+#undef DMXQ_PKL
+#undef DMXQ_PKU
 #undef DMXQ_PKV
 #undef DMXQ_PK
   } else {
