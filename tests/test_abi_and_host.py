@@ -46,6 +46,19 @@ def test_argument_validation_without_gpu(dmx):
     assert L.dmxq_nm_mask(one, lib.F32, null, 0, one, lib.F32, null, 0, 1, 6, 1, 2, 4, null) == lib.ERR_BAD_ARG  # L % M
     assert L.dmxq_nm_mask(one, lib.F32, null, 0, one, lib.F32, null, 0, 1, 8, 1, 5, 4, null) == lib.ERR_BAD_ARG  # K > M
     assert L.dmxq_nm_mask(one, lib.F32, null, 0, null, 0, null, 0, 1, 8, 1, 2, 4, null) == lib.ERR_BAD_ARG      # no output
+    # round 3: a module AND its consumer's BFP input cast in one launch -- the same rules, checked before any launch
+    assert L.dmxq_binary_cast_bfp(null, null, null, lib.BF16, 0, 0, null, null, null, 64, 64, 8, null) == lib.OK            # n == 0
+    assert L.dmxq_binary_cast_bfp(null, null, null, lib.BF16, 64, 0, null, null, null, 64, 64, 8, null) == lib.ERR_BAD_ARG   # null tensors
+    assert L.dmxq_binary_cast_bfp(one, one, one, lib.BF16, 64, 2, null, null, null, 64, 64, 8, null) == lib.ERR_BAD_ARG      # op
+    assert L.dmxq_binary_cast_bfp(one, one, one, 9, 64, 0, null, null, null, 64, 64, 8, null) == lib.ERR_BAD_ARG            # dtype
+    assert L.dmxq_binary_cast_bfp(one, one, one, lib.BF16, 64, 0, null, null, null, 64, 0, 8, null) == lib.ERR_BAD_ARG       # block size
+    assert L.dmxq_binary_cast_bfp(one, one, one, lib.BF16, 128, 0, null, null, null, 96, 64, 8, null) == lib.ERR_UNSUPPORTED # rows of 1.5 blocks
+    assert L.dmxq_binary_cast_bfp(one, one, one, lib.BF16, 128, 0, null, null, null, 64, 24, 8, null) == lib.ERR_UNSUPPORTED # not 2^k lane-vectors
+    assert L.dmxq_binary_cast_bfp(one, one, one, lib.BF16, 128, 0, null, null, null, 64, 64, 40, null) == lib.ERR_UNSUPPORTED # precision
+    assert L.dmxq_relu_cast_bfp(null, null, lib.F32, 0, null, null, 64, 64, 8, null) == lib.OK
+    assert L.dmxq_relu_cast_bfp(null, one, lib.F32, 64, null, null, 64, 64, 8, null) == lib.ERR_BAD_ARG
+    assert L.dmxq_relu_cast_bfp(one, one, lib.F32, 128, null, null, 96, 64, 8, null) == lib.ERR_UNSUPPORTED
+    assert L.dmxq_relu_cast_bfp(one, one, lib.F32, 1024, null, null, 512, 512, 8, null) == lib.ERR_UNSUPPORTED               # a block wider than a wave
 
 
 def test_no_cpu_fallback(dmx):
