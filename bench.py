@@ -85,6 +85,19 @@ def parse():
     ap.add_argument("--no-resident", action="store_true",
                     help="skip the cache-resident loop (one 64 MiB buffer pair, served by the Infinity Cache): a rocprofv3 "
                          "kernel-trace of the run then holds rotating-buffer launches only")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="harness transport for barrier / max-over-ranks / gather.  nccl (= RCCL, the default and what the driver "
+                         "runs).  gloo: HARNESS-ONLY alternative that lets N ranks SHARE the box's GPUs (rank r -> cuda:(r mod "
+                         "device_count)), so the whole N > 1 path -- shard, K launches per rank, max over ranks, gather, whole-tensor "
+                         "bit compare -- runs on real HIP kernels on a 1-GPU lease (RCCL refuses two ranks per device); collectives "
+                         "then carry host copies.  Throughput of such a run is NOT a scaling figure: the ranks share one GPU")
+    ap.add_argument("--sync", choices=["poll", "block"], default="poll",
+                    help="how the end of a wall-clock region is observed: poll = spin on hipStreamQuery until the launch stream is "
+                         "drained, then torch.cuda.synchronize() (returns at once); block = torch.cuda.synchronize() alone, whose "
+                         "blocking wait adds the host's wake-up latency (10-20 us) to every region.  Both are in the line")
+    ap.add_argument("--input", choices=["portable", "device"], default="portable",
+                    help="c2 inputs: portable = tests/_data.py's counter-based generator on the host (identical bits on every "
+                         "machine: outputs are compared with the reference's committed digests); device = torch.randn on the GPU")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks through torch.distributed.run even for --gpus 1 (exercises the self-launch path)")
     return ap.parse_args()
@@ -119,6 +132,27 @@ def synth(seed, rows, cols, device):
     a = torch.randn(rows, cols, generator=g, device=device)
     b = torch.randn(rows, cols, generator=g, device=device)
     return (a * torch.exp(2.0 * b)).to(torch.bfloat16)
+
+
+def slot_seed(rank, slot):
+    """seed of rank `rank`'s rotation slot `slot` (c2): what oracle/gen_golden_r4.py committed the reference's digests for"""
+    return 1000 * rank + slot
+
+
+def portable_inputs(seeds, rows, cols):
+    """c2 inputs from tests/_data.py's counter-based generator (splitmix64 on the linear index -> Box-Muller in fp64 -> bf16),
+    kind "heavy" (N(0,1) * exp(4 N(0,1)): per-block exponent spread), computed on the host cores in index chunks: the same bits
+    on every machine, so a run's outputs can be compared with the reference's committed digests (tests/golden/c2_digests.json)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    if os.path.join(ROOT, "tests") not in sys.path:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _data import make_chunked
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    inner = max(1, min(16, cores))
+    with ThreadPoolExecutor(max(1, min(8, cores // inner))) as ex:
+        return list(ex.map(lambda sd: make_chunked("heavy", (rows, cols), sd, torch.bfloat16, workers=inner), seeds))
 
 
 def _time_cpu(fn, seconds, max_n):
@@ -198,7 +232,13 @@ class Workload:
             self.global_rows = ROWS * world
             self.shard = parallel.row_shards(self.global_rows, world)[rank]
             rows = self.shard[1] - self.shard[0]
-            self.ins = [synth(1000 * rank + i, rows, COLS, dev) for i in range(args.nbuf)]
+            self.seeds = [slot_seed(rank, i) for i in range(args.nbuf)]
+            if args.input == "portable":
+                self.host_ins = portable_inputs(self.seeds, rows, COLS)
+                self.ins = [t.to(dev) for t in self.host_ins]
+            else:
+                self.host_ins = None
+                self.ins = [synth(sd, rows, COLS, dev) for sd in self.seeds]
             self.outs = [torch.empty_like(t) for t in self.ins]
             for i in range(args.nbuf):
                 self.calls.append([("dmxq_bfp_qdq", (ctypes.c_void_p(self.ins[i].data_ptr()), ctypes.c_void_p(self.outs[i].data_ptr()),
@@ -262,22 +302,65 @@ class Workload:
                 raise RuntimeError(f"{name} failed: {rc}")
 
     def check(self, dist):
-        """gather the output shards of slot 0 (RCCL all_gather, harness only) and compare with a whole-tensor launch on
-        rank 0: shard -> op -> concat must equal op on the whole tensor, bit for bit."""
+        """Outside the timed region.  (1) EVERY rotation slot is launched once more and its output compared, bit for bit, with
+        the CPU oracle (oracle/oracle.c: the checker, never the thing measured) and -- for the portable inputs -- with the SHA-256
+        the REFERENCE's own CastTo produced for that slot in the build container (tests/golden/c2_digests.json, written by
+        oracle/gen_golden_r4.py).  (2) The output shards of slot 0 are gathered (harness-only all_gather) and rank 0 compares them
+        with its own whole-tensor launch: shard -> op -> concat must equal op on the whole tensor."""
         import dmx_compressor_amd as d
 
+        for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import oracle as O
+        from _data import bits_equal, sha256_bits
+
         P, rank, world = self.P, self.rank, self.world
+        stream = torch.cuda.current_stream(self.dev)
+        sp = ctypes.c_void_p(stream.cuda_stream)
+        for i in range(len(self.calls)):
+            self.launch(i, sp)
+        torch.cuda.synchronize(self.dev)
         if self.args.workload in ("c2", "replica"):
-            full_in = P.gather_rows(self.ins[0], self.global_rows, world)
-            full_out = P.gather_rows(self.outs[0], self.global_rows, world)
-            if rank == 0:
-                whole = d.CastTo(format="BFP[8|8]{16}(SN)")(full_in)
-                assert torch.equal(whole.view(torch.int16), full_out.view(torch.int16)), \
-                    "gathered shard outputs differ from the whole-tensor CastTo result"
-            return f"all_gather of {world} row shards == whole-tensor CastTo on rank 0 (bit-exact)" if world > 1 \
-                else "outs[0] == CastTo(ins[0]) (bit-exact)"
+            gold = {}
+            gp = os.path.join(ROOT, "tests", "golden", "c2_digests.json")
+            if self.host_ins is not None and os.path.exists(gp):
+                gold = json.load(open(gp))["slots"]
+            n, n_ref, n_foreign = len(self.ins), 0, 0
+            for i in range(n):
+                x = self.host_ins[i] if self.host_ins is not None else self.ins[i].cpu()
+                got = self.outs[i].cpu()
+                bad = bits_equal(got, O.bfp_cast(x, PRECISION, BLOCK).to(torch.bfloat16))
+                assert bad == 0, f"rank {rank} slot {i}: {bad} elements differ from oracle.bfp_cast"
+                g = gold.get(str(self.seeds[i]))
+                if g is not None:
+                    if sha256_bits(x) != g["input_sha256"]:
+                        n_foreign += 1      # this host's libm rounded some fp64 log / cos differently: the oracle check stands
+                    else:
+                        assert sha256_bits(got) == g["output_sha256"], f"rank {rank} slot {i}: output differs from the reference's digest"
+                        n_ref += 1
+            msg = f"{n}/{n} slots == oracle.bfp_cast (bit-exact)"
+            if gold:
+                msg += f"; {n_ref}/{n} slots == SHA-256 of the reference's CastTo output (tests/golden/c2_digests.json)"
+                if n_foreign:
+                    msg += f" ({n_foreign} inputs differ from the committed input digests on this host)"
+            if world > 1:
+                full_in = P.gather_rows(self.ins[0], self.global_rows, world)
+                full_out = P.gather_rows(self.outs[0], self.global_rows, world)
+                if rank == 0:
+                    whole = d.CastTo(format="BFP[8|8]{16}(SN)")(full_in)
+                    assert torch.equal(whole.view(torch.int16), full_out.view(torch.int16)), \
+                        "gathered shard outputs differ from the whole-tensor CastTo result"
+                msg = f"all_gather of {world} row shards == whole-tensor CastTo on rank 0 (bit-exact); every rank: " + msg
+            return msg
         hyper = self.args.op == "hypernet"
+        B = 64 if hyper else 16
         for nm, rows, cols, (s, e), w, sc, out in self.layers[0]:
+            if e > s:   # this rank's shard against the oracle composed like the reference (sparse.py:287-301 -> format.py:304-343)
+                wc = w.cpu()
+                want = O.bfp_cast(O.sparsify(wc, sc.cpu(), 2, 4) if hyper else wc, PRECISION, B).to(torch.bfloat16)
+                bad = bits_equal(out.cpu(), want)
+                assert bad == 0, f"rank {rank} {nm}: {bad} elements differ from the oracle chain"
             full_w = P.gather_rows(w, rows, world)
             full_o = P.gather_rows(out, rows, world)
             full_s = P.gather_rows(sc, rows, world) if hyper else None
@@ -290,14 +373,15 @@ class Workload:
                     whole = d.ops.bfp_qdq(full_w, PRECISION, 16)
                 assert torch.equal(whole.view(torch.int16), full_o.view(torch.int16)), f"{nm}: gathered shards differ from whole tensor"
             del full_w, full_o, full_s
-        return f"7 weights: all_gather of {world} row shards == whole-tensor result on rank 0 (bit-exact)"
+        return (f"7 weights: all_gather of {world} row shards == whole-tensor result on rank 0 (bit-exact); every rank: its shards == "
+                "oracle " + ("sparsify -> bfp_cast" if hyper else "bfp_cast") + " (bit-exact)")
 
 
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         have = torch.cuda.device_count()   # does not initialise HIP on this image
-        if args.gpus > have:
+        if args.gpus > have and not (args.dist_backend == "gloo" and have >= 1):
             print(f"bench.py --gpus {args.gpus}: this box has {have} GPU(s)", file=sys.stderr)
             sys.exit(2)
         self_launch(args)
@@ -320,6 +404,8 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    if args.dist_backend == "gloo":   # harness-only: ranks may share a GPU (see --dist-backend)
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -331,7 +417,10 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+            if args.dist_backend == "gloo":
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
             dist.barrier()                                  # (communicator creation is lazy without this)
             torch.cuda.synchronize(dev)
         finally:
@@ -380,14 +469,29 @@ def main():
                 for i in range(K):
                     wl.launch(i, sp)
 
-        # (a) whole-job wall clock: R timed regions of exactly K steps, barrier + synchronize on both sides
-        for _ in range(R):
+        # (a) whole-job wall clock: R timed regions of exactly K steps, barrier + synchronize on both sides.  The end of a
+        # region is OBSERVED by spinning on hipStreamQuery (stream.query()) until the launch stream has drained -- every one of
+        # the K steps has completed at that moment -- and then torch.cuda.synchronize(), which returns at once; the clock stops
+        # after it.  A blocking synchronize alone parks the host thread and adds its wake-up latency to every region (10-20 us
+        # on a 220 us region); `--sync block` times it that way, and the line carries both figures (`config.sync_alt`).
+        def region(poll):
             barrier()
             t0 = time.perf_counter()
             run_k()
+            if poll:
+                while not stream.query():
+                    pass
             torch.cuda.synchronize(dev)
-            walls.append(time.perf_counter() - t0)
+            t1 = time.perf_counter()
             barrier()
+            return t1 - t0
+
+        poll = args.sync == "poll"
+        for _ in range(3):           # untimed: the first regions after graph upload / a long idle run slower (clocks)
+            region(poll)
+        for _ in range(R):
+            walls.append(region(poll))
+        walls_alt = [region(not poll) for _ in range(R)]
         # (b) the kernels' own time with HIP events on the launch stream, over R more regions of the same K steps.  A
         # short device-side delay is queued in front of the first event so that the host has finished enqueueing the
         # region before the GPU reaches it: the events then bracket back-to-back kernel execution and not the
@@ -411,12 +515,13 @@ def main():
             evs.append(e0.elapsed_time(e1) / 1e3)
         barrier()
 
-    t = torch.tensor([walls, evs], device=dev, dtype=torch.float64)
-    elems = torch.tensor([float(wl.elems_per_step_rank)], device=dev, dtype=torch.float64)
+    cdev = "cpu" if args.dist_backend == "gloo" else dev
+    t = torch.tensor([walls, evs, walls_alt], device=cdev, dtype=torch.float64)
+    elems = torch.tensor([float(wl.elems_per_step_rank)], device=cdev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)   # per replay: the slowest rank
         dist.all_reduce(elems, op=dist.ReduceOp.SUM)
-    walls, evs = t[0].tolist(), t[1].tolist()
+    walls, evs, walls_alt = t[0].tolist(), t[1].tolist(), t[2].tolist()
     wall_med, ev_med = statistics.median(walls), statistics.median(evs)
     total_elems = float(elems[0])
 
@@ -471,6 +576,15 @@ def main():
                        "launches_per_step": wl.launches_per_step,
                        "replays": R,
                        "replay_ms": [round(w * 1e3, 4) for w in walls],
+                       "sync": ("region end = hipStreamQuery spin until the stream is drained, then torch.cuda.synchronize()"
+                                if args.sync == "poll" else "region end = blocking torch.cuda.synchronize()"),
+                       "sync_alt": {"sync": "block" if args.sync == "poll" else "poll",
+                                    "ms_per_step": round(statistics.median(walls_alt) * 1e3 / K, 6),
+                                    "value": round(total_elems / (statistics.median(walls_alt) / K) / 1e9, 2)},
+                       "dist_backend": (args.dist_backend + (" (harness-only transport; ranks share GPUs: not a scaling figure)"
+                                                             if args.dist_backend == "gloo" else " (RCCL)")) if dist is not None else None,
+                       "input": ("tests/_data.py make('heavy', (4096, 4096), seed = 1000 rank + slot, bf16): counter-based, host-generated"
+                                 if args.input == "portable" else "torch.randn on the device") if args.workload != "llama-shard" else "torch.randn on the device",
                        "timing": "one untimed replay, then R wall-clock regions of exactly K steps (barrier+sync, K steps, sync; "
                                  "max over ranks; median region -> ms_per_step, value) and R HIP-event regions of the same K steps "
                                  "(events on the launch stream, a queued device-side delay in front so that host launch latency is "

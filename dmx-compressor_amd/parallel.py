@@ -33,12 +33,24 @@ def my_rows(x: torch.Tensor, rank: int, world: int, multiple: int = 1) -> torch.
     return x[s:e]
 
 
+def _host_staged(t: torch.Tensor, group=None) -> bool:
+    """gloo carries host memory: device tensors go through a host copy (harness-only transport, bench.py --dist-backend gloo)"""
+    import torch.distributed as dist
+
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def allreduce_max_(v: torch.Tensor, group=None) -> torch.Tensor:
     """in-place MAX all-reduce (per-channel maxabs under row sharding; timing max-over-ranks in the bench)"""
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
+        if _host_staged(v, group):
+            h = v.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+            v.copy_(h)
+        else:
+            dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
     return v
 
 
@@ -52,6 +64,11 @@ def gather_rows(shard: torch.Tensor, n_rows: int, world: int, multiple: int = 1,
     mx = max(sizes)
     pad = torch.zeros((mx,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
     pad[: shard.shape[0]] = shard
+    if _host_staged(pad, group):
+        pad_h = pad.cpu()
+        bufs = [torch.empty_like(pad_h) for _ in range(world)]
+        dist.all_gather(bufs, pad_h, group=group)
+        return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0).to(shard.device)
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
     return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)

@@ -14,15 +14,43 @@ def splitmix64(idx, seed):
         return z ^ (z >> np.uint64(31))
 
 
-def uniform(n, seed):
-    """float64 in (0, 1)"""
-    r = splitmix64(np.arange(n, dtype=np.uint64), seed)
+def uniform(n, seed, start=0):
+    """float64 in (0, 1); element i of the stream is a function of (seed, start + i) only"""
+    r = splitmix64(np.arange(start, start + n, dtype=np.uint64), seed)
     return ((r >> np.uint64(11)).astype(np.float64) + 0.5) / float(1 << 53)
 
 
-def normal(n, seed):
-    u1, u2 = uniform(n, seed), uniform(n, seed ^ 0xABCDEF1234567)
+def normal(n, seed, start=0):
+    u1, u2 = uniform(n, seed, start), uniform(n, seed ^ 0xABCDEF1234567, start)
     return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def make_chunked(kind, shape, seed=0, dtype=torch.float32, workers=None, chunk=1 << 20):
+    """make("normal" | "heavy", ...) computed in index chunks on a thread pool (numpy releases the GIL): the SAME bits
+    as make() -- every element is a function of (seed, linear index) -- at a fraction of the time for the 16.8 M-element
+    benchmark tensors (bench.py generates 20 of them per rank; tests/test_abi_and_host.py checks the equality)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    if kind not in ("normal", "heavy"):
+        raise ValueError(kind)
+    n = int(np.prod(shape))
+    out = torch.empty(n, dtype=dtype)
+
+    def one(start):
+        m = min(chunk, n - start)
+        v = normal(m, seed, start)
+        if kind == "heavy":
+            v = v * np.exp(4.0 * normal(m, seed + 1, start))
+        t = torch.from_numpy(v.astype(np.float32))
+        if dtype == torch.float16:
+            t = t.clamp(-65504.0, 65504.0)
+        out[start:start + m] = t.to(dtype)
+
+    workers = workers or max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(one, range(0, n, chunk)))
+    return out.reshape(shape)
 
 
 def make(kind, shape, seed=0, dtype=torch.float32, block=16):
@@ -57,6 +85,15 @@ def make(kind, shape, seed=0, dtype=torch.float32, block=16):
     if dtype == torch.float16:  # keep inputs finite: Inf/NaN blocks are covered by their own test
         t = t.clamp(-65504.0, 65504.0)
     return t.to(dtype)
+
+
+def sha256_bits(t: torch.Tensor) -> str:
+    """SHA-256 of a tensor's raw bytes (contiguous, host order): the digest form of tests/golden/*.json"""
+    import hashlib
+
+    t = t.detach().cpu().contiguous()
+    it = {4: torch.int32, 2: torch.int16, 8: torch.int64, 1: torch.uint8}[t.element_size()]
+    return hashlib.sha256(t.view(it).numpy().tobytes()).hexdigest()
 
 
 def mismatches_nan_aware(a: torch.Tensor, b: torch.Tensor) -> int:

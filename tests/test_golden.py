@@ -414,3 +414,29 @@ def test_packed_bfp_oracle_is_consistent_with_the_cast_oracle(oracle):
         y = torch.ldexp(mant.float(), e - 127 - (wl - 2))
         ok = (e > 0) & (e < 255)
         assert torch.equal(y[ok].view(torch.int32), q[ok].view(torch.int32))
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE.json config 2 itself
+def test_chunked_generator_equals_make():
+    """tests/_data.py make_chunked (bench.py's input generator) == make, bit for bit, incl. a ragged last chunk"""
+    from _data import bits_equal, make, make_chunked
+
+    for kind, shape, seed, dt in (("heavy", (37, 129), 3, torch.bfloat16), ("normal", (5, 1000), 1, torch.float32),
+                                  ("heavy", (1 << 10, 1 << 10), 1019, torch.float16)):
+        assert bits_equal(make_chunked(kind, shape, seed, dt, workers=3, chunk=1000), make(kind, shape, seed, dt)) == 0
+
+
+def test_c2_oracle_reproduces_the_reference_digests(oracle):
+    """tests/golden/c2_digests.json (oracle/gen_golden_r4.py): SHA-256 of the reference's CastTo("BFP[8|8]{16}(SN)") output on the
+    counter-generated 4096 x 4096 bf16 tensors.  The oracle must reproduce them (two of the 44 here: seconds, not minutes)."""
+    import json
+
+    from _data import make_chunked, sha256_bits
+
+    g = json.load(open(os.path.join(GOLD, "c2_digests.json")))
+    assert g["format"] == "BFP[8|8]{16}(SN)" and g["shape"] == [4096, 4096] and len(g["slots"]) == 40 and len(g["kinds"]) == 4
+    for key, kind, seed in (("kinds", "normal", 0), ("slots", "heavy", 1007)):
+        e = g[key][kind if key == "kinds" else str(seed)]
+        x = make_chunked(kind, (4096, 4096), seed, torch.bfloat16)
+        assert sha256_bits(x) == e["input_sha256"]
+        assert sha256_bits(oracle.bfp_cast(x, 8, 16).to(torch.bfloat16)) == e["output_sha256"]

@@ -206,6 +206,41 @@ def test_full_size_headline_config(dmx, cuda, oracle):
     assert _run(dmx, cuda, oracle, x, 8, 16) == 0
 
 
+def _c2_gold():
+    import json
+    import os
+
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_digests.json")))
+
+
+@pytest.mark.parametrize("kind", ["normal", "heavy", "outlier", "ties"])
+def test_c2_reference_digests_by_input_kind(dmx, cuda, oracle, kind):
+    """BASELINE.json config 2 against the REFERENCE itself: the SHA-256 of what the reference's CastTo("BFP[8|8]{16}(SN)") returned in
+    the build container for the four SURVEY §8(d) input kinds of the counter-based generator (oracle/gen_golden_r4.py ->
+    tests/golden/c2_digests.json).  The oracle comparison stands beside it, so a host whose libm rounds the generator's fp64
+    log / cos differently (input digest mismatch) still tests the kernel."""
+    from _data import make_chunked, sha256_bits
+
+    g = _c2_gold()["kinds"][kind]
+    x = make_chunked(kind, (4096, 4096), 0, torch.bfloat16) if kind in ("normal", "heavy") else make(kind, (4096, 4096), seed=0, dtype=torch.bfloat16)
+    got = dmx.CastTo(format="BFP[8|8]{16}(SN)")(x.to(cuda))
+    assert got.dtype == torch.bfloat16
+    assert bits_equal(got, oracle.bfp_cast(x, 8, 16).to(torch.bfloat16)) == 0
+    assert sha256_bits(x) == g["input_sha256"], "the generator produced different bits on this host"
+    assert sha256_bits(got) == g["output_sha256"]
+
+
+@pytest.mark.parametrize("seed", [1, 7, 19, 1000, 1013])
+def test_c2_reference_digests_of_bench_slots(dmx, cuda, seed):
+    """the inputs bench.py rotates over (rank 0 slots 1 / 7 / 19, rank 1 slots 0 / 13) through the C-ABI front end"""
+    from _data import make_chunked, sha256_bits
+
+    g = _c2_gold()["slots"][str(seed)]
+    x = make_chunked("heavy", (4096, 4096), seed, torch.bfloat16)
+    assert sha256_bits(x) == g["input_sha256"]
+    assert sha256_bits(dmx.ops.bfp_qdq(x.to(cuda), 8, 16)) == g["output_sha256"]
+
+
 def test_properties_at_full_size(dmx, cuda):
     """Size-independent properties on the 4096x4096 bf16 tensor (no oracle involved)."""
     x = make("heavy", (4096, 4096), seed=1, dtype=torch.bfloat16).to(cuda)

@@ -41,6 +41,23 @@ def test_bench_two_ranks_shards_and_gathers(extra, scaling, plain):
     assert line["value"] > 0 and 0 < line["roofline"]["frac"] < 1.0
 
 
+@pytest.mark.parametrize("extra,scaling", [([], "weak"), (["--workload", "llama-shard", "--op", "bfp", "--layers", "1"], "strong"),
+                                           (["--workload", "llama-shard", "--layers", "1"], "strong")])
+def test_bench_two_ranks_share_one_gpu_over_gloo(extra, scaling):
+    """The N > 1 path on REAL kernels with the lease's single GPU: world = 2, both ranks on cuda:0, the harness transport swapped
+    for gloo (`--dist-backend gloo`; RCCL refuses two ranks per device).  Everything else is the N = 2 run: row shards, K launches
+    per rank through the C ABI, max over ranks of every region, all_gather of the output shards, rank 0's whole-tensor bit
+    compare, every rank's slots against the oracle.  Only the RCCL transport itself is left to the 2-GPU test above."""
+    line = _run(extra + ["--dist-backend", "gloo", "--nbuf", "4"], 29620 + len(extra), n=2, plain=True)
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == scaling
+    assert "all_gather of 2 row shards" in line["config"]["check"] and "bit-exact" in line["config"]["check"]
+    assert "oracle" in line["config"]["check"] and "gloo" in line["config"]["dist_backend"]
+    if not extra:
+        assert line["config"]["per_gpu_elements_per_step"] == 4096 * 4096
+        assert "4/4 slots == oracle" in line["config"]["check"] and "4/4 slots == SHA-256 of the reference" in line["config"]["check"]
+    assert line["value"] > 0
+
+
 @pytest.mark.parametrize("extra", [[], ["--workload", "llama-shard", "--layers", "1"]])
 def test_bench_starts_its_own_ranks(extra):
     """The self-launch path on ONE GPU: `bench.py --gpus 1 --spawn` runs its single rank as a torch.distributed.run child
@@ -52,7 +69,7 @@ def test_bench_starts_its_own_ranks(extra):
 
 
 def test_bench_refuses_more_ranks_than_gpus():
-    n = torch.cuda.device_count() + 1
+    n = torch.cuda.device_count() + 1   # (with the default RCCL transport; `--dist-backend gloo` lets ranks share a GPU)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"],
                        cwd=ROOT, capture_output=True, text=True, timeout=300,
                        env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
