@@ -69,7 +69,9 @@ def parse():
     ap.add_argument("--model", choices=["opt125m", "llama", "whisper"], default="llama",
                     help="--workload layer: which configured layer (BASELINE.json configs 3 / 4 / 5), see tools/bench_layer.py")
     ap.add_argument("--layer-modes", default="live,folded,unfused", help="--workload layer: which variants to time")
-    ap.add_argument("--op", choices=["hypernet", "bfp"], default="hypernet", help="llama-shard only")
+    ap.add_argument("--op", choices=["hypernet", "hypernet-each", "bfp"], default="hypernet",
+                    help="llama-shard only.  hypernet: the rank's seven weight shards in ONE launch (dmxq_weight_hypernet_multi); "
+                         "hypernet-each: one dmxq_weight_hypernet launch per weight (rounds 2-3); bfp: plain BFP16_16 per weight")
     ap.add_argument("--replays", type=int, default=15, help="timed replays of the K-step graph (median reported)")
     ap.add_argument("--nbuf", type=int, default=20, help="c2: distinct in/out buffer pairs (20 x 64 MiB = 1.25 GiB)")
     ap.add_argument("--layers", type=int, default=2, help="llama-shard: distinct layer copies rotated over")
@@ -91,10 +93,15 @@ def parse():
                          "device_count)), so the whole N > 1 path -- shard, K launches per rank, max over ranks, gather, whole-tensor "
                          "bit compare -- runs on real HIP kernels on a 1-GPU lease (RCCL refuses two ranks per device); collectives "
                          "then carry host copies.  Throughput of such a run is NOT a scaling figure: the ranks share one GPU")
-    ap.add_argument("--sync", choices=["poll", "block"], default="poll",
-                    help="how the end of a wall-clock region is observed: poll = spin on hipStreamQuery until the launch stream is "
-                         "drained, then torch.cuda.synchronize() (returns at once); block = torch.cuda.synchronize() alone, whose "
-                         "blocking wait adds the host's wake-up latency (10-20 us) to every region.  Both are in the line")
+    ap.add_argument("--sync", choices=["block", "poll"], default="block",
+                    help="how the end of a wall-clock region is observed: block = torch.cuda.synchronize() alone (the contract's form); "
+                         "poll = spin on hipStreamQuery until the launch stream is drained, then torch.cuda.synchronize().  Measured "
+                         "(tools/region_probe.py, profiles/r04_region_probe.txt): polling is 2-7 us per region SLOWER than the blocking "
+                         "call, which already spins; hipStreamSynchronize, event waits and hipDeviceScheduleSpin change nothing.  Both "
+                         "figures are in the line (`config.sync_alt`)")
+    ap.add_argument("--preheat", type=int, default=2000,
+                    help="untimed launches right before the timed regions (c2 only; ~22 ms of continuous load): the host-side input "
+                         "generation leaves the GPU idle for seconds, and the first regions after that measured ~10 us slower")
     ap.add_argument("--input", choices=["portable", "device"], default="portable",
                     help="c2 inputs: portable = tests/_data.py's counter-based generator on the host (identical bits on every "
                          "machine: outputs are compared with the reference's committed digests); device = torch.randn on the GPU")
@@ -251,9 +258,10 @@ class Workload:
                          "configs[1]); rank r owns rows [4096 r, 4096 (r+1)) of a global [N*4096, 4096] tensor")
         else:
             self.scaling = "strong"
-            hyper = args.op == "hypernet"
+            hyper = args.op in ("hypernet", "hypernet-each")
             B = 64 if hyper else 16
             self.layers = []
+            self.keep = []   # host descriptor arrays of the multi-tensor calls (must outlive the launches that read them)
             for c in range(args.layers):
                 layer = []
                 for t, (nm, rows, cols) in enumerate(LLAMA_LAYER):
@@ -272,6 +280,16 @@ class Workload:
             torch.cuda.empty_cache()
             for layer in self.layers:
                 cl = []
+                if args.op == "hypernet":   # the whole layer's shards in one launch
+                    live = [t for t in layer if t[3][1] > t[3][0]]
+                    descs = (lib.HypernetDesc * len(live))()
+                    for d, (nm, rows, cols, (s, e), w, sc, out) in zip(descs, live):
+                        d.w, d.score, d.sq_scale, d.out, d.rows, d.L = w.data_ptr(), sc.data_ptr(), None, out.data_ptr(), e - s, cols
+                    self.keep.append(descs)
+                    if live:
+                        cl.append(("dmxq_weight_hypernet_multi", (descs, len(live), bf16, bf16, 2, 4, bf16, B, PRECISION, 1)))
+                    self.calls.append(cl)
+                    continue
                 for nm, rows, cols, (s, e), w, sc, out in layer:
                     n = (e - s)
                     if n == 0:
@@ -287,10 +305,12 @@ class Workload:
             mine = sum((e - s) * cols for _, _, cols, (s, e), *_ in self.layers[0])
             self.elems_per_step_rank = mine
             self.bytes_per_step = per_elem * mine
-            self.launches_per_step = len(self.calls[0])
+            self.launches_per_step = max(1, len(self.calls[0]))
             self.describe_args = None
             self.name = ("Llama-3-8B decoder-layer weights (q,k,v,o,gate,up,down = 218.1 M elements, bf16), each row-sharded over "
                          "the N ranks; " + ("BTOPK{2:4,-1} mask -> BFP[8|8]{64}(SN) in one launch per weight (dmxq_weight_hypernet), "
+                                            "score bf16" if args.op == "hypernet-each" else
+                                            "BTOPK{2:4,-1} mask -> BFP[8|8]{64}(SN), the rank's seven shards in ONE launch (dmxq_weight_hypernet_multi), "
                                             "score bf16" if hyper else "BFP[8|8]{16}(SN) Q->DQ (dmxq_bfp_qdq)")
                          + " (BASELINE.json configs[3])")
         self.total_elems_per_step = None  # filled by main (sum over ranks)
@@ -353,7 +373,7 @@ class Workload:
                         "gathered shard outputs differ from the whole-tensor CastTo result"
                 msg = f"all_gather of {world} row shards == whole-tensor CastTo on rank 0 (bit-exact); every rank: " + msg
             return msg
-        hyper = self.args.op == "hypernet"
+        hyper = self.args.op in ("hypernet", "hypernet-each")
         B = 64 if hyper else 16
         for nm, rows, cols, (s, e), w, sc, out in self.layers[0]:
             if e > s:   # this rank's shard against the oracle composed like the reference (sparse.py:287-301 -> format.py:304-343)
@@ -469,11 +489,11 @@ def main():
                 for i in range(K):
                     wl.launch(i, sp)
 
-        # (a) whole-job wall clock: R timed regions of exactly K steps, barrier + synchronize on both sides.  The end of a
-        # region is OBSERVED by spinning on hipStreamQuery (stream.query()) until the launch stream has drained -- every one of
-        # the K steps has completed at that moment -- and then torch.cuda.synchronize(), which returns at once; the clock stops
-        # after it.  A blocking synchronize alone parks the host thread and adds its wake-up latency to every region (10-20 us
-        # on a 220 us region); `--sync block` times it that way, and the line carries both figures (`config.sync_alt`).
+        # (a) whole-job wall clock: R timed regions of exactly K steps, barrier + synchronize on both sides.  A region carries
+        # ~12-16 us that are not kernel time (tools/region_probe.py: K = 1 takes 24.4 us for one 10.9 us kernel; K = 20 ->
+        # 231 us, K = 40 -> 450 us: 10.93 us per step + 13 us): the first launch's way to an idle queue and the completion's way
+        # back to the host.  `--sync poll` observes the end by spinning on hipStreamQuery instead; it measured slower than the
+        # blocking call (which spins itself); the line carries both (`config.sync_alt`).
         def region(poll):
             barrier()
             t0 = time.perf_counter()
@@ -487,7 +507,10 @@ def main():
             return t1 - t0
 
         poll = args.sync == "poll"
-        for _ in range(3):           # untimed: the first regions after graph upload / a long idle run slower (clocks)
+        if args.workload in ("c2", "replica"):
+            for i in range(args.preheat):   # untimed: the GPU sat idle while the host generated and checked inputs
+                wl.launch(i, sp)
+        for _ in range(10):          # untimed regions
             region(poll)
         for _ in range(R):
             walls.append(region(poll))

@@ -17,18 +17,30 @@ class HostFlags:
     _scalar_names = ()
 
     def _set_scalar(self, name: str, value: float) -> None:
-        getattr(self, name).fill_(float(value))
-        self.__dict__["_h_" + name] = float(value)
+        buf = getattr(self, name)
+        buf.fill_(float(value))
+        # the mirror holds what the BUFFER holds (0.3 -> 0.30000001192 in a float32 buffer), whichever path wrote it last;
+        # rounded on the host: no device read
+        import torch
+        self.__dict__["_h_" + name] = float(torch.tensor(float(value), dtype=buf.dtype))
 
     def _scalar(self, name: str) -> float:
-        return self.__dict__["_h_" + name]
+        try:
+            return self.__dict__["_h_" + name]
+        except KeyError:   # a module whose __dict__ predates the mirrors (whole-module pickle of an earlier version), or a buffer
+            self.refresh_flags()   # that was assigned directly: read the buffers once
+            return self.__dict__["_h_" + name]
 
     def _set_flag(self, name: str, value) -> None:
         getattr(self, name)[0] = 1 if value else 0
         self.__dict__["_h_" + name] = 1 if value else 0
 
     def _flag(self, name: str) -> int:
-        return self.__dict__["_h_" + name]
+        try:
+            return self.__dict__["_h_" + name]
+        except KeyError:
+            self.refresh_flags()
+            return self.__dict__["_h_" + name]
 
     def refresh_flags(self) -> None:
         for n in self._flag_names:

@@ -30,6 +30,7 @@ SIGNATURES = {
     "dmxq_bfp_pack": [_vp, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_bfp_unpack": [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp],
     "dmxq_weight_hypernet": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
+    "dmxq_weight_hypernet_multi": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp],
     "dmxq_weight_hypernet_strided": [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_input_hypernet": [_vp, _i32, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_binary_cast": [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
@@ -70,6 +71,11 @@ SIGNATURES = {
 class TensorDesc(ctypes.Structure):
     """dmxq_tensor_desc (include/dmxq.h)"""
     _fields_ = [("in_", _vp), ("out", _vp), ("outer", _i64), ("L", _i64), ("inner", _i64)]
+
+
+class HypernetDesc(ctypes.Structure):
+    """dmxq_hypernet_desc (include/dmxq.h)"""
+    _fields_ = [("w", _vp), ("score", _vp), ("sq_scale", _vp), ("out", _vp), ("rows", _i64), ("L", _i64)]
 
 
 class FloatFmt(ctypes.Structure):

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "group_minmax_accumulate", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "weight_hypernet_multi", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "group_minmax_accumulate", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -152,6 +152,43 @@ def weight_hypernet(w, precision: int, block_size: int, symmetric: bool = True, 
         return None
     check(rc, "dmxq_weight_hypernet")
     return out
+
+
+def weight_hypernet_multi(ws, precision: int, block_size: int, symmetric: bool = True, scores=None, K: int = 0, M: int = 0,
+                          sq_scales=None, out_dtype: Optional[torch.dtype] = None):
+    """The weight chain of MANY Linear weights (one dtype, one device, one N:M pattern, one BFP format) in as few launches as
+    possible (`dmxq_weight_hypernet_multi`): the same results as `[weight_hypernet(w, ...) for w in ws]`.  scores / sq_scales: one
+    per weight, or None.  Returns None -- nothing launched -- when any of them is not fusable (the caller goes one by one)."""
+    ws = list(ws)
+    if not ws:
+        return []
+    wcs = [_prep(w, "weight_hypernet_multi") for w in ws]
+    dt, dev = wcs[0].dtype, wcs[0].device
+    if any(w.dtype != dt or w.device != dev for w in wcs):
+        raise ValueError("weight_hypernet_multi: all weights must share one dtype and one device")
+    masked = scores is not None and M != 0
+    scs = [_prep(s, "weight_hypernet_multi") for s in scores] if masked else []
+    sqs = [q.detach().to(device=dev, dtype=torch.float32).contiguous() for q in sq_scales] if sq_scales is not None else []
+    if (masked and len(scs) != len(wcs)) or (sqs and len(sqs) != len(wcs)):
+        raise ValueError("weight_hypernet_multi: one score / scale per weight")
+    if masked and (any(s.dtype != scs[0].dtype for s in scs) or any(s.shape != w.shape for s, w in zip(scs, wcs))):
+        return None
+    od = out_dtype or (torch.promote_types(dt, scs[0].dtype) if masked else dt)
+    outs = [torch.empty(w.shape, dtype=od, device=dev) for w in wcs]
+    descs = (_lib.HypernetDesc * len(wcs))()
+    for i, (d, w, o) in enumerate(zip(descs, wcs, outs)):
+        L = w.shape[-1] if w.dim() else 1
+        if sqs and sqs[i].numel() != L:
+            return None
+        d.w, d.score, d.sq_scale, d.out = w.data_ptr(), (scs[i].data_ptr() if masked else None), (sqs[i].data_ptr() if sqs else None), o.data_ptr()
+        d.rows, d.L = w.numel() // max(L, 1), L
+    with torch.cuda.device(dev):
+        rc = lib().dmxq_weight_hypernet_multi(descs, len(wcs), dtype_code(dt), dtype_code(scs[0].dtype) if masked else 0, K,
+                                              M if masked else 0, dtype_code(od), block_size, precision, int(symmetric), stream_of(wcs[0]))
+    if rc == _lib.ERR_UNSUPPORTED:
+        return None
+    check(rc, "dmxq_weight_hypernet_multi")
+    return outs
 
 
 def input_hypernet(x, sq_scale, precision: int, block_size: int, symmetric: bool = True):
@@ -723,6 +760,6 @@ def _on_tensor_device(fn):
 
 
 for _name in __all__:
-    if _name not in ("bfp_qdq_multi", "fixed_qdq_multi"):  # (take lists; switch device themselves)
+    if _name not in ("bfp_qdq_multi", "fixed_qdq_multi", "weight_hypernet_multi"):  # (take lists; switch device themselves)
         globals()[_name] = _on_tensor_device(globals()[_name])
 del _name

@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import DmxqError, ROUNDING_CODE, require_gpu
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "group_minmax_accumulate", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "weight_hypernet_multi", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "group_minmax_accumulate", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -114,6 +114,8 @@ def bfp_qdq_multi(tensors, precision: int, block_size: int, block_dim: int = -1,
     """BFP Q->DQ of MANY tensors of one dtype on one device in as few launches as possible (`dmxq_bfp_qdq_multi`): the
     same results as `[bfp_qdq(t, ...) for t in tensors]`."""
     tensors = list(tensors)
+    if not tensors:
+        return []   # (an empty Tensor[] carries no dispatch key)
     for t in tensors:
         require_gpu(t, "bfp_qdq_multi")
     if tensors and any(t.dtype != tensors[0].dtype or t.device != tensors[0].device for t in tensors):
@@ -143,6 +145,23 @@ def weight_hypernet(w, precision: int, block_size: int, symmetric: bool = True, 
     try:
         return _ops.weight_hypernet(w, precision, block_size, symmetric, score if M else None, K, M if score is not None else 0,
                                     sq_scale, out_dtype, block_dim)
+    except NotImplementedError:
+        return None
+
+
+def weight_hypernet_multi(ws, precision: int, block_size: int, symmetric: bool = True, scores=None, K: int = 0, M: int = 0,
+                          sq_scales=None, out_dtype: Optional[torch.dtype] = None):
+    """The weight chain of MANY Linear weights (one dtype, one device, one N:M pattern, one BFP format) in as few launches as
+    possible (`dmxq_weight_hypernet_multi`): the same results as `[weight_hypernet(w, ...) for w in ws]`.  scores / sq_scales: one
+    per weight, or None.  Returns None -- nothing launched -- when any of them is not fusable (the caller goes one by one)."""
+    ws = list(ws)
+    if not ws:
+        return []   # (an empty Tensor[] carries no dispatch key)
+    for w in ws:
+        require_gpu(w, "weight_hypernet_multi")
+    try:
+        return list(_ops.weight_hypernet_multi(ws, precision, block_size, symmetric, list(scores) if (scores is not None and M) else [],
+                                               K, M if scores is not None else 0, list(sq_scales) if sq_scales is not None else [], out_dtype))
     except NotImplementedError:
         return None
 

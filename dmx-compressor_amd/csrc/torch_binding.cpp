@@ -206,6 +206,50 @@ Tensor weight_hypernet_meta(const Tensor& w, int64_t, int64_t, bool, const OptTe
   return empty_like_shape(w, hypernet_dtype(w, score, M, out_dtype));
 }
 
+// the Linear weights of a layer in one launch (dmxq_weight_hypernet_multi); scores / sq_scales: empty, or one per weight
+std::vector<Tensor> weight_hypernet_multi(at::TensorList ws, int64_t precision, int64_t block_size, bool symmetric, at::TensorList scores,
+                                          int64_t K, int64_t M, at::TensorList sq_scales, OptDtype out_dtype) {
+  std::vector<Tensor> outs, wcs, scs, sqs;
+  if (ws.empty()) return outs;
+  const bool masked = !scores.empty() && M != 0;
+  TORCH_CHECK(!masked || scores.size() == ws.size(), "weight_hypernet_multi: one score per weight");
+  TORCH_CHECK(sq_scales.empty() || sq_scales.size() == ws.size(), "weight_hypernet_multi: one scale per weight, or none");
+  std::vector<dmxq_hypernet_desc> d(ws.size());
+  for (size_t i = 0; i < ws.size(); i++) {
+    wcs.push_back(prep(ws[i], "weight_hypernet_multi"));
+    TORCH_CHECK(wcs[i].scalar_type() == wcs[0].scalar_type() && wcs[i].device() == wcs[0].device(),
+                "weight_hypernet_multi: all weights must share one dtype and one device");
+    const int64_t L = wcs[i].dim() ? wcs[i].size(-1) : 1;
+    const int64_t rows = L ? wcs[i].numel() / L : 0;
+    if (masked) {
+      scs.push_back(prep(scores[i], "weight_hypernet_multi"));
+      TORCH_CHECK(scs[i].scalar_type() == scs[0].scalar_type(), "weight_hypernet_multi: all scores must share one dtype");
+      TORCH_CHECK_NOT_IMPLEMENTED(scs[i].sizes() == wcs[i].sizes(), "weight_hypernet_multi: score and weight shapes differ");
+    }
+    if (!sq_scales.empty()) {
+      sqs.push_back(sq_scales[i].detach().to(wcs[i].device(), at::kFloat).contiguous());
+      TORCH_CHECK_NOT_IMPLEMENTED(sqs[i].numel() == L, "weight_hypernet_multi: scale length differs from the channel count");
+    }
+    const at::ScalarType od = out_dtype.value_or(masked ? at::promote_types(wcs[i].scalar_type(), scs[i].scalar_type()) : wcs[i].scalar_type());
+    outs.push_back(empty_like_shape(wcs[i], od));
+    d[i] = dmxq_hypernet_desc{wcs[i].data_ptr(), masked ? scs[i].data_ptr() : nullptr,
+                              sqs.empty() ? nullptr : (const float*)sqs[i].data_ptr(), outs[i].data_ptr(), rows, L};
+  }
+  Launch l(wcs[0]);
+  check(dmxq_weight_hypernet_multi(d.data(), (int64_t)d.size(), dt_code(wcs[0].scalar_type()), masked ? dt_code(scs[0].scalar_type()) : 0,
+                                   (int)K, masked ? (int)M : 0, dt_code(outs[0].scalar_type()), block_size, (int)precision, symmetric,
+                                   l.stream), "dmxq_weight_hypernet_multi");
+  return outs;
+}
+std::vector<Tensor> weight_hypernet_multi_meta(at::TensorList ws, int64_t, int64_t, bool, at::TensorList scores, int64_t, int64_t M,
+                                               at::TensorList, OptDtype out_dtype) {
+  std::vector<Tensor> outs;
+  const bool masked = !scores.empty() && M != 0;
+  for (size_t i = 0; i < ws.size(); i++)
+    outs.push_back(empty_like_shape(ws[i], out_dtype.value_or(masked ? at::promote_types(ws[i].scalar_type(), scores[i].scalar_type()) : ws[i].scalar_type())));
+  return outs;
+}
+
 Tensor input_hypernet(const Tensor& x, const Tensor& sq_scale, int64_t precision, int64_t block_size, bool symmetric) {
   const Tensor xc = prep(x, "input_hypernet");
   const int64_t L = xc.dim() ? xc.size(-1) : 1;
@@ -688,6 +732,7 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("bfp_qdq(Tensor x, int precision, int block_size, int block_dim=-1, bool symmetric=True, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");
   m.def("bfp_qdq_nograd(Tensor x, int precision, int block_size, int block_dim=-1, bool symmetric=True, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");  // the same kernel without the Python STE autograd wrapper (2.5 us per call)
   m.def("block_quantize(Tensor a, int wl, bool symmetric, int rounding, int seed=0) -> Tensor");
+  m.def("weight_hypernet_multi(Tensor[] ws, int precision, int block_size, bool symmetric, Tensor[] scores, int K, int M, Tensor[] sq_scales, ScalarType? out_dtype=None) -> Tensor[]");
   m.def("bfp_qdq_multi(Tensor[] xs, int precision, int block_size, int block_dim=-1, bool symmetric=True, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor[]");
   m.def("bfp_pack(Tensor x, int precision, int block_size, bool symmetric=True) -> (Tensor, Tensor)");
   m.def("bfp_unpack(Tensor mant, Tensor exps, int precision, int block_size, ScalarType out_dtype) -> Tensor");
@@ -727,7 +772,7 @@ TORCH_LIBRARY(dmxq, m) {
 #define DMXQ_IMPL(m, name) m.impl(#name, &name)
 #define DMXQ_META(m, name) m.impl(#name, &name##_meta)
 #define DMXQ_FOR_ALL(X, m) \
-  X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, input_hypernet); X(m, binary_cast); X(m, relu_cast); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
+  X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, weight_hypernet_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, input_hypernet); X(m, binary_cast); X(m, relu_cast); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
   X(m, float_qdq); X(m, fixed_qdq); X(m, fixed_qdq_multi); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
   X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, rope); X(m, rope_cast); X(m, softmax); X(m, norm); \
   X(m, unary_cast); X(m, softmax_cast); X(m, norm_cast); X(m, group_minmax_accumulate)

@@ -192,12 +192,12 @@ class DmxModule(torch.nn.Module):
     #: use the single-kernel weight path (csrc/hypernet.hip) when the configuration allows it; results are bit-identical
     fuse_weight_hypernet = True
 
-    def _fused_weight(self, _w, out_dtype=None):
-        """mask -> SmoothQuant scale -> BFP in ONE launch, or None when this configuration must take the chain:
+    def _fused_weight_plan(self, _w):
+        """The arguments of the single-kernel weight path for this module's configuration, or None when it must take the chain:
         inference only (no autograd through the fused op), mask groups, SmoothQuant channels and BFP blocks all along ONE dim -- the
         last (Linear layout: the tiled kernel) or any other (Conv1d / Conv2d weights along in-channels, torch_modules.py:582-585,
         674-677: dmxq_weight_hypernet_strided) --, BlockTopK or Dense sparseness, SAME storage format, plain BFP weight format with
-        nearest rounding."""
+        nearest rounding.  -> (fmt, block_dim, last, score, K, M, sq_scale)"""
         from .format import BlockFloatingPoint
         from .sparse import BlockTopK
         if not self.fuse_weight_hypernet or self.weight_cast is None or _w.dim() == 0 or torch.is_grad_enabled() and _w.requires_grad:
@@ -227,6 +227,14 @@ class DmxModule(torch.nn.Module):
             sq = self.smoothquant.scale
         if not last and score is None and sq is None:
             return None  # a plain cast along another dim: the chain IS one launch (dmxq_bfp_qdq: the column / sub-slab kernels)
+        return fmt, bd, last, score, K, M, sq
+
+    def _fused_weight(self, _w, out_dtype=None):
+        """mask -> SmoothQuant scale -> BFP in ONE launch, or None when this configuration must take the chain (_fused_weight_plan)"""
+        plan = self._fused_weight_plan(_w)
+        if plan is None:
+            return None
+        fmt, bd, last, score, K, M, sq = plan
         from . import ops
         if out_dtype is not None and last:
             # the tiled kernel is instantiated for these (weight, score, output) dtypes (csrc/hypernet.hip); anything else keeps the chain's
@@ -239,8 +247,8 @@ class DmxModule(torch.nn.Module):
             if out_dtype not in ok:
                 out_dtype = None
         y = ops.weight_hypernet(_w.detach(), fmt.precision, fmt.block_size, fmt.symmetric, score, K, M, sq, out_dtype=out_dtype, block_dim=bd)
-        if y is not None and sp is not None and M:
-            sp.mask = None  # not materialised on the fused path
+        if y is not None and self.weight_sparsifier is not None and M:
+            self.weight_sparsifier.mask = None  # not materialised on the fused path
         return y
 
     @property
@@ -817,7 +825,7 @@ class QuickGELU(DmxModule):
     def __init__(self):
         torch.nn.Module.__init__(self)
         self._dmx_init()
-        self.functional_forward = lambda x: x * torch.sigmoid(1.702 * x)
+        self.functional_forward = _quick_gelu
 
     def _forward(self, _input):
         return self.approx_forward((_input,))
@@ -1003,10 +1011,12 @@ class Dropout(DmxModule, torch.nn.Dropout):
     def __init__(self, p: float = 0.5, inplace: bool = False):
         torch.nn.Dropout.__init__(self, p=p, inplace=False)
         self._dmx_init()
-        self.functional_forward = lambda x: F.dropout(x, self.p, self.training, False)
+        # (the function itself, never a closure over `self`: copy.deepcopy treats functions as atomic, so a copied module's closure
+        #  would keep reading the ORIGINAL's p / training, and a local lambda cannot be pickled -- ADVICE r3)
+        self.functional_forward = F.dropout
 
     def _forward(self, _input, *args, **kwargs):
-        return self.approx_forward((_input,))
+        return self.approx_forward((_input,), self.p, self.training, False)
 
 
 class _GELUVariant(DmxModule):
@@ -1126,6 +1136,11 @@ class BAddBMM(DmxModule):
         return torch.baddbmm(input, batch1, batch2, **kwargs)
 
 
+def _quick_gelu(x):
+    """transformers.activations.QuickGELUActivation, a module-level function (picklable, nothing captured)"""
+    return x * torch.sigmoid(1.702 * x)
+
+
 def _all_same_casts(m) -> bool:
     return all(isinstance(c.format, Same) and not c.pre_transform for c in list(m.input_casts.values()) + list(m.output_casts.values()))
 
@@ -1242,18 +1257,32 @@ def link_consumers_from_fx(gm) -> int:
     are leaf `call_module` nodes (what the reference's transform produces: modeling/model.py).  For each DmxModule node, follow its
     value through dropouts that are the identity in inference (p == 0 or eval mode, SAME casts); if EVERY remaining
     user is a `call_module` of a DmxModule that takes the value as its FIRST positional argument (and the value is not a graph output),
-    link the producer to those modules.  Returns the number of producers linked.  (`DmxTracer` below traces a plain nn.Module that way.)"""
+    link the producer to those modules.  Never linked: a producer instance called at more than one site, consumers that do not run
+    DmxModule.forward (compound modules).  Returns the number of producers linked.  (`DmxTracer` below traces a plain nn.Module that way.)"""
     import torch.fx as fx
+    from collections import Counter
     mods = dict(gm.named_modules())
     linked = 0
+    # The link lives on the MODULE, the graph speaks of call SITES: a module instance called at several sites (a shared `self.act`)
+    # has no single set of consumers, and linking it by its last call would hand the BFP-cast (or uncast) value to the readers of
+    # its other calls.  Such producers are never linked (ADVICE r3).
+    calls = Counter(n.target for n in gm.graph.nodes if n.op == "call_module")
 
     def is_identity_dropout(n):
         m = mods.get(n.target) if n.op == "call_module" else None
         return isinstance(m, Dropout) and (not m.training or m.p == 0.0) and _all_same_casts(m)
 
+    def applies_its_input_casts(m):
+        # a consumer whose forward is not DmxModule's (the compound ScaledDotProductAttention, which -- like the reference's,
+        # torch_modules.py:108-192 -- never applies its own query / key / value casts) would drop an absorbed cast entirely
+        return isinstance(m, DmxModule) and not getattr(m, "is_compound", False) and type(m).forward is DmxModule.forward
+
     for node in gm.graph.nodes:
         prod = mods.get(node.target) if node.op == "call_module" else None
         if not isinstance(prod, DmxModule) or isinstance(prod, Dropout):
+            continue
+        if calls[node.target] > 1:
+            link_consumer(prod)
             continue
         frontier, consumers, ok = [node], [], True
         while frontier and ok:
@@ -1266,7 +1295,7 @@ def link_consumers_from_fx(gm) -> int:
                 else:
                     m = mods.get(u.target) if u.op == "call_module" else None
                     pos = [i for i, a in enumerate(u.args) if a is n]
-                    if (isinstance(m, DmxModule) and len(pos) == 1 and not any(a is n for a in u.kwargs.values())
+                    if (applies_its_input_casts(m) and len(pos) == 1 and not any(a is n for a in u.kwargs.values())
                             and all(isinstance(a, fx.Node) for a in u.args[:pos[0]])):   # (earlier args are tensors: the index counts tensors)
                         consumers.append((m, pos[0]))
                     else:
@@ -1315,7 +1344,8 @@ def fold_weights_and_biases(model: torch.nn.Module) -> torch.nn.Module:
     the launch-bound part on a small model (opt-125m: 73 Linear weights of 0.6-2.4 M elements, ~4 us of launch each for
     0.4-1.6 us of streaming), so the modules whose weight path is a single plain cast are BATCHED through the multi-tensor
     entry points (`ops.bfp_qdq_multi` for BFP formats, `ops.fixed_qdq_multi` for calibrated INT8 / INT4 per-tensor or
-    row-group quantisation: one launch per 40-48 tensors); everything else -- sparsifiers, SmoothQuant, storage formats,
+    row-group quantisation: one launch per 40-48 tensors; `ops.weight_hypernet_multi` for the fused N:M mask / SmoothQuant scale ->
+    BFP chain along the last dim: one launch per 32 weights); everything else -- sparsifiers, SmoothQuant, storage formats,
     pre-transforms, the biases -- goes through the module's own `fold_weight_and_bias`, which also finishes the batched ones
     (their weight cast is already SAME by then).  Bit-identical to folding module by module."""
     from . import ops
@@ -1339,6 +1369,33 @@ def fold_weights_and_biases(model: torch.nn.Module) -> torch.nn.Module:
             else:
                 continue
             groups.setdefault(key, []).append(m)
+        # modules whose weight path is the FUSED chain along the last dim (N:M mask and / or SmoothQuant scale -> BFP: Llama-3-8B under
+        # BASELINE.json configs[3]): the whole set in one launch per 32 weights (dmxq_weight_hypernet_multi) -- the loop of
+        # modeling/nn/core.py:178-198 over a layer's weights; the modules' own fold then finds every stage done
+        hyper = {}
+        for m in mods:
+            if any(m in ms for ms in groups.values()) or not m.weight.is_cuda or m.training:
+                continue
+            with torch.no_grad():
+                plan = m._fused_weight_plan(m.weight.data)
+            if plan is None or not plan[2]:
+                continue
+            fmt, _, _, score, K, M, sq = plan
+            key = (m.weight.dtype, m.weight.device, score.dtype if score is not None else None, K, M, sq is not None,
+                   fmt.precision, fmt.block_size, fmt.symmetric)
+            hyper.setdefault(key, []).append((m, score, sq))
+        for (_, _, _, K, M, has_sq, precision, block_size, symmetric), items in hyper.items():
+            outs = ops.weight_hypernet_multi([m.weight.data for m, _, _ in items], precision, block_size, symmetric,
+                                             [sc for _, sc, _ in items] if M else None, K, M, [q for _, _, q in items] if has_sq else None)
+            if outs is None:   # some member is not fusable as a set (alignment, dtype triple): the modules fold one by one below
+                continue
+            for (m, _, _), o in zip(items, outs):
+                m.weight.data = o
+                if M:
+                    m.weight_sparsifier = _LazySparsify(sparseness=Dense())
+                if has_sq:
+                    m.smoothquant._set_flag("fused_to_weight", True)
+                m.weight_cast = CastTo(format=Same())
         for key, ms in groups.items():
             ws = [m.weight.data for m in ms]
             if key[0] == "bfp":

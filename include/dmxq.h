@@ -205,6 +205,17 @@ int dmxq_weight_hypernet(const void* w, int dtype_w, const void* score, int dtyp
                          const float* sq_scale, void* out, int dtype_out, int64_t rows, int64_t L, int64_t block_size,
                          int precision, int symmetric, void* stream);
 
+/* Multi-tensor form of dmxq_weight_hypernet: exactly the result of one dmxq_weight_hypernet call per tensor (one dtype triple, one
+ * N:M pattern, one BFP format for all), in as few launches as possible -- up to 32 weights per launch over a concatenated tile
+ * space.  Replaces the per-module loop of modeling/nn/core.py:178-198 (DmxModule.weight_hypernet, once per module and forward) and
+ * of modeling/model.py fold_weights_and_biases over the Linear weights of a layer: under row sharding over 8 GPUs a
+ * rank's seven Llama-3-8B shards are 1-15 MB each, launch-bound one by one.  `tensors` is a HOST array; sq_scale is float[L] for
+ * every tensor or NULL for every tensor; score is ignored when M == 0.  All-or-nothing: DMXQ_ERR_UNSUPPORTED (nothing launched)
+ * when any tensor has a geometry dmxq_weight_hypernet does not fuse -- the caller then goes tensor by tensor. */
+typedef struct { const void* w; const void* score; const float* sq_scale; void* out; int64_t rows, L; } dmxq_hypernet_desc;
+int dmxq_weight_hypernet_multi(const dmxq_hypernet_desc* tensors, int64_t n_tensors, int dtype_w, int dtype_score, int K, int M,
+                               int dtype_out, int64_t block_size, int precision, int symmetric, void* stream);
+
 /* The same chain for layouts whose blocked dimension is not the contiguous one: w viewed as [outer, L, inner] with the N:M groups,
  * the SmoothQuant channels and the BFP blocks all along L (stride inner) -- Conv1d / Conv2d weights [out, in, k...], whose weight
  * cast, sparsifier and SmoothQuant axis are dim 1 (modeling/nn/torch_modules.py:582-585, 674-677; the chain is

@@ -304,3 +304,90 @@ def test_module_results_never_alias_inputs_or_parameters(dmx):
     lin._weight.data.zero_()
     assert torch.equal(lin.weight, w0)
     assert all(not c.copy_on_same for c in lin.modules() if isinstance(c, dmx.CastTo))
+
+
+# ------------------------------------------------------------------------------------------------ ADVICE r3
+def test_fx_links_skip_producers_called_at_several_sites_and_compound_consumers(dmx):
+    """link_consumers_from_fx: the link is stored on the MODULE, so a producer instance called twice has no single consumer set and
+    must stay unlinked; a consumer that does not run DmxModule.forward (the compound SDPA never applies its own input casts)
+    must not absorb a producer's cast."""
+    import torch.fx as fx
+    nn = dmx.nn
+
+    class Shared(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc0, self.fc1, self.fc2 = nn.Linear(64, 64), nn.Linear(64, 64), nn.Linear(64, 64)
+            self.act = nn.ReLU()
+            self.norm = nn.LayerNorm(64)
+
+        def forward(self, x):
+            a = self.act(self.fc0(x))            # first call site: read by torch.sin AND fc1
+            b = self.act(self.fc1(a) + torch.sin(a))   # second call site: read by fc2 only
+            return self.fc2(self.norm(b))
+
+    m = Shared()
+    for mod in m.modules():
+        if isinstance(mod, nn.DmxModule):
+            mod.configure({"input_formats": ["BFP[8|8]{64}(SN)"]} if isinstance(mod, nn.Linear) else {})
+    gm = fx.GraphModule(m, nn.DmxTracer().trace(m))
+    nn.link_consumers_from_fx(gm)
+    assert "_next_consumers" not in m.act.__dict__, "a module called at two sites must not be linked by its last call"
+    assert m.norm.__dict__.get("_next_consumers") == ((m.fc2, 0),)      # single call site, single DmxModule reader: linked
+
+    class IntoCompound(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q = nn.Linear(64, 64)
+            self.sdpa = nn.ScaledDotProductAttention()
+
+        def forward(self, x):
+            q = self.q(x)
+            return self.sdpa(q, x, x)
+
+    m2 = IntoCompound()
+    gm2 = fx.GraphModule(m2, nn.DmxTracer().trace(m2))
+    nn.link_consumers_from_fx(gm2)
+    assert "_next_consumers" not in m2.q.__dict__
+
+
+def test_dropout_and_quick_gelu_survive_deepcopy_and_pickle(dmx):
+    """functional_forward must not be a closure over the instance: a deepcopy would keep reading the ORIGINAL's p / training, and a
+    local lambda cannot be pickled (the reference's modules have neither problem)"""
+    import copy
+    import io
+    import pickle
+
+    nn = dmx.nn
+    d = nn.Dropout(p=0.5)
+    d.train()
+    c = copy.deepcopy(d)
+    c.eval()
+    x = torch.ones(1000)
+    assert torch.equal(c(x), x), "a copied Dropout in eval() must be the identity"
+    d.eval()
+    c.train()
+    assert int((c(x) == 0).sum()) > 300 and torch.equal(d(x), x)
+    for mod in (nn.Dropout(p=0.25), nn.QuickGELU()):
+        back = pickle.loads(pickle.dumps(mod))
+        assert type(back) is type(mod)
+        buf = io.BytesIO()
+        torch.save(mod, buf)
+    q = nn.QuickGELU()
+    xs = torch.linspace(-3, 3, 50)
+    assert torch.equal(copy.deepcopy(q)(xs), xs * torch.sigmoid(1.702 * xs))
+
+
+def test_host_flag_mirrors_fall_back_to_the_buffers(dmx):
+    """_flags.HostFlags: a module whose __dict__ lacks the mirrors (pickled by an earlier version) reads its buffers once; the
+    scalar mirror equals the BUFFER's value (0.3 -> float32(0.3)) whichever path wrote it"""
+    sq = dmx.smoothquant.ActivationWeightSmoothQuant(ch_axis=-1, win_ch_axis=-1) if hasattr(dmx, "smoothquant") else None
+    if sq is None:
+        pytest.skip("no smoothquant module")
+    sq.set_migration_strength(0.3)
+    via_set = sq._scalar("migration_strength")
+    for k in [k for k in sq.__dict__ if k.startswith("_h_")]:
+        del sq.__dict__[k]
+    assert sq._scalar("migration_strength") == via_set == float(torch.tensor(0.3, dtype=torch.float32))
+    assert sq._flag("enabled") in (0, 1)
+    assert "migration_strength" in sq.extra_repr()

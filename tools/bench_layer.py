@@ -3,7 +3,7 @@
 
     python bench.py --workload layer --model {opt125m,llama,whisper} [--steps K --warmup W]      (prints one JSON line)
     python tools/bench_layer.py --model llama                                                     (the same, stand-alone)
-    rocprofv3 --kernel-trace --stats ... -- python3 bench.py --workload layer --model llama --profile-mode eager
+    rocprofv3 --kernel-trace --stats ... -- python3 bench.py --workload layer --model llama --layer-modes live
     python tools/bench_layer.py --summarise <dir with *_kernel_stats.csv>                          (dmxq / GEMM / other shares)
 
 The layer is built from this library's DmxModules (dmx_compressor_amd.nn: the mirror of modeling/nn/torch_modules.py) with
