@@ -391,3 +391,28 @@ def test_host_flag_mirrors_fall_back_to_the_buffers(dmx):
     assert sq._scalar("migration_strength") == via_set == float(torch.tensor(0.3, dtype=torch.float32))
     assert sq._flag("enabled") in (0, 1)
     assert "migration_strength" in sq.extra_repr()
+
+
+def test_patch_reference_surface_and_cpu_routing(dmx):
+    """integration.patch_reference against the RECORDED surface of the real classes (oracle/check_patch_reference.py ran it on the
+    reference itself): every attribute the wrappers read is there; on stand-ins, CPU tensors reach the original methods and undo()
+    restores them."""
+    import json
+
+    from dmx_compressor_amd import integration as I
+
+    surf = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_surface.json")))
+    for cls, names in I.SURFACE.items():
+        assert set(names) <= set(surf["attributes"][cls]), cls
+    assert surf["cpu_results_identical_before_and_after_patching"] >= 60
+    fm, sm, qm, StandinCalled = I.standins_from_surface(surf["attributes"])
+    before = fm.BlockFloatingPoint.cast
+    undo = I.patch_reference(format_module=fm, sparse_module=sm, quant_function_module=qm)
+    assert len(undo.patched) == 7 and fm.BlockFloatingPoint.cast is not before
+    f = fm.BlockFloatingPoint()
+    f.precision, f.block_size, f.symmetric, f.rounding = 8, 16, True, "nearest"
+    with pytest.raises(StandinCalled):
+        f.cast(torch.zeros(4, 16), -1)
+    assert qm.get_module(torch.zeros(2)) == "reference-native-module"
+    undo()
+    assert fm.BlockFloatingPoint.cast is before

@@ -101,3 +101,81 @@ def test_hypernet_multi_c_abi_validation(dmx, cuda):
     assert f(d, 2, lib.BF16, 0, 0, 0, lib.BF16, 64, 8, 1, sp) == lib.ERR_BAD_ARG                # scale on some tensors only
     assert f(d, 0, lib.BF16, 0, 0, 0, lib.BF16, 64, 8, 1, sp) == lib.OK
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------ the reference-side binding
+def _surface():
+    import json
+    import os
+
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_surface.json")))
+
+
+def _standin(cls, **attrs):
+    o = cls()
+    for k, v in attrs.items():
+        setattr(o, k, v)
+    return o
+
+
+def test_patch_reference_on_standins_sends_gpu_tensors_to_the_library(dmx, cuda, oracle):
+    """integration.patch_reference -- the function a maintainer applies to the real reference (checked against it in the build
+    container: oracle/check_patch_reference.py) -- applied here to stand-ins built from the RECORDED surface of the reference's
+    classes (attribute and parameter names, tests/golden/reference_surface.json).  GPU tensors must come back as the oracle's
+    results; CPU tensors must reach the original method (which, on a stand-in, raises)."""
+    from dmx_compressor_amd import integration as I
+
+    surf = _surface()
+    for cls, names in I.SURFACE.items():
+        assert set(names) <= set(surf["attributes"][cls]), (cls, "the patch reads an attribute the real class does not have")
+    assert surf["parameters"]["BlockFloatingPoint.cast"] == ["self", "x", "block_dim"]
+    fm, sm, qm, StandinCalled = I.standins_from_surface(surf["attributes"])
+    undo = I.patch_reference(format_module=fm, sparse_module=sm, quant_function_module=qm)
+    try:
+        x = make("heavy", (64, 256), seed=3)
+        xb = x.to(BF16)
+        # BFP: symmetric / asymmetric / block_dim / the block-size-1 detour
+        for p, B, sym, bd, t in ((8, 64, True, -1, xb), (8, 16, False, -1, x), (8, 16, True, 0, xb), (24, 1, True, -1, x)):
+            f = _standin(fm.BlockFloatingPoint, precision=p, block_size=B, symmetric=sym, rounding="nearest")
+            got = f.cast(t.to(cuda), bd)
+            assert got.dtype == F32 and bits_equal(got, oracle.bfp_cast(t, p, B, bd, sym).contiguous()) == 0, (p, B, sym, bd)
+            with pytest.raises(StandinCalled):
+                f.cast(t, bd)                               # CPU tensors stay with the reference
+        # FloatingPoint: FLOAT16-FN, E4M3, unsigned; the pass-through of the native dtype
+        fp = type("FP", (fm.FloatingPoint,), {"__repr__": lambda s: s._r})
+        f16fn = _standin(fp, mantissa=10, exponent=5, bias=15, flush_subnormal=True, unsigned=False, rounding="nearest", _r="FP[1|5|10,15](FN)")
+        assert bits_equal(f16fn.cast(x.to(cuda)), oracle.floating_point_cast(x, 10, 5, 15, True)) == 0
+        e4m3 = _standin(fp, mantissa=3, exponent=4, bias=7, flush_subnormal=False, unsigned=True, rounding="nearest", _r="FP[0|4|3,7](_N)")
+        assert bits_equal(e4m3.cast(xb.to(cuda)), oracle.floating_point_cast(xb, 3, 4, 7, False, unsigned=True)) == 0
+        f16n = _standin(fp, mantissa=10, exponent=5, bias=15, flush_subnormal=False, unsigned=False, rounding="nearest", _r="FP[1|5|10,15](_N)")
+        h = x.to(F16).to(cuda)
+        assert f16n.cast(h) is h
+        # FixedPoint, SBFP, MXFP
+        xp = _standin(fm.FixedPoint, precision=8, fraction=0, clamp=True, symmetric=True, rounding="nearest")
+        assert bits_equal(xp.cast((x * 20).to(cuda)), oracle.fixed_point_cast(x * 20, 8, 0, True, True)) == 0
+        sb = _standin(fm.ScaledBlockFloatingPoint, block_size=16, scaler_format_exponent_bias_determined=True,
+                      block_format=_standin(fm.FixedPoint, precision=4, fraction=0, clamp=True, symmetric=True, rounding="nearest"),
+                      scaler_format=_standin(fp, mantissa=4, exponent=4, bias=7, flush_subnormal=True, unsigned=True, rounding="nearest", _r=""))
+        assert bits_equal(sb.cast(x.to(cuda), -1), oracle.sbfp_cast(x, 4, 16, 4, 4, 7)) == 0
+        mx = _standin(fm.MXFP, block_size=32, element_format=_standin(fp, mantissa=3, exponent=4, _r=""))
+        assert bits_equal(mx.cast(x.to(cuda), -1), oracle.mxfp_cast(x, 3, 4, 32)) == 0
+        # Sparsify.forward: inference on the GPU -> this library's mask, `x * mask`; training / CPU -> the reference
+        score = make("normal", (64, 256), seed=9).abs()
+        sp = _standin(sm.Sparsify, sparseness=_standin(sm.BlockTopK, K=2, block_size=4, block_dim=-1), plastic=False,
+                      score=score.to(cuda), mask=None, training=False)
+        y = sp.forward(x.to(cuda))
+        assert bits_equal(y, oracle.sparsify(x, score, 2, 4)) == 0 and bits_equal(sp.mask, oracle.nm_mask(score, 2, 4)) == 0
+        sp.plastic, sp.score_func = True, (lambda s, t: t.abs())     # used for exactly ONE forward (sparse.py:289-293)
+        y = sp.forward(x.to(cuda))
+        assert sp.plastic is False and bits_equal(y, oracle.sparsify(x, x.abs(), 2, 4)) == 0
+        sp.training = True
+        with pytest.raises(StandinCalled):
+            sp.forward(x.to(cuda))
+        # the native-module choice (S1)
+        assert qm.get_module(x.to(cuda)) is dmx.quant.quant_hip and qm.get_module(x) == "reference-native-module"
+        with pytest.raises(RuntimeError):
+            I.patch_reference(format_module=fm)             # twice
+    finally:
+        undo()
+    with pytest.raises(StandinCalled):
+        _standin(fm.BlockFloatingPoint, precision=8, block_size=64, symmetric=True, rounding="nearest").cast(x.to(cuda), -1)
