@@ -24,22 +24,74 @@ __device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
   else atomicMax((unsigned int*)addr, f2u(v));
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+// ---------------------------------------------------------------------------------------------------------------------------
+// min / max of 16-bit floats ON THE PACKED WORDS (round 4).  bf16 and fp16 are sign-magnitude: read as u16, every negative pattern
+// lies above every positive one and grows with the magnitude; read as i16, positives lie above negatives and grow with the value.
+// With umax = max_u16, imax = max_i16, umin = min_u16 over all words (3 packed operations per dword = 2 elements, instead of two
+// widenings, two v_min and two v_max):
+//   min = umax if its sign bit is set (some negative value: the one of largest magnitude), else umin (all positive: the smallest);
+//   max = imax if imax >= 0 (some positive value: the largest), else umin (all negative: the one of smallest magnitude).
+// NaN comes out for free: a +NaN (0x7F81.. / 0x7C01..) is the largest i16, a -NaN the largest u16, and torch.amin / amax -- what
+// the reference's observer calls (numerical/observer.py:173-193) -- propagate NaN: either one makes BOTH results NaN.
+// (tools/tune_reduce2.hip, profiles/r04_tune_reduce_tickets.txt: 7.44 -> 7.19 us for the reduction pass over 32 MiB.)
+struct PkMinMax {
+  u16x2 umax, umin;
+  i16x2 imax;
+  __device__ __forceinline__ void init() { umax = (u16x2){0, 0}; umin = (u16x2){0xFFFF, 0xFFFF}; imax = (i16x2){(int16_t)-32768, (int16_t)-32768}; }
+  __device__ __forceinline__ void add(uint32_t w) {
+    const u16x2 u = __builtin_bit_cast(u16x2, w);
+    umax = __builtin_elementwise_max(umax, u);
+    umin = __builtin_elementwise_min(umin, u);
+    imax = __builtin_elementwise_max(imax, __builtin_bit_cast(i16x2, w));
+  }
+  // -> (lo, hi) as floats; `seen` = at least one element was added; a NaN anywhere gives (-NaN, +NaN), which the float atomics
+  // below carry to the output (the -NaN pattern wins every unsigned max, the +NaN pattern every signed max)
+  template <int DT>
+  __device__ __forceinline__ void finish(float& lo, float& hi) const {
+    const uint32_t um = max((uint32_t)umax.x, (uint32_t)umax.y), un = min((uint32_t)umin.x, (uint32_t)umin.y);
+    const int im = max((int)imax.x, (int)imax.y);
+    constexpr uint32_t kInf = DT == DMXQ_BF16 ? 0x7F80u : 0x7C00u;
+    const bool nan = (um & 0x7FFFu) > kInf && (um & 0x8000u) ? true : (im > (int)kInf);
+    const uint32_t lo16 = (um & 0x8000u) ? um : un, hi16 = im >= 0 ? (uint32_t)im : un;
+    if (DT == DMXQ_BF16) { lo = u2f(lo16 << 16); hi = u2f(hi16 << 16); }
+    else { lo = half_lo(lo16); hi = half_lo(hi16); }
+    if (nan) { lo = u2f(0xFFC00000u); hi = u2f(0x7FC00000u); }
+  }
+};
+// float32 path: fminf / fmaxf drop NaN, so a NaN is tracked on the side (integer max of the |x| patterns: above +Inf's) and
+// turned into (-NaN, +NaN) at the end, as above
+__device__ __forceinline__ void nan_to_both(uint32_t amax_bits, float& lo, float& hi) {
+  if (amax_bits > 0x7F800000u) { lo = u2f(0xFFC00000u); hi = u2f(0x7FC00000u); }
 }
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-  return v;
-}
+__device__ __forceinline__ bool lo_hi_valid(float lo, float hi) { return lo <= hi || lo != lo; }  // something was seen (or NaN)
 
 __global__ void fill2_kernel(float* a, float va, float* b, float vb, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     a[i] = va;
     if (b) b[i] = vb;
+  }
+}
+
+// (lo, hi) of every lane -> one pair per workgroup -> the float atomics.  NaN-aware: a lane that saw a NaN carries (-NaN, +NaN);
+// the wave / workgroup combine keeps it (integer comparisons on the patterns, like the atomics) and the atomics deliver it.
+__device__ __forceinline__ float nmin(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }
+__device__ __forceinline__ float nmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
+template <int T>
+__device__ __forceinline__ void block_minmax_finish(float lo, float hi, float* mn, float* mx) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = nmin(lo, __shfl_xor(lo, o)); hi = nmax(hi, __shfl_xor(hi, o)); }
+  __shared__ float s_lo[T / kWave], s_hi[T / kWave];
+  const int w = threadIdx.x / kWave;
+  if ((threadIdx.x & (kWave - 1)) == 0) { s_lo[w] = lo; s_hi[w] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 1; i < T / kWave; i++) { lo = nmin(lo, s_lo[i]); hi = nmax(hi, s_hi[i]); }
+    if (lo_hi_valid(lo, hi)) {  // at least one element seen
+      atomic_min_f32(mn, lo);
+      atomic_max_f32(mx, hi);
+    }
   }
 }
 
@@ -52,27 +104,17 @@ __global__ __launch_bounds__(kThreads) void group_minmax_kernel(const void* __re
   const int64_t len = ((C - c0 < gs) ? (C - c0) : gs) * inner;  // run length per o
   const int64_t total = outer * len;
   float lo = INFINITY, hi = -INFINITY;
+  uint32_t am = 0u;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   for (int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x; t < total; t += stride) {
     const int64_t o = t / len, r = t % len;
     const float v = load_rt(in, dt, (o * C + c0) * inner + r);
     lo = fminf(lo, v);
     hi = fmaxf(hi, v);
+    am = max(am, f2u(v) & 0x7FFFFFFFu);
   }
-  lo = wave_min(lo);
-  hi = wave_max(hi);
-  __shared__ float s_lo[kThreads / kWave], s_hi[kThreads / kWave];
-  const int w = threadIdx.x / kWave;
-  if ((threadIdx.x & (kWave - 1)) == 0) { s_lo[w] = lo; s_hi[w] = hi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 1; i < kThreads / kWave; i++) { lo = fminf(lo, s_lo[i]); hi = fmaxf(hi, s_hi[i]); }
-    if (lo <= hi) {  // at least one element seen
-      atomic_min_f32(&mn[g], lo);
-      atomic_max_f32(&mx[g], hi);
-    }
-  }
+  nan_to_both(am, lo, hi);
+  block_minmax_finish<kThreads>(lo, hi, &mn[g], &mx[g]);
 }
 
 // 8 consecutive elements, compile-time dtype: the RAW 16-byte vectors first (so that a batch of loads is issued back to
@@ -131,9 +173,13 @@ __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const 
   const int64_t lenv = ((C - c0 < gs) ? (C - c0) : gs) * inner / 8;  // vectors per run
   const int64_t total = outer * lenv;
   float lo = INFINITY, hi = -INFINITY;
+  uint32_t am = 0u;
+  PkMinMax pk;
+  pk.init();
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   // (o, r) walked with carries instead of a 64-bit division per vector; 4 independent loads in flight per lane
   int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const bool any = t < total;
   int64_t o = t / lenv, r = t % lenv;
   const int64_t so = stride / lenv, sr = stride % lenv;
   while (t < total) {
@@ -153,26 +199,20 @@ __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const 
     (void)nv;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      float v[8];
-      widen8<DT>(raw[u], v);
+      if (DT != DMXQ_F32) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) { lo = fminf(lo, v[k]); hi = fmaxf(hi, v[k]); }
+        for (int j = 0; j < 4; j++) pk.add(raw[u].a[j]);
+      } else {
+        float v[8];
+        widen8<DT>(raw[u], v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { lo = fminf(lo, v[k]); hi = fmaxf(hi, v[k]); am = max(am, f2u(v[k]) & 0x7FFFFFFFu); }
+      }
     }
   }
-  lo = wave_min(lo);
-  hi = wave_max(hi);
-  __shared__ float s_lo[kThreads / kWave], s_hi[kThreads / kWave];
-  const int w = threadIdx.x / kWave;
-  if ((threadIdx.x & (kWave - 1)) == 0) { s_lo[w] = lo; s_hi[w] = hi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 1; i < kThreads / kWave; i++) { lo = fminf(lo, s_lo[i]); hi = fmaxf(hi, s_hi[i]); }
-    if (lo <= hi) {
-      atomic_min_f32(&mn[g], lo);
-      atomic_max_f32(&mx[g], hi);
-    }
-  }
+  if (DT != DMXQ_F32) { if (any) pk.finish<DT>(lo, hi); }
+  else nan_to_both(am, lo, hi);
+  block_minmax_finish<kThreads>(lo, hi, &mn[g], &mx[g]);
 }
 
 // outer == 1 (a weight's row slabs along dim 0, or the whole tensor as one group): the vectors of group g are ONE contiguous run, so a
@@ -190,6 +230,10 @@ __global__ __launch_bounds__(kFlatThreads) void group_minmax_flat_kernel(const v
   const int64_t lenv = ((C - c0 < gs) ? (C - c0) : gs) * inner / 8;  // vectors of this group
   const int64_t v0 = c0 * inner / 8;
   float lo = INFINITY, hi = -INFINITY;
+  uint32_t am = 0u;
+  PkMinMax pk;
+  pk.init();
+  const bool any = (int64_t)blockIdx.x * (T * U) < lenv;   // (every lane of a workgroup that has a tile adds at least one -- clamped -- vector)
   for (int64_t b = (int64_t)blockIdx.x * (T * U); b < lenv; b += (int64_t)gridDim.x * (T * U)) {
     Raw8<DT> raw[U];
 #pragma unroll
@@ -200,26 +244,20 @@ __global__ __launch_bounds__(kFlatThreads) void group_minmax_flat_kernel(const v
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      float v[8];
-      widen8<DT>(raw[u], v);
+      if (DT != DMXQ_F32) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) { lo = fminf(lo, v[k]); hi = fmaxf(hi, v[k]); }
+        for (int j = 0; j < 4; j++) pk.add(raw[u].a[j]);
+      } else {
+        float v[8];
+        widen8<DT>(raw[u], v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { lo = fminf(lo, v[k]); hi = fmaxf(hi, v[k]); am = max(am, f2u(v[k]) & 0x7FFFFFFFu); }
+      }
     }
   }
-  lo = wave_min(lo);
-  hi = wave_max(hi);
-  __shared__ float s_lo[T / kWave], s_hi[T / kWave];
-  const int w = threadIdx.x / kWave;
-  if ((threadIdx.x & (kWave - 1)) == 0) { s_lo[w] = lo; s_hi[w] = hi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 1; i < T / kWave; i++) { lo = fminf(lo, s_lo[i]); hi = fmaxf(hi, s_hi[i]); }
-    if (lo <= hi) {
-      atomic_min_f32(&mn[g], lo);
-      atomic_max_f32(&mx[g], hi);
-    }
-  }
+  if (DT != DMXQ_F32) { if (any) pk.finish<DT>(lo, hi); }
+  else nan_to_both(am, lo, hi);
+  block_minmax_finish<T>(lo, hi, &mn[g], &mx[g]);
 }
 
 // vectorised twin of channel_maxabs_kernel: a workgroup covers a strip of 64 x 8 = 512 consecutive columns of the
@@ -236,13 +274,18 @@ __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(cons
   const int64_t col0 = ((int64_t)blockIdx.x * kWave + lane) * 8;
   const int64_t plane = C * inner;
   const bool ok = col0 < plane;
-  float m[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) m[k] = 0.0f;
   // a workgroup takes W * U consecutive rows per pass: wave w rows w, w + W, ...; the U row loads of a lane are all in flight
   // before the first is consumed (tools/tune_reduce.hip: W16 x U8 = 9.4 us on 4096 x 4096 bf16 against 11.6 us with 4 loads per
   // batch and 16 row splits).  Rows past the end re-read the last row: harmless for a maximum.
   // (U < 8: activations of a few thousand rows -- fewer rows per workgroup, more workgroups; see dmxq_channel_maxabs)
+  // 16-bit inputs (round 4): max |x| on the PACKED words -- v_and clears both signs, v_pk_max_u16 -- 2 operations per dword instead of
+  // 4, half the LDS traffic in the combine, and a NaN (the largest magnitude pattern) propagates like torch.amax's
+  // (tools/tune_reduce2.hip: 7.67 -> 7.23 us for the pass over 32 MiB).
+  constexpr bool PK = DT != DMXQ_F32;
+  constexpr int NW = PK ? 4 : 8;   // dwords a lane keeps: 8 columns as 4 packed pairs, or 8 float patterns
+  uint32_t m[NW];
+#pragma unroll
+  for (int k = 0; k < NW; k++) m[k] = 0u;
   if (ok) {
     for (int64_t o = (int64_t)blockIdx.y * (W * U) + w; o < outer; o += (int64_t)gridDim.y * (W * U)) {
       Raw8<DT> raw[U];
@@ -253,27 +296,41 @@ __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(cons
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        float v[8];
-        widen8<DT>(raw[u], v);
+        if (PK) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) m[k] = fmaxf(m[k], fabsf(v[k]));
+          for (int j = 0; j < 4; j++)
+            m[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, m[j]), __builtin_bit_cast(u16x2, raw[u].a[j] & 0x7FFF7FFFu)));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) { m[j] = max(m[j], raw[u].a[j] & 0x7FFFFFFFu); m[4 + j] = max(m[4 + j], raw[u].b[j] & 0x7FFFFFFFu); }
+        }
       }
     }
   }
-  __shared__ float sm[W][kWave * 8];  // [wave][column of the strip]: written 8 consecutive floats per lane, read one per thread
+  __shared__ uint32_t sm[W][NW][kWave];  // [wave][dword of the lane][lane]: conflict-free writes and reads
 #pragma unroll
-  for (int k = 0; k < 8; k++) sm[w][lane * 8 + k] = m[k];
+  for (int k = 0; k < NW; k++) sm[w][k][lane] = m[k];
   __syncthreads();
   // the strip's 512 columns over the first 512 threads (8 waves), each combining the W partial maxima of its column
   if (threadIdx.x < 8 * kWave) {
-    const int c = threadIdx.x;
+    const int c = threadIdx.x;                 // column c of the strip = element c % 8 of lane c / 8
     const int64_t col = (int64_t)blockIdx.x * (kWave * 8) + c;
     if (col < plane) {
-      float r = sm[0][c];
+      const int l = c >> 3, e = c & 7;
+      uint32_t r;
+      if (PK) {
+        uint32_t p = sm[0][e >> 1][l];
 #pragma unroll
-      for (int i = 1; i < W; i++) r = fmaxf(r, sm[i][c]);
+        for (int i = 1; i < W; i++) p = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, p), __builtin_bit_cast(u16x2, sm[i][e >> 1][l])));
+        const uint32_t h = (e & 1) ? (p >> 16) : (p & 0xFFFFu);
+        r = DT == DMXQ_BF16 ? (h << 16) : f2u(half_lo(h));
+      } else {
+        r = sm[0][e][l];
+#pragma unroll
+        for (int i = 1; i < W; i++) r = max(r, sm[i][e][l]);
+      }
       const int64_t ch = inner == 1 ? col : (plane < (1ll << 31) ? (int64_t)((uint32_t)col / (uint32_t)inner) : col / inner);
-      atomicMax((int*)&out[ch], (int)f2u(r));  // r >= 0: int order == float order
+      atomicMax((int*)&out[ch], (int)r);  // |x| patterns: int order == float order, a NaN pattern is above +Inf's
     }
   }
 }
@@ -304,9 +361,9 @@ __global__ __launch_bounds__(kThreads) void channel_maxabs_kernel(const void* __
   const int64_t col = (int64_t)blockIdx.x * kThreads + threadIdx.x;
   const int64_t plane = C * inner;
   if (col >= plane) return;
-  float m = 0.0f;
-  for (int64_t o = blockIdx.y; o < outer; o += gridDim.y) m = fmaxf(m, fabsf(load_rt(in, dt, o * plane + col)));
-  atomicMax((int*)&out[col / inner], (int)f2u(m));  // m >= 0: int order == float order
+  uint32_t m = 0u;  // |x| as bit patterns: integer order == float order, and a NaN pattern (above +Inf's) propagates like torch.amax's
+  for (int64_t o = blockIdx.y; o < outer; o += gridDim.y) m = max(m, f2u(load_rt(in, dt, o * plane + col)) & 0x7FFFFFFFu);
+  atomicMax((int*)&out[col / inner], (int)m);
 }
 
 __global__ void smoothquant_scale_kernel(const float* a, const float* b, int64_t C, float alpha, float smin,

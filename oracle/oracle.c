@@ -390,6 +390,8 @@ int oracle_group_minmax(const float* in, int64_t outer, int64_t C, int64_t inner
       const int64_t g = c / group_size;
       const float* p = in + (o * C + c) * inner;
       for (int64_t i = 0; i < inner; i++) {
+        /* torch.amin / torch.amax (observer.py:181-182) propagate NaN: one NaN in a group makes both results NaN, for good */
+        if (isnan(p[i]) || isnan(mn[g])) { mn[g] = NAN; mx[g] = NAN; continue; }
         if (p[i] < mn[g]) mn[g] = p[i];
         if (p[i] > mx[g]) mx[g] = p[i];
       }

@@ -179,3 +179,59 @@ def test_patch_reference_on_standins_sends_gpu_tensors_to_the_library(dmx, cuda,
         undo()
     with pytest.raises(StandinCalled):
         _standin(fm.BlockFloatingPoint, precision=8, block_size=64, symmetric=True, rounding="nearest").cast(x.to(cuda), -1)
+
+
+# ------------------------------------------------------------------------------------------------ calibration reductions (round 4)
+def _mm_equal(got, want):
+    """min / max compare: same values, NaN == NaN (-0.0 == +0.0: which zero torch.amin keeps depends on its traversal order)"""
+    g, w = got.cpu().float(), want.cpu().float()
+    return bool(((g == w) | (torch.isnan(g) & torch.isnan(w))).all())
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16, F32])
+def test_group_minmax_packed_words_every_sign_mix_and_nan(dmx, cuda, oracle, dtype):
+    """The 16-bit min / max runs on the packed words (max_u16 / max_i16 / min_u16): all-positive, all-negative and mixed groups,
+    zeros of both signs, +-Inf, and NaN -- which must make BOTH results NaN like torch.amin / amax (numerical/observer.py:181-182) --
+    through the flat (outer = 1), the vectorised (outer > 1), the scalar (unaligned) and the accumulate forms."""
+    base = make("heavy", (64, 512), seed=21, dtype=F32).clamp(-6e4, 6e4)
+    x = base.clone()
+    x[0:8] = x[0:8].abs() + 0.5            # all positive
+    x[8:16] = -x[8:16].abs() - 0.5         # all negative
+    x[16:24] = 0.0
+    x[17, 5] = -0.0
+    x[24, 3], x[25, 7] = float("inf"), float("-inf")
+    x[32, 100] = float("nan")
+    x[40:48] = -x[40:48].abs() - 0.5
+    x[41, 9] = float("nan")                # NaN among negatives: must not hide behind the integer order
+    x = x.to(dtype)
+    xn = -x                                # ... and with the NaN's sign flipped
+    for t in (x, xn):
+        for ax, gs in ((0, 8), (0, 64), (1, 64), (1, 8)):
+            mn, mx = dmx.ops.group_minmax(t.to(cuda), ax, gs)
+            omn, omx = oracle.group_minmax(t, ax, gs)
+            assert _mm_equal(mn, omn) and _mm_equal(mx, omx), (dtype, ax, gs)
+            assert torch.isnan(omn).any()
+        mn, mx = dmx.ops.group_minmax(t.reshape(1, -1).to(cuda), 0, 1)
+        assert torch.isnan(mn).all() and torch.isnan(mx).all()
+        u = t[:, 1:].contiguous()          # rows of 511 elements: the scalar kernel
+        mn, mx = dmx.ops.group_minmax(u.to(cuda), 0, 8)
+        omn, omx = oracle.group_minmax(u, 0, 8)
+        assert _mm_equal(mn, omn) and _mm_equal(mx, omx)
+        am = dmx.ops.channel_maxabs(t.to(cuda), -1)
+        assert _mm_equal(am, oracle.channel_maxabs(t, -1)) and torch.isnan(am).sum() == 2
+        assert _mm_equal(dmx.ops.channel_maxabs(u.to(cuda), -1), oracle.channel_maxabs(u, -1))
+    # a running min / max that met a NaN stays NaN (torch.min(cur, running) in the reference)
+    mn, mx = dmx.ops.group_minmax(x.to(cuda), 0, 8)
+    clean = make("normal", (64, 512), seed=22, dtype=dtype)
+    dmx.ops.group_minmax_accumulate(clean.to(cuda), 0, 8, mn, mx)
+    omn, omx = oracle.group_minmax(torch.cat([x, clean], dim=1), 0, 8)
+    assert _mm_equal(mn, omn) and _mm_equal(mx, omx)
+
+
+@pytest.mark.parametrize("shape,ax,gs", [((4096, 4096), 0, 128), ((4096, 4096), 0, 4096), ((1500, 768), 1, 768), ((2, 300, 1024), 2, 16)])
+def test_group_minmax_and_maxabs_at_size_vs_oracle(dmx, cuda, oracle, shape, ax, gs):
+    x = make("heavy", shape, seed=shape[0], dtype=BF16)
+    mn, mx = dmx.ops.group_minmax(x.to(cuda), ax, gs)
+    omn, omx = oracle.group_minmax(x, ax, gs)
+    assert bits_equal(mn, omn) == 0 and bits_equal(mx, omx) == 0
+    assert bits_equal(dmx.ops.channel_maxabs(x.to(cuda), -1), oracle.channel_maxabs(x, -1)) == 0
