@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import DmxqError, check, dtype_code, lib, ptr, require_gpu, split3, stream_of
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "weight_hypernet_multi", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "group_minmax_accumulate", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "weight_hypernet_multi", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "unary_cast_table", "lut16_apply", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "group_minmax_accumulate", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -686,6 +686,29 @@ def unary_cast(x, func: str, cast_in=None, cast_out=None):
     out = torch.empty_like(xc)
     rc = lib().dmxq_unary_cast(ptr(xc), ptr(out), dtype_code(xc.dtype), xc.numel(), _UNARY_KIND[func], 0.0, *cp[0], stream_of(xc))
     return _fused_rc(rc, "dmxq_unary_cast", out)
+
+
+def unary_cast_table(like, func: str, cast_in=None, cast_out=None, param: float = 0.0):
+    """The 65,536-entry table of a unary DmxModule on `like`'s 16-bit dtype and device (dmxq_unary_cast_table); None when a cast is
+    not tabulable."""
+    require_gpu(like, "unary_cast_table")
+    cp = _cast_ptrs(cast_in, cast_out)
+    if cp is None or like.dtype not in (torch.bfloat16, torch.float16):
+        return None
+    kind = 5 if func == "silu_experimental" else _UNARY_KIND[func]
+    table = torch.empty(65536, dtype=torch.int16, device=like.device)
+    rc = lib().dmxq_unary_cast_table(dtype_code(like.dtype), kind, float(param), *cp[0], ptr(table), stream_of(like))
+    return _fused_rc(rc, "dmxq_unary_cast_table", table)
+
+
+def lut16_apply(x, table):
+    """out[i] = table[x[i] as a 16-bit pattern] (dmxq_lut16_apply); None when x is not a whole number of aligned 16-byte vectors."""
+    xc = _prep(x, "lut16_apply")
+    if xc.element_size() != 2 or table.numel() != 65536 or table.element_size() != 2 or table.device != xc.device or not table.is_contiguous():
+        raise ValueError("lut16_apply: a 16-bit tensor and a 65536-entry 16-bit table on its device")
+    out = torch.empty_like(xc)
+    rc = lib().dmxq_lut16_apply(ptr(xc), ptr(out), xc.numel(), ptr(table), stream_of(xc))
+    return _fused_rc(rc, "dmxq_lut16_apply", out)
 
 
 def softmax_cast(x, dim: int = -1, cast_in=None, cast_out=None, input_clamp: Optional[float] = None, then_bfp=None):

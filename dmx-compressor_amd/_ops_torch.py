@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import DmxqError, ROUNDING_CODE, require_gpu
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "weight_hypernet_multi", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "group_minmax_accumulate", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "weight_hypernet_multi", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "unary_cast_table", "lut16_apply", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "group_minmax_accumulate", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -466,6 +466,30 @@ def unary_cast(x, func: str, cast_in=None, cast_out=None):
         return None
     try:
         return _ops.unary_cast(x, _UNARY_KIND[func], 0.0, _fmt4(cast_in), _fmt4(cast_out))
+    except NotImplementedError:
+        return None
+
+
+def unary_cast_table(like, func: str, cast_in=None, cast_out=None, param: float = 0.0):
+    """The 65,536-entry table of a unary DmxModule on `like`'s 16-bit dtype and device: table[p] = cast_out(f(cast_in(x_p))) for input
+    pattern p, f in float64 rounded once (dmxq_unary_cast_table).  func as unary_cast, plus "silu_experimental" (param = scale).
+    Casts: FloatingPoint formats (nearest, signed; rounding casts allowed) or None.  None when a cast is not tabulable."""
+    require_gpu(like, "unary_cast_table")
+    if like.dtype not in (torch.bfloat16, torch.float16) or not _casts_ok(cast_in, cast_out):
+        return None
+    kind = 5 if func == "silu_experimental" else _UNARY_KIND[func]
+    try:
+        return _ops.unary_cast_table(like, kind, float(param), _fmt4(cast_in), _fmt4(cast_out))
+    except NotImplementedError:
+        return None
+
+
+def lut16_apply(x, table):
+    """out[i] = table[x[i] as a 16-bit pattern] (dmxq_lut16_apply): the application of unary_cast_table's result.  None when x is not
+    a whole number of aligned 16-byte vectors."""
+    require_gpu(x, "lut16_apply")
+    try:
+        return _ops.lut16_apply(x, table)
     except NotImplementedError:
         return None
 

@@ -63,7 +63,6 @@ struct PkMinMax {
 __device__ __forceinline__ void nan_to_both(uint32_t amax_bits, float& lo, float& hi) {
   if (amax_bits > 0x7F800000u) { lo = u2f(0xFFC00000u); hi = u2f(0x7FC00000u); }
 }
-__device__ __forceinline__ bool lo_hi_valid(float lo, float hi) { return lo <= hi || lo != lo; }  // something was seen (or NaN)
 
 __global__ void fill2_kernel(float* a, float va, float* b, float vb, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,24 +72,38 @@ __global__ void fill2_kernel(float* a, float va, float* b, float vb, int64_t n) 
   }
 }
 
-// (lo, hi) of every lane -> one pair per workgroup -> the float atomics.  NaN-aware: a lane that saw a NaN carries (-NaN, +NaN);
-// the wave / workgroup combine keeps it (integer comparisons on the patterns, like the atomics) and the atomics deliver it.
-__device__ __forceinline__ float nmin(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }
-__device__ __forceinline__ float nmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
+// (lo, hi) of every lane -> one pair per workgroup -> the float atomics, on ORDER-PRESERVING KEYS: key(f) = bits ^ (sign ? ~0 : 1 << 31)
+// orders like the floats as an unsigned integer, puts -NaN below -Inf and +NaN above +Inf -- so a lane that saw a NaN (and carries
+// (-NaN, +NaN)) wins every unsigned min / max of the combine with no special case and no branch, like it wins the atomics.
+__device__ __forceinline__ uint32_t fkey(float f) { const uint32_t b = f2u(f); return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u); }
+__device__ __forceinline__ float fkey_inv(uint32_t k) { return u2f(k ^ ((k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu)); }
+__device__ __forceinline__ void wave_minmax_keys(uint32_t& lo, uint32_t& hi) {
+  // 16-lane rows by DPP (no LDS crossbar), then two xor shuffles across the rows
+#define DMXQ_MM_DPP(ctrl)                                                                                   \
+  lo = min(lo, (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, ctrl, 0xF, 0xF, false));            \
+  hi = max(hi, (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, ctrl, 0xF, 0xF, false))
+  DMXQ_MM_DPP(0xB1);   // quad_perm 1,0,3,2
+  DMXQ_MM_DPP(0x4E);   // quad_perm 2,3,0,1
+  DMXQ_MM_DPP(0x141);  // row_half_mirror
+  DMXQ_MM_DPP(0x140);  // row_mirror
+#undef DMXQ_MM_DPP
+  lo = min(lo, (uint32_t)__shfl_xor((int)lo, 16)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, 16));
+  lo = min(lo, (uint32_t)__shfl_xor((int)lo, 32)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, 32));
+}
 template <int T>
-__device__ __forceinline__ void block_minmax_finish(float lo, float hi, float* mn, float* mx) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { lo = nmin(lo, __shfl_xor(lo, o)); hi = nmax(hi, __shfl_xor(hi, o)); }
-  __shared__ float s_lo[T / kWave], s_hi[T / kWave];
+__device__ __forceinline__ void block_minmax_finish(float flo, float fhi, float* mn, float* mx) {
+  uint32_t lo = fkey(flo), hi = fkey(fhi);   // (nothing seen: (+Inf, -Inf), which no combine prefers)
+  wave_minmax_keys(lo, hi);
+  __shared__ uint32_t s_lo[T / kWave], s_hi[T / kWave];
   const int w = threadIdx.x / kWave;
   if ((threadIdx.x & (kWave - 1)) == 0) { s_lo[w] = lo; s_hi[w] = hi; }
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int i = 1; i < T / kWave; i++) { lo = nmin(lo, s_lo[i]); hi = nmax(hi, s_hi[i]); }
-    if (lo_hi_valid(lo, hi)) {  // at least one element seen
-      atomic_min_f32(mn, lo);
-      atomic_max_f32(mx, hi);
+    for (int i = 1; i < T / kWave; i++) { lo = min(lo, s_lo[i]); hi = max(hi, s_hi[i]); }
+    if (lo <= hi || lo < fkey(-INFINITY)) {  // at least one element seen (or a NaN: (-NaN, +NaN) also has lo <= hi as keys)
+      atomic_min_f32(mn, fkey_inv(lo));
+      atomic_max_f32(mx, fkey_inv(hi));
     }
   }
 }

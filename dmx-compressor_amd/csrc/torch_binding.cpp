@@ -674,6 +674,31 @@ Tensor unary_cast(const Tensor& x, int64_t kind, double param, at::IntArrayRef c
 }
 Tensor unary_cast_meta(const Tensor& x, int64_t, double, at::IntArrayRef, at::IntArrayRef) { return empty_like_shape(x, x.scalar_type()); }
 
+// the 65,536-entry table of a unary module on a 16-bit dtype (dmxq_unary_cast_table) and its application (dmxq_lut16_apply)
+Tensor unary_cast_table(const Tensor& like, int64_t kind, double param, at::IntArrayRef cast_in, at::IntArrayRef cast_out) {
+  TORCH_CHECK(like.is_cuda() && (like.scalar_type() == at::kBFloat16 || like.scalar_type() == at::kHalf),
+              "unary_cast_table: a bfloat16 / float16 GPU tensor names the dtype and the device");
+  Tensor table = at::empty({65536}, like.options().dtype(at::kShort));
+  dmxq_float_fmt fi, fo;
+  Launch l(like);
+  check(dmxq_unary_cast_table(dt_code(like.scalar_type()), (int)kind, (float)param, fmt_of(cast_in, &fi), fmt_of(cast_out, &fo), table.data_ptr(),
+                              l.stream), "dmxq_unary_cast_table");
+  return table;
+}
+Tensor unary_cast_table_meta(const Tensor& like, int64_t, double, at::IntArrayRef, at::IntArrayRef) {
+  return at::empty({65536}, like.options().dtype(at::kShort));
+}
+Tensor lut16_apply(const Tensor& x, const Tensor& table) {
+  const Tensor xc = prep(x, "lut16_apply");
+  TORCH_CHECK(xc.element_size() == 2 && table.is_cuda() && table.device() == xc.device() && table.numel() == 65536 && table.element_size() == 2 &&
+              table.is_contiguous(), "lut16_apply: a 16-bit tensor and a 65536-entry 16-bit table on its device");
+  Tensor out = empty_like_shape(xc, xc.scalar_type());
+  Launch l(xc);
+  check(dmxq_lut16_apply(xc.data_ptr(), out.data_ptr(), xc.numel(), table.data_ptr(), l.stream), "dmxq_lut16_apply");
+  return out;
+}
+Tensor lut16_apply_meta(const Tensor& x, const Tensor&) { return empty_like_shape(x, x.scalar_type()); }
+
 Tensor softmax_cast(const Tensor& x, double clamp_min, at::IntArrayRef cast_in, at::IntArrayRef cast_out, int64_t bfp_block,
                     int64_t bfp_precision) {  // over the contiguous last dim; bfp_block > 0: the consumer's BFP input cast applied too
   const Tensor xc = prep(x, "softmax_cast");
@@ -766,6 +791,8 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("norm(Tensor x, int cols, Tensor? weight, Tensor? bias, float eps, int kind, ScalarType? out_dtype=None) -> Tensor");
   m.def("unary_cast(Tensor x, int kind, float param, int[] cast_in, int[] cast_out) -> Tensor");
   m.def("softmax_cast(Tensor x, float clamp_min, int[] cast_in, int[] cast_out, int bfp_block=0, int bfp_precision=0) -> Tensor");
+  m.def("unary_cast_table(Tensor like, int kind, float param, int[] cast_in, int[] cast_out) -> Tensor");
+  m.def("lut16_apply(Tensor x, Tensor table) -> Tensor");
   m.def("norm_cast(Tensor x, int cols, Tensor? weight, Tensor? bias, float eps, int kind, int[] cast_in, int[] cast_out, int bfp_block=0, int bfp_precision=0) -> Tensor");
 }
 
@@ -775,7 +802,7 @@ TORCH_LIBRARY(dmxq, m) {
   X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, weight_hypernet_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, input_hypernet); X(m, binary_cast); X(m, relu_cast); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
   X(m, float_qdq); X(m, fixed_qdq); X(m, fixed_qdq_multi); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
   X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, rope); X(m, rope_cast); X(m, softmax); X(m, norm); \
-  X(m, unary_cast); X(m, softmax_cast); X(m, norm_cast); X(m, group_minmax_accumulate)
+  X(m, unary_cast); X(m, unary_cast_table); X(m, lut16_apply); X(m, softmax_cast); X(m, norm_cast); X(m, group_minmax_accumulate)
 
 // "CUDA" is the dispatch key of HIP tensors in a ROCm build of PyTorch
 TORCH_LIBRARY_IMPL(dmxq, CUDA, m) {

@@ -497,13 +497,43 @@ class DmxModule(torch.nn.Module):
                 return False
         return p.detach()
 
+    #: 16-bit tensors: run a unary module (input cast, function, output cast) as a 65,536-entry TABLE lookup (csrc/lut16.hip): the
+    #: table is built once per (function, casts, dtype, device) with the function in float64 rounded ONCE -- the correctly rounded
+    #: result, bit-identical to the reference's CPU evaluation wherever that is correctly rounded -- and kept on the module.
+    #: Tensors below `lut_min_elems` elements keep the direct kernel (dmxq_unary_cast: within one ulp of the same value).
+    lut_activation = True
+    lut_min_elems = 1 << 16
+
+    def _unary_table(self, x, func, cast_in, cast_out):
+        from . import ops
+        key = (func, repr(cast_in), repr(cast_out), x.dtype, x.device)
+        cache = self.__dict__.setdefault("_lut_cache", {})   # (a plain attribute: not a buffer, not in the state_dict; rebuilt on demand)
+        t = cache.get(key)
+        if t is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None   # (no allocation of long-lived state inside a capture: GraphedForward's warm-up forwards build it first)
+            t = ops.unary_cast_table(x, func, cast_in, cast_out)
+            if t is None:
+                return None
+            if len(cache) >= 8:
+                cache.clear()
+            cache[key] = t
+        return t
+
     def _fused_unary(self, x, func_id, func, args, kwargs):
-        """input cast -> per-element function -> output cast as ONE launch (dmxq_unary_cast), or None"""
+        """input cast -> per-element function -> output cast as ONE launch (a table lookup for 16-bit tensors: dmxq_lut16_apply, else
+        dmxq_unary_cast), or None"""
         c = None if (args or kwargs) else self._act_casts(x, func_id)
         if c is None or c[2]:
             return None
         from . import ops
-        out = ops.unary_cast(x.detach(), func, c[0], c[1])
+        out = None
+        if self.lut_activation and x.element_size() == 2 and x.numel() >= self.lut_min_elems and x.numel() % 8 == 0:
+            table = self._unary_table(x, func, c[0], c[1])
+            if table is not None:
+                out = ops.lut16_apply(x.detach(), table)
+        if out is None:
+            out = ops.unary_cast(x.detach(), func, c[0], c[1])
         if out is not None:
             self.approximation_error = None
         return out

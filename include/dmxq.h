@@ -323,6 +323,19 @@ int dmxq_layernorm(const void* in, void* out, int dtype_in, int dtype_out, int64
  * multiple of 4 elements); weight / bias are in the row dtype.  kind: DMXQ_UNARY_GELU .. DMXQ_UNARY_EXP. */
 int dmxq_unary_cast(const void* in, void* out, int dtype, int64_t n, int kind, float param, const dmxq_float_fmt* cast_in,
                     const dmxq_float_fmt* cast_out, void* stream);
+
+/* The same module on a 16-bit tensor as a TABLE (csrc/lut16.hip): cast_out(f(cast_in(x))) is a function of the 16 input bits.
+ * dmxq_unary_cast_table fills table[p] (65,536 entries of 16 bits, device memory owned by the caller) with the module's result for
+ * input PATTERN p: the two casts are the bit-exact casts of dmxq_float_qdq (ANY FloatingPoint format with man_bits <= 22, nearest
+ * rounding -- rounding casts too, which dmxq_unary_cast refuses on 16-bit tensors) with CastTo's `.to(dtype)`, and f is evaluated in
+ * float64 and rounded ONCE to the tensor dtype: the correctly rounded f(cast_in(x)) (QUICK_GELU: its three roundings in the tensor
+ * dtype; DMXQ_UNARY_SILU_EXPERIMENTAL: functional/functions.py:7-21 with scale = param).  dmxq_lut16_apply then computes
+ * out[i] = table[in[i]] with the table in the LDS: no arithmetic per element.  dtype: DMXQ_BF16 or DMXQ_F16.  The table is the
+ * caller's to keep (one per (function, casts, dtype)); the library holds no state.  dmxq_lut16_apply: DMXQ_ERR_UNSUPPORTED when n
+ * is not a whole number of 16-byte vectors or a pointer is not 16-byte aligned. */
+int dmxq_unary_cast_table(int dtype, int kind, float param, const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* table,
+                          void* stream);
+int dmxq_lut16_apply(const void* in, void* out, int64_t n, const void* table, void* stream);
 int dmxq_softmax_cast(const void* in, void* out, int dtype, int64_t rows, int64_t cols, float input_clamp_min,
                       const dmxq_float_fmt* cast_in, const dmxq_float_fmt* cast_out, void* stream);
 /* ... followed by the NEXT module's BFP input cast of the result (the `input_casts` entry of the ActActMatMul / Linear that consumes the

@@ -235,3 +235,92 @@ def test_group_minmax_and_maxabs_at_size_vs_oracle(dmx, cuda, oracle, shape, ax,
     omn, omx = oracle.group_minmax(x, ax, gs)
     assert bits_equal(mn, omn) == 0 and bits_equal(mx, omx) == 0
     assert bits_equal(dmx.ops.channel_maxabs(x.to(cuda), -1), oracle.channel_maxabs(x, -1)) == 0
+
+
+# ------------------------------------------------------------------------------------------------ unary modules as a table (csrc/lut16.hip)
+_FUNC64 = {
+    "gelu": lambda v: v * 0.5 * torch.special.erfc(-v * 0.7071067811865476),
+    "gelu_tanh": lambda v: v * torch.sigmoid(2.0 * 0.7978845608028654 * (v + 0.044715 * v * v * v)),
+    "silu": lambda v: v * torch.sigmoid(v),
+    "exp": torch.exp,
+}
+
+
+def _all_patterns(dtype):
+    return torch.arange(65536, dtype=torch.int32).to(torch.int16).view(dtype)
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("func", ["gelu", "gelu_tanh", "silu", "exp", "quick_gelu"])
+@pytest.mark.parametrize("fmts", [("FP[1|5|10,15](FN)", "FP[1|5|10,15](FN)"), (None, None), ("FP[1|4|3,7](_N)", "FP[1|5|2,15](_N)")])
+def test_unary_table_is_the_correctly_rounded_module_on_every_pattern(dmx, cuda, oracle, dtype, func, fmts):
+    """table[p] == cast_out(round_once(f64 f(cast_in(x_p)))) for all 65,536 input patterns: the casts from the oracle (bit-exact,
+    rounding casts included), the function in float64 rounded ONCE to the tensor dtype -- not "within one ulp".  NaN results by
+    magnitude after the output cast (formats without NaN codes saturate them)."""
+    from dmx_compressor_amd.format import Format
+
+    fi, fo = (Format.from_shorthand(f) if f else None for f in fmts)
+    x = _all_patterns(dtype)
+    table = dmx.ops.unary_cast_table(x.to(cuda), func, fi, fo)
+    assert table is not None and table.dtype == torch.int16 and table.numel() == 65536
+    got = table.cpu().view(dtype)
+
+    def cast(t, f):
+        return t if f is None else oracle.floating_point_cast(t, f.mantissa, f.exponent, f.bias, f.flush_subnormal).to(dtype)
+
+    v = cast(x, fi)
+    if func == "quick_gelu":   # transformers' QuickGELUActivation in the tensor dtype: three roundings
+        t = (1.702 * v.float()).to(dtype)
+        s = torch.sigmoid(t.double()).to(dtype)
+        y = (v.float() * s.float()).to(dtype)
+    else:
+        y = _FUNC64[func](v.double()).to(dtype)     # float64 -> 16 bits: one rounding
+    want = cast(y, fo)
+    g, w = got.float(), want.float()
+    both_nan = torch.isnan(g) & torch.isnan(w)
+    # a NaN before the output cast carries the hardware's / c10's sign: compare magnitudes where the truth was NaN
+    was_nan = torch.isnan(y.float())
+    ok = (got.view(torch.int16) == want.view(torch.int16)) | both_nan | (was_nan & (g.abs() == w.abs()))
+    assert int((~ok).sum()) == 0, (func, dtype, fmts, int((~ok).sum()), x[~ok][:5], got[~ok][:5], want[~ok][:5])
+
+
+@pytest.mark.parametrize("func,ref", [("silu", torch.nn.functional.silu), ("exp", torch.exp), ("gelu", torch.nn.functional.gelu)])
+def test_unary_table_vs_torch_cpu_the_reference_device(dmx, cuda, func, ref):
+    """What the reference returns with vsimd absent is torch's CPU evaluation (functional/approximate.py:300-304).  On bf16 that is
+    the correctly rounded value for silu / exp on every finite input -- so the table is BIT-IDENTICAL to it there; gelu's CPU kernel
+    rounds twice on a few inputs (counted, and within one ulp)."""
+    x = _all_patterns(BF16)
+    got = dmx.ops.unary_cast_table(x.to(cuda), func).cpu().view(BF16)
+    want = ref(x)
+    fin = torch.isfinite(x.float())
+    diff = (got.view(torch.int16) != want.view(torch.int16)) & fin & ~(torch.isnan(got.float()) & torch.isnan(want.float()))
+    n = int(diff.sum())
+    if func in ("silu", "exp"):
+        assert n == 0, (func, n, x[diff][:8], got[diff][:8], want[diff][:8])
+    else:
+        assert n < 300 and float(((got.float() - want.float()).abs()[diff] / want.float().abs()[diff]).max()) < 2.0 ** -6, n
+
+
+@pytest.mark.parametrize("shape", [(4096, 4096), (1, 128, 14336), (300, 264), (3, 8)])
+def test_lut16_apply_and_the_module_path(dmx, cuda, shape):
+    """dmxq_lut16_apply == table[x] on tensors of every size class (one tile per workgroup, looping workgroups, a ragged last tile,
+    fewer vectors than lanes), and the GELU module takes the table for 16-bit tensors above lut_min_elems: same bits as the direct
+    application of its table, within one ulp of the direct kernel."""
+    x = make("heavy", shape, seed=shape[-1], dtype=BF16).to(cuda)
+    table = dmx.ops.unary_cast_table(x, "gelu")
+    got = dmx.ops.lut16_apply(x, table)
+    want = table.view(BF16)[x.view(torch.int16).long() & 0xFFFF]
+    assert bits_equal(got, want) == 0
+    m = dmx.nn.GELU().to(cuda)
+    m.configure({"input_formats": ["FP[1|5|10,15](FN)"], "output_formats": ["FP[1|5|10,15](FN)"]})
+    m.eval()
+    with torch.no_grad():
+        y = m(x)
+        m.lut_activation = False
+        y_direct = m(x)
+    if x.numel() >= m.lut_min_elems:
+        t2 = dmx.ops.unary_cast_table(x, "gelu", m.input_casts.input_cast.format, m.output_casts.output_cast.format)
+        assert bits_equal(y, dmx.ops.lut16_apply(x, t2)) == 0 and len(m.__dict__["_lut_cache"]) == 1
+    d = (y.float() - y_direct.float()).abs()
+    ulp = torch.exp2(torch.floor(torch.log2(y_direct.float().abs().clamp_min(2.0 ** -126)))) * 2.0 ** -7
+    assert bool((d <= ulp).all())

@@ -232,6 +232,13 @@ def main():
             lambda i: L.dmxq_unary_cast(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, n, kind, ctypes.c_float(0.0), pf, pf, sp), k, n * 4)
         run(f"  the three launches it replaces (float_qdq, torch {nm}, float_qdq)",
             lambda i: (fq(xs[i], ys[i], _lib.BF16, n), fq(tf(ys[i], None), ys[(i + 1) % k], _lib.BF16, n)), k, n * 4)
+    # the same modules as a 65,536-entry table lookup (csrc/lut16.hip): the table is built once (not timed), any function costs the same
+    lut = torch.empty(65536, dtype=torch.int16, device=dev)
+    for kind, nm in ((0, "gelu"), (3, "quick_gelu")):
+        assert L.dmxq_unary_cast_table(_lib.BF16, kind, ctypes.c_float(0.0), pf, pf, vp(lut.data_ptr()), sp) == 0
+        torch.cuda.synchronize()
+        run(f"lut16_apply {nm} module: FLOAT16 -> {nm} -> FLOAT16, bf16, as a table lookup (correctly rounded; 4 B/elem)",
+            lambda i: L.dmxq_lut16_apply(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), n, vp(lut.data_ptr()), sp), k, n * 4)
     run("unary_cast gelu module on float32 tensors (general form, 8 B/elem)",
         lambda i: L.dmxq_unary_cast(vp(f32a[i % 6].data_ptr()), vp(f32o[i % 6].data_ptr()), _lib.F32, n, 0, ctypes.c_float(0.0), pf, pf, sp), 6, n * 8)
     run("  the three launches it replaces (float_qdq fp32, torch gelu, float_qdq fp32)",
