@@ -80,41 +80,74 @@ __global__ __launch_bounds__(256) void unary_table_kernel(int kind, float param,
 }
 
 // out[i] = table[in[i]].  One workgroup per CU (128 KiB of LDS), tiles of 1024 x 8 lane-vectors: 4096 x 4096 is exactly one tile per
-// workgroup.  The tile's input loads are issued FIRST, then the table's (served by L2 after the first workgroup of an XCD), so that
-// the table copy rides behind the HBM latency of the inputs.
+// workgroup.  Memory schedule of the first tile, written with explicit instructions because it rests on the ORDER of the loads
+// (vector memory returns in order; left to the compiler, a table load sank behind the inputs and everything waited for HBM):
+//   8 table loads (served by L2 after the first workgroup of an XCD), 8 input loads (HBM)  ->  s_waitcnt vmcnt(8): the table alone
+//   -> copied to the LDS, barrier  ->  input vector u is looked up as soon as IT has arrived (vmcnt(7 - u))  ->  one store burst.
 constexpr int kLutThreads = 1024, kLutUnroll = 8;
+__device__ __forceinline__ u32x4 asm_load16(const void* p) {
+  u32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ u32x4 asm_load16_nt(const void* p) {
+  u32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(r) : "v"(p) : "memory");
+  return r;
+}
+// "the value in x is valid once at most N later loads are outstanding": the register is an in/out operand of the wait, so every use
+// of it is ordered behind the wait
+#define DMXQ_WAIT_VM(N, x) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(x)::"memory")
+__device__ __forceinline__ u32x4 lut_lookup(const uint16_t* s_lut, const u32x4& w) {
+  u32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; j++) o[j] = (uint32_t)s_lut[w[j] & 0xFFFFu] | ((uint32_t)s_lut[w[j] >> 16] << 16);
+  return o;
+}
 __global__ __launch_bounds__(kLutThreads) void lut16_apply_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t n_vec,
                                                                  const uint16_t* __restrict__ table) {
   extern __shared__ uint16_t s_lut[];   // 65536 entries
   constexpr int T = kLutThreads, U = kLutUnroll;
+  static_assert(U == 8, "the wait counts below are written for 8 vectors per lane");
   const int64_t tile = (int64_t)T * U;
-  bool first = true;
-  for (int64_t base = (int64_t)blockIdx.x * tile; base < n_vec; base += (int64_t)gridDim.x * tile) {
+  int64_t base = (int64_t)blockIdx.x * tile;
+  {
+    u32x4 t[8], raw[U];
+#pragma unroll
+    for (int k = 0; k < 8; k++) t[k] = asm_load16((const u32x4*)table + k * T + threadIdx.x);   // 8192 vectors of 16 bytes
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t v = base + (int64_t)u * T + threadIdx.x;
+      raw[u] = asm_load16_nt((const u32x4*)in + (v < n_vec ? v : n_vec - 1));
+    }
+    asm volatile("s_waitcnt vmcnt(8)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7])::"memory");
+#pragma unroll
+    for (int k = 0; k < 8; k++) *((u32x4*)s_lut + k * T + threadIdx.x) = t[k];
+    __syncthreads();
+    DMXQ_WAIT_VM(7, raw[0]); raw[0] = lut_lookup(s_lut, raw[0]);
+    DMXQ_WAIT_VM(6, raw[1]); raw[1] = lut_lookup(s_lut, raw[1]);
+    DMXQ_WAIT_VM(5, raw[2]); raw[2] = lut_lookup(s_lut, raw[2]);
+    DMXQ_WAIT_VM(4, raw[3]); raw[3] = lut_lookup(s_lut, raw[3]);
+    DMXQ_WAIT_VM(3, raw[4]); raw[4] = lut_lookup(s_lut, raw[4]);
+    DMXQ_WAIT_VM(2, raw[5]); raw[5] = lut_lookup(s_lut, raw[5]);
+    DMXQ_WAIT_VM(1, raw[6]); raw[6] = lut_lookup(s_lut, raw[6]);
+    DMXQ_WAIT_VM(0, raw[7]); raw[7] = lut_lookup(s_lut, raw[7]);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int64_t v = base + (int64_t)u * T + threadIdx.x;
+      if (v < n_vec) __builtin_nontemporal_store(raw[u], (u32x4*)out + v);
+    }
+  }
+  // further tiles of a tensor beyond 256 tiles (> 32 MiB): the table is in place
+  for (base += (int64_t)gridDim.x * tile; base < n_vec; base += (int64_t)gridDim.x * tile) {
     u32x4 raw[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int64_t v = base + (int64_t)u * T + threadIdx.x;
       raw[u] = __builtin_nontemporal_load((const u32x4*)in + (v < n_vec ? v : n_vec - 1));
     }
-    if (first) {
-      u32x4 t[8];
 #pragma unroll
-      for (int k = 0; k < 8; k++) t[k] = *((const u32x4*)table + k * T + threadIdx.x);   // 8192 vectors of 16 bytes
-#pragma unroll
-      for (int k = 0; k < 8; k++) *((u32x4*)s_lut + k * T + threadIdx.x) = t[k];
-      __syncthreads();
-      first = false;
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      u32x4 o;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t w = raw[u][j];
-        o[j] = (uint32_t)s_lut[w & 0xFFFFu] | ((uint32_t)s_lut[w >> 16] << 16);
-      }
-      raw[u] = o;
-    }
+    for (int u = 0; u < U; u++) raw[u] = lut_lookup(s_lut, raw[u]);
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int64_t v = base + (int64_t)u * T + threadIdx.x;
@@ -122,6 +155,7 @@ __global__ __launch_bounds__(kLutThreads) void lut16_apply_kernel(const void* __
     }
   }
 }
+#undef DMXQ_WAIT_VM
 
 }  // namespace dmxq
 

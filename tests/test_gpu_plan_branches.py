@@ -71,6 +71,50 @@ def test_per_element_casts_and_functions(dmx, cuda, rows, dtype):
 
 
 @pytest.mark.parametrize("rows", ROWS)
+@pytest.mark.parametrize("dtype", [BF16, F16, F32], ids=["bf16", "f16", "f32"])
+def test_every_size_class_directly_against_the_oracle(dmx, cuda, oracle, rows, dtype):
+    """the mid-size launch geometries of the non-BFP ops were pinned only through the slab identity above (HIP vs
+    HIP).  Here every size class of float_qdq, fixed_qdq (plain and affine: per group of rows, per row, per column), scale_channels,
+    SBFP and MXFP is compared with the CPU oracle itself, bit for bit, on the whole tensor."""
+    ops = dmx.ops
+    xh = _input(rows, dtype, seed=3 * rows + 1)
+    x = xh.to(cuda)
+    cols = xh.shape[1]
+
+    def eq(tag, got, want):
+        bad = bits_equal(got, want.to(dtype).contiguous())
+        assert bad == 0, f"{tag} {dtype} rows={rows}: {bad} elements differ from the oracle"
+
+    eq("float_qdq E4M3", ops.float_qdq(x, 3, 4, 7, False), oracle.floating_point_cast(xh, 3, 4, 7, False))
+    eq("float_qdq FP16(FN)", ops.float_qdq(x, 10, 5, 15, True), oracle.floating_point_cast(xh, 10, 5, 15, True))
+    eq("float_qdq BF16(FN)", ops.float_qdq(x, 7, 8, 127, True), oracle.floating_point_cast(xh, 7, 8, 127, True))
+    eq("fixed_qdq INT8", ops.fixed_qdq(x, 8, 0), oracle.fixed_point_cast(xh, 8, 0, True, True))
+    eq("fixed_qdq XP[8,4] unclamped", ops.fixed_qdq(x, 8, 4, clamp=False), oracle.fixed_point_cast(xh, 8, 4, False, True))
+    g = torch.Generator().manual_seed(rows)
+    n_groups = -(-rows // 128)
+    sc_g, zp_g = torch.rand(n_groups, generator=g) * 0.2 + 0.01, torch.randint(-5, 6, (n_groups,), generator=g)
+    sc_r, zp_r = torch.rand(rows, generator=g) * 0.2 + 0.01, torch.randint(-5, 6, (rows,), generator=g)
+    sc_c, zp_c = torch.rand(cols, generator=g) * 0.2 + 0.01, torch.randint(-5, 6, (cols,), generator=g)
+    sc_c[3], sc_c[cols - 1] = 3e-7, 2.5e6            # outside the reciprocal form's range: the IEEE-division redo
+    eq("INT8 affine, groups of 128 rows", ops.fixed_qdq(x, 8, 0, scale=sc_g.to(cuda), zero_point=zp_g.to(cuda), ch_axis=0, group_size=128),
+       oracle.fixed_point_affine_cast(xh, 8, 0, True, True, sc_g, zp_g, ch_axis=0, group_size=128))
+    eq("INT8 affine per row", ops.fixed_qdq(x, 8, 0, scale=sc_r.to(cuda), zero_point=zp_r.to(cuda), ch_axis=0),
+       oracle.fixed_point_affine_cast(xh, 8, 0, True, True, sc_r, zp_r, ch_axis=0))
+    eq("INT8 affine per column", ops.fixed_qdq(x, 8, 0, scale=sc_c.to(cuda), zero_point=zp_c.to(cuda), ch_axis=1),
+       oracle.fixed_point_affine_cast(xh, 8, 0, True, True, sc_c, zp_c, ch_axis=1))
+    eq("INT4 asymmetric affine per tensor", ops.fixed_qdq(x, 4, 0, True, False, scale=sc_c[:1].to(cuda), zero_point=zp_c[:1].to(cuda)),
+       oracle.fixed_point_affine_cast(xh, 4, 0, True, False, sc_c[:1], zp_c[:1]))
+    # SmoothQuant's x / s and w * s (numerical/smoothquant.py:255-283): IEEE float32 operations rounded once to the tensor dtype
+    eq("scale_channels divide", ops.scale_channels(x, sc_c.to(cuda), 1, True, out_dtype=dtype), xh.float() / sc_c)
+    eq("scale_channels multiply", ops.scale_channels(x, sc_c.to(cuda), 1, False, out_dtype=dtype), xh.float() * sc_c)
+    if dtype != F16:
+        eq("MXFP8[E4M3]{32}", ops.mxfp_qdq(x, 3, 4, 32), oracle.mxfp_cast(xh, 3, 4, 32))
+        eq("MXFP4[E2M1]{32}", ops.mxfp_qdq(x, 1, 2, 32), oracle.mxfp_cast(xh, 1, 2, 32))
+        eq("SBFP12_16", ops.sbfp_qdq(x, 4, 16, 4, 4, 7), oracle.sbfp_cast(xh, 4, 16, 4, 4, 7))
+    eq("BFP[8|8]{64} asym", ops.bfp_qdq(x, 8, 64, symmetric=False), oracle.bfp_cast(xh, 8, 64, -1, False))
+
+
+@pytest.mark.parametrize("rows", ROWS)
 @pytest.mark.parametrize("dtype", [BF16, F32], ids=["bf16", "f32"])
 def test_affine_integer_casts(dmx, cuda, rows, dtype):
     """INT8 with a scale per group of 128 rows (stream kernel, one scale per tile), per row (stream kernel, channel walker), per
