@@ -305,7 +305,11 @@ def test_unary_table_vs_torch_cpu_the_reference_device(dmx, cuda, func, ref):
     x = _all_patterns(BF16)
     got = dmx.ops.unary_cast_table(x.to(cuda), func).cpu().view(BF16)
     want = ref(x)
-    fin = torch.isfinite(x.float())
+    # finite inputs whose TRUE result is a normal number (or zero): in the denormal range torch's float32 evaluation is not the
+    # correctly rounded value any more -- silu(-92.5) = -6.2e-39 is a bf16 denormal, torch returns -0 because its exp(92.5)
+    # overflows float32 -- and the table keeps the true value (17 inputs)
+    truth = _FUNC64[func](x.double()).abs()
+    fin = torch.isfinite(x.float()) & ((truth >= 2.0 ** -126) | (truth == 0))
     diff = (got.view(torch.int16) != want.view(torch.int16)) & fin & ~(torch.isnan(got.float()) & torch.isnan(want.float()))
     n = int(diff.sum())
     if func in ("silu", "exp"):
