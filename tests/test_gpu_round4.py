@@ -308,8 +308,10 @@ def test_unary_table_vs_torch_cpu_the_reference_device(dmx, cuda, func, ref):
     # finite inputs whose TRUE result is a normal number (or zero): in the denormal range torch's float32 evaluation is not the
     # correctly rounded value any more -- silu(-92.5) = -6.2e-39 is a bf16 denormal, torch returns -0 because its exp(92.5)
     # overflows float32 -- and the table keeps the true value (17 inputs)
+    # ... and so do the 6 inputs just above it: for x < -88.7 torch's exp(-x) is already +Inf and silu comes out as -0, where the true
+    # value is still a normal number (silu(-89) = -2.0e-37)
     truth = _FUNC64[func](x.double()).abs()
-    fin = torch.isfinite(x.float()) & ((truth >= 2.0 ** -126) | (truth == 0))
+    fin = torch.isfinite(x.float()) & ((truth >= 2.0 ** -126) | (truth == 0)) & ((x.float() > -88.0) if func == "silu" else True)
     diff = (got.view(torch.int16) != want.view(torch.int16)) & fin & ~(torch.isnan(got.float()) & torch.isnan(want.float()))
     n = int(diff.sum())
     if func in ("silu", "exp"):
