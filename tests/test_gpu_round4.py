@@ -311,13 +311,19 @@ def test_unary_table_vs_torch_cpu_the_reference_device(dmx, cuda, func, ref):
     # ... and so do the 6 inputs just above it: for x < -88.7 torch's exp(-x) is already +Inf and silu comes out as -0, where the true
     # value is still a normal number (silu(-89) = -2.0e-37)
     truth = _FUNC64[func](x.double()).abs()
-    fin = torch.isfinite(x.float()) & ((truth >= 2.0 ** -126) | (truth == 0)) & ((x.float() > -88.0) if func == "silu" else True)
+    # gelu: torch's float32 form 0.5 x (1 + erf(x / sqrt 2)) overflows to Inf for x > 1.7e38 and cancels to +-0 below x = -13, where
+    # the true value is still a normal number: outside the compared range as well
+    fin = torch.isfinite(x.float()) & ((truth >= 2.0 ** -126) | (truth == 0))
+    if func == "silu":
+        fin &= x.float() > -88.0
+    if func == "gelu":
+        fin &= (x.float() > -13.0) & (x.float() < 1.0e38)
     diff = (got.view(torch.int16) != want.view(torch.int16)) & fin & ~(torch.isnan(got.float()) & torch.isnan(want.float()))
     n = int(diff.sum())
     if func in ("silu", "exp"):
         assert n == 0, (func, n, x[diff][:8], got[diff][:8], want[diff][:8])
     else:
-        assert n < 300 and float(((got.float() - want.float()).abs()[diff] / want.float().abs()[diff]).max()) < 2.0 ** -6, n
+        assert n < 100 and float(((got.float() - want.float()).abs()[diff] / want.float().abs()[diff]).max()) < 2.0 ** -6, n
 
 
 @pytest.mark.parametrize("shape", [(4096, 4096), (1, 128, 14336), (300, 264), (3, 8)])
