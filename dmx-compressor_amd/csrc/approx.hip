@@ -321,45 +321,6 @@ __device__ __forceinline__ float seg_max(float v) {
   if (LPR == 64) return fmaxf(lo, hi);
   return (threadIdx.x & 32) ? hi : lo;
 }
-// Lane-vector arithmetic in PAIRS through the packed fp32 pipe (round 4): v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 do two IEEE
-// operations per instruction, and these kernels are bound by VALU issue on 16-bit rows (profiles/r03_pmc_second_tier.txt).  The
-// normalisation keeps the operation sequence of the scalar form element by element -- d = x - mean, g = rstd w, y = fma(d, g, b) --
-// so its values are unchanged; the sums add even and odd elements separately and combine the two at the end (a different, equally
-// valid summation order: results stay within the stated ulps of the float64 truth, tests/test_gpu_act_cast.py).
-template <int EPL>
-__device__ __forceinline__ float vec_sum(const float (&x)[EPL]) {
-  static_assert(EPL % 2 == 0, "pairs");
-  f32x2 t = {x[0], x[1]};
-#pragma unroll
-  for (int k = 2; k < EPL; k += 2) t = t + (f32x2){x[k], x[k + 1]};
-  return t.x + t.y;
-}
-template <int EPL>
-__device__ __forceinline__ float vec_sumsq_centred(const float (&x)[EPL], float mean) {
-  const f32x2 m2 = {mean, mean};
-  f32x2 t = {0.0f, 0.0f};
-#pragma unroll
-  for (int k = 0; k < EPL; k += 2) {
-    const f32x2 d = (f32x2){x[k], x[k + 1]} - m2;
-    t = __builtin_elementwise_fma(d, d, t);
-  }
-  return t.x + t.y;
-}
-// y = (x - mean) * (rstd * w) + b, with w / b optional (wave-uniform pointers decide): layer_norm's affine step
-template <int EPL>
-__device__ __forceinline__ void vec_normalise(const float (&x)[EPL], float mean, float rstd, bool has_w, const float (&ww)[EPL], bool has_b,
-                                              const float (&bb)[EPL], float (&y)[EPL]) {
-  const f32x2 m2 = {mean, mean}, r2 = {rstd, rstd};
-#pragma unroll
-  for (int k = 0; k < EPL; k += 2) {
-    const f32x2 d = (f32x2){x[k], x[k + 1]} - m2;
-    const f32x2 g = has_w ? r2 * (f32x2){ww[k], ww[k + 1]} : r2;
-    const f32x2 r = has_b ? __builtin_elementwise_fma(d, g, (f32x2){bb[k], bb[k + 1]}) : d * g;
-    y[k] = r.x;
-    y[k + 1] = r.y;
-  }
-}
-
 // row slots per wave iteration: about 32 fp32 values per lane (occupancy beats bytes in flight per wave here: 64 was
 // 1-4 % slower on every shape of tools/bench_rows.py)
 constexpr bool kRowEarlyLoads = false;  // layernorm_wave_kernel: next rows requested before this iteration's stores (measured slower, see there)
@@ -442,22 +403,11 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
       s[j] = 0.0f;
 #pragma unroll
       for (int i = 0; i < VPL; i++) {
-        float t;
-        if constexpr (FAST) {   // exp2(x log2 e - m log2 e): the argument and the row sum in pairs (v_pk_fma_f32 / v_pk_add_f32)
-          f32x2 t2 = {0.0f, 0.0f};
+        float t = 0.0f;
 #pragma unroll
-          for (int k = 0; k < EPL; k += 2) {
-            const f32x2 a = __builtin_elementwise_fma((f32x2){x[j][i][k], x[j][i][k + 1]}, (f32x2){1.4426950408889634f, 1.4426950408889634f}, (f32x2){mc, mc});
-            const f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
-            x[j][i][k] = e.x;
-            x[j][i][k + 1] = e.y;
-            t2 = t2 + e;
-          }
-          t = t2.x + t2.y;
-        } else {
-          t = 0.0f;
-#pragma unroll
-          for (int k = 0; k < EPL; k++) { x[j][i][k] = exp_diff(x[j][i][k], m[j]); t += x[j][i][k]; }
+        for (int k = 0; k < EPL; k++) {
+          x[j][i][k] = FAST ? __builtin_amdgcn_exp2f(__builtin_fmaf(x[j][i][k], 1.4426950408889634f, mc)) : exp_diff(x[j][i][k], m[j]);
+          t += x[j][i][k];
         }
         if (RAG && tail && i == i_tail) {  // (wave-uniform) the slot of the overlapped last vector: its repeated elements do not count
           float t2 = 0.0f;
@@ -487,10 +437,7 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
           const int v = i * LPR + sl;
           float y[EPL], q[EPL];
 #pragma unroll
-          for (int k = 0; k < EPL; k += 2) {
-            if constexpr (FAST) { const f32x2 r = (f32x2){x[j][i][k], x[j][i][k + 1]} * (f32x2){inv, inv}; y[k] = r.x; y[k + 1] = r.y; }
-            else { y[k] = x[j][i][k] / s[j]; y[k + 1] = x[j][i][k + 1] / s[j]; }
-          }
+          for (int k = 0; k < EPL; k++) y[k] = FAST ? x[j][i][k] * inv : x[j][i][k] / s[j];
           bfp_epilogue<DT, EPL>(rowcast_pack_out<CAST, DT, EPL>(y, rc), v < nv, lpb, wl, q);
           if (v < nv && r < rows) row_store<DT, EPL>(out, r * cols + (int64_t)v * EPL, q);  // CastTo's `.to(dtype)`: one RNE rounding
         }
@@ -507,10 +454,7 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
           if (v < nv) {
             float y[EPL];
 #pragma unroll
-            for (int k = 0; k < EPL; k += 2) {
-              if constexpr (FAST) { const f32x2 r = (f32x2){x[j][i][k], x[j][i][k + 1]} * (f32x2){inv, inv}; y[k] = r.x; y[k + 1] = r.y; }
-              else { y[k] = x[j][i][k] / s[j]; y[k + 1] = x[j][i][k + 1] / s[j]; }
-            }
+            for (int k = 0; k < EPL; k++) y[k] = FAST ? x[j][i][k] * inv : x[j][i][k] / s[j];
             if constexpr (CAST) {
               const RowVec<DT, EPL> o = rowcast_pack_out<CAST, DT, EPL>(y, rc);
               if constexpr (!RAG) row_store_raw<DT, EPL>(out, r * cols + (int64_t)v * EPL, o);
@@ -604,7 +548,10 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
         rowcast_raw_in<CAST, DT, EPL>(raw[j][i], rc);
         row_widen<DT, EPL>(raw[j][i], x[j][i]);
         rowcast_x_in<CAST, DT, EPL>(x[j][i], rc);
-        if constexpr (!RMS) s += (i * LPR + sl < nv) ? vec_sum<EPL>(x[j][i]) : 0.0f;   // (RMSNorm: no centring, no row sum)
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < EPL; k++) t += x[j][i][k];
+        s += (i * LPR + sl < nv) ? t : 0.0f;
       }
       mean[j] = s;
     }
@@ -619,7 +566,12 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
     for (int j = 0; j < RPW; j++) {
       float q = 0.0f;
 #pragma unroll
-      for (int i = 0; i < VPL; i++) q += (i * LPR + sl < nv) ? vec_sumsq_centred<EPL>(x[j][i], mean[j]) : 0.0f;
+      for (int i = 0; i < VPL; i++) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < EPL; k++) { const float d = x[j][i][k] - mean[j]; t = __builtin_fmaf(d, d, t); }
+        q += (i * LPR + sl < nv) ? t : 0.0f;
+      }
       rstd[j] = q;
     }
 #pragma unroll
@@ -641,7 +593,12 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
         for (int j = 0; j < RPW; j++) {
           const int64_t r = r0 + j * SUB + sub;
           float y[EPL], q[EPL];
-          vec_normalise<EPL>(x[j][i], mean[j], rstd[j], w != nullptr, HOIST_F32 ? wf[i] : ww, b != nullptr, HOIST_F32 ? bf[i] : bb, y);
+#pragma unroll
+          for (int k = 0; k < EPL; k++) {
+            const float g = w ? rstd[j] * (HOIST_F32 ? wf[i][k] : ww[k]) : rstd[j];
+            const float d = x[j][i][k] - mean[j];
+            y[k] = b ? __builtin_fmaf(d, g, HOIST_F32 ? bf[i][k] : bb[k]) : d * g;
+          }
           bfp_epilogue<DT, EPL>(rowcast_pack_out<CAST, DT, EPL>(y, rc), v < nv, lpb, wl, q);
           if (v < nv && r < rows) row_store<DT, EPL>(out, r * cols + (int64_t)v * EPL, q);
         }
@@ -662,7 +619,12 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
           const int64_t r = r0 + j * SUB + sub;
           if (r < rows) {
             float y[EPL];
-            vec_normalise<EPL>(x[j][i], mean[j], rstd[j], w != nullptr, HOIST_F32 ? wf[i] : ww, b != nullptr, HOIST_F32 ? bf[i] : bb, y);
+#pragma unroll
+            for (int k = 0; k < EPL; k++) {
+              const float g = w ? rstd[j] * (HOIST_F32 ? wf[i][k] : ww[k]) : rstd[j];
+              const float d = x[j][i][k] - mean[j];
+              y[k] = b ? __builtin_fmaf(d, g, HOIST_F32 ? bf[i][k] : bb[k]) : d * g;
+            }
             if constexpr (CAST) row_store_raw<DT, EPL>(out, r * cols + (int64_t)v * EPL, rowcast_pack_out<CAST, DT, EPL>(y, rc));
             else row_store<DT, EPL>(out, r * cols + (int64_t)v * EPL, y);
           }
@@ -721,7 +683,12 @@ __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* _
         rowcast_raw_in<CAST, DT, EPL>(raw[j][i], rc);
         row_widen<DT, EPL>(raw[j][i], x[j][i]);
         rowcast_x_in<CAST, DT, EPL>(x[j][i], rc);
-        if constexpr (!RMS) s += (i * kThreads + t < nv) ? vec_sum<EPL>(x[j][i]) : 0.0f;
+        if constexpr (!RMS) {
+          float u = 0.0f;
+#pragma unroll
+          for (int k = 0; k < EPL; k++) u += x[j][i][k];
+          s += (i * kThreads + t < nv) ? u : 0.0f;
+        }
       }
       if constexpr (!RMS) {
         s = seg_sum<kWave>(s);
@@ -740,7 +707,12 @@ __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* _
       mean[j] = RMS ? 0.0f : s * inv_n;
       float q = 0.0f;
 #pragma unroll
-      for (int i = 0; i < VPL; i++) q += (i * kThreads + t < nv) ? vec_sumsq_centred<EPL>(x[j][i], mean[j]) : 0.0f;
+      for (int i = 0; i < VPL; i++) {
+        float u = 0.0f;
+#pragma unroll
+        for (int k = 0; k < EPL; k++) { const float d = x[j][i][k] - mean[j]; u = __builtin_fmaf(d, d, u); }
+        q += (i * kThreads + t < nv) ? u : 0.0f;
+      }
       q = seg_sum<kWave>(q);
       if (lane == 0) red[qb][j][wv] = q;
     }
@@ -764,7 +736,12 @@ __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* _
 #pragma unroll
         for (int j = 0; j < RPW; j++) {
           float y[EPL], q[EPL];
-          vec_normalise<EPL>(x[j][i], mean[j], rstd[j], w != nullptr, ww, b != nullptr, bb, y);
+#pragma unroll
+          for (int k = 0; k < EPL; k++) {
+            const float g = w ? rstd[j] * ww[k] : rstd[j];
+            const float d = x[j][i][k] - mean[j];
+            y[k] = b ? __builtin_fmaf(d, g, bb[k]) : d * g;
+          }
           bfp_epilogue<DT, EPL>(rowcast_pack_out<CAST, DT, EPL>(y, rc), v < nv, lpb, wl, q);
           if (v < nv && r0 + j < rows) row_store<DT, EPL>(out, (r0 + j) * cols + (int64_t)v * EPL, q);
         }
@@ -782,7 +759,12 @@ __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* _
         for (int j = 0; j < RPW; j++) {
           if (r0 + j < rows) {
             float y[EPL];
-            vec_normalise<EPL>(x[j][i], mean[j], rstd[j], w != nullptr, ww, b != nullptr, bb, y);
+#pragma unroll
+            for (int k = 0; k < EPL; k++) {
+              const float g = w ? rstd[j] * ww[k] : rstd[j];
+              const float d = x[j][i][k] - mean[j];
+              y[k] = b ? __builtin_fmaf(d, g, bb[k]) : d * g;
+            }
             if constexpr (CAST) row_store_raw<DT, EPL>(out, (r0 + j) * cols + (int64_t)v * EPL, rowcast_pack_out<CAST, DT, EPL>(y, rc));
             else row_store<DT, EPL>(out, (r0 + j) * cols + (int64_t)v * EPL, y);
           }
