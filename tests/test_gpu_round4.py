@@ -300,8 +300,9 @@ def test_unary_table_is_the_correctly_rounded_module_on_every_pattern(dmx, cuda,
 @pytest.mark.parametrize("func,ref", [("silu", torch.nn.functional.silu), ("exp", torch.exp), ("gelu", torch.nn.functional.gelu)])
 def test_unary_table_vs_torch_cpu_the_reference_device(dmx, cuda, func, ref):
     """What the reference returns with vsimd absent is torch's CPU evaluation (functional/approximate.py:300-304).  On bf16 that is
-    the correctly rounded value for silu / exp on every finite input -- so the table is BIT-IDENTICAL to it there; gelu's CPU kernel
-    rounds twice on a few inputs (counted, and within one ulp)."""
+    the correctly rounded value for silu / exp / gelu wherever its float32 evaluation neither overflows nor cancels -- and the table
+    is BIT-IDENTICAL to it there; in gelu's negative tail (-13 < x <= -3, where 1 + erf(x / sqrt 2) cancels) torch is up to one ulp off
+    the truth on ~200 inputs (counted)."""
     x = _all_patterns(BF16)
     got = dmx.ops.unary_cast_table(x.to(cuda), func).cpu().view(BF16)
     want = ref(x)
@@ -317,13 +318,16 @@ def test_unary_table_vs_torch_cpu_the_reference_device(dmx, cuda, func, ref):
     if func == "silu":
         fin &= x.float() > -88.0
     if func == "gelu":
-        fin &= (x.float() > -13.0) & (x.float() < 1.0e38)
+        tail = fin & (x.float() > -13.0) & (x.float() <= -3.0)   # 1 + erf cancels here: torch is up to an ulp off, the table is not
+        fin &= (x.float() > -3.0) & (x.float() < 1.0e38)
     diff = (got.view(torch.int16) != want.view(torch.int16)) & fin & ~(torch.isnan(got.float()) & torch.isnan(want.float()))
     n = int(diff.sum())
     if func in ("silu", "exp"):
         assert n == 0, (func, n, x[diff][:8], got[diff][:8], want[diff][:8])
     else:
-        assert n < 100 and float(((got.float() - want.float()).abs()[diff] / want.float().abs()[diff]).max()) < 2.0 ** -6, n
+        assert n == 0, (func, n, x[diff][:8], got[diff][:8], want[diff][:8])
+        dt = (got.view(torch.int16) != want.view(torch.int16)) & tail
+        assert 0 < int(dt.sum()) < 400 and float(((got.float() - want.float()).abs()[dt] / want.float().abs()[dt]).max()) <= 2.0 ** -7
 
 
 @pytest.mark.parametrize("shape", [(4096, 4096), (1, 128, 14336), (300, 264), (3, 8)])
