@@ -17,6 +17,9 @@ SHAPES = [(2048, 4096), (3072, 4096), (4096, 4096), (4100, 4096), (4608, 4096), 
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--mid":   # the 16 - 64 MiB band only (A/B of the one-round plan: DMXQ_ROWS_ROUND=0 / 1)
+        global SHAPES
+        SHAPES = [(r, 4096) for r in (2048, 2560, 3072, 3584, 4096, 4100, 4352, 4608, 5000, 5632, 6144, 6200, 8192)]
     dev = torch.device("cuda:0")
     L = _lib.lib()
     vp = ctypes.c_void_p
@@ -35,20 +38,24 @@ def main():
                 def launch(i):
                     rc = L.dmxq_bfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, R, C, 1, B, 8, 2, 1, 0, sp)
                     assert rc == 0
-                for i in range(100):   # long warm-up: clocks and caches settle (10 launches read 10-30 % slow)
-                    launch(i % nbuf)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                for i in range(iters):   # eager C-ABI launches (a hipGraph replay of big kernels measured ~30 % slower here)
-                    launch(i % nbuf)
-                e1.record(stream)
-                torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / iters
+                us = float("inf")
+                for rep in range(3):   # best of three (round 3 printed a single pass: 3072 x 4096 read 10.3 us there, 9.3-9.4 in every later run)
+                    for i in range(100):   # long warm-up: clocks and caches settle (10 launches read 10-30 % slow)
+                        launch(i % nbuf)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    for i in range(iters):   # eager C-ABI launches (a hipGraph replay of big kernels measured ~30 % slower here)
+                        launch(i % nbuf)
+                    e1.record(stream)
+                    torch.cuda.synchronize()
+                    us = min(us, e0.elapsed_time(e1) * 1e3 / iters)
             gbs = n * 4 / (us * 1e-6) / 1e9
             print(f"{R:>9d}x{C:<6d} {B:>4d} {us:9.2f} {gbs:9.1f} {100 * gbs / 8000:6.1f}%  {nbuf}", flush=True)
         del xs, ys
         torch.cuda.empty_cache()  # fresh allocations per shape: blocks carved out of a fragmented cache measured up to 50 % slower
 
+    if len(sys.argv) > 1 and sys.argv[1] == "--mid":
+        return
     # many small weights: one launch per tensor vs the multi-tensor entry point (opt-125m's 73 Linear weights, BFP16_64).
     # Straight C-ABI calls with prebuilt arguments / descriptors (the Python front end adds ~3 us per tensor for allocation
     # and descriptor filling, which is a one-off at fold time and would hide the kernels here).
