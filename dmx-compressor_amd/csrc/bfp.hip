@@ -26,18 +26,12 @@
 //                     blocks (bfp_urows.hip).
 //   bfp_generic_kernel  everything else: one lane per block, strided two-pass (correct for any layout).
 #include <stdio.h>
-#include <stdlib.h>
 
 #include "bfp_rows.hpp"
 
 namespace dmxq {
 
 constexpr int kRowsMaxGrid = 1 << 20;
-// DMXQ_ROWS_ROUND=0 switches the one-round plan for 32-48 MiB tensors off (A/B runs: tools/bench_shapes.py prints both)
-static bool rows_round_enabled() {
-  static const bool on = [] { const char* e = getenv("DMXQ_ROWS_ROUND"); return !(e && e[0] == '0'); }();
-  return on;
-}
 
 // (tile geometry: rows_plan, common.hpp)
 
@@ -122,17 +116,6 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
     // instantiate only what can run (see bfp_cols.hip): literal path for the runtime-rounding build, magic-add for
     // nearest-even; nearest with wl > 20 is routed to the runtime-rounding build by dispatch_mode
     constexpr bool in16 = Elem<DTI>::bytes == 2;
-    // 16-bit -> same 16-bit tensors just above the 512 x 16 plan: ONE round of <= 256 workgroups with a run-time depth (bfp_rows.hpp
-    // bfp_rows_round_kernel) instead of the first, almost empty second round
-    if constexpr (RND == DMXQ_ROUND_NEAREST && in16 && DTI == DTO) {
-      const int64_t per_cu = (int64_t)256 * kRoundThreads;
-      if (fast == 2 && n_vec > ((int64_t)1 << 21) && n_vec <= per_cu * kRoundMaxU && rows_round_enabled()) {
-        const int ucount = (int)((n_vec + per_cu - 1) / per_cu);
-        const int64_t tiles = (n_vec + (int64_t)kRoundThreads * ucount - 1) / ((int64_t)kRoundThreads * ucount);
-        DMXQ_LAUNCH((bfp_rows_round_kernel<DTI, DTO, ASYM, 2, IVB>), dim3((unsigned)tiles), dim3(kRoundThreads), 0, s, in, out, n_vec, ucount, lpb, wl);
-        return launch_status();
-      }
-    }
     if constexpr (RND == kRuntimeRounding) {
       DMXQ_ROWS_GEOM(4);
     } else {
@@ -331,13 +314,6 @@ extern "C" int dmxq_bfp_qdq_describe(int dtype_in, int dtype_out, int64_t outer,
   if (inner == 1 && L % block_size == 0 && pow2 && block_size >= epl && block_size <= 64 * epl && aligned) {
     const bool nearest = rounding == DMXQ_ROUND_NEAREST && precision <= 20;
     const bool single = nearest && ((dtype_in == DMXQ_BF16 && precision <= 14) || (dtype_in == DMXQ_F16 && precision <= 11));
-    const int64_t nv = n / epl, per_cu = (int64_t)256 * kRoundThreads;
-    if (single && dtype_in == dtype_out && nv > ((int64_t)1 << 21) && nv <= per_cu * kRoundMaxU && rows_round_enabled()) {
-      const int u = (int)((nv + per_cu - 1) / per_cu);
-      snprintf(buf, (size_t)buf_len, "dmxq::bfp_rows_round_kernel<%s,%s,nearest,%s,magic-add single rounding> ONE round, tile %dx%d vectors (run-time depth), grid %lld, nt loads+stores",
-               dn[dtype_in], dn[dtype_out], symmetric ? "sym" : "asym", kRoundThreads, u, (long long)((nv + (int64_t)kRoundThreads * u - 1) / ((int64_t)kRoundThreads * u)));
-      return DMXQ_OK;
-    }
     const RowsPlan pl = rows_plan(n / epl, nearest);
     const int64_t grid = pl.tiles < kRowsMaxGrid ? pl.tiles : kRowsMaxGrid;
     snprintf(buf, (size_t)buf_len, "dmxq::bfp_rows_kernel<%s,%s,%s,%s,%s> tile %dx%d vectors, grid %lld, nt loads+stores",

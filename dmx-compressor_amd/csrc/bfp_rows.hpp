@@ -187,75 +187,6 @@ __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restric
 #undef DMXQ_TILE_LOOP
 }
 
-// ONE round for tensors just above the 512 x 16 plan (32 MiB < input <= 48 MiB of 16-bit data; round 4).  Beyond 256 tiles of
-// 512 x 16 the plan used to fall to small 512 x 2 tiles and several rounds per CU, and the first extra round costs a step: 4096 rows of
-// 4096 bf16 ran at 74-77 % of the roofline, 4100-5000 rows at 66 % (profiles/r03_secondary_shapes.txt).  Here the tensor stays ONE
-// round of <= 256 workgroups: each takes 512 x U vectors with U = ceil(n_vec / (256 x 512)) <= 24 chosen at RUN time -- the kernel is
-// compiled for 24 vectors per lane and every per-vector step sits behind a wave-uniform `u < U` -- so the work per workgroup grows
-// with the tensor instead of jumping to a second round.  The last workgroup's vectors past the end are loaded CLAMPED (the same lane
-// position of the tensor's last 512 vectors: whole, valid blocks, so every lane takes part in the DPP block maxima) and not stored.
-constexpr int kRoundThreads = 512, kRoundMaxU = 24;
-template <int DTI, int DTO, bool ASYM, int FAST, int IVB, int LPBC>
-__device__ __forceinline__ void bfp_rows_round_body(const void* __restrict__ in, void* __restrict__ out, int64_t n_vec, int ucount,
-                                                    int lpb_rt, int wl) {
-  constexpr int T = kRoundThreads, UM = kRoundMaxU;
-  constexpr int EPL = IVB / Elem<DTI>::bytes;
-  constexpr int OVB = EPL * Elem<DTO>::bytes;
-  const int lpb = LPBC > 0 ? LPBC : lpb_rt;
-  const int64_t v0 = (int64_t)blockIdx.x * T * ucount + threadIdx.x;
-  const int64_t v_last = n_vec - T + threadIdx.x;   // (n_vec >= T on this plan)
-  u32x4 raw[UM];
-#pragma unroll
-  for (int u = 0; u < UM; u++) {
-    if (u < ucount) {
-      const int64_t vi = v0 + (int64_t)u * T;
-      raw[u] = load_rawv<IVB>((const char*)in + (vi < n_vec ? vi : v_last) * IVB, 0u);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);  // every load is issued before any arithmetic
-  OutVec<DTO, EPL> o[UM];
-  bool all_fast = true;
-#pragma unroll
-  for (int u = 0; u < UM; u++) {
-    if (u < ucount) {
-      const uint32_t mb = group_max_u32(absmax_bits<DTI>(raw[u]), lpb);
-      all_fast = all_fast && bfp_fast_ok(mb, wl);
-      o[u] = bfp_rows_vector<DTI, DTO, DMXQ_ROUND_NEAREST, ASYM, FAST, true, EPL>(raw[u], mb, 0, wl, DMXQ_ROUND_NEAREST, false, 0ull);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  if (__builtin_amdgcn_ballot_w64(!all_fast) != 0ull) {  // rare: a block outside the magic-add form -> literal bit path, from a fresh read
-#pragma unroll
-    for (int u = 0; u < UM; u++) {
-      if (u < ucount) {
-        const int64_t vi = v0 + (int64_t)u * T;
-        const u32x4 r = load_rawv<IVB>((const char*)in + (vi < n_vec ? vi : v_last) * IVB, 0u);
-        const uint32_t m = group_max_u32(absmax_bits<DTI>(r), lpb);
-        if (__builtin_amdgcn_ballot_w64(!bfp_fast_ok(m, wl)) != 0ull)
-          o[u] = bfp_rows_vector<DTI, DTO, DMXQ_ROUND_NEAREST, ASYM, FAST, false, EPL>(r, m, 0, wl, DMXQ_ROUND_NEAREST, false, 0ull);
-      }
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);  // ... and the stores go out as one burst
-#pragma unroll
-  for (int u = 0; u < UM; u++) {
-    if (u < ucount) {
-      const int64_t vi = v0 + (int64_t)u * T;
-      if (vi < n_vec) store_out<DTO, EPL, true>((char*)out + vi * OVB, o[u]);
-    }
-  }
-}
-template <int DTI, int DTO, bool ASYM, int FAST, int IVB = 16>
-__global__ __launch_bounds__(kRoundThreads) void bfp_rows_round_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t n_vec,
-                                                                      int ucount_arg, int lpb_arg, int wl) {
-  const int ucount = __builtin_amdgcn_readfirstlane(ucount_arg), lpb = __builtin_amdgcn_readfirstlane(lpb_arg);
-  switch (lpb) {  // the usual block sizes with a compile-time lane count (branch-free DPP maxima), as bfp_rows_kernel
-    case 2: bfp_rows_round_body<DTI, DTO, ASYM, FAST, IVB, 2>(in, out, n_vec, ucount, lpb, wl); break;
-    case 8: bfp_rows_round_body<DTI, DTO, ASYM, FAST, IVB, 8>(in, out, n_vec, ucount, lpb, wl); break;
-    default: bfp_rows_round_body<DTI, DTO, ASYM, FAST, IVB, 0>(in, out, n_vec, ucount, lpb, wl); break;
-  }
-}
-
 // Multi-tensor form: up to kMultiMax flat tensors in ONE launch (small weights are launch-bound one by one: an empty
 // launch costs ~1.6 us, a 768x768 bf16 tensor streams in 0.4 us).  The tile space of all tensors is concatenated;
 // a workgroup finds its tensor with a scalar search over the descriptors (kernel arguments: s_load, no memory traffic).

@@ -301,8 +301,8 @@ def test_unary_table_is_the_correctly_rounded_module_on_every_pattern(dmx, cuda,
 def test_unary_table_vs_torch_cpu_the_reference_device(dmx, cuda, func, ref):
     """What the reference returns with vsimd absent is torch's CPU evaluation (functional/approximate.py:300-304).  On bf16 that is
     the correctly rounded value for silu / exp / gelu wherever its float32 evaluation neither overflows nor cancels -- and the table
-    is BIT-IDENTICAL to it there; in gelu's negative tail (-13 < x <= -3, where 1 + erf(x / sqrt 2) cancels) torch is up to one ulp off
-    the truth on ~200 inputs (counted)."""
+    is BIT-IDENTICAL to it there; in gelu's negative tail (-13 < x <= -3, where 1 + erf(x / sqrt 2) cancels) torch differs from the
+    truth on ~200 inputs (counted)."""
     x = _all_patterns(BF16)
     got = dmx.ops.unary_cast_table(x.to(cuda), func).cpu().view(BF16)
     want = ref(x)
@@ -327,7 +327,8 @@ def test_unary_table_vs_torch_cpu_the_reference_device(dmx, cuda, func, ref):
     else:
         assert n == 0, (func, n, x[diff][:8], got[diff][:8], want[diff][:8])
         dt = (got.view(torch.int16) != want.view(torch.int16)) & tail
-        assert 0 < int(dt.sum()) < 400 and float(((got.float() - want.float()).abs()[dt] / want.float().abs()[dt]).max()) <= 2.0 ** -7
+        assert 0 < int(dt.sum()) < 400   # (torch loses all relative accuracy there -- gelu(-4.9) comes out 7 % off, gelu(-8) as -0 -- which is
+        #                                     why DESIGN 4.1 counts gelu's error against the cancelling terms; the table holds the true values)
 
 
 @pytest.mark.parametrize("shape", [(4096, 4096), (1, 128, 14336), (300, 264), (3, 8)])

@@ -17,7 +17,7 @@ SHAPES = [(2048, 4096), (3072, 4096), (4096, 4096), (4100, 4096), (4608, 4096), 
 
 
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "--mid":   # the 16 - 64 MiB band only (A/B of the one-round plan: DMXQ_ROWS_ROUND=0 / 1)
+    if len(sys.argv) > 1 and sys.argv[1] == "--mid":   # the 16 - 64 MiB band only
         global SHAPES
         SHAPES = [(r, 4096) for r in (2048, 2560, 3072, 3584, 4096, 4100, 4352, 4608, 5000, 5632, 6144, 6200, 8192)]
     dev = torch.device("cuda:0")
