@@ -49,7 +49,10 @@ struct HnArgs {
 // DIVIDE: the ACTIVATION path of a SmoothQuant module (dmxq_input_hypernet): x / scale instead of w * scale, the quotient kept in
 // torch's promotion of (x dtype, fp32 scale) = fp32, which is then also the dtype the BFP cast sees and hands back.
 // UN units of a lane, `stride` units apart, starting at u0: all their loads are issued before the first one is ranked.
-constexpr int kHnUnits = 4;
+#ifndef DMXQ_HN_UNITS
+#define DMXQ_HN_UNITS 4   // (tools/ab_hn_units.sh builds a second library with 8 for an A/B run)
+#endif
+constexpr int kHnUnits = DMXQ_HN_UNITS;
 template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP, int LPBC, bool ASYM, bool DIVIDE = false>
 __device__ __forceinline__ void hypernet_rows_units(const HnArgs& a, const int lpb, const int64_t u0, const int64_t stride) {
   // T1: dtype after the mask multiply = torch promotion of (w, score); without a mask it stays the weight dtype

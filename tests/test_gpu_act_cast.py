@@ -207,8 +207,18 @@ def test_activation_module_runs_the_fused_kernel(dmx, cuda, oracle, dtype, name)
     fi, fo = m.input_casts.input_cast.format, m.output_casts.output_cast.format
     y = m(x)
     assert m._fused_forward(x) is not None, "fused path not taken"
+    # 16-bit tensors from lut_min_elems elements up take the module's TABLE (csrc/lut16.hip: float64 evaluation rounded once), smaller
+    # ones and float32 the direct kernel
+    if dtype != torch.float32 and x.numel() >= m.lut_min_elems and m.lut_activation:
+        want = dmx.ops.lut16_apply(x, dmx.ops.unary_cast_table(x, func, fi, fo))
+    else:
+        want = dmx.ops.unary_cast(x, func, fi, fo)
     assert torch.equal(y.view(torch.int16 if dtype != torch.float32 else torch.int32),
+                       want.view(torch.int16 if dtype != torch.float32 else torch.int32))
+    m.lut_activation = False
+    assert torch.equal(m(x).view(torch.int16 if dtype != torch.float32 else torch.int32),
                        dmx.ops.unary_cast(x, func, fi, fo).view(torch.int16 if dtype != torch.float32 else torch.int32))
+    m.lut_activation = True
     assert y.dtype == dtype and y.data_ptr() != x.data_ptr()
     f64, floor_fn, tol = UNARY[func]
     cin = _cpu_cast(oracle, fi)(x.cpu())
