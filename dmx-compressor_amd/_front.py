@@ -1,19 +1,20 @@
-"""torch-extension binding of the tensor-level front ends (see ops.py): `torch.ops.dmxq.*`, registered by
-`lib/dmxq_torch.so` (csrc/torch_binding.cpp: device guard, torch's current HIP stream, output allocation, one C-ABI call
-per op, meta kernels).  This module adds what belongs on the Python side: argument spelling (rounding names, torch
-dtypes), the `DmxqError` for non-GPU tensors, seeds for stochastic rounding, and the straight-through-estimator backward
-(`torch.library.register_autograd`) of the fake-quantisation ops -- the reference's CastToFormat / STE
-(numerical/cast.py:19-55: `grad_output` passed through unchanged).
+"""The tensor-level front ends of the library, written ONCE for both bindings of the C ABI (include/dmxq.h).
+
+Every function here is the Python spelling of one (or two) dispatcher ops -- rounding names, torch dtypes, Format objects, the
+`DmxqError` for non-GPU tensors, seeds for stochastic rounding, "None when not fusable" -- over a RAW namespace `_ops` whose
+functions carry the schema of `torch.ops.dmxq.*` (csrc/torch_binding.cpp):
+  * `_backend_torch.RAW`   the TORCH_LIBRARY extension `lib/dmxq_torch.so` (meta kernels, registered straight-through backward);
+  * `_backend_ctypes`      the same schema in Python over plain ctypes (no compiler against the torch headers needed).
+`ops.py` binds one of them (`DMXQ_BINDING=torch|ctypes`).  A new entry point is therefore written in the C ABI, in the two bindings
+(which only allocate and call) and HERE -- not, as until round 3, as two complete front ends.
 
 No CPU path: a non-GPU tensor or a missing library raises `DmxqError`.
 """
 import math
-import os
 from typing import Optional
 
 import torch
 
-from . import _lib
 from ._lib import DmxqError, ROUNDING_CODE, require_gpu
 
 __all__ = [
@@ -22,51 +23,14 @@ __all__ = [
     "rmsnorm", "histc",
 ]
 
-TORCH_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "dmxq_torch.so")
+_ops = None   # the raw namespace: set by bind()
 
 
-def _load():
-    _lib.lib()  # libdmxq.so first (raises DmxqError when it has not been built): dmxq_torch.so links against it
-    if not os.path.exists(TORCH_LIB_PATH):
-        raise DmxqError(f"{TORCH_LIB_PATH} not found: build the torch extension first (python dmx-compressor_amd/build.py or "
-                        "__graft_entry__.build()), or set DMXQ_BINDING=ctypes for the compiler-free binding")
-    torch.ops.load_library(TORCH_LIB_PATH)
-    return torch.ops.dmxq
+def bind(raw) -> None:
+    """ops.py hands over the binding's raw namespace (torch.ops.dmxq overloads, or the _backend_ctypes module)"""
+    global _ops
+    _ops = raw
 
-
-class _Overloads:
-    """`torch.ops.dmxq.<name>.default` resolved once: calling an OpOverload skips the packet's per-call overload
-    resolution (~1.5 us of the host cost of a call)."""
-
-    def __init__(self, ns):
-        self._ns = ns
-
-    def __getattr__(self, name):
-        op = getattr(self._ns, name).default
-        setattr(self, name, op)
-        return op
-
-
-_ops = _Overloads(_load())
-
-
-# ---------------------------------------------------------------------------------------------------- autograd (STE)
-def _ste_setup(ctx, inputs, output):
-    ctx.in_dtype = inputs[0].dtype
-
-
-def _ste_backward(n_args):
-    def backward(ctx, g):
-        if g is not None and g.dtype != ctx.in_dtype:
-            g = g.to(ctx.in_dtype)
-        return (g,) + (None,) * (n_args - 1)
-
-    return backward
-
-
-for _name, _n in (("bfp_qdq", 8), ("sbfp_qdq", 11), ("mxfp_qdq", 6), ("float_qdq", 9), ("fixed_qdq", 12)):
-    torch.library.register_autograd(f"dmxq::{_name}", _ste_backward(_n), setup_context=_ste_setup)
-del _name, _n
 
 _SEED_COUNTER = [0x5EED]
 

@@ -416,3 +416,24 @@ def test_patch_reference_surface_and_cpu_routing(dmx):
     assert qm.get_module(torch.zeros(2)) == "reference-native-module"
     undo()
     assert fm.BlockFloatingPoint.cast is before
+
+
+def test_one_front_end_two_bindings_same_raw_schema(dmx):
+    """`_front.py` is written once over a raw namespace; both bindings must offer every raw op it calls, under the SAME name and
+    parameter list as the dispatcher schema of csrc/torch_binding.cpp (no second front end to keep in step)."""
+    import inspect
+
+    from dmx_compressor_amd import _backend_ctypes as B
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    front = open(os.path.join(root, "dmx-compressor_amd", "_front.py")).read()
+    used = set(re.findall(r"_ops\.([a-z_0-9]+)", front))
+    cpp = open(os.path.join(root, "dmx-compressor_amd", "csrc", "torch_binding.cpp")).read()
+    schemas = {n: re.sub(r"\(\w!\)", "", ps) for n, ps in re.findall(r'm\.def\("([a-z_0-9]+)\((.*?)\) ->', cpp)}   # (drop alias annotations)
+    assert used <= set(schemas), used - set(schemas)
+    for name, params in schemas.items():
+        assert hasattr(B, name), f"the ctypes binding lacks the raw op {name}"
+        want = [p.strip().split("=")[0].split()[-1] for p in params.split(",") if p.strip()]
+        got = list(inspect.signature(getattr(B, name)).parameters)
+        assert got == want, (name, got, want)
+    assert not os.path.exists(os.path.join(root, "dmx-compressor_amd", "_ops_ctypes.py"))

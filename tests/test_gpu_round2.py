@@ -38,8 +38,8 @@ def ulp_distance(a, b):
 # ------------------------------------------------------------------------------------------------ the two bindings
 def test_the_torch_extension_is_the_default_binding_and_is_loaded(dmx, cuda):
     assert dmx.ops.BINDING == os.environ.get("DMXQ_BINDING", "torch")
-    from dmx_compressor_amd import _ops_torch
-    assert os.path.exists(_ops_torch.TORCH_LIB_PATH)
+    from dmx_compressor_amd import _backend_torch
+    assert os.path.exists(_backend_torch.TORCH_LIB_PATH)
     assert hasattr(torch.ops.dmxq, "bfp_qdq") and hasattr(torch.ops.dmxq, "norm")
     maps = open("/proc/self/maps").read()
     assert "dmxq_torch.so" in maps and "libdmxq.so" in maps
@@ -47,8 +47,7 @@ def test_the_torch_extension_is_the_default_binding_and_is_loaded(dmx, cuda):
 
 def test_ctypes_and_torch_bindings_agree(dmx, cuda):
     """the same C ABI behind both: every front end returns identical bits through either binding"""
-    from dmx_compressor_amd import _ops_ctypes as C
-    from dmx_compressor_amd import _ops_torch as T
+    C, T = dmx.ops.front("ctypes"), dmx.ops.front("torch")   # ONE front end (_front.py) over the two bindings' raw namespaces
     x = make("mixed", (96, 512), seed=1, dtype=torch.bfloat16, block=16).to(cuda)
     xf = make("heavy", (64, 384), seed=2).to(cuda)
     score = make("normal", (96, 512), seed=3).to(cuda)
@@ -146,7 +145,7 @@ def test_host_overhead_of_one_cast_call(dmx, cuda):
     x = make("normal", (64, 256), seed=10, dtype=torch.bfloat16).to(cuda)
     c = dmx.CastTo(format="BFP[8|8]{16}(SN)").to(cuda)
     res = {}
-    from dmx_compressor_amd import _ops_ctypes
+    _ops_ctypes = dmx.ops.front("ctypes")
     raw = torch.ops.dmxq.bfp_qdq.default
     y = torch.empty_like(x)
     L, lib = dmx._lib.lib(), dmx._lib

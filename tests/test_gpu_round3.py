@@ -191,8 +191,7 @@ def test_graphed_forward_replays_a_configured_layer(dmx, cuda):
 def test_round3_entry_points_through_both_bindings(dmx, cuda):
     """the round-3 entry points (fused activation / normalisation modules, the strided weight chain) return identical bits through
     the torch extension and the ctypes binding -- the same C ABI behind both"""
-    from dmx_compressor_amd import _ops_ctypes as C
-    from dmx_compressor_amd import _ops_torch as T
+    C, T = dmx.ops.front("ctypes"), dmx.ops.front("torch")
     f16, b16 = dmx.Format.from_shorthand("FP[1|5|10,15](FN)"), dmx.Format.from_shorthand("FP[1|8|7,127](FN)")
     x = (make("normal", (96, 512), seed=1) * 3).to(BF16).to(cuda)
     xf = (make("heavy", (64, 384), seed=2)).clamp(-1e4, 1e4).to(cuda)
