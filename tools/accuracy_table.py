@@ -71,7 +71,7 @@ def fused_modules():
     f16 = d.format.FLOAT16
     cast = lambda t: f16.cast(t, out_dtype=t.dtype)
     print()
-    print(f"{'fused module, FLOAT16 casts (inputs)':46s} {'dtype':9s} {'fused max ulp':>13s} {'unfused max ulp':>15s} {'fused != unfused':>17s}   (vs cast(round(f64 truth(cast(x)))))")
+    print(f"{'fused module, FLOAT16 casts (inputs)':46s} {'dtype':9s} {'fused max ulp':>13s} {'unfused max ulp':>15s} {'fused != unfused':>17s} {'torch-CPU module max ulp':>25s} {'fused != torch-CPU module':>26s}   (ulps vs cast(round(f64 truth(cast(x)))); 'torch-CPU module' = the bit-exact casts around torch's CPU function: what the reference returns with vsimd absent)")
     for dt in (torch.bfloat16, torch.float16, torch.float32):
         x = (make("normal", (1 << 20,), seed=11) * 4.0).to(dt).to(dev)
         r15 = (make("normal", (512, 1500), seed=12) * 3.0).to(dt).to(dev)
@@ -86,14 +86,16 @@ def fused_modules():
             return (cd.abs().amax(-1, keepdim=True) + mu.abs()) * rstd * w.double().abs() + b.double().abs()
 
         cases = [
-            ("GELU, N(0,16)", nn.GELU(), x, lambda c: F.gelu(c.double()), lambda c: c.double().abs() / 2),
-            ("SiLU, N(0,16)", nn.SiLU(), x, lambda c: F.silu(c.double()), None),
-            ("Exp, N(0,16) clamped to +-10", nn.Exp(), x.clamp(-10, 10), lambda c: torch.exp(c.double()), None),
-            ("Softmax rows of 1500, N(0,9)", nn.Softmax(dim=-1), r15, lambda c: torch.softmax(c.double(), -1), None),
-            ("LayerNorm rows of 768, affine", nn.LayerNorm(768), r768, lambda c: F.layer_norm(c.double(), (768,), w768.double(), b768.double(), 1e-5), lambda c: ln_floor(c, w768, b768)),
-            ("RMSNorm rows of 4096, weight", nn.RMSNorm(4096, eps=1e-5), r4096, lambda c: F.rms_norm(c.double(), (4096,), w4096.double(), 1e-5), None),
+            ("GELU, N(0,16)", nn.GELU(), x, lambda c: F.gelu(c.double()), lambda c: c.double().abs() / 2, F.gelu),
+            ("SiLU, N(0,16)", nn.SiLU(), x, lambda c: F.silu(c.double()), None, F.silu),
+            ("Exp, N(0,16) clamped to +-10", nn.Exp(), x.clamp(-10, 10), lambda c: torch.exp(c.double()), None, torch.exp),
+            ("Softmax rows of 1500, N(0,9)", nn.Softmax(dim=-1), r15, lambda c: torch.softmax(c.double(), -1), None, lambda c: torch.softmax(c, -1)),
+            ("LayerNorm rows of 768, affine", nn.LayerNorm(768), r768, lambda c: F.layer_norm(c.double(), (768,), w768.double(), b768.double(), 1e-5), lambda c: ln_floor(c, w768, b768),
+             lambda c: F.layer_norm(c, (768,), w768.cpu(), b768.cpu(), 1e-5)),
+            ("RMSNorm rows of 4096, weight", nn.RMSNorm(4096, eps=1e-5), r4096, lambda c: F.rms_norm(c.double(), (4096,), w4096.double(), 1e-5), None,
+             lambda c: F.rms_norm(c, (4096,), w4096.cpu(), 1e-5)),
         ]
-        for name, m, inp, f64, floor_fn in cases:
+        for name, m, inp, f64, floor_fn, cpu_fn in cases:
             m = m.to(dev).to(dt)
             d.configure_model(m, *d.config_rules.BASIC)
             with torch.no_grad():
@@ -110,7 +112,11 @@ def fused_modules():
             unit = dt if dt != torch.float32 else torch.float16   # float32 tensors: ulps of the OUTPUT CAST's format (10 mantissa bits)
             a, b = err_in_ulps(fused, truth.double(), unit, fl), err_in_ulps(unfused, truth.double(), unit, fl)
             diff = float((fused.float() != unfused.float()).float().mean()) * 100
-            print(f"{name:46s} {str(dt).replace('torch.', ''):9s} {a:13.2f} {b:15.2f} {diff:16.3f}%", flush=True)
+            with torch.no_grad():
+                refm = cast(cpu_fn(c.cpu()).to(dt).to(dev))    # the reference's module: bit-exact casts around torch's CPU evaluation
+            r_ulp = err_in_ulps(refm, truth.double(), unit, fl)
+            rdiff = float((fused.float() != refm.float()).float().mean()) * 100
+            print(f"{name:46s} {str(dt).replace('torch.', ''):9s} {a:13.2f} {b:15.2f} {diff:16.3f}% {r_ulp:25.2f} {rdiff:25.3f}%", flush=True)
 
 
 if __name__ == "__main__":
