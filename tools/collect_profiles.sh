@@ -2,13 +2,21 @@
 # tools/collect_profiles.sh <round tag, e.g. r02> — everything under profiles/ that is measured on the GPU box, in one go.
 # Run through gpurun from the repo root; results land in gpurun_out/<tag>/ and are copied to profiles/ by hand.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 # 1. bench lines: the driver's configuration, the default one, the sharded Llama workloads, a 1-rank torchrun (RCCL init path)
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line_steps20.json 2> $OUT/bench.err
+for i in 2 3; do python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_steps20_run$i.json 2>> $OUT/bench.err; done
+# the N > 1 path on real kernels with the box's single GPU: two ranks share cuda:0, harness transport gloo (round 4)
+python3 bench.py --gpus 2 --dist-backend gloo --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_world2_gloo.json 2>> $OUT/bench.err
+python3 bench.py --gpus 2 --dist-backend gloo --workload llama-shard --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_world2_gloo_llama_hypernet.json 2>> $OUT/bench.err
+python3 bench.py --gpus 2 --dist-backend gloo --workload llama-shard --op bfp --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_world2_gloo_llama_bfp.json 2>> $OUT/bench.err
+python3 bench.py --workload llama-shard --op hypernet-each --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_llama_hypernet_each.json 2>> $OUT/bench.err
+python3 tools/bench_shard_sets.py > $OUT/shard_sets.txt 2>&1
+python3 tools/region_probe.py > $OUT/region_probe.txt 2>&1
 python3 bench.py --no-cpu-baseline > $OUT/bench_line_default.json 2>> $OUT/bench.err
 python3 bench.py --workload llama-shard --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_llama_hypernet.json 2>> $OUT/bench.err
 python3 bench.py --workload llama-shard --op bfp --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_llama_bfp.json 2>> $OUT/bench.err
@@ -58,7 +66,10 @@ rm -rf $OUT/prof_bench $OUT/pmc_fetch $OUT/pmc_write
 python3 tools/bench_shapes.py > $OUT/secondary_shapes.txt 2>&1
 python3 tools/bench_ops.py > $OUT/ops_roofline_table.txt 2>&1
 python3 tools/bench_rows.py > $OUT/row_ops.txt 2>&1
-bash tools/collect_pmc.sh gpurun_out/$TAG/pmc "per-channel along last,group_size=128,group_minmax,channel_maxabs,bf16 score,SBFP12,rnd=3,histc,bfloat16->bfloat16 B=16 wl=8 sym rnd=2,scale_channels,layernorm,rmsnorm,softmax,unary,_cast,E4M3,block_dim=-2" > /dev/null 2>&1
+bash tools/collect_pmc.sh gpurun_out/$TAG/pmc "per-channel along last,group_size=128,group_minmax,channel_maxabs,bf16 score,SBFP12,rnd=3,histc,bfloat16->bfloat16 B=16 wl=8 sym rnd=2,scale_channels,layernorm,rmsnorm,softmax,unary,_cast,lut16,E4M3,block_dim=-2" > /dev/null 2>&1
+python3 tools/accuracy_table.py > $OUT/accuracy_table.txt 2>&1
+python3 tools/bench_small.py > $OUT/small_tensor_ops.txt 2>&1
+python3 tools/bench_conv_shapes.py > $OUT/conv_shapes.txt 2>&1
 python3 -m pytest tests/test_gpu_round2.py -m gpu -q -k host_overhead > $OUT/host_overhead.log 2>&1
 cp gpurun_out/host_overhead.txt $OUT/host_overhead.txt 2>/dev/null
 ls -la $OUT
