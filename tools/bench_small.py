@@ -80,6 +80,12 @@ def main():
     row("BFP16_64 input cast [128, 14336]", (t, 14336), BF16, lambda x: ops.bfp_qdq(x, 8, 64))
     row("RMSNorm module [128, 4096] (FLOAT16 casts)", (t, h), BF16, lambda x: ops.rmsnorm_cast(x, h, w, 1e-5, F16, F16))
     row("SiLU module [128, 14336] (FLOAT16 casts)", (t, 14336), BF16, lambda x: ops.unary_cast(x, "silu", F16, F16))
+    # the same module as a table lookup (csrc/lut16.hip; the table is built once): where the 128 KiB table copy per workgroup pays
+    _tab = ops.unary_cast_table(torch.empty(8, device=dev, dtype=BF16), "silu", F16, F16)
+    row("  ... as a table lookup (dmxq_lut16_apply)", (t, 14336), BF16, lambda x: ops.lut16_apply(x, _tab))
+    for rows_ in (16, 64, 512, 2048):
+        row(f"SiLU module [{rows_}, 4096] bf16: direct kernel", (rows_, 4096), BF16, lambda x: ops.unary_cast(x, "silu", F16, F16))
+        row(f"SiLU module [{rows_}, 4096] bf16: table lookup", (rows_, 4096), BF16, lambda x: ops.lut16_apply(x, _tab))
     row("Mul module [128, 14336] (FLOAT16 casts)", (t, 14336), BF16, lambda x: ops.binary_cast(x, x, "mul", F16, F16, F16))
     row("Mul module + down_proj's BFP16_64 input cast [128, 14336], one launch", (t, 14336), BF16, lambda x: ops.binary_cast(x, x, "mul", F16, F16, F16, then_bfp=(8, 64)))
     row("softmax module [32, 128, 128] (FLOAT16 casts)", (32, 128, 128), BF16, lambda x: ops.softmax_cast(x, -1, F16, F16))
