@@ -17,17 +17,20 @@
 
 namespace dmxq {
 
+// units per lane of the single-tensor kernel: 2 for the masked BFP chain (hypernet_rows.hpp kHnUnitsSmall), 4 for the rest
+constexpr int hn_units_of(int M, bool bfp) { return (M != 0 && bfp) ? kHnUnitsSmall : kHnUnits; }
 template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP = true, bool DIVIDE = false>
 __global__ __launch_bounds__(kThreads) void hypernet_rows_kernel(HnArgs a) {
   // BFP16_64 (8 lanes per block: the BASIC rule's weight format) gets the branch-free form; other block sizes the runtime one
   // symmetric / asymmetric codes: chosen once per launch as well, not once per unit
   const bool asym = BFP && __builtin_amdgcn_readfirstlane(a.asym) != 0;
+  constexpr int UN = hn_units_of(M, BFP);
   if (BFP && __builtin_amdgcn_readfirstlane(a.lpb) == 8) {
-    if (asym) hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 8, true, DIVIDE>(a);
-    else hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 8, false, DIVIDE>(a);
+    if (asym) hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 8, true, DIVIDE, UN>(a);
+    else hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 8, false, DIVIDE, UN>(a);
   } else {
-    if (asym) hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 0, true, DIVIDE>(a);
-    else hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 0, false, DIVIDE>(a);
+    if (asym) hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 0, true, DIVIDE, UN>(a);
+    else hypernet_rows_body<DTW, DTS, DTO, M, HAS_SCALE, BFP, 0, false, DIVIDE, UN>(a);
   }
 }
 
@@ -106,7 +109,8 @@ static int launch_hn(const HnArgs& a, int M, bool has_scale, hipStream_t s) {
   // masked chains (workgroup-contiguous tiles of kThreads x 4 units): ONE pass per workgroup -- a grid capped at 2048 looping
   // workgroups measured 233 us on the seven Llama-3-8B weights against 205 us for one-pass workgroups (the multi-tensor kernel on
   // the same tensors, profiles/r04_shard_sets.txt: 70 -> 80 % of the roofline); the dense path keeps its strided, capped grid
-  const int64_t tiles = (a.n_units + (int64_t)kThreads * kHnUnits - 1) / ((int64_t)kThreads * kHnUnits);
+  const int64_t un = hn_units_of(M, true);
+  const int64_t tiles = (a.n_units + (int64_t)kThreads * un - 1) / ((int64_t)kThreads * un);
   const int grid = (M != 0 && tiles < ((int64_t)1 << 31)) ? (int)tiles : grid_for((a.n_units + 3) / 4);
 #define DMXQ_HN(M_, S_) DMXQ_LAUNCH((hypernet_rows_kernel<DTW, DTS, DTO, M_, S_>), dim3(grid), dim3(kThreads), 0, s, a)
   if (has_scale) { switch (M) { case 0: DMXQ_HN(0, true); break; case 2: DMXQ_HN(2, true); break; case 4: DMXQ_HN(4, true); break; default: DMXQ_HN(8, true); } }

@@ -6,7 +6,7 @@
 // [128, 4096] x 2, [512, 4096], [1792, 4096] x 2, [512, 14336]: 1-15 MB each, i.e. 2-5 us of streaming behind a ~1.6 us launch
 // floor per weight -- seven launches cost ~36 us where the bytes need ~29.  Here the tile spaces of up to kHnMultiMax weights are
 // concatenated (the scheme of bfp_rows_multi_kernel, bfp_rows.hpp): a workgroup finds its tensor by a scalar search over
-// descriptors held in kernel arguments and runs ONE tile of kThreads x 4 units of hypernet_rows_units on it.  The arithmetic is
+// descriptors held in kernel arguments and runs ONE tile of kThreads x 2 (4 for sets above 160 M elements) units of hypernet_rows_units on it.  The arithmetic is
 // the single-tensor kernel's, unit for unit: results are bit-identical to one dmxq_weight_hypernet call per tensor.
 #include "hypernet_rows.hpp"
 
@@ -22,29 +22,33 @@ struct HnMultiDesc {
 struct HnMultiArgs { HnMultiDesc d[kHnMultiMax]; int n, K, lpb, wl, asym; };
 static_assert(sizeof(HnMultiArgs) <= 3072, "kernel arguments stay well under the 4 KiB limit");
 
-template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE>
+template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, int UN>
 __global__ __launch_bounds__(kThreads) void hypernet_rows_multi_kernel(const HnMultiArgs ma) {
   const int64_t tile = blockIdx.x;
   int k = 0;
   for (int i = 1; i < ma.n; i++) k = (ma.d[i].tile0 <= tile) ? i : k;  // tile0 ascending; <= 32 scalar compares
   const HnMultiDesc& d = ma.d[k];
   const HnArgs a{d.w, d.score, d.scale, d.out, d.n_units, d.L, ma.K, ma.lpb, ma.wl, ma.asym, d.small, d.f_L};
-  const int64_t u0 = (tile - d.tile0) * ((int64_t)kThreads * kHnUnits) + threadIdx.x;
+  const int64_t u0 = (tile - d.tile0) * ((int64_t)kThreads * UN) + threadIdx.x;
   if (u0 >= a.n_units) return;  // (whole lane groups of a block leave together: n_units is a multiple of the lanes of a block)
   const bool asym = __builtin_amdgcn_readfirstlane(ma.asym) != 0;
   const int lpb = __builtin_amdgcn_readfirstlane(ma.lpb);
   if (lpb == 8) {  // BFP16_64, the BASIC rule's weight format: compile-time lane count (branch-free DPP maximum)
-    if (asym) hypernet_rows_units<DTW, DTS, DTO, M, HAS_SCALE, true, 8, true>(a, 8, u0, kThreads);
-    else hypernet_rows_units<DTW, DTS, DTO, M, HAS_SCALE, true, 8, false>(a, 8, u0, kThreads);
+    if (asym) hypernet_rows_units<DTW, DTS, DTO, M, HAS_SCALE, true, 8, true, false, UN>(a, 8, u0, kThreads);
+    else hypernet_rows_units<DTW, DTS, DTO, M, HAS_SCALE, true, 8, false, false, UN>(a, 8, u0, kThreads);
   } else {
-    if (asym) hypernet_rows_units<DTW, DTS, DTO, M, HAS_SCALE, true, 0, true>(a, lpb, u0, kThreads);
-    else hypernet_rows_units<DTW, DTS, DTO, M, HAS_SCALE, true, 0, false>(a, lpb, u0, kThreads);
+    if (asym) hypernet_rows_units<DTW, DTS, DTO, M, HAS_SCALE, true, 0, true, false, UN>(a, lpb, u0, kThreads);
+    else hypernet_rows_units<DTW, DTS, DTO, M, HAS_SCALE, true, 0, false, false, UN>(a, lpb, u0, kThreads);
   }
 }
 
 template <int DTW, int DTS, int DTO>
-static int launch_hn_multi(const HnMultiArgs& a, int64_t tiles, int M, bool has_scale, hipStream_t s) {
-#define DMXQ_HM(M_, S_) DMXQ_LAUNCH((hypernet_rows_multi_kernel<DTW, DTS, DTO, M_, S_>), dim3((unsigned)tiles), dim3(kThreads), 0, s, a)
+static int launch_hn_multi(const HnMultiArgs& a, int64_t tiles, int M, bool has_scale, int units, hipStream_t s) {
+#define DMXQ_HM(M_, S_)                                                                                                                       \
+  do {                                                                                                                                        \
+    if (units == kHnUnitsSmall) DMXQ_LAUNCH((hypernet_rows_multi_kernel<DTW, DTS, DTO, M_, S_, kHnUnitsSmall>), dim3((unsigned)tiles), dim3(kThreads), 0, s, a); \
+    else DMXQ_LAUNCH((hypernet_rows_multi_kernel<DTW, DTS, DTO, M_, S_, kHnUnits>), dim3((unsigned)tiles), dim3(kThreads), 0, s, a);        \
+  } while (0)
   if (has_scale) { switch (M) { case 0: DMXQ_HM(0, true); break; case 2: DMXQ_HM(2, true); break; case 4: DMXQ_HM(4, true); break; default: DMXQ_HM(8, true); } }
   else { switch (M) { case 0: DMXQ_HM(0, false); break; case 2: DMXQ_HM(2, false); break; case 4: DMXQ_HM(4, false); break; default: DMXQ_HM(8, false); } }
 #undef DMXQ_HM
@@ -83,7 +87,11 @@ extern "C" int dmxq_weight_hypernet_multi(const dmxq_hypernet_desc* tensors, int
   }
   if (!any) return DMXQ_OK;
   hipStream_t s = (hipStream_t)stream;
-  constexpr int64_t TILE = (int64_t)kThreads * kHnUnits;
+  // units per lane by the size of the whole set (hypernet_rows.hpp): 2 up to 160 M elements, 4 beyond
+  int64_t total = 0;
+  for (int64_t i = 0; i < n_tensors; i++) total += tensors[i].rows * tensors[i].L;
+  const int units = total <= ((int64_t)160 << 20) ? kHnUnitsSmall : kHnUnits;
+  const int64_t TILE = (int64_t)kThreads * units;
   HnMultiArgs a;
   a.n = 0; a.K = K; a.lpb = (int)(B / 8); a.wl = precision; a.asym = symmetric ? 0 : 1;
   int64_t tiles = 0;
@@ -93,7 +101,7 @@ extern "C" int dmxq_weight_hypernet_multi(const dmxq_hypernet_desc* tensors, int
     if (a.n == 0) return;
     int r = DMXQ_ERR_UNSUPPORTED;
 #define DMXQ_DT(W_, S_, O_) \
-  if (dtype_w == W_ && ds == S_ && dtype_out == O_) r = launch_hn_multi<W_, S_, O_>(a, tiles, M, has_scale, s);
+  if (dtype_w == W_ && ds == S_ && dtype_out == O_) r = launch_hn_multi<W_, S_, O_>(a, tiles, M, has_scale, units, s);
     DMXQ_DT(DMXQ_BF16, DMXQ_F32, DMXQ_BF16)   // the dtype triples of dmxq_weight_hypernet
     DMXQ_DT(DMXQ_BF16, DMXQ_F32, DMXQ_F32)
     DMXQ_DT(DMXQ_BF16, DMXQ_BF16, DMXQ_BF16)

@@ -53,11 +53,15 @@ struct HnArgs {
 #define DMXQ_HN_UNITS 4   // (tools/ab_hn_units.sh builds a second library with 8 for an A/B run)
 #endif
 constexpr int kHnUnits = DMXQ_HN_UNITS;
-template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP, int LPBC, bool ASYM, bool DIVIDE = false>
+// ... and 2 for the masked BFP chain on everything but the largest sets (tools/ab_hn_units.sh, profiles/r04_ab_hypernet_units.txt: a rank's
+// Llama-3-8B shard set at N = 8 32.2 -> 30.0 us, the seven single launches 228.7 -> 220.9 us; the whole 218 M-element layer in one launch
+// 206.6 -> 211.4 us, so the multi-tensor launch keeps 4 above 160 M elements; 8 units per lane: 20-27 % slower everywhere)
+constexpr int kHnUnitsSmall = 2;
+template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP, int LPBC, bool ASYM, bool DIVIDE = false, int UNITS = kHnUnits>
 __device__ __forceinline__ void hypernet_rows_units(const HnArgs& a, const int lpb, const int64_t u0, const int64_t stride) {
   // T1: dtype after the mask multiply = torch promotion of (w, score); without a mask it stays the weight dtype
   constexpr int T1 = DIVIDE ? DMXQ_F32 : ((M == 0) ? DTW : ((DTW == DMXQ_F32 || DTS == DMXQ_F32 || DTW != DTS) ? DMXQ_F32 : DTW));
-  constexpr int UN = kHnUnits;
+  constexpr int UN = UNITS;
   {
     float xa[UN][8], sa[M != 0 ? UN : 1][8], sva[HAS_SCALE ? UN : 1][8];
 #pragma unroll
@@ -140,10 +144,10 @@ __device__ __forceinline__ void hypernet_rows_units(const HnArgs& a, const int l
   }
 }
 
-template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP, int LPBC, bool ASYM, bool DIVIDE = false>
+template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP, int LPBC, bool ASYM, bool DIVIDE = false, int UNITS = kHnUnits>
 __device__ __forceinline__ void hypernet_rows_body(const HnArgs& a) {
   const int lpb = LPBC > 0 ? LPBC : __builtin_amdgcn_readfirstlane(a.lpb);
-  constexpr int UN = kHnUnits;
+  constexpr int UN = UNITS;
   // workgroup-CONTIGUOUS tiles of kThreads x UN units (a grid-strided assignment, unit r of a lane a whole grid apart, cost the
   // hot kernel ~15 %: bfp_rows.hpp)
   // -- with a mask (two or three streams per unit): 2:4 + BFP 23.1 -> 22.5 us, the Llama-3-8B layer of bench.py 63 -> 69 %; the dense
@@ -154,7 +158,7 @@ __device__ __forceinline__ void hypernet_rows_body(const HnArgs& a) {
     const int64_t u0 = kContig ? ((int64_t)blockIdx.x + k * gridDim.x) * ((int64_t)kThreads * UN) + threadIdx.x
                                : (int64_t)blockIdx.x * kThreads + threadIdx.x + k * UN * stride;
     if (u0 >= a.n_units) break;  // (whole waves leave together: n_units is a multiple of the lanes of a block)
-    hypernet_rows_units<DTW, DTS, DTO, M, HAS_SCALE, BFP, LPBC, ASYM, DIVIDE>(a, lpb, u0, stride);
+    hypernet_rows_units<DTW, DTS, DTO, M, HAS_SCALE, BFP, LPBC, ASYM, DIVIDE, UNITS>(a, lpb, u0, stride);
   }
 }
 
