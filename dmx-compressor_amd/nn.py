@@ -499,10 +499,24 @@ class DmxModule(torch.nn.Module):
 
     #: 16-bit tensors: run a unary module (input cast, function, output cast) as a 65,536-entry TABLE lookup (csrc/lut16.hip): the
     #: table is built once per (function, casts, dtype, device) with the function in float64 rounded ONCE -- the correctly rounded
-    #: result, bit-identical to the reference's CPU evaluation wherever that is correctly rounded -- and kept on the module.
-    #: Tensors below `lut_min_elems` elements keep the direct kernel (dmxq_unary_cast: within one ulp of the same value).
-    lut_activation = True
-    lut_min_elems = 1 << 16
+    #: result, bit-identical to the reference's CPU evaluation wherever that is itself exact -- and kept on the module.
+    #:   "auto" (default)  the table where it is not slower than the direct kernel (dmxq_unary_cast: within one ulp of the same value):
+    #:                     GELU (erf / tanh) and QuickGELU from 12 M elements up (4096 x 4096 bf16: 12.6 vs 15.3 / 13.4 us); a workgroup
+    #:                     pays 128 KiB of L2 -> LDS traffic for the table, so small tensors (3.7 MB: 7.8 vs 3.1 us) and the cheap
+    #:                     functions (SiLU, Exp: one transcendental, 11.9 us direct) keep the direct kernel
+    #:   True              the table for every function and every tensor of at least `lut_min_elems` elements: correctly rounded
+    #:                     results at every size, at that price (profiles/r04_small_tensor_ops.txt)
+    #:   False             never
+    lut_activation = "auto"
+    lut_min_elems = 8
+    _LUT_AUTO_MIN = {"gelu": 12 << 20, "gelu_tanh": 12 << 20, "quick_gelu": 12 << 20}
+
+    def _lut_wanted(self, x, func) -> bool:
+        if not self.lut_activation or x.element_size() != 2 or x.numel() % 8 != 0 or x.numel() < self.lut_min_elems:
+            return False
+        if self.lut_activation == "auto":
+            return x.numel() >= self._LUT_AUTO_MIN.get(func, 1 << 62)
+        return True
 
     def _unary_table(self, x, func, cast_in, cast_out):
         from . import ops
@@ -528,7 +542,7 @@ class DmxModule(torch.nn.Module):
             return None
         from . import ops
         out = None
-        if self.lut_activation and x.element_size() == 2 and x.numel() >= self.lut_min_elems and x.numel() % 8 == 0:
+        if self._lut_wanted(x, func):
             table = self._unary_table(x, func, c[0], c[1])
             if table is not None:
                 out = ops.lut16_apply(x.detach(), table)

@@ -209,16 +209,17 @@ def test_activation_module_runs_the_fused_kernel(dmx, cuda, oracle, dtype, name)
     assert m._fused_forward(x) is not None, "fused path not taken"
     # 16-bit tensors from lut_min_elems elements up take the module's TABLE (csrc/lut16.hip: float64 evaluation rounded once), smaller
     # ones and float32 the direct kernel
-    if dtype != torch.float32 and x.numel() >= m.lut_min_elems and m.lut_activation:
-        want = dmx.ops.lut16_apply(x, dmx.ops.unary_cast_table(x, func, fi, fo))
-    else:
-        want = dmx.ops.unary_cast(x, func, fi, fo)
-    assert torch.equal(y.view(torch.int16 if dtype != torch.float32 else torch.int32),
-                       want.view(torch.int16 if dtype != torch.float32 else torch.int32))
-    m.lut_activation = False
-    assert torch.equal(m(x).view(torch.int16 if dtype != torch.float32 else torch.int32),
-                       dmx.ops.unary_cast(x, func, fi, fo).view(torch.int16 if dtype != torch.float32 else torch.int32))
-    m.lut_activation = True
+    it = torch.int16 if dtype != torch.float32 else torch.int32
+    assert m.lut_activation == "auto" and not m._lut_wanted(x, func)      # 64 Ki elements: the direct kernel
+    assert torch.equal(y.view(it), dmx.ops.unary_cast(x, func, fi, fo).view(it))
+    m.lut_activation = True            # the module's TABLE at every size (csrc/lut16.hip: float64 evaluation rounded once): 16-bit tensors only
+    want = dmx.ops.lut16_apply(x, dmx.ops.unary_cast_table(x, func, fi, fo)) if dtype != torch.float32 else dmx.ops.unary_cast(x, func, fi, fo)
+    y_t = m(x)
+    assert torch.equal(y_t.view(it), want.view(it))
+    f64_, floor_fn_, tol_ = UNARY[func]
+    cin_ = _cpu_cast(oracle, fi)(x.cpu())
+    assert outside_cast_bracket(y_t, f64_(cin_, dtype), _cpu_cast(oracle, fo), dtype, _n_ulp(tol_, dtype, fo), None if floor_fn_ is None else floor_fn_(cin_)) == 0
+    m.lut_activation = "auto"
     assert y.dtype == dtype and y.data_ptr() != x.data_ptr()
     f64, floor_fn, tol = UNARY[func]
     cin = _cpu_cast(oracle, fi)(x.cpu())
