@@ -935,5 +935,5 @@ extern "C" const char* dmxq_status_string(int status) {
   return "unknown status";
 }
 
-extern "C" int dmxq_abi_version(void) { return 2; }
+extern "C" int dmxq_abi_version(void) { return 3; }  // 3: + dmxq_weight_hypernet_multi, dmxq_unary_cast_table, dmxq_lut16_apply (additive)
 #endif  // part 1b

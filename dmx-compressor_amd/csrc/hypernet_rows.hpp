@@ -56,7 +56,10 @@ constexpr int kHnUnits = DMXQ_HN_UNITS;
 // ... and 2 for the masked BFP chain on everything but the largest sets (tools/ab_hn_units.sh, profiles/r04_ab_hypernet_units.txt: a rank's
 // Llama-3-8B shard set at N = 8 32.2 -> 30.0 us, the seven single launches 228.7 -> 220.9 us; the whole 218 M-element layer in one launch
 // 206.6 -> 211.4 us, so the multi-tensor launch keeps 4 above 160 M elements; 8 units per lane: 20-27 % slower everywhere)
-constexpr int kHnUnitsSmall = 2;
+#ifndef DMXQ_HN_UNITS_SMALL
+#define DMXQ_HN_UNITS_SMALL 2
+#endif
+constexpr int kHnUnitsSmall = DMXQ_HN_UNITS_SMALL;
 template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, bool BFP, int LPBC, bool ASYM, bool DIVIDE = false, int UNITS = kHnUnits>
 __device__ __forceinline__ void hypernet_rows_units(const HnArgs& a, const int lpb, const int64_t u0, const int64_t stride) {
   // T1: dtype after the mask multiply = torch promotion of (w, score); without a mask it stays the weight dtype

@@ -41,7 +41,7 @@ typedef enum {
 } dmxq_status;
 
 const char* dmxq_status_string(int status);
-/* ABI version: bumped on any signature change. */
+/* ABI version: bumped on any signature change or addition (3 = round 4: + dmxq_weight_hypernet_multi, dmxq_unary_cast_table, dmxq_lut16_apply; nothing removed or changed). */
 int dmxq_abi_version(void);
 
 /* Block floating point Q->DQ ("BFP[p|8]{B}", MXINT).

@@ -116,6 +116,21 @@ _EPS = {torch.float32: 2.0 ** -23, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0
 _TINY = {torch.float32: 2.0 ** -126, torch.bfloat16: 2.0 ** -126, torch.float16: 2.0 ** -14}
 
 
+def round_once(y64: torch.Tensor, dtype) -> torch.Tensor:
+    """float64 -> `dtype` with ONE rounding.  torch converts double -> half / bfloat16 THROUGH float32 (two roundings: 2 of the 65,536
+    fp16 gelu values come out one ulp off); here the float32 step rounds to odd (truncate, set the last bit when inexact), after which
+    the round-to-nearest-even to 16 bits equals a single rounding of the double (float32 targets: torch's own single rounding)."""
+    if dtype == torch.float32 or dtype == torch.float64:
+        return y64.to(dtype)
+    f = y64.float()
+    b = f.view(torch.int32).clone()
+    inexact = (f.double() != y64) & torch.isfinite(f) & ~torch.isnan(y64)
+    away = f.double().abs() > y64.abs()
+    b = torch.where(inexact & away, b - 1, b)
+    b = torch.where(inexact, b | 1, b)
+    return b.view(torch.float32).to(dtype)
+
+
 def err_in_ulps(got: torch.Tensor, truth64: torch.Tensor, dtype, floor=None) -> float:
     """Largest |got - truth| in units of the last place OF THE OUTPUT FORMAT `dtype`, against `truth64` (the function
     evaluated in float64 on the same inputs; it is rounded to `dtype` here, once: the correctly rounded result).
@@ -124,7 +139,7 @@ def err_in_ulps(got: torch.Tensor, truth64: torch.Tensor, dtype, floor=None) -> 
     layer_norm's centring): where the result is much smaller than those terms, no fp32 evaluation of the formula --
     torch's own included -- is accurate relative to the RESULT, and the error is counted in ulps of the cancelling terms
     (what a backward-stable evaluation guarantees).  NaN must meet NaN, +-inf must meet the same inf."""
-    g, t = got.detach().cpu().double(), truth64.detach().cpu().double().to(dtype).double()
+    g, t = got.detach().cpu().double(), round_once(truth64.detach().cpu().double(), dtype).double()
     nan_g, nan_t = torch.isnan(g), torch.isnan(t)
     if bool((nan_g ^ nan_t).any()):
         return float("inf")

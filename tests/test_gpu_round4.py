@@ -246,17 +246,7 @@ _FUNC64 = {
 }
 
 
-def _round_once(y64, dtype):
-    """float64 -> 16-bit dtype with ONE rounding.  torch converts double -> half / bfloat16 THROUGH float32 (two roundings: 2 of the
-    65,536 fp16 gelu values differ); here the float32 step rounds to odd (truncate, set the last bit when inexact), after which the
-    round-to-nearest-even to 16 bits equals a single rounding of the double."""
-    f = y64.float()
-    b = f.view(torch.int32).clone()
-    inexact = (f.double() != y64) & torch.isfinite(f) & ~torch.isnan(y64)
-    away = f.double().abs() > y64.abs()
-    b = torch.where(inexact & away, b - 1, b)
-    b = torch.where(inexact, b | 1, b)
-    return b.view(torch.float32).to(dtype)
+from _data import round_once as _round_once  # noqa: E402  (float64 -> 16 bits with ONE rounding; torch rounds twice)
 
 
 def _all_patterns(dtype):

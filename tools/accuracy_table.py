@@ -16,7 +16,7 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 import dmx_compressor_amd as d  # noqa: E402
-from _data import err_in_ulps, make  # noqa: E402
+from _data import err_in_ulps, make, round_once  # noqa: E402
 
 dev = torch.device("cuda:0")
 
@@ -107,7 +107,7 @@ def fused_modules():
                 m.fuse_activation = False
                 unfused = m(inp)
                 c = cast(inp)
-                truth = cast(f64(c).to(dt))           # cast_out(round_D(truth)): the value both paths approximate
+                truth = cast(round_once(f64(c).cpu(), dt).to(dev))   # cast_out(round_D(truth)), ONE rounding: the value both paths approximate
             fl = None if floor_fn is None else floor_fn(c)
             unit = dt if dt != torch.float32 else torch.float16   # float32 tensors: ulps of the OUTPUT CAST's format (10 mantissa bits)
             a, b = err_in_ulps(fused, truth.double(), unit, fl), err_in_ulps(unfused, truth.double(), unit, fl)
