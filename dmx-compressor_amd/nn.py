@@ -1476,6 +1476,15 @@ class GraphedForward:
     def __init__(self, model: torch.nn.Module, *example_inputs: torch.Tensor, warmup: int = 3):
         if not example_inputs or not all(isinstance(t, torch.Tensor) and t.is_cuda for t in example_inputs):
             raise ValueError("GraphedForward: tensor inputs on the GPU required")
+        # calibration must precede capture: an enabled observer updates its running min / max IN PLACE (dmxq_group_minmax_accumulate) and a
+        # calibrating SmoothQuant recomputes its scale -- captured, every replay would repeat that on the static input
+        from .cast import CastTo
+        from .smoothquant import ActivationWeightSmoothQuant as SmoothQuant
+        for name, mod in model.named_modules():
+            if isinstance(mod, CastTo) and mod._flag("observer_enabled"):
+                raise RuntimeError(f"GraphedForward: the observer of {name or 'the model'} is enabled; finish calibration (disable_observer) before capture")
+            if isinstance(mod, SmoothQuant) and (getattr(mod, "calibrating", False) or mod._flag("dynamic")):
+                raise RuntimeError(f"GraphedForward: SmoothQuant of {name or 'the model'} is calibrating / dynamic; capture a frozen scale")
         self.model = model
         self.static_in = [t.detach().clone() for t in example_inputs]
         dev = self.static_in[0].device

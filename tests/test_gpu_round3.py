@@ -186,6 +186,11 @@ def test_graphed_forward_replays_a_configured_layer(dmx, cuda):
     assert torch.equal(y1, e1) and torch.equal(y2, e2) and not torch.equal(y1, y2)
     with pytest.raises(ValueError):
         g(x1[:2])
+    # calibration must precede capture: an enabled observer (in-place running min / max) is refused
+    m.fc1.input_casts.input_cast.enable_observer()
+    with pytest.raises(RuntimeError, match="observer"):
+        nn.GraphedForward(m, x1)
+    m.fc1.input_casts.input_cast.disable_observer()
 
 
 def test_round3_entry_points_through_both_bindings(dmx, cuda):
