@@ -500,16 +500,16 @@ class DmxModule(torch.nn.Module):
     #: 16-bit tensors: run a unary module (input cast, function, output cast) as a 65,536-entry TABLE lookup (csrc/lut16.hip): the
     #: table is built once per (function, casts, dtype, device) with the function in float64 rounded ONCE -- the correctly rounded
     #: result, bit-identical to the reference's CPU evaluation wherever that is itself exact -- and kept on the module.
-    #:   "auto" (default)  the table where it is not slower than the direct kernel (dmxq_unary_cast: within one ulp of the same value):
-    #:                     GELU (erf / tanh) and QuickGELU from 12 M elements up (4096 x 4096 bf16: 12.6 vs 15.3 / 13.4 us); a workgroup
-    #:                     pays 128 KiB of L2 -> LDS traffic for the table, so small tensors (3.7 MB: 7.8 vs 3.1 us) and the cheap
-    #:                     functions (SiLU, Exp: one transcendental, 11.9 us direct) keep the direct kernel
-    #:   True              the table for every function and every tensor of at least `lut_min_elems` elements: correctly rounded
-    #:                     results at every size, at that price (profiles/r04_small_tensor_ops.txt)
-    #:   False             never
-    lut_activation = "auto"
+    #:   True (default)  every function, every 16-bit tensor of a whole number of 16-byte vectors: ONE rounding policy at every size.
+    #:                   Costs ~1 us per launch over the direct kernel on small tensors (the 128 KiB table copy per workgroup: 4.2 vs
+    #:                   3.1 us on Llama's [128, 14336] SiLU input, 3.0 vs 1.9 us on 128 KB), nothing from ~16 MiB up, and is the
+    #:                   FASTER kernel for the GELU family from ~8 MiB (4096 x 4096 bf16: 12.7 vs 15.3-16.1 us) -- profiles/r04_small_tensor_ops.txt
+    #:   "auto"          the table only where it is not slower than the direct kernel (dmxq_unary_cast: within one ulp of the same
+    #:                   value): GELU (erf / tanh) and QuickGELU from 4 M elements up
+    #:   False           never
+    lut_activation = True
     lut_min_elems = 8
-    _LUT_AUTO_MIN = {"gelu": 12 << 20, "gelu_tanh": 12 << 20, "quick_gelu": 12 << 20}
+    _LUT_AUTO_MIN = {"gelu": 4 << 20, "gelu_tanh": 4 << 20, "quick_gelu": 4 << 20}
 
     def _lut_wanted(self, x, func) -> bool:
         if not self.lut_activation or x.element_size() != 2 or x.numel() % 8 != 0 or x.numel() < self.lut_min_elems:

@@ -210,16 +210,19 @@ def test_activation_module_runs_the_fused_kernel(dmx, cuda, oracle, dtype, name)
     # 16-bit tensors from lut_min_elems elements up take the module's TABLE (csrc/lut16.hip: float64 evaluation rounded once), smaller
     # ones and float32 the direct kernel
     it = torch.int16 if dtype != torch.float32 else torch.int32
-    assert m.lut_activation == "auto" and not m._lut_wanted(x, func)      # 64 Ki elements: the direct kernel
-    assert torch.equal(y.view(it), dmx.ops.unary_cast(x, func, fi, fo).view(it))
-    m.lut_activation = True            # the module's TABLE at every size (csrc/lut16.hip: float64 evaluation rounded once): 16-bit tensors only
+    # default policy: 16-bit tensors through the module's TABLE (csrc/lut16.hip: float64 evaluation rounded once), float32 tensors and
+    # lut_activation = False / "auto" below its sizes through the direct kernel
+    assert m.lut_activation is True and m._lut_wanted(x, func) == (dtype != torch.float32)
     want = dmx.ops.lut16_apply(x, dmx.ops.unary_cast_table(x, func, fi, fo)) if dtype != torch.float32 else dmx.ops.unary_cast(x, func, fi, fo)
-    y_t = m(x)
-    assert torch.equal(y_t.view(it), want.view(it))
-    f64_, floor_fn_, tol_ = UNARY[func]
-    cin_ = _cpu_cast(oracle, fi)(x.cpu())
-    assert outside_cast_bracket(y_t, f64_(cin_, dtype), _cpu_cast(oracle, fo), dtype, _n_ulp(tol_, dtype, fo), None if floor_fn_ is None else floor_fn_(cin_)) == 0
-    m.lut_activation = "auto"
+    assert torch.equal(y.view(it), want.view(it))
+    for mode in (False, "auto"):       # 64 Ki elements: below "auto"'s sizes
+        m.lut_activation = mode
+        y_d = m(x)
+        assert torch.equal(y_d.view(it), dmx.ops.unary_cast(x, func, fi, fo).view(it))
+        f64_, floor_fn_, tol_ = UNARY[func]
+        cin_ = _cpu_cast(oracle, fi)(x.cpu())
+        assert outside_cast_bracket(y_d, f64_(cin_, dtype), _cpu_cast(oracle, fo), dtype, _n_ulp(tol_, dtype, fo), None if floor_fn_ is None else floor_fn_(cin_)) == 0
+    m.lut_activation = True
     assert y.dtype == dtype and y.data_ptr() != x.data_ptr()
     f64, floor_fn, tol = UNARY[func]
     cin = _cpu_cast(oracle, fi)(x.cpu())

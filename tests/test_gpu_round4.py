@@ -324,8 +324,8 @@ def test_unary_table_vs_torch_cpu_the_reference_device(dmx, cuda, func, ref):
 @pytest.mark.parametrize("shape", [(4096, 4096), (1, 128, 14336), (300, 264), (3, 8)])
 def test_lut16_apply_and_the_module_path(dmx, cuda, shape):
     """dmxq_lut16_apply == table[x] on tensors of every size class (one tile per workgroup, looping workgroups, a ragged last tile,
-    fewer vectors than lanes), and the GELU module's policy: "auto" takes the table from 12 M elements up, True at every size (same bits
-    as the direct application of its table), False never; table and direct kernel within one ulp of each other."""
+    fewer vectors than lanes), and the GELU module's policy: True (default) at every size (same bits as the direct application of its
+    table), "auto" from 4 M elements up, False never; table and direct kernel within one ulp of each other."""
     x = make("heavy", shape, seed=shape[-1], dtype=BF16).to(cuda)
     table = dmx.ops.unary_cast_table(x, "gelu")
     got = dmx.ops.lut16_apply(x, table)
@@ -334,14 +334,16 @@ def test_lut16_apply_and_the_module_path(dmx, cuda, shape):
     m = dmx.nn.GELU().to(cuda)
     m.configure({"input_formats": ["FP[1|5|10,15](FN)"], "output_formats": ["FP[1|5|10,15](FN)"]})
     m.eval()
-    assert m.lut_activation == "auto" and m._lut_wanted(x, "gelu") == (x.numel() >= 12 << 20) and not m._lut_wanted(x, "silu")
+    tab_ok = x.numel() % 8 == 0
+    assert m.lut_activation is True and m._lut_wanted(x, "gelu") == tab_ok and m._lut_wanted(x, "silu") == tab_ok
     with torch.no_grad():
-        y_auto = m(x)
-        m.lut_activation = True
         y = m(x)
+        m.lut_activation = "auto"
+        assert m._lut_wanted(x, "gelu") == (tab_ok and x.numel() >= 4 << 20) and not m._lut_wanted(x, "silu")
+        y_auto = m(x)
         m.lut_activation = False
         y_direct = m(x)
-    assert bits_equal(y_auto, y if x.numel() >= 12 << 20 else y_direct) == 0
+    assert bits_equal(y_auto, y if x.numel() >= 4 << 20 else y_direct) == 0
     if x.numel() >= m.lut_min_elems and x.numel() % 8 == 0:
         t2 = dmx.ops.unary_cast_table(x, "gelu", m.input_casts.input_cast.format, m.output_casts.output_cast.format)
         assert bits_equal(y, dmx.ops.lut16_apply(x, t2)) == 0 and len(m.__dict__["_lut_cache"]) == 1
