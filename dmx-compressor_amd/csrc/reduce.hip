@@ -9,9 +9,57 @@
 // bit patterns (order-preserving for non-NaN values), so the outputs are exact and order-independent.
 #include <math.h>
 
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
 #include "common.hpp"
 
 namespace dmxq {
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// THE INIT GATE (round 4): the atomics of a reduction need their destination initialised first -- until now by a fill launch in
+// front of the kernel, ~1.6 us of the ~9 (profiles/r03_ops_roofline_table.txt).  A ticket (last workgroup reduces partials) costs
+// MORE than the fill on this chip (a RETURNING device-scope atomic per workgroup: profiles/r04_tune_reduce_tickets.txt).  The gate
+// needs neither: workgroup (0, 0) stores the identities with agent-scope stores, waits for them (s_waitcnt vmcnt(0)), and publishes
+// the launch's EPOCH in a flag word; every workgroup requests that word right BEHIND its data loads -- vector memory returns in
+// order, so the value arrives with the last data, for free -- and one thread re-reads it only while it does not yet hold the epoch,
+// before the workgroup issues its (non-returning) atomics.  tools/tune_reduce2.hip: 11.00 -> 9.47 us (per-tensor min / max),
+// 9.91 -> 8.12 (32 groups), 9.42 -> 7.76 (per-column max |x|) on 32 MiB of bf16: exactly the fill launch.
+//   * a flag slot belongs to ONE stream (launches of a stream are ordered, so a slot never serves two running kernels: no launch can
+//     overwrite the epoch another one still waits for); epochs count up per slot and skip 0, the value of a fresh slot;
+//   * no gate -- the fill launch as before -- while the stream is being captured (a replayed graph would present the SAME epoch
+//     again, already in the flag), on hipStreamPerThread (one handle, many streams), past kGateSlots streams, for more outputs than
+//     one workgroup initialises quickly, and on the scalar kernels.
+// on == 0: the destination is initialised already (a fill launch in front, or the accumulate form)
+struct InitGate { unsigned* flag; unsigned epoch; int on; };
+constexpr int kGateSlots = 1024, kGateStride = 16 /* words: one slot per 64-byte line */, kGateMaxOut = 8192;
+
+// (GATED is a template parameter of the kernels: the un-gated instances -- the accumulate forms, the fallbacks -- carry none of this;
+// as a run-time flag it cost them 0.3 us)
+template <bool GATED, typename F>
+__device__ __forceinline__ void gate_open(const InitGate& g, int64_t n, int threads, F&& init) {
+  if (GATED && blockIdx.x == 0 && blockIdx.y == 0) {   // (block-uniform)
+    for (int64_t i = threadIdx.x; i < n; i += threads) init(i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // agent-scope stores: acknowledged where the atomics execute
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(g.flag, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ void gate_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// thread 0 only, behind the data loads of its wave.  (Measured: the same load by EVERY wave -- which spares wave 0 the join, where
+// the compiler waits for the loaded value and so for all data before it -- costs 0.4 us: 4096 agent-scope reads of one address.)
+template <bool GATED>
+__device__ __forceinline__ unsigned gate_peek(const InitGate& g, unsigned seen) {
+  if (GATED && threadIdx.x == 0) seen = __hip_atomic_load(g.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return seen;
+}
+// thread 0, before the atomics (the others follow it through a barrier or are thread 0 themselves)
+template <bool GATED>
+__device__ __forceinline__ void gate_wait(const InitGate& g, unsigned seen) {
+  if (GATED && threadIdx.x == 0)
+    while (seen != g.epoch) seen = __hip_atomic_load(g.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // float atomic min/max through integer atomics: non-negative floats order like signed ints, negative floats
 // order inversely like unsigned ints.
@@ -90,8 +138,9 @@ __device__ __forceinline__ void wave_minmax_keys(uint32_t& lo, uint32_t& hi) {
   lo = min(lo, (uint32_t)__shfl_xor((int)lo, 16)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, 16));
   lo = min(lo, (uint32_t)__shfl_xor((int)lo, 32)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, 32));
 }
-template <int T>
-__device__ __forceinline__ void block_minmax_finish(float flo, float fhi, float* mn, float* mx) {
+template <int T, bool GATED = false>
+__device__ __forceinline__ void block_minmax_finish(float flo, float fhi, float* mn, float* mx, const InitGate& gate,
+                                                    unsigned seen) {
   uint32_t lo = fkey(flo), hi = fkey(fhi);   // (nothing seen: (+Inf, -Inf), which no combine prefers)
   wave_minmax_keys(lo, hi);
   __shared__ uint32_t s_lo[T / kWave], s_hi[T / kWave];
@@ -102,6 +151,7 @@ __device__ __forceinline__ void block_minmax_finish(float flo, float fhi, float*
 #pragma unroll
     for (int i = 1; i < T / kWave; i++) { lo = min(lo, s_lo[i]); hi = max(hi, s_hi[i]); }
     if (lo <= hi || lo < fkey(-INFINITY)) {  // at least one element seen (or a NaN: (-NaN, +NaN) also has lo <= hi as keys)
+      gate_wait<GATED>(gate, seen);
       atomic_min_f32(mn, fkey_inv(lo));
       atomic_max_f32(mx, fkey_inv(hi));
     }
@@ -127,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void group_minmax_kernel(const void* __re
     am = max(am, f2u(v) & 0x7FFFFFFFu);
   }
   nan_to_both(am, lo, hi);
-  block_minmax_finish<kThreads>(lo, hi, &mn[g], &mx[g]);
+  block_minmax_finish<kThreads>(lo, hi, &mn[g], &mx[g], InitGate{nullptr, 0u, 0}, 0u);
 }
 
 // 8 consecutive elements, compile-time dtype: the RAW 16-byte vectors first (so that a batch of loads is issued back to
@@ -176,12 +226,14 @@ __device__ __forceinline__ void load8_rt(const void* p, int dt, int64_t e, float
 
 // vectorised twin of group_minmax_kernel: every run of a group is a whole number of aligned 8-element vectors
 constexpr int kMinmaxThreads = 1024;  // big workgroups: few contended atomics per group, 16 waves of loads in flight
-template <int DT>
+template <int DT, bool GATED>
 __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const void* __restrict__ in,
                                                                          int64_t outer, int64_t C, int64_t inner,
-                                                                         int64_t gs, float* mn, float* mx) {
+                                                                         int64_t gs, float* mn, float* mx, const InitGate gate) {
   constexpr int kThreads = kMinmaxThreads;  // shadows the namespace constant inside this kernel
   const int64_t g = blockIdx.y;
+  gate_open<GATED>(gate, gridDim.y, kThreads, [&](int64_t i) { gate_store(&mn[i], INFINITY); gate_store(&mx[i], -INFINITY); });
+  unsigned seen = ~gate.epoch;   // not the epoch: a workgroup that never peeks must wait
   const int64_t c0 = g * gs;
   const int64_t lenv = ((C - c0 < gs) ? (C - c0) : gs) * inner / 8;  // vectors per run
   const int64_t total = outer * lenv;
@@ -209,6 +261,7 @@ __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const 
       }
       raw[u] = load8_raw<DT>(in, last);
     }
+    seen = gate_peek<GATED>(gate, seen);
     (void)nv;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -225,7 +278,7 @@ __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const 
   }
   if (DT != DMXQ_F32) { if (any) pk.finish<DT>(lo, hi); }
   else nan_to_both(am, lo, hi);
-  block_minmax_finish<kThreads>(lo, hi, &mn[g], &mx[g]);
+  block_minmax_finish<kThreads, GATED>(lo, hi, &mn[g], &mx[g], gate, seen);
 }
 
 // outer == 1 (a weight's row slabs along dim 0, or the whole tensor as one group): the vectors of group g are ONE contiguous run, so a
@@ -234,11 +287,13 @@ __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const 
 // flight, grid-strided) -- and no 64-bit index arithmetic per vector.  One round for a 32 MiB tensor (256 workgroups).
 constexpr int kFlatThreads = 512;
 template <int DT> struct FlatUnroll { static constexpr int value = DT == DMXQ_F32 ? 8 : 16; };  // 256 bytes in flight per lane either way
-template <int DT>
+template <int DT, bool GATED>
 __global__ __launch_bounds__(kFlatThreads) void group_minmax_flat_kernel(const void* __restrict__ in, int64_t C, int64_t inner, int64_t gs,
-                                                                        float* mn, float* mx) {
+                                                                        float* mn, float* mx, const InitGate gate) {
   constexpr int T = kFlatThreads, U = FlatUnroll<DT>::value;
   const int64_t g = blockIdx.y;
+  gate_open<GATED>(gate, gridDim.y, T, [&](int64_t i) { gate_store(&mn[i], INFINITY); gate_store(&mx[i], -INFINITY); });
+  unsigned seen = ~gate.epoch;   // not the epoch: a workgroup that never peeks must wait
   const int64_t c0 = g * gs;
   const int64_t lenv = ((C - c0 < gs) ? (C - c0) : gs) * inner / 8;  // vectors of this group
   const int64_t v0 = c0 * inner / 8;
@@ -254,6 +309,7 @@ __global__ __launch_bounds__(kFlatThreads) void group_minmax_flat_kernel(const v
       const int64_t v = b + (int64_t)u * T + threadIdx.x;
       raw[u] = load8_raw<DT>(in, (v0 + (v < lenv ? v : lenv - 1)) * 8);  // clamped: a repeated vector cannot change a min / max
     }
+    seen = gate_peek<GATED>(gate, seen);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -270,7 +326,7 @@ __global__ __launch_bounds__(kFlatThreads) void group_minmax_flat_kernel(const v
   }
   if (DT != DMXQ_F32) { if (any) pk.finish<DT>(lo, hi); }
   else nan_to_both(am, lo, hi);
-  block_minmax_finish<T>(lo, hi, &mn[g], &mx[g]);
+  block_minmax_finish<T, GATED>(lo, hi, &mn[g], &mx[g], gate, seen);
 }
 
 // vectorised twin of channel_maxabs_kernel: a workgroup covers a strip of 64 x 8 = 512 consecutive columns of the
@@ -278,11 +334,13 @@ __global__ __launch_bounds__(kFlatThreads) void group_minmax_flat_kernel(const v
 // partial maxima are combined through LDS and ONE wave issues the integer atomics.
 constexpr int kMaxabsThreads = 1024;  // 16 waves over rows per column strip: parallelism without more atomics
 constexpr int kMaxabsRows = 8;        // rows in flight per lane
-template <int DT, int U = kMaxabsRows>
+template <int DT, int U, bool GATED>
 __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(const void* __restrict__ in,
                                                                            int64_t outer, int64_t C, int64_t inner,
-                                                                           float* out) {
+                                                                           float* out, const InitGate gate) {
   constexpr int W = kMaxabsThreads / kWave;
+  gate_open<GATED>(gate, C, kMaxabsThreads, [&](int64_t i) { gate_store(&out[i], 0.0f); });
+  unsigned seen = ~gate.epoch;   // not the epoch: a workgroup that never peeks must wait
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int64_t col0 = ((int64_t)blockIdx.x * kWave + lane) * 8;
   const int64_t plane = C * inner;
@@ -307,6 +365,7 @@ __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(cons
         const int64_t r = o + u * W < outer ? o + u * W : outer - 1;
         raw[u] = load8_raw<DT>(in, r * plane + col0);
       }
+      seen = gate_peek<GATED>(gate, seen);
 #pragma unroll
       for (int u = 0; u < U; u++) {
         if (PK) {
@@ -323,6 +382,7 @@ __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(cons
   __shared__ uint32_t sm[W][NW][kWave];  // [wave][dword of the lane][lane]: conflict-free writes and reads
 #pragma unroll
   for (int k = 0; k < NW; k++) sm[w][k][lane] = m[k];
+  gate_wait<GATED>(gate, seen);   // thread 0; the barrier carries it to the threads that issue the atomics
   __syncthreads();
   // the strip's 512 columns over the first 512 threads (8 waves), each combining the W partial maxima of its column
   if (threadIdx.x < 8 * kWave) {
@@ -409,11 +469,13 @@ __device__ __forceinline__ void hist_add(uint32_t* s, float v, float lo, float h
     atomicAdd(&s[pos], 1u);
   }
 }
-template <int DT, bool FAST>
+template <int DT, bool FAST, bool GATED>
 __global__ __launch_bounds__(kHistThreads) void histc_kernel(const void* __restrict__ in, int64_t n, int bins,
-                                                             float lo, float hi, int vec, uint32_t* counts) {
+                                                             float lo, float hi, int vec, uint32_t* counts, const InitGate gate) {
   constexpr int dt = DT;
   extern __shared__ uint32_t s_hist[];
+  gate_open<GATED>(gate, bins, kHistThreads, [&](int64_t i) { __hip_atomic_store(&counts[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
+  unsigned seen = ~gate.epoch;
   for (int b = threadIdx.x; b < bins; b += kHistThreads) s_hist[b] = 0;
   __syncthreads();
   const float fb = (float)bins;
@@ -427,6 +489,7 @@ __global__ __launch_bounds__(kHistThreads) void histc_kernel(const void* __restr
       Raw8<DT> raw[U];
 #pragma unroll
       for (int u = 0; u < U; u++) raw[u] = load8_raw<DT>(in, (t + u * stride < nv ? t + u * stride : t) * 8);
+      seen = gate_peek<GATED>(gate, seen);
 #pragma unroll
       for (int u = 0; u < U; u++) {
         if (u == 0 || t + u * stride < nv) {
@@ -441,6 +504,7 @@ __global__ __launch_bounds__(kHistThreads) void histc_kernel(const void* __restr
   } else {
     for (int64_t e = t0; e < n; e += stride) hist_add<FAST>(s_hist, load_rt(in, dt, e), lo, hi, fb, width, bins);
   }
+  gate_wait<GATED>(gate, seen);   // thread 0; the barrier carries it to everyone
   __syncthreads();
   for (int b = threadIdx.x; b < bins; b += kHistThreads) {
     const uint32_t c = s_hist[b];
@@ -455,6 +519,52 @@ __global__ void hist_to_float_kernel(uint32_t* counts, int bins) {
 
 using namespace dmxq;
 
+// host side of the init gate: flag slots per device, one per stream
+namespace {
+struct GateDevice {
+  unsigned* flags = nullptr;
+  bool failed = false;
+  std::unordered_map<hipStream_t, int> slot_of;
+  std::vector<unsigned> epoch;
+};
+constexpr int kGateDevices = 64;
+std::mutex g_gate_mu;
+GateDevice g_gate[kGateDevices];
+
+InitGate take_gate(hipStream_t s, int64_t n_out) {
+  const InitGate none{nullptr, 0u, 0};
+  if (n_out > kGateMaxOut || s == hipStreamPerThread) return none;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return none; }
+  if (cap != hipStreamCaptureStatusNone) return none;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kGateDevices) { (void)hipGetLastError(); return none; }
+  std::lock_guard<std::mutex> lk(g_gate_mu);
+  GateDevice& G = g_gate[dev];
+  if (G.failed) return none;
+  if (!G.flags) {
+    // (another thread capturing in global mode makes hipMalloc fail: the fill launch serves until a later call succeeds)
+    unsigned* p = nullptr;
+    const size_t bytes = (size_t)kGateSlots * kGateStride * sizeof(unsigned);
+    if (hipMalloc((void**)&p, bytes) != hipSuccess) { (void)hipGetLastError(); return none; }
+    if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); G.failed = true; return none; }
+    G.flags = p;
+    G.epoch.assign(kGateSlots, 0u);
+  }
+  int slot;
+  auto it = G.slot_of.find(s);
+  if (it != G.slot_of.end()) slot = it->second;
+  else {
+    if ((int)G.slot_of.size() >= kGateSlots) return none;
+    slot = (int)G.slot_of.size();
+    G.slot_of.emplace(s, slot);
+  }
+  unsigned e = ++G.epoch[slot];
+  if (e == 0u) e = ++G.epoch[slot];
+  return InitGate{G.flags + (size_t)slot * kGateStride, e, 1};
+}
+}  // namespace
+
 // FILL: mn / mx are initialised to +inf / -inf by a first launch (dmxq_group_minmax); without it the kernel's atomics fold this
 // tensor's extrema INTO the values already there (dmxq_group_minmax_accumulate: a running min / max updated in ONE launch)
 static int group_minmax_impl(const void* in, int dtype_in, int64_t outer, int64_t C, int64_t inner, int64_t group_size, float* mn, float* mx,
@@ -465,7 +575,11 @@ static int group_minmax_impl(const void* in, int dtype_in, int64_t outer, int64_
   hipStream_t s = (hipStream_t)stream;
   const int64_t G = (C + group_size - 1) / group_size;
   if (G > 65535) return DMXQ_ERR_UNSUPPORTED;
-  if (fill) DMXQ_LAUNCH(fill2_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, mn, INFINITY, mx, -INFINITY, G);
+  const bool vec = outer * inner > 0 && aligned16(in) && (group_size * inner) % 8 == 0 && (C * inner) % 8 == 0;
+  // the identities: by the kernel's own first workgroup behind the init gate (vector kernels), else by a launch in front of it
+  InitGate gate{nullptr, 0u, 0};
+  if (fill && vec && in) gate = take_gate(s, G);
+  if (fill && !gate.on) DMXQ_LAUNCH(fill2_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, mn, INFINITY, mx, -INFINITY, G);
   if (outer * inner > 0) {
     if (!in) return DMXQ_ERR_BAD_ARG;
     const int64_t per_group = outer * group_size * inner;
@@ -473,25 +587,32 @@ static int group_minmax_impl(const void* in, int dtype_in, int64_t outer, int64_
     const int64_t cap = (kMaxBlocks + G - 1) / G;
     if (splits > cap) splits = cap;
     if (splits < 1) splits = 1;
-    // every run [(o*C + g*gs) * inner, + len*inner) starts 16-byte aligned and is a whole number of 8-element vectors
-    const bool vec = aligned16(in) && (group_size * inner) % 8 == 0 && (C * inner) % 8 == 0;
+    // (vec: every run [(o*C + g*gs) * inner, + len*inner) starts 16-byte aligned and is a whole number of 8-element vectors)
     if (vec && outer == 1) {
       const int64_t tile = (int64_t)kFlatThreads * (dtype_in == DMXQ_F32 ? 8 : 16);
       int64_t sv = (per_group / 8 + tile - 1) / tile;
-      const int64_t capv = (512 + G - 1) / G;
+      // <= 512 workgroups in all, and <= 160 per group: every workgroup ends in two atomics on its group's pair of addresses, and
+      // same-address atomics serialise (~1.4 ns each) -- per-tensor on 32 MiB: 512 x 1 tile 9.3 us, 256 x 2 9.3, 192 8.8, 160 x 3-4
+      // tiles 8.6, 128 x 4 8.8, 96 10.5 (too few loads in flight)
+      int64_t capv = (512 + G - 1) / G;
+      if (capv > 160) capv = 160;
       if (sv > capv) sv = capv;
       if (sv < 1) sv = 1;
-#define DMXQ_MF(D_) DMXQ_LAUNCH(group_minmax_flat_kernel<D_>, dim3((unsigned)sv, (unsigned)G), dim3(kFlatThreads), 0, s, in, C, inner, group_size, mn, mx)
+#define DMXQ_MF1(D_, G_) DMXQ_LAUNCH((group_minmax_flat_kernel<D_, G_>), dim3((unsigned)sv, (unsigned)G), dim3(kFlatThreads), 0, s, in, C, inner, group_size, mn, mx, gate)
+#define DMXQ_MF(D_) do { if (gate.on) DMXQ_MF1(D_, true); else DMXQ_MF1(D_, false); } while (0)
       if (dtype_in == DMXQ_F32) DMXQ_MF(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_MF(DMXQ_F16); else DMXQ_MF(DMXQ_BF16);
 #undef DMXQ_MF
+#undef DMXQ_MF1
     } else if (vec) {
       int64_t sv = (per_group / 8 + kMinmaxThreads * 8 - 1) / (kMinmaxThreads * 8);  // ~8 vectors per lane
       const int64_t capv = (512 + G - 1) / G;  // ~512 workgroups of 1024 threads in total
       if (sv > capv) sv = capv;
       if (sv < 1) sv = 1;
-#define DMXQ_MM(D_) DMXQ_LAUNCH(group_minmax_vec_kernel<D_>, dim3((unsigned)sv, (unsigned)G), dim3(kMinmaxThreads), 0, s, in, outer, C, inner, group_size, mn, mx)
+#define DMXQ_MM1(D_, G_) DMXQ_LAUNCH((group_minmax_vec_kernel<D_, G_>), dim3((unsigned)sv, (unsigned)G), dim3(kMinmaxThreads), 0, s, in, outer, C, inner, group_size, mn, mx, gate)
+#define DMXQ_MM(D_) do { if (gate.on) DMXQ_MM1(D_, true); else DMXQ_MM1(D_, false); } while (0)
       if (dtype_in == DMXQ_F32) DMXQ_MM(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_MM(DMXQ_F16); else DMXQ_MM(DMXQ_BF16);
 #undef DMXQ_MM
+#undef DMXQ_MM1
     } else
       DMXQ_LAUNCH(group_minmax_kernel, dim3((unsigned)splits, (unsigned)G), dim3(kThreads), 0, s, in, dtype_in,
                          outer, C, inner, group_size, mn, mx);
@@ -524,11 +645,13 @@ extern "C" int dmxq_channel_maxabs(const void* in, int dtype_in, int64_t outer, 
   if (C == 0) return DMXQ_OK;
   if (!out) return DMXQ_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  DMXQ_LAUNCH(fill2_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, out, 0.0f, (float*)nullptr, 0.0f, C);
   const int64_t plane = C * inner;
+  const bool vec = outer * plane > 0 && in && aligned16(in) && plane % 8 == 0;
+  InitGate gate{nullptr, 0u, 0};
+  if (vec) gate = take_gate(s, C);   // zeros by the kernel's first workgroup (the init gate above), else by a launch in front
+  if (!gate.on) DMXQ_LAUNCH(fill2_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, out, 0.0f, (float*)nullptr, 0.0f, C);
   if (outer * plane > 0) {
     if (!in) return DMXQ_ERR_BAD_ARG;
-    const bool vec = aligned16(in) && plane % 8 == 0;
     const int64_t gx = vec ? (plane / 8 + kWave - 1) / kWave : (plane + kThreads - 1) / kThreads;
     int64_t gy = kMaxBlocks / gx;
     if (gy < 1) gy = 1;
@@ -546,11 +669,13 @@ extern "C" int dmxq_channel_maxabs(const void* in, int dtype_in, int64_t outer, 
     }
     if (gy > 65535) gy = 65535;
     if (vec)
-#define DMXQ_MAU(D_, U_) DMXQ_LAUNCH((channel_maxabs_vec_kernel<D_, U_>), dim3((unsigned)gx, (unsigned)gy), dim3(kMaxabsThreads), 0, s, in, outer, C, inner, out)
+#define DMXQ_MAU1(D_, U_, G_) DMXQ_LAUNCH((channel_maxabs_vec_kernel<D_, U_, G_>), dim3((unsigned)gx, (unsigned)gy), dim3(kMaxabsThreads), 0, s, in, outer, C, inner, out, gate)
+#define DMXQ_MAU(D_, U_) do { if (gate.on) DMXQ_MAU1(D_, U_, true); else DMXQ_MAU1(D_, U_, false); } while (0)
 #define DMXQ_MA(D_) do { if (rows_in_flight == 8) DMXQ_MAU(D_, 8); else if (rows_in_flight == 4) DMXQ_MAU(D_, 4); else DMXQ_MAU(D_, 2); } while (0)
     { if (dtype_in == DMXQ_F32) DMXQ_MA(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_MA(DMXQ_F16); else DMXQ_MA(DMXQ_BF16); }
 #undef DMXQ_MA
 #undef DMXQ_MAU
+#undef DMXQ_MAU1
     else
       DMXQ_LAUNCH(channel_maxabs_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, s, in, dtype_in,
                          outer, C, inner, out);
@@ -574,7 +699,10 @@ extern "C" int dmxq_histc(const void* in, int dtype_in, int64_t n, int64_t bins,
     return DMXQ_ERR_BAD_ARG;
   if (bins > kHistMaxBins) return DMXQ_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(hist, 0, (size_t)bins * sizeof(float), s) != hipSuccess) return DMXQ_ERR_LAUNCH;
+  // the zeros: by the kernel's first workgroup behind the init gate (above), else by a memset in front of it
+  InitGate gate{nullptr, 0u, 0};
+  if (n > 0 && in) gate = take_gate(s, bins);
+  if (!gate.on && hipMemsetAsync(hist, 0, (size_t)bins * sizeof(float), s) != hipSuccess) return DMXQ_ERR_LAUNCH;
   if (n > 0) {
     if (!in) return DMXQ_ERR_BAD_ARG;
     // one workgroup of 16 waves per CU: every workgroup ends with one global atomic per non-empty bin (512 workgroups x 2048
@@ -582,13 +710,15 @@ extern "C" int dmxq_histc(const void* in, int dtype_in, int64_t n, int64_t bins,
     int64_t blocks = (n + kHistThreads * 32 - 1) / (kHistThreads * 32);
     if (blocks > 256) blocks = 256;
     const bool fast = recip_ok(hi - lo);
-#define DMXQ_HC(D_)                                                                                                              \
-  do {                                                                                                                           \
-    if (fast) DMXQ_LAUNCH((histc_kernel<D_, true>), dim3((unsigned)blocks), dim3(kHistThreads), (size_t)bins * sizeof(uint32_t), s, in, n, (int)bins, lo, hi, aligned16(in) ? 1 : 0, (uint32_t*)hist); \
-    else DMXQ_LAUNCH((histc_kernel<D_, false>), dim3((unsigned)blocks), dim3(kHistThreads), (size_t)bins * sizeof(uint32_t), s, in, n, (int)bins, lo, hi, aligned16(in) ? 1 : 0, (uint32_t*)hist); \
+#define DMXQ_HC1(D_, F_, G_) DMXQ_LAUNCH((histc_kernel<D_, F_, G_>), dim3((unsigned)blocks), dim3(kHistThreads), (size_t)bins * sizeof(uint32_t), s, in, n, (int)bins, lo, hi, aligned16(in) ? 1 : 0, (uint32_t*)hist, gate)
+#define DMXQ_HC(D_)                                                                  \
+  do {                                                                               \
+    if (fast) { if (gate.on) DMXQ_HC1(D_, true, true); else DMXQ_HC1(D_, true, false); }   \
+    else { if (gate.on) DMXQ_HC1(D_, false, true); else DMXQ_HC1(D_, false, false); }      \
   } while (0)
     if (dtype_in == DMXQ_F32) DMXQ_HC(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_HC(DMXQ_F16); else DMXQ_HC(DMXQ_BF16);
 #undef DMXQ_HC
+#undef DMXQ_HC1
     DMXQ_LAUNCH(hist_to_float_kernel, dim3((unsigned)((bins + 255) / 256)), dim3(256), 0, s, (uint32_t*)hist, (int)bins);
   }
   return launch_status();

@@ -237,6 +237,70 @@ def test_group_minmax_and_maxabs_at_size_vs_oracle(dmx, cuda, oracle, shape, ax,
     assert bits_equal(dmx.ops.channel_maxabs(x.to(cuda), -1), oracle.channel_maxabs(x, -1)) == 0
 
 
+def test_init_gate_every_workgroup_counts_streams_capture_and_fallbacks(dmx, cuda, oracle):
+    """The init gate of the reductions (csrc/reduce.hip): the kernel's first workgroup writes the identities, the others wait for
+    its epoch before their atomics.  A contribution issued BEFORE the identities landed would be overwritten: with the extreme of
+    every group / column placed in ONE workgroup's tile -- a different one per launch -- a lost update shows.  Also: destinations
+    holding garbage, several streams at once (a slot per stream), graph capture and > 8192 outputs (both: the fill launch)."""
+    rows, cols = 2048, 4096                                    # 16 MiB bf16: 128 tiles of 512 x 16 vectors for the flat kernel
+    base = make("normal", (rows, cols), seed=77, dtype=BF16).clamp(-8, 8)
+    g = torch.Generator().manual_seed(5)
+    xs, want = [], []
+    for it in range(24):
+        x = base.clone()
+        r = int(torch.randint(0, rows, (1,), generator=g))
+        x[r, :] = 100.0 + it                                   # every column's max |x|, the per-tensor max: in row r only
+        x[(r + 7) % rows, 3::5] = -(200.0 + it)                # ... and the minimum / some columns' max |x| in another tile
+        xs.append(x.to(cuda))
+        want.append((oracle.group_minmax(x.reshape(1, -1), 0, 1), oracle.group_minmax(x, 0, 64), oracle.channel_maxabs(x, -1)))
+    for x, (w1, w64, wa) in zip(xs, want):
+        for _ in range(3):                                     # epochs advance; the destination is whatever the allocator returns
+            mn, mx = dmx.ops.group_minmax(x.reshape(1, -1), 0, 1)
+            assert bits_equal(mn, w1[0]) == 0 and bits_equal(mx, w1[1]) == 0
+            mn, mx = dmx.ops.group_minmax(x, 0, 64)
+            assert bits_equal(mn, w64[0]) == 0 and bits_equal(mx, w64[1]) == 0
+            assert bits_equal(dmx.ops.channel_maxabs(x, -1), wa) == 0
+    # back to back WITHOUT a synchronisation in between, on several streams at once
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(8):
+        for k, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                i = (rep * 4 + k) % len(xs)
+                outs.append((i, dmx.ops.group_minmax(xs[i].reshape(1, -1), 0, 1), dmx.ops.group_minmax(xs[i], 0, 64),
+                             dmx.ops.channel_maxabs(xs[i], -1)))
+    torch.cuda.synchronize()
+    for i, a, b, c in outs:
+        assert bits_equal(a[0], want[i][0][0]) == 0 and bits_equal(a[1], want[i][0][1]) == 0
+        assert bits_equal(b[0], want[i][1][0]) == 0 and bits_equal(b[1], want[i][1][1]) == 0
+        assert bits_equal(c, want[i][2]) == 0
+    # captured: a replay presents the same kernel arguments again -- the library must not gate there; every replay is right
+    x0, x1 = xs[0], xs[1]
+    buf = x0.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dmx.ops.channel_maxabs(buf, -1)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g1 = dmx.ops.group_minmax(buf.reshape(1, -1), 0, 1)
+        ga = dmx.ops.channel_maxabs(buf, -1)
+    for src, w in ((x1, want[1]), (x0, want[0]), (x1, want[1])):
+        buf.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert bits_equal(g1[0], w[0][0]) == 0 and bits_equal(g1[1], w[0][1]) == 0 and bits_equal(ga, w[2]) == 0
+    # more outputs than one workgroup initialises: 16384 columns / 16384 groups
+    wide = make("heavy", (64, 16384), seed=9, dtype=BF16)
+    assert bits_equal(dmx.ops.channel_maxabs(wide.to(cuda), -1), oracle.channel_maxabs(wide, -1)) == 0
+    tall = wide.reshape(16384, 64)                               # 16384 groups of one 64-element row: the vector kernel, filled in front
+    mn, mx = dmx.ops.group_minmax(tall.to(cuda), 0, 1)
+    omn, omx = oracle.group_minmax(tall, 0, 1)
+    assert bits_equal(mn, omn) == 0 and bits_equal(mx, omx) == 0
+
+
 # ------------------------------------------------------------------------------------------------ unary modules as a table (csrc/lut16.hip)
 _FUNC64 = {
     "gelu": lambda v: v * 0.5 * torch.special.erfc(-v * 0.7071067811865476),

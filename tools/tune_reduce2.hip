@@ -80,14 +80,30 @@ __device__ __forceinline__ void lane_minmax(const u32x4 (&raw)[U], float& lo, fl
 // FIN 0: atomics (out pre-filled); 1: round-2 ticket (__threadfence x 2); 2: partial only; 4: LIGHT ticket (agent-scope partial stores,
 // s_waitcnt, relaxed ticket atomic, agent-scope partial loads); 5: ticket with release / acquire on the atomic (the compiler's fences);
 // 6: LIGHT ticket in two levels of <= 16 arrivals per address; 7: relaxed ticket with NO ordering at all (timing only: cost of the arrivals)
+// FIN 8: ONE launch, no ticket: workgroup 0 writes the identities to mn / mx with agent-scope stores, waits for them, then publishes
+// this launch's EPOCH in a flag word; every workgroup requests the flag word right BEHIND its data loads (vector memory returns in
+// order: the value arrives with the last data, for free) and only spins -- re-reading it -- if it does not yet hold the epoch, before
+// it issues its (non-returning) atomics.  `cnt[1024 + slot]` is the flag, `epoch` a host counter (unique per launch).
 template <int T, int U, int FIN, int PK>
 __global__ __launch_bounds__(T) void minmax_tile(const void* __restrict__ in, int64_t n_vec, int tiles_per_group, float* mn, float* mx,
-                                                 float* part, unsigned* cnt) {
+                                                 float* part, unsigned* cnt, unsigned epoch = 0, int n_groups = 1) {
   const int tile = blockIdx.x, g = tile / tiles_per_group;
   const int64_t base = (int64_t)tile * T * U + threadIdx.x;
+  unsigned* flag = cnt + 1024 + (epoch & 63u);
+  if (FIN == 8 && tile == 0) {
+    for (int i = threadIdx.x; i < n_groups; i += T) {
+      __hip_atomic_store(&mn[i], INFINITY, __ATOMIC_RELAXED, AGENT);
+      __hip_atomic_store(&mx[i], -INFINITY, __ATOMIC_RELAXED, AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, AGENT);
+  }
   u32x4 raw[U];
 #pragma unroll
   for (int u = 0; u < U; u++) raw[u] = __builtin_nontemporal_load((const u32x4*)in + (base + (int64_t)u * T < n_vec ? base + (int64_t)u * T : n_vec - 1));
+  unsigned seen = 0;
+  if (FIN == 8 && threadIdx.x == 0) seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, AGENT);   // issued behind the data loads
   float lo, hi;
   lane_minmax<U, PK>(raw, lo, hi);
 #pragma unroll
@@ -103,6 +119,13 @@ __global__ __launch_bounds__(T) void minmax_tile(const void* __restrict__ in, in
 #pragma unroll
   for (int o = T / 128; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
   if (FIN == 0) { if (threadIdx.x == 0) { atomic_min_f(&mn[g], lo); atomic_max_f(&mx[g], hi); } return; }
+  if (FIN == 8) {
+    if (threadIdx.x == 0) {
+      while (seen != epoch) seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, AGENT);
+      atomic_min_f(&mn[g], lo); atomic_max_f(&mx[g], hi);
+    }
+    return;
+  }
   if (FIN == 2) { if (threadIdx.x == 0) { part[2 * tile] = lo; part[2 * tile + 1] = hi; } return; }
   int last = 0;
   if (FIN == 1) {
@@ -168,16 +191,26 @@ __global__ __launch_bounds__(T) void minmax_tile(const void* __restrict__ in, in
 // FIN 0: atomics (out pre-zeroed), 2: partial only, 4: light ticket per strip (arrivals = row splits)
 // PK: |x| maxima on the packed 16-bit words (v_and + v_pk_max_u16 per dword)
 template <int W, int U, int FIN, int PK>
-__global__ __launch_bounds__(W * 64) void maxabs_cols(const void* __restrict__ in, int64_t rows, int64_t cols, float* out, float* part, unsigned* cnt) {
+__global__ __launch_bounds__(W * 64) void maxabs_cols(const void* __restrict__ in, int64_t rows, int64_t cols, float* out, float* part, unsigned* cnt,
+                                                       unsigned epoch = 0) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t col0 = ((int64_t)blockIdx.x * 64 + lane) * 8;
   const int64_t r0 = (int64_t)blockIdx.y * W * U + w;
+  unsigned* flag = cnt + 1024 + (epoch & 63u);
+  if (FIN == 8 && blockIdx.x == 0 && blockIdx.y == 0) {   // self-initialising: see minmax_tile FIN 8
+    for (int64_t i = threadIdx.x; i < cols; i += W * 64) __hip_atomic_store((uint32_t*)&out[i], 0u, __ATOMIC_RELAXED, AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, AGENT);
+  }
   u32x4 raw[U];
 #pragma unroll
   for (int u = 0; u < U; u++) {
     const int64_t r = r0 + (int64_t)u * W < rows ? r0 + (int64_t)u * W : rows - 1;
     raw[u] = __builtin_nontemporal_load((const u32x4*)((const uint16_t*)in + r * cols + col0));
   }
+  unsigned seen = 0;
+  if (FIN == 8 && threadIdx.x == 0) seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, AGENT);
   __shared__ uint32_t sm[W][PK ? 4 : 8][64];
   __shared__ int s_last;
   if (PK) {
@@ -202,6 +235,13 @@ __global__ __launch_bounds__(W * 64) void maxabs_cols(const void* __restrict__ i
 #pragma unroll
     for (int k = 0; k < 8; k++) sm[w][k][lane] = m[k];
   }
+  if (FIN == 8) {
+    __shared__ unsigned s_seen;
+    if (threadIdx.x == 0) {
+      while (seen != epoch) seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, AGENT);
+      s_seen = seen;
+    }
+  }
   __syncthreads();
   // 512 columns of the strip: column c = lane l * 8 + k
   for (int c = threadIdx.x; c < 512; c += W * 64) {
@@ -219,7 +259,7 @@ __global__ __launch_bounds__(W * 64) void maxabs_cols(const void* __restrict__ i
       for (int i = 1; i < W; i++) r = max(r, sm[i][k][l]);
     }
     const int64_t col = (int64_t)blockIdx.x * 512 + c;
-    if (FIN == 0) atomicMax((unsigned*)&out[col], r);
+    if (FIN == 0 || FIN == 8) atomicMax((unsigned*)&out[col], r);
     else if (FIN == 2) part[(int64_t)blockIdx.y * cols + col] = u2f(r);
     else __hip_atomic_store((uint32_t*)&part[(int64_t)blockIdx.y * cols + col], r, __ATOMIC_RELAXED, AGENT);
   }
@@ -240,6 +280,7 @@ __global__ __launch_bounds__(W * 64) void maxabs_cols(const void* __restrict__ i
   }
 }
 
+static unsigned g_epoch = 0;
 struct Variant { std::string name; std::function<void(const void*, hipStream_t)> run; std::vector<float> us; };
 
 int main(int argc, char** argv) {
@@ -256,22 +297,24 @@ int main(int argc, char** argv) {
   CK(hipMemset(cnt, 0, 65536 * 4));
   hipStream_t st; CK(hipStreamCreate(&st));
   std::vector<Variant> vs;
-  static const char* fin_name[] = {"fill+atomics", "ticket __threadfence (round 2)", "partial-only", "", "LIGHT ticket", "ticket acq_rel atomic", "LIGHT ticket 2-level (16 x 16)", "ticket, no ordering (timing only)"};
+  static const char* fin_name[] = {"fill+atomics", "ticket __threadfence (round 2)", "partial-only", "", "LIGHT ticket", "ticket acq_rel atomic", "LIGHT ticket 2-level (16 x 16)", "ticket, no ordering (timing only)", "SELF-INIT: wg 0 fills + epoch flag read behind the loads"};
 #define ADD_READ(T, U) vs.push_back({"read        T" #T " U" #U, [=](const void* i, hipStream_t q) { \
     hipLaunchKernelGGL((read_only<T, U>), dim3((unsigned)((n_vec + T * U - 1) / (T * U))), dim3(T), 0, q, i, n_vec, sink); }, {}})
 #define ADD_MM(T, U, FIN, G, PK) vs.push_back({std::string("minmax G" #G " T" #T " U" #U " ") + (PK ? "pk16 " : "f32  ") + fin_name[FIN], [=](const void* i, hipStream_t q) { \
     const int tiles = (int)((n_vec + T * U - 1) / (T * U)); \
     if (FIN == 0) hipLaunchKernelGGL(fill2, dim3((G + 255) / 256), dim3(256), 0, q, mn, INFINITY, mx, -INFINITY, G); \
-    hipLaunchKernelGGL((minmax_tile<T, U, FIN, PK>), dim3(tiles), dim3(T), 0, q, i, n_vec, std::max(1, tiles / G), mn, mx, part, cnt); }, {}})
+    hipLaunchKernelGGL((minmax_tile<T, U, FIN, PK>), dim3(tiles), dim3(T), 0, q, i, n_vec, std::max(1, tiles / G), mn, mx, part, cnt, ++g_epoch, (int)G); }, {}})
 #define ADD_MA(W, U, FIN, PK) vs.push_back({std::string("maxabs W" #W " U" #U " ") + (PK ? "pk16 " : "u32  ") + fin_name[FIN], [=](const void* i, hipStream_t q) { \
     if (FIN == 0) hipLaunchKernelGGL(fill2, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, q, mn, 0.0f, (float*)nullptr, 0.0f, (int)cols); \
-    hipLaunchKernelGGL((maxabs_cols<W, U, FIN, PK>), dim3((unsigned)(cols / 512), (unsigned)((rows + W * U - 1) / (W * U))), dim3(W * 64), 0, q, i, rows, cols, mn, part, cnt); }, {}})
+    hipLaunchKernelGGL((maxabs_cols<W, U, FIN, PK>), dim3((unsigned)(cols / 512), (unsigned)((rows + W * U - 1) / (W * U))), dim3(W * 64), 0, q, i, rows, cols, mn, part, cnt, ++g_epoch); }, {}})
   ADD_READ(512, 16); ADD_READ(256, 8);
   ADD_MM(512, 16, 0, 1, 0); ADD_MM(512, 16, 2, 1, 0); ADD_MM(512, 16, 2, 1, 1); ADD_MM(512, 16, 1, 1, 0); ADD_MM(512, 16, 5, 1, 0); ADD_MM(512, 16, 4, 1, 0);
   ADD_MM(512, 16, 7, 1, 0); ADD_MM(512, 16, 6, 1, 0); ADD_MM(512, 16, 6, 1, 1); ADD_MM(512, 16, 4, 1, 1);
   ADD_MM(512, 16, 0, 32, 0); ADD_MM(512, 16, 2, 32, 0); ADD_MM(512, 16, 4, 32, 0); ADD_MM(512, 16, 4, 32, 1); ADD_MM(512, 16, 5, 32, 0);
+  ADD_MM(512, 16, 8, 1, 1); ADD_MM(512, 16, 8, 32, 1); ADD_MM(512, 16, 8, 1, 0);
   ADD_MM(256, 16, 2, 1, 1); ADD_MM(256, 16, 6, 1, 1); ADD_MM(256, 16, 4, 32, 1); ADD_MM(256, 8, 2, 1, 1); ADD_MM(1024, 8, 4, 32, 1); ADD_MM(1024, 8, 6, 1, 1);
   ADD_MA(16, 8, 0, 0); ADD_MA(16, 8, 2, 0); ADD_MA(16, 8, 2, 1); ADD_MA(16, 8, 4, 0); ADD_MA(16, 8, 4, 1);
+  ADD_MA(16, 8, 8, 1); ADD_MA(16, 8, 8, 0);
   ADD_MA(8, 16, 2, 1); ADD_MA(8, 16, 4, 1); ADD_MA(8, 8, 4, 1); ADD_MA(4, 16, 4, 1); ADD_MA(16, 4, 4, 1); ADD_MA(4, 8, 4, 1);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   // every finishing form must reproduce fill + atomics
