@@ -103,7 +103,13 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
   } while (0)
 #define DMXQ_ROWS_GEOM(F_)                                                                         \
   do {                                                                                             \
-    const RowsPlan pl = rows_plan(n_vec, (F_) != 4);                                               \
+    /* the deep one-round plans: 16-bit -> same 16-bit, symmetric, single rounding (243 / 255 VGPRs; the others would spill) */ \
+    constexpr bool kDeep = (F_) == 2 && DTO == DTI && !ASYM;                                        \
+    const RowsPlan pl = rows_plan(n_vec, (F_) != 4, kDeep);                                        \
+    if constexpr (kDeep) {                                                                         \
+      if (pl.id == 6) { DMXQ_ROWS(512, 17, F_); break; }                                           \
+      if (pl.id == 7) { DMXQ_ROWS(512, 18, F_); break; }                                           \
+    }                                                                                              \
     if constexpr ((F_) != 4) {                                                                     \
       if (pl.id == 2) { DMXQ_ROWS(512, 4, F_); break; }                                            \
       if (pl.id == 3) { DMXQ_ROWS(128, 8, F_); break; }                                            \

@@ -388,8 +388,12 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
 //     512x4 (<= 16 MiB), 128x8 (<= 20 MiB), 512x16 (<= 32 MiB: the 4096x4096 bf16 headline tensor, 256 tiles);
 //   * beyond that several rounds per CU are needed anyway, and small 512x2 tiles (4 resident workgroups per CU that
 //     desynchronise, so reads of one overlap writes of another) win: 77-79 % of 8 TB/s vs 68-71 % for 512x16.
+//   * round 4: just above 32 MiB the multi-round plan starts at 65 % (its second round is almost empty; a plain copy shows the same
+//     step).  ONE round of <= 256 workgroups with 17 / 18 vectors per lane instead (allow_deep: the kernels that fit 17 / 18 vectors
+//     in 256 VGPRs): 4100 rows 65 -> 75-77 %, 4352 rows 66 -> 75 %, 4608 rows 66 -> 74 % (tools/tune_bfp TUNE_SET=deep,
+//     profiles/r04_tune_bfp_deep.txt).  19 .. 24 vectors spill with whole-tile groups and gain <= 1-3 points with smaller ones: not built.
 struct RowsPlan { int id, threads, unroll; int64_t tiles; };
-inline RowsPlan rows_plan(int64_t n_vec, bool allow_big) {
+inline RowsPlan rows_plan(int64_t n_vec, bool allow_big, bool allow_deep = false) {
   auto mk = [&](int id, int t, int u) { return RowsPlan{id, t, u, (n_vec + (int64_t)t * u - 1) / ((int64_t)t * u)}; };
   if (n_vec <= ((int64_t)1 << 18)) return mk(0, 512, 1);
   if (n_vec <= ((int64_t)3 << 18)) return mk(1, 128, 2);
@@ -399,6 +403,8 @@ inline RowsPlan rows_plan(int64_t n_vec, bool allow_big) {
     //  512x16 and ~9.5 on 2560 rows against 7.98 for 128x8: 60 % -> 67-69 % of the roofline at 20-24 MiB)
     if (n_vec <= ((int64_t)5 << 18)) return mk(3, 128, 8);
     if (n_vec <= ((int64_t)1 << 21)) return mk(4, 512, 16);
+    if (allow_deep && n_vec <= ((int64_t)17 << 17)) return mk(6, 512, 17);
+    if (allow_deep && n_vec <= ((int64_t)18 << 17)) return mk(7, 512, 18);
   }
   return mk(5, 512, 2);
 }

@@ -371,10 +371,10 @@ def test_widening_outputs_take_the_same_values_on_every_geometry(dmx, cuda, rows
     assert bits_equal(ops.scale_channels(x, sq, -1, True, out_dtype=F32), x.float() / sq) == 0
 
 
-@pytest.mark.parametrize("rows", [600, 1400, 2000, 2500, 3072, 4096, 4200])
+@pytest.mark.parametrize("rows", [600, 1400, 2000, 2500, 3072, 4096, 4200, 4500, 4700])
 @pytest.mark.parametrize("dtype", [BF16, F32], ids=["bf16", "f32"])
 def test_hot_kernel_tile_plans(dmx, cuda, rows, dtype):
-    """every size class of csrc/common.hpp rows_plan (512x1, 128x2, 512x4, 128x8, 512x16, 512x2; float32 tensors reach the classes at half
+    """every size class of csrc/common.hpp rows_plan (512x1, 128x2, 512x4, 128x8, 512x16, round 4: 512x17 and 512x18 in one round, 512x2; float32 tensors reach the classes at half
     the rows) for the hot BFP kernel, its widening / stochastic / asymmetric builds and the range-only FLOAT16 cast that shares the plan:
     whole tensor == 128-row slabs."""
     ops = dmx.ops
@@ -388,4 +388,24 @@ def test_hot_kernel_tile_plans(dmx, cuda, rows, dtype):
         "FLOAT16 cast": lambda t: ops.float_qdq(t, 10, 5, 15, True),
     }
     for tag, fn in cases.items():
+        _check(f"{tag} {dtype} rows={rows}", fn(x), _slabs(fn, x))
+
+
+@pytest.mark.parametrize("rows", [4097, 4100, 4352, 4353, 4500, 4608, 4609])
+@pytest.mark.parametrize("dtype", [BF16, F16], ids=["bf16", "f16"])
+def test_deep_one_round_plans_against_the_oracle(dmx, cuda, oracle, rows, dtype):
+    """Round 4: 32-36 MiB of a 16-bit tensor run as ONE round of <= 256 workgroups with 17 / 18 vectors per lane (rows_plan ids 6, 7)
+    instead of starting the multi-round plan at 65 % of the roofline.  Both sides of each class boundary (4096 | 4097, 4352 | 4353,
+    4608 | 4609 rows of 4096), full tiles and the partial last tile, directly against the CPU oracle; the builds that do NOT take the
+    deep plans (asymmetric, widening, other rounding) on the same tensors through the slab identity."""
+    ops = dmx.ops
+    xh = _input(rows, dtype, seed=11 * rows)
+    x = xh.to(cuda)
+    for B in (16, 64, 128):
+        bad = bits_equal(ops.bfp_qdq(x, 8, B), oracle.bfp_cast(xh, 8, B, -1).to(dtype))
+        assert bad == 0, f"BFP[8|8]{{{B}}} {dtype} rows={rows}: {bad} elements differ from the oracle"
+    bad = bits_equal(ops.bfp_qdq(x, 4, 32), oracle.bfp_cast(xh, 4, 32, -1).to(dtype))
+    assert bad == 0, f"BFP[4|8]{{32}} {dtype} rows={rows}: {bad} elements differ from the oracle"
+    for tag, fn in {"asym": lambda t: ops.bfp_qdq(t, 8, 64, symmetric=False), "-> f32": lambda t: ops.bfp_qdq(t, 8, 64, out_dtype=F32),
+                    "down": lambda t: ops.bfp_qdq(t, 8, 32, rounding="down")}.items():
         _check(f"{tag} {dtype} rows={rows}", fn(x), _slabs(fn, x))

@@ -30,8 +30,15 @@ def main():
         torch.cuda.empty_cache()
         n = R * C
         nbuf = max(2, min(16, math.ceil(600 * 2 ** 20 / (n * 4))))
-        xs = [(torch.randn(R, C, device=dev) * torch.exp(2 * torch.randn(R, C, device=dev))).to(torch.bfloat16) for _ in range(nbuf)]
+        # buffers FIRST, in a clean cache (every one its own allocation), then the heavy-tailed values slab by slab: with whole-tensor
+        # float32 temporaries in between, the bf16 tensors were carved back to back out of recycled blocks, and the one-round plans
+        # are sensitive to that placement (tools/probe_deep.py: 4100 x 4096 11.1 us or 12.6 us with the same kernel and data)
+        xs = [torch.empty(R, C, device=dev, dtype=torch.bfloat16) for _ in range(nbuf)]
         ys = [torch.empty_like(x) for x in xs]
+        for x in xs:
+            for r0 in range(0, R, 1024):
+                r1 = min(R, r0 + 1024)
+                x[r0:r1] = (torch.randn(r1 - r0, C, device=dev) * torch.exp(2 * torch.randn(r1 - r0, C, device=dev))).to(torch.bfloat16)
         for B in (16, 64):
             iters = 200
             with torch.cuda.stream(stream):

@@ -83,6 +83,14 @@ int main(int argc, char** argv) {
     ADD_COPY(2, 7, 512, 0); ADD_COPY(4, 7, 512, 0);
     ADD_BFPG(1, 3, 512, 0, 2, 1); ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPG(3, 3, 512, 0, 2, 3); ADD_BFPG(4, 3, 512, 0, 2, 4); ADD_BFPG(6, 3, 512, 0, 2, 6); ADD_BFPG(8, 3, 512, 0, 2, 8);
     ADD_BFPG(2, 3, 128, 0, 2, 2); ADD_BFPG(1, 3, 256, 0, 2, 1); ADD_BFPG(2, 3, 256, 0, 2, 2); ADD_BFPG(4, 3, 256, 0, 2, 4); ADD_BFPG(8, 3, 256, 0, 2, 8);
+  } else if (getenv("TUNE_SET") && std::string(getenv("TUNE_SET")) == "deep") {
+    // round 4: ONE round of <= 256 workgroups with a compile-time depth of 17 .. 24 vectors per lane for 32-48 MiB, against 512 x 2
+    ADD_COPY(2, 7, 512, 0);
+    ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPG(16, 3, 512, 0, 2, 16);
+    ADD_BFPG(17, 3, 512, 0, 2, 17); ADD_BFPG(18, 3, 512, 0, 2, 18); ADD_BFPG(18, 3, 512, 0, 2, 9); ADD_BFPG(18, 3, 512, 0, 2, 6);
+    ADD_BFPG(19, 3, 512, 0, 2, 1); ADD_BFPG(20, 3, 512, 0, 2, 10); ADD_BFPG(20, 3, 512, 0, 2, 5); ADD_BFPG(20, 3, 512, 0, 2, 4);
+    ADD_BFPG(21, 3, 512, 0, 2, 7); ADD_BFPG(22, 3, 512, 0, 2, 11); ADD_BFPG(22, 3, 512, 0, 2, 2); ADD_BFPG(23, 3, 512, 0, 2, 1);
+    ADD_BFPG(24, 3, 512, 0, 2, 12); ADD_BFPG(24, 3, 512, 0, 2, 8); ADD_BFPG(24, 3, 512, 0, 2, 6); ADD_BFPG(24, 3, 512, 0, 2, 4);
   } else if (getenv("TUNE_SET") && std::string(getenv("TUNE_SET")) == "sweep") {
     // tile-plan continuity (round 3): the one-round shapes against the multi-round 512x2 just above the 32 MiB headline size
     ADD_COPY(2, 7, 512, 0); ADD_COPY(16, 7, 512, 0);
