@@ -94,21 +94,28 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
     const int lpb = (int)(B / EPL);
     // nearest-even: the magic-add path (bfp_math.hpp (2)); single rounding where the input dtype allows it
     const int fast = (RND == DMXQ_ROUND_NEAREST && wl <= 20) ? (bfp_single_rounding_ok<DTI>(wl) ? 2 : 1) : 0;
-#define DMXQ_ROWS(T_, U_, F_)                                                                                    \
+#define DMXQ_ROWS_G(T_, U_, F_, G_)                                                                              \
   do {                                                                                                           \
     const int64_t tiles = (n_vec + (int64_t)(T_) * (U_) - 1) / ((int64_t)(T_) * (U_));                           \
     const int grid = (int)(tiles < kRowsMaxGrid ? tiles : kRowsMaxGrid);                                         \
-    DMXQ_LAUNCH((bfp_rows_kernel<DTI, DTO, RND, ASYM, U_, MODE, T_, F_, U_, IVB>), dim3(grid), dim3(T_), 0, s, in, \
+    DMXQ_LAUNCH((bfp_rows_kernel<DTI, DTO, RND, ASYM, U_, MODE, T_, F_, G_, IVB>), dim3(grid), dim3(T_), 0, s, in, \
                        out, n_vec, lpb, wl, rounding, seed);                                                     \
   } while (0)
+#define DMXQ_ROWS(T_, U_, F_) DMXQ_ROWS_G(T_, U_, F_, U_)
 #define DMXQ_ROWS_GEOM(F_)                                                                         \
   do {                                                                                             \
-    /* the deep one-round plans: 16-bit -> same 16-bit, symmetric, single rounding (243 / 255 VGPRs; the others would spill) */ \
+    /* the exact-depth one-round plans (rows_plan): 16-bit -> same 16-bit, symmetric, single rounding (<= 255 VGPRs) */          \
     constexpr bool kDeep = (F_) == 2 && DTO == DTI && !ASYM;                                        \
     const RowsPlan pl = rows_plan(n_vec, (F_) != 4, kDeep);                                        \
     if constexpr (kDeep) {                                                                         \
-      if (pl.id == 6) { DMXQ_ROWS(512, 17, F_); break; }                                           \
-      if (pl.id == 7) { DMXQ_ROWS(512, 18, F_); break; }                                           \
+      if (pl.id == 111) { DMXQ_ROWS(512, 11, F_); break; }                                         \
+      if (pl.id == 112) { DMXQ_ROWS(512, 12, F_); break; }                                         \
+      if (pl.id == 113) { DMXQ_ROWS(512, 13, F_); break; }                                         \
+      if (pl.id == 114) { DMXQ_ROWS(512, 14, F_); break; }                                         \
+      if (pl.id == 115) { DMXQ_ROWS(512, 15, F_); break; }                                         \
+      if (pl.id == 116) { DMXQ_ROWS(512, 16, F_); break; }                                         \
+      if (pl.id == 117) { DMXQ_ROWS(512, 17, F_); break; }                                         \
+      if (pl.id == 118) { DMXQ_ROWS(512, 18, F_); break; }                                         \
     }                                                                                              \
     if constexpr ((F_) != 4) {                                                                     \
       if (pl.id == 2) { DMXQ_ROWS(512, 4, F_); break; }                                            \
@@ -133,6 +140,7 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
     }
 #undef DMXQ_ROWS_GEOM
 #undef DMXQ_ROWS
+#undef DMXQ_ROWS_G
     return launch_status();
   }
   const int64_t nblk = (L + B - 1) / B;

@@ -82,6 +82,64 @@ __device__ __forceinline__ u32x4 load_rawv(const void* p, uint32_t off) {
   return u32x4{t.x, t.y, 0u, 0u};
 }
 
+// The LAST tile of a tensor that is not a whole number of tiles: bfp_rows_tile's schedule with predicated loads (zeros elsewhere: an
+// all-zero block takes the fast path, and is never stored) and predicated stores.  A block never straddles the predicate (n_vec % lpb
+// == 0, lpb | THREADS).  Until round 4 this tile ran vector by vector -- load, wait, quantise, store, UNROLL times in series: a tile
+// that was 80-95 % full cost ~15 serial round trips, 19 us instead of 12 at 4300 x 4096 (tools/probe_deep.py), and made every one-round
+// plan erratic between the sizes it was tuned on (profiles/r04_tune_bfp_fit.txt).  A function of its own, NOT inlined: sharing one
+// body with the full tile (a generic lambda over a PARTIAL tag) changed the full tile's code -- outputs in place of the raw vectors,
+// 108 instead of 229 VGPRs -- and cost the headline launch 9 % (tools/tune_bfp -DTUNE_MIN: 10.84 -> 11.81 us).
+// `rem` = n_vec - (first vector of this lane): vector u of the lane exists iff u * THREADS < rem.
+template <int DTI, int DTO, int RND, bool ASYM, int UNROLL, int MODE, int THREADS, int FAST, int GROUP, int IVB, int LPBC>
+__device__ __attribute__((noinline)) void bfp_rows_tile_partial(const char* __restrict__ src, char* __restrict__ dst, int64_t rem, int64_t v0,
+                                                                int lpb_rt, int wl, int rounding, bool stoch, uint64_t seed) {
+  const int lpb = LPBC > 0 ? LPBC : lpb_rt;
+  constexpr bool NTS = (MODE & kRowsNtStore) != 0;
+  constexpr int SK = (MODE & kRowsSc1Store) ? 2 : ((MODE & kRowsSc0Store) ? 3 : (NTS ? 1 : 0));
+  constexpr int EPL = IVB / Elem<DTI>::bytes;
+  constexpr int OVB = EPL * Elem<DTO>::bytes;
+  const uint32_t lane_in = threadIdx.x * (uint32_t)IVB, lane_out = threadIdx.x * (uint32_t)OVB;
+  u32x4 raw[UNROLL];
+#pragma unroll
+  for (int u = 0; u < UNROLL; u++) {
+    if ((int64_t)u * THREADS < rem) raw[u] = load_rawv<IVB>(src + u * (THREADS * IVB), lane_in);
+    else raw[u] = u32x4{0u, 0u, 0u, 0u};
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < UNROLL; g += GROUP) {
+    uint32_t mb[GROUP];
+    constexpr bool kFast = FAST == 4 || (FAST != 0 && RND == DMXQ_ROUND_NEAREST);
+    bool all_fast = kFast;
+#pragma unroll
+    for (int u = 0; u < GROUP; u++) {
+      mb[u] = group_max_u32(absmax_bits<DTI>(raw[g + u]), lpb);
+      if (kFast) all_fast = all_fast && (FAST == 4 ? bfp_bitfast_ok(mb[u], rounding) : bfp_fast_ok(mb[u], wl));
+    }
+    OutVec<DTO, EPL> o[GROUP];
+#pragma unroll
+    for (int u = 0; u < GROUP; u++) {
+      o[u] = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, kFast, EPL>(raw[g + u], mb[u], v0 + (int64_t)(g + u) * THREADS, wl, rounding, stoch, seed);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kFast && __builtin_amdgcn_ballot_w64(!all_fast) != 0ull) {  // rare: see bfp_rows_tile
+#pragma unroll
+      for (int u = 0; u < GROUP; u++) {
+        u32x4 r = u32x4{0u, 0u, 0u, 0u};
+        if ((int64_t)(g + u) * THREADS < rem) r = load_rawv<IVB>(src + (g + u) * (THREADS * IVB), lane_in);
+        const uint32_t m = group_max_u32(absmax_bits<DTI>(r), lpb);
+        if (__builtin_amdgcn_ballot_w64(!(FAST == 4 ? bfp_bitfast_ok(m, rounding) : bfp_fast_ok(m, wl))) != 0ull)
+          o[u] = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, false, EPL>(r, m, v0 + (int64_t)(g + u) * THREADS, wl, rounding, stoch, seed);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < GROUP; u++)
+      if ((int64_t)(g + u) * THREADS < rem) store_out_kind<DTO, EPL, SK>(dst + (g + u) * (THREADS * OVB) + lane_out, o[u]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ONE tile (THREADS*UNROLL lane-vectors) of a flat tensor of n_vec vectors: `tile` is the tile index inside that tensor.
 // Shared by the single-tensor kernel below and the multi-tensor kernel of bfp.hip.
 // LPBC: lanes per block as a compile-time constant (0 = the runtime value `lpb_rt`): the DPP reduction of the block maximum
@@ -144,16 +202,9 @@ __device__ __forceinline__ void bfp_rows_tile(const void* __restrict__ in, void*
       for (int u = 0; u < GROUP; u++) store_out_kind<DTO, EPL, SK>(dst + (g + u) * (THREADS * OVB) + lane_out, o[u]);
       __builtin_amdgcn_sched_barrier(0);
     }
-  } else {  // last, partial tile: a block never straddles the predicate (n_vec % lpb == 0, lpb | THREADS)
-    for (int u = 0; u < UNROLL; u++) {
-      const int64_t vi = v0 + (int64_t)u * THREADS;
-      if (vi < n_vec) {
-        const u32x4 raw = load_rawv<IVB>(src + u * (THREADS * IVB), lane_in);
-        const uint32_t mb = group_max_u32(absmax_bits<DTI>(raw), lpb);
-        const OutVec<DTO, EPL> o = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, false, EPL>(raw, mb, vi, wl, rounding, stoch, seed);
-        store_out<DTO, EPL, NTS>(dst + u * (THREADS * OVB) + lane_out, o);
-      }
-    }
+  } else {
+    // last, partial tile (workgroup-uniform): the same schedule with predicated loads and stores, in a function of its own
+    bfp_rows_tile_partial<DTI, DTO, RND, ASYM, UNROLL, MODE, THREADS, FAST, GROUP, IVB, LPBC>(src, dst, n_vec - v0, v0, lpb, wl, rounding, stoch, seed);
   }
 }
 

@@ -23,7 +23,8 @@ def run(R, C, nbuf, kind, B=16):
             e1.record(stream); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) * 1e3 / 200)
     print(f"{R}x{C} nbuf {nbuf:2d} {kind:6s} B{B}: {best:6.2f} us  {R*C*4/best/1e3/8000*100:5.1f}%  ptr%2MiB={xs[0].data_ptr() % (2<<20)} {xs[1].data_ptr()-xs[0].data_ptr()}", flush=True)
-for R in (4100, 4352, 4608):
-    for nbuf in (9, 10, 16):
+rows = [int(a) for a in sys.argv[1:]] or [4100, 4352, 4608]
+for R in rows:
+    for nbuf in ((9, 10, 16) if len(sys.argv) == 1 else (10,)):
         for kind in ("heavy", "normal"):
             run(R, 4096, nbuf, kind)

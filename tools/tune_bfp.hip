@@ -48,13 +48,26 @@ int main(int argc, char** argv) {
   std::vector<uint16_t> h(n);
   uint64_t s = 88172645463325252ull;
   for (int64_t i = 0; i < n; i++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = (uint16_t)(((s >> 20) & 0x8FFF) | 0x3000) ^ (uint16_t)((s >> 40) & 0x0F00); }
+  // TUNE_CARVE=1: all inputs, then all outputs, carved back to back out of ONE allocation (what a caching allocator hands out from a
+  // recycled block) instead of one hipMalloc each
+  if (getenv("TUNE_CARVE") && atoi(getenv("TUNE_CARVE"))) {
+    char* big; CK(hipMalloc((void**)&big, (size_t)n_alloc * 2 * 2 * NBUF));
+    for (int b = 0; b < NBUF; b++) { in[b] = big + (size_t)b * n_alloc * 2; out[b] = big + (size_t)(NBUF + b) * n_alloc * 2; CK(hipMemcpy(in[b], h.data(), n * 2, hipMemcpyHostToDevice)); }
+  } else
   for (int b = 0; b < NBUF; b++) { CK(hipMalloc(&in[b], n_alloc * 2)); CK(hipMalloc(&out[b], n_alloc * 2)); CK(hipMemcpy(in[b], h.data(), n * 2, hipMemcpyHostToDevice)); }
   printf("# rows %lld cols %lld alloc_rows %lld nbuf %d  in[0]=%p out[0]=%p in[1]=%p\n", (long long)rows, (long long)cols, (long long)alloc_rows, NBUF, in[0], out[0], in[1]);
   hipStream_t st; CK(hipStreamCreate(&st));
   std::vector<Variant> vs;
+  // TUNE_LDS=<KiB>: reserve that much dynamic LDS per workgroup when the grid is one round of <= 256 workgroups, so that the dispatcher
+  // cannot place two of them on one CU (160 KiB) and leave another CU idle
+  static const size_t lds_reserve = getenv("TUNE_LDS") ? (size_t)atoi(getenv("TUNE_LDS")) * 1024 : 0;
 #define ADD_BFPG(U, M, T, GRID, F, GR) vs.push_back({"bfp  U" #U " M" #M " T" #T " G" #GRID " F" #F " grp" #GR, [=](const void* i, void* o, hipStream_t q) { \
     int g = (GRID) > 0 ? (GRID) : (int)((n_vec + (int64_t)T * U - 1) / ((int64_t)T * U)); \
-    hipLaunchKernelGGL((bfp_rows_kernel<DMXQ_BF16, DMXQ_BF16, DMXQ_ROUND_NEAREST, false, U, M, T, F, GR>), dim3(g), dim3(T), 0, q, i, o, n_vec, 2, 8, 2, 0ull); }, {}})
+    auto kern = bfp_rows_kernel<DMXQ_BF16, DMXQ_BF16, DMXQ_ROUND_NEAREST, false, U, M, T, F, GR>; \
+    const size_t lds = (g <= 256 && (U) >= 4) ? lds_reserve : 0; \
+    static bool attr = false; \
+    if (lds && !attr) { CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
+    hipLaunchKernelGGL(kern, dim3(g), dim3(T), lds, q, i, o, n_vec, 2, 8, 2, 0ull); }, {}})
 #define ADD_BFPL(U, M, T, GRID, F, GR, LPBC) vs.push_back({"bfp  U" #U " M" #M " T" #T " G" #GRID " F" #F " grp" #GR " lpbc" #LPBC, [=](const void* i, void* o, hipStream_t q) { \
     int g = (GRID) > 0 ? (GRID) : (int)((n_vec + (int64_t)T * U - 1) / ((int64_t)T * U)); \
     hipLaunchKernelGGL((bfp_rows_kernel<DMXQ_BF16, DMXQ_BF16, DMXQ_ROUND_NEAREST, false, U, M, T, F, GR, 16, LPBC>), dim3(g), dim3(T), 0, q, i, o, n_vec, 2, 8, 2, 0ull); }, {}})
@@ -67,6 +80,9 @@ int main(int argc, char** argv) {
 #define ADD_BFPB(ASYM_, LPB_, LPBC_) vs.push_back({"bfp  512x16 " #ASYM_ " lpb" #LPB_ " lpbc" #LPBC_, [=](const void* i, void* o, hipStream_t q) { \
     int g = (int)((n_vec + (int64_t)512 * 16 - 1) / ((int64_t)512 * 16)); \
     hipLaunchKernelGGL((bfp_rows_kernel<DMXQ_BF16, DMXQ_BF16, DMXQ_ROUND_NEAREST, ASYM_, 16, 3, 512, 2, 16, 16, LPBC_>), dim3(g), dim3(512), 0, q, i, o, n_vec, LPB_, 8, 2, 0ull); }, {}})
+#ifdef TUNE_MIN   // -DTUNE_MIN: five variants only (compiles in a minute)
+  ADD_COPY(16, 7, 512, 0); ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPG(17, 3, 512, 0, 2, 17); ADD_BFPG(18, 3, 512, 0, 2, 18);
+#else
   if (getenv("TUNE_SET") && std::string(getenv("TUNE_SET")) == "blocks") {
     // round 3: block size 64 / 128 (8 / 16 lanes per block), symmetric vs asymmetric, lane count compile-time vs run-time
     ADD_COPY(16, 7, 512, 0);
@@ -91,6 +107,20 @@ int main(int argc, char** argv) {
     ADD_BFPG(19, 3, 512, 0, 2, 1); ADD_BFPG(20, 3, 512, 0, 2, 10); ADD_BFPG(20, 3, 512, 0, 2, 5); ADD_BFPG(20, 3, 512, 0, 2, 4);
     ADD_BFPG(21, 3, 512, 0, 2, 7); ADD_BFPG(22, 3, 512, 0, 2, 11); ADD_BFPG(22, 3, 512, 0, 2, 2); ADD_BFPG(23, 3, 512, 0, 2, 1);
     ADD_BFPG(24, 3, 512, 0, 2, 12); ADD_BFPG(24, 3, 512, 0, 2, 8); ADD_BFPG(24, 3, 512, 0, 2, 6); ADD_BFPG(24, 3, 512, 0, 2, 4);
+  } else if (getenv("TUNE_SET") && std::string(getenv("TUNE_SET")) == "fit") {
+    // round 4: 16-32 MiB with the depth that fills ONE round of 256 workgroups exactly (U = ceil(n_vec / (256 x 512))), against the product's 128 x 8 / 512 x 16
+    ADD_COPY(16, 7, 512, 0);
+    ADD_BFPG(8, 3, 128, 0, 2, 8); ADD_BFPG(16, 3, 512, 0, 2, 16);
+    ADD_BFPG(9, 3, 512, 0, 2, 9); ADD_BFPG(10, 3, 512, 0, 2, 10); ADD_BFPG(11, 3, 512, 0, 2, 11); ADD_BFPG(12, 3, 512, 0, 2, 12);
+    ADD_BFPG(13, 3, 512, 0, 2, 13); ADD_BFPG(14, 3, 512, 0, 2, 14); ADD_BFPG(15, 3, 512, 0, 2, 15);
+    ADD_BFPG(5, 3, 512, 0, 2, 5); ADD_BFPG(6, 3, 512, 0, 2, 6); ADD_BFPG(7, 3, 512, 0, 2, 7); ADD_BFPG(8, 3, 512, 0, 2, 8);
+  } else if (getenv("TUNE_SET") && std::string(getenv("TUNE_SET")) == "oneround") {
+    // round 4: every depth 5 .. 18 as ONE round (with TUNE_LDS=84: one workgroup per CU guaranteed) against the product's plans
+    ADD_COPY(16, 7, 512, 0); ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPG(4, 3, 512, 0, 2, 4); ADD_BFPG(8, 3, 128, 0, 2, 8);
+    ADD_BFPG(5, 3, 512, 0, 2, 5); ADD_BFPG(6, 3, 512, 0, 2, 6); ADD_BFPG(7, 3, 512, 0, 2, 7); ADD_BFPG(8, 3, 512, 0, 2, 8);
+    ADD_BFPG(9, 3, 512, 0, 2, 9); ADD_BFPG(10, 3, 512, 0, 2, 10); ADD_BFPG(11, 3, 512, 0, 2, 11); ADD_BFPG(12, 3, 512, 0, 2, 12);
+    ADD_BFPG(13, 3, 512, 0, 2, 13); ADD_BFPG(14, 3, 512, 0, 2, 14); ADD_BFPG(15, 3, 512, 0, 2, 15); ADD_BFPG(16, 3, 512, 0, 2, 16);
+    ADD_BFPG(17, 3, 512, 0, 2, 17); ADD_BFPG(18, 3, 512, 0, 2, 18); ADD_BFPG(20, 3, 512, 0, 2, 10); ADD_BFPG(22, 3, 512, 0, 2, 11); ADD_BFPG(24, 3, 512, 0, 2, 12);
   } else if (getenv("TUNE_SET") && std::string(getenv("TUNE_SET")) == "sweep") {
     // tile-plan continuity (round 3): the one-round shapes against the multi-round 512x2 just above the 32 MiB headline size
     ADD_COPY(2, 7, 512, 0); ADD_COPY(16, 7, 512, 0);
@@ -102,6 +132,7 @@ int main(int argc, char** argv) {
   ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPL(16, 3, 512, 0, 2, 16, 2); ADD_BFPG(16, 3, 256, 0, 2, 16); ADD_BFPL(16, 3, 256, 0, 2, 16, 2);
   ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPL(2, 3, 512, 0, 2, 2, 2); ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPL(16, 3, 512, 0, 2, 16, 2);
   }
+#endif
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto& v : vs) for (int i = 0; i < 10; i++) v.run(in[i % NBUF], out[i % NBUF], st);
   CK(hipStreamSynchronize(st));
