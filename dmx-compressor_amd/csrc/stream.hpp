@@ -118,6 +118,11 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict_
       for (int u = 0; u < UNROLL; u++) prep[u] = OpPrep<OP>::get(op, (v0 + (int64_t)u * THREADS) * EPL);
       finish([&](int u) -> const typename OpPrep<OP>::type& { return prep[u]; });
     } else {
+      // the last, partial tile, vector by vector.  (The hot BFP kernel runs its partial tile on the full tile's schedule, in a function
+      // of its own -- bfp_rows_tile_partial.  The same here measured a DISASTER: with a non-inlined call in the kernel the full tiles
+      // of float_qdq went 12.0 -> 21.9 us, fixed_qdq 11.0 -> 16.2, silu 11.2 -> 12.2 on 4096 x 4096 bf16; and these kernels keep >= 2
+      // workgroups per CU, so the serial tail of ONE workgroup costs them at most ~5 % at a few sizes, not the 40 % it cost a
+      // one-workgroup-per-CU plan: tools/probe_partial.py.)
       for (int u = 0; u < UNROLL; u++) {
         const int64_t vi = v0 + (int64_t)u * THREADS;
         if (vi < n_vec) {
