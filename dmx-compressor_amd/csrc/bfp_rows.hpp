@@ -202,9 +202,21 @@ __device__ __forceinline__ void bfp_rows_tile(const void* __restrict__ in, void*
       for (int u = 0; u < GROUP; u++) store_out_kind<DTO, EPL, SK>(dst + (g + u) * (THREADS * OVB) + lane_out, o[u]);
       __builtin_amdgcn_sched_barrier(0);
     }
-  } else {
+  } else if constexpr (UNROLL >= 4) {
     // last, partial tile (workgroup-uniform): the same schedule with predicated loads and stores, in a function of its own
     bfp_rows_tile_partial<DTI, DTO, RND, ASYM, UNROLL, MODE, THREADS, FAST, GROUP, IVB, LPBC>(src, dst, n_vec - v0, v0, lpb, wl, rounding, stoch, seed);
+  } else {
+    // 1 or 2 vectors per lane (the multi-round plans): nothing to overlap, and a call in these kernels costs their FULL tiles 5-9 %
+    // (bf16 -> float32 with run-time rounding, 64 MiB: 19.0 -> 20.6 us) -- vector by vector, inline
+    for (int u = 0; u < UNROLL; u++) {
+      const int64_t vi = v0 + (int64_t)u * THREADS;
+      if (vi < n_vec) {
+        const u32x4 raw = load_rawv<IVB>(src + u * (THREADS * IVB), lane_in);
+        const uint32_t mb = group_max_u32(absmax_bits<DTI>(raw), lpb);
+        const OutVec<DTO, EPL> o = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, false, EPL>(raw, mb, vi, wl, rounding, stoch, seed);
+        store_out<DTO, EPL, NTS>(dst + u * (THREADS * OVB) + lane_out, o);
+      }
+    }
   }
 }
 
