@@ -64,6 +64,8 @@ PY
 rm -rf $OUT/prof_bench $OUT/pmc_fetch $OUT/pmc_write
 # 3. shape / op tables, counters of the second-tier kernels, host overhead
 python3 tools/bench_shapes.py > $OUT/secondary_shapes.txt 2>&1
+python3 tools/bench_shapes.py --mid > $OUT/mid_shapes.txt 2>&1
+python3 tools/probe_partial.py > $OUT/probe_partial.txt 2>&1
 python3 tools/bench_ops.py > $OUT/ops_roofline_table.txt 2>&1
 python3 tools/bench_rows.py > $OUT/row_ops.txt 2>&1
 bash tools/collect_pmc.sh gpurun_out/$TAG/pmc "per-channel along last,group_size=128,group_minmax,channel_maxabs,bf16 score,SBFP12,rnd=3,histc,bfloat16->bfloat16 B=16 wl=8 sym rnd=2,scale_channels,layernorm,rmsnorm,softmax,unary,_cast,lut16,E4M3,block_dim=-2" > /dev/null 2>&1
