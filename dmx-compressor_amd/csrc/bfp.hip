@@ -104,16 +104,18 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
 #define DMXQ_ROWS(T_, U_, F_) DMXQ_ROWS_G(T_, U_, F_, U_)
 #define DMXQ_ROWS_GEOM(F_)                                                                         \
   do {                                                                                             \
-    /* the exact-depth one-round plans (rows_plan): 16-bit -> same 16-bit, symmetric, single rounding (<= 255 VGPRs) */          \
-    constexpr bool kDeep = (F_) == 2 && DTO == DTI && !ASYM;                                        \
-    const RowsPlan pl = rows_plan(n_vec, (F_) != 4, kDeep);                                        \
-    if constexpr (kDeep) {                                                                         \
+    /* the exact-depth one-round plans (rows_plan): symmetric same-dtype builds; 17 / 18 vectors only where they fit 256 VGPRs */ \
+    constexpr int kDepth = ((F_) != 4 && DTO == DTI && !ASYM) ? ((F_) == 2 ? 18 : 16) : 0;         \
+    const RowsPlan pl = rows_plan(n_vec, (F_) != 4, kDepth);                                       \
+    if constexpr (kDepth >= 16) {                                                                  \
       if (pl.id == 111) { DMXQ_ROWS(512, 11, F_); break; }                                         \
       if (pl.id == 112) { DMXQ_ROWS(512, 12, F_); break; }                                         \
       if (pl.id == 113) { DMXQ_ROWS(512, 13, F_); break; }                                         \
       if (pl.id == 114) { DMXQ_ROWS(512, 14, F_); break; }                                         \
       if (pl.id == 115) { DMXQ_ROWS(512, 15, F_); break; }                                         \
       if (pl.id == 116) { DMXQ_ROWS(512, 16, F_); break; }                                         \
+    }                                                                                              \
+    if constexpr (kDepth >= 18) {                                                                  \
       if (pl.id == 117) { DMXQ_ROWS(512, 17, F_); break; }                                         \
       if (pl.id == 118) { DMXQ_ROWS(512, 18, F_); break; }                                         \
     }                                                                                              \

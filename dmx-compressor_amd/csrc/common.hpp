@@ -388,11 +388,12 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
 //     512x4 (<= 16 MiB), 128x8 (<= 20 MiB), 512x16 (<= 32 MiB: the 4096x4096 bf16 headline tensor, 256 tiles);
 //   * beyond that several rounds per CU are needed anyway, and small 512x2 tiles (4 resident workgroups per CU that
 //     desynchronise, so reads of one overlap writes of another) win: 77-79 % of 8 TB/s vs 68-71 % for 512x16.
-//   * round 4 (allow_deep: the symmetric 16-bit -> same-16-bit single-rounding build, whose 17 / 18-vector tiles fit 256 VGPRs):
-//     between 20 and 40 MiB ONE round of <= 256 workgroups with exactly the depth that takes -- see below.  Needed the partial last
+//   * round 4 (max_depth: 18 for the symmetric 16-bit -> same-16-bit single-rounding build, whose 17 / 18-vector tiles fit 256 VGPRs;
+//     16 for the other symmetric same-dtype builds): between 20 and 36 MiB ONE round of <= 256 workgroups with exactly the depth
+//     that takes -- see below.  Needed the partial last
 //     tile on the same schedule as a full one first (bfp_rows_tile_partial): run vector by vector it made every such plan erratic.
 struct RowsPlan { int id, threads, unroll; int64_t tiles; };
-inline RowsPlan rows_plan(int64_t n_vec, bool allow_big, bool allow_deep = false) {
+inline RowsPlan rows_plan(int64_t n_vec, bool allow_big, int max_depth = 0 /* exact-depth one-round plans up to this many vectors per lane */) {
   auto mk = [&](int id, int t, int u) { return RowsPlan{id, t, u, (n_vec + (int64_t)t * u - 1) / ((int64_t)t * u)}; };
   if (n_vec <= ((int64_t)1 << 18)) return mk(0, 512, 1);
   if (n_vec <= ((int64_t)3 << 18)) return mk(1, 128, 2);
@@ -401,14 +402,14 @@ inline RowsPlan rows_plan(int64_t n_vec, bool allow_big, bool allow_deep = false
     // (round 3, tools/tune_bfp TUNE_SET=wg -> profiles/r03_tune_bfp_mid.txt: 512x6 measured 10.4 us on 3072 x 4096 bf16 against 9.35 for
     //  512x16 and ~9.5 on 2560 rows against 7.98 for 128x8: 60 % -> 67-69 % of the roofline at 20-24 MiB)
     if (n_vec <= ((int64_t)5 << 18)) return mk(3, 128, 8);
-    if (allow_deep) {
+    if (max_depth >= 11) {
       // the depth that fills ONE round of 256 workgroups: U = ceil(n_vec / (256 x 512)) for 11 .. 18; id = 100 + U.  Against 512 x 16
       // below 32 MiB: +4 .. +9 points at 2688 - 3584 rows of 4096 bf16 (192 - 224 of 256 CUs busy there), +1 at 3840; against 512 x 2
       // above: +5 .. +10 at 4100 - 4608 rows (profiles/r04_tune_bfp_oneround.txt, r04_mid_shapes.txt).  Deeper needs store groups
       // smaller than the tile (19+ vectors with a whole-tile group spill): 20 vectors in groups of 10 measured +4 in the tuner and
       // -4 in the library (62-64 % at 4700 - 5120 rows against 66-68 % for 512 x 2), 22 / 24 <= +1: not built.
       const int64_t units = (n_vec + ((int64_t)1 << 17) - 1) >> 17;
-      if (units >= 11 && units <= 18) return mk(100 + (int)units, 512, (int)units);
+      if (units >= 11 && units <= max_depth) return mk(100 + (int)units, 512, (int)units);
     }
     if (n_vec <= ((int64_t)1 << 21)) return mk(4, 512, 16);
   }

@@ -413,6 +413,17 @@ def test_exact_depth_one_round_plans_against_the_oracle(dmx, cuda, oracle, rows,
             _check(f"{tag} {dtype} rows={rows}", fn(x), _slabs(fn, x))
 
 
+@pytest.mark.parametrize("rows", [2700, 3001, 3400, 3840])
+def test_exact_depth_plans_float32_against_the_oracle(dmx, cuda, oracle, rows):
+    """the exact-depth plans of the float32 -> float32 build (11 .. 16 vectors of 4 elements per lane): [rows, 2048] float32, whole tiles
+    and a partial last one, BFP16 and a 16-bit-mantissa format (double rounding build)."""
+    xh = _input(rows, F32, seed=13 * rows)
+    x = xh.to(cuda)
+    for wl, B in ((8, 16), (8, 64), (16, 32)):
+        bad = bits_equal(dmx.ops.bfp_qdq(x, wl, B), oracle.bfp_cast(xh, wl, B, -1))
+        assert bad == 0, f"BFP[{wl}|8]{{{B}}} float32 rows={rows}: {bad} elements differ from the oracle"
+
+
 def test_partial_last_tile_special_values_and_the_literal_redo(dmx, cuda, oracle):
     """The predicated partial tile with blocks that cannot take the magic-add path (denormal block maxima, NaN) INSIDE it and just
     before it: the rare literal redo re-reads predicated too."""
