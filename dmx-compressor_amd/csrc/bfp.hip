@@ -29,6 +29,14 @@
 
 #include "bfp_rows.hpp"
 
+// This file is compiled THREE times (build.py: -DDMXQ_EW_PART=1 / 2 / 3): the flat-stream kernel has ~9 tile shapes x 5 block-size cases per
+// (dtype pair, symmetry, rounding path) -- one translation unit took 5-7 minutes, the critical path of the whole build.
+//   part 1: the C entry points, 16-bit -> same 16-bit, the multi-tensor kernels;  part 2: float32 inputs;  part 3: 16-bit -> float32.
+#ifndef DMXQ_EW_PART
+#define DMXQ_EW_PART 0
+#endif
+#define DMXQ_BP(P_) (DMXQ_EW_PART == 0 || DMXQ_EW_PART == (P_))
+
 namespace dmxq {
 
 constexpr int kRowsMaxGrid = 1 << 20;
@@ -178,6 +186,34 @@ extern "C" int dmxq_internal_bfp_cols(const void* in, void* out, int dtype_in, i
 extern "C" int dmxq_internal_bfp_smallinner(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L,
                                             int64_t inner, int64_t B, int wl, int rounding, int symmetric, void* stream);
 
+// parts 2 / 3: the flat-stream / generic dispatch of the other dtype pairs
+extern "C" int dmxq_internal_bfp_flat_f32(const void* in, void* out, int dtype_out, int64_t outer, int64_t L, int64_t inner, int64_t block_size,
+                                          int precision, int rounding, int asym, uint64_t seed, void* stream);
+extern "C" int dmxq_internal_bfp_flat_widen(const void* in, void* out, int dtype_in, int64_t outer, int64_t L, int64_t inner, int64_t block_size,
+                                            int precision, int rounding, int asym, uint64_t seed, void* stream);
+#if DMXQ_BP(2)
+extern "C" int dmxq_internal_bfp_flat_f32(const void* in, void* out, int dtype_out, int64_t outer, int64_t L, int64_t inner, int64_t block_size,
+                                          int precision, int rounding, int asym, uint64_t seed, void* stream) {
+  using namespace dmxq;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype_out == DMXQ_F32) return dispatch_mode<DMXQ_F32, DMXQ_F32>(in, out, outer, L, inner, block_size, precision, rounding, asym != 0, seed, s);
+  if (dtype_out == DMXQ_BF16) return dispatch_mode<DMXQ_F32, DMXQ_BF16>(in, out, outer, L, inner, block_size, precision, rounding, asym != 0, seed, s);
+  if (dtype_out == DMXQ_F16) return dispatch_mode<DMXQ_F32, DMXQ_F16>(in, out, outer, L, inner, block_size, precision, rounding, asym != 0, seed, s);
+  return DMXQ_ERR_BAD_ARG;
+}
+#endif
+#if DMXQ_BP(3)
+extern "C" int dmxq_internal_bfp_flat_widen(const void* in, void* out, int dtype_in, int64_t outer, int64_t L, int64_t inner, int64_t block_size,
+                                            int precision, int rounding, int asym, uint64_t seed, void* stream) {
+  using namespace dmxq;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype_in == DMXQ_BF16) return dispatch_mode<DMXQ_BF16, DMXQ_F32>(in, out, outer, L, inner, block_size, precision, rounding, asym != 0, seed, s);
+  if (dtype_in == DMXQ_F16) return dispatch_mode<DMXQ_F16, DMXQ_F32>(in, out, outer, L, inner, block_size, precision, rounding, asym != 0, seed, s);
+  return DMXQ_ERR_BAD_ARG;
+}
+#endif
+
+#if DMXQ_BP(1)
 extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L,
                             int64_t inner, int64_t block_size, int precision, int rounding, int symmetric,
                             uint64_t seed, void* stream) {
@@ -226,12 +262,9 @@ extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_o
     return dispatch_mode<I_, O_>(in, out, outer, L, inner, block_size, precision, rounding, asym, seed, s);
   DMXQ_DT(DMXQ_BF16, DMXQ_BF16)
   DMXQ_DT(DMXQ_F16, DMXQ_F16)
-  DMXQ_DT(DMXQ_F32, DMXQ_F32)
-  DMXQ_DT(DMXQ_BF16, DMXQ_F32)
-  DMXQ_DT(DMXQ_F16, DMXQ_F32)
-  DMXQ_DT(DMXQ_F32, DMXQ_BF16)
-  DMXQ_DT(DMXQ_F32, DMXQ_F16)
 #undef DMXQ_DT
+  if (dtype_in == DMXQ_F32) return dmxq_internal_bfp_flat_f32(in, out, dtype_out, outer, L, inner, block_size, precision, rounding, asym ? 1 : 0, seed, stream);
+  if (dtype_out == DMXQ_F32) return dmxq_internal_bfp_flat_widen(in, out, dtype_in, outer, L, inner, block_size, precision, rounding, asym ? 1 : 0, seed, stream);
   return DMXQ_ERR_BAD_ARG;
 }
 
@@ -330,7 +363,7 @@ extern "C" int dmxq_bfp_qdq_describe(int dtype_in, int dtype_out, int64_t outer,
   if (inner == 1 && L % block_size == 0 && pow2 && block_size >= epl && block_size <= 64 * epl && aligned) {
     const bool nearest = rounding == DMXQ_ROUND_NEAREST && precision <= 20;
     const bool single = nearest && ((dtype_in == DMXQ_BF16 && precision <= 14) || (dtype_in == DMXQ_F16 && precision <= 11));
-    const RowsPlan pl = rows_plan(n / epl, nearest);
+    const RowsPlan pl = rows_plan(n / epl, nearest, (nearest && symmetric && dtype_in == dtype_out) ? (single ? 18 : 16) : 0);
     const int64_t grid = pl.tiles < kRowsMaxGrid ? pl.tiles : kRowsMaxGrid;
     snprintf(buf, (size_t)buf_len, "dmxq::bfp_rows_kernel<%s,%s,%s,%s,%s> tile %dx%d vectors, grid %lld, nt loads+stores",
              dn[dtype_in], dn[dtype_out], nearest ? "nearest" : rn[rounding], symmetric ? "sym" : "asym",
@@ -341,3 +374,4 @@ extern "C" int dmxq_bfp_qdq_describe(int dtype_in, int dtype_out, int64_t outer,
   snprintf(buf, (size_t)buf_len, "%s", inner == 1 ? "dmxq::bfp_urows_kernel (ragged / unaligned rows)" : "dmxq::bfp_cols_kernel or bfp_generic_kernel (blocks along a strided dim)");
   return DMXQ_OK;
 }
+#endif  // DMXQ_BP(1)
