@@ -301,6 +301,38 @@ def test_init_gate_every_workgroup_counts_streams_capture_and_fallbacks(dmx, cud
     assert bits_equal(mn, omn) == 0 and bits_equal(mx, omx) == 0
 
 
+def test_init_gate_from_concurrent_host_threads(dmx, cuda, oracle):
+    """take_gate (csrc/reduce.hip) hands out flag slots and epochs under a mutex: four host threads, each on its own stream, issue
+    reductions at the same time (both bindings release the GIL inside the call); every result equals the oracle's."""
+    import threading
+    xs = [make("heavy", (1024, 2048), seed=300 + i, dtype=BF16) for i in range(4)]
+    want = [(oracle.group_minmax(x, 0, 128), oracle.channel_maxabs(x, -1)) for x in xs]
+    dx = [x.to(cuda) for x in xs]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(cuda)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(150):
+                    mn, mx = dmx.ops.group_minmax(dx[i], 0, 128)
+                    am = dmx.ops.channel_maxabs(dx[i], -1)
+                st.synchronize()
+                if bits_equal(mn, want[i][0][0]) or bits_equal(mx, want[i][0][1]) or bits_equal(am, want[i][1]):
+                    errors.append(f"thread {i}: result differs from the oracle")
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {i}: {type(e).__name__}: {e}")
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
 # ------------------------------------------------------------------------------------------------ unary modules as a table (csrc/lut16.hip)
 _FUNC64 = {
     "gelu": lambda v: v * 0.5 * torch.special.erfc(-v * 0.7071067811865476),
