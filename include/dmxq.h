@@ -7,7 +7,11 @@
  * (= one kernel launch) handles a whole tensor.
  *
  * Conventions (all entry points):
- *   - plain C: raw DEVICE pointers + explicit 64-bit sizes, no torch types, no global state, never throws;
+ *   - plain C: raw DEVICE pointers + explicit 64-bit sizes, no torch types, never throws, no state for the caller to manage
+ *     (the reductions -- dmxq_group_minmax, dmxq_channel_maxabs, dmxq_histc -- keep 64 KiB of flag words per device, allocated on
+ *     first use and never freed: the kernel's first workgroup initialises the outputs and the others wait for its flag, instead
+ *     of a fill launch in front of every call; csrc/reduce.hip "init gate".  While `stream` is being captured into a graph they
+ *     use the fill launch, so a captured call is replayable);
  *   - caller-allocated outputs (the reference allocates with zeros_like and returns a new tensor,
  *     quant_cuda.cpp:116-139 — the host mirror keeps that ownership contract above this ABI);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are asynchronous;
