@@ -90,6 +90,12 @@ __global__ __launch_bounds__(T) void minmax_tile(const void* __restrict__ in, in
   const int tile = blockIdx.x, g = tile / tiles_per_group;
   const int64_t base = (int64_t)tile * T * U + threadIdx.x;
   unsigned* flag = cnt + 1024 + (epoch & 63u);
+  if (FIN == 9 && tile == 0) {   // FIN 9: the identities go out FIRST, the data loads right behind them; the flag follows once only the loads are outstanding
+    for (int i = threadIdx.x; i < n_groups; i += T) {
+      __hip_atomic_store(&mn[i], INFINITY, __ATOMIC_RELAXED, AGENT);
+      __hip_atomic_store(&mx[i], -INFINITY, __ATOMIC_RELAXED, AGENT);
+    }
+  }
   if (FIN == 8 && tile == 0) {
     for (int i = threadIdx.x; i < n_groups; i += T) {
       __hip_atomic_store(&mn[i], INFINITY, __ATOMIC_RELAXED, AGENT);
@@ -102,8 +108,14 @@ __global__ __launch_bounds__(T) void minmax_tile(const void* __restrict__ in, in
   u32x4 raw[U];
 #pragma unroll
   for (int u = 0; u < U; u++) raw[u] = __builtin_nontemporal_load((const u32x4*)in + (base + (int64_t)u * T < n_vec ? base + (int64_t)u * T : n_vec - 1));
+  if (FIN == 9 && tile == 0) {
+    static_assert(U == 16 || FIN != 9, "the wait below counts the data loads");
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the stores in front of the 16 data loads are acknowledged
+    __builtin_amdgcn_s_barrier();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, AGENT);
+  }
   unsigned seen = 0;
-  if (FIN == 8 && threadIdx.x == 0) seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, AGENT);   // issued behind the data loads
+  if ((FIN == 8 || FIN == 9) && threadIdx.x == 0) seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, AGENT);   // issued behind the data loads
   float lo, hi;
   lane_minmax<U, PK>(raw, lo, hi);
 #pragma unroll
@@ -119,7 +131,7 @@ __global__ __launch_bounds__(T) void minmax_tile(const void* __restrict__ in, in
 #pragma unroll
   for (int o = T / 128; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
   if (FIN == 0) { if (threadIdx.x == 0) { atomic_min_f(&mn[g], lo); atomic_max_f(&mx[g], hi); } return; }
-  if (FIN == 8) {
+  if (FIN == 8 || FIN == 9) {
     if (threadIdx.x == 0) {
       while (seen != epoch) seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, AGENT);
       atomic_min_f(&mn[g], lo); atomic_max_f(&mx[g], hi);
@@ -297,7 +309,7 @@ int main(int argc, char** argv) {
   CK(hipMemset(cnt, 0, 65536 * 4));
   hipStream_t st; CK(hipStreamCreate(&st));
   std::vector<Variant> vs;
-  static const char* fin_name[] = {"fill+atomics", "ticket __threadfence (round 2)", "partial-only", "", "LIGHT ticket", "ticket acq_rel atomic", "LIGHT ticket 2-level (16 x 16)", "ticket, no ordering (timing only)", "SELF-INIT: wg 0 fills + epoch flag read behind the loads"};
+  static const char* fin_name[] = {"fill+atomics", "ticket __threadfence (round 2)", "partial-only", "", "LIGHT ticket", "ticket acq_rel atomic", "LIGHT ticket 2-level (16 x 16)", "ticket, no ordering (timing only)", "SELF-INIT: wg 0 fills + epoch flag read behind the loads", "SELF-INIT, wg 0: stores, loads, vmcnt(16), flag"};
 #define ADD_READ(T, U) vs.push_back({"read        T" #T " U" #U, [=](const void* i, hipStream_t q) { \
     hipLaunchKernelGGL((read_only<T, U>), dim3((unsigned)((n_vec + T * U - 1) / (T * U))), dim3(T), 0, q, i, n_vec, sink); }, {}})
 #define ADD_MM(T, U, FIN, G, PK) vs.push_back({std::string("minmax G" #G " T" #T " U" #U " ") + (PK ? "pk16 " : "f32  ") + fin_name[FIN], [=](const void* i, hipStream_t q) { \
@@ -311,7 +323,7 @@ int main(int argc, char** argv) {
   ADD_MM(512, 16, 0, 1, 0); ADD_MM(512, 16, 2, 1, 0); ADD_MM(512, 16, 2, 1, 1); ADD_MM(512, 16, 1, 1, 0); ADD_MM(512, 16, 5, 1, 0); ADD_MM(512, 16, 4, 1, 0);
   ADD_MM(512, 16, 7, 1, 0); ADD_MM(512, 16, 6, 1, 0); ADD_MM(512, 16, 6, 1, 1); ADD_MM(512, 16, 4, 1, 1);
   ADD_MM(512, 16, 0, 32, 0); ADD_MM(512, 16, 2, 32, 0); ADD_MM(512, 16, 4, 32, 0); ADD_MM(512, 16, 4, 32, 1); ADD_MM(512, 16, 5, 32, 0);
-  ADD_MM(512, 16, 8, 1, 1); ADD_MM(512, 16, 8, 32, 1); ADD_MM(512, 16, 8, 1, 0);
+  ADD_MM(512, 16, 8, 1, 1); ADD_MM(512, 16, 8, 32, 1); ADD_MM(512, 16, 8, 1, 0); ADD_MM(512, 16, 9, 1, 1); ADD_MM(512, 16, 9, 32, 1); ADD_MM(512, 16, 2, 32, 1);
   ADD_MM(256, 16, 2, 1, 1); ADD_MM(256, 16, 6, 1, 1); ADD_MM(256, 16, 4, 32, 1); ADD_MM(256, 8, 2, 1, 1); ADD_MM(1024, 8, 4, 32, 1); ADD_MM(1024, 8, 6, 1, 1);
   ADD_MA(16, 8, 0, 0); ADD_MA(16, 8, 2, 0); ADD_MA(16, 8, 2, 1); ADD_MA(16, 8, 4, 0); ADD_MA(16, 8, 4, 1);
   ADD_MA(16, 8, 8, 1); ADD_MA(16, 8, 8, 0);
