@@ -437,3 +437,29 @@ def test_one_front_end_two_bindings_same_raw_schema(dmx):
         got = list(inspect.signature(getattr(B, name)).parameters)
         assert got == want, (name, got, want)
     assert not os.path.exists(os.path.join(root, "dmx-compressor_amd", "_ops_ctypes.py"))
+
+
+def test_rows_plan_size_classes_through_describe():
+    """csrc/common.hpp rows_plan, without a GPU (dmxq_bfp_qdq_describe launches nothing): from 20 to 36 MiB the symmetric 16-bit ->
+    same-16-bit build runs ONE round of <= 256 workgroups whose depth is ceil(n_vec / 2^17) (round 4); the float32 build up to depth
+    16; asymmetric / widening builds keep 512 x 16 and the multi-round 512 x 2."""
+    import ctypes
+    import re
+    from dmx_compressor_amd import _lib
+    L = _lib.lib()
+    buf = ctypes.create_string_buffer(256)
+
+    def plan(dt_in, dt_out, rows, cols, sym=1):
+        assert L.dmxq_bfp_qdq_describe(dt_in, dt_out, rows, cols, 1, 16, 8, _lib.ROUND_NEAREST, sym, 1, buf, 256) == _lib.OK
+        m = re.search(r"tile (\d+)x(\d+) vectors, grid (\d+)", buf.value.decode())
+        return int(m.group(1)), int(m.group(2)), int(m.group(3))
+
+    for rows in range(2561, 4609, 37):
+        t, u, grid = plan(_lib.BF16, _lib.BF16, rows, 4096)
+        assert (t, u) == (512, -(-rows // 256)) and grid <= 256 and grid * 512 * u >= rows * 512, (rows, t, u, grid)
+    assert plan(_lib.BF16, _lib.BF16, 2560, 4096)[:2] == (128, 8)
+    assert plan(_lib.BF16, _lib.BF16, 4609, 4096)[:2] == (512, 2)
+    assert plan(_lib.F16, _lib.F16, 4300, 4096)[:2] == (512, 17)
+    assert plan(_lib.F32, _lib.F32, 3072, 2048)[:2] == (512, 12) and plan(_lib.F32, _lib.F32, 4200, 2048)[:2] == (512, 2)
+    assert plan(_lib.BF16, _lib.BF16, 3072, 4096, sym=0)[:2] == (512, 16) and plan(_lib.BF16, _lib.BF16, 4300, 4096, sym=0)[:2] == (512, 2)
+    assert plan(_lib.BF16, _lib.F32, 1400, 4096)[:2] == (512, 16)   # widening: lane-vectors of 4 elements, no exact-depth build
