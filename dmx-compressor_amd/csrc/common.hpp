@@ -384,7 +384,7 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
 // (profiles/r02_tune_bfp_sweep.txt), 256 CUs:
 //   * up to 32 MiB of input the best shape keeps the WHOLE tensor in flight in one round of <= 2 workgroups per CU
 //     (every CU reads its share, computes, writes it: the phases stay in lockstep and HBM sees pure read bursts
-//     followed by pure write bursts): 512x1 (<= 4 MiB), 128x2 (<= 12 MiB: many small workgroups ramp fastest),
+//     followed by pure write bursts): 512x1 (<= 4 MiB), 128x2 (<= 14 MiB: many small workgroups ramp fastest),
 //     512x4 (<= 16 MiB), 128x8 (<= 20 MiB), 512x16 (<= 32 MiB: the 4096x4096 bf16 headline tensor, 256 tiles);
 //   * beyond that several rounds per CU are needed anyway, and small 512x2 tiles (4 resident workgroups per CU that
 //     desynchronise, so reads of one overlap writes of another) win: 77-79 % of 8 TB/s vs 68-71 % for 512x16.
@@ -396,7 +396,9 @@ struct RowsPlan { int id, threads, unroll; int64_t tiles; };
 inline RowsPlan rows_plan(int64_t n_vec, bool allow_big, int max_depth = 0 /* exact-depth one-round plans up to this many vectors per lane */) {
   auto mk = [&](int id, int t, int u) { return RowsPlan{id, t, u, (n_vec + (int64_t)t * u - 1) / ((int64_t)t * u)}; };
   if (n_vec <= ((int64_t)1 << 18)) return mk(0, 512, 1);
-  if (n_vec <= ((int64_t)3 << 18)) return mk(1, 128, 2);
+  // (round 4: 128 x 2 up to 14 MiB instead of 12 -- 1600 / 1792 rows of 4096 bf16: 58.7 / 61.2 % against 50.3 / 56.1 % for 512 x 4; at 1920
+  //  rows 512 x 4 leads 61.0 to 55.9; exactly fitting one-round depths of 5 .. 8 vectors lose to both: tools/tune_bfp -DTUNE_SMALLFIT)
+  if (n_vec <= ((int64_t)7 << 17)) return mk(1, 128, 2);
   if (allow_big) {  // (the any-rounding build would spill at many vectors per lane: it goes straight to 512x2)
     if (n_vec <= ((int64_t)1 << 20)) return mk(2, 512, 4);
     // (round 3, tools/tune_bfp TUNE_SET=wg -> profiles/r03_tune_bfp_mid.txt: 512x6 measured 10.4 us on 3072 x 4096 bf16 against 9.35 for

@@ -80,7 +80,11 @@ int main(int argc, char** argv) {
 #define ADD_BFPB(ASYM_, LPB_, LPBC_) vs.push_back({"bfp  512x16 " #ASYM_ " lpb" #LPB_ " lpbc" #LPBC_, [=](const void* i, void* o, hipStream_t q) { \
     int g = (int)((n_vec + (int64_t)512 * 16 - 1) / ((int64_t)512 * 16)); \
     hipLaunchKernelGGL((bfp_rows_kernel<DMXQ_BF16, DMXQ_BF16, DMXQ_ROUND_NEAREST, ASYM_, 16, 3, 512, 2, 16, 16, LPBC_>), dim3(g), dim3(512), 0, q, i, o, n_vec, LPB_, 8, 2, 0ull); }, {}})
-#ifdef TUNE_MIN   // -DTUNE_MIN: five variants only (compiles in a minute)
+#ifdef TUNE_SMALLFIT   // -DTUNE_SMALLFIT: 9-16 MiB, the product's 128 x 2 / 512 x 4 against one round of exactly fitting depth
+  ADD_COPY(4, 7, 512, 0); ADD_BFPG(2, 3, 128, 0, 2, 2); ADD_BFPG(4, 3, 512, 0, 2, 4); ADD_BFPG(3, 3, 512, 0, 2, 3);
+  ADD_BFPG(5, 3, 512, 0, 2, 5); ADD_BFPG(6, 3, 512, 0, 2, 6); ADD_BFPG(7, 3, 512, 0, 2, 7); ADD_BFPG(8, 3, 512, 0, 2, 8);
+  ADD_BFPG(10, 3, 256, 0, 2, 10); ADD_BFPG(12, 3, 256, 0, 2, 12); ADD_BFPG(14, 3, 256, 0, 2, 14); ADD_BFPG(16, 3, 256, 0, 2, 16);
+#elif defined(TUNE_MIN)   // -DTUNE_MIN: five variants only (compiles in a minute)
   ADD_COPY(16, 7, 512, 0); ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPG(17, 3, 512, 0, 2, 17); ADD_BFPG(18, 3, 512, 0, 2, 18);
 #else
   if (getenv("TUNE_SET") && std::string(getenv("TUNE_SET")) == "blocks") {
