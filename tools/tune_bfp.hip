@@ -80,7 +80,14 @@ int main(int argc, char** argv) {
 #define ADD_BFPB(ASYM_, LPB_, LPBC_) vs.push_back({"bfp  512x16 " #ASYM_ " lpb" #LPB_ " lpbc" #LPBC_, [=](const void* i, void* o, hipStream_t q) { \
     int g = (int)((n_vec + (int64_t)512 * 16 - 1) / ((int64_t)512 * 16)); \
     hipLaunchKernelGGL((bfp_rows_kernel<DMXQ_BF16, DMXQ_BF16, DMXQ_ROUND_NEAREST, ASYM_, 16, 3, 512, 2, 16, 16, LPBC_>), dim3(g), dim3(512), 0, q, i, o, n_vec, LPB_, 8, 2, 0ull); }, {}})
-#ifdef TUNE_SMALLFIT   // -DTUNE_SMALLFIT: 9-16 MiB, the product's 128 x 2 / 512 x 4 against one round of exactly fitting depth
+#ifdef TUNE_RT   // -DTUNE_RT: the run-time-rounding build (literal path, FAST = 4) at deeper tiles; argv[5] = rounding code (1 down, 3 stochastic)
+  const int rt_round = argc > 5 ? atoi(argv[5]) : 1;
+#define ADD_RT(U, T, GR) vs.push_back({"bfp-rt U" #U " T" #T " grp" #GR, [=](const void* i, void* o, hipStream_t q) { \
+    int g = (int)((n_vec + (int64_t)T * U - 1) / ((int64_t)T * U)); \
+    hipLaunchKernelGGL((bfp_rows_kernel<DMXQ_BF16, DMXQ_BF16, kRuntimeRounding, false, U, 3, T, 4, GR>), dim3(g), dim3(T), 0, q, i, o, n_vec, 2, 8, rt_round, 1234ull); }, {}})
+  ADD_COPY(16, 7, 512, 0); ADD_COPY(2, 7, 512, 0);
+  ADD_RT(2, 512, 2); ADD_RT(4, 512, 4); ADD_RT(8, 512, 4); ADD_RT(12, 512, 4); ADD_RT(16, 512, 2); ADD_RT(16, 512, 4); ADD_RT(16, 512, 8); ADD_RT(8, 256, 4); ADD_RT(16, 256, 4);
+#elif defined(TUNE_SMALLFIT)   // -DTUNE_SMALLFIT: 9-16 MiB, the product's 128 x 2 / 512 x 4 against one round of exactly fitting depth
   ADD_COPY(4, 7, 512, 0); ADD_BFPG(2, 3, 128, 0, 2, 2); ADD_BFPG(4, 3, 512, 0, 2, 4); ADD_BFPG(3, 3, 512, 0, 2, 3);
   ADD_BFPG(5, 3, 512, 0, 2, 5); ADD_BFPG(6, 3, 512, 0, 2, 6); ADD_BFPG(7, 3, 512, 0, 2, 7); ADD_BFPG(8, 3, 512, 0, 2, 8);
   ADD_BFPG(10, 3, 256, 0, 2, 10); ADD_BFPG(12, 3, 256, 0, 2, 12); ADD_BFPG(14, 3, 256, 0, 2, 14); ADD_BFPG(16, 3, 256, 0, 2, 16);
