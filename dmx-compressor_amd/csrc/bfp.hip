@@ -113,7 +113,7 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
 #define DMXQ_ROWS_GEOM(F_)                                                                         \
   do {                                                                                             \
     /* the exact-depth one-round plans (rows_plan): symmetric same-dtype builds; 17 / 18 vectors only where they fit 256 VGPRs */ \
-    constexpr int kDepth = ((F_) != 4 && DTO == DTI && !ASYM) ? ((F_) == 2 ? 18 : 16) : 0;         \
+    constexpr int kDepth = ((F_) != 4 && DTO == DTI && !ASYM) ? ((F_) == 2 ? 20 : 16) : 0;         \
     const RowsPlan pl = rows_plan(n_vec, (F_) != 4, kDepth);                                       \
     if constexpr (kDepth >= 16) {                                                                  \
       if (pl.id == 111) { DMXQ_ROWS(512, 11, F_); break; }                                         \
@@ -126,6 +126,9 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
     if constexpr (kDepth >= 18) {                                                                  \
       if (pl.id == 117) { DMXQ_ROWS(512, 17, F_); break; }                                         \
       if (pl.id == 118) { DMXQ_ROWS(512, 18, F_); break; }                                         \
+      /* 19 / 20 vectors: the compact kernel (results in place of the raw vectors), bfp_rows.hpp */ \
+      if (pl.id == 119) { DMXQ_LAUNCH((bfp_rows_compact_kernel<DTI, 19, 512, 19>), dim3((unsigned)pl.tiles), dim3(512), 0, s, in, out, n_vec, lpb, wl); break; } \
+      if (pl.id == 120) { DMXQ_LAUNCH((bfp_rows_compact_kernel<DTI, 20, 512, 10>), dim3((unsigned)pl.tiles), dim3(512), 0, s, in, out, n_vec, lpb, wl); break; } \
     }                                                                                              \
     if constexpr ((F_) != 4) {                                                                     \
       if (pl.id == 2) { DMXQ_ROWS(512, 4, F_); break; }                                            \
@@ -363,7 +366,7 @@ extern "C" int dmxq_bfp_qdq_describe(int dtype_in, int dtype_out, int64_t outer,
   if (inner == 1 && L % block_size == 0 && pow2 && block_size >= epl && block_size <= 64 * epl && aligned) {
     const bool nearest = rounding == DMXQ_ROUND_NEAREST && precision <= 20;
     const bool single = nearest && ((dtype_in == DMXQ_BF16 && precision <= 14) || (dtype_in == DMXQ_F16 && precision <= 11));
-    const RowsPlan pl = rows_plan(n / epl, nearest, (nearest && symmetric && dtype_in == dtype_out) ? (single ? 18 : 16) : 0);
+    const RowsPlan pl = rows_plan(n / epl, nearest, (nearest && symmetric && dtype_in == dtype_out) ? (single ? 20 : 16) : 0);
     const int64_t grid = pl.tiles < kRowsMaxGrid ? pl.tiles : kRowsMaxGrid;
     snprintf(buf, (size_t)buf_len, "dmxq::bfp_rows_kernel<%s,%s,%s,%s,%s> tile %dx%d vectors, grid %lld, nt loads+stores",
              dn[dtype_in], dn[dtype_out], nearest ? "nearest" : rn[rounding], symmetric ? "sym" : "asym",

@@ -250,6 +250,82 @@ __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restric
 #undef DMXQ_TILE_LOOP
 }
 
+// COMPACT form of the flat-stream kernel for the deepest one-round classes (19+ vectors per lane; symmetric 16-bit -> same 16-bit,
+// nearest-even single rounding): every result overwrites the raw vector it came from, so a lane holds 4 x UNROLL registers of tile
+// data instead of the ~14 per vector of bfp_rows_tile (whose whole-tile store group keeps raw AND result vectors alive: 229 VGPRs at 16
+// vectors, scratch from 19).  A kernel of its own: giving bfp_rows_tile this form costs the 32 MiB launch 9 % (see bfp_rows_tile_partial).
+template <int DT, int UNROLL, int THREADS, int GROUP, int LPBC>
+__device__ __forceinline__ void bfp_rows_tile_compact(const char* __restrict__ src, char* __restrict__ dst, int64_t v0, int lpb_rt, int wl) {
+  static_assert(UNROLL % GROUP == 0 && DT != DMXQ_F32, "16-bit tensors; GROUP divides UNROLL");
+  constexpr int EPL = 8;
+  const int lpb = LPBC > 0 ? LPBC : lpb_rt;
+  const uint32_t lane = threadIdx.x * 16u;
+  u32x4 raw[UNROLL];
+#pragma unroll
+  for (int u = 0; u < UNROLL; u++) raw[u] = load_rawv<16>(src + u * (THREADS * 16), lane);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < UNROLL; g += GROUP) {
+    uint32_t mb[GROUP];
+    bool all_fast = true;
+#pragma unroll
+    for (int u = 0; u < GROUP; u++) {
+      mb[u] = group_max_u32(absmax_bits<DT>(raw[g + u]), lpb);
+      all_fast = all_fast && bfp_fast_ok(mb[u], wl);
+    }
+#pragma unroll
+    for (int u = 0; u < GROUP; u++) {
+      const OutVec<DT, EPL> o = bfp_rows_vector<DT, DT, DMXQ_ROUND_NEAREST, false, 2, true, EPL>(raw[g + u], mb[u], v0 + (int64_t)(g + u) * THREADS, wl,
+                                                                                             DMXQ_ROUND_NEAREST, false, 0ull);
+      raw[g + u] = u32x4{o.w[0], o.w[1], o.w[2], o.w[3]};
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (__builtin_amdgcn_ballot_w64(!all_fast) != 0ull) {  // rare: literal bit path from a fresh read (see bfp_rows_tile)
+#pragma unroll
+      for (int u = 0; u < GROUP; u++) {
+        const u32x4 r = load_rawv<16>(src + (g + u) * (THREADS * 16), lane);
+        const uint32_t m = group_max_u32(absmax_bits<DT>(r), lpb);
+        if (__builtin_amdgcn_ballot_w64(!bfp_fast_ok(m, wl)) != 0ull) {
+          const OutVec<DT, EPL> o = bfp_rows_vector<DT, DT, DMXQ_ROUND_NEAREST, false, 2, false, EPL>(r, m, v0 + (int64_t)(g + u) * THREADS, wl,
+                                                                                                  DMXQ_ROUND_NEAREST, false, 0ull);
+          raw[g + u] = u32x4{o.w[0], o.w[1], o.w[2], o.w[3]};
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < GROUP; u++) __builtin_nontemporal_store(raw[g + u], (u32x4*)(dst + (g + u) * (THREADS * 16) + lane));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int DT, int UNROLL, int THREADS, int GROUP>
+__global__ __launch_bounds__(THREADS) void bfp_rows_compact_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t n_vec,
+                                                                  int lpb_arg, int wl) {
+  constexpr int64_t TILE = (int64_t)THREADS * UNROLL;
+  constexpr int MODE = kRowsNtLoad | kRowsNtStore;
+  const int lpb = __builtin_amdgcn_readfirstlane(lpb_arg);
+  const int64_t tile = blockIdx.x;   // one tile per workgroup: the host launches exactly ceil(n_vec / TILE) of them
+  const char* src = (const char*)in + tile * (TILE * 16);
+  char* dst = (char*)out + tile * (TILE * 16);
+  const int64_t v0 = tile * TILE + threadIdx.x;
+  const bool full = (tile + 1) * TILE <= n_vec;
+#define DMXQ_COMPACT(L_)                                                                                                              \
+  do {                                                                                                                                \
+    if (full) bfp_rows_tile_compact<DT, UNROLL, THREADS, GROUP, L_>(src, dst, v0, lpb, wl);                                             \
+    else bfp_rows_tile_partial<DT, DT, DMXQ_ROUND_NEAREST, false, UNROLL, MODE, THREADS, 2, GROUP, 16, L_>(src, dst, n_vec - v0, v0, lpb, wl, \
+                                                                                                         DMXQ_ROUND_NEAREST, false, 0ull); \
+  } while (0)
+  switch (lpb) {
+    case 2: DMXQ_COMPACT(2); break;
+    case 4: DMXQ_COMPACT(4); break;
+    case 8: DMXQ_COMPACT(8); break;
+    case 16: DMXQ_COMPACT(16); break;
+    default: DMXQ_COMPACT(0); break;
+  }
+#undef DMXQ_COMPACT
+}
+
 // Multi-tensor form: up to kMultiMax flat tensors in ONE launch (small weights are launch-bound one by one: an empty
 // launch costs ~1.6 us, a 768x768 bf16 tensor streams in 0.4 us).  The tile space of all tensors is concatenated;
 // a workgroup finds its tensor with a scalar search over the descriptors (kernel arguments: s_load, no memory traffic).

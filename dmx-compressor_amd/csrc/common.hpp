@@ -405,11 +405,13 @@ inline RowsPlan rows_plan(int64_t n_vec, bool allow_big, int max_depth = 0 /* ex
     //  512x16 and ~9.5 on 2560 rows against 7.98 for 128x8: 60 % -> 67-69 % of the roofline at 20-24 MiB)
     if (n_vec <= ((int64_t)5 << 18)) return mk(3, 128, 8);
     if (max_depth >= 11) {
-      // the depth that fills ONE round of 256 workgroups: U = ceil(n_vec / (256 x 512)) for 11 .. 18; id = 100 + U.  Against 512 x 16
+      // the depth that fills ONE round of 256 workgroups: U = ceil(n_vec / (256 x 512)) for 11 .. 20 (19 / 20: the compact kernel,
+      // bfp_rows_compact_kernel); id = 100 + U.  Against 512 x 16
       // below 32 MiB: +4 .. +9 points at 2688 - 3584 rows of 4096 bf16 (192 - 224 of 256 CUs busy there), +1 at 3840; against 512 x 2
-      // above: +5 .. +10 at 4100 - 4608 rows (profiles/r04_tune_bfp_oneround.txt, r04_mid_shapes.txt).  Deeper needs store groups
-      // smaller than the tile (19+ vectors with a whole-tile group spill): 20 vectors in groups of 10 measured +4 in the tuner and
-      // -4 in the library (62-64 % at 4700 - 5120 rows against 66-68 % for 512 x 2), 22 / 24 <= +1: not built.
+      // above: +5 .. +10 at 4100 - 4608 rows (profiles/r04_tune_bfp_oneround.txt, r04_mid_shapes.txt).  19+ vectors spill in
+      // bfp_rows_tile (whole-tile store groups; 20 vectors in groups of 10: 62-64 % at 4700 - 5120 rows against 66-68 % for 512 x 2);
+      // the COMPACT kernel runs 19 vectors at 74-75 % (4700 / 4864 rows, +8) and 20 in groups of 10 at 71-72 % (5120 rows, +4);
+      // 22 / 24 vectors gain 1-2.6 points: not built (profiles/r04_tune_bfp_compact.txt).
       const int64_t units = (n_vec + ((int64_t)1 << 17) - 1) >> 17;
       if (units >= 11 && units <= max_depth) return mk(100 + (int)units, 512, (int)units);
     }

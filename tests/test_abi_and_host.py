@@ -440,7 +440,7 @@ def test_one_front_end_two_bindings_same_raw_schema(dmx):
 
 
 def test_rows_plan_size_classes_through_describe():
-    """csrc/common.hpp rows_plan, without a GPU (dmxq_bfp_qdq_describe launches nothing): from 20 to 36 MiB the symmetric 16-bit ->
+    """csrc/common.hpp rows_plan, without a GPU (dmxq_bfp_qdq_describe launches nothing): from 20 to 40 MiB the symmetric 16-bit ->
     same-16-bit build runs ONE round of <= 256 workgroups whose depth is ceil(n_vec / 2^17) (round 4); the float32 build up to depth
     16; asymmetric / widening builds keep 512 x 16 and the multi-round 512 x 2."""
     import ctypes
@@ -454,11 +454,11 @@ def test_rows_plan_size_classes_through_describe():
         m = re.search(r"tile (\d+)x(\d+) vectors, grid (\d+)", buf.value.decode())
         return int(m.group(1)), int(m.group(2)), int(m.group(3))
 
-    for rows in range(2561, 4609, 37):
+    for rows in range(2561, 5121, 37):
         t, u, grid = plan(_lib.BF16, _lib.BF16, rows, 4096)
         assert (t, u) == (512, -(-rows // 256)) and grid <= 256 and grid * 512 * u >= rows * 512, (rows, t, u, grid)
     assert plan(_lib.BF16, _lib.BF16, 2560, 4096)[:2] == (128, 8)
-    assert plan(_lib.BF16, _lib.BF16, 4609, 4096)[:2] == (512, 2)
+    assert plan(_lib.BF16, _lib.BF16, 5121, 4096)[:2] == (512, 2)
     assert plan(_lib.F16, _lib.F16, 4300, 4096)[:2] == (512, 17)
     assert plan(_lib.F32, _lib.F32, 3072, 2048)[:2] == (512, 12) and plan(_lib.F32, _lib.F32, 4200, 2048)[:2] == (512, 2)
     assert plan(_lib.BF16, _lib.BF16, 3072, 4096, sym=0)[:2] == (512, 16) and plan(_lib.BF16, _lib.BF16, 4300, 4096, sym=0)[:2] == (512, 2)

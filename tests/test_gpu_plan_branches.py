@@ -391,11 +391,11 @@ def test_hot_kernel_tile_plans(dmx, cuda, rows, dtype):
         _check(f"{tag} {dtype} rows={rows}", fn(x), _slabs(fn, x))
 
 
-@pytest.mark.parametrize("rows", [2561, 2700, 2816, 2817, 3000, 3100, 3400, 3700, 3950, 4097, 4100, 4352, 4353, 4500, 4608, 4609, 4800])
+@pytest.mark.parametrize("rows", [2561, 2700, 2816, 2817, 3000, 3100, 3400, 3700, 3950, 4097, 4100, 4352, 4353, 4500, 4608, 4609, 4800, 4864, 4865, 5000, 5120, 5121])
 @pytest.mark.parametrize("dtype", [BF16, F16], ids=["bf16", "f16"])
 def test_exact_depth_one_round_plans_against_the_oracle(dmx, cuda, oracle, rows, dtype):
-    """Round 4: 20-40 MiB of a 16-bit tensor run as ONE round of <= 256 workgroups whose depth is exactly what that takes -- 11 .. 18
-    vectors per lane (csrc/common.hpp rows_plan) -- and the last, partial tile of any tensor runs on the
+    """Round 4: 20-40 MiB of a 16-bit tensor run as ONE round of <= 256 workgroups whose depth is exactly what that takes -- 11 .. 20
+    vectors per lane (csrc/common.hpp rows_plan; 19 and 20 through the compact kernel, results in place of the raw vectors) -- and the last, partial tile of any tensor runs on the
     same schedule with predicated loads and stores (bfp_rows_tile_partial; it used to run vector by vector).  Both sides of class
     boundaries, nearly empty and nearly full last tiles, directly against the CPU oracle; the builds that do NOT take these plans
     (asymmetric, widening, other rounding) on the same tensors through the slab identity."""
@@ -405,7 +405,7 @@ def test_exact_depth_one_round_plans_against_the_oracle(dmx, cuda, oracle, rows,
     for B in (16, 128):
         bad = bits_equal(ops.bfp_qdq(x, 8, B), oracle.bfp_cast(xh, 8, B, -1).to(dtype))
         assert bad == 0, f"BFP[8|8]{{{B}}} {dtype} rows={rows}: {bad} elements differ from the oracle"
-    if rows in (2817, 4100, 4609):
+    if rows in (2817, 4100, 4609, 5000):
         bad = bits_equal(ops.bfp_qdq(x, 4, 32), oracle.bfp_cast(xh, 4, 32, -1).to(dtype))
         assert bad == 0, f"BFP[4|8]{{32}} {dtype} rows={rows}: {bad} elements differ from the oracle"
         for tag, fn in {"asym": lambda t: ops.bfp_qdq(t, 8, 64, symmetric=False), "-> f32": lambda t: ops.bfp_qdq(t, 8, 64, out_dtype=F32),
@@ -440,4 +440,16 @@ def test_partial_last_tile_special_values_and_the_literal_redo(dmx, cuda, oracle
     for B in (16, 64):
         got, want = dmx.ops.bfp_qdq(x, 8, B), oracle.bfp_cast(xh, 8, B, -1).to(BF16)
         # (NaN-aware: which NaN a poisoned block's elements become when narrowed to 16 bits is pinned in test_gpu_bfp.py)
+        assert mismatches_nan_aware(got, want) == 0 and int(torch.isnan(got).sum()) == 2 * B
+    # the compact kernel (19 vectors per lane at 4800 rows): the literal redo inside FULL tiles and in the partial one
+    xh = _input(4800, BF16, seed=6)
+    flat = xh.view(-1)
+    n = flat.numel()
+    for off in (48, 8 * 512 * 19 * 3 + 8 * 512 * 7 + 320, n - 64, n // 2):
+        flat[off - off % 16: off - off % 16 + 16] = torch.tensor([1e-39] * 16).to(BF16)
+    flat[8 * 512 * 19 * 100 + 5] = float("nan")
+    flat[n - 3] = float("inf")
+    x = xh.to(cuda)
+    for B in (16, 64):
+        got, want = dmx.ops.bfp_qdq(x, 8, B), oracle.bfp_cast(xh, 8, B, -1).to(BF16)
         assert mismatches_nan_aware(got, want) == 0 and int(torch.isnan(got).sum()) == 2 * B

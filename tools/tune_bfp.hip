@@ -80,7 +80,13 @@ int main(int argc, char** argv) {
 #define ADD_BFPB(ASYM_, LPB_, LPBC_) vs.push_back({"bfp  512x16 " #ASYM_ " lpb" #LPB_ " lpbc" #LPBC_, [=](const void* i, void* o, hipStream_t q) { \
     int g = (int)((n_vec + (int64_t)512 * 16 - 1) / ((int64_t)512 * 16)); \
     hipLaunchKernelGGL((bfp_rows_kernel<DMXQ_BF16, DMXQ_BF16, DMXQ_ROUND_NEAREST, ASYM_, 16, 3, 512, 2, 16, 16, LPBC_>), dim3(g), dim3(512), 0, q, i, o, n_vec, LPB_, 8, 2, 0ull); }, {}})
-#ifdef TUNE_RT   // -DTUNE_RT: the run-time-rounding build (literal path, FAST = 4) at deeper tiles; argv[5] = rounding code (1 down, 3 stochastic)
+#ifdef TUNE_COMPACT   // -DTUNE_COMPACT: the compact (results in place) one-round kernel at 16 .. 24 vectors per lane against 512 x 2 / 512 x 16 / 17 / 18
+#define ADD_CP(U, GR) vs.push_back({"compact U" #U " T512 grp" #GR, [=](const void* i, void* o, hipStream_t q) { \
+    int g = (int)((n_vec + (int64_t)512 * U - 1) / ((int64_t)512 * U)); \
+    hipLaunchKernelGGL((bfp_rows_compact_kernel<DMXQ_BF16, U, 512, GR>), dim3(g), dim3(512), 0, q, i, o, n_vec, 2, 8); }, {}})
+  ADD_COPY(2, 7, 512, 0); ADD_BFPG(2, 3, 512, 0, 2, 2); ADD_BFPG(16, 3, 512, 0, 2, 16); ADD_BFPG(18, 3, 512, 0, 2, 18);
+  ADD_CP(16, 16); ADD_CP(18, 18); ADD_CP(19, 19); ADD_CP(20, 20); ADD_CP(20, 10); ADD_CP(21, 21); ADD_CP(22, 22); ADD_CP(22, 11); ADD_CP(23, 23); ADD_CP(24, 24); ADD_CP(24, 12);
+#elif defined(TUNE_RT)   // -DTUNE_RT: the run-time-rounding build (literal path, FAST = 4) at deeper tiles; argv[5] = rounding code (1 down, 3 stochastic)
   const int rt_round = argc > 5 ? atoi(argv[5]) : 1;
 #define ADD_RT(U, T, GR) vs.push_back({"bfp-rt U" #U " T" #T " grp" #GR, [=](const void* i, void* o, hipStream_t q) { \
     int g = (int)((n_vec + (int64_t)T * U - 1) / ((int64_t)T * U)); \
