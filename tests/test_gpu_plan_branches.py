@@ -394,6 +394,8 @@ def test_hot_kernel_tile_plans(dmx, cuda, rows, dtype):
 @pytest.mark.parametrize("rows", [2561, 2700, 2816, 2817, 3000, 3100, 3400, 3700, 3950, 4097, 4100, 4352, 4353, 4500, 4608, 4609, 4800, 4864, 4865, 5000, 5120, 5121])
 @pytest.mark.parametrize("dtype", [BF16, F16], ids=["bf16", "f16"])
 def test_exact_depth_one_round_plans_against_the_oracle(dmx, cuda, oracle, rows, dtype):
+    if dtype == F16 and rows not in (2700, 3400, 4100, 4609, 4865, 5120):
+        pytest.skip("float16: one size per kernel family (the bf16 run covers every boundary)")
     """Round 4: 20-40 MiB of a 16-bit tensor run as ONE round of <= 256 workgroups whose depth is exactly what that takes -- 11 .. 20
     vectors per lane (csrc/common.hpp rows_plan; 19 and 20 through the compact kernel, results in place of the raw vectors) -- and the last, partial tile of any tensor runs on the
     same schedule with predicated loads and stores (bfp_rows_tile_partial; it used to run vector by vector).  Both sides of class
