@@ -173,9 +173,29 @@ def _time_cpu(fn, seconds, max_n):
     return best, n
 
 
+def _port_leg_main(argv):
+    """`python bench.py --cpu-port-leg THREADS SECONDS TENSOR.pt` (internal): times the oracle's whole-tensor C port in THIS process,
+    started with OMP_NUM_THREADS / OMP_PROC_BIND / OMP_PLACES in its environment (libgomp reads them when it is loaded: inside the
+    bench process torch has loaded it long before)."""
+    threads, seconds, path = int(argv[0]), float(argv[1]), argv[2]
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+
+    x = torch.load(path)
+    best, n = _time_cpu(lambda: O.bfp_cast(x, PRECISION, BLOCK).to(torch.bfloat16), seconds, 200)
+    print(json.dumps({"best": best, "n": n, "threads": threads}))
+
+
 def cpu_baseline(seconds):
-    """Times the CPU paths on the host cores for the same 4096x4096 bf16 workload (three labelled legs)."""
-    x = (torch.randn(ROWS, COLS, generator=torch.Generator().manual_seed(0))).to(torch.bfloat16)
+    """Times the CPU paths on the host cores for the same 4096x4096 bf16 workload (three labelled legs).  The timed
+    input is the bench's own rotation slot 0 of rank 0 (the counter-generated tensor, tests/_data.py: the same bits on every box);
+    the OpenMP leg runs in a fresh process with its threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores), one thread per
+    physical core -- in-process, with torch's libgomp already initialised and 2 SMT threads per core, the all-cores figure moved
+    between 0.17 and 0.58 Gelements/s from box to box."""
+    import subprocess
+    import tempfile
+
+    x = portable_inputs([slot_seed(0, 0)], ROWS, COLS)[0]
     legs = []
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
     try:
@@ -192,29 +212,35 @@ def cpu_baseline(seconds):
         best, n = _time_cpu(ref_fn, seconds, 50)
         legs.append({"kind": "reference", "value": round(ROWS * COLS / best / 1e9, 5), "unit": "Gelements/s",
                      "cores": torch.get_num_threads(),
-                     "sample": f"{n} full passes over one 4096x4096 bf16 tensor (min {best * 1e3:.1f} ms): reference "
+                     "sample": f"{n} full passes over the bench's slot-0 tensor, 4096x4096 bf16 (min {best * 1e3:.1f} ms): reference "
                                "quant_cpu.block_quantize_nearest per [4096,16] chunk inside the reference's split/cat loop"})
     except Exception as e:  # _ref not built (never on the GPU box: the prebuilt .so travels with the snapshot)
         legs.append({"kind": "reference", "value": None, "error": repr(e)[:200]})
     try:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle as O
-
-        gomp = ctypes.CDLL("libgomp.so.1")
-        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        ncores = max(1, min(ncores, torch.get_num_threads()))
-
-        def port_fn():
-            return O.bfp_cast(x, PRECISION, BLOCK).to(torch.bfloat16)
-
-        for threads, budget in ((ncores, min(4.0, seconds)), (1, min(6.0, seconds))):
-            gomp.omp_set_num_threads(threads)
-            best, n = _time_cpu(port_fn, budget, 200)
-            legs.append({"kind": "port", "value": round(ROWS * COLS / best / 1e9, 5), "unit": "Gelements/s",
-                         "cores": threads,
-                         "sample": f"{n} full passes over one 4096x4096 bf16 tensor (min {best * 1e3:.1f} ms): "
-                                   f"oracle/oracle.c whole-tensor port, OpenMP threads = {threads}"})
-        gomp.omp_set_num_threads(ncores)
+        logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:   # physical cores among the allowed CPUs (one OpenMP thread each)
+            sib = set()
+            for c in (os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else range(logical)):
+                with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                    sib.add(f.read().strip())
+            physical = max(1, len(sib))
+        except OSError:
+            physical = logical
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "x.pt")
+            torch.save(x, path)
+            for threads, budget in ((physical, min(4.0, seconds)), (1, min(6.0, seconds))):
+                env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_DYNAMIC="false")
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-port-leg", str(threads), str(budget), path],
+                                   env=env, capture_output=True, text=True, timeout=600)
+                out = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode != 0 or not out:
+                    raise RuntimeError(f"port leg failed: {r.stderr[-300:]}")
+                d = json.loads(out[-1])
+                legs.append({"kind": "port", "value": round(ROWS * COLS / d["best"] / 1e9, 5), "unit": "Gelements/s", "cores": threads,
+                             "sample": f"{d['n']} full passes over the bench's slot-0 tensor, 4096x4096 bf16 (min {d['best'] * 1e3:.1f} ms): "
+                                       f"oracle/oracle.c whole-tensor port in a fresh process, OpenMP threads = {threads} pinned "
+                                       f"(OMP_PROC_BIND=close, OMP_PLACES=cores; {physical} physical / {logical} logical CPUs allowed)"})
     except Exception as e:
         legs.append({"kind": "port", "value": None, "error": repr(e)[:200]})
     head = next((l for l in legs if l.get("value")), legs[0])
@@ -515,6 +541,21 @@ def main():
         for _ in range(R):
             walls.append(region(poll))
         walls_alt = [region(not poll) for _ in range(R)]
+        # (a') the same regions with 10 K steps (eager launches only): a region carries ~13 us that are not kernel time, 0.65 us per
+        # step at the driver's K = 20 and 0.07 at 200 -- reported side by side, never as `value`
+        walls_10x = []
+        if graph is None and K * 10 * wl.launches_per_step <= 4096:
+            def region_10x():
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(10 * K):
+                    wl.launch(i, sp)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                barrier()
+                return t1 - t0
+            region_10x()
+            walls_10x = [region_10x() for _ in range(max(3, R // 3))]
         # (b) the kernels' own time with HIP events on the launch stream, over R more regions of the same K steps.  A
         # short device-side delay is queued in front of the first event so that the host has finished enqueueing the
         # region before the GPU reaches it: the events then bracket back-to-back kernel execution and not the
@@ -539,6 +580,11 @@ def main():
         barrier()
 
     cdev = "cpu" if args.dist_backend == "gloo" else dev
+    if walls_10x:
+        t10 = torch.tensor(walls_10x, device=cdev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t10, op=dist.ReduceOp.MAX)
+        walls_10x = t10.tolist()
     t = torch.tensor([walls, evs, walls_alt], device=cdev, dtype=torch.float64)
     elems = torch.tensor([float(wl.elems_per_step_rank)], device=cdev, dtype=torch.float64)
     if dist is not None:
@@ -604,6 +650,11 @@ def main():
                        "sync_alt": {"sync": "block" if args.sync == "poll" else "poll",
                                     "ms_per_step": round(statistics.median(walls_alt) * 1e3 / K, 6),
                                     "value": round(total_elems / (statistics.median(walls_alt) / K) / 1e9, 2)},
+                       "at_10x_steps": ({"steps": 10 * K, "ms_per_step": round(statistics.median(walls_10x) * 1e3 / (10 * K), 6),
+                                         "value": round(total_elems / (statistics.median(walls_10x) / (10 * K)) / 1e9, 2),
+                                         "note": "the same eager launches in regions of 10 K steps: the ~13 us a region carries besides "
+                                                 "kernel time weigh a tenth as much; informative, `value` is the K-step figure"}
+                                        if walls_10x else None),
                        "dist_backend": (args.dist_backend + (" (harness-only transport; ranks share GPUs: not a scaling figure)"
                                                              if args.dist_backend == "gloo" else " (RCCL)")) if dist is not None else None,
                        "input": ("tests/_data.py make('heavy', (4096, 4096), seed = 1000 rank + slot, bf16): counter-based, host-generated"
@@ -633,4 +684,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-port-leg":
+        _port_leg_main(sys.argv[2:])
+    else:
+        main()

@@ -20,6 +20,32 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-fast-math"
          "-fgpu-flush-denormals-to-zero" if False else "-fno-gpu-flush-denormals-to-zero"]
 
 
+# Kernels whose hand-issued loads and hand-counted s_waitcnt (asm volatile: invisible to the compiler's waitcnt pass) are only correct while
+# the compiler adds NO vector memory operation of its own, i.e. no scratch (a spill store can retire out of order against the loads on
+# gfx9): checked at build time from the compiler's own resource remarks -- a compiler upgrade or an edit that makes one of them spill
+# fails the build instead of silently reading registers before their data has landed.  source -> substrings of kernel names
+NO_SCRATCH = {"lut16.hip": ["lut16_apply_kernel"]}
+
+
+def _check_no_scratch(src, remarks_file):
+    import re
+
+    wanted, cur, seen = NO_SCRATCH[src], None, set()
+    for line in open(remarks_file, errors="replace"):
+        m = re.search(r"remark:\s+(Function Name|ScratchSize \[bytes/lane\]): (\S+)", line)
+        if not m:
+            continue
+        if m.group(1) == "Function Name":
+            cur = m.group(2)
+        elif cur is not None and any(w in cur for w in wanted):
+            seen.add(cur)
+            if int(m.group(2)) != 0:
+                raise RuntimeError(f"{src}: kernel {cur} uses {m.group(2)} bytes/lane of scratch: its hand-counted s_waitcnt would be wrong "
+                                   f"(build.py NO_SCRATCH)")
+    if not seen:
+        raise RuntimeError(f"{src}: no kernel matching {wanted} in the compiler's resource remarks: the NO_SCRATCH check did not run")
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -58,7 +84,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
             cmd = [hipcc] + FLAGS + ([f"-DDMXQ_EW_PART={part}"] if part else []) + ["-MD", "-MF", o + ".d", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            if src in NO_SCRATCH:
+                with open(o + ".remarks", "w") as rf:
+                    subprocess.check_call(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=rf)
+            else:
+                subprocess.check_call(cmd)
+        if src in NO_SCRATCH:   # (every build, also when the object was up to date: the remarks of ITS compilation are kept beside it)
+            if not os.path.exists(o + ".remarks"):
+                os.remove(o)
+                return compile_one(spec)
+            _check_no_scratch(src, o + ".remarks")
         return o
 
     with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, len(srcs) + 1)) as ex:

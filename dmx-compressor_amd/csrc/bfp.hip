@@ -114,7 +114,9 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
   do {                                                                                             \
     /* the exact-depth one-round plans (rows_plan): symmetric same-dtype builds; 17 / 18 vectors only where they fit 256 VGPRs */ \
     constexpr int kDepth = ((F_) != 4 && DTO == DTI && !ASYM) ? ((F_) == 2 ? 20 : 16) : 0;         \
-    const RowsPlan pl = rows_plan(n_vec, (F_) != 4, kDepth);                                       \
+    /* the one-round plans up to 512 x 16: not the any-rounding and stochastic builds (1 KiB of scratch per lane at 16 vectors) */ \
+    constexpr bool kBig = (F_) != 4 || RND == DMXQ_ROUND_DOWN || RND == DMXQ_ROUND_UP;             \
+    const RowsPlan pl = rows_plan(n_vec, kBig, kDepth);                                            \
     if constexpr (kDepth >= 16) {                                                                  \
       if (pl.id == 111) { DMXQ_ROWS(512, 11, F_); break; }                                         \
       if (pl.id == 112) { DMXQ_ROWS(512, 12, F_); break; }                                         \
@@ -130,7 +132,7 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
       if (pl.id == 119) { DMXQ_LAUNCH((bfp_rows_compact_kernel<DTI, 19, 512, 19>), dim3((unsigned)pl.tiles), dim3(512), 0, s, in, out, n_vec, lpb, wl); break; } \
       if (pl.id == 120) { DMXQ_LAUNCH((bfp_rows_compact_kernel<DTI, 20, 512, 10>), dim3((unsigned)pl.tiles), dim3(512), 0, s, in, out, n_vec, lpb, wl); break; } \
     }                                                                                              \
-    if constexpr ((F_) != 4) {                                                                     \
+    if constexpr (kBig) {                                                                          \
       if (pl.id == 2) { DMXQ_ROWS(512, 4, F_); break; }                                            \
       if (pl.id == 3) { DMXQ_ROWS(128, 8, F_); break; }                                            \
       if (pl.id == 4) { DMXQ_ROWS(512, 16, F_); break; }                                           \
@@ -142,7 +144,11 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
     // instantiate only what can run (see bfp_cols.hip): literal path for the runtime-rounding build, magic-add for
     // nearest-even; nearest with wl > 20 is routed to the runtime-rounding build by dispatch_mode
     constexpr bool in16 = Elem<DTI>::bytes == 2;
-    if constexpr (RND == kRuntimeRounding) {
+    if constexpr (RND != DMXQ_ROUND_NEAREST) {
+      // literal rounding on the bit pattern + clamp (bfp_math.hpp (5)).  RND = down / up / stochastic as a COMPILE-TIME mode (round 5;
+      // symmetric formats): round_bitwise folds to 1-2 operations per element and the draw is computed without the run-time mode's
+      // branch and scheduling fence -- the any-rounding build paid a chain of scalar compares and selects per element (50-57 % of
+      // the roofline on 4096 x 4096 bf16) and spilled on deep tiles
       DMXQ_ROWS_GEOM(4);
     } else {
       if (in16 && fast == 2) {
@@ -156,11 +162,16 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
 #undef DMXQ_ROWS_G
     return launch_status();
   }
-  const int64_t nblk = (L + B - 1) / B;
-  const int grid = grid_for(outer * nblk * inner);
-  DMXQ_LAUNCH((bfp_generic_kernel<DTI, DTO, RND, ASYM>), dim3(grid), dim3(kThreads), 0, s, in, out, outer, L,
-                     inner, B, wl, rounding, seed);
-  return launch_status();
+  if constexpr (RND != DMXQ_ROUND_NEAREST && RND != kRuntimeRounding) {
+    // (the compile-time modes exist for the row kernel only: everything else shares the any-rounding build)
+    return launch_bfp<DTI, DTO, kRuntimeRounding, ASYM>(in, out, outer, L, inner, B, wl, rounding, seed, s);
+  } else {
+    const int64_t nblk = (L + B - 1) / B;
+    const int grid = grid_for(outer * nblk * inner);
+    DMXQ_LAUNCH((bfp_generic_kernel<DTI, DTO, RND, ASYM>), dim3(grid), dim3(kThreads), 0, s, in, out, outer, L,
+                       inner, B, wl, rounding, seed);
+    return launch_status();
+  }
 }
 
 template <int DTI, int DTO>
@@ -169,6 +180,11 @@ static int dispatch_mode(const void* in, void* out, int64_t outer, int64_t L, in
   if (rounding == DMXQ_ROUND_NEAREST && wl <= 20)
     return asym ? launch_bfp<DTI, DTO, DMXQ_ROUND_NEAREST, true>(in, out, outer, L, inner, B, wl, rounding, seed, s)
                 : launch_bfp<DTI, DTO, DMXQ_ROUND_NEAREST, false>(in, out, outer, L, inner, B, wl, rounding, seed, s);
+  if (!asym && wl <= 20) {
+    if (rounding == DMXQ_ROUND_DOWN) return launch_bfp<DTI, DTO, DMXQ_ROUND_DOWN, false>(in, out, outer, L, inner, B, wl, rounding, seed, s);
+    if (rounding == DMXQ_ROUND_UP) return launch_bfp<DTI, DTO, DMXQ_ROUND_UP, false>(in, out, outer, L, inner, B, wl, rounding, seed, s);
+    if (rounding == DMXQ_ROUND_STOCHASTIC) return launch_bfp<DTI, DTO, DMXQ_ROUND_STOCHASTIC, false>(in, out, outer, L, inner, B, wl, rounding, seed, s);
+  }
   return asym ? launch_bfp<DTI, DTO, kRuntimeRounding, true>(in, out, outer, L, inner, B, wl, rounding, seed, s)
               : launch_bfp<DTI, DTO, kRuntimeRounding, false>(in, out, outer, L, inner, B, wl, rounding, seed, s);
 }

@@ -51,7 +51,7 @@ __device__ __forceinline__ OutVec<DTO, EPLV> bfp_rows_vector(const u32x4& raw, u
     const int64_t e0 = vi * EPL;
 #pragma unroll
     for (int k = 0; k < EPL; k++)
-      y[k] = bfp_q1_bitfast<RND, ASYM>(x[k], p, wl, rounding, rnd_if(stoch, seed, (uint64_t)(e0 + k)));
+      y[k] = bfp_q1_bitfast<RND, ASYM>(x[k], p, wl, rounding, rnd_for<RND>(stoch, seed, (uint64_t)(e0 + k)));
   } else if (PATH_FAST) {
 #pragma unroll
     for (int k = 0; k < EPL; k++) y[k] = bfp_q1_fast<FAST == 2, ASYM>(x[k], p);
@@ -59,7 +59,7 @@ __device__ __forceinline__ OutVec<DTO, EPLV> bfp_rows_vector(const u32x4& raw, u
     const int64_t e0 = vi * EPL;
 #pragma unroll
     for (int k = 0; k < EPL; k++)
-      y[k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, rnd_if(stoch, seed, (uint64_t)(e0 + k)));
+      y[k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, rnd_for<RND>(stoch, seed, (uint64_t)(e0 + k)));
   }
   // single-rounding fast path on a 16-bit input with the same 16-bit output: results are exactly representable
   // (not for asymmetric formats: their extra code -2^(e+1) overflows fp16 at e = 15 and must round to -inf)
@@ -114,7 +114,7 @@ __device__ __attribute__((noinline)) void bfp_rows_tile_partial(const char* __re
 #pragma unroll
     for (int u = 0; u < GROUP; u++) {
       mb[u] = group_max_u32(absmax_bits<DTI>(raw[g + u]), lpb);
-      if (kFast) all_fast = all_fast && (FAST == 4 ? bfp_bitfast_ok(mb[u], rounding) : bfp_fast_ok(mb[u], wl));
+      if (kFast) all_fast = all_fast && (FAST == 4 ? bfp_bitfast_ok(mb[u], RND == kRuntimeRounding ? rounding : RND) : bfp_fast_ok(mb[u], wl));
     }
     OutVec<DTO, EPL> o[GROUP];
 #pragma unroll
@@ -128,7 +128,7 @@ __device__ __attribute__((noinline)) void bfp_rows_tile_partial(const char* __re
         u32x4 r = u32x4{0u, 0u, 0u, 0u};
         if ((int64_t)(g + u) * THREADS < rem) r = load_rawv<IVB>(src + (g + u) * (THREADS * IVB), lane_in);
         const uint32_t m = group_max_u32(absmax_bits<DTI>(r), lpb);
-        if (__builtin_amdgcn_ballot_w64(!(FAST == 4 ? bfp_bitfast_ok(m, rounding) : bfp_fast_ok(m, wl))) != 0ull)
+        if (__builtin_amdgcn_ballot_w64(!(FAST == 4 ? bfp_bitfast_ok(m, RND == kRuntimeRounding ? rounding : RND) : bfp_fast_ok(m, wl))) != 0ull)
           o[u] = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, false, EPL>(r, m, v0 + (int64_t)(g + u) * THREADS, wl, rounding, stoch, seed);
       }
     }
@@ -174,7 +174,7 @@ __device__ __forceinline__ void bfp_rows_tile(const void* __restrict__ in, void*
 #pragma unroll
       for (int u = 0; u < GROUP; u++) {
         mb[u] = group_max_u32(absmax_bits<DTI>(raw[g + u]), lpb);
-        if (kFast) all_fast = all_fast && (FAST == 4 ? bfp_bitfast_ok(mb[u], rounding) : bfp_fast_ok(mb[u], wl));
+        if (kFast) all_fast = all_fast && (FAST == 4 ? bfp_bitfast_ok(mb[u], RND == kRuntimeRounding ? rounding : RND) : bfp_fast_ok(mb[u], wl));
       }
       OutVec<DTO, EPL> o[GROUP];
 #pragma unroll
@@ -192,7 +192,7 @@ __device__ __forceinline__ void bfp_rows_tile(const void* __restrict__ in, void*
         for (int u = 0; u < GROUP; u++) {
           const u32x4 r = load_rawv<IVB>(src + (g + u) * (THREADS * IVB), lane_in);
           const uint32_t m = group_max_u32(absmax_bits<DTI>(r), lpb);
-          if (__builtin_amdgcn_ballot_w64(!(FAST == 4 ? bfp_bitfast_ok(m, rounding) : bfp_fast_ok(m, wl))) != 0ull)
+          if (__builtin_amdgcn_ballot_w64(!(FAST == 4 ? bfp_bitfast_ok(m, RND == kRuntimeRounding ? rounding : RND) : bfp_fast_ok(m, wl))) != 0ull)
             o[u] = bfp_rows_vector<DTI, DTO, RND, ASYM, FAST, false, EPL>(r, m, v0 + (int64_t)(g + u) * THREADS, wl, rounding,
                                                                      stoch, seed);
         }
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restric
                                                           int64_t n_vec, int lpb_arg /*lanes per block*/, int wl,
                                                           int rounding, uint64_t seed) {
   constexpr int64_t TILE = (int64_t)THREADS * UNROLL;
-  const bool stoch = (RND == kRuntimeRounding) && rounding == DMXQ_ROUND_STOCHASTIC;
+  const bool stoch = RND == DMXQ_ROUND_STOCHASTIC || ((RND == kRuntimeRounding) && rounding == DMXQ_ROUND_STOCHASTIC);
   const int lpb = __builtin_amdgcn_readfirstlane(lpb_arg);
   const int64_t n_tiles = (n_vec + TILE - 1) / TILE;
 #define DMXQ_TILE_LOOP(L_)                                                                                          \
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restric
   // constant, chosen ONCE per launch -- with a runtime value every vector's DPP reduction is a chain of six scalar
   // branches, which cost 6.7 % of the 64 MiB headline launch (tools/tune_bfp: 11.71 -> 10.93 us).  Multi-round 512x2
   // tiles measured no difference and keep the single runtime form.
-  if constexpr (LPBC == 0 && UNROLL >= 4 && (FAST == 1 || FAST == 2)) {
+  if constexpr (LPBC == 0 && UNROLL >= 4 && (FAST == 1 || FAST == 2 || (FAST == 4 && RND != kRuntimeRounding))) {
     switch (lpb) {
       case 2: DMXQ_TILE_LOOP(2); break;
       case 4: DMXQ_TILE_LOOP(4); break;

@@ -43,6 +43,14 @@ __device__ __forceinline__ uint32_t rnd_if(bool stoch, uint64_t seed, uint64_t i
   return r;
 }
 
+// the draw of element `idx` for a kernel built for rounding mode RND (compile time), or for any mode (kRuntimeRounding_: `stoch` says
+// whether the launch is stochastic)
+template <int RND>
+__device__ __forceinline__ uint32_t rnd_for(bool stoch, uint64_t seed, uint64_t idx) {
+  if (RND == -1 /* kRuntimeRounding */) return rnd_if(stoch, seed, idx);
+  return RND == DMXQ_ROUND_STOCHASTIC ? rnd_bits(seed, idx) : 0u;
+}
+
 // quant_cpu.cpp:211-237 round_bitwise: keep `man_bits` (0..22) mantissa bits of an fp32 bit pattern.
 // nearest == round-half-to-even on the bit pattern, written as the branch-free (half-1)+lsb form:
 // dropped > half carries, dropped < half does not, dropped == half carries iff the kept LSB is odd.
@@ -348,27 +356,33 @@ __device__ __forceinline__ float div_for_clamped_int(float n, const Recip& c) {
 // for every FINITE quotient; a lane whose q0 is Inf / NaN (where the correction step and v_med3 are wrong: NaN must stay NaN)
 // reports `special` and the caller redoes its vector per element behind one cold wave-uniform branch.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int N>
+// ZP0: the caller knows z == +0.0f (wave-uniform, decided per tile): the + z and - z steps are skipped -- exact, see FixedOp::tile_variant.
+// Special quotients (round 5): a q0 that is Inf / NaN makes its corrected quotient q a NaN (d (+-Inf) - n is +-Inf or NaN, and
+// (-+Inf) rs + (+-Inf) = NaN), so ONE class test on the SUM of the vector's quotients replaces a test per element (N / 2 packed adds + 2
+// operations instead of N compares); a finite sum that overflows only sends the lane through the exact redo needlessly.
+template <int N, bool ZP0 = false>
 __device__ __forceinline__ bool affine_int_pairs(const float (&x)[N], float (&y)[N], float d, float rs, float z, float t_min, float t_max) {
   static_assert(N % 2 == 0, "pairs");
-  bool special = false;
+  f32x2 acc = {0.0f, 0.0f};
 #pragma unroll
   for (int k = 0; k < N; k += 2) {
     const f32x2 n2 = {x[k], x[k + 1]};
     const f32x2 q0 = n2 * rs;
     const f32x2 t = __builtin_elementwise_fma((f32x2){d, d}, q0, -n2);    // -(r): r = n - d q0, exact
     const f32x2 q = __builtin_elementwise_fma(-t, (f32x2){rs, rs}, q0);
-    special = special || __builtin_amdgcn_classf(q0.x, 0x001 | 0x002 | 0x004 | 0x200) || __builtin_amdgcn_classf(q0.y, 0x001 | 0x002 | 0x004 | 0x200);
-    f32x2 u = q + z;
+    acc = k == 0 ? q : acc + q;
+    f32x2 u = q;
+    if (!ZP0) u = u + z;
     u = (u + 0.5f) - 0.5f;
     f32x2 v;
     v.x = __builtin_amdgcn_fmed3f(__builtin_rintf(u.x), t_min, t_max);
     v.y = __builtin_amdgcn_fmed3f(__builtin_rintf(u.y), t_min, t_max);
-    const f32x2 o = (v - z) * d;
+    if (!ZP0) v = v - z;
+    const f32x2 o = v * d;
     y[k] = o.x;
     y[k + 1] = o.y;
   }
-  return special;
+  return __builtin_amdgcn_classf(acc.x + acc.y, 0x001 | 0x002 | 0x004 | 0x200);  // sNaN, qNaN, -inf, +inf
 }
 
 // a value the program knows to be the same in every lane, moved to scalar registers (what follows it -- index arithmetic,
@@ -377,6 +391,15 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
   return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// A read of memory that no thread of the running kernel writes (parameter tables produced by EARLIER launches), through the
+// constant address space: with a wave-uniform address the compiler emits an s_load whatever stores it has seen -- through a plain
+// global pointer it must prove that nothing in the kernel may have clobbered the location, gives up on most of our kernels and
+// issues a vector load, whose first consumer then waits an L2 round trip.
+template <class T>
+__device__ __forceinline__ T load_uniform_const(const T* p) {
+  return *(const __attribute__((address_space(4))) T*)(uintptr_t)p;
 }
 
 // Tile geometry of the flat-stream kernel for a tensor of n_vec lane-vectors: workgroup-contiguous tiles of

@@ -130,6 +130,7 @@ struct FixedOp {
   // 20-32 MiB tensors (stream.hpp), clamped integer formats, 3072 / 3584 / 4096 x 4096 bf16: no affine 64 x 16 8.5 / 9.9 / 11.1 us (256 x 8
   // 9.9 / 11.8 / 13.7); per-group scale 128 x 16 11.1 / 11.6 / 12.4 us (256 x 8 10.9 / 13.9 / 14.9; 512 x 16 12.2 / 12.9 / 13.7)
   static constexpr int kTileUnroll = !SIMPLE ? 4 : 16, kTileThreads = !SIMPLE ? 256 : (MODE == kNone ? 64 : 128);
+  static constexpr bool kWaitAll = SIMPLE;  // stream.hpp OpWaitAll: the whole tile's data before the first vector's arithmetic (+3.5 % without a scale)
   FixedFmt f;
   ChannelMap cm;
   const float* scale;
@@ -202,7 +203,8 @@ struct FixedOp {
       // the arithmetic of common.hpp affine_int_pairs with a (scale, reciprocal, zero point) PAIR per instruction: ~7.5 VALU per
       // element, straight-line.  Lanes holding a scale outside the reciprocal's range, or an Inf / NaN quotient, redo their vector
       // with the IEEE division behind one cold wave-uniform branch.
-      bool redo = !p.fast;
+      // (an Inf / NaN quotient shows as a NaN in the SUM of the vector's corrected quotients: common.hpp affine_int_pairs)
+      f32x2 acc = {0.0f, 0.0f};
 #pragma unroll
       for (int k = 0; k < N; k += 2) {
         const f32x2 d = p.d[k / 2], rs = p.rs[k / 2], z = p.z[k / 2];
@@ -210,7 +212,7 @@ struct FixedOp {
         const f32x2 q0 = n2 * rs;
         const f32x2 t = __builtin_elementwise_fma(d, q0, -n2);  // -(r): r = n - d q0, exact
         const f32x2 q = __builtin_elementwise_fma(-t, rs, q0);
-        redo = redo || __builtin_amdgcn_classf(q0.x, 0x001 | 0x002 | 0x004 | 0x200) || __builtin_amdgcn_classf(q0.y, 0x001 | 0x002 | 0x004 | 0x200);
+        acc = k == 0 ? q : acc + q;
         f32x2 u = q + z;
         u = (u + 0.5f) - 0.5f;
         f32x2 v;
@@ -220,6 +222,7 @@ struct FixedOp {
         y[k] = o.x;
         y[k + 1] = o.y;
       }
+      const bool redo = !p.fast || __builtin_amdgcn_classf(acc.x + acc.y, 0x001 | 0x002 | 0x004 | 0x200);
       if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo) != 0ull, 0)) {
         if (redo) {
 #pragma unroll
@@ -232,9 +235,9 @@ struct FixedOp {
     }
   }
   // the vector's (scale, zero point) when it has a single one: fetched ahead of the arithmetic (stream.hpp OpPrep)
-  struct Prep { float sc, z; };
+  struct Prep { float sc, z, rs; int64_t zraw; };  // rs, and z from zraw: completed by tile_variant (kTileVariants == 3)
   __device__ __forceinline__ Prep prepare(int64_t e0) const {
-    Prep p{1.0f, 0.0f};
+    Prep p{1.0f, 0.0f, 1.0f, 0};
     if (MODE == kTensor) { p.sc = scale[0]; p.z = (float)zp[0]; }
     if (MODE == kUniform) {
       ChanIter it;
@@ -250,17 +253,52 @@ struct FixedOp {
   __device__ __forceinline__ bool tile_prepare(int64_t e0, int64_t len, Prep& p) const {
     int64_t g = 0;
     if (MODE == kUniform) {
-      ChanIter it;
-      it.start(cm, uniform_i64(e0));
-      const int64_t left = cm.C - it.g * cm.group_size;
-      const int64_t run = (left < cm.group_size ? left : cm.group_size) * cm.inner;
-      if (it.r * cm.inner + it.i + len > run) return false;
-      g = uniform_i64(it.g);  // (the index arithmetic above ran on the vector unit: back to scalar registers, so that the two table
-                              // reads are s_load and not two more vector loads queued in front of the tile's own)
+      if (cm.run_align >= (uint32_t)len) {
+        // equal runs, and the (power-of-two) tile divides them (ChannelMap): the group from the tile's first element by two scalar
+        // multiply-highs -- round 5; the walker below costs ~30 vector instructions and a readfirstlane ahead of the tile's first load
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)e0);
+        const uint32_t k = cm.f_run.div(e);
+        g = k - cm.f_G.div(k) * cm.G;
+      } else {
+        ChanIter it;
+        it.start(cm, uniform_i64(e0));
+        const int64_t left = cm.C - it.g * cm.group_size;
+        const int64_t run = (left < cm.group_size ? left : cm.group_size) * cm.inner;
+        if (it.r * cm.inner + it.i + len > run) return false;
+        g = uniform_i64(it.g);  // (the index arithmetic above ran on the vector unit: back to scalar registers, so that the two table
+                                // reads are s_load and not two more vector loads queued in front of the tile's own)
+      }
     }
-    p.sc = scale[g];
-    p.z = (float)zp[g];
+    // The two table reads are REQUESTED here, ahead of the tile's loads, as scalar loads (load_uniform_const: through plain global
+    // pointers the compiler issued vector loads and moved the zero point to scalar registers at once -- a full L2 round trip in
+    // front of every tile's first load, 11.6 -> 14.0 us on 4096 x 4096 bf16); what consumes them (the int64 -> float conversion
+    // included) runs behind the tile's loads, in tile_variant.
+    p.sc = load_uniform_const(scale + g);
+    if constexpr (kTileVariants == 3) p.zraw = load_uniform_const(zp + g);
+    else p.z = (float)load_uniform_const(zp + g);
     return true;
+  }
+  // stream.hpp OpTileVariants (round 5): for a tile with ONE (scale, zero point) the choice between the reciprocal form and the IEEE
+  // division is a scalar compare per TILE, and so is "zero point == 0" (every symmetric scheme): 2 = reciprocal form without the
+  // + z / - z steps, 1 = reciprocal form, 0 = the general per-vector code.  Skipping + 0.0f / - 0.0f is exact: q + 0 differs from q
+  // only for q = -0 (-> +0), and (u + 0.5f) - 0.5f maps both zeros to +0; v - (+0) == v for every v, -0 included.
+  static constexpr int kTileVariants = (SIMPLE && (MODE == kTensor || MODE == kUniform)) ? 3 : 1;
+  __device__ __forceinline__ int tile_variant(Prep& p) const {
+    p.z = zp_float(p.zraw);
+    const float sc = u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(p.sc)));
+    const float z = u2f((uint32_t)__builtin_amdgcn_readfirstlane((int)f2u(p.z)));
+    p.rs = 1.0f / sc;  // ONE IEEE division per tile (inside apply_vec_tile it was redone per vector: the tile loop's scheduling fences pin it)
+    return recip_ok(sc) ? (z == 0.0f ? 2 : 1) : 0;
+  }
+  template <int V, int N>
+  __device__ __forceinline__ bool apply_vec_tile(const float (&x)[N], float (&y)[N], const Prep& pp) const {
+    static_assert(N % 2 == 0, "pairs");
+    return affine_int_pairs<N, V == 2>(x, y, pp.sc, pp.rs, pp.z, f.t_min, f.t_max);
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_vec_exact(const float (&x)[N], float (&y)[N], int64_t e0, const Prep& pp) const {
+#pragma unroll
+    for (int k = 0; k < N; k++) y[k] = q<true>(x[k], pp.sc, pp.z, e0 + k, pp.rs);
   }
   template <int N>
   __device__ __forceinline__ void apply_vec(const float (&x)[N], float (&y)[N], int64_t e0) const {
@@ -435,7 +473,16 @@ struct BernoulliOp {
 static inline ChannelMap make_channel_map(int64_t C, int64_t inner, int64_t group_size, int64_t n) {
   const int64_t c = C < 1 ? 1 : C, in = inner < 1 ? 1 : inner;
   const int small = (n < (int64_t)1 << 31 && c < (int64_t)1 << 31 && in < (int64_t)1 << 31) ? 1 : 0;
-  return ChannelMap{c, in, group_size, small, make_fastdiv31(in), make_fastdiv31(c), make_fastdiv31(group_size)};
+  ChannelMap m{c, in, group_size, small, make_fastdiv31(in), make_fastdiv31(c), make_fastdiv31(group_size), 0u, 1u, make_fastdiv31(1), make_fastdiv31(1)};
+  const int64_t gs = group_size < c ? group_size : c;  // (one group when the group covers the dim)
+  if (small && gs >= 1 && c % gs == 0 && gs * in < ((int64_t)1 << 31)) {
+    const int64_t run = gs * in;
+    m.run_align = (uint32_t)(run & -run);
+    m.G = (uint32_t)(c / gs);
+    m.f_run = make_fastdiv31(run);
+    m.f_G = make_fastdiv31(c / gs);
+  }
+  return m;
 }
 
 }  // namespace dmxq

@@ -66,9 +66,12 @@ extern "C" int dmxq_weight_hypernet_multi(const dmxq_hypernet_desc* tensors, int
   if (M != 0 && (!valid_dtype(dtype_score) || K < 1 || K > M)) return DMXQ_ERR_BAD_ARG;
   const int64_t B = block_size;
   bool any = false, has_scale = false, first = true;
+  int64_t total = 0;   // elements of the whole set (overflow-checked: rows * L and the running sum stay below 2^62)
   for (int64_t i = 0; i < n_tensors; i++) {
     const dmxq_hypernet_desc& t = tensors[i];
     if (t.rows < 0 || t.L < 0) return DMXQ_ERR_BAD_ARG;
+    if (t.rows != 0 && t.L > (((int64_t)1 << 62) - total) / t.rows) return DMXQ_ERR_BAD_ARG;
+    total += t.rows * t.L;
     if (t.rows * t.L == 0) continue;
     if (!t.w || !t.out || (M != 0 && !t.score)) return DMXQ_ERR_BAD_ARG;
     if (first) { has_scale = t.sq_scale != nullptr; first = false; }
@@ -78,20 +81,21 @@ extern "C" int dmxq_weight_hypernet_multi(const dmxq_hypernet_desc* tensors, int
   // the fusable geometry of dmxq_weight_hypernet, for every tensor; anything else is the caller's job (one call per tensor / unfused)
   if (!(M == 0 || M == 2 || M == 4 || M == 8) || (B & (B - 1)) != 0 || B < 8 || B > 512 || precision < 2 || precision > 20)
     return DMXQ_ERR_UNSUPPORTED;
+  // units per lane by the size of the whole set (hypernet_rows.hpp): 2 up to 160 M elements, 4 beyond
+  const int units = total <= ((int64_t)160 << 20) ? kHnUnitsSmall : kHnUnits;
+  const int64_t TILE = (int64_t)kThreads * units;
+  // ALL-OR-NOTHING (include/dmxq.h): every check that can return UNSUPPORTED runs here, before the first launch -- the per-tensor tile
+  // count too (it sat in the launch loop below until round 5, behind a possible flush() of earlier batches: ADVICE r4)
   for (int64_t i = 0; i < n_tensors; i++) {
     const dmxq_hypernet_desc& t = tensors[i];
     if (t.rows * t.L == 0) continue;
     if (t.L % B != 0 || t.L % 8 != 0 || !aligned16(t.w) || !aligned16(t.out) || (M != 0 && !aligned16(t.score)) ||
         (t.sq_scale && !aligned16(t.sq_scale)))
       return DMXQ_ERR_UNSUPPORTED;
+    if ((t.rows * t.L / 8 + TILE - 1) / TILE >= ((int64_t)1 << 31)) return DMXQ_ERR_UNSUPPORTED;
   }
   if (!any) return DMXQ_OK;
   hipStream_t s = (hipStream_t)stream;
-  // units per lane by the size of the whole set (hypernet_rows.hpp): 2 up to 160 M elements, 4 beyond
-  int64_t total = 0;
-  for (int64_t i = 0; i < n_tensors; i++) total += tensors[i].rows * tensors[i].L;
-  const int units = total <= ((int64_t)160 << 20) ? kHnUnitsSmall : kHnUnits;
-  const int64_t TILE = (int64_t)kThreads * units;
   HnMultiArgs a;
   a.n = 0; a.K = K; a.lpb = (int)(B / 8); a.wl = precision; a.asym = symmetric ? 0 : 1;
   int64_t tiles = 0;
@@ -125,8 +129,7 @@ extern "C" int dmxq_weight_hypernet_multi(const dmxq_hypernet_desc* tensors, int
     const dmxq_hypernet_desc& t = tensors[i];
     const int64_t n = t.rows * t.L;
     if (n == 0) continue;
-    const int64_t nt = (n / 8 + TILE - 1) / TILE;
-    if (nt >= ((int64_t)1 << 31)) return DMXQ_ERR_UNSUPPORTED;
+    const int64_t nt = (n / 8 + TILE - 1) / TILE;   // (< 2^31: checked above)
     if (a.n == kHnMultiMax || tiles + nt >= ((int64_t)1 << 31)) flush();
     a.d[a.n] = HnMultiDesc{t.w, M ? t.score : nullptr, t.sq_scale, t.out, n / 8, t.L, tiles, make_fastdiv31(t.L),
                            n < ((int64_t)1 << 31) ? 1 : 0};

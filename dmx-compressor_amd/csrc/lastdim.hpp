@@ -65,6 +65,9 @@ __global__ __launch_bounds__(THREADS) void lastdim_kernel(const void* __restrict
   __builtin_amdgcn_sched_barrier(0);
   const auto p = op.template make_params<EPL>(pr);
   __builtin_amdgcn_sched_barrier(0);
+#ifdef DMXQ_EXP_LD_WAITALL
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   OutVec<DTO, EPL> o[RPI];
 #pragma unroll
   for (int j = 0; j < RPI; j++) {

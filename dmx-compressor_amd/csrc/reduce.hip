@@ -7,7 +7,9 @@
 // The reference builds one observer nn.Module per group in a Python loop and runs two ATen reductions per
 // group; here one launch covers all groups.  Partial results are combined with integer atomics on the float
 // bit patterns (order-preserving for non-NaN values), so the outputs are exact and order-independent.
+#include <dlfcn.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <unordered_map>
@@ -18,47 +20,82 @@
 namespace dmxq {
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// THE INIT GATE (round 4): the atomics of a reduction need their destination initialised first -- until now by a fill launch in
-// front of the kernel, ~1.6 us of the ~9 (profiles/r03_ops_roofline_table.txt).  A ticket (last workgroup reduces partials) costs
-// MORE than the fill on this chip (a RETURNING device-scope atomic per workgroup: profiles/r04_tune_reduce_tickets.txt).  The gate
-// needs neither: workgroup (0, 0) stores the identities with agent-scope stores, waits for them (s_waitcnt vmcnt(0)), and publishes
-// the launch's EPOCH in a flag word; every workgroup requests that word right BEHIND its data loads -- vector memory returns in
-// order, so the value arrives with the last data, for free -- and one thread re-reads it only while it does not yet hold the epoch,
-// before the workgroup issues its (non-returning) atomics.  tools/tune_reduce2.hip: 11.00 -> 9.47 us (per-tensor min / max),
-// 9.91 -> 8.12 (32 groups), 9.42 -> 7.76 (per-column max |x|) on 32 MiB of bf16: exactly the fill launch.
+// THE INIT GATE (round 4; made placement-independent in round 5): the atomics of a reduction need their destination initialised
+// first -- until round 4 by a fill launch in front of the kernel, ~1.6 us of the ~9 (profiles/r03_ops_roofline_table.txt).  A ticket
+// (last workgroup reduces partials) costs MORE than the fill on this chip (a RETURNING device-scope atomic per workgroup at the END of
+// a one-round kernel: profiles/r04_tune_reduce_tickets.txt).  The gate needs neither: ONE wave stores the identities, makes them
+// visible at agent scope (release fence) and publishes the launch's EPOCH in a flag word (release store); thread 0 of every workgroup
+// reads that word once its own data has arrived -- the latency hides behind the workgroup's arithmetic -- and polls it only while it
+// does not yet hold the epoch, before the workgroup issues its (non-returning) atomics (acquire fence).
+//   * WHO initialises is decided by a claim, not by position: `flag[1]` is an election word, and whoever swaps the epoch into it first
+//     (a returning exchange) does the job.  Wave 0 of workgroup (0, 0) volunteers at the very start of the kernel, before its loads
+//     -- uncontended, one wave of the whole grid pays the round trip -- so on an idle chip the flag is up ~2 us into the kernel, long
+//     before anybody asks.  A workgroup that has polled kGateTakeover times without seeing the epoch stops assuming that (0, 0) is
+//     running and claims the job itself: it IS running, so the identities get written whatever order the dispatcher chose and
+//     whatever else occupies the chip (MI355X_MICROARCH.md, correctness boundaries: dispatch order is undefined; round 4 had every
+//     workgroup wait for (0, 0) unconditionally).  A late (0, 0) finds the word claimed and just waits like everybody else.
 //   * a flag slot belongs to ONE stream (launches of a stream are ordered, so a slot never serves two running kernels: no launch can
-//     overwrite the epoch another one still waits for); epochs count up per slot and skip 0, the value of a fresh slot;
+//     overwrite the epoch another one still waits for), keyed by (device of the stream, hipStreamGetId where the runtime has it --
+//     ids are never reused, a destroyed stream's handle may be --, else the handle); epochs count up per slot and skip 0, the value
+//     of a fresh slot;
 //   * no gate -- the fill launch as before -- while the stream is being captured (a replayed graph would present the SAME epoch
 //     again, already in the flag), on hipStreamPerThread (one handle, many streams), past kGateSlots streams, for more outputs than
-//     one workgroup initialises quickly, and on the scalar kernels.
-// on == 0: the destination is initialised already (a fill launch in front, or the accumulate form)
+//     one wave initialises quickly, on the scalar kernels, and when DMXQ_NO_INIT_GATE is set in the environment.
+// on == 0: the destination is initialised already (a fill launch in front, or the accumulate form); 2: test hook, (0, 0) does not
+// volunteer (every launch goes through the takeover path: dmxq_internal_gate_mode)
 struct InitGate { unsigned* flag; unsigned epoch; int on; };
 constexpr int kGateSlots = 1024, kGateStride = 16 /* words: one slot per 64-byte line */, kGateMaxOut = 8192;
+constexpr int kGateTakeover = 48;  // polls (~1 us each) before a waiting workgroup claims the initialisation
 
+// The calling WAVE (all 64 lanes, wave-uniform control flow) tries to become the initialiser.  true: it was, and the flag is up.
+template <typename F>
+__device__ __forceinline__ bool gate_claim_and_init(const InitGate& g, int64_t n, F&& init) {
+  const int lane = threadIdx.x & (kWave - 1);
+  unsigned old = g.epoch;
+  if (lane == 0) old = __hip_atomic_exchange(g.flag + 1, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+  if (old == g.epoch) return false;   // claimed before: that wave initialises (or has)
+  for (int64_t i = lane; i < n; i += kWave) init(i);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every lane's identity stores, before ...
+  if (lane == 0) __hip_atomic_store(g.flag, g.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... the epoch
+  return true;
+}
 // (GATED is a template parameter of the kernels: the un-gated instances -- the accumulate forms, the fallbacks -- carry none of this;
 // as a run-time flag it cost them 0.3 us)
 template <bool GATED, typename F>
-__device__ __forceinline__ void gate_open(const InitGate& g, int64_t n, int threads, F&& init) {
-  if (GATED && blockIdx.x == 0 && blockIdx.y == 0) {   // (block-uniform)
-    for (int64_t i = threadIdx.x; i < n; i += threads) init(i);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // agent-scope stores: acknowledged where the atomics execute
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(g.flag, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+__device__ __forceinline__ void gate_open(const InitGate& g, int64_t n, F&& init) {
+  if (GATED && g.on == 1 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kWave) (void)gate_claim_and_init(g, n, init);
 }
 __device__ __forceinline__ void gate_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// thread 0 only, behind the data loads of its wave.  (Measured: the same load by EVERY wave -- which spares wave 0 the join, where
-// the compiler waits for the loaded value and so for all data before it -- costs 0.4 us: 4096 agent-scope reads of one address.)
+// thread 0 only, and only while it has not seen the epoch.  `dep`: a register of the caller's FIRST data load of the batch -- the
+// flag's address is made to depend on it, so the read is issued when the first data arrives (>= ~2 us into the kernel: the volunteer's
+// claim + stores + fence take ~1.5-2 us, and a read issued right behind the loads, as in round 4, would find the old value and cost
+// the workgroup a poll at its end) and returns while the rest of the batch still streams in.
+// (Measured in round 4: the same load by EVERY wave costs 0.4 us: 4096 agent-scope reads of one address.)
 template <bool GATED>
-__device__ __forceinline__ unsigned gate_peek(const InitGate& g, unsigned seen) {
-  if (GATED && threadIdx.x == 0) seen = __hip_atomic_load(g.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ unsigned gate_peek(const InitGate& g, unsigned seen, uint32_t dep) {
+  if (GATED && threadIdx.x == 0 && seen != g.epoch) {
+    uint32_t off = 0u;
+    asm volatile("" : "+v"(off) : "v"(dep));
+    seen = __hip_atomic_load(g.flag + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   return seen;
 }
-// thread 0, before the atomics (the others follow it through a barrier or are thread 0 themselves)
-template <bool GATED>
-__device__ __forceinline__ void gate_wait(const InitGate& g, unsigned seen) {
-  if (GATED && threadIdx.x == 0)
-    while (seen != g.epoch) seen = __hip_atomic_load(g.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// wave 0 of the workgroup (every lane calls it; the others fall through), before the atomics: the threads that issue them follow
+// through a barrier or are thread 0 themselves
+template <bool GATED, typename F>
+__device__ __forceinline__ void gate_wait(const InitGate& g, unsigned seen, int64_t n, F&& init) {
+  if (GATED && threadIdx.x < kWave) {
+    unsigned s = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);   // thread 0's
+    int polls = 0;
+    while (s != g.epoch) {
+      unsigned v = 0u;
+      if (threadIdx.x == 0) v = __hip_atomic_load(g.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+      if (s != g.epoch && ++polls == kGateTakeover && gate_claim_and_init(g, n, init)) s = g.epoch;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the identities, before this workgroup's atomics
+  }
 }
 
 // float atomic min/max through integer atomics: non-negative floats order like signed ints, negative floats
@@ -138,20 +175,20 @@ __device__ __forceinline__ void wave_minmax_keys(uint32_t& lo, uint32_t& hi) {
   lo = min(lo, (uint32_t)__shfl_xor((int)lo, 16)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, 16));
   lo = min(lo, (uint32_t)__shfl_xor((int)lo, 32)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, 32));
 }
-template <int T, bool GATED = false>
+template <int T, bool GATED = false, typename F>
 __device__ __forceinline__ void block_minmax_finish(float flo, float fhi, float* mn, float* mx, const InitGate& gate,
-                                                    unsigned seen) {
+                                                    unsigned seen, int64_t n_init, F&& init) {
   uint32_t lo = fkey(flo), hi = fkey(fhi);   // (nothing seen: (+Inf, -Inf), which no combine prefers)
   wave_minmax_keys(lo, hi);
   __shared__ uint32_t s_lo[T / kWave], s_hi[T / kWave];
   const int w = threadIdx.x / kWave;
   if ((threadIdx.x & (kWave - 1)) == 0) { s_lo[w] = lo; s_hi[w] = hi; }
   __syncthreads();
+  gate_wait<GATED>(gate, seen, n_init, init);   // wave 0
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int i = 1; i < T / kWave; i++) { lo = min(lo, s_lo[i]); hi = max(hi, s_hi[i]); }
     if (lo <= hi || lo < fkey(-INFINITY)) {  // at least one element seen (or a NaN: (-NaN, +NaN) also has lo <= hi as keys)
-      gate_wait<GATED>(gate, seen);
       atomic_min_f32(mn, fkey_inv(lo));
       atomic_max_f32(mx, fkey_inv(hi));
     }
@@ -177,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void group_minmax_kernel(const void* __re
     am = max(am, f2u(v) & 0x7FFFFFFFu);
   }
   nan_to_both(am, lo, hi);
-  block_minmax_finish<kThreads>(lo, hi, &mn[g], &mx[g], InitGate{nullptr, 0u, 0}, 0u);
+  block_minmax_finish<kThreads>(lo, hi, &mn[g], &mx[g], InitGate{nullptr, 0u, 0}, 0u, 0, [](int64_t) {});
 }
 
 // 8 consecutive elements, compile-time dtype: the RAW 16-byte vectors first (so that a batch of loads is issued back to
@@ -232,7 +269,8 @@ __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const 
                                                                          int64_t gs, float* mn, float* mx, const InitGate gate) {
   constexpr int kThreads = kMinmaxThreads;  // shadows the namespace constant inside this kernel
   const int64_t g = blockIdx.y;
-  gate_open<GATED>(gate, gridDim.y, kThreads, [&](int64_t i) { gate_store(&mn[i], INFINITY); gate_store(&mx[i], -INFINITY); });
+  auto init = [&](int64_t i) { gate_store(&mn[i], INFINITY); gate_store(&mx[i], -INFINITY); };
+  gate_open<GATED>(gate, gridDim.y, init);
   unsigned seen = ~gate.epoch;   // not the epoch: a workgroup that never peeks must wait
   const int64_t c0 = g * gs;
   const int64_t lenv = ((C - c0 < gs) ? (C - c0) : gs) * inner / 8;  // vectors per run
@@ -261,7 +299,7 @@ __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const 
       }
       raw[u] = load8_raw<DT>(in, last);
     }
-    seen = gate_peek<GATED>(gate, seen);
+    seen = gate_peek<GATED>(gate, seen, raw[0].a.x);
     (void)nv;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -278,7 +316,7 @@ __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const 
   }
   if (DT != DMXQ_F32) { if (any) pk.finish<DT>(lo, hi); }
   else nan_to_both(am, lo, hi);
-  block_minmax_finish<kThreads, GATED>(lo, hi, &mn[g], &mx[g], gate, seen);
+  block_minmax_finish<kThreads, GATED>(lo, hi, &mn[g], &mx[g], gate, seen, gridDim.y, init);
 }
 
 // outer == 1 (a weight's row slabs along dim 0, or the whole tensor as one group): the vectors of group g are ONE contiguous run, so a
@@ -292,7 +330,8 @@ __global__ __launch_bounds__(kFlatThreads) void group_minmax_flat_kernel(const v
                                                                         float* mn, float* mx, const InitGate gate) {
   constexpr int T = kFlatThreads, U = FlatUnroll<DT>::value;
   const int64_t g = blockIdx.y;
-  gate_open<GATED>(gate, gridDim.y, T, [&](int64_t i) { gate_store(&mn[i], INFINITY); gate_store(&mx[i], -INFINITY); });
+  auto init = [&](int64_t i) { gate_store(&mn[i], INFINITY); gate_store(&mx[i], -INFINITY); };
+  gate_open<GATED>(gate, gridDim.y, init);
   unsigned seen = ~gate.epoch;   // not the epoch: a workgroup that never peeks must wait
   const int64_t c0 = g * gs;
   const int64_t lenv = ((C - c0 < gs) ? (C - c0) : gs) * inner / 8;  // vectors of this group
@@ -309,7 +348,7 @@ __global__ __launch_bounds__(kFlatThreads) void group_minmax_flat_kernel(const v
       const int64_t v = b + (int64_t)u * T + threadIdx.x;
       raw[u] = load8_raw<DT>(in, (v0 + (v < lenv ? v : lenv - 1)) * 8);  // clamped: a repeated vector cannot change a min / max
     }
-    seen = gate_peek<GATED>(gate, seen);
+    seen = gate_peek<GATED>(gate, seen, raw[0].a.x);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -326,7 +365,7 @@ __global__ __launch_bounds__(kFlatThreads) void group_minmax_flat_kernel(const v
   }
   if (DT != DMXQ_F32) { if (any) pk.finish<DT>(lo, hi); }
   else nan_to_both(am, lo, hi);
-  block_minmax_finish<T, GATED>(lo, hi, &mn[g], &mx[g], gate, seen);
+  block_minmax_finish<T, GATED>(lo, hi, &mn[g], &mx[g], gate, seen, gridDim.y, init);
 }
 
 // vectorised twin of channel_maxabs_kernel: a workgroup covers a strip of 64 x 8 = 512 consecutive columns of the
@@ -339,7 +378,8 @@ __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(cons
                                                                            int64_t outer, int64_t C, int64_t inner,
                                                                            float* out, const InitGate gate) {
   constexpr int W = kMaxabsThreads / kWave;
-  gate_open<GATED>(gate, C, kMaxabsThreads, [&](int64_t i) { gate_store(&out[i], 0.0f); });
+  auto init = [&](int64_t i) { gate_store(&out[i], 0.0f); };
+  gate_open<GATED>(gate, C, init);
   unsigned seen = ~gate.epoch;   // not the epoch: a workgroup that never peeks must wait
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int64_t col0 = ((int64_t)blockIdx.x * kWave + lane) * 8;
@@ -365,7 +405,7 @@ __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(cons
         const int64_t r = o + u * W < outer ? o + u * W : outer - 1;
         raw[u] = load8_raw<DT>(in, r * plane + col0);
       }
-      seen = gate_peek<GATED>(gate, seen);
+      seen = gate_peek<GATED>(gate, seen, raw[0].a.x);
 #pragma unroll
       for (int u = 0; u < U; u++) {
         if (PK) {
@@ -382,7 +422,7 @@ __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(cons
   __shared__ uint32_t sm[W][NW][kWave];  // [wave][dword of the lane][lane]: conflict-free writes and reads
 #pragma unroll
   for (int k = 0; k < NW; k++) sm[w][k][lane] = m[k];
-  gate_wait<GATED>(gate, seen);   // thread 0; the barrier carries it to the threads that issue the atomics
+  gate_wait<GATED>(gate, seen, C, init);   // wave 0; the barrier carries it to the threads that issue the atomics
   __syncthreads();
   // the strip's 512 columns over the first 512 threads (8 waves), each combining the W partial maxima of its column
   if (threadIdx.x < 8 * kWave) {
@@ -474,7 +514,8 @@ __global__ __launch_bounds__(kHistThreads) void histc_kernel(const void* __restr
                                                              float lo, float hi, int vec, uint32_t* counts, const InitGate gate) {
   constexpr int dt = DT;
   extern __shared__ uint32_t s_hist[];
-  gate_open<GATED>(gate, bins, kHistThreads, [&](int64_t i) { __hip_atomic_store(&counts[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
+  auto init = [&](int64_t i) { __hip_atomic_store(&counts[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  gate_open<GATED>(gate, bins, init);
   unsigned seen = ~gate.epoch;
   for (int b = threadIdx.x; b < bins; b += kHistThreads) s_hist[b] = 0;
   __syncthreads();
@@ -489,7 +530,7 @@ __global__ __launch_bounds__(kHistThreads) void histc_kernel(const void* __restr
       Raw8<DT> raw[U];
 #pragma unroll
       for (int u = 0; u < U; u++) raw[u] = load8_raw<DT>(in, (t + u * stride < nv ? t + u * stride : t) * 8);
-      seen = gate_peek<GATED>(gate, seen);
+      seen = gate_peek<GATED>(gate, seen, raw[0].a.x);
 #pragma unroll
       for (int u = 0; u < U; u++) {
         if (u == 0 || t + u * stride < nv) {
@@ -504,7 +545,7 @@ __global__ __launch_bounds__(kHistThreads) void histc_kernel(const void* __restr
   } else {
     for (int64_t e = t0; e < n; e += stride) hist_add<FAST>(s_hist, load_rt(in, dt, e), lo, hi, fb, width, bins);
   }
-  gate_wait<GATED>(gate, seen);   // thread 0; the barrier carries it to everyone
+  gate_wait<GATED>(gate, seen, bins, init);   // wave 0; the barrier carries it to everyone
   __syncthreads();
   for (int b = threadIdx.x; b < bins; b += kHistThreads) {
     const uint32_t c = s_hist[b];
@@ -524,12 +565,15 @@ namespace {
 struct GateDevice {
   unsigned* flags = nullptr;
   bool failed = false;
-  std::unordered_map<hipStream_t, int> slot_of;
+  std::unordered_map<unsigned long long, int> slot_of;   // stream key (see take_gate) -> slot
   std::vector<unsigned> epoch;
 };
 constexpr int kGateDevices = 64;
 std::mutex g_gate_mu;
 GateDevice g_gate[kGateDevices];
+// 0: gate on; 1: off (the fill launch in front of every reduction); 2: on, workgroup (0, 0) does not volunteer (tests: every launch
+// takes the takeover path).  Initial value from DMXQ_NO_INIT_GATE (set and not "0": off).
+int g_gate_mode = [] { const char* e = getenv("DMXQ_NO_INIT_GATE"); return (e && e[0] && !(e[0] == '0' && !e[1])) ? 1 : 0; }();
 
 InitGate take_gate(hipStream_t s, int64_t n_out) {
   const InitGate none{nullptr, 0u, 0};
@@ -537,12 +581,27 @@ InitGate take_gate(hipStream_t s, int64_t n_out) {
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return none; }
   if (cap != hipStreamCaptureStatusNone) return none;
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kGateDevices) { (void)hipGetLastError(); return none; }
+  // the slot belongs to the STREAM's device (not the thread's current one) and to the stream's id
+  hipDevice_t dev = -1;
+  if (hipStreamGetDevice(s, &dev) != hipSuccess || dev < 0 || dev >= kGateDevices) { (void)hipGetLastError(); return none; }
+  // hipStreamGetId (HIP 7.1) where the loaded runtime has it -- resolved at run time: torch's bundled libamdhip64 is 7.0 and a link-time
+  // reference would keep the library from loading there --, else the handle (a handle is only reused after its stream's work is done)
+  typedef hipError_t (*stream_id_fn)(hipStream_t, unsigned long long*);
+  static const stream_id_fn get_id = (stream_id_fn)dlsym(RTLD_DEFAULT, "hipStreamGetId");
+  unsigned long long sid = (unsigned long long)(uintptr_t)s;
+  if (get_id && s != nullptr) {
+    unsigned long long id = 0ull;
+    if (get_id(s, &id) == hipSuccess) sid = (id << 1) | 1ull;   // (odd: never equal to a handle, which is at least 2-byte aligned)
+    else (void)hipGetLastError();
+  }
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return none; }
   std::lock_guard<std::mutex> lk(g_gate_mu);
+  if (g_gate_mode == 1) return none;
   GateDevice& G = g_gate[dev];
   if (G.failed) return none;
   if (!G.flags) {
+    if (cur != (int)dev) return none;   // (the flag words are allocated from a call whose current device is the stream's)
     // (another thread capturing in global mode makes hipMalloc fail: the fill launch serves until a later call succeeds)
     unsigned* p = nullptr;
     const size_t bytes = (size_t)kGateSlots * kGateStride * sizeof(unsigned);
@@ -552,18 +611,26 @@ InitGate take_gate(hipStream_t s, int64_t n_out) {
     G.epoch.assign(kGateSlots, 0u);
   }
   int slot;
-  auto it = G.slot_of.find(s);
+  auto it = G.slot_of.find(sid);
   if (it != G.slot_of.end()) slot = it->second;
   else {
     if ((int)G.slot_of.size() >= kGateSlots) return none;
     slot = (int)G.slot_of.size();
-    G.slot_of.emplace(s, slot);
+    G.slot_of.emplace(sid, slot);
   }
   unsigned e = ++G.epoch[slot];
   if (e == 0u) e = ++G.epoch[slot];
-  return InitGate{G.flags + (size_t)slot * kGateStride, e, 1};
+  return InitGate{G.flags + (size_t)slot * kGateStride, e, g_gate_mode == 2 ? 2 : 1};
 }
 }  // namespace
+
+// Test / diagnosis hook (not part of include/dmxq.h): 0 gate on, 1 gate off, 2 gate on without the volunteer; returns the old mode
+extern "C" int dmxq_internal_gate_mode(int mode) {
+  std::lock_guard<std::mutex> lk(g_gate_mu);
+  const int old = g_gate_mode;
+  if (mode >= 0 && mode <= 2) g_gate_mode = mode;
+  return old;
+}
 
 // FILL: mn / mx are initialised to +inf / -inf by a first launch (dmxq_group_minmax); without it the kernel's atomics fold this
 // tensor's extrema INTO the values already there (dmxq_group_minmax_accumulate: a running min / max updated in ONE launch)

@@ -39,6 +39,29 @@ struct OpPrep<OP, std::void_t<typename OP::Prep>> {
 template <class OP, class = void> struct OpTilePrep { static constexpr bool value = false; };
 template <class OP> struct OpTilePrep<OP, std::void_t<decltype(OP::kTilePrep)>> { static constexpr bool value = OP::kTilePrep; };
 
+// Optional straight-line tile forms: an OP with `static constexpr int kTileVariants = 3` offers, for tiles whose side data came from
+// tile_prepare, `int tile_variant(Prep&) const` (wave-uniform; 0 = the general apply_vec; may complete the Prep, e.g. a reciprocal),
+// `bool apply_vec_tile<V>(x, y, prep)` for V = 1, 2 -- true: this lane's vector needs `apply_vec_exact(x, y, e0, prep)` instead, which
+// the kernel runs in one cold loop after the tile's store burst.  One scalar branch per TILE picks the body, nothing per vector.
+template <class OP, class = void> struct OpTileVariants { static constexpr int value = 1; };
+template <class OP> struct OpTileVariants<OP, std::void_t<decltype(OP::kTileVariants)>> { static constexpr int value = OP::kTileVariants; };
+
+template <class OP, class = void> struct OpWaitAll { static constexpr bool value = false; };
+template <class OP> struct OpWaitAll<OP, std::void_t<decltype(OP::kWaitAll)>> { static constexpr bool value = OP::kWaitAll; };
+
+template <int V, class OP, class PREP, int N>
+__device__ __forceinline__ void tile_apply(const OP& op, const float (&x)[N], float (&y)[N], int64_t e0, const PREP& p) {
+  OpPrep<OP>::apply(op, x, y, e0, p);
+}
+template <int V, class OP, class PREP, int N>
+__device__ __forceinline__ bool tile_apply_flag(const OP& op, const float (&x)[N], float (&y)[N], const PREP& p) {
+  return op.template apply_vec_tile<V>(x, y, p);
+}
+template <class OP, class PREP, int N>
+__device__ __forceinline__ void tile_apply_exact(const OP& op, const float (&x)[N], float (&y)[N], int64_t e0, const PREP& p) {
+  op.apply_vec_exact(x, y, e0, p);
+}
+
 // Optional raw-word hooks (act_cast.hip): an OP with `static constexpr bool kRawHooks = true` sees every 16-byte input vector
 // before it is widened (raw_in) and every packed output vector before it is stored (raw_out) -- the range-only casts of 16-bit
 // tensors act on the packed words (common.hpp range16_word), two elements per operation.
@@ -84,39 +107,94 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict_
       // load burst + compute + store burst of a full tile, with the per-vector side data coming from prep_of(u).  The side data
       // (scale / zero-point reads) is requested BEFORE the tile's own loads: vector memory returns in order, so behind them it
       // would only arrive after the whole tile, and the first vector's arithmetic could not start while the rest streams in.
-      auto finish = [&](auto prep_of) __attribute__((always_inline)) {
+      u32x4 raw[UNROLL];
+      auto load_tile = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
-        u32x4 raw[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) raw[u] = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
         __builtin_amdgcn_sched_barrier(0);
+      };
+      // `variant`: std::integral_constant<int, V>; V = 0 is the op's general per-vector form, V > 0 a straight-line form the op
+      // offers for tiles whose (wave-uniform) side data allows it (OpTileVariants below)
+      auto finish = [&](auto prep_of, auto variant) __attribute__((always_inline)) {
+        constexpr int V = decltype(variant)::value;
         OutVec<DTO, EPL> o[UNROLL];
+        uint32_t redo = 0u;  // (V > 0) bit u: this lane's vector u needs the op's exact form
+#ifdef DMXQ_EXP_WAITALL_ALL
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+        if constexpr (V == 0 && OpWaitAll<OP>::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // The whole tile's data before the first vector's arithmetic (round 5).  Left to the compiler the waits are per vector
+        // (vmcnt(15), (14), ...): a wave then starts converting while the rest of its tile -- and the other workgroups' tiles -- still
+        // stream in, finishes early and starts STORING while others still read.  Measured on the INT8 group cast, 4096 x 4096 bf16,
+        // 128 x 16 tiles: 13.06 us per-vector waits, 11.48 us with this one wait (tools/tune_stream, -DDMXQ_EXP_*): read bursts
+        // followed by write bursts, the finding of the BFP kernel's tile schedule, applies inside a tile's wait
+        // pattern too.  Per op, measured (profiles/r05_tune_stream_waitall.txt): light ops gain 3-8 % (INT8 without a scale 11.06 -> 10.68 us,
+        // the FLOAT16 cast of float32 tensors 12.04 -> 11.00), VALU-heavy ones on deep tiles LOSE 5-15 % (SiLU 512 x 16 11.35 -> 12.91:
+        // their arithmetic no longer overlaps the tail of the loads) -- hence a trait (`static constexpr bool kWaitAll = true`), not a rule.
+        if constexpr (V > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
           float x[EPL], y[EPL];
           if constexpr (OpRawHooks<OP>::value) op.raw_in(raw[u]);
           stream_widen<DTI, EPL>(raw[u], x);
-          OpPrep<OP>::apply(op, x, y, (v0 + (int64_t)u * THREADS) * EPL, prep_of(u));
+          if constexpr (V == 0) tile_apply<V>(op, x, y, (v0 + (int64_t)u * THREADS) * EPL, prep_of(u));
+          else redo |= tile_apply_flag<V>(op, x, y, prep_of(u)) ? 1u << u : 0u;
           o[u] = pack_vec<DTO, EPL>(y);
           if constexpr (OpRawHooks<OP>::value) op.raw_out(o[u]);
+#ifdef DMXQ_EXP_NOFENCE
+          if constexpr (V == 0) __builtin_amdgcn_sched_barrier(0);
+#else
           __builtin_amdgcn_sched_barrier(0);
+#endif
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) store_out<DTO, EPL, true, UNAL>(dst + u * (THREADS * OVB) + lane_out, o[u]);
+        if constexpr (V > 0) {
+          // The straight-line forms do not cover every input (Inf / NaN quotients): flagged vectors are redone AFTER the store burst,
+          // from a fresh load, and stored again by the same lane (same-address stores of a lane stay ordered) -- ONE cold loop per
+          // tile.  Redone in place behind a branch per vector, the compiler laid 16 cold blocks of ~250 instructions between the hot
+          // ones: the tile body no longer fitted the instruction cache (INT8 per group, zero point 0: 12.2 us where the form WITH
+          // a zero point, whose cold blocks happened to be placed out of line, ran 11.6; tools/tune_stream int8g0 / int8g).
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo != 0u) != 0ull, 0)) {
+#pragma unroll 1
+            for (int u = 0; u < UNROLL; u++) {
+              if ((redo >> u) & 1u) {
+                const u32x4 r1 = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
+                float x[EPL], y[EPL];
+                stream_widen<DTI, EPL>(r1, x);
+                tile_apply_exact(op, x, y, (v0 + (int64_t)u * THREADS) * EPL, prep_of(u));
+                store_out<DTO, EPL, true, UNAL>(dst + u * (THREADS * OVB) + lane_out, pack_vec<DTO, EPL>(y));
+              }
+            }
+          }
+        }
       };
       if constexpr (OpTilePrep<OP>::value) {
         // the whole tile shares one set of side data (one quantisation group): fetched once, from a wave-uniform address,
         // instead of an index computation and two dependent loads per 16-byte vector
         typename OP::Prep tp;
         if (op.tile_prepare(tile * (TILE * EPL), TILE * EPL, tp)) {  // wave-uniform
-          finish([&](int) -> const typename OP::Prep& { return tp; });
+          load_tile();
+          auto pf = [&](int) -> const typename OP::Prep& { return tp; };
+          if constexpr (OpTileVariants<OP>::value == 3) {
+            // (the scalar table reads are waited for HERE, behind the tile's loads)
+            const int v = op.tile_variant(tp);  // (also completes tp)
+            if (v == 2) finish(pf, std::integral_constant<int, 2>{});
+            else if (v == 1) finish(pf, std::integral_constant<int, 1>{});
+            else finish(pf, std::integral_constant<int, 0>{});
+          } else {
+            finish(pf, std::integral_constant<int, 0>{});
+          }
           continue;
         }
       }
       typename OpPrep<OP>::type prep[UNROLL];
 #pragma unroll
       for (int u = 0; u < UNROLL; u++) prep[u] = OpPrep<OP>::get(op, (v0 + (int64_t)u * THREADS) * EPL);
-      finish([&](int u) -> const typename OpPrep<OP>::type& { return prep[u]; });
+      load_tile();
+      finish([&](int u) -> const typename OpPrep<OP>::type& { return prep[u]; }, std::integral_constant<int, 0>{});
     } else {
       // the last, partial tile, vector by vector.  (The hot BFP kernel runs its partial tile on the full tile's schedule, in a function
       // of its own -- bfp_rows_tile_partial.  The same here measured a DISASTER: with a non-inlined call in the kernel the full tiles
@@ -244,6 +322,12 @@ struct ChannelMap {
   int64_t C, inner, group_size;
   int small;  // 1: n < 2^31, 32-bit index arithmetic
   FastDiv31 f_inner, f_C, f_gs;
+  // Whole groups of equal length (C % group_size == 0, or a single group): the tensor is a sequence of RUNS of run = group_size * inner
+  // contiguous elements, run k belonging to group k % G.  run_align = the largest power of two dividing run (0: not applicable):
+  // a power-of-two tile of at most run_align elements starting at a multiple of its length lies inside ONE run, and its group is
+  // two scalar multiply-highs away from the tile index -- no vector instruction ahead of the tile's first load.
+  uint32_t run_align, G;
+  FastDiv31 f_run, f_G;
 };
 
 struct ChanIter {

@@ -58,10 +58,41 @@ class MinMaxObserver(ObserverBase):
             raise NotImplementedError("MinMaxObserver does not support qscheme: torch.per_channel_affine_float_qparams")
         self.register_buffer("min_val", torch.tensor(float("inf")))
         self.register_buffer("max_val", torch.tensor(float("-inf")))
+        self.process_group = None
+
+    def set_process_group(self, process_group):
+        """Sharded calibration: every rank observes a SHARD of the tensor and all ranks hold the same set of groups (per tensor; per
+        channel along an axis that is not the sharded one) -- after each step the running minima / maxima are completed over the
+        group with one all_reduce(MIN) and one all_reduce(MAX) of `[n_groups]` floats (`parallel.WORLD` = the default group; None =
+        off).  Groups that live inside one rank's shard (slabs along the sharded axis) need no exchange: leave it off."""
+        self.process_group = process_group
+
+    def _exchange(self):
+        if self.process_group is not None and self.min_val.dim() == self.max_val.dim() and self.min_val.is_floating_point():
+            from . import parallel
+
+            g = parallel.resolve_group(self.process_group)
+            parallel.allreduce_min_(self.min_val, g)
+            parallel.allreduce_max_(self.max_val, g)
 
     def forward(self, x, group_size: Optional[int] = None):
         if x.numel() == 0:
-            return x
+            if self.process_group is None:
+                return x
+            # an empty shard still takes part in the exchange, with the identities in the shape the other ranks hold
+            if group_size or self.qscheme in _PER_CHANNEL:
+                n_groups = -(-x.shape[self.ch_axis] // (group_size or 1)) if x.dim() else 1
+                if self.min_val.dim() == 0 and n_groups > 0:
+                    self.min_val = torch.full((n_groups,), float("inf"), device=x.device)
+                    self.max_val = torch.full((n_groups,), float("-inf"), device=x.device)
+            else:
+                self.min_val, self.max_val = self.min_val.to(x.device), self.max_val.to(x.device)
+        else:
+            self._observe(x, group_size)
+        self._exchange()
+        return x
+
+    def _observe(self, x, group_size: Optional[int] = None):
         xd = x.detach()
         # the running state has this observation's shape already (every call after the first): ONE launch folds the tensor's extrema
         # into it (dmxq_group_minmax_accumulate) -- reduction and `min_val = torch.min(x_min, min_val)` together, no fill launch

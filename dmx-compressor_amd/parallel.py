@@ -54,6 +54,28 @@ def allreduce_max_(v: torch.Tensor, group=None) -> torch.Tensor:
     return v
 
 
+def allreduce_min_(v: torch.Tensor, group=None) -> torch.Tensor:
+    """in-place MIN all-reduce (the running minimum of a per-tensor MinMaxObserver whose tensor is sharded over the ranks)"""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if _host_staged(v, group):
+            h = v.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MIN, group=group)
+            v.copy_(h)
+        else:
+            dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
+    return v
+
+
+WORLD = "world"   # `process_group=parallel.WORLD`: the default process group (torch.distributed spells that `None`, which here means "no exchange")
+
+
+def resolve_group(process_group):
+    """the `group=` argument torch.distributed expects for a module's `process_group` attribute"""
+    return None if isinstance(process_group, str) and process_group == WORLD else process_group
+
+
 def gather_rows(shard: torch.Tensor, n_rows: int, world: int, multiple: int = 1, group=None) -> torch.Tensor:
     """all-gather of row shards back into the full tensor (harness-only: result checks)"""
     import torch.distributed as dist

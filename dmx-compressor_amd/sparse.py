@@ -192,28 +192,53 @@ class Sparsify(torch.nn.Module):
     mask on every forward and multiplies.  Reference quirk kept: a `score_func` result
     is used for exactly one forward and never written back to `self.score`."""
 
+    # which of (x, score) receive a gradient through x * mask, per backward mode (sparse.py:266-275)
+    _GRADIENT_ROUTES = {"ste": (True, False), "supermask": (False, True), "joint": (True, True)}
+
     def __init__(self, tensor_shape, sparseness="DENSE", backward_mode="STE", score_func=None):
         super().__init__()
-        self.score = torch.nn.Parameter(torch.rand(tensor_shape), requires_grad=True)
-        self.mask = None
-        self.configure(sparseness, backward_mode, score_func)
-        self.plastic = False
+        self.mask, self.plastic = None, False
+        self.score = torch.nn.Parameter(torch.rand(tensor_shape), requires_grad=True)   # uniform-random until trained / assigned
+        self._set_sparseness(sparseness)
+        self._set_backward_mode(backward_mode)
+        if score_func is not None:
+            self.score_func = score_func   # (the constructor does NOT arm the one-shot rewiring: only configure() does)
+
+    # configure(): every argument optional, each with a setter of its own
+    def _set_sparseness(self, spec):
+        new = Sparseness.from_shorthand(spec)
+        current = getattr(self, "sparseness", None)
+        if current is None or repr(current) != repr(new):   # the shorthand is the identity of a sparseness
+            self.sparseness = new
+
+    def _set_backward_mode(self, mode):
+        self.backward_mode = mode
+        self.enable_weight_gradient, self.enable_mask_gradient = self._GRADIENT_ROUTES.get(mode.lower(), (False, False))
 
     def configure(self, sparseness=None, backward_mode=None, score_func=None):
         if sparseness is not None:
-            sparseness = Sparseness.from_shorthand(sparseness)
-            if not hasattr(self, "sparseness") or repr(sparseness) != repr(self.sparseness):
-                self.sparseness = sparseness
+            self._set_sparseness(sparseness)
         if backward_mode is not None:
-            self.backward_mode = backward_mode
-            self.enable_weight_gradient = backward_mode.lower() in {"ste", "joint"}
-            self.enable_mask_gradient = backward_mode.lower() in {"supermask", "joint"}
+            self._set_backward_mode(backward_mode)
         if score_func is not None:
-            self.score_func = score_func
-            self.plastic = True  # rewire on the next forward()
+            self.score_func, self.plastic = score_func, True   # the next forward scores through it, once (quirk above)
 
     def update_mask(self, score):
         self.mask = self.sparseness.get_mask(score)
+
+    @property
+    def density(self):
+        """the sparseness' nominal density, or -- where it has none -- the measured one of the mask the stored score gives
+        (which also becomes `self.mask`, as in the reference: sparse.py:303-308)"""
+        nominal = self.sparseness.density
+        if nominal is not None:
+            return nominal
+        self.update_mask(self.score)
+        kept = self.mask.data
+        return kept.sum() / kept.numel()
+
+    def extra_repr(self):
+        return f"sparseness = {self.sparseness!r}, backward_mode = {self.backward_mode}"
 
     def forward(self, x):
         if isinstance(self.sparseness, Dense):
@@ -245,12 +270,3 @@ class Sparsify(torch.nn.Module):
         self.mask = mask
         return y
 
-    @property
-    def density(self) -> float:
-        if self.sparseness.density is not None:
-            return self.sparseness.density
-        self.update_mask(self.score)
-        return self.mask.data.sum() / self.mask.numel()
-
-    def extra_repr(self):
-        return f"sparseness = {self.sparseness.__repr__()}, backward_mode = {self.backward_mode}"

@@ -394,25 +394,33 @@ def test_hot_kernel_tile_plans(dmx, cuda, rows, dtype):
 @pytest.mark.parametrize("rows", [2561, 2700, 2816, 2817, 3100, 3400, 3700, 3950, 4097, 4100, 4353, 4608, 4609, 4864, 4865, 5000, 5120, 5121])
 @pytest.mark.parametrize("dtype", [BF16, F16], ids=["bf16", "f16"])
 def test_exact_depth_one_round_plans_against_the_oracle(dmx, cuda, oracle, rows, dtype):
-    if dtype == F16 and rows not in (2700, 3400, 4100, 4609, 4865, 5120):
-        pytest.skip("float16: one size per kernel family (the bf16 run covers every boundary)")
     """Round 4: 20-40 MiB of a 16-bit tensor run as ONE round of <= 256 workgroups whose depth is exactly what that takes -- 11 .. 20
     vectors per lane (csrc/common.hpp rows_plan; 19 and 20 through the compact kernel, results in place of the raw vectors) -- and the last, partial tile of any tensor runs on the
     same schedule with predicated loads and stores (bfp_rows_tile_partial; it used to run vector by vector).  Both sides of class
-    boundaries, nearly empty and nearly full last tiles, directly against the CPU oracle; the builds that do NOT take these plans
-    (asymmetric, widening, other rounding) on the same tensors through the slab identity."""
+    boundaries, nearly empty and nearly full last tiles, directly against the CPU oracle, for both 16-bit dtypes (the float16 builds
+    are distinct code objects: round 4 skipped 12 of their sizes).  Round 5: the builds that do NOT take these plans -- asymmetric,
+    widening (16-bit -> float32), rounding down / up (compile-time modes since round 5, on the 512 x 4 ... 512 x 16 plans) and
+    stochastic -- are compared with the ORACLE once per depth class as well (round 4: the slab identity, HIP against HIP)."""
     ops = dmx.ops
     xh = _input(rows, dtype, seed=11 * rows)
     x = xh.to(cuda)
     for B in (16, 128):
         bad = bits_equal(ops.bfp_qdq(x, 8, B), oracle.bfp_cast(xh, 8, B, -1).to(dtype))
         assert bad == 0, f"BFP[8|8]{{{B}}} {dtype} rows={rows}: {bad} elements differ from the oracle"
-    if rows in (2817, 4100, 4609, 5000):
+    if rows in (2700, 2817, 3100, 3400, 3700, 3950, 4100, 4353, 4609, 5000):   # one size per depth class 11 .. 20
         bad = bits_equal(ops.bfp_qdq(x, 4, 32), oracle.bfp_cast(xh, 4, 32, -1).to(dtype))
         assert bad == 0, f"BFP[4|8]{{32}} {dtype} rows={rows}: {bad} elements differ from the oracle"
-        for tag, fn in {"asym": lambda t: ops.bfp_qdq(t, 8, 64, symmetric=False), "-> f32": lambda t: ops.bfp_qdq(t, 8, 64, out_dtype=F32),
-                        "down": lambda t: ops.bfp_qdq(t, 8, 32, rounding="down")}.items():
-            _check(f"{tag} {dtype} rows={rows}", fn(x), _slabs(fn, x))
+        others = {
+            "asym": (lambda t: ops.bfp_qdq(t, 8, 64, symmetric=False), lambda t: oracle.bfp_cast(t, 8, 64, -1, symmetric=False).to(dtype)),
+            "-> f32": (lambda t: ops.bfp_qdq(t, 8, 64, out_dtype=F32), lambda t: oracle.bfp_cast(t, 8, 64, -1)),
+            "down": (lambda t: ops.bfp_qdq(t, 8, 32, rounding="down"), lambda t: oracle.bfp_cast(t, 8, 32, -1, rounding="down").to(dtype)),
+            "up": (lambda t: ops.bfp_qdq(t, 8, 16, rounding="up"), lambda t: oracle.bfp_cast(t, 8, 16, -1, rounding="up").to(dtype)),
+            "stochastic": (lambda t: ops.bfp_qdq(t, 8, 16, rounding="stochastic", seed=rows),
+                           lambda t: oracle.bfp_cast(t, 8, 16, -1, rounding="stochastic", seed=rows).to(dtype)),
+        }
+        for tag, (fn, ref) in others.items():
+            bad = bits_equal(fn(x), ref(xh))
+            assert bad == 0, f"{tag} {dtype} rows={rows}: {bad} elements differ from the oracle"
 
 
 @pytest.mark.parametrize("rows", [2700, 3001, 3400, 3840])

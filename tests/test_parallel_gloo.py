@@ -45,6 +45,46 @@ def _worker(rank, world, port, q):
         # 5. bench-style timing reduction: max over ranks
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         ok &= float(P.allreduce_max_(t)) == float(world)
+        # 6. the same exchange THROUGH THE PRODUCT's host code (smoothquant.py / observer.py `set_process_group`): the module calls
+        #    parallel.allreduce_max_ / allreduce_min_ itself.  No GPU here, so the module's kernel front end is swapped for the oracle
+        #    (test infrastructure standing in for the launches; the GPU twin is tests/test_gpu_multi_gpu.py).
+        from types import SimpleNamespace
+
+        import dmx_compressor_amd as dmx
+        import dmx_compressor_amd.observer as obs_mod
+        import dmx_compressor_amd.smoothquant as sq_mod
+
+        def sq_scale(a, b, alpha, smin):
+            return torch.clamp(a.pow(alpha) / torch.clamp(b, min=smin).pow(1.0 - alpha), min=smin)
+
+        sq_mod.ops = SimpleNamespace(channel_maxabs=O.channel_maxabs, smoothquant_scale=sq_scale)
+        obs_mod.ops = SimpleNamespace(group_minmax=O.group_minmax)
+        inp = make("heavy", (19, 24), seed=4)
+        shard = P.my_rows(w, rank, world)
+        sq = dmx.ActivationWeightSmoothQuant(ch_axis=-1, win_ch_axis=-1)
+        sq.set_process_group(P.WORLD, weight=True, input=False)
+        sq(inp, shard)
+        ok &= torch.equal(sq.weight_maxabs, O.channel_maxabs(w, -1))
+        ok &= torch.equal(sq.scale, sq_scale(O.channel_maxabs(inp, -1), O.channel_maxabs(w, -1), 0.5, 1e-5))
+        sq2 = dmx.ActivationWeightSmoothQuant(ch_axis=-1, win_ch_axis=-1)   # tokens sharded too
+        sq2.set_process_group(P.WORLD, weight=True, input=True)
+        sq2(P.my_rows(inp, rank, world), shard)
+        ok &= torch.equal(sq2.scale, sq.scale)
+        sq3 = dmx.ActivationWeightSmoothQuant(ch_axis=-1, win_ch_axis=-1)   # no group: the shard's own maxima, another scale
+        sq3(inp, shard)
+        ok &= not torch.equal(sq3.scale, sq.scale)
+        mm = dmx.MinMaxObserver(qscheme=torch.per_tensor_symmetric)
+        mm.set_process_group(P.WORLD)
+        mm(shard)
+        ok &= float(mm.min_val) == float(w.min()) and float(mm.max_val) == float(w.max())
+        pc = dmx.MinMaxObserver(qscheme=torch.per_channel_symmetric, ch_axis=-1)  # per input channel over row shards: same groups on every rank
+        pc.set_process_group(P.WORLD)
+        pc(shard)
+        ok &= torch.equal(pc.min_val, w.amin(0)) and torch.equal(pc.max_val, w.amax(0))
+        empty = dmx.MinMaxObserver(qscheme=torch.per_channel_symmetric, ch_axis=-1)   # a rank with an EMPTY shard still takes part
+        empty.set_process_group(P.WORLD)
+        empty(w[:5] if rank == 0 else w[:0])
+        ok &= torch.equal(empty.min_val, w[:5].amin(0)) and torch.equal(empty.max_val, w[:5].amax(0))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

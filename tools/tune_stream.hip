@@ -48,10 +48,12 @@ int main(int argc, char** argv) {
   float* d_scale; int64_t* d_zp;
   CK(hipMalloc(&d_scale, G * 4)); CK(hipMalloc(&d_zp, G * 8));
   CK(hipMemcpy(d_scale, hs.data(), G * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_zp, hz.data(), G * 8, hipMemcpyHostToDevice));
+  int64_t* d_zp0; CK(hipMalloc(&d_zp0, G * 8)); CK(hipMemset(d_zp0, 0, G * 8));  // symmetric schemes: every zero point 0
   printf("# rows %lld C %lld nbuf %d\n", (long long)rows, (long long)C, NBUF);
   hipStream_t st; CK(hipStreamCreate(&st));
   const FixedFmt fx{0, 1, DMXQ_ROUND_NEAREST, -128.0f, 127.0f, 0ull};  // INT8: fraction 0, clamped, nearest
   const FixedOp<kUniform, true> int8g{fx, make_channel_map(rows, C, 128, n), d_scale, d_zp};   // [1, rows, C], groups of 128 rows
+  const FixedOp<kUniform, true> int8g0{fx, make_channel_map(rows, C, 128, n), d_scale, d_zp0};
   const FixedOp<kNone, true> int8n{fx, make_channel_map(1, 1, 1, n), nullptr, nullptr};
   const FloatFmt e4{3, 4, 7, 0, 0, DMXQ_ROUND_NEAREST, 0ull};
   const FloatOp<DMXQ_ROUND_NEAREST> e4m3{e4, make_float_fast(3, 4, 7), make_flush_fast(3, 4, 7, 0)};
@@ -103,6 +105,9 @@ int main(int argc, char** argv) {
     ADD_SMALL("int8g ", int8g); ADD_HEAVY("int8g ", int8g); ADD_SMALL("silu  ", silu); ADD_HEAVY("silu  ", silu); ADD_SMALL("gelu_m", gelum); ADD_HEAVY("gelu_m", gelum); }
   if (ss == "block") { ADD_HEAVY("mxfp8 ", mxfp); ADD_HEAVY("sbfp  ", sbfp); }
   if (ss == "f32") { ADD_ALL32("f16c32", f16cast); ADD_ALL32("gelm32", gelum32); ADD_ALL32("silm32", silum32); }
+  if (ss == "int8g") { ADD_ST("int8g ", int8g, 64, 16); ADD_ST("int8g ", int8g, 128, 8); ADD_ST("int8g ", int8g, 128, 16); ADD_ST("int8g ", int8g, 256, 8); ADD_ST("int8g ", int8g, 256, 16); ADD_ST("int8g ", int8g, 512, 16); ADD_ST("int8g ", int8g, 256, 2); ADD_ST("int8g ", int8g, 512, 2);
+    ADD_ST("int8g0", int8g0, 64, 16); ADD_ST("int8g0", int8g0, 128, 8); ADD_ST("int8g0", int8g0, 128, 16); ADD_ST("int8g0", int8g0, 256, 8); ADD_ST("int8g0", int8g0, 256, 16); ADD_ST("int8g0", int8g0, 512, 16); ADD_ST("int8g0", int8g0, 256, 2); ADD_ST("int8g0", int8g0, 512, 2);
+    ADD_ST("int8n ", int8n, 64, 16); ADD_ST("int8n ", int8n, 128, 16); }
   if (ss.empty() || ss == "fixed") { ADD_ALL("int8g ", int8g); ADD_ALL("int8n ", int8n); ADD_HEAVY("e4m3  ", e4m3); }
   if (ss.empty() || ss == "unary") { ADD_ALL("silu  ", silu); ADD_HEAVY("qgelu ", qgelu); ADD_ALL("gelu  ", gelu); ADD_ALL("gelu_m", gelum); ADD_ALL("silu_m", silum); }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
