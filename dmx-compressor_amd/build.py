@@ -15,8 +15,11 @@ LIB = os.path.join(HERE, "lib", "libdmxq.so")
 TORCH_LIB = os.path.join(HERE, "lib", "dmxq_torch.so")
 # "file.hip" or "file.hip#N": the file compiled with -DDMXQ_EW_PART=N into file_pN.o (elementwise.hip: three objects, approx.hip: two, in parallel)
 SOURCES = ["bfp.hip#1", "approx.hip#3", "approx.hip#5", "approx.hip#1", "approx.hip#2", "approx.hip#4", "elementwise.hip#2", "elementwise.hip#1", "elementwise.hip#3", "bfp_cols.hip#1", "bfp_cols.hip#2", "bfp_cols.hip#3", "bfp.hip#2", "bfp.hip#3", "bfp_urows.hip", "bfp_smallinner.hip", "blockfmt.hip", "bfp_pack.hip", "hypernet.hip", "hypernet_multi.hip", "nm_mask.hip", "topk.hip", "reduce.hip", "unary.hip", "act_cast.hip", "lut16.hip", "fixed_multi.hip", "rope.hip"]
-# bit-exact fp32: no fast-math, no fma contraction; fp32 denormals stay on (gfx950 default)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
+# bit-exact fp32: no fast-math, no fma contraction; fp32 denormals stay on (gfx950 default).
+# --offload-compress (round 5): the gfx950 code objects are stored zstd-compressed inside the fat binary and unpacked by the HIP runtime at
+# load: libdmxq.so 88 MB -> 17 MB (what a gpurun snapshot pushes, what a wheel would ship), load time and kernels unchanged
+# (profiles/r05_lib_size.txt).
+FLAGS = ["--offload-arch=gfx950", "--offload-compress", "-O3", "-fPIC", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
          "-fgpu-flush-denormals-to-zero" if False else "-fno-gpu-flush-denormals-to-zero"]
 
 
@@ -101,7 +104,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs = list(ex.map(compile_one, srcs))
         binding_obj = binding.result()
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "--offload-compress", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -74,9 +74,9 @@ __global__ __launch_bounds__(kThreads) void bfp_generic_kernel(const void* __res
       const float x = load1<DTI>(in, e);
       if (NATIVE && x == -u2f(mb) && ((mb >> 16) & 0x7Fu) == 0x7Fu) {
         const BfpBlockParams pe = bfp_block_params<false>(((mb >> 23) + 1u) << 23, wl);
-        store1<DTO>(out, e, bfp_q1<RND, false>(x, pe, wl, rounding, rnd_if(stoch, seed, ridx)));
+        store1<DTO>(out, e, bfp_q1<RND, false>(x, pe, wl, rounding, bfp_rnd_if(stoch, seed, ridx)));
       } else {
-        store1<DTO>(out, e, bfp_q1<RND, ASYM>(x, p, wl, rounding, rnd_if(stoch, seed, ridx)));
+        store1<DTO>(out, e, bfp_q1<RND, ASYM>(x, p, wl, rounding, bfp_rnd_if(stoch, seed, ridx)));
       }
     }
   }

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void bfp_cols_kernel(const void* __restri
         for (int k = 0; k < EPL; k++) {
           // the oracle numbers random draws by position in the transposed [outer*inner, L] matrix
           const uint64_t ridx = (uint64_t)((o * inner + ce + k) * L + row0 + r);
-          y[k] = bfp_q1<RND, ASYM>(x[k], p[k], wl, rounding, rnd_if(stoch, seed, ridx));
+          y[k] = bfp_q1<RND, ASYM>(x[k], p[k], wl, rounding, bfp_rnd_if(stoch, seed, ridx));
         }
         if (col_ok && row0 + r < L) store_out<DTO, EPL, true, UNAL>(obase + r * ostride, pack_vec<DTO, EPL>(y));
       }

@@ -49,9 +49,16 @@ __device__ __forceinline__ OutVec<DTO, EPLV> bfp_rows_vector(const u32x4& raw, u
   for (int k = 0; k < EPL; k++) x[k] = xw[k];
   if (PATH_FAST && FAST == 4) {  // any rounding mode: literal rounding, clamp instead of the exponent-field clip
     const int64_t e0 = vi * EPL;
+    if constexpr (RND == DMXQ_ROUND_STOCHASTIC && (EPL == 4 || EPL == 8)) {
+      uint32_t rnd[EPL];
+      bfp_rnd_vec<EPL>(seed, e0, rnd);   // one hash per lane-vector (common.hpp)
 #pragma unroll
-    for (int k = 0; k < EPL; k++)
-      y[k] = bfp_q1_bitfast<RND, ASYM>(x[k], p, wl, rounding, rnd_for<RND>(stoch, seed, (uint64_t)(e0 + k)));
+      for (int k = 0; k < EPL; k++) y[k] = bfp_q1_bitfast<RND, ASYM>(x[k], p, wl, rounding, rnd[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < EPL; k++)
+        y[k] = bfp_q1_bitfast<RND, ASYM>(x[k], p, wl, rounding, bfp_rnd_for<RND>(stoch, seed, (uint64_t)(e0 + k)));
+    }
   } else if (PATH_FAST) {
 #pragma unroll
     for (int k = 0; k < EPL; k++) y[k] = bfp_q1_fast<FAST == 2, ASYM>(x[k], p);
@@ -59,7 +66,7 @@ __device__ __forceinline__ OutVec<DTO, EPLV> bfp_rows_vector(const u32x4& raw, u
     const int64_t e0 = vi * EPL;
 #pragma unroll
     for (int k = 0; k < EPL; k++)
-      y[k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, rnd_for<RND>(stoch, seed, (uint64_t)(e0 + k)));
+      y[k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, bfp_rnd_for<RND>(stoch, seed, (uint64_t)(e0 + k)));
   }
   // single-rounding fast path on a 16-bit input with the same 16-bit output: results are exactly representable
   // (not for asymmetric formats: their extra code -2^(e+1) overflows fp16 at e = 15 and must round to -inf)

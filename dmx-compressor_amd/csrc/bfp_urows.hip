@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void bfp_urows_kernel(const void* __restr
         const BfpBlockParams p = bfp_block_params<ASYM, false>(mb, wl);
 #pragma unroll
         for (int k = 0; k < EPL; k++)
-          y[u][k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, rnd_if(stoch, seed, (uint64_t)(eoff[u] + k)));
+          y[u][k] = bfp_q1<RND, ASYM>(x[k], p, wl, rounding, bfp_rnd_if(stoch, seed, (uint64_t)(eoff[u] + k)));
       }
     }
 #pragma unroll

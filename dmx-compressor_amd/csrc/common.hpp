@@ -43,12 +43,48 @@ __device__ __forceinline__ uint32_t rnd_if(bool stoch, uint64_t seed, uint64_t i
   return r;
 }
 
-// the draw of element `idx` for a kernel built for rounding mode RND (compile time), or for any mode (kRuntimeRounding_: `stoch` says
+// The stochastic draws of the BFP cast (round 5; oracle/oracle.c bfp_rnd is the same function): ONE avalanche hash per aligned group of
+// 8 elements, expanded to the group's four pairs by a Weyl step and a xor-shift, an element taking its pair's word (even index) or that
+// word with its halves swapped (odd index) -- round_bitwise uses the low 23 - wl bits, <= 16 of them for every format with wl >= 7, so
+// the two elements of a pair draw from disjoint halves.  ~4 operations per element when a lane holds the whole group (bfp_rnd_vec)
+// instead of a hash with two quarter-rate multiplies per element (~18 cycles' worth): the stochastic mode of the row kernel was bound by
+// it (50 % of the roofline).  The stream is this library's own -- the reference's is an unseeded global mt19937 -- so kernel and oracle
+// changed together; marginals stay uniform, an element's draw still depends on (seed, linear index) only.
+__device__ __forceinline__ uint32_t bfp_rnd_word(uint32_t h, uint32_t pair) {
+  const uint32_t w = h + pair * 0x9E3779B9u;
+  return w ^ (w >> 15);
+}
+__device__ __forceinline__ uint32_t bfp_rnd(uint64_t seed, uint64_t idx) {
+  const uint32_t w = bfp_rnd_word(rnd_bits(seed, idx >> 3), ((uint32_t)idx & 7u) >> 1);
+  return ((uint32_t)idx & 1u) ? __builtin_amdgcn_alignbit(w, w, 16) : w;
+}
+__device__ __forceinline__ uint32_t bfp_rnd_if(bool stoch, uint64_t seed, uint64_t idx) {
+  uint32_t r = 0u;
+  if (stoch) {
+    r = bfp_rnd(seed, idx);
+    asm volatile("" : "+v"(r));
+  }
+  return r;
+}
+// the draw of element `idx` for a kernel built for rounding mode RND (compile time), or for any mode (kRuntimeRounding: `stoch` says
 // whether the launch is stochastic)
 template <int RND>
-__device__ __forceinline__ uint32_t rnd_for(bool stoch, uint64_t seed, uint64_t idx) {
-  if (RND == -1 /* kRuntimeRounding */) return rnd_if(stoch, seed, idx);
-  return RND == DMXQ_ROUND_STOCHASTIC ? rnd_bits(seed, idx) : 0u;
+__device__ __forceinline__ uint32_t bfp_rnd_for(bool stoch, uint64_t seed, uint64_t idx) {
+  if (RND == -1 /* kRuntimeRounding */) return bfp_rnd_if(stoch, seed, idx);
+  return RND == DMXQ_ROUND_STOCHASTIC ? bfp_rnd(seed, idx) : 0u;
+}
+// EPL (4 or 8) consecutive draws starting at e0, e0 % EPL == 0: one hash, then the expansion
+template <int EPL>
+__device__ __forceinline__ void bfp_rnd_vec(uint64_t seed, int64_t e0, uint32_t (&r)[EPL]) {
+  static_assert(EPL == 4 || EPL == 8, "a lane-vector of 4 or 8 elements");
+  const uint32_t h = rnd_bits(seed, (uint64_t)e0 >> 3);
+  const uint32_t p0 = EPL == 8 ? 0u : ((uint32_t)e0 & 4u) >> 1;   // first pair of this vector inside its group of 8
+#pragma unroll
+  for (int k = 0; k < EPL; k += 2) {
+    const uint32_t w = bfp_rnd_word(h, p0 + (uint32_t)(k >> 1));
+    r[k] = w;
+    r[k + 1] = __builtin_amdgcn_alignbit(w, w, 16);
+  }
 }
 
 // quant_cpu.cpp:211-237 round_bitwise: keep `man_bits` (0..22) mantissa bits of an fp32 bit pattern.
@@ -348,6 +384,23 @@ __device__ __forceinline__ float div_for_clamped_int(float n, const Recip& c) {
   return __builtin_amdgcn_classf(q0, 0x001 | 0x002 | 0x004 | 0x200) ? q0 : q;  // sNaN, qNaN, -inf, +inf
 }
 
+// The QUOTIENT itself through the reciprocal (round 5: SmoothQuant's x / s, whose result IS the quotient -- until now an IEEE division per
+// element, ~13 VALU cycles' worth with its quarter-rate v_rcp).  Same three operations as above; by Markstein's theorem the result is
+// RN(n / d) whenever rs = RN(1 / d), q0 is normal and the residual is exact, i.e. for d in [2^-20, 2^20] (recip_ok) and n = +-0 or
+// 2^-100 <= |n| <= 2^100 (q0 >= 2^-120; the residual, a multiple of 2^(e_n - 47), is representable; no overflow).  Anything else --
+// tiny, huge, Inf, NaN -- is the caller's cold IEEE redo: div_by_recip_ok is three compares (abs modifiers are free), so a quotient
+// costs 6 operations instead of ~13.  Checked bit for bit against the IEEE division (tests/test_gpu_round5.py: random, every exponent,
+// all-ones mantissas, zeros of both signs).
+__device__ __forceinline__ float div_by_recip(float n, float d, float rs) {
+  const float q0 = n * rs;
+  const float r = -__builtin_fmaf(d, q0, -n);   // (this form keeps the sign of a zero numerator: common.hpp div_for_clamped_int)
+  return __builtin_fmaf(r, rs, q0);
+}
+__device__ __forceinline__ bool div_by_recip_ok(float n) {
+  const float a = __builtin_fabsf(n);
+  return (a >= 0x1p-100f && a <= 0x1p100f) || n == 0.0f;
+}
+
 // The affine integer cast  (clamp(rne'(x / d + z)) - z) * d  of N elements that share ONE scale (a vector inside a quantisation
 // group), two elements per instruction through the packed fp32 pipe: v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 carry the
 // reciprocal quotient of div_for_clamped_int, the + z, the (a + 0.5f) - 0.5f rounding helper (sim_helper.cpp:14-21 in its fp32
@@ -463,6 +516,21 @@ inline FastDiv31 make_fastdiv31(int64_t d64) {
   int l = 0;
   while (((uint64_t)1 << l) < d) l++;
   return FastDiv31{(uint32_t)((((uint64_t)1 << (31 + l)) + d - 1) / d), (uint32_t)(l - 1), d};
+}
+
+// n / d for ANY n < 2^32 and a launch-invariant d >= 1 without a branch (Granlund-Montgomery: t = umulhi(M, n); q = (t + ((n - t) >> s1)) >> s2):
+// FastDiv31's `d == 1 ? n : ...` is a branch around a kernel-argument load when it runs first thing in a kernel -- two dependent scalar
+// loads ahead of the workgroup's first data load (the reductions' workgroup-id decode: +0.3 us on a 8 us kernel).
+struct FastDivU32 {
+  uint32_t M, s1, s2, d;
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { const uint32_t t = __umulhi(M, n); return (t + ((n - t) >> s1)) >> s2; }
+};
+inline FastDivU32 make_fastdiv_u32(int64_t d64) {
+  const uint32_t d = d64 < 1 ? 1u : (d64 > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)d64);
+  int l = 0;
+  while (((uint64_t)1 << l) < d) l++;
+  const uint64_t m = ((((uint64_t)1 << l) - d) << 32) / d + 1;   // < 2^32
+  return FastDivU32{(uint32_t)m, (uint32_t)(l < 1 ? l : 1), (uint32_t)(l > 1 ? l - 1 : 0), d};
 }
 
 // Launch-error scoping.  HIP keeps ONE "last error" per host thread, shared with every other HIP user of the thread

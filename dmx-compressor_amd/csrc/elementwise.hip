@@ -197,41 +197,49 @@ struct FixedOp {
     p.fast = ok;  // per lane: every one of its N scales has an exact-enough reciprocal
     return p;
   }
+  // (lastdim.hpp OpDeferredRedo is NOT taken here: with the flagged rows redone after the stores the hot path has no branch, the
+  //  compiler overlaps more rows and the kernel needs 214-224 VGPRs instead of 166 -- two waves per SIMD instead of three, i.e. exactly
+  //  as many workgroup slots as a 32 MiB tensor has workgroups, no slack for the dispatcher: 11.9 -> 12.8 us, x / s 12.0 -> 15.5.
+  //  The redo stays in place behind one cold wave-uniform branch per row.)
+  template <int N>
+  __device__ __forceinline__ bool apply_chan_flag(const float (&x)[N], const ChanParams<N>& p, float (&y)[N], int64_t) const {
+    // the arithmetic of common.hpp affine_int_pairs with a (scale, reciprocal, zero point) PAIR per instruction: ~7 VALU per element,
+    // straight-line.  Lanes holding a scale outside the reciprocal's range, or an Inf / NaN quotient (it shows as a NaN in the SUM of
+    // the vector's corrected quotients: affine_int_pairs), are flagged.
+    f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < N; k += 2) {
+      const f32x2 d = p.d[k / 2], rs = p.rs[k / 2], z = p.z[k / 2];
+      const f32x2 n2 = {x[k], x[k + 1]};
+      const f32x2 q0 = n2 * rs;
+      const f32x2 t = __builtin_elementwise_fma(d, q0, -n2);  // -(r): r = n - d q0, exact
+      const f32x2 q = __builtin_elementwise_fma(-t, rs, q0);
+      acc = k == 0 ? q : acc + q;
+      f32x2 u = q + z;
+      u = (u + 0.5f) - 0.5f;
+      f32x2 v;
+      v.x = __builtin_amdgcn_fmed3f(__builtin_rintf(u.x), f.t_min, f.t_max);
+      v.y = __builtin_amdgcn_fmed3f(__builtin_rintf(u.y), f.t_min, f.t_max);
+      const f32x2 o = (v - z) * d;
+      y[k] = o.x;
+      y[k + 1] = o.y;
+    }
+    return !p.fast || __builtin_amdgcn_classf(acc.x + acc.y, 0x001 | 0x002 | 0x004 | 0x200);
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_chan_exact(const float (&x)[N], const ChanParams<N>& p, float (&y)[N], int64_t e0) const {
+#pragma unroll
+    for (int k = 0; k < N; k++) y[k] = q(x[k], p.d[k / 2][k % 2], p.z[k / 2][k % 2], e0 + k);
+  }
   template <int N>
   __device__ __forceinline__ void apply_chan(const float (&x)[N], const ChanParams<N>& p, float (&y)[N], int64_t e0) const {
     if (SIMPLE) {
-      // the arithmetic of common.hpp affine_int_pairs with a (scale, reciprocal, zero point) PAIR per instruction: ~7.5 VALU per
-      // element, straight-line.  Lanes holding a scale outside the reciprocal's range, or an Inf / NaN quotient, redo their vector
-      // with the IEEE division behind one cold wave-uniform branch.
-      // (an Inf / NaN quotient shows as a NaN in the SUM of the vector's corrected quotients: common.hpp affine_int_pairs)
-      f32x2 acc = {0.0f, 0.0f};
-#pragma unroll
-      for (int k = 0; k < N; k += 2) {
-        const f32x2 d = p.d[k / 2], rs = p.rs[k / 2], z = p.z[k / 2];
-        const f32x2 n2 = {x[k], x[k + 1]};
-        const f32x2 q0 = n2 * rs;
-        const f32x2 t = __builtin_elementwise_fma(d, q0, -n2);  // -(r): r = n - d q0, exact
-        const f32x2 q = __builtin_elementwise_fma(-t, rs, q0);
-        acc = k == 0 ? q : acc + q;
-        f32x2 u = q + z;
-        u = (u + 0.5f) - 0.5f;
-        f32x2 v;
-        v.x = __builtin_amdgcn_fmed3f(__builtin_rintf(u.x), f.t_min, f.t_max);
-        v.y = __builtin_amdgcn_fmed3f(__builtin_rintf(u.y), f.t_min, f.t_max);
-        const f32x2 o = (v - z) * d;
-        y[k] = o.x;
-        y[k + 1] = o.y;
-      }
-      const bool redo = !p.fast || __builtin_amdgcn_classf(acc.x + acc.y, 0x001 | 0x002 | 0x004 | 0x200);
+      const bool redo = apply_chan_flag(x, p, y, e0);
       if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo) != 0ull, 0)) {
-        if (redo) {
-#pragma unroll
-          for (int k = 0; k < N; k++) y[k] = q(x[k], p.d[k / 2][k % 2], p.z[k / 2][k % 2], e0 + k);
-        }
+        if (redo) apply_chan_exact(x, p, y, e0);
       }
     } else {
-#pragma unroll
-      for (int k = 0; k < N; k++) y[k] = q(x[k], p.d[k / 2][k % 2], p.z[k / 2][k % 2], e0 + k);
+      apply_chan_exact(x, p, y, e0);
     }
   }
   // the vector's (scale, zero point) when it has a single one: fetched ahead of the arithmetic (stream.hpp OpPrep)
@@ -373,7 +381,8 @@ struct ScaleOp {
     const float s = scale[it.g];
     y = DIVIDE ? x / s : x * s;
   }
-  template <int N> struct ChanParams { float s[N]; };
+  // (DIVIDE: the reciprocals of the lane's N scales too, once per workgroup; `fast`: every one of them has an exact-enough reciprocal)
+  template <int N> struct ChanParams { float s[N]; float rs[DIVIDE ? N : 1]; bool fast; };
   template <int N> struct RawParams { f32x4 sc[N / 4]; };
   template <int N>
   __device__ __forceinline__ RawParams<N> fetch_params(int64_t c0) const {
@@ -385,17 +394,42 @@ struct ScaleOp {
   template <int N>
   __device__ __forceinline__ ChanParams<N> make_params(const RawParams<N>& r) const {
     ChanParams<N> p;
+    p.fast = DIVIDE;
 #pragma unroll
     for (int k = 0; k < N; k += 4) {
       const f32x4 t = r.sc[k / 4];
       p.s[k] = t.x; p.s[k + 1] = t.y; p.s[k + 2] = t.z; p.s[k + 3] = t.w;
     }
+    if (DIVIDE) {
+#pragma unroll
+      for (int k = 0; k < N; k++) { p.rs[k] = 1.0f / p.s[k]; p.fast = p.fast && recip_ok(p.s[k]); }
+    }
     return p;
   }
+  // the quotient through the lane's reciprocals (common.hpp div_by_recip: 6 operations instead of an IEEE division's ~13); lanes with
+  // a scale or an element outside its range redo theirs with the division behind one cold wave-uniform branch (in place: see FixedOp)
   template <int N>
-  __device__ __forceinline__ void apply_chan(const float (&x)[N], const ChanParams<N>& p, float (&y)[N], int64_t) const {
+  __device__ __forceinline__ bool apply_chan_flag(const float (&x)[N], const ChanParams<N>& p, float (&y)[N], int64_t) const {
+    bool ok = p.fast;
+#pragma unroll
+    for (int k = 0; k < N; k++) { y[k] = div_by_recip(x[k], p.s[k], p.rs[k]); ok = ok && div_by_recip_ok(x[k]); }
+    return !ok;
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_chan_exact(const float (&x)[N], const ChanParams<N>& p, float (&y)[N], int64_t) const {
 #pragma unroll
     for (int k = 0; k < N; k++) y[k] = DIVIDE ? x[k] / p.s[k] : x[k] * p.s[k];
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_chan(const float (&x)[N], const ChanParams<N>& p, float (&y)[N], int64_t e0) const {
+    if (DIVIDE) {
+      const bool redo = apply_chan_flag(x, p, y, e0);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo) != 0ull, 0)) {
+        if (redo) apply_chan_exact(x, p, y, e0);
+      }
+    } else {
+      apply_chan_exact(x, p, y, e0);
+    }
   }
   struct Prep { float s; };
   __device__ __forceinline__ Prep prepare(int64_t e0) const {

@@ -12,6 +12,8 @@
 //   scale: fl32(x * s) rounded to T1 (ActivationWeightSmoothQuant.scale_weight's `.to(wgt.dtype)`);
 //   BFP nearest-even on the T1 value (bfp_math.hpp), result rounded to T1, then to dtype_out (`.to(input dtype)`).
 // Scope: inner == 1, L % B == 0, B = 2^k in [8, 512], L % 8 == 0, M in {0 (dense), 2, 4, 8}, nearest rounding.
+#include <stdlib.h>
+
 #include "hypernet_rows.hpp"
 #include "lastdim.hpp"
 
@@ -89,6 +91,92 @@ struct HnLastOp {
     for (int k = 0; k < N; k++) y[k] = round_to<DTW>(y[k]);   // CastTo's `.to(physical_dtype)`, then the caller's dtype
   }
 };
+
+// The ACTIVATION twin (round 5): x / s[c] -> BFP in float32 (dmxq_input_hypernet) as an op of lastdim_kernel too.  The tiled kernel
+// below gives every lane-vector its own four channels, i.e. an IEEE division per element (~13 VALU cycles' worth); here a lane keeps
+// its four channels for all its rows, so their RECIPROCALS are formed once per workgroup and a quotient is common.hpp's div_by_recip:
+// RN(x / s) exactly, 6 operations, with the IEEE division as the cold redo of lanes holding a tiny / huge / Inf / NaN element or an
+// out-of-range scale.  Then the float32 tile arithmetic of the hot kernel (double-rounding magic add, literal redo).
+template <bool ASYM, int LPBC>
+struct InLastOp {
+  const float* scale;
+  int lpb, wl;
+  template <int N> struct RawParams { f32x4 sc[N / 4]; };
+  template <int N> struct ChanParams { float s[N], rs[N]; bool fast; };
+  template <int N>
+  __device__ __forceinline__ RawParams<N> fetch_params(int64_t c0) const {
+    RawParams<N> r;
+#pragma unroll
+    for (int k = 0; k < N / 4; k++) r.sc[k] = *(const f32x4*)(scale + c0 + 4 * k);
+    return r;
+  }
+  template <int N>
+  __device__ __forceinline__ ChanParams<N> make_params(const RawParams<N>& r) const {
+    ChanParams<N> p;
+    p.fast = true;
+#pragma unroll
+    for (int k = 0; k < N; k += 4) {
+      const f32x4 t = r.sc[k / 4];
+      p.s[k] = t.x; p.s[k + 1] = t.y; p.s[k + 2] = t.z; p.s[k + 3] = t.w;
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) { p.rs[k] = 1.0f / p.s[k]; p.fast = p.fast && recip_ok(p.s[k]); }
+    return p;
+  }
+  // lastdim.hpp OpDeferredRedo: straight-line for every row (reciprocal quotient, magic-add BFP); a row with an out-of-range element or
+  // scale, or a block the magic add does not cover, is flagged -- by every lane of its block, the flag is taken on the block's
+  // maximum and on the wave's ballot -- and redone with the IEEE division and the literal bit path after the stores
+  static constexpr bool kDeferredRedo = true;
+  template <int N>
+  __device__ __forceinline__ bool apply_chan_flag(const float (&xin)[N], const ChanParams<N>& p, float (&y)[N], int64_t) const {
+    const int lanes = LPBC > 0 ? LPBC : __builtin_amdgcn_readfirstlane(lpb);
+    float x[N];
+    bool ok = p.fast;
+#pragma unroll
+    for (int k = 0; k < N; k++) { x[k] = div_by_recip(xin[k], p.s[k], p.rs[k]); ok = ok && div_by_recip_ok(xin[k]); }
+    uint32_t mb = 0u;
+#pragma unroll
+    for (int k = 0; k < N; k++) mb = max(mb, f2u(x[k]) & 0x7FFFFFFFu);
+    // a lane whose quotients are not exact marks its block's maximum as unusable (an all-ones pattern: the largest): the whole block
+    // is then flagged through the same DPP reduction
+    mb = group_max_u32(ok ? mb : 0xFFFFFFFFu, lanes);
+    const BfpBlockParams bp = bfp_block_params<ASYM, true>(mb, wl);
+#pragma unroll
+    for (int k = 0; k < N; k++) y[k] = bfp_q1_fast<false, ASYM>(x[k], bp);
+    return mb == 0xFFFFFFFFu || !bfp_fast_ok(mb, wl);
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_chan_exact(const float (&xin)[N], const ChanParams<N>& p, float (&y)[N], int64_t) const {
+    const int lanes = LPBC > 0 ? LPBC : __builtin_amdgcn_readfirstlane(lpb);
+    float x[N];
+    uint32_t mb = 0u;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      x[k] = xin[k] / p.s[k];   // smoothquant.py:255-268 `a / scale`, fp32
+      mb = max(mb, f2u(x[k]) & 0x7FFFFFFFu);
+    }
+    mb = group_max_u32(mb, lanes);
+    const BfpBlockParams bp = bfp_block_params<ASYM, false>(mb, wl);
+#pragma unroll
+    for (int k = 0; k < N; k++) y[k] = bfp_q1<DMXQ_ROUND_NEAREST, ASYM>(x[k], bp, wl, DMXQ_ROUND_NEAREST, 0u);
+  }
+  template <int N>
+  __device__ __forceinline__ void apply_chan(const float (&xin)[N], const ChanParams<N>& p, float (&y)[N], int64_t e0) const {
+    apply_chan_exact(xin, p, y, e0);
+  }
+};
+template <int DTX>
+static int launch_in_lastdim(const void* x, void* out, const float* scale, int64_t rows, int64_t L, int64_t B, int wl, bool asym, hipStream_t s) {
+  constexpr int IVB = 4 * Elem<DTX>::bytes;   // a lane owns 4 elements: 16 contiguous bytes of float32 output
+  const int64_t lpb = B / 4;
+  if (lpb < 1 || lpb > 64 || (lpb & (lpb - 1)) != 0 || L % B != 0) return DMXQ_ERR_UNSUPPORTED;  // a block is lpb adjacent lanes of ONE wave
+#define DMXQ_INL(L_) (asym ? launch_lastdim_typed<DTX, DMXQ_F32, InLastOp<true, L_>, IVB>(x, out, rows, L, InLastOp<true, L_>{scale, (int)lpb, wl}, s) \
+                           : launch_lastdim_typed<DTX, DMXQ_F32, InLastOp<false, L_>, IVB>(x, out, rows, L, InLastOp<false, L_>{scale, (int)lpb, wl}, s))
+  if (lpb == 16) return DMXQ_INL(16);   // BFP16_64, the BASIC rules' activation format
+  if (lpb == 4) return DMXQ_INL(4);
+  return DMXQ_INL(0);
+#undef DMXQ_INL
+}
 
 // DMXQ_ERR_UNSUPPORTED: geometry the lastdim kernel does not take (the caller falls back to hypernet_rows_kernel)
 template <int DTW, int DTO>
@@ -356,6 +444,15 @@ extern "C" int dmxq_input_hypernet(const void* x, int dtype_x, const float* sq_s
   if (!x || !out || !sq_scale) return DMXQ_ERR_BAD_ARG;
   if (!aligned16(x) || !aligned16(out) || !aligned16(sq_scale)) return DMXQ_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  // per-lane channels with hoisted reciprocals (InLastOp, round 5); DMXQ_INPUT_HYPERNET_TILED=1 keeps the tiled kernel (A/B runs)
+  static const bool force_tiled = [] { const char* e = getenv("DMXQ_INPUT_HYPERNET_TILED"); return e && e[0] == '1'; }();
+  if (!force_tiled) {
+    int rc = DMXQ_ERR_UNSUPPORTED;
+    if (dtype_x == DMXQ_BF16) rc = launch_in_lastdim<DMXQ_BF16>(x, out, sq_scale, rows, L, B, precision, !symmetric, s);
+    else if (dtype_x == DMXQ_F16) rc = launch_in_lastdim<DMXQ_F16>(x, out, sq_scale, rows, L, B, precision, !symmetric, s);
+    else rc = launch_in_lastdim<DMXQ_F32>(x, out, sq_scale, rows, L, B, precision, !symmetric, s);
+    if (rc != DMXQ_ERR_UNSUPPORTED) return rc;
+  }
   if (B / 4 <= 64) {  // the tiled kernel: a block = B / 4 adjacent lanes of one wave
     const int64_t n_vec = rows * L / 4, tiles = (n_vec + kInThreads * kInUnroll - 1) / (kInThreads * kInUnroll);
     if (tiles <= 0x7FFFFFFF) {

@@ -6,10 +6,21 @@
 //   template <int N> struct ChanParams; ChanParams<N> make_params<N>(const RawParams<N>&)  their arithmetic (reciprocals, conversions)
 //   void apply_chan(const float (&x)[N], const ChanParams<N>&, float (&y)[N], int64_t e0)  N elements of one row; called by EVERY lane of
 //                                                                                           a wave (cross-lane ops are allowed)
+// Optional (round 5), `static constexpr bool kDeferredRedo = true`: the op's straight-line form may not cover every input; then
+//   bool apply_chan_flag(x, p, y, e0)   computes y with the straight-line form and returns true when this lane's row needs
+//   void apply_chan_exact(x, p, y, e0)  instead -- which the kernel runs in ONE cold loop after the store burst, from a fresh load
+//                                       (every lane of the wave takes part again: cross-lane ops stay legal), the flagged lanes storing.
+// In place, behind a wave-uniform branch per row, the 16 rows of a lane could not overlap (a branch fences the scheduling of what
+// surrounds it) and the cold blocks sat between the hot ones (stream.hpp has the same finding for its tiles).
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace dmxq {
+
+template <class OP, class = void> struct OpDeferredRedo { static constexpr bool value = false; };
+template <class OP> struct OpDeferredRedo<OP, std::void_t<decltype(OP::kDeferredRedo)>> { static constexpr bool value = OP::kDeferredRedo; };
 
 // Per-channel parameters along the CONTIGUOUS dim (activations per hidden channel, SmoothQuant's input / weight
 // scaling): a lane keeps the parameters of its EPL channels in registers and handles RPI rows of them, instead of
@@ -69,19 +80,24 @@ __global__ __launch_bounds__(THREADS) void lastdim_kernel(const void* __restrict
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   OutVec<DTO, EPL> o[RPI];
+  uint32_t redo = 0u;   // (kDeferredRedo) bit j: this lane's row j needs the op's exact form
+  auto widen_row = [&](const u32x4& rw, float (&x)[EPL]) __attribute__((always_inline)) {
+    if constexpr (IVB == 16) {
+      widen<DTI, EPL>(rw, x);
+    } else {
+      float xw[16 / Elem<DTI>::bytes];
+      widen<DTI, 16 / Elem<DTI>::bytes>(rw, xw);
+#pragma unroll
+      for (int k = 0; k < EPL; k++) x[k] = xw[k];
+    }
+  };
 #pragma unroll
   for (int j = 0; j < RPI; j++) {
     const int64_t r = r0 + (int64_t)j * rpp + sub;
     float x[EPL], y[EPL];
-    if constexpr (IVB == 16) {
-      widen<DTI, EPL>(raw[j], x);
-    } else {
-      float xw[16 / Elem<DTI>::bytes];
-      widen<DTI, 16 / Elem<DTI>::bytes>(raw[j], xw);
-#pragma unroll
-      for (int k = 0; k < EPL; k++) x[k] = xw[k];
-    }
-    op.apply_chan(x, p, y, r * C + (int64_t)cb * EPL);
+    widen_row(raw[j], x);
+    if constexpr (OpDeferredRedo<OP>::value) redo |= op.apply_chan_flag(x, p, y, r * C + (int64_t)cb * EPL) ? 1u << j : 0u;
+    else op.apply_chan(x, p, y, r * C + (int64_t)cb * EPL);
     o[j] = pack_vec<DTO, EPL>(y);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -96,6 +112,20 @@ __global__ __launch_bounds__(THREADS) void lastdim_kernel(const void* __restrict
     for (int j = 0; j < RPI; j++) {
       const int64_t r = r0 + (int64_t)j * rpp + sub;
       if (active && r < rows) store_out<DTO, EPL, true>((char*)out + (r * cv + cb) * OVB, o[j]);
+    }
+  }
+  if constexpr (OpDeferredRedo<OP>::value) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo != 0u) != 0ull, 0)) {
+#pragma unroll 1
+      for (int j = 0; j < RPI; j++) {
+        if (__builtin_amdgcn_ballot_w64(((redo >> j) & 1u) != 0u) == 0ull) continue;   // (wave-uniform: every lane of the wave redoes the row)
+        const int64_t r = r0 + (int64_t)j * rpp + sub, rc = r < rows ? r : rows - 1;
+        const u32x4 rw = lastdim_load<IVB>(in, (rc * cv + cbc) * IVB);
+        float x[EPL], y[EPL];
+        widen_row(rw, x);
+        op.apply_chan_exact(x, p, y, r * C + (int64_t)cb * EPL);
+        if (((redo >> j) & 1u) && active && r < rows) store_out<DTO, EPL, true>((char*)out + (r * cv + cb) * OVB, pack_vec<DTO, EPL>(y));
+      }
     }
   }
 }

@@ -28,12 +28,15 @@ namespace dmxq {
 // reads that word once its own data has arrived -- the latency hides behind the workgroup's arithmetic -- and polls it only while it
 // does not yet hold the epoch, before the workgroup issues its (non-returning) atomics (acquire fence).
 //   * WHO initialises is decided by a claim, not by position: `flag[1]` is an election word, and whoever swaps the epoch into it first
-//     (a returning exchange) does the job.  Wave 0 of workgroup (0, 0) volunteers at the very start of the kernel, before its loads
-//     -- uncontended, one wave of the whole grid pays the round trip -- so on an idle chip the flag is up ~2 us into the kernel, long
-//     before anybody asks.  A workgroup that has polled kGateTakeover times without seeing the epoch stops assuming that (0, 0) is
-//     running and claims the job itself: it IS running, so the identities get written whatever order the dispatcher chose and
-//     whatever else occupies the chip (MI355X_MICROARCH.md, correctness boundaries: dispatch order is undefined; round 4 had every
-//     workgroup wait for (0, 0) unconditionally).  A late (0, 0) finds the word claimed and just waits like everybody else.
+//     (a returning exchange) does the job.  A gated launch carries ONE EXTRA workgroup (linear id 0: the grids are one-dimensional,
+//     the data workgroups are ids 1 ..) that has no data of its own: its first wave volunteers at once -- uncontended -- so on an
+//     idle chip the flag is up ~1.5-2 us into the kernel, before the first data arrives anywhere, and no data wave is delayed by the
+//     claim's round trip.  (A data wave as the volunteer -- wave 0 of workgroup (0, 0) -- requests its own rows ~2 us late, behind
+//     everybody's: that workgroup then finishes last and the kernel is as slow as with the fill launch, 7.9 -> 9.3 us measured.)
+//     A workgroup that has polled kGateTakeover times without seeing the epoch stops assuming that the volunteer is running and
+//     claims the job itself: it IS running, so the identities get written whatever order the dispatcher chose and whatever else
+//     occupies the chip (MI355X_MICROARCH.md, correctness boundaries: dispatch order is undefined; round 4 had every workgroup wait
+//     for (0, 0) unconditionally).  A late volunteer finds the word claimed and exits.
 //   * a flag slot belongs to ONE stream (launches of a stream are ordered, so a slot never serves two running kernels: no launch can
 //     overwrite the epoch another one still waits for), keyed by (device of the stream, hipStreamGetId where the runtime has it --
 //     ids are never reused, a destroyed stream's handle may be --, else the handle); epochs count up per slot and skip 0, the value
@@ -43,6 +46,36 @@ namespace dmxq {
 //     one wave initialises quickly, on the scalar kernels, and when DMXQ_NO_INIT_GATE is set in the environment.
 // on == 0: the destination is initialised already (a fill launch in front, or the accumulate form); 2: test hook, (0, 0) does not
 // volunteer (every launch goes through the takeover path: dmxq_internal_gate_mode)
+// ORDERING.  What must hold: (1) the identity stores are performed at agent scope before the epoch is; (2) a workgroup's atomics are
+// issued after it has read the epoch.  Both sides touch the coherence point directly -- the identities and the epoch are agent-scope
+// (sc1, write-through) stores, the epoch is read with agent-scope loads, the contributions are atomic read-modify-writes, which execute
+// at the L2 / memory side and never on a cached copy -- so NO cache maintenance is needed for correctness, only ORDER:
+//   publish:  identity stores; s_waitcnt vmcnt(0) (every one acknowledged at agent scope; a compiler barrier too); then the epoch store;
+//   observe:  epoch load; s_waitcnt vmcnt(0) (the value is there, the branch on it resolved; compiler barrier); then the atomics --
+//             a wave issues in program order and nothing after the wait reads ordinary memory that the initialiser wrote.
+// The formal spelling -- `fence(release, agent)` before an `atomic_store(release)`, `fence(acquire, agent)` after the load -- compiles
+// to the same waits PLUS `buffer_wbl2 sc1` (write back every dirty line of the XCD's L2) and `buffer_inv sc1` (invalidate it), the latter
+// once per WORKGROUP at the end of a kernel whose other workgroups still stream through that L2.  Measured (same box, A/B of two
+// builds, 4096 x 4096 bf16): per-group min / max 7.9 us with the waits, 9.2 us with the fences; per-column max |x| 7.6 vs 10.4 us --
+// the fences cost more than the fill launch the gate exists to remove.  -DDMXQ_GATE_FENCES=1 builds the formal form (profiles/
+// r05_gate_fences.txt); the default is the waits.
+#ifndef DMXQ_GATE_FENCES
+#define DMXQ_GATE_FENCES 0
+#endif
+__device__ __forceinline__ void gate_release_stores() {
+#if DMXQ_GATE_FENCES
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void gate_acquire_epoch() {
+#if DMXQ_GATE_FENCES
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
 struct InitGate { unsigned* flag; unsigned epoch; int on; };
 constexpr int kGateSlots = 1024, kGateStride = 16 /* words: one slot per 64-byte line */, kGateMaxOut = 8192;
 constexpr int kGateTakeover = 48;  // polls (~1 us each) before a waiting workgroup claims the initialisation
@@ -56,15 +89,38 @@ __device__ __forceinline__ bool gate_claim_and_init(const InitGate& g, int64_t n
   old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
   if (old == g.epoch) return false;   // claimed before: that wave initialises (or has)
   for (int64_t i = lane; i < n; i += kWave) init(i);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // every lane's identity stores, before ...
-  if (lane == 0) __hip_atomic_store(g.flag, g.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... the epoch
+  gate_release_stores();   // every lane's identity stores (one wave: one wait covers them all), before ...
+  if (lane == 0) __hip_atomic_store(g.flag, g.epoch, DMXQ_GATE_FENCES ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... the epoch
   return true;
 }
 // (GATED is a template parameter of the kernels: the un-gated instances -- the accumulate forms, the fallbacks -- carry none of this;
 // as a run-time flag it cost them 0.3 us)
+// First statement of a gated kernel: true = this is the volunteer workgroup (linear id 0), the caller returns; else `wid` is the
+// linear id among the DATA workgroups.  Ungated instances: wid = blockIdx.x.
 template <bool GATED, typename F>
-__device__ __forceinline__ void gate_open(const InitGate& g, int64_t n, F&& init) {
-  if (GATED && g.on == 1 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kWave) (void)gate_claim_and_init(g, n, init);
+__device__ __forceinline__ bool gate_open(const InitGate& g, int64_t n, F&& init, uint32_t& wid) {
+  wid = blockIdx.x;
+  if (!GATED) return false;
+  if (wid == 0u) {
+    // the volunteer workgroup: thread 0 claims, then EVERY thread stores its share of the identities (4096 per-column maxima by one
+    // wave were 64 stores per lane, ~1 us of issue: the epoch came up after the first workgroups had asked, and per-column max |x|
+    // ran 9.1 us instead of 7.5) -- the workgroup has nothing else to do, so the two barriers are free
+    __shared__ unsigned s_claimed;
+    if (g.on == 1) {
+      if (threadIdx.x == 0) s_claimed = __hip_atomic_exchange(g.flag + 1, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (s_claimed != g.epoch) {   // (block-uniform) not claimed before: ours
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) init(i);
+        gate_release_stores();      // each wave's own stores
+        __syncthreads();
+        if (threadIdx.x == 0)
+          __hip_atomic_store(g.flag, g.epoch, DMXQ_GATE_FENCES ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return true;
+  }
+  wid -= 1u;
+  return false;
 }
 __device__ __forceinline__ void gate_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // thread 0 only, and only while it has not seen the epoch.  `dep`: a register of the caller's FIRST data load of the batch -- the
@@ -94,7 +150,7 @@ __device__ __forceinline__ void gate_wait(const InitGate& g, unsigned seen, int6
       s = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
       if (s != g.epoch && ++polls == kGateTakeover && gate_claim_and_init(g, n, init)) s = g.epoch;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the identities, before this workgroup's atomics
+    gate_acquire_epoch();   // the epoch read, before this workgroup's atomics
   }
 }
 
@@ -266,11 +322,14 @@ constexpr int kMinmaxThreads = 1024;  // big workgroups: few contended atomics p
 template <int DT, bool GATED>
 __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const void* __restrict__ in,
                                                                          int64_t outer, int64_t C, int64_t inner,
-                                                                         int64_t gs, float* mn, float* mx, const InitGate gate) {
+                                                                         int64_t gs, float* mn, float* mx, const InitGate gate,
+                                                                         const FastDivU32 nx /* splits per group */, uint32_t ng /* groups */) {
   constexpr int kThreads = kMinmaxThreads;  // shadows the namespace constant inside this kernel
-  const int64_t g = blockIdx.y;
   auto init = [&](int64_t i) { gate_store(&mn[i], INFINITY); gate_store(&mx[i], -INFINITY); };
-  gate_open<GATED>(gate, gridDim.y, init);
+  uint32_t wid;
+  if (gate_open<GATED>(gate, ng, init, wid)) return;
+  const int64_t g = nx.div(wid);   // (the workgroup id is wave-uniform: two scalar instructions)
+  const uint32_t bx = wid - (uint32_t)g * nx.d;
   unsigned seen = ~gate.epoch;   // not the epoch: a workgroup that never peeks must wait
   const int64_t c0 = g * gs;
   const int64_t lenv = ((C - c0 < gs) ? (C - c0) : gs) * inner / 8;  // vectors per run
@@ -279,9 +338,9 @@ __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const 
   uint32_t am = 0u;
   PkMinMax pk;
   pk.init();
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  const int64_t stride = (int64_t)nx.d * kThreads;
   // (o, r) walked with carries instead of a 64-bit division per vector; 4 independent loads in flight per lane
-  int64_t t = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  int64_t t = (int64_t)bx * kThreads + threadIdx.x;
   const bool any = t < total;
   int64_t o = t / lenv, r = t % lenv;
   const int64_t so = stride / lenv, sr = stride % lenv;
@@ -316,7 +375,7 @@ __global__ __launch_bounds__(kMinmaxThreads) void group_minmax_vec_kernel(const 
   }
   if (DT != DMXQ_F32) { if (any) pk.finish<DT>(lo, hi); }
   else nan_to_both(am, lo, hi);
-  block_minmax_finish<kThreads, GATED>(lo, hi, &mn[g], &mx[g], gate, seen, gridDim.y, init);
+  block_minmax_finish<kThreads, GATED>(lo, hi, &mn[g], &mx[g], gate, seen, ng, init);
 }
 
 // outer == 1 (a weight's row slabs along dim 0, or the whole tensor as one group): the vectors of group g are ONE contiguous run, so a
@@ -327,11 +386,13 @@ constexpr int kFlatThreads = 512;
 template <int DT> struct FlatUnroll { static constexpr int value = DT == DMXQ_F32 ? 8 : 16; };  // 256 bytes in flight per lane either way
 template <int DT, bool GATED>
 __global__ __launch_bounds__(kFlatThreads) void group_minmax_flat_kernel(const void* __restrict__ in, int64_t C, int64_t inner, int64_t gs,
-                                                                        float* mn, float* mx, const InitGate gate) {
+                                                                        float* mn, float* mx, const InitGate gate, const FastDivU32 nx, uint32_t ng) {
   constexpr int T = kFlatThreads, U = FlatUnroll<DT>::value;
-  const int64_t g = blockIdx.y;
   auto init = [&](int64_t i) { gate_store(&mn[i], INFINITY); gate_store(&mx[i], -INFINITY); };
-  gate_open<GATED>(gate, gridDim.y, init);
+  uint32_t wid;
+  if (gate_open<GATED>(gate, ng, init, wid)) return;
+  const int64_t g = nx.div(wid);   // (the workgroup id is wave-uniform: two scalar instructions)
+  const uint32_t bx = wid - (uint32_t)g * nx.d;
   unsigned seen = ~gate.epoch;   // not the epoch: a workgroup that never peeks must wait
   const int64_t c0 = g * gs;
   const int64_t lenv = ((C - c0 < gs) ? (C - c0) : gs) * inner / 8;  // vectors of this group
@@ -340,8 +401,8 @@ __global__ __launch_bounds__(kFlatThreads) void group_minmax_flat_kernel(const v
   uint32_t am = 0u;
   PkMinMax pk;
   pk.init();
-  const bool any = (int64_t)blockIdx.x * (T * U) < lenv;   // (every lane of a workgroup that has a tile adds at least one -- clamped -- vector)
-  for (int64_t b = (int64_t)blockIdx.x * (T * U); b < lenv; b += (int64_t)gridDim.x * (T * U)) {
+  const bool any = (int64_t)bx * (T * U) < lenv;   // (every lane of a workgroup that has a tile adds at least one -- clamped -- vector)
+  for (int64_t b = (int64_t)bx * (T * U); b < lenv; b += (int64_t)nx.d * (T * U)) {
     Raw8<DT> raw[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -365,7 +426,7 @@ __global__ __launch_bounds__(kFlatThreads) void group_minmax_flat_kernel(const v
   }
   if (DT != DMXQ_F32) { if (any) pk.finish<DT>(lo, hi); }
   else nan_to_both(am, lo, hi);
-  block_minmax_finish<T, GATED>(lo, hi, &mn[g], &mx[g], gate, seen, gridDim.y, init);
+  block_minmax_finish<T, GATED>(lo, hi, &mn[g], &mx[g], gate, seen, ng, init);
 }
 
 // vectorised twin of channel_maxabs_kernel: a workgroup covers a strip of 64 x 8 = 512 consecutive columns of the
@@ -376,13 +437,16 @@ constexpr int kMaxabsRows = 8;        // rows in flight per lane
 template <int DT, int U, bool GATED>
 __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(const void* __restrict__ in,
                                                                            int64_t outer, int64_t C, int64_t inner,
-                                                                           float* out, const InitGate gate) {
+                                                                           float* out, const InitGate gate, const FastDivU32 nx /* column strips */,
+                                                                           uint32_t ny /* row splits */) {
   constexpr int W = kMaxabsThreads / kWave;
   auto init = [&](int64_t i) { gate_store(&out[i], 0.0f); };
-  gate_open<GATED>(gate, C, init);
+  uint32_t wid;
+  if (gate_open<GATED>(gate, C, init, wid)) return;
+  const uint32_t by = nx.div(wid), bx = wid - by * nx.d;
   unsigned seen = ~gate.epoch;   // not the epoch: a workgroup that never peeks must wait
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-  const int64_t col0 = ((int64_t)blockIdx.x * kWave + lane) * 8;
+  const int64_t col0 = ((int64_t)bx * kWave + lane) * 8;
   const int64_t plane = C * inner;
   const bool ok = col0 < plane;
   // a workgroup takes W * U consecutive rows per pass: wave w rows w, w + W, ...; the U row loads of a lane are all in flight
@@ -398,7 +462,7 @@ __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(cons
 #pragma unroll
   for (int k = 0; k < NW; k++) m[k] = 0u;
   if (ok) {
-    for (int64_t o = (int64_t)blockIdx.y * (W * U) + w; o < outer; o += (int64_t)gridDim.y * (W * U)) {
+    for (int64_t o = (int64_t)by * (W * U) + w; o < outer; o += (int64_t)ny * (W * U)) {
       Raw8<DT> raw[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -427,7 +491,7 @@ __global__ __launch_bounds__(kMaxabsThreads) void channel_maxabs_vec_kernel(cons
   // the strip's 512 columns over the first 512 threads (8 waves), each combining the W partial maxima of its column
   if (threadIdx.x < 8 * kWave) {
     const int c = threadIdx.x;                 // column c of the strip = element c % 8 of lane c / 8
-    const int64_t col = (int64_t)blockIdx.x * (kWave * 8) + c;
+    const int64_t col = (int64_t)bx * (kWave * 8) + c;
     if (col < plane) {
       const int l = c >> 3, e = c & 7;
       uint32_t r;
@@ -515,14 +579,16 @@ __global__ __launch_bounds__(kHistThreads) void histc_kernel(const void* __restr
   constexpr int dt = DT;
   extern __shared__ uint32_t s_hist[];
   auto init = [&](int64_t i) { __hip_atomic_store(&counts[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  gate_open<GATED>(gate, bins, init);
+  uint32_t wid;
+  if (gate_open<GATED>(gate, bins, init, wid)) return;
+  const uint32_t nb = gridDim.x - (GATED ? 1u : 0u);   // data workgroups
   unsigned seen = ~gate.epoch;
   for (int b = threadIdx.x; b < bins; b += kHistThreads) s_hist[b] = 0;
   __syncthreads();
   const float fb = (float)bins;
   const Recip width = make_recip(hi - lo);
-  const int64_t stride = (int64_t)gridDim.x * kHistThreads;
-  const int64_t t0 = (int64_t)blockIdx.x * kHistThreads + threadIdx.x;
+  const int64_t stride = (int64_t)nb * kHistThreads;
+  const int64_t t0 = (int64_t)wid * kHistThreads + threadIdx.x;
   if (vec) {
     constexpr int U = 4;  // 16-byte loads in flight per lane
     const int64_t nv = n / 8;
@@ -665,7 +731,7 @@ static int group_minmax_impl(const void* in, int dtype_in, int64_t outer, int64_
       if (capv > 160) capv = 160;
       if (sv > capv) sv = capv;
       if (sv < 1) sv = 1;
-#define DMXQ_MF1(D_, G_) DMXQ_LAUNCH((group_minmax_flat_kernel<D_, G_>), dim3((unsigned)sv, (unsigned)G), dim3(kFlatThreads), 0, s, in, C, inner, group_size, mn, mx, gate)
+#define DMXQ_MF1(D_, G_) DMXQ_LAUNCH((group_minmax_flat_kernel<D_, G_>), dim3((unsigned)(sv * G + ((G_) ? 1 : 0))), dim3(kFlatThreads), 0, s, in, C, inner, group_size, mn, mx, gate, make_fastdiv_u32(sv), (uint32_t)G)
 #define DMXQ_MF(D_) do { if (gate.on) DMXQ_MF1(D_, true); else DMXQ_MF1(D_, false); } while (0)
       if (dtype_in == DMXQ_F32) DMXQ_MF(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_MF(DMXQ_F16); else DMXQ_MF(DMXQ_BF16);
 #undef DMXQ_MF
@@ -675,7 +741,7 @@ static int group_minmax_impl(const void* in, int dtype_in, int64_t outer, int64_
       const int64_t capv = (512 + G - 1) / G;  // ~512 workgroups of 1024 threads in total
       if (sv > capv) sv = capv;
       if (sv < 1) sv = 1;
-#define DMXQ_MM1(D_, G_) DMXQ_LAUNCH((group_minmax_vec_kernel<D_, G_>), dim3((unsigned)sv, (unsigned)G), dim3(kMinmaxThreads), 0, s, in, outer, C, inner, group_size, mn, mx, gate)
+#define DMXQ_MM1(D_, G_) DMXQ_LAUNCH((group_minmax_vec_kernel<D_, G_>), dim3((unsigned)(sv * G + ((G_) ? 1 : 0))), dim3(kMinmaxThreads), 0, s, in, outer, C, inner, group_size, mn, mx, gate, make_fastdiv_u32(sv), (uint32_t)G)
 #define DMXQ_MM(D_) do { if (gate.on) DMXQ_MM1(D_, true); else DMXQ_MM1(D_, false); } while (0)
       if (dtype_in == DMXQ_F32) DMXQ_MM(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_MM(DMXQ_F16); else DMXQ_MM(DMXQ_BF16);
 #undef DMXQ_MM
@@ -735,8 +801,9 @@ extern "C" int dmxq_channel_maxabs(const void* in, int dtype_in, int64_t outer, 
       if (gy > 64) gy = 64;
     }
     if (gy > 65535) gy = 65535;
+    if (vec && gx * gy > 0x7FFFFFF0ll) gy = 0x7FFFFFF0ll / gx > 0 ? 0x7FFFFFF0ll / gx : 1;   // (one-dimensional grid: strips x row splits)
     if (vec)
-#define DMXQ_MAU1(D_, U_, G_) DMXQ_LAUNCH((channel_maxabs_vec_kernel<D_, U_, G_>), dim3((unsigned)gx, (unsigned)gy), dim3(kMaxabsThreads), 0, s, in, outer, C, inner, out, gate)
+#define DMXQ_MAU1(D_, U_, G_) DMXQ_LAUNCH((channel_maxabs_vec_kernel<D_, U_, G_>), dim3((unsigned)(gx * gy + ((G_) ? 1 : 0))), dim3(kMaxabsThreads), 0, s, in, outer, C, inner, out, gate, make_fastdiv_u32(gx), (uint32_t)gy)
 #define DMXQ_MAU(D_, U_) do { if (gate.on) DMXQ_MAU1(D_, U_, true); else DMXQ_MAU1(D_, U_, false); } while (0)
 #define DMXQ_MA(D_) do { if (rows_in_flight == 8) DMXQ_MAU(D_, 8); else if (rows_in_flight == 4) DMXQ_MAU(D_, 4); else DMXQ_MAU(D_, 2); } while (0)
     { if (dtype_in == DMXQ_F32) DMXQ_MA(DMXQ_F32); else if (dtype_in == DMXQ_F16) DMXQ_MA(DMXQ_F16); else DMXQ_MA(DMXQ_BF16); }
@@ -777,7 +844,7 @@ extern "C" int dmxq_histc(const void* in, int dtype_in, int64_t n, int64_t bins,
     int64_t blocks = (n + kHistThreads * 32 - 1) / (kHistThreads * 32);
     if (blocks > 256) blocks = 256;
     const bool fast = recip_ok(hi - lo);
-#define DMXQ_HC1(D_, F_, G_) DMXQ_LAUNCH((histc_kernel<D_, F_, G_>), dim3((unsigned)blocks), dim3(kHistThreads), (size_t)bins * sizeof(uint32_t), s, in, n, (int)bins, lo, hi, aligned16(in) ? 1 : 0, (uint32_t*)hist, gate)
+#define DMXQ_HC1(D_, F_, G_) DMXQ_LAUNCH((histc_kernel<D_, F_, G_>), dim3((unsigned)blocks + ((G_) ? 1u : 0u)), dim3(kHistThreads), (size_t)bins * sizeof(uint32_t), s, in, n, (int)bins, lo, hi, aligned16(in) ? 1 : 0, (uint32_t*)hist, gate)
 #define DMXQ_HC(D_)                                                                  \
   do {                                                                               \
     if (fast) { if (gate.on) DMXQ_HC1(D_, true, true); else DMXQ_HC1(D_, true, false); }   \

@@ -29,7 +29,7 @@ __all__ = ["DmxModule", "DmxQuantizerCalibrationHyperparams", "DmxModuleQuantize
            "DmxModuleSmoothQuantHyperparams", "Linear", "Conv1d", "Conv2d", "ResAdd", "ActActMatMul", "Softmax", "LayerNorm", "GELU", "ReLU", "SiLU", "QuickGELU", "Exp", "Mul", "RMSNorm", "ApplyRotaryPosEmb",
            "MaxPool2d", "AvgPool2d", "Embedding", "ReLU6", "Tanh", "Dropout", "NewGELU", "FastGELU", "BloomGELU", "ClippedGELU", "AdaptiveAvgPool2d",
            "BatchNorm2d", "GroupNorm", "ConvTranspose2d", "BAddBMM", "ScaledDotProductAttention", "DmxConfigRule", "configure_model",
-           "fold_weights_and_biases", "GraphedForward", "link_consumer", "link_consumers_from_fx", "DmxTracer"]
+           "fold_weights_and_biases", "GraphedForward", "LiveWeightBatch", "link_consumer", "link_consumers_from_fx", "DmxTracer"]
 
 
 class _LazySparsify(Sparsify):
@@ -257,6 +257,10 @@ class DmxModule(torch.nn.Module):
             """out_dtype: the dtype the CONSUMER converts the result to anyway (Linear: `_weight.to(_input.dtype)`, torch_modules.py:
             347-350) -- the fused kernel then rounds to it directly (the chain's dtype is torch's promotion of weight and score dtypes:
             float32 for a bf16 weight with an N:M score Parameter, i.e. a 4 B/element store and a separate conversion pass)"""
+            if _w is self.weight:
+                lw = self._batched_live_weight(out_dtype)
+                if lw is not None:
+                    return lw
             fused = self._fused_weight(_w, out_dtype)
             if fused is not None:
                 return fused
@@ -272,10 +276,25 @@ class DmxModule(torch.nn.Module):
 
         return _weight_hypernet
 
+    def _batched_live_weight(self, out_dtype=None):
+        """this forward's quantised weight when a `LiveWeightBatch` computed it together with its siblings' (one launch for the set), else
+        None.  Valid only for the Parameter state it was computed from (same storage, same version) and in inference."""
+        lw = self.__dict__.get("_live_weight")
+        if lw is None:
+            return None
+        w, (o, ver, ptr, natural) = self.weight, lw
+        if ver != w._version or ptr != w.data_ptr() or (torch.is_grad_enabled() and w.requires_grad) or torch.compiler.is_compiling():
+            self.__dict__.pop("_live_weight", None)
+            return None
+        # `natural`: the dtype the module's own chain returns when nobody asks for one (torch's promotion of weight and score dtypes for
+        # a masked weight); the batch rounds straight to the weight's dtype -- what Linear asks for -- and serves only that request
+        return o if o.dtype == (out_dtype if out_dtype is not None else natural) else None
+
     @property
     def _weight_ro(self):
         """the weight as `_forward` consumes it: READ-ONLY, may be the Parameter itself when every stage is a no-op"""
-        return self.weight_hypernet(self.weight)
+        lw = self._batched_live_weight()
+        return lw if lw is not None else self.weight_hypernet(self.weight)
 
     @property
     def _bias_ro(self):
@@ -1382,20 +1401,15 @@ class DmxConfigRule:
                 m.configure(self.module_config)
 
 
-def fold_weights_and_biases(model: torch.nn.Module) -> torch.nn.Module:
-    """`DmxModel.fold_weights_and_biases` (modeling/model.py: every DmxModule's `fold_weight_and_bias`, core.py:146-176) for a
-    model built from these modules: weights are quantised ONCE instead of on every forward.  The per-module weight casts are
-    the launch-bound part on a small model (opt-125m: 73 Linear weights of 0.6-2.4 M elements, ~4 us of launch each for
-    0.4-1.6 us of streaming), so the modules whose weight path is a single plain cast are BATCHED through the multi-tensor
-    entry points (`ops.bfp_qdq_multi` for BFP formats, `ops.fixed_qdq_multi` for calibrated INT8 / INT4 per-tensor or
-    row-group quantisation: one launch per 40-48 tensors; `ops.weight_hypernet_multi` for the fused N:M mask / SmoothQuant scale ->
-    BFP chain along the last dim: one launch per 32 weights); everything else -- sparsifiers, SmoothQuant, storage formats,
-    pre-transforms, the biases -- goes through the module's own `fold_weight_and_bias`, which also finishes the batched ones
-    (their weight cast is already SAME by then).  Bit-identical to folding module by module."""
-    from . import ops
+def _weight_batches(mods):
+    """The modules of `mods` whose weight path can run as a SET: -> (groups, hyper).
+    groups: {("bfp" | "fixed", dtype, device, format parameters ...): [module, ...]} -- a single plain cast (BFP along the last dim; calibrated
+    INT8 / INT4 per tensor or per row group) through `ops.bfp_qdq_multi` / `ops.fixed_qdq_multi`;
+    hyper: {(weight dtype, device, score dtype, K, M, has SmoothQuant scale, precision, block size, symmetric): [(module, score, scale), ...]}
+    -- the fused N:M mask / SmoothQuant scale -> BFP chain along the last dim through `ops.weight_hypernet_multi`.
+    Everything else (other sparsifiers, storage formats, pre-transforms, per-channel affine casts) is the module's own business."""
     from .format import BlockFloatingPoint, FixedPoint
     from .sparse import Dense
-    mods = [m for m in model.modules() if isinstance(m, DmxModule) and getattr(m, "weight", None) is not None]
     groups = {}
     with torch.no_grad():
         for m in mods:
@@ -1428,6 +1442,24 @@ def fold_weights_and_biases(model: torch.nn.Module) -> torch.nn.Module:
             key = (m.weight.dtype, m.weight.device, score.dtype if score is not None else None, K, M, sq is not None,
                    fmt.precision, fmt.block_size, fmt.symmetric)
             hyper.setdefault(key, []).append((m, score, sq))
+    return groups, hyper
+
+
+def fold_weights_and_biases(model: torch.nn.Module) -> torch.nn.Module:
+    """`DmxModel.fold_weights_and_biases` (modeling/model.py: every DmxModule's `fold_weight_and_bias`, core.py:146-176) for a
+    model built from these modules: weights are quantised ONCE instead of on every forward.  The per-module weight casts are
+    the launch-bound part on a small model (opt-125m: 73 Linear weights of 0.6-2.4 M elements, ~4 us of launch each for
+    0.4-1.6 us of streaming), so the modules whose weight path is a single plain cast are BATCHED through the multi-tensor
+    entry points (`ops.bfp_qdq_multi` for BFP formats, `ops.fixed_qdq_multi` for calibrated INT8 / INT4 per-tensor or
+    row-group quantisation: one launch per 40-48 tensors; `ops.weight_hypernet_multi` for the fused N:M mask / SmoothQuant scale ->
+    BFP chain along the last dim: one launch per 32 weights); everything else -- sparsifiers, SmoothQuant, storage formats,
+    pre-transforms, the biases -- goes through the module's own `fold_weight_and_bias`, which also finishes the batched ones
+    (their weight cast is already SAME by then).  Bit-identical to folding module by module."""
+    from . import ops
+    from .sparse import Dense
+    mods = [m for m in model.modules() if isinstance(m, DmxModule) and getattr(m, "weight", None) is not None]
+    with torch.no_grad():
+        groups, hyper = _weight_batches(mods)
         for (_, _, _, K, M, has_sq, precision, block_size, symmetric), items in hyper.items():
             outs = ops.weight_hypernet_multi([m.weight.data for m, _, _ in items], precision, block_size, symmetric,
                                              [sc for _, sc, _ in items] if M else None, K, M, [q for _, _, q in items] if has_sq else None)
@@ -1458,6 +1490,79 @@ def fold_weights_and_biases(model: torch.nn.Module) -> torch.nn.Module:
     return model
 
 
+class LiveWeightBatch:
+    """The weight chains of a (sub)model's DmxModules as a few multi-tensor launches per forward, for weights that are NOT folded --
+    the reference re-runs every module's weight hypernet on every forward (modeling/nn/core.py:178-203), one launch chain per weight:
+    an opt-125m decoder layer launches six INT8 casts of 0.6-2.4 M elements per forward, each ~4 us of launch for ~1 us of streaming.
+
+        batch = LiveWeightBatch(layer)      # a forward pre-hook on `layer`
+        y = layer(x)                        # pre-hook: ONE launch per group of sibling weights; the modules then pick their result up
+        batch.remove()
+
+    The pre-hook plans the groups afresh on every forward (`_weight_batches`: same dtype / device / format / N:M pattern, the rule of
+    `fold_weights_and_biases`), launches `ops.fixed_qdq_multi` / `ops.bfp_qdq_multi` / `ops.weight_hypernet_multi` and leaves each
+    result on its module, stamped with the Parameter's storage and version: `DmxModule.weight_hypernet` returns it for THAT state of
+    the Parameter only (an optimiser step or an assignment in between invalidates it) and only in inference.  Weights stay "live":
+    a changed weight, scale or configuration shows in the next forward.  Results are bit-identical to the per-module path (the
+    multi-tensor entry points are, tests/test_gpu_round2.py / round4.py).  Memory: one quantised copy of every batched weight of
+    `root` at a time -- put the batch on a decoder layer, not on a 70 B model.  `GraphedForward(..., batch_live_weights=True)`
+    installs one for the capture."""
+
+    def __init__(self, root: torch.nn.Module):
+        self.root = root
+        self._handle = root.register_forward_pre_hook(self._prepare)
+
+    def remove(self):
+        self._handle.remove()
+        for m in self.root.modules():
+            if isinstance(m, DmxModule):
+                m.__dict__.pop("_live_weight", None)
+
+    def _prepare(self, module, args):
+        from . import ops
+        mods = [m for m in self.root.modules() if isinstance(m, DmxModule) and getattr(m, "weight", None) is not None]
+        for m in mods:
+            m.__dict__.pop("_live_weight", None)
+        if torch.compiler.is_compiling():
+            return
+        mods = [m for m in mods if m.weight.is_cuda and not (torch.is_grad_enabled() and m.weight.requires_grad)]
+        if len(mods) < 2:
+            return
+        with torch.no_grad():
+            groups, hyper = _weight_batches(mods)
+
+            def stamp(m, o, natural=None):
+                m.__dict__["_live_weight"] = (o, m.weight._version, m.weight.data_ptr(), natural or m.weight.dtype)
+
+            for (_, _, _, K, M, has_sq, precision, block_size, symmetric), items in hyper.items():
+                if len(items) < 2:
+                    continue
+                # (rounded straight to the weight's dtype, what `Linear._forward` asks its own fused launch for: `_weight.to(_input.dtype)`)
+                outs = ops.weight_hypernet_multi([m.weight.detach() for m, _, _ in items], precision, block_size, symmetric,
+                                                 [sc for _, sc, _ in items] if M else None, K, M, [q for _, _, q in items] if has_sq else None,
+                                                 out_dtype=items[0][0].weight.dtype)
+                if outs is not None:
+                    for (m, sc, _), o in zip(items, outs):
+                        stamp(m, o, torch.promote_types(m.weight.dtype, sc.dtype) if (M and sc is not None) else m.weight.dtype)
+            for key, ms in groups.items():
+                if len(ms) < 2:
+                    continue
+                ws = [m.weight.detach() for m in ms]
+                if key[0] == "bfp":
+                    _, _, _, precision, block_size, symmetric, rounding = key
+                    if rounding == "stochastic":
+                        continue   # (an implicit seed per call: the per-module path draws one per weight)
+                    outs = ops.bfp_qdq_multi(ws, precision, block_size, -1, symmetric, rounding)
+                else:
+                    _, _, _, precision, fraction, clamp, symmetric, rounding, gs = key
+                    if rounding == "stochastic":
+                        continue
+                    outs = ops.fixed_qdq_multi(ws, precision, fraction, clamp, symmetric, [m.weight_cast.scale for m in ms],
+                                               [m.weight_cast.zero_point for m in ms], group_size=gs, rounding=rounding)
+                for m, o in zip(ms, outs):
+                    stamp(m, o)
+
+
 class GraphedForward:
     """A configured model's inference forward as ONE hipGraph replay.
 
@@ -1473,9 +1578,11 @@ class GraphedForward:
     overwritten by the next call -- clone what must outlive it.  Inference only (captured under torch.no_grad); calibration
     (observers, SmoothQuant `calibrating`) and stochastic rounding with an implicit seed must be done before capture."""
 
-    def __init__(self, model: torch.nn.Module, *example_inputs: torch.Tensor, warmup: int = 3):
+    def __init__(self, model: torch.nn.Module, *example_inputs: torch.Tensor, warmup: int = 3, batch_live_weights: bool = True):
         if not example_inputs or not all(isinstance(t, torch.Tensor) and t.is_cuda for t in example_inputs):
             raise ValueError("GraphedForward: tensor inputs on the GPU required")
+        # un-folded weights: the sibling weights' chains as a few multi-tensor launches inside the captured forward (LiveWeightBatch)
+        self.live_batch = LiveWeightBatch(model) if batch_live_weights else None
         # calibration must precede capture: an enabled observer updates its running min / max IN PLACE (dmxq_group_minmax_accumulate) and a
         # calibrating SmoothQuant recomputes its scale -- captured, every replay would repeat that on the static input (ADVICE r3)
         from .cast import CastTo

@@ -9,9 +9,12 @@
  * Conventions (all entry points):
  *   - plain C: raw DEVICE pointers + explicit 64-bit sizes, no torch types, never throws, no state for the caller to manage
  *     (the reductions -- dmxq_group_minmax, dmxq_channel_maxabs, dmxq_histc -- keep 64 KiB of flag words per device, allocated on
- *     first use and never freed: the kernel's first workgroup initialises the outputs and the others wait for its flag, instead
- *     of a fill launch in front of every call; csrc/reduce.hip "init gate".  While `stream` is being captured into a graph they
- *     use the fill launch, so a captured call is replayable);
+ *     first use and never freed: ONE wave of the kernel initialises the outputs and publishes the launch's epoch, the workgroups wait
+ *     for it before their atomics, instead of a fill launch in front of every call.  Which wave is decided by a claim on an election
+ *     word -- an extra workgroup without data volunteers at once, any waiting workgroup takes the job over after a bounded number of
+ *     polls -- so the protocol does not depend on dispatch order or on what else occupies the GPU; csrc/reduce.hip "init gate".
+ *     While `stream` is being captured into a graph, and with DMXQ_NO_INIT_GATE set in the environment, they use the fill launch,
+ *     so a captured call is replayable);
  *   - caller-allocated outputs (the reference allocates with zeros_like and returns a new tensor,
  *     quant_cuda.cpp:116-139 — the host mirror keeps that ownership contract above this ABI);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are asynchronous;

@@ -41,6 +41,15 @@ static inline uint32_t rnd_bits(uint64_t seed, uint64_t idx) {
   return x;
 }
 
+/* The draws of the BFP cast's stochastic mode (round 5; csrc/common.hpp bfp_rnd is the same function): one hash per aligned group of 8
+ * elements, a Weyl step and a xor-shift per pair, the pair's word for the even element and the word with its halves swapped for the odd
+ * one.  A function of (seed, linear element index) like rnd_bits; four operations per element on the GPU instead of a full hash. */
+static inline uint32_t bfp_rnd(uint64_t seed, uint64_t idx) {
+  uint32_t w = rnd_bits(seed, idx >> 3) + (((uint32_t)idx & 7u) >> 1) * 0x9E3779B9u;
+  w ^= w >> 15;
+  return ((uint32_t)idx & 1u) ? ((w >> 16) | (w << 16)) : w;
+}
+
 /* quant_cpu.cpp:211-237 round_bitwise: keep `man_bits` mantissa bits of an fp32 bit pattern.
  * nearest = round-half-to-even on the bit pattern; the carry may ripple into the exponent (intended).
  * Valid for 0 <= man_bits <= 22 (the reference shifts by a negative count at 23: undefined behaviour). */
@@ -185,7 +194,7 @@ int oracle_bfp_qdq(const float* in, float* out, int64_t rows, int64_t L, int64_t
       for (int64_t i = 0; i < len; i++) { float a = fabsf(xi[b0 + i]); if (a > m || isnan(a)) m = a; }
       for (int64_t i = 0; i < len; i++)
         yo[b0 + i] = bfp_q1n(xi[b0 + i], m, wl, rounding,
-                             rounding == R_STOCHASTIC ? rnd_bits(seed, (uint64_t)(r * L + b0 + i)) : 0u, symmetric == 2);
+                             rounding == R_STOCHASTIC ? bfp_rnd(seed, (uint64_t)(r * L + b0 + i)) : 0u, symmetric == 2);
       /* NaN/Inf maximum, or a maximum >= 2^126 whose base 6*2^e overflows: the symmetric pass already turned the
        * whole block into NaN and the reference's post-pass is garbage-in/garbage-out there -> the block stays NaN */
       /* symmetric: 1 = symmetric, 0 = the Python layer's asymmetric post-pass (format.py:349-372), 2 = the native

@@ -140,3 +140,126 @@ def test_int8_group_tile_forms_against_the_oracle(dmx, cuda, oracle, dtype, shap
         # (a NaN compares equal to a NaN: torch's CPU float32 -> bfloat16 conversion, which narrows the oracle's result here, writes
         #  0xFFFF for a NaN in its vectorised part and 0x7FC0 in its tail; which ELEMENTS are NaN must agree, and every other bit)
         assert got.dtype == dtype and mismatches_nan_aware(got.float().cpu(), want.to(dtype).float()) == 0, (name, dtype, shape)
+
+
+# ------------------------------------------------------------------------------------------------ live weights as a set (nn.LiveWeightBatch)
+class _Stack(torch.nn.Module):
+    def __init__(self, dmx, dims, dtype, bias=True):
+        super().__init__()
+        self.layers = torch.nn.ModuleList([dmx.nn.Linear(a, b, bias=bias) for a, b in zip(dims[:-1], dims[1:])])
+        for i, l in enumerate(self.layers):
+            l.weight.data = (make("normal", tuple(l.weight.shape), seed=900 + i) * 0.05).to(dtype)
+            if bias:
+                l.bias.data = (make("normal", tuple(l.bias.shape), seed=950 + i) * 0.02).to(dtype)
+
+    def forward(self, x):
+        for l in self.layers:
+            x = l(x)
+        return x
+
+
+def _configure_basic(dmx, model):
+    for m in model.modules():
+        if isinstance(m, dmx.nn.DmxModule):
+            for r in dmx.config_rules.BASIC:
+                if isinstance(m, r.module_types):
+                    m.configure(r.module_config)
+
+
+@pytest.mark.parametrize("kind", ["int8_group", "bfp", "nm_bfp"])
+def test_live_weight_batch_equals_the_per_module_path(dmx, cuda, kind):
+    """Un-folded weights re-quantised every forward (modeling/nn/core.py:178-203) as ONE multi-tensor launch per group of sibling
+    weights (nn.LiveWeightBatch: opt-125m style INT8 per row group, plain BFP, Llama style 2:4 mask -> BFP) == the modules' own
+    per-weight launches, bit for bit; a weight changed between two forwards shows in the next one; GraphedForward installs it."""
+    dtype = F32 if kind == "int8_group" else BF16
+    model = _Stack(dmx, [768, 768, 3072, 768], dtype, bias=kind != "nm_bfp").to(cuda).eval()
+    _configure_basic(dmx, model)
+    if kind == "int8_group":
+        hp = dmx.nn.DmxModuleQuantizerCalibrationHyperparams(weight=dmx.nn.DmxQuantizerCalibrationHyperparams(
+            observer_cls=dmx.MinMaxObserver, qscheme_to_overload=torch.per_tensor_symmetric, group_size=128, ch_axis=0))
+        for l in model.layers:
+            l.configure(dict(weight_format=dmx.format.INT8))
+            with l.calibrating_quantizers(hp), torch.no_grad():
+                l._weight
+    elif kind == "nm_bfp":
+        for i, l in enumerate(model.layers):
+            l.configure(dict(weight_sparseness="BTOPK{2:4,-1}(U)"))
+            with torch.no_grad():
+                l.weight_sparsifier(l.weight)
+                l.weight_sparsifier.score.data = make("normal", tuple(l.weight.shape), seed=970 + i).abs().to(cuda)
+    x = (make("heavy", (2, 128, 768), seed=990).clamp(-100, 100)).to(dtype).to(cuda)
+    with torch.no_grad():
+        want = model(x).clone()
+        want_w = [l._weight_ro.clone() for l in model.layers]
+        batch = dmx.nn.LiveWeightBatch(model)
+        got = model(x)
+        assert all("_live_weight" in l.__dict__ for l in model.layers), "every sibling weight should have been batched"
+        for l, w in zip(model.layers, want_w):   # (what Linear._forward asks for: the weight rounded to the input's dtype)
+            assert bits_equal(l.weight_hypernet(l.weight, dtype), w.to(dtype)) == 0
+            assert l._weight_ro.dtype == w.dtype and bits_equal(l._weight_ro, w) == 0
+        assert bits_equal(got, want) == 0
+        # a weight changed in place: the stamp (storage + version) no longer matches before the next forward's batch, and the next
+        # forward re-quantises everything -- the live semantics of the reference
+        model.layers[1].weight.mul_(1.5)     # (in place on the Parameter: a version bump, as an optimiser step makes)
+        stale = model.layers[1].__dict__["_live_weight"][0]
+        fresh = model.layers[1].weight_hypernet(model.layers[1].weight, dtype)   # NOT the stamped result: it belongs to the Parameter's previous version
+        assert "_live_weight" not in model.layers[1].__dict__ and bits_equal(fresh.to(dtype), stale) != 0
+        batch.remove()
+        want2 = model(x).clone()
+        batch = dmx.nn.LiveWeightBatch(model)
+        got2 = model(x)
+        assert bits_equal(got2, want2) == 0 and bits_equal(got2, want) != 0
+        batch.remove()
+        assert not any("_live_weight" in l.__dict__ for l in model.layers)
+        g = dmx.nn.GraphedForward(model, x)
+        assert g.live_batch is not None
+        assert bits_equal(g(x), want2) == 0
+        assert bits_equal(g(x * 0.5), model(x * 0.5)) == 0
+
+
+# ------------------------------------------------------------------------------------------------ x / s through the reciprocal
+def _every_exponent(n, dtype, seed):
+    """values with every float32 exponent (denormals, the extremes), random and all-ones / all-zeros mantissas, both signs, zeros, Inf, NaN"""
+    g = torch.Generator().manual_seed(seed)
+    e = torch.randint(0, 255, (n,), generator=g, dtype=torch.int64)
+    m = torch.randint(0, 1 << 23, (n,), generator=g, dtype=torch.int64)
+    m[::5] = (1 << 23) - 1
+    m[1::5] = 0
+    sgn = torch.randint(0, 2, (n,), generator=g, dtype=torch.int64)
+    bits = ((sgn << 31) | (e << 23) | m).to(torch.int64)
+    bits = torch.where(bits >= (1 << 31), bits - (1 << 32), bits).to(torch.int32)
+    x = bits.view(torch.float32).clone()
+    x[7::97] = 0.0
+    x[11::101] = -0.0
+    x[13::103] = float("inf")
+    x[17::107] = -float("inf")
+    x[19::109] = float("nan")
+    return x.to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16, F32])
+def test_scale_channels_divide_is_the_ieee_quotient_for_every_input(dmx, cuda, oracle, dtype):
+    """SmoothQuant's x / s (smoothquant.py:255-268) comes from the lane's reciprocals since round 5 (common.hpp div_by_recip: Markstein's
+    correction makes it RN(x / s) inside a stated operand range, an IEEE division redoes everything else).  Bit for bit against torch's
+    CPU division -- IEEE -- on inputs of EVERY exponent, all-ones mantissas, zeros of both signs, Inf, NaN, and scales inside, at the
+    edge of and outside the reciprocal's range; same for the fused x / s -> BFP16_64 input path against the oracle composed like the
+    reference, and for the transposed layout (scale along dim 0: the flat kernel)."""
+    rows, C = 1024, 2048
+    x = _every_exponent(rows * C, dtype, 77).reshape(rows, C)
+    g = torch.Generator().manual_seed(5)
+    s = torch.exp(torch.rand(C, generator=g) * 18.0 - 11.0)     # 1.7e-5 .. 1.1e3
+    s[3], s[64], s[65], s[1000], s[2047] = 2.0 ** -20, 2.0 ** 20, 1e-9, 3e7, 1.0
+    s[5::64] = torch.tensor(2.0 - 2.0 ** -23)                      # all-ones mantissa
+    want = x.float() / s
+    got = dmx.ops.scale_channels(x.to(cuda), s.to(cuda), -1, True, out_dtype=F32)
+    assert mismatches_nan_aware(got, want) == 0
+    if dtype != F32:
+        got16 = dmx.ops.scale_channels(x.to(cuda), s.to(cuda), -1, True, out_dtype=dtype)
+        assert mismatches_nan_aware(got16.float(), want.to(dtype).float()) == 0
+    gotT = dmx.ops.scale_channels(x.t().contiguous().to(cuda), s.to(cuda), 0, True, out_dtype=F32)
+    assert mismatches_nan_aware(gotT, want.t().contiguous()) == 0
+    # the fused activation path: BFP16_64(x / s) in float32 (finite inputs: a block with an Inf / NaN is all-NaN in both)
+    xf = torch.where(torch.isfinite(x.float()), x.float(), torch.zeros(())).to(dtype)
+    fused = dmx.ops.input_hypernet(xf.to(cuda), s.to(cuda), 8, 64)
+    assert fused is not None and fused.dtype == F32
+    assert mismatches_nan_aware(fused, oracle.bfp_cast(xf.float() / s, 8, 64, -1)) == 0
