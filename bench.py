@@ -617,7 +617,7 @@ def main():
         launch_s = step_s / wl.launches_per_step
         achieved = wl.bytes_per_step / step_s
         traffic, traffic_src = None, None
-        for fn in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for fn in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tp = os.path.join(ROOT, "profiles", fn)
             if os.path.exists(tp) and args.workload != "llama-shard":
                 try:

@@ -19,7 +19,11 @@ SOURCES = ["bfp.hip#1", "approx.hip#3", "approx.hip#5", "approx.hip#1", "approx.
 # --offload-compress (round 5): the gfx950 code objects are stored zstd-compressed inside the fat binary and unpacked by the HIP runtime at
 # load: libdmxq.so 88 MB -> 17 MB (what a gpurun snapshot pushes, what a wheel would ship), load time and kernels unchanged
 # (profiles/r05_lib_size.txt).
-FLAGS = ["--offload-arch=gfx950", "--offload-compress", "-O3", "-fPIC", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
+# -amdgpu-kernarg-preload-count=16 (round 5): the first 16 dwords of a kernel's arguments arrive in SGPRs with the wave (gfx940+ kernarg
+# preloading) instead of through s_load + s_waitcnt ahead of the workgroup's first data load: +0.9 % on average over the op table, up
+# to +5 % (same-lease A/B of two builds, profiles/r05_kernarg_preload.txt) -- "nothing may precede a workgroup's first load" applied
+# to the one thing every kernel did first.
+FLAGS = ["--offload-arch=gfx950", "--offload-compress", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-O3", "-fPIC", "-std=c++17", "-fno-fast-math", "-ffp-contract=off",
          "-fgpu-flush-denormals-to-zero" if False else "-fno-gpu-flush-denormals-to-zero"]
 
 

@@ -382,7 +382,9 @@ extern "C" int dmxq_bfp_qdq_describe(int dtype_in, int dtype_out, int64_t outer,
   if (inner == 1 && L % block_size == 0 && pow2 && block_size >= epl && block_size <= 64 * epl && aligned) {
     const bool nearest = rounding == DMXQ_ROUND_NEAREST && precision <= 20;
     const bool single = nearest && ((dtype_in == DMXQ_BF16 && precision <= 14) || (dtype_in == DMXQ_F16 && precision <= 11));
-    const RowsPlan pl = rows_plan(n / epl, nearest, (nearest && symmetric && dtype_in == dtype_out) ? (single ? 20 : 16) : 0);
+    // (round 5: down / up of symmetric formats are compile-time builds on the one-round plans; stochastic and asymmetric non-nearest stay on 512 x 2)
+    const bool big = nearest || (symmetric && precision <= 20 && (rounding == DMXQ_ROUND_DOWN || rounding == DMXQ_ROUND_UP));
+    const RowsPlan pl = rows_plan(n / epl, big, (nearest && symmetric && dtype_in == dtype_out) ? (single ? 20 : 16) : 0);
     const int64_t grid = pl.tiles < kRowsMaxGrid ? pl.tiles : kRowsMaxGrid;
     snprintf(buf, (size_t)buf_len, "dmxq::bfp_rows_kernel<%s,%s,%s,%s,%s> tile %dx%d vectors, grid %lld, nt loads+stores",
              dn[dtype_in], dn[dtype_out], nearest ? "nearest" : rn[rounding], symmetric ? "sym" : "asym",

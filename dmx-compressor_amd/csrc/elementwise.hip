@@ -129,7 +129,10 @@ struct FixedOp {
   static constexpr bool kHeavy = true;
   // 20-32 MiB tensors (stream.hpp), clamped integer formats, 3072 / 3584 / 4096 x 4096 bf16: no affine 64 x 16 8.5 / 9.9 / 11.1 us (256 x 8
   // 9.9 / 11.8 / 13.7); per-group scale 128 x 16 11.1 / 11.6 / 12.4 us (256 x 8 10.9 / 13.9 / 14.9; 512 x 16 12.2 / 12.9 / 13.7)
-  static constexpr int kTileUnroll = !SIMPLE ? 4 : 16, kTileThreads = !SIMPLE ? 256 : (MODE == kNone ? 64 : 128);
+#ifndef DMXQ_EXP_FIXED_T
+#define DMXQ_EXP_FIXED_T 128
+#endif
+  static constexpr int kTileUnroll = !SIMPLE ? 4 : 16, kTileThreads = !SIMPLE ? 256 : (MODE == kNone ? 64 : DMXQ_EXP_FIXED_T);
   static constexpr bool kWaitAll = SIMPLE;  // stream.hpp OpWaitAll: the whole tile's data before the first vector's arithmetic (+3.5 % without a scale)
   FixedFmt f;
   ChannelMap cm;

@@ -1508,9 +1508,16 @@ class LiveWeightBatch:
     `root` at a time -- put the batch on a decoder layer, not on a 70 B model.  `GraphedForward(..., batch_live_weights=True)`
     installs one for the capture."""
 
-    def __init__(self, root: torch.nn.Module):
-        self.root = root
+    def __init__(self, root: torch.nn.Module, replan: bool = True):
+        """replan: plan the groups afresh on every forward (any reconfiguration shows at once; ~13 us of Python per weight-bearing
+        module -- nothing inside a graph capture, 10 % of an EAGER opt-125m layer).  False: plan at the first forward and keep it
+        until `refresh()` -- for a configuration that is frozen while the batch is installed."""
+        self.root, self.replan, self._plan = root, replan, None
         self._handle = root.register_forward_pre_hook(self._prepare)
+
+    def refresh(self):
+        """drop the kept plan (replan = False): the next forward groups the weights again"""
+        self._plan = None
 
     def remove(self):
         self._handle.remove()
@@ -1520,16 +1527,29 @@ class LiveWeightBatch:
 
     def _prepare(self, module, args):
         from . import ops
-        mods = [m for m in self.root.modules() if isinstance(m, DmxModule) and getattr(m, "weight", None) is not None]
+        if self.replan or self._plan is None:
+            mods = [m for m in self.root.modules() if isinstance(m, DmxModule) and getattr(m, "weight", None) is not None]
+        else:
+            mods = self._plan[0]
         for m in mods:
             m.__dict__.pop("_live_weight", None)
         if torch.compiler.is_compiling():
             return
-        mods = [m for m in mods if m.weight.is_cuda and not (torch.is_grad_enabled() and m.weight.requires_grad)]
+        if torch.is_grad_enabled() and any(m.weight.requires_grad for m in mods):
+            mods = [m for m in mods if not m.weight.requires_grad]
+            kept = None
+        else:
+            kept = self._plan if not self.replan else None
         if len(mods) < 2:
             return
         with torch.no_grad():
-            groups, hyper = _weight_batches(mods)
+            if kept is not None:
+                _, groups, hyper = kept
+            else:
+                live = [m for m in mods if m.weight.is_cuda]
+                groups, hyper = _weight_batches(live)
+                if not self.replan and not torch.is_grad_enabled():
+                    self._plan = (mods, groups, hyper)
 
             def stamp(m, o, natural=None):
                 m.__dict__["_live_weight"] = (o, m.weight._version, m.weight.data_ptr(), natural or m.weight.dtype)

@@ -42,11 +42,18 @@ static inline uint32_t rnd_bits(uint64_t seed, uint64_t idx) {
 }
 
 /* The draws of the BFP cast's stochastic mode (round 5; csrc/common.hpp bfp_rnd is the same function): one hash per aligned group of 8
- * elements, a Weyl step and a xor-shift per pair, the pair's word for the even element and the word with its halves swapped for the odd
- * one.  A function of (seed, linear element index) like rnd_bits; four operations per element on the GPU instead of a full hash. */
+ * elements; per pair a Weyl step, a xor-shift, a 24-bit multiply (full rate on the GPU) and a xor-shift; the pair's word for the even
+ * element, the word with its halves swapped for the odd one.  A function of (seed, linear element index) like rnd_bits; unbiased and
+ * pairwise uncorrelated by measurement (tests/test_golden.py). */
 static inline uint32_t bfp_rnd(uint64_t seed, uint64_t idx) {
-  uint32_t w = rnd_bits(seed, idx >> 3) + (((uint32_t)idx & 7u) >> 1) * 0x9E3779B9u;
-  w ^= w >> 15;
+  const uint32_t pair = ((uint32_t)idx & 7u) >> 1;
+  uint32_t w = rnd_bits(seed, idx >> 3);
+  if (pair != 0u) {   /* (the group's hash itself serves its first pair) */
+    w += pair * 0x9E3779B9u;
+    w ^= w >> 15;
+    w = (w & 0xFFFFFFu) * 0xB5297Bu;
+    w ^= w >> 12;
+  }
   return ((uint32_t)idx & 1u) ? ((w >> 16) | (w << 16)) : w;
 }
 

@@ -440,3 +440,34 @@ def test_c2_oracle_reproduces_the_reference_digests(oracle):
         x = make_chunked(kind, (4096, 4096), seed, torch.bfloat16)
         assert sha256_bits(x) == e["input_sha256"]
         assert sha256_bits(oracle.bfp_cast(x, 8, 16).to(torch.bfloat16)) == e["output_sha256"]
+
+
+def test_stochastic_bfp_draws_are_unbiased_and_pairwise_uncorrelated(oracle):
+    """The BFP cast's stochastic stream (round 5: oracle.c bfp_rnd == csrc/common.hpp bfp_rnd, one hash per 8 elements expanded per pair;
+    the reference's is an unseeded global mt19937, so parity with IT is statistical only -- SURVEY Appendix C).  What a stochastic
+    rounding needs of its draws: P(round up) == the dropped fraction for every element position of the group of 8 (unbiased), and
+    the decisions of neighbouring elements -- the two halves of one word, two words of one hash -- uncorrelated."""
+    import torch
+
+    n_blocks, B, wl = 1 << 16, 16, 8
+    # block maximum 1.0 -> exponent 0, quantum 2^-6; every other element sits a fraction f of a quantum above a code
+    fracs = torch.tensor([0.1, 0.25, 0.5, 0.7, 0.9, 0.33, 0.05, 0.95, 0.6, 0.4, 0.8, 0.2, 0.15, 0.85, 0.45])
+    q = 2.0 ** -6
+    x = torch.empty(n_blocks, B)
+    x[:, 0] = 1.0
+    x[:, 1:] = (3.0 + fracs) * q
+    up = torch.zeros(B - 1)
+    ups = []
+    for seed in (1, 2, 3):
+        y = oracle.bfp_cast(x, wl, B, -1, rounding="stochastic", seed=seed)
+        d = ((y[:, 1:] / q).round() - 3.0)                    # 0 = rounded down, 1 = up
+        assert bool(((d == 0) | (d == 1)).all())
+        ups.append(d)
+        up += d.mean(0)
+    up /= 3
+    # 3 x 65536 draws per position: standard error of a frequency <= 0.5 / sqrt(196608) = 0.0011
+    assert float((up - fracs).abs().max()) < 0.006, (up - fracs)
+    d = torch.cat(ups, 0)
+    c = torch.corrcoef(d.t())
+    off = c - torch.eye(B - 1)
+    assert float(off.abs().max()) < 0.02, float(off.abs().max())   # (independent draws: |r| ~ 1 / sqrt(196608) = 0.002)

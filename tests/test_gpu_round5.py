@@ -211,6 +211,9 @@ def test_live_weight_batch_equals_the_per_module_path(dmx, cuda, kind):
         assert bits_equal(got2, want2) == 0 and bits_equal(got2, want) != 0
         batch.remove()
         assert not any("_live_weight" in l.__dict__ for l in model.layers)
+        kept = dmx.nn.LiveWeightBatch(model, replan=False)     # the plan of the first forward serves the following ones
+        assert bits_equal(model(x), want2) == 0 and kept._plan is not None and bits_equal(model(x), want2) == 0
+        kept.remove()
         g = dmx.nn.GraphedForward(model, x)
         assert g.live_batch is not None
         assert bits_equal(g(x), want2) == 0

@@ -211,6 +211,11 @@ def run(name, steps=20, warmup=5, dev=None, modes=("live", "folded", "unfused"))
     n_mod = sum(1 for mod in m.modules() if isinstance(mod, d.nn.DmxModule))
     if "live" in modes:
         res["live"] = time_forward(m, x, extra, steps, warmup, dev)
+        # the same un-folded weights, their chains batched into one multi-tensor launch per group of sibling weights per forward
+        # (nn.LiveWeightBatch, round 5: what GraphedForward installs by default)
+        batch = d.nn.LiveWeightBatch(m, replan=False)   # (the layer's configuration is frozen here: the plan of the first forward is kept)
+        res["live_batched"] = time_forward(m, x, extra, steps, warmup, dev)
+        batch.remove()
     if "unfused" in modes:
         set_fusions(m, False)
         res["unfused"] = time_forward(m, x, extra, steps, warmup, dev)

@@ -2,7 +2,7 @@
 # tools/collect_profiles.sh <round tag, e.g. r02> — everything under profiles/ that is measured on the GPU box, in one go.
 # Run through gpurun from the repo root; results land in gpurun_out/<tag>/ and are copied to profiles/ by hand.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -15,6 +15,9 @@ python3 bench.py --gpus 2 --dist-backend gloo --steps 20 --warmup 5 --no-cpu-bas
 python3 bench.py --gpus 2 --dist-backend gloo --workload llama-shard --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_world2_gloo_llama_hypernet.json 2>> $OUT/bench.err
 python3 bench.py --gpus 2 --dist-backend gloo --workload llama-shard --op bfp --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_world2_gloo_llama_bfp.json 2>> $OUT/bench.err
 python3 bench.py --workload llama-shard --op hypernet-each --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_llama_hypernet_each.json 2>> $OUT/bench.err
+# the N = 8 rehearsal on the box's one GPU (round 5): eight ranks over gloo, c2 and the sharded Llama layer in one multi-tensor launch per rank
+python3 bench.py --gpus 8 --dist-backend gloo --nbuf 4 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_world8_gloo.json 2>> $OUT/bench.err
+python3 bench.py --gpus 8 --dist-backend gloo --workload llama-shard --op hypernet --layers 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line_world8_gloo_llama_hypernet.json 2>> $OUT/bench.err
 python3 tools/bench_shard_sets.py > $OUT/shard_sets.txt 2>&1
 python3 tools/region_probe.py > $OUT/region_probe.txt 2>&1
 python3 bench.py --no-cpu-baseline > $OUT/bench_line_default.json 2>> $OUT/bench.err
