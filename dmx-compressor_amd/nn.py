@@ -519,7 +519,12 @@ class DmxModule(torch.nn.Module):
     #: 16-bit tensors: run a unary module (input cast, function, output cast) as a 65,536-entry TABLE lookup (csrc/lut16.hip): the
     #: table is built once per (function, casts, dtype, device) with the function in float64 rounded ONCE -- the correctly rounded
     #: result, bit-identical to the reference's CPU evaluation wherever that is itself exact -- and kept on the module.
-    #:   True (default)  every function, every 16-bit tensor of a whole number of 16-byte vectors: ONE rounding policy at every size.
+    #:   True (default)  every function, every 16-bit tensor of a whole number of 16-byte vectors (numel % 8 == 0, 16-byte aligned):
+    #:                   ONE rounding policy at every such size.  What it does NOT cover takes the direct kernel -- float32 evaluation
+    #:                   rounded once, within one ulp of the same value -- and says so here rather than silently: tensors that are not
+    #:                   whole aligned vectors; and a stream CAPTURE that finds no table yet RAISES (a capture must not allocate
+    #:                   long-lived state, and falling back would make the captured module return other last bits than the eager
+    #:                   one: run one forward first, or capture through `GraphedForward`, whose warm-up forwards build the table).
     #:                   Costs ~1 us per launch over the direct kernel on small tensors (the 128 KiB table copy per workgroup: 4.2 vs
     #:                   3.1 us on Llama's [128, 14336] SiLU input, 3.0 vs 1.9 us on 128 KB), nothing from ~16 MiB up, and is the
     #:                   FASTER kernel for the GELU family from ~8 MiB (4096 x 4096 bf16: 12.7 vs 15.3-16.1 us) -- profiles/r04_small_tensor_ops.txt
@@ -544,7 +549,13 @@ class DmxModule(torch.nn.Module):
         t = cache.get(key)
         if t is None:
             if torch.cuda.is_current_stream_capturing():
-                return None   # (no allocation of long-lived state inside a capture: GraphedForward's warm-up forwards build it first)
+                # no allocation of long-lived state inside a capture.  With the table as the module's POLICY (lut_activation = True)
+                # a silent fall-back to the direct kernel would make the captured forward differ from the eager one in last bits
+                # (ADVICE r4): refuse; "auto" is a speed choice and may fall back
+                if self.lut_activation is True:
+                    raise RuntimeError(f"{type(self).__name__}: the {func} table for {x.dtype} is not built yet and a stream capture is in progress; "
+                                       "run one forward before capturing (GraphedForward's warm-up does), or set lut_activation = 'auto' / False")
+                return None
             t = ops.unary_cast_table(x, func, cast_in, cast_out)
             if t is None:
                 return None

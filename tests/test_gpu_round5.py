@@ -266,3 +266,28 @@ def test_scale_channels_divide_is_the_ieee_quotient_for_every_input(dmx, cuda, o
     fused = dmx.ops.input_hypernet(xf.to(cuda), s.to(cuda), 8, 64)
     assert fused is not None and fused.dtype == F32
     assert mismatches_nan_aware(fused, oracle.bfp_cast(xf.float() / s, 8, 64, -1)) == 0
+
+
+def test_lut_module_refuses_a_capture_that_would_change_its_bits(dmx, cuda):
+    """A 16-bit unary module whose policy is the table (`lut_activation = True`, the default) must not silently fall back to the direct
+    kernel inside a stream capture that finds no table (ADVICE r4: eager and captured forwards would differ in last bits): it raises;
+    after one eager forward -- or with the speed-only policy "auto" -- the capture goes through."""
+    m = dmx.nn.GELU().to(cuda).eval()
+    dmx.configure_model(m, *dmx.config_rules.BASIC)
+    x = make("normal", (64, 1024), seed=3, dtype=BF16).to(cuda)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.no_grad(), torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with pytest.raises(RuntimeError, match="table"):
+            with torch.cuda.graph(g, stream=side):
+                m(x)
+        torch.cuda.synchronize()
+        want = m(x).clone()            # builds the table
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=side):
+            y = m(x)
+        g2.replay()
+        torch.cuda.synchronize()
+        assert bits_equal(y, want) == 0
+    torch.cuda.current_stream().wait_stream(side)
