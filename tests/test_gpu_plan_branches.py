@@ -373,22 +373,27 @@ def test_widening_outputs_take_the_same_values_on_every_geometry(dmx, cuda, rows
 
 @pytest.mark.parametrize("rows", [600, 1400, 2000, 2500, 3072, 4096, 4200, 4500, 4700])
 @pytest.mark.parametrize("dtype", [BF16, F32], ids=["bf16", "f32"])
-def test_hot_kernel_tile_plans(dmx, cuda, rows, dtype):
+def test_hot_kernel_tile_plans(dmx, cuda, oracle, rows, dtype):
     """every size class of csrc/common.hpp rows_plan (512x1, 128x2, 512x4, 128x8, 512x16, round 4: 512x17 and 512x18 in one round, 512x2; float32 tensors reach the classes at half
-    the rows) for the hot BFP kernel, its widening / stochastic / asymmetric builds and the range-only FLOAT16 cast that shares the plan:
-    whole tensor == 128-row slabs."""
+    the rows) for the hot BFP kernel, its widening / down / asymmetric builds and the range-only FLOAT16 cast that shares the plan:
+    whole tensor == 128-row slabs, and (round 5) every one of them directly against the CPU ORACLE as well -- the slab identity alone
+    compares the library with itself."""
     ops = dmx.ops
-    x = _input(rows, dtype, seed=7 * rows).to(cuda)
+    xh = _input(rows, dtype, seed=7 * rows)
+    x = xh.to(cuda)
     cases = {
-        "BFP[8|8]{16}": lambda t: ops.bfp_qdq(t, 8, 16),
-        "BFP[8|8]{64}": lambda t: ops.bfp_qdq(t, 8, 64),
-        "BFP[8|8]{64} asym": lambda t: ops.bfp_qdq(t, 8, 64, symmetric=False),
-        "BFP[8|8]{32} down": lambda t: ops.bfp_qdq(t, 8, 32, rounding="down"),
-        "BFP[8|8]{64} -> f32": lambda t: ops.bfp_qdq(t, 8, 64, out_dtype=F32),
-        "FLOAT16 cast": lambda t: ops.float_qdq(t, 10, 5, 15, True),
+        "BFP[8|8]{16}": (lambda t: ops.bfp_qdq(t, 8, 16), lambda t: oracle.bfp_cast(t, 8, 16, -1).to(dtype)),
+        "BFP[8|8]{64}": (lambda t: ops.bfp_qdq(t, 8, 64), lambda t: oracle.bfp_cast(t, 8, 64, -1).to(dtype)),
+        "BFP[8|8]{64} asym": (lambda t: ops.bfp_qdq(t, 8, 64, symmetric=False), lambda t: oracle.bfp_cast(t, 8, 64, -1, symmetric=False).to(dtype)),
+        "BFP[8|8]{32} down": (lambda t: ops.bfp_qdq(t, 8, 32, rounding="down"), lambda t: oracle.bfp_cast(t, 8, 32, -1, rounding="down").to(dtype)),
+        "BFP[8|8]{64} -> f32": (lambda t: ops.bfp_qdq(t, 8, 64, out_dtype=F32), lambda t: oracle.bfp_cast(t, 8, 64, -1)),
+        "FLOAT16 cast": (lambda t: ops.float_qdq(t, 10, 5, 15, True), lambda t: oracle.float_quantize(t, 10, 5, 15, True).to(dtype)),
     }
-    for tag, fn in cases.items():
-        _check(f"{tag} {dtype} rows={rows}", fn(x), _slabs(fn, x))
+    for tag, (fn, ref) in cases.items():
+        whole = fn(x)
+        _check(f"{tag} {dtype} rows={rows}", whole, _slabs(fn, x))
+        bad = bits_equal(whole, ref(xh))
+        assert bad == 0, f"{tag} {dtype} rows={rows}: {bad} elements differ from the oracle"
 
 
 @pytest.mark.parametrize("rows", [2561, 2700, 2816, 2817, 3100, 3400, 3700, 3950, 4097, 4100, 4353, 4608, 4609, 4864, 4865, 5000, 5120, 5121])
