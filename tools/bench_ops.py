@@ -28,12 +28,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=4096)
     ap.add_argument("--cols", type=int, default=4096)
-    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--iters", type=int, default=200, help="launches per timed group; the median of 5 groups is reported")
+    ap.add_argument("--warm-ms", type=float, default=40.0, help="untimed launches of the op until this much GPU time has passed")
     ap.add_argument("--json", default=None)
     ap.add_argument("--data", default="heavy", choices=("heavy", "randn"),
                     help="input distribution of the [rows, cols] operands: randn * exp(2 randn) (default: outliers in every block, ~40 "
                          "binades) or plain randn; the chip streams plain randn 10-15 %% faster through the SAME instruction stream "
-                         "(profiles/r05_data_dependence.txt)")
+                         "(profiles/r05_warmup_effect.txt)")
     ap.add_argument("--only", default=None, help="comma-separated substrings: run only the ops whose name contains one of them")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -59,19 +60,32 @@ def main():
     def run(name, launch, nbuf, bytes_per_launch, check=None):
         if only is not None and not any(t in name for t in only):
             return
+        # warm-up by GPU TIME, not by count: the first few hundred launches after the input generation (Philox kernels, allocations)
+        # run 5-15 % slow whatever the op -- same instruction counts (SQ_INSTS_VALU / SALU identical), the chip's clocks settling --
+        # and 20 launches hid that in the first op measured on every new buffer set (profiles/r05_warmup_effect.txt)
         with torch.cuda.stream(stream):
-            for i in range(20):
-                launch(i % nbuf)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for i in range(args.iters):
-                launch(i % nbuf)
-            e1.record(stream)
-            torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / args.iters
+            warmed = 0.0
+            while warmed < args.warm_ms:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for i in range(100):
+                    launch(i % nbuf)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                warmed += e0.elapsed_time(e1)
+            groups = []
+            for r in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for i in range(args.iters):
+                    launch(i % nbuf)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                groups.append(e0.elapsed_time(e1) * 1e3 / args.iters)
+        us = sorted(groups)[2]
         gbs = bytes_per_launch / (us * 1e-6) / 1e9
         results.append({"op": name, "us": round(us, 2), "GB/s": round(gbs, 1), "frac": round(gbs * 1e9 / PEAK, 4),
-                        "bytes": bytes_per_launch})
+                        "bytes": bytes_per_launch, "us_groups": [round(g, 2) for g in groups]})
         print(f"{name:58s} {us:9.2f} us {gbs:9.1f} GB/s {100 * gbs * 1e9 / PEAK:6.1f}%", flush=True)
 
     def nb(per_set_bytes):  # buffer sets needed to exceed 512 MiB total
