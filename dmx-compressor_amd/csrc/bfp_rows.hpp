@@ -151,7 +151,7 @@ __device__ __attribute__((noinline)) void bfp_rows_tile_partial(const char* __re
 // Shared by the single-tensor kernel below and the multi-tensor kernel of bfp.hip.
 // LPBC: lanes per block as a compile-time constant (0 = the runtime value `lpb_rt`): the DPP reduction of the block maximum
 // then has no scalar branches (six `s_cbranch` + `s_nop` per vector otherwise, which also fence the VALU scheduling).
-template <int DTI, int DTO, int RND, bool ASYM, int UNROLL, int MODE, int THREADS, int FAST, int GROUP, int IVB, int LPBC = 0>
+template <int DTI, int DTO, int RND, bool ASYM, int UNROLL, int MODE, int THREADS, int FAST, int GROUP, int IVB, int LPBC = 0, int PACE = 0>
 __device__ __forceinline__ void bfp_rows_tile(const void* __restrict__ in, void* __restrict__ out, int64_t n_vec,
                                               int64_t tile, int lpb_rt, int wl, int rounding, bool stoch, uint64_t seed) {
   const int lpb = LPBC > 0 ? LPBC : lpb_rt;
@@ -169,7 +169,10 @@ __device__ __forceinline__ void bfp_rows_tile(const void* __restrict__ in, void*
   if ((tile + 1) * TILE <= n_vec) {  // full tile (workgroup-uniform): no predicates
     u32x4 raw[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; u++) raw[u] = load_rawv<IVB>(src + u * (THREADS * IVB), lane_in);
+    for (int u = 0; u < UNROLL; u++) {
+      raw[u] = load_rawv<IVB>(src + u * (THREADS * IVB), lane_in);
+      if (u + 1 < UNROLL) pace_issue<PACE>();
+    }
     __builtin_amdgcn_sched_barrier(0);  // every load is issued before any arithmetic: 16 B x UNROLL in flight per lane
 #pragma unroll
     for (int g = 0; g < UNROLL; g += GROUP) {
@@ -228,7 +231,7 @@ __device__ __forceinline__ void bfp_rows_tile(const void* __restrict__ in, void*
 }
 
 template <int DTI, int DTO, int RND, bool ASYM, int UNROLL, int MODE, int THREADS, int FAST = 0, int GROUP = UNROLL,
-          int IVB = 16, int LPBC = 0>
+          int IVB = 16, int LPBC = 0, int PACE = 0>
 __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                           int64_t n_vec, int lpb_arg /*lanes per block*/, int wl,
                                                           int rounding, uint64_t seed) {
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(THREADS) void bfp_rows_kernel(const void* __restric
   const int64_t n_tiles = (n_vec + TILE - 1) / TILE;
 #define DMXQ_TILE_LOOP(L_)                                                                                          \
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)                                                \
-    bfp_rows_tile<DTI, DTO, RND, ASYM, UNROLL, MODE, THREADS, FAST, GROUP, IVB, L_>(in, out, n_vec, tile, lpb, wl, rounding, stoch, seed)
+    bfp_rows_tile<DTI, DTO, RND, ASYM, UNROLL, MODE, THREADS, FAST, GROUP, IVB, L_, PACE>(in, out, n_vec, tile, lpb, wl, rounding, stoch, seed)
   // One-round geometries (UNROLL >= 4) on the magic-add paths: the lanes-per-block of the usual block sizes as a compile-time
   // constant, chosen ONCE per launch -- with a runtime value every vector's DPP reduction is a chain of six scalar
   // branches, which cost 6.7 % of the 64 MiB headline launch (tools/tune_bfp: 11.71 -> 10.93 us).  Multi-round 512x2

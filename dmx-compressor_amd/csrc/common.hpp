@@ -311,6 +311,26 @@ __device__ __forceinline__ uint32_t group_max_u32(uint32_t m, int lanes) {
 // raw 16-byte input vector: load once, then (a) widen to fp32 and (b) take max|x| on the raw bit patterns.
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 
+// PACED LOAD ISSUE (round 5).  N x 8 idle issue cycles of this wave between two of its tile loads.  A wave that issues its 16 loads
+// back to back fills the CU's address queue with ITS tile before the next wave gets a slot; paced, the waves of a CU interleave load
+// by load.  Measured on 4096 x 4096 bf16 (tools/tune_pace, tools/scratch -> profiles/r05_tune_pace.txt): a trivial op on deep flat tiles
+// 128 x 16 12.7 -> 10.8 us, 256 x 16 11.7 -> 10.9, 512 x 16 11.4 -> 10.9 (the plateau the hot BFP kernel sits on: pacing does
+// nothing for it); rows 8 KiB apart (lastdim_kernel, x * s) 12.4 -> 11.2 -- but ops with ~50+ VALU per vector LOSE (x / s 11.9 -> 14.1,
+// INT8 per channel 12.3 -> 12.9: their arithmetic waits for data that now arrives later), and the optimum is not smooth in N.  Hence an op
+// trait (`static constexpr int kLoadPace`), default 0, set only where the gain was >= 5 % over a range of N.
+template <class OP, class = void> struct OpLoadPace { static constexpr int value = 0; };
+template <class OP> struct OpLoadPace<OP, decltype((void)OP::kLoadPace)> { static constexpr int value = OP::kLoadPace; };
+template <int N>
+__device__ __forceinline__ void pace_issue() {
+  if constexpr (N > 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (N >= 8) __builtin_amdgcn_s_sleep(N / 8);   // (64 cycles each)
+#pragma unroll
+    for (int q = 0; q < N % 8; q++) asm volatile("s_nop 7");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <bool NT, typename OFF = int64_t, bool UNAL = false>
 __device__ __forceinline__ u32x4 load_raw16(const void* p, OFF byte_off) {
   if (UNAL) {

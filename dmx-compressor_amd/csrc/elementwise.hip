@@ -378,6 +378,9 @@ template <bool DIVIDE, int MODE>
 struct ScaleOp {
   ChannelMap cm;
   const float* scale;
+  // lastdim_kernel, x * s: 16 idle issue cycles between a lane's row loads (common.hpp OpLoadPace: 4096 x 4096 bf16 12.4 -> 11.2 us,
+  // the same for 2 .. 12); x / s carries ~54 VALU per row behind its loads and LOSES with any pace (11.9 -> 13.7+)
+  static constexpr int kLoadPace = DIVIDE ? 0 : 2;
   __device__ __forceinline__ void apply_one(float x, float& y, int64_t e) const {
     ChanIter it;
     it.start(cm, e);

@@ -42,35 +42,41 @@ __device__ __forceinline__ u32x4 lastdim_load(const void* p, int64_t off) {
   const u32x2 t = __builtin_nontemporal_load((const u32x2*)((const char*)p + off));
   return u32x4{t.x, t.y, 0u, 0u};
 }
-template <int DTI, int DTO, class OP, int THREADS, int RPI, int IVB = 16>
+template <int DTI, int DTO, class OP, int THREADS, int RPI, int IVB = 16, int PACE = 0>
 __global__ __launch_bounds__(THREADS) void lastdim_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t rows,
-                                                         int64_t C, int cv, int lpr, int rpp, OP op) {
+                                                         int64_t C, int cv, const FastDivU32 lpr_div, int rpp, OP op) {
   constexpr int EPL = IVB / Elem<DTI>::bytes, OVB = EPL * Elem<DTO>::bytes;
   const int t = threadIdx.x;
-  const int sub = t / lpr, sl = t - sub * lpr;
+  const int lpr = (int)lpr_div.d;
+  const int sub = (int)lpr_div.div((uint32_t)t), sl = t - sub * lpr;
   const int cb = blockIdx.y * lpr + sl;
   const bool active = sub < rpp && cb < cv;
   const int cbc = cb < cv ? cb : cv - 1;
   const int subc = sub < rpp ? sub : rpp - 1;
   const int64_t r0 = (int64_t)blockIdx.x * rpp * RPI;
   const auto pr = op.template fetch_params<EPL>((int64_t)cbc * EPL);
-  // whole workgroups (all but the last along the rows): a scalar base per row group + one 32-bit lane offset, no per-load address
-  // arithmetic between the loads; the last one clamps its rows (unconditional loads) and predicates its stores
+  // Addresses: ONE scalar base per workgroup (its first row), a scalar step per row group, one 32-bit lane offset (lastdim_plan keeps a
+  // workgroup's rpp * RPI rows under 4 GiB in either dtype).  Whole workgroups (all but the last along the rows): no per-load address
+  // arithmetic between the loads; the last one clamps its rows (unconditional loads) and predicates its stores.
   const bool whole = r0 + (int64_t)rpp * RPI <= rows;  // wave-uniform
   const uint32_t lane_v = (uint32_t)subc * (uint32_t)cv + (uint32_t)cbc;
+  const uint32_t step_v = (uint32_t)rpp * (uint32_t)cv;   // vectors from one of a lane's rows to its next
+  const char* src = (const char*)in + r0 * cv * IVB;
   u32x4 raw[RPI];
   if (whole) {
-    const char* src = (const char*)in + r0 * cv * IVB;
 #pragma unroll
     for (int j = 0; j < RPI; j++) {
-      if constexpr (IVB == 16) raw[j] = load_raw16<true, uint32_t>(src + (int64_t)j * rpp * cv * 16, lane_v * 16u);
-      else raw[j] = lastdim_load<IVB>(src + (int64_t)j * rpp * cv * IVB, (int64_t)(lane_v * (uint32_t)IVB));
+      const char* rowp = src + (uint64_t)((uint32_t)j * step_v) * IVB;
+      if constexpr (IVB == 16) raw[j] = load_raw16<true, uint32_t>(rowp, lane_v * 16u);
+      else raw[j] = lastdim_load<IVB>(rowp, (int64_t)(lane_v * (uint32_t)IVB));
+      if (j + 1 < RPI) pace_issue<PACE>();
     }
   } else {
+    const uint32_t last = (uint32_t)(rows - 1 - r0);  // (the last row of the tensor, counted from this workgroup's first)
 #pragma unroll
     for (int j = 0; j < RPI; j++) {
-      const int64_t r = r0 + (int64_t)j * rpp + subc;
-      raw[j] = lastdim_load<IVB>(in, ((r < rows ? r : rows - 1) * cv + cbc) * IVB);
+      const uint32_t lr = (uint32_t)j * (uint32_t)rpp + (uint32_t)subc;
+      raw[j] = lastdim_load<IVB>(src, (int64_t)(((lr < last ? lr : last) * (uint32_t)cv + (uint32_t)cbc) * (uint32_t)IVB));
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -101,17 +107,18 @@ __global__ __launch_bounds__(THREADS) void lastdim_kernel(const void* __restrict
     o[j] = pack_vec<DTO, EPL>(y);
     __builtin_amdgcn_sched_barrier(0);
   }
+  char* dst = (char*)out + r0 * cv * OVB;
   if (whole) {
-    char* dst = (char*)out + r0 * cv * OVB;
     if (active) {
 #pragma unroll
-      for (int j = 0; j < RPI; j++) store_out<DTO, EPL, true>(dst + (int64_t)j * rpp * cv * OVB + lane_v * (uint32_t)OVB, o[j]);
+      for (int j = 0; j < RPI; j++)
+        store_out<DTO, EPL, true>(dst + (uint64_t)((uint32_t)j * step_v) * OVB + lane_v * (uint32_t)OVB, o[j]);
     }
   } else {
 #pragma unroll
     for (int j = 0; j < RPI; j++) {
-      const int64_t r = r0 + (int64_t)j * rpp + sub;
-      if (active && r < rows) store_out<DTO, EPL, true>((char*)out + (r * cv + cb) * OVB, o[j]);
+      const uint32_t lr = (uint32_t)j * (uint32_t)rpp + (uint32_t)sub;
+      if (active && r0 + lr < rows) store_out<DTO, EPL, true>(dst + (lr * (uint32_t)cv + (uint32_t)cb) * (uint32_t)OVB, o[j]);
     }
   }
   if constexpr (OpDeferredRedo<OP>::value) {
@@ -139,7 +146,7 @@ static inline bool lastdim_plan(int dti, int dto, int64_t rows, int64_t C, Lastd
   const int threads = kThreads;
   const int lpr = cv < threads ? cv : threads, rpp = threads / lpr;
   const int strips = (cv + lpr - 1) / lpr;
-  if (strips > 65535 || (int64_t)rpp * cv * 32 > 0xFFFFFFFFll) return false;  // (32-bit lane offsets: a row group < 4 GiB in either dtype)
+  if (strips > 65535 || (int64_t)rpp * 16 * cv * 32 > 0xFFFFFFFFll) return false;  // (32-bit lane offsets: a workgroup's <= 16 row groups < 4 GiB in either dtype)
   // rows per lane: as many (16, 8, 4) as still leave two workgroups per CU
   // (a widening output -- 32 bytes per lane, two half-line stores -- keeps 8: with 16 the partial lines of a row group no longer merge
   //  before they leave the L2, 95 MB written for 67 MB of output and 34.0 instead of 30.3 us, bf16 -> float32 x / s on 4096 x 4096)
@@ -156,9 +163,14 @@ template <int DTI, int DTO, class OP, int IVB = 16>
 static int launch_lastdim_typed(const void* in, void* out, int64_t rows, int64_t C, const OP& op, hipStream_t s) {
   LastdimPlan pl;
   if (!aligned16(in) || !aligned16(out) || !lastdim_plan(DTI, DTO, rows, C, &pl, IVB)) return DMXQ_ERR_UNSUPPORTED;
+#ifdef DMXQ_EXP_LD_PACE
+  constexpr int kPace = DMXQ_EXP_LD_PACE;
+#else
+  constexpr int kPace = OpLoadPace<OP>::value;   // common.hpp: idle issue cycles between a lane's row loads
+#endif
 #define DMXQ_LDK(R_)                                                                                                          \
-  DMXQ_LAUNCH((lastdim_kernel<DTI, DTO, OP, kThreads, R_, IVB>), dim3((unsigned)pl.gx, (unsigned)pl.strips), dim3(kThreads), 0, s, in, out, rows, C, \
-              pl.cv, pl.lpr, pl.rpp, op)
+  DMXQ_LAUNCH((lastdim_kernel<DTI, DTO, OP, kThreads, R_, IVB, kPace>), dim3((unsigned)pl.gx, (unsigned)pl.strips), dim3(kThreads), 0, s, in, out, rows, C, \
+              pl.cv, make_fastdiv_u32(pl.lpr), pl.rpp, op)
   if (pl.rpi == 16) DMXQ_LDK(16);
   else if (pl.rpi == 8) DMXQ_LDK(8);
   else DMXQ_LDK(4);

@@ -89,7 +89,7 @@ __device__ __forceinline__ void stream_widen(const u32x4& raw, float (&x)[EPL]) 
     for (int k = 0; k < EPL; k++) x[k] = xw[k];
   }
 }
-template <int DTI, int DTO, int UNROLL, int THREADS, class OP, bool UNAL = false, int IVB = 16>
+template <int DTI, int DTO, int UNROLL, int THREADS, class OP, bool UNAL = false, int IVB = 16, int PACE = 0>
 __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                         int64_t n, OP op) {
   static_assert(IVB == 16 || (IVB == 8 && !UNAL && !OpRawHooks<OP>::value), "8-byte input vectors: aligned tensors, no raw-word hooks");
@@ -111,7 +111,10 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict_
       auto load_tile = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) raw[u] = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
+        for (int u = 0; u < UNROLL; u++) {
+          raw[u] = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
+          if (u + 1 < UNROLL) pace_issue<PACE>();
+        }
         __builtin_amdgcn_sched_barrier(0);
       };
       // `variant`: std::integral_constant<int, V>; V = 0 is the op's general per-vector form, V > 0 a straight-line form the op

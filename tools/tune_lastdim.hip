@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
 #define ADD_LD(NAME, OPV, T, R) vs.push_back({std::string(NAME) + " T" #T " R" #R, [=](const void* i, void* o, hipStream_t q) { \
     const int lpr = cv < T ? cv : T, rpp = T / lpr, strips = (cv + lpr - 1) / lpr; \
     int64_t gx = (rows + (int64_t)rpp * R - 1) / ((int64_t)rpp * R); \
-    hipLaunchKernelGGL((lastdim_kernel<DMXQ_BF16, DMXQ_BF16, decltype(OPV), T, R>), dim3((unsigned)gx, (unsigned)strips), dim3(T), 0, q, i, o, rows, C, cv, lpr, rpp, OPV); }, {}})
+    hipLaunchKernelGGL((lastdim_kernel<DMXQ_BF16, DMXQ_BF16, decltype(OPV), T, R>), dim3((unsigned)gx, (unsigned)strips), dim3(T), 0, q, i, o, rows, C, cv, make_fastdiv_u32(lpr), rpp, OPV); }, {}})
 #define ADD_ALL(NAME, OPV) \
   ADD_LD(NAME, OPV, 128, 16); ADD_LD(NAME, OPV, 128, 32); ADD_LD(NAME, OPV, 256, 4); ADD_LD(NAME, OPV, 256, 8); ADD_LD(NAME, OPV, 256, 16); ADD_LD(NAME, OPV, 256, 32); \
   ADD_LD(NAME, OPV, 512, 4); ADD_LD(NAME, OPV, 512, 8); ADD_LD(NAME, OPV, 512, 16); ADD_LD(NAME, OPV, 512, 32); ADD_LD(NAME, OPV, 1024, 8); ADD_LD(NAME, OPV, 1024, 16);
