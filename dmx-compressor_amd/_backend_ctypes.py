@@ -260,6 +260,23 @@ def float_qdq(x, man, exp, bias, flush_subnormal, unsigned_abs=False, rounding=2
 float_qdq_nograd = float_qdq
 
 
+@_guarded
+def float_qdq_multi(xs, man, exp, bias, flush_subnormal, unsigned_abs=False, rounding=2, out_dtype=None, seed=0):
+    if not xs:
+        return []
+    ins = [_prep(t, "float_qdq_multi") for t in xs]
+    dt, dev = ins[0].dtype, ins[0].device
+    if any(x.dtype != dt or x.device != dev for x in ins):
+        raise RuntimeError("float_qdq_multi: all tensors must share one dtype and one device")
+    outs = [torch.empty(x.shape, dtype=out_dtype or dt, device=dev) for x in ins]
+    descs = (_lib.TensorDesc * len(ins))()
+    for d, x, o in zip(descs, ins, outs):
+        d.in_, d.out, d.outer, d.L, d.inner = x.data_ptr(), o.data_ptr(), 1, x.numel(), 1
+    check(lib().dmxq_float_qdq_multi(descs, len(ins), dtype_code(dt), dtype_code(outs[0].dtype), man, exp, bias, int(flush_subnormal),
+                                     int(unsigned_abs), rounding, seed & _U64, stream_of(ins[0])), "dmxq_float_qdq_multi")
+    return outs
+
+
 def _affine_need(C, scale_numel, group_size, has_axis):
     return (-(-C // (group_size or 1))) if has_axis else 1
 

@@ -18,7 +18,7 @@ import torch
 from ._lib import DmxqError, ROUNDING_CODE, require_gpu
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "weight_hypernet_multi", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "unary_cast_table", "lut16_apply", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "group_minmax_accumulate", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "weight_hypernet_multi", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "unary_cast_table", "lut16_apply", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "float_qdq_multi", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "group_minmax_accumulate", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -195,6 +195,20 @@ def fixed_qdq(x, precision: int, fraction: int, clamp: bool = True, symmetric: b
     op = _ops.fixed_qdq if (x.requires_grad and torch.is_grad_enabled()) else _ops.fixed_qdq_nograd
     return op(x, precision, fraction, clamp, symmetric, ROUNDING_CODE[rounding], scale, zero_point, ch_axis,
                           group_size or None, out_dtype, _seed_arg(seed, rounding))
+
+
+def float_qdq_multi(tensors, mantissa: int, exponent: int, bias: Optional[int] = None, flush_subnormal: bool = True,
+                    unsigned: bool = False, rounding: str = "nearest", out_dtype: Optional[torch.dtype] = None, seed: Optional[int] = None):
+    """Low-bit floating point Q->DQ (format.py:208-233) of MANY tensors of one dtype on one device in as few launches as possible
+    (`dmxq_float_qdq_multi`): the same results as `[float_qdq(t, mantissa, exponent, bias, ...) for t in tensors]` -- the bias casts
+    of a layer's modules (modeling/nn/core.py:191-203), a few hundred elements each, as ONE launch."""
+    tensors = list(tensors)
+    for t in tensors:
+        require_gpu(t, "float_qdq_multi")
+    if bias is None:
+        bias = (1 << (exponent - 1)) - 1
+    return list(_ops.float_qdq_multi(tensors, mantissa, exponent, bias, bool(flush_subnormal), bool(unsigned), ROUNDING_CODE[rounding],
+                                     out_dtype, _seed_arg(seed, rounding)))
 
 
 def fixed_qdq_multi(tensors, precision: int, fraction: int, clamp: bool, symmetric: bool, scales, zero_points,

@@ -89,136 +89,143 @@ __device__ __forceinline__ void stream_widen(const u32x4& raw, float (&x)[EPL]) 
     for (int k = 0; k < EPL; k++) x[k] = xw[k];
   }
 }
+// ONE tile (THREADS x UNROLL lane-vectors) of a flat tensor of n_vec vectors; `tile` is the tile index inside that tensor.  Shared by the
+// single-tensor kernel below and the multi-tensor kernel (stream_multi_kernel: many small tensors of one op in one launch).
+template <int DTI, int DTO, int UNROLL, int THREADS, class OP, bool UNAL, int IVB, int PACE, bool NTS = true>
+__device__ __forceinline__ void stream_tile(const void* __restrict__ in, void* __restrict__ out, int64_t n_vec, int64_t tile, const OP& op) {
+  constexpr int EPL = IVB / Elem<DTI>::bytes;
+  constexpr int OVB = EPL * Elem<DTO>::bytes;
+  constexpr int64_t TILE = (int64_t)THREADS * UNROLL;
+  const uint32_t lane_in = threadIdx.x * (uint32_t)IVB, lane_out = threadIdx.x * (uint32_t)OVB;
+  const char* src = (const char*)in + tile * (TILE * IVB);
+  char* dst = (char*)out + tile * (TILE * OVB);
+  const int64_t v0 = tile * TILE + threadIdx.x;
+  if ((tile + 1) * TILE <= n_vec) {
+    // load burst + compute + store burst of a full tile, with the per-vector side data coming from prep_of(u).  The side data
+    // (scale / zero-point reads) is requested BEFORE the tile's own loads: vector memory returns in order, so behind them it
+    // would only arrive after the whole tile, and the first vector's arithmetic could not start while the rest streams in.
+    u32x4 raw[UNROLL];
+    auto load_tile = [&]() __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) {
+        raw[u] = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
+        if (u + 1 < UNROLL) pace_issue<PACE>();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // `variant`: std::integral_constant<int, V>; V = 0 is the op's general per-vector form, V > 0 a straight-line form the op
+    // offers for tiles whose (wave-uniform) side data allows it (OpTileVariants below)
+    auto finish = [&](auto prep_of, auto variant) __attribute__((always_inline)) {
+      constexpr int V = decltype(variant)::value;
+      OutVec<DTO, EPL> o[UNROLL];
+      uint32_t redo = 0u;  // (V > 0) bit u: this lane's vector u needs the op's exact form
+#ifdef DMXQ_EXP_WAITALL_ALL
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+      if constexpr (V == 0 && OpWaitAll<OP>::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // The whole tile's data before the first vector's arithmetic (round 5).  Left to the compiler the waits are per vector
+      // (vmcnt(15), (14), ...): a wave then starts converting while the rest of its tile -- and the other workgroups' tiles -- still
+      // stream in, finishes early and starts STORING while others still read.  Measured on the INT8 group cast, 4096 x 4096 bf16,
+      // 128 x 16 tiles: 13.06 us per-vector waits, 11.48 us with this one wait (tools/tune_stream, -DDMXQ_EXP_*): read bursts
+      // followed by write bursts, the finding of the BFP kernel's tile schedule, applies inside a tile's wait
+      // pattern too.  Per op, measured (profiles/r05_tune_stream_waitall.txt): light ops gain 3-8 % (INT8 without a scale 11.06 -> 10.68 us,
+      // the FLOAT16 cast of float32 tensors 12.04 -> 11.00), VALU-heavy ones on deep tiles LOSE 5-15 % (SiLU 512 x 16 11.35 -> 12.91:
+      // their arithmetic no longer overlaps the tail of the loads) -- hence a trait (`static constexpr bool kWaitAll = true`), not a rule.
+      if constexpr (V > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) {
+        float x[EPL], y[EPL];
+        if constexpr (OpRawHooks<OP>::value) op.raw_in(raw[u]);
+        stream_widen<DTI, EPL>(raw[u], x);
+        if constexpr (V == 0) tile_apply<V>(op, x, y, (v0 + (int64_t)u * THREADS) * EPL, prep_of(u));
+        else redo |= tile_apply_flag<V>(op, x, y, prep_of(u)) ? 1u << u : 0u;
+        o[u] = pack_vec<DTO, EPL>(y);
+        if constexpr (OpRawHooks<OP>::value) op.raw_out(o[u]);
+#ifdef DMXQ_EXP_NOFENCE
+        if constexpr (V == 0) __builtin_amdgcn_sched_barrier(0);
+#else
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) store_out<DTO, EPL, NTS, UNAL>(dst + u * (THREADS * OVB) + lane_out, o[u]);
+      if constexpr (V > 0) {
+        // The straight-line forms do not cover every input (Inf / NaN quotients): flagged vectors are redone AFTER the store burst,
+        // from a fresh load, and stored again by the same lane (same-address stores of a lane stay ordered) -- ONE cold loop per
+        // tile.  Redone in place behind a branch per vector, the compiler laid 16 cold blocks of ~250 instructions between the hot
+        // ones: the tile body no longer fitted the instruction cache (INT8 per group, zero point 0: 12.2 us where the form WITH
+        // a zero point, whose cold blocks happened to be placed out of line, ran 11.6; tools/tune_stream int8g0 / int8g).
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo != 0u) != 0ull, 0)) {
+#pragma unroll 1
+          for (int u = 0; u < UNROLL; u++) {
+            if ((redo >> u) & 1u) {
+              const u32x4 r1 = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
+              float x[EPL], y[EPL];
+              stream_widen<DTI, EPL>(r1, x);
+              tile_apply_exact(op, x, y, (v0 + (int64_t)u * THREADS) * EPL, prep_of(u));
+              store_out<DTO, EPL, NTS, UNAL>(dst + u * (THREADS * OVB) + lane_out, pack_vec<DTO, EPL>(y));
+            }
+          }
+        }
+      }
+    };
+    if constexpr (OpTilePrep<OP>::value) {
+      // the whole tile shares one set of side data (one quantisation group): fetched once, from a wave-uniform address,
+      // instead of an index computation and two dependent loads per 16-byte vector
+      typename OP::Prep tp;
+      if (op.tile_prepare(tile * (TILE * EPL), TILE * EPL, tp)) {  // wave-uniform
+        load_tile();
+        auto pf = [&](int) -> const typename OP::Prep& { return tp; };
+        if constexpr (OpTileVariants<OP>::value == 3) {
+          // (the scalar table reads are waited for HERE, behind the tile's loads)
+          const int v = op.tile_variant(tp);  // (also completes tp)
+          if (v == 2) finish(pf, std::integral_constant<int, 2>{});
+          else if (v == 1) finish(pf, std::integral_constant<int, 1>{});
+          else finish(pf, std::integral_constant<int, 0>{});
+        } else {
+          finish(pf, std::integral_constant<int, 0>{});
+        }
+        return;
+      }
+    }
+    typename OpPrep<OP>::type prep[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) prep[u] = OpPrep<OP>::get(op, (v0 + (int64_t)u * THREADS) * EPL);
+    load_tile();
+    finish([&](int u) -> const typename OpPrep<OP>::type& { return prep[u]; }, std::integral_constant<int, 0>{});
+  } else {
+    // the last, partial tile, vector by vector.  (The hot BFP kernel runs its partial tile on the full tile's schedule, in a function
+    // of its own -- bfp_rows_tile_partial.  The same here measured a DISASTER: with a non-inlined call in the kernel the full tiles
+    // of float_qdq went 12.0 -> 21.9 us, fixed_qdq 11.0 -> 16.2, silu 11.2 -> 12.2 on 4096 x 4096 bf16; and these kernels keep >= 2
+    // workgroups per CU, so the serial tail of ONE workgroup costs them at most ~5 % at a few sizes, not the 40 % it cost a
+    // one-workgroup-per-CU plan: tools/probe_partial.py.)
+    for (int u = 0; u < UNROLL; u++) {
+      const int64_t vi = v0 + (int64_t)u * THREADS;
+      if (vi < n_vec) {
+        u32x4 raw = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
+        float x[EPL], y[EPL];
+        if constexpr (OpRawHooks<OP>::value) op.raw_in(raw);
+        stream_widen<DTI, EPL>(raw, x);
+        op.apply_vec(x, y, vi * EPL);
+        OutVec<DTO, EPL> o1 = pack_vec<DTO, EPL>(y);
+        if constexpr (OpRawHooks<OP>::value) op.raw_out(o1);
+        store_out<DTO, EPL, NTS, UNAL>(dst + u * (THREADS * OVB) + lane_out, o1);
+      }
+    }
+  }
+}
+
 template <int DTI, int DTO, int UNROLL, int THREADS, class OP, bool UNAL = false, int IVB = 16, int PACE = 0>
 __global__ __launch_bounds__(THREADS) void stream_kernel(const void* __restrict__ in, void* __restrict__ out,
                                                         int64_t n, OP op) {
   static_assert(IVB == 16 || (IVB == 8 && !UNAL && !OpRawHooks<OP>::value), "8-byte input vectors: aligned tensors, no raw-word hooks");
   constexpr int EPL = IVB / Elem<DTI>::bytes;
-  constexpr int OVB = EPL * Elem<DTO>::bytes;
   constexpr int64_t TILE = (int64_t)THREADS * UNROLL;
   const int64_t n_vec = n / EPL;
   const int64_t n_tiles = (n_vec + TILE - 1) / TILE;
-  const uint32_t lane_in = threadIdx.x * (uint32_t)IVB, lane_out = threadIdx.x * (uint32_t)OVB;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const char* src = (const char*)in + tile * (TILE * IVB);
-    char* dst = (char*)out + tile * (TILE * OVB);
-    const int64_t v0 = tile * TILE + threadIdx.x;
-    if ((tile + 1) * TILE <= n_vec) {
-      // load burst + compute + store burst of a full tile, with the per-vector side data coming from prep_of(u).  The side data
-      // (scale / zero-point reads) is requested BEFORE the tile's own loads: vector memory returns in order, so behind them it
-      // would only arrive after the whole tile, and the first vector's arithmetic could not start while the rest streams in.
-      u32x4 raw[UNROLL];
-      auto load_tile = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-          raw[u] = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
-          if (u + 1 < UNROLL) pace_issue<PACE>();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      // `variant`: std::integral_constant<int, V>; V = 0 is the op's general per-vector form, V > 0 a straight-line form the op
-      // offers for tiles whose (wave-uniform) side data allows it (OpTileVariants below)
-      auto finish = [&](auto prep_of, auto variant) __attribute__((always_inline)) {
-        constexpr int V = decltype(variant)::value;
-        OutVec<DTO, EPL> o[UNROLL];
-        uint32_t redo = 0u;  // (V > 0) bit u: this lane's vector u needs the op's exact form
-#ifdef DMXQ_EXP_WAITALL_ALL
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-        if constexpr (V == 0 && OpWaitAll<OP>::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // The whole tile's data before the first vector's arithmetic (round 5).  Left to the compiler the waits are per vector
-        // (vmcnt(15), (14), ...): a wave then starts converting while the rest of its tile -- and the other workgroups' tiles -- still
-        // stream in, finishes early and starts STORING while others still read.  Measured on the INT8 group cast, 4096 x 4096 bf16,
-        // 128 x 16 tiles: 13.06 us per-vector waits, 11.48 us with this one wait (tools/tune_stream, -DDMXQ_EXP_*): read bursts
-        // followed by write bursts, the finding of the BFP kernel's tile schedule, applies inside a tile's wait
-        // pattern too.  Per op, measured (profiles/r05_tune_stream_waitall.txt): light ops gain 3-8 % (INT8 without a scale 11.06 -> 10.68 us,
-        // the FLOAT16 cast of float32 tensors 12.04 -> 11.00), VALU-heavy ones on deep tiles LOSE 5-15 % (SiLU 512 x 16 11.35 -> 12.91:
-        // their arithmetic no longer overlaps the tail of the loads) -- hence a trait (`static constexpr bool kWaitAll = true`), not a rule.
-        if constexpr (V > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-          float x[EPL], y[EPL];
-          if constexpr (OpRawHooks<OP>::value) op.raw_in(raw[u]);
-          stream_widen<DTI, EPL>(raw[u], x);
-          if constexpr (V == 0) tile_apply<V>(op, x, y, (v0 + (int64_t)u * THREADS) * EPL, prep_of(u));
-          else redo |= tile_apply_flag<V>(op, x, y, prep_of(u)) ? 1u << u : 0u;
-          o[u] = pack_vec<DTO, EPL>(y);
-          if constexpr (OpRawHooks<OP>::value) op.raw_out(o[u]);
-#ifdef DMXQ_EXP_NOFENCE
-          if constexpr (V == 0) __builtin_amdgcn_sched_barrier(0);
-#else
-          __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) store_out<DTO, EPL, true, UNAL>(dst + u * (THREADS * OVB) + lane_out, o[u]);
-        if constexpr (V > 0) {
-          // The straight-line forms do not cover every input (Inf / NaN quotients): flagged vectors are redone AFTER the store burst,
-          // from a fresh load, and stored again by the same lane (same-address stores of a lane stay ordered) -- ONE cold loop per
-          // tile.  Redone in place behind a branch per vector, the compiler laid 16 cold blocks of ~250 instructions between the hot
-          // ones: the tile body no longer fitted the instruction cache (INT8 per group, zero point 0: 12.2 us where the form WITH
-          // a zero point, whose cold blocks happened to be placed out of line, ran 11.6; tools/tune_stream int8g0 / int8g).
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo != 0u) != 0ull, 0)) {
-#pragma unroll 1
-            for (int u = 0; u < UNROLL; u++) {
-              if ((redo >> u) & 1u) {
-                const u32x4 r1 = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
-                float x[EPL], y[EPL];
-                stream_widen<DTI, EPL>(r1, x);
-                tile_apply_exact(op, x, y, (v0 + (int64_t)u * THREADS) * EPL, prep_of(u));
-                store_out<DTO, EPL, true, UNAL>(dst + u * (THREADS * OVB) + lane_out, pack_vec<DTO, EPL>(y));
-              }
-            }
-          }
-        }
-      };
-      if constexpr (OpTilePrep<OP>::value) {
-        // the whole tile shares one set of side data (one quantisation group): fetched once, from a wave-uniform address,
-        // instead of an index computation and two dependent loads per 16-byte vector
-        typename OP::Prep tp;
-        if (op.tile_prepare(tile * (TILE * EPL), TILE * EPL, tp)) {  // wave-uniform
-          load_tile();
-          auto pf = [&](int) -> const typename OP::Prep& { return tp; };
-          if constexpr (OpTileVariants<OP>::value == 3) {
-            // (the scalar table reads are waited for HERE, behind the tile's loads)
-            const int v = op.tile_variant(tp);  // (also completes tp)
-            if (v == 2) finish(pf, std::integral_constant<int, 2>{});
-            else if (v == 1) finish(pf, std::integral_constant<int, 1>{});
-            else finish(pf, std::integral_constant<int, 0>{});
-          } else {
-            finish(pf, std::integral_constant<int, 0>{});
-          }
-          continue;
-        }
-      }
-      typename OpPrep<OP>::type prep[UNROLL];
-#pragma unroll
-      for (int u = 0; u < UNROLL; u++) prep[u] = OpPrep<OP>::get(op, (v0 + (int64_t)u * THREADS) * EPL);
-      load_tile();
-      finish([&](int u) -> const typename OpPrep<OP>::type& { return prep[u]; }, std::integral_constant<int, 0>{});
-    } else {
-      // the last, partial tile, vector by vector.  (The hot BFP kernel runs its partial tile on the full tile's schedule, in a function
-      // of its own -- bfp_rows_tile_partial.  The same here measured a DISASTER: with a non-inlined call in the kernel the full tiles
-      // of float_qdq went 12.0 -> 21.9 us, fixed_qdq 11.0 -> 16.2, silu 11.2 -> 12.2 on 4096 x 4096 bf16; and these kernels keep >= 2
-      // workgroups per CU, so the serial tail of ONE workgroup costs them at most ~5 % at a few sizes, not the 40 % it cost a
-      // one-workgroup-per-CU plan: tools/probe_partial.py.)
-      for (int u = 0; u < UNROLL; u++) {
-        const int64_t vi = v0 + (int64_t)u * THREADS;
-        if (vi < n_vec) {
-          u32x4 raw = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
-          float x[EPL], y[EPL];
-          if constexpr (OpRawHooks<OP>::value) op.raw_in(raw);
-          stream_widen<DTI, EPL>(raw, x);
-          op.apply_vec(x, y, vi * EPL);
-          OutVec<DTO, EPL> o1 = pack_vec<DTO, EPL>(y);
-          if constexpr (OpRawHooks<OP>::value) op.raw_out(o1);
-          store_out<DTO, EPL, true, UNAL>(dst + u * (THREADS * OVB) + lane_out, o1);
-        }
-      }
-    }
-  }
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) stream_tile<DTI, DTO, UNROLL, THREADS, OP, UNAL, IVB, PACE>(in, out, n_vec, tile, op);
   // scalar tail: the n % EPL elements after the last whole vector
   if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n_vec * EPL)) {
     const int64_t e = n_vec * EPL + threadIdx.x;
@@ -300,6 +307,68 @@ static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hip
   else if (n_vec <= ((int64_t)1 << 21)) DMXQ_STREAM(TT, TU);
   else DMXQ_STREAM(256, 2);
 #undef DMXQ_STREAM
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// MANY tensors of one op in ONE launch (round 5): the tile body above, the tensor found from the workgroup index.  For sets of sibling
+// parameters that are launch-bound one by one -- the INT8 casts of a decoder layer's weights, the bias casts of its six Linear
+// modules (768 .. 3072 elements each: ~2.3 us of launch for nothing to stream).  Every tensor has its OWN op instance (its scale /
+// zero-point tables, its channel map); whole 16-byte vectors, 16-byte aligned, < 2^31 vectors: the callers give every other tensor a
+// launch of its own, so the result is always what one call per tensor gives.  Geometry: launch_stream's size rule applied to the
+// TOTAL of the set.  (The hand-written predecessor of this kernel, fixed_multi_kernel, ran 256 x 4 tiles with a table read and a
+// division per vector: 13.8 us for the 56 MB of an opt-125m layer's six float32 weights, 51 % of the roofline.)
+template <class OP> struct StreamMultiDesc { const void* in; void* out; int64_t n_vec, tile0; OP op; };
+template <class OP> struct StreamMultiArgs {
+  static constexpr int kMax = (int)(3600 / sizeof(StreamMultiDesc<OP>)) < 32 ? (int)(3600 / sizeof(StreamMultiDesc<OP>)) : 32;  // (a 4 KiB argument block)
+  int n;
+  StreamMultiDesc<OP> d[kMax];
+};
+// WHICH tensor a workgroup belongs to comes from ten scalar arguments -- e[i] = the first tile of tensor i + 1 (0xFFFFFFFF beyond the
+// last) -- that arrive in SGPRs with the wave (kernel-argument preloading covers the first 44 bytes of SCALAR arguments): no memory
+// access for sets of up to 11 tensors.  Scanned from the argument block instead, a workgroup made two DEPENDENT scalar-memory round
+// trips (the tile table, then its descriptor) before its first data load: ~1 us on a 10 us launch.  Larger sets finish the scan in the
+// argument block.
+constexpr int kStreamMultiPre = 10;
+// NTS: non-temporal stores.  Off for sets of up to 32 MiB: their results are consumed at once (a layer's quantised weights by its GEMMs)
+// and fit the Infinity Cache -- opt-125m layer, one hipGraph of the forward: 188.5 -> 185.1 us with plain stores in this kernel.
+template <int DTI, int DTO, int UNROLL, int THREADS, class OP, bool NTS>
+__global__ __launch_bounds__(THREADS) void stream_multi_kernel(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3, uint32_t e4, uint32_t e5,
+                                                              uint32_t e6, uint32_t e7, uint32_t e8, uint32_t e9, int n,
+                                                              const StreamMultiArgs<OP> a) {
+  const uint32_t gt = blockIdx.x;
+  int k = (e0 <= gt) + (e1 <= gt) + (e2 <= gt) + (e3 <= gt) + (e4 <= gt) + (e5 <= gt) + (e6 <= gt) + (e7 <= gt) + (e8 <= gt) + (e9 <= gt);
+  if (k == kStreamMultiPre) {
+    for (int i = kStreamMultiPre + 1; i < n; i++) k = ((uint32_t)a.d[i].tile0 <= gt) ? i : k;
+  }
+  const StreamMultiDesc<OP>& d = a.d[k];
+  stream_tile<DTI, DTO, UNROLL, THREADS, OP, false, 16, 0, NTS>(d.in, d.out, d.n_vec, (int64_t)gt - d.tile0, d.op);
+}
+
+// Host side of one launch: a.d[i].{in, out, n_vec, op} filled for i < a.n (n_vec > 0, whole vectors, aligned); fills tile0 and launches.
+template <int DTI, int DTO, class OP>
+static int launch_stream_multi(StreamMultiArgs<OP>& a, hipStream_t s) {
+  if (a.n < 1) return DMXQ_OK;
+  constexpr bool WIDE = Elem<DTO>::bytes > Elem<DTI>::bytes;
+  constexpr int UB = WIDE ? 8 : 16;
+  constexpr int TT = OpTileThreads<OP>::value, TU = OpTileUnroll<OP>::value < UB ? OpTileUnroll<OP>::value : UB;
+  int64_t total = 0;
+  for (int i = 0; i < a.n; i++) total += a.d[i].n_vec;
+#define DMXQ_STREAM_MULTI(T_, U_, N_)                                                                                   \
+  do {                                                                                                                \
+    int64_t tiles = 0;                                                                                                \
+    for (int i = 0; i < a.n; i++) { a.d[i].tile0 = tiles; tiles += (a.d[i].n_vec + (int64_t)(T_) * (U_) - 1) / ((int64_t)(T_) * (U_)); } \
+    if (tiles >= ((int64_t)1 << 31)) return DMXQ_ERR_UNSUPPORTED;                                                     \
+    uint32_t e[kStreamMultiPre];                                                                                      \
+    for (int i = 0; i < kStreamMultiPre; i++) e[i] = i + 1 < a.n ? (uint32_t)a.d[i + 1].tile0 : 0xFFFFFFFFu;           \
+    DMXQ_LAUNCH((stream_multi_kernel<DTI, DTO, U_, T_, OP, N_>), dim3((unsigned)tiles), dim3(T_), 0, s, e[0], e[1], e[2], e[3], e[4], e[5], \
+                e[6], e[7], e[8], e[9], a.n, a);                                                                     \
+  } while (0)
+  if (total <= ((int64_t)1 << 17)) DMXQ_STREAM_MULTI(256, 1, false);
+  else if (total <= ((int64_t)5 << 18)) DMXQ_STREAM_MULTI(256, 4, false);
+  else if (total <= ((int64_t)1 << 21)) DMXQ_STREAM_MULTI(TT, TU, false);
+  else DMXQ_STREAM_MULTI(256, 2, true);
+#undef DMXQ_STREAM_MULTI
   return launch_status();
 }
 

@@ -350,6 +350,29 @@ Tensor float_qdq_meta(const Tensor& x, int64_t, int64_t, int64_t, bool, bool, in
   return empty_like_shape(x, out_dtype);
 }
 
+std::vector<Tensor> float_qdq_multi(at::TensorList xs, int64_t man, int64_t exp, int64_t bias, bool flush, bool unsigned_abs, int64_t rounding,
+                                    OptDtype out_dtype, int64_t seed) {
+  std::vector<Tensor> outs, ins;
+  if (xs.empty()) return outs;
+  std::vector<dmxq_tensor_desc> d(xs.size());
+  for (size_t i = 0; i < xs.size(); i++) {
+    ins.push_back(prep(xs[i], "float_qdq_multi"));
+    TORCH_CHECK(ins[i].scalar_type() == ins[0].scalar_type() && ins[i].device() == ins[0].device(),
+                "float_qdq_multi: all tensors must share one dtype and one device");
+    outs.push_back(empty_like_shape(ins[i], out_dtype));
+    d[i] = dmxq_tensor_desc{ins[i].data_ptr(), outs[i].data_ptr(), 1, ins[i].numel(), 1};
+  }
+  Launch l(ins[0]);
+  check(dmxq_float_qdq_multi(d.data(), (int64_t)d.size(), dt_code(ins[0].scalar_type()), dt_code(outs[0].scalar_type()), (int)man, (int)exp,
+                             (int)bias, flush, unsigned_abs, (int)rounding, (uint64_t)seed, l.stream), "dmxq_float_qdq_multi");
+  return outs;
+}
+std::vector<Tensor> float_qdq_multi_meta(at::TensorList xs, int64_t, int64_t, int64_t, bool, bool, int64_t, OptDtype out_dtype, int64_t) {
+  std::vector<Tensor> outs;
+  for (const Tensor& x : xs) outs.push_back(empty_like_shape(x, out_dtype));
+  return outs;
+}
+
 Tensor fixed_qdq(const Tensor& x, int64_t precision, int64_t fraction, bool clamp, bool symmetric, int64_t rounding,
                  const OptTensor& scale, const OptTensor& zero_point, c10::optional<int64_t> ch_axis,
                  c10::optional<int64_t> group_size, OptDtype out_dtype, int64_t seed) {
@@ -773,6 +796,7 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("float_qdq_nograd(Tensor x, int man, int exp, int bias, bool flush_subnormal, bool unsigned_abs=False, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor");  // the same kernel without the Python STE autograd wrapper (2.5 us per call)
   m.def("fixed_qdq(Tensor x, int precision, int fraction, bool clamp, bool symmetric, int rounding, Tensor? scale, Tensor? zero_point, int? ch_axis, int? group_size, ScalarType? out_dtype=None, int seed=0) -> Tensor");
   m.def("fixed_qdq_nograd(Tensor x, int precision, int fraction, bool clamp, bool symmetric, int rounding, Tensor? scale, Tensor? zero_point, int? ch_axis, int? group_size, ScalarType? out_dtype=None, int seed=0) -> Tensor");  // the same kernel without the Python STE autograd wrapper (2.5 us per call)
+  m.def("float_qdq_multi(Tensor[] xs, int man, int exp, int bias, bool flush_subnormal, bool unsigned_abs=False, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor[]");
   m.def("fixed_qdq_multi(Tensor[] xs, int precision, int fraction, bool clamp, bool symmetric, int rounding, Tensor[] scales, Tensor[] zero_points, int group_size, ScalarType? out_dtype=None, int seed=0) -> Tensor[]");
   m.def("nm_mask(Tensor score, Tensor? x, int K, int M, int block_dim, bool want_mask, bool want_y, ScalarType? mask_dtype=None, ScalarType? y_dtype=None) -> (Tensor, Tensor)");
   m.def("topk_mask(Tensor score, Tensor? x, int n_zero, bool want_mask, bool want_y, ScalarType? mask_dtype=None, ScalarType? y_dtype=None) -> (Tensor, Tensor)");
@@ -800,7 +824,7 @@ TORCH_LIBRARY(dmxq, m) {
 #define DMXQ_META(m, name) m.impl(#name, &name##_meta)
 #define DMXQ_FOR_ALL(X, m) \
   X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, weight_hypernet_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, input_hypernet); X(m, binary_cast); X(m, relu_cast); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
-  X(m, float_qdq); X(m, fixed_qdq); X(m, fixed_qdq_multi); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
+  X(m, float_qdq); X(m, float_qdq_multi); X(m, fixed_qdq); X(m, fixed_qdq_multi); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
   X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, rope); X(m, rope_cast); X(m, softmax); X(m, norm); \
   X(m, unary_cast); X(m, unary_cast_table); X(m, lut16_apply); X(m, softmax_cast); X(m, norm_cast); X(m, group_minmax_accumulate)
 

@@ -118,6 +118,14 @@ int dmxq_bfp_unpack(const int8_t* mant, const uint8_t* exps, void* out, int dtyp
 int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int man_bits, int exp_bits,
                    int exp_bias, int flush_subnormal, int unsigned_abs, int rounding, uint64_t seed, void* stream);
 
+/* Multi-tensor twin of dmxq_float_qdq (round 5): exactly the result of one dmxq_float_qdq call per tensor (same dtype pair and format for
+ * all; tensor i holds outer * L * inner elements), in as few launches as possible.  Replaces the per-module bias casts of a layer
+ * (modeling/nn/core.py:191-203 `_bias = self.bias_cast(self.bias)`, one launch per Linear per forward while biases are not folded:
+ * an opt-125m decoder layer has six of 768 .. 3072 elements).  `tensors` is a HOST array.  Batched: nearest rounding, whole 16-byte
+ * vectors, 16-byte aligned, < 2^31 elements; every other tensor gets its own launch (stochastic rounding: seed + index). */
+int dmxq_float_qdq_multi(const dmxq_tensor_desc* tensors, int64_t n_tensors, int dtype_in, int dtype_out, int man_bits, int exp_bits,
+                         int exp_bias, int flush_subnormal, int unsigned_abs, int rounding, uint64_t seed, void* stream);
+
 /* Fixed point Q->DQ ("XP[p,f](C|_ S|_ R)") with the optional affine wrapper fused in.
  * Replaces: numerical/format.py:134-142 FixedPoint.cast -> quant_function.py:47-84 fixed_point_quantize
  *           -> quant_cpu.cpp:127-209 (CPU rounding: half-to-even through sim_helper.cpp:14-21), and
@@ -131,7 +139,7 @@ int dmxq_fixed_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64
 /* Multi-tensor twin of dmxq_fixed_qdq: exactly the result of one dmxq_fixed_qdq call per tensor (same dtype pair, format
  * and group_size for all; each tensor its own scale / zero-point arrays), in as few launches as possible.  Replaces the
  * per-module loop over the INT8 group-quantised Linear weights of a whole model (numerical/cast.py:278-296 once per module;
- * opt-125m: 73 weights).  `tensors` is a HOST array.  Batched (40 tensors per launch): integer formats (fraction 0, clamped,
+ * opt-125m: 73 weights).  `tensors` is a HOST array.  Batched (20 tensors per launch, each with its own op instance in the argument block): integer formats (fraction 0, clamped,
  * nearest), outer == 1 with row slabs of group_size channels or a single group, inner a multiple of the 16-byte vector,
  * < 2^31 elements; every other tensor gets its own launch (stochastic rounding: seed + index). */
 typedef struct { const void* in; void* out; const float* scale; const int64_t* zero_point; int64_t outer, C, inner; } dmxq_affine_desc;

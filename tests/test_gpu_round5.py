@@ -291,3 +291,102 @@ def test_lut_module_refuses_a_capture_that_would_change_its_bits(dmx, cuda):
         torch.cuda.synchronize()
         assert bits_equal(y, want) == 0
     torch.cuda.current_stream().wait_stream(side)
+
+
+# ------------------------------------------------------------------------------------------------ multi-tensor casts on the stream skeleton
+@pytest.mark.parametrize("dtype,out_dtype", [(BF16, None), (F32, None), (F16, None), (BF16, F32), (F32, BF16)])
+def test_float_qdq_multi_equals_one_call_per_tensor_and_the_oracle(dmx, cuda, oracle, dtype, out_dtype):
+    """`dmxq_float_qdq_multi` (round 5: the bias casts of a layer's modules, modeling/nn/core.py:191-203, as one launch): the result of one
+    `float_qdq` per tensor, bit for bit, and the oracle's -- 40 tensors (two launches of the 32-tensor argument block) from 1 element to
+    600,000 (partial tiles, three tile plans by total size), a ragged one (not a whole vector), a view that starts mid-allocation and an
+    empty one ride along on single launches."""
+    sizes = [768, 3072, 768, 2304, 8, 16, 1, 5, 4096, 100000, 600000, 1000, 0, 12345] + [768 + 8 * i for i in range(26)]
+    xs = [make("heavy", (n,), seed=1200 + i).clamp(-6e4, 6e4).to(dtype) for i, n in enumerate(sizes)]
+    dev = [x.to(cuda) for x in xs]
+    base = make("heavy", (4099,), seed=1300).to(dtype).to(cuda)
+    dev[3] = base[3:3 + 2304]                     # 6- or 12-byte offset: not 16-byte aligned
+    xs[3] = dev[3].cpu()
+    for man, exp, bias, flush in ((10, 5, 15, True), (3, 4, 7, False), (2, 5, 15, True)):
+        got = dmx.ops.float_qdq_multi(dev, man, exp, bias, flush, out_dtype=out_dtype)
+        assert len(got) == len(xs)
+        for i, (x, d, y) in enumerate(zip(xs, dev, got)):
+            assert y.shape == x.shape and y.dtype == (out_dtype or dtype)
+            if x.numel() == 0:
+                continue
+            single = dmx.ops.float_qdq(d, man, exp, bias, flush, out_dtype=out_dtype)
+            assert mismatches_nan_aware(y, single) == 0, (i, sizes[i], man, exp)
+            if i < 16:
+                want = oracle.float_quantize(x.float(), man, exp, bias, flush).to(out_dtype or dtype)
+                assert mismatches_nan_aware(y, want) == 0, (i, sizes[i], man, exp)
+    # other roundings: every tensor on its own launch, still the single-call results (nearest is the only batched mode)
+    got = dmx.ops.float_qdq_multi(dev[:4], 3, 4, 7, False, rounding="down", out_dtype=out_dtype)
+    for d, y in zip(dev[:4], got):
+        assert mismatches_nan_aware(y, dmx.ops.float_qdq(d, 3, 4, 7, False, rounding="down", out_dtype=out_dtype)) == 0
+
+
+def test_fixed_qdq_multi_every_tile_plan_and_outer_dims_through_the_c_abi(dmx, cuda, oracle):
+    """`dmxq_fixed_qdq_multi` on the stream skeleton (round 5): sets whose TOTAL size selects each tile plan (256 x 1, 256 x 4, the op's
+    128 x 16, 256 x 2 beyond 32 MiB), float32 and bf16, [outer, C, inner] descriptors with outer > 1 (batched since round 5), groups that do
+    not divide C, one group for the whole tensor -- against one `dmxq_fixed_qdq` call per tensor, bit for bit, and the oracle for the
+    small ones."""
+    lib, L = dmx._lib, dmx._lib.lib()
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for dtype, code in ((F32, lib.F32), (BF16, lib.BF16)):
+        for shapes, gs in (([(1, 64, 128), (1, 24, 64), (3, 8, 16)], 4),                       # tiny: 256 x 1
+                           ([(1, 768, 768), (1, 3072, 768), (2, 100, 256), (1, 30, 64)], 128),  # 256 x 4 (30 rows: one short group ... C % gs != 0)
+                           ([(1, 4096, 1024), (1, 1024, 4096), (1, 2048, 1024), (1, 300, 1000)], 128),   # the op's own plan
+                           ([(1, 4096, 4096), (1, 4096, 2048), (1, 1, 4096)], 128)):            # beyond 32 MiB; a one-row tensor
+            ws, outs, singles, scs, zps, descs = [], [], [], [], [], (lib.AffineDesc * len(shapes))()
+            for i, (outer, C, inner) in enumerate(shapes):
+                w = (make("normal", (outer, C, inner), seed=1400 + i) * 0.05).to(dtype)
+                G = -(-C // gs)
+                mn, mx = oracle.group_minmax(w[0].float().reshape(C, inner), 0, gs)
+                sc, zp = oracle.qparams(mn, mx, 8, True, True)
+                assert sc.numel() == G
+                ws.append(w.to(cuda)); scs.append(sc.to(cuda)); zps.append(zp.to(cuda))
+                outs.append(torch.empty_like(ws[-1])); singles.append(torch.empty_like(ws[-1]))
+                d = descs[i]
+                d.in_, d.out, d.scale, d.zero_point, d.outer, d.C, d.inner = ws[-1].data_ptr(), outs[-1].data_ptr(), scs[-1].data_ptr(), zps[-1].data_ptr(), outer, C, inner
+            assert L.dmxq_fixed_qdq_multi(descs, len(shapes), code, code, 8, 0, 1, 1, lib.ROUND_NEAREST, gs, 0, sp) == lib.OK
+            for i, (outer, C, inner) in enumerate(shapes):
+                assert L.dmxq_fixed_qdq(ctypes.c_void_p(ws[i].data_ptr()), ctypes.c_void_p(singles[i].data_ptr()), code, code, outer, C, inner, 8, 0, 1, 1,
+                                        lib.ROUND_NEAREST, ctypes.c_void_p(scs[i].data_ptr()), ctypes.c_void_p(zps[i].data_ptr()), gs, 0, sp) == lib.OK
+                assert bits_equal(outs[i], singles[i]) == 0, (dtype, shapes[i])
+                if outer * C * inner <= 1 << 21:
+                    want = torch.stack([oracle.fixed_point_affine_cast(ws[i][o].cpu().float(), 8, 0, True, True, scs[i].cpu(), zps[i].cpu(), ch_axis=0, group_size=gs)
+                                        for o in range(outer)]).to(dtype)
+                    assert bits_equal(outs[i], want) == 0, (dtype, shapes[i])
+
+
+def test_live_weight_batch_also_batches_the_bias_casts(dmx, cuda):
+    """The bias casts of a layer's modules as ONE `float_qdq_multi` launch per forward (nn.LiveWeightBatch, round 5): stamped results equal
+    the modules' own casts, a bias changed in place is re-cast by the next forward, `remove()` drops the stamps."""
+    model = _Stack(dmx, [768, 768, 3072, 768], F32, bias=True).to(cuda).eval()
+    _configure_basic(dmx, model)
+    assert repr(model.layers[0].bias_format) == "BFP[24|8]{1}(SN)"   # BASIC: blocks of one element = float_quantize with 22 mantissa bits
+    for l in model.layers[1:]:
+        l.configure(dict(bias_format="FP[1|5|10,15](FN)"))   # (a 2-byte minifloat on float32 biases; two groups: [0] stays alone, unbatched)
+    model.layers[0].configure(dict(bias_format="BFP[24|8]{1}(SN)"))
+    x = make("normal", (4, 768), seed=1500).to(cuda)
+    with torch.no_grad():
+        want_b = [l.bias_cast(l.bias).clone() for l in model.layers]
+        want = model(x).clone()
+        batch = dmx.nn.LiveWeightBatch(model)
+        got = model(x)
+        assert "_live_bias" not in model.layers[0].__dict__ and all("_live_bias" in l.__dict__ for l in model.layers[1:])
+        for l, b in zip(model.layers, want_b):
+            assert bits_equal(l._bias_ro, b) == 0 and bits_equal(b, l.bias) != 0
+        assert bits_equal(got, want) == 0
+        model.layers[1].bias.add_(0.37)
+        assert bits_equal(model.layers[1]._bias_ro, model.layers[1].bias_cast(model.layers[1].bias)) == 0 and "_live_bias" not in model.layers[1].__dict__
+        ref2 = [l.bias_cast(l.bias).clone() for l in model.layers]
+        model(x)
+        assert all(bits_equal(l.__dict__["_live_bias"][0], b) == 0 for l, b in zip(model.layers[1:], ref2[1:]))
+        # BFP32_1 on every module (the BASIC configuration): one group of three
+        for l in model.layers:
+            l.configure(dict(bias_format="BFP[24|8]{1}(SN)"))
+        ref3 = [l.bias_cast(l.bias).clone() for l in model.layers]
+        model(x)
+        assert all(bits_equal(l.__dict__["_live_bias"][0], b) == 0 and bits_equal(b, l.bias) != 0 for l, b in zip(model.layers, ref3))
+        batch.remove()
+        assert not any("_live_bias" in l.__dict__ for l in model.layers)
