@@ -569,6 +569,10 @@ __device__ __forceinline__ uint32_t range_or_relu(uint32_t w, const Range16& r, 
   const uint32_t q = relu16_word(c, x.inf2);
   return RELU == 1 ? range16_word(q, x.ro) : q;
 }
+// Paced load issue on the 512 x 16 tiles (common.hpp pace_issue: 24 idle issue cycles between a wave's loads): the BASIC activation cast
+// 11.35 -> 10.45 us on 4096 x 4096 bf16 (74 -> 80 % of the roofline), the ReLU module 10.98 -> 10.45; pace 1: 11.1, 2 / 3 / 4: 10.47 / 10.45 /
+// 10.52 (same-lease A/B of five builds, profiles/r05_tune_pace.txt section 6)
+constexpr int kRangePace = 3;
 template <int T, int U, int RELU = 0>
 __global__ __launch_bounds__(T) void float_range_bf16_kernel(const void* __restrict__ in, void* __restrict__ out, int64_t n_vec, Range16 r,
                                                             ReluExtra rx) {
@@ -582,7 +586,10 @@ __global__ __launch_bounds__(T) void float_range_bf16_kernel(const void* __restr
     if ((tile + 1) * TILE <= n_vec) {
       u32x4 raw[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) raw[u] = load_raw16<true>(src + u * (T * 16), lane);
+      for (int u = 0; u < U; u++) {
+        raw[u] = load_raw16<true>(src + u * (T * 16), lane);
+        if (U >= 16 && u + 1 < U) pace_issue<kRangePace>();
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -815,7 +822,9 @@ extern "C" int dmxq_binary_cast(const void* a, const void* b, void* out, int dty
       !range16_of(cast_b, dtype, &g.rb) || !range16_of(cast_out, dtype, &g.ro))  // not range-only: the general form
     return op == DMXQ_BINARY_ADD ? launch_fused_generic<0>(a, b, out, dtype, n, cast_a, cast_b, cast_out, (hipStream_t)stream)
                                  : launch_fused_generic<1>(a, b, out, dtype, n, cast_a, cast_b, cast_out, (hipStream_t)stream);
-  constexpr int T = 256, U = 2;  // measured: 256x2 17.9 us, 256x4 18.3, 512x8 19.3 (three streams: small tiles interleave best)
+  // measured: 256x2 17.9 us, 256x4 18.3, 512x8 19.3 (three streams: small tiles interleave best); round 5, with paced loads (common.hpp
+  // pace_issue): 256x2 17.45, 256x8 pace 0 / 2 / 4 18.0 / 17.8 / 17.9, 512x8 pace 2 18.1, 256x4 pace 3 17.5 -- no deep tile catches up
+  constexpr int T = 256, U = 2;
   const int64_t tiles = (g.n_vec + T * U - 1) / (T * U);
   if (tiles > 0x7FFFFFFF) return DMXQ_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
