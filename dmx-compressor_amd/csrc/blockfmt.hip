@@ -42,8 +42,8 @@ __device__ __forceinline__ float fixed_rne(float a) {  // sim_helper.cpp:14-21 w
   return mag >= 8388608.0f ? (odd ? a1 - 1.0f : a1) : rintf(a1 - 0.5f);
 }
 
-struct SbfpFmt { static constexpr int kThreads = 128, kUnroll = 8; int p, clamp; float t_min, t_max, man_scaling; int man, exp_bits, bias, flush; };
-struct MxfpFmt { static constexpr int kThreads = 256, kUnroll = 8; int man, exp_bits, bias; float big; FloatFast fast; int big_log2, exact_exponent, xdomain; };
+struct SbfpFmt { static constexpr int kThreads = 128, kUnroll = 8, kPace = 0; int p, clamp; float t_min, t_max, man_scaling; int man, exp_bits, bias, flush; };
+struct MxfpFmt { static constexpr int kThreads = 256, kUnroll = 8, kPace = 6; int man, exp_bits, bias; float big; FloatFast fast; int big_log2, exact_exponent, xdomain; };
 
 struct SbfpBlock {
   static constexpr bool kHasXDomain = false;
@@ -202,6 +202,7 @@ template <class FMT, class BLK>
 struct BlockOp {
   static constexpr bool kHeavy = true;
   static constexpr bool kFixedVector = true;  // a block is lpb adjacent lanes of 16-byte vectors: no 8-byte-vector form for widening outputs
+  static constexpr int kLoadPace = FMT::kPace;  // common.hpp OpLoadPace: MXFP 256 x 8 tiles 11.75 -> 11.5 us with 4-6 (2: 12.2); SBFP: nothing (11.6 at 0 / 2 / 4 / 6)
   static constexpr int kTileUnroll = FMT::kUnroll, kTileThreads = FMT::kThreads;  // stream.hpp, 20-32 MiB tensors: MXFP 256 x 8 (12.3 vs 13.5 us for 256 x 2, with the x-domain element cast); SBFP 128 x 8 since round 5 (re-measured with the round-3 arithmetic in place: 12.3 us against 13.9 for the 128 x 4 chosen before it, profiles/r05_tune_stream_waitall.txt "block")
   FMT f;
   int lpb;

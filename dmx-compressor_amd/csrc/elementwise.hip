@@ -134,6 +134,9 @@ struct FixedOp {
 #endif
   static constexpr int kTileUnroll = !SIMPLE ? 4 : 16, kTileThreads = !SIMPLE ? 256 : (MODE == kNone ? 64 : DMXQ_EXP_FIXED_T);
   static constexpr bool kWaitAll = SIMPLE;  // stream.hpp OpWaitAll: the whole tile's data before the first vector's arithmetic (+3.5 % without a scale)
+  // common.hpp OpLoadPace (round 5): without a scale, 16 idle issue cycles between a wave's loads on the 64 x 16 tiles: 10.81 -> 10.26 us
+  // (pace 4: 10.89, 6: 11.30); with a per-group scale every pace LOSES (11.18 -> 11.42 / 11.81 / 12.21)
+  static constexpr int kLoadPace = (SIMPLE && MODE == kNone) ? 2 : 0;
   FixedFmt f;
   ChannelMap cm;
   const float* scale;

@@ -304,7 +304,17 @@ static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hip
   if (n_vec <= ((int64_t)1 << 17)) DMXQ_STREAM(256, 1);
   else if (n_vec <= ((int64_t)3 << 18)) DMXQ_STREAM(256, 2);
   else if (n_vec <= ((int64_t)5 << 18)) DMXQ_STREAM(256, 4);
-  else if (n_vec <= ((int64_t)1 << 21)) DMXQ_STREAM(TT, TU);
+  else if (n_vec <= ((int64_t)1 << 21)) {
+    // the op's own geometry, with the op's own pace between a wave's loads (common.hpp OpLoadPace; 0 for most ops)
+#ifdef DMXQ_EXP_STREAM_PACE
+    constexpr int kPace = DMXQ_EXP_STREAM_PACE;
+#else
+    constexpr int kPace = OpLoadPace<OP>::value;
+#endif
+    int64_t tiles = (n_vec + (int64_t)TT * TU - 1) / ((int64_t)TT * TU);
+    if (tiles < 1) tiles = 1;
+    DMXQ_LAUNCH((stream_kernel<DTI, DTO, TU, TT, OP, false, 16, kPace>), dim3((unsigned)tiles), dim3(TT), 0, s, in, out, n, op);
+  }
   else DMXQ_STREAM(256, 2);
 #undef DMXQ_STREAM
   return launch_status();

@@ -127,6 +127,9 @@ struct UnaryOp {
   static constexpr bool kHeavy = true;
   static constexpr int kTileUnroll = KIND == DMXQ_UNARY_SILU ? 8 : (KIND == DMXQ_UNARY_QUICK_GELU ? 2 : 4);  // stream.hpp
   static constexpr int kTileUnrollF32 = kTileUnroll;
+  // common.hpp OpLoadPace (round 5): 32 idle issue cycles between a wave's loads on SiLU's 256 x 8 tiles -- 4096 x 4096 bf16 11.50 -> 10.42 us
+  // (73 -> 80.5 %; pace 2 / 4 / 6: 11.09 / 10.42 / 10.48, library builds in one lease); QuickGELU 13.10 -> 12.96 (not taken), erf GELU nothing
+  static constexpr int kLoadPace = KIND == DMXQ_UNARY_SILU ? 4 : 0;
   // the fused module on 16-bit tensors (act_cast.hip): silu 512 x 16 10.6 / 11.0 / 11.7 us on 3072 / 3584 / 4096 x 4096 bf16 (256 x 8: 9.3 / 12.8 / 13.3)
   static constexpr int kCastUnroll = KIND == DMXQ_UNARY_SILU ? 16 : kTileUnroll, kCastThreads = KIND == DMXQ_UNARY_SILU ? 512 : 256;
   float param;
