@@ -102,13 +102,14 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
     const int lpb = (int)(B / EPL);
     // nearest-even: the magic-add path (bfp_math.hpp (2)); single rounding where the input dtype allows it
     const int fast = (RND == DMXQ_ROUND_NEAREST && wl <= 20) ? (bfp_single_rounding_ok<DTI>(wl) ? 2 : 1) : 0;
-#define DMXQ_ROWS_G(T_, U_, F_, G_)                                                                              \
+#define DMXQ_ROWS_GP(T_, U_, F_, G_, P_)                                                                         \
   do {                                                                                                           \
     const int64_t tiles = (n_vec + (int64_t)(T_) * (U_) - 1) / ((int64_t)(T_) * (U_));                           \
     const int grid = (int)(tiles < kRowsMaxGrid ? tiles : kRowsMaxGrid);                                         \
-    DMXQ_LAUNCH((bfp_rows_kernel<DTI, DTO, RND, ASYM, U_, MODE, T_, F_, G_, IVB>), dim3(grid), dim3(T_), 0, s, in, \
+    DMXQ_LAUNCH((bfp_rows_kernel<DTI, DTO, RND, ASYM, U_, MODE, T_, F_, G_, IVB, 0, P_>), dim3(grid), dim3(T_), 0, s, in, \
                        out, n_vec, lpb, wl, rounding, seed);                                                     \
   } while (0)
+#define DMXQ_ROWS_G(T_, U_, F_, G_) DMXQ_ROWS_GP(T_, U_, F_, G_, 0)
 #define DMXQ_ROWS(T_, U_, F_) DMXQ_ROWS_G(T_, U_, F_, U_)
 #define DMXQ_ROWS_GEOM(F_)                                                                         \
   do {                                                                                             \
@@ -133,8 +134,10 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
       if (pl.id == 120) { DMXQ_LAUNCH((bfp_rows_compact_kernel<DTI, 20, 512, 10>), dim3((unsigned)pl.tiles), dim3(512), 0, s, in, out, n_vec, lpb, wl); break; } \
     }                                                                                              \
     if constexpr (kBig) {                                                                          \
-      if (pl.id == 2) { DMXQ_ROWS(512, 4, F_); break; }                                            \
-      if (pl.id == 3) { DMXQ_ROWS(128, 8, F_); break; }                                            \
+      /* paced loads (common.hpp pace_issue, 16 idle issue cycles between a wave's loads): 2560 x 4096 bf16 8.15 -> 7.04 us (64 -> 74.5 %), */ \
+      /* 2048 rows 6.31 -> 6.11; the one-round depths 11 .. 20 and 512 x 2 gain nothing (profiles/r05_tune_pace.txt section 10) */ \
+      if (pl.id == 2) { DMXQ_ROWS_GP(512, 4, F_, 4, 2); break; }                                   \
+      if (pl.id == 3) { DMXQ_ROWS_GP(128, 8, F_, 8, 2); break; }                                   \
       if (pl.id == 4) { DMXQ_ROWS(512, 16, F_); break; }                                           \
     }                                                                                              \
     if (pl.id == 0) DMXQ_ROWS(512, 1, F_);                                                         \
@@ -160,6 +163,7 @@ static int launch_bfp(const void* in, void* out, int64_t outer, int64_t L, int64
 #undef DMXQ_ROWS_GEOM
 #undef DMXQ_ROWS
 #undef DMXQ_ROWS_G
+#undef DMXQ_ROWS_GP
     return launch_status();
   }
   if constexpr (RND != DMXQ_ROUND_NEAREST && RND != kRuntimeRounding) {
