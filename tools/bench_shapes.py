@@ -123,7 +123,7 @@ def main():
         assert L.dmxq_fixed_qdq_multi(adescs[i], len(shapes), _lib.BF16, _lib.BF16, 8, 0, 1, 1, 2, 128, 0, sp) == 0
 
     with torch.cuda.stream(stream):
-        for name, fn in (("one dmxq_fixed_qdq launch per tensor (73 launches)", f_one_by_one), ("dmxq_fixed_qdq_multi (2 launches)", f_multi)):
+        for name, fn in (("one dmxq_fixed_qdq launch per tensor (73 launches)", f_one_by_one), ("dmxq_fixed_qdq_multi (4 launches)", f_multi)):
             for i in range(6):
                 fn(i % 3)
             torch.cuda.synchronize()
