@@ -323,6 +323,10 @@ __device__ __forceinline__ float seg_max(float v) {
 }
 // row slots per wave iteration: about 32 fp32 values per lane (occupancy beats bytes in flight per wave here: 64 was
 // 1-4 % slower on every shape of tools/bench_rows.py)
+#ifndef DMXQ_EXP_ROW_PACE
+#define DMXQ_EXP_ROW_PACE 0
+#endif
+constexpr int kRowPace = DMXQ_EXP_ROW_PACE;   // common.hpp pace_issue between a wave's row loads (experiment)
 constexpr bool kRowEarlyLoads = false;  // layernorm_wave_kernel: next rows requested before this iteration's stores (measured slower, see there)
 constexpr int rows_per_wave(int vpl, int epl) { return 32 / (vpl * epl) >= 4 ? 4 : (32 / (vpl * epl) >= 2 ? 2 : 1); }
 
@@ -365,6 +369,7 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
           dst[j][i] = row_load_u<DT, EPL>(in, base + (v < nvf ? (int64_t)v * EPL : cols - EPL));
         } else {
           dst[j][i] = row_load<DT, EPL>(in, base + (int64_t)(v < nvf ? v : nvf - 1) * EPL);
+          pace_issue<kRowPace>();
         }
       }
     }
@@ -520,6 +525,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
       for (int i = 0; i < VPL; i++) {
         const int v = i * LPR + sl;
         dst[j][i] = row_load<DT, EPL>(in, base + (int64_t)(v < nv ? v : nv - 1) * EPL);
+        pace_issue<kRowPace>();
       }
     }
   };
@@ -672,6 +678,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* _
       for (int i = 0; i < VPL; i++) {
         const int v = i * kThreads + t;
         raw[j][i] = row_load<DT, EPL>(in, base + (int64_t)(v < nv ? v : nv - 1) * EPL);
+        pace_issue<kRowPace>();
       }
     }
     float x[RPW][VPL][EPL], mean[RPW], rstd[RPW];

@@ -94,6 +94,13 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(k, dim3(g), dim3(kThreads), 0, q, i, o, rows1500, (int64_t)1500, -INFINITY, a); }, {}}); }
 #define ADD_GRIDS(M, C, R) M(C, R, 0) M(C, R, 1) M(C, R, 2)
   ADD_COPY(512, 16); ADD_COPY(256, 16); ADD_COPY(512, 2);
+#ifdef TUNE_ROWS_SHORT
+  ADD_GRIDS(ADD_LN, false, 1) ADD_GRIDS(ADD_LN, false, 2) ADD_GRIDS(ADD_LN, false, 4) ADD_GRIDS(ADD_LN, false, 8)
+  ADD_GRIDS(ADD_LN, true, 1) ADD_GRIDS(ADD_LN, true, 2) ADD_GRIDS(ADD_LN, true, 4) ADD_GRIDS(ADD_LN, true, 8)
+  ADD_GRIDS(ADD_RMS, true, 1) ADD_GRIDS(ADD_RMS, true, 2) ADD_GRIDS(ADD_RMS, true, 4)
+  ADD_GRIDS(ADD_SM, false, 1) ADD_GRIDS(ADD_SM, false, 2) ADD_GRIDS(ADD_SM, false, 4)
+  ADD_GRIDS(ADD_SM, true, 1) ADD_GRIDS(ADD_SM, true, 2) ADD_GRIDS(ADD_SM, true, 4)
+#else
   ADD_LNP(false, 1, 0, 0, 0) ADD_LNP(false, 1, 0, 0, 1) ADD_LNP(false, 2, 0, 0, 0) ADD_LNP(false, 2, 0, 0, 1) ADD_LNP(false, 1, 0, 1, 0) ADD_LNP(false, 1, 0, 1, 1) ADD_LNP(false, 2, 0, 1, 1) ADD_LNP(false, 4, 0, 0, 1)
   ADD_LNP(true, 1, 0, 0, 0) ADD_LNP(true, 1, 0, 0, 1) ADD_LNP(true, 1, 0, 1, 1) ADD_LNP(true, 2, 0, 0, 1)
   ADD_LNH(false, 1, 0, 1) ADD_LNH(false, 1, 1, 1) ADD_LNH(false, 2, 0, 1) ADD_LNH(false, 2, 1, 1) ADD_LNH(false, 1, 0, 2) ADD_LNH(false, 1, 1, 2) ADD_LNH(false, 2, 0, 2) ADD_LNH(false, 2, 1, 2)
@@ -105,6 +112,7 @@ int main(int argc, char** argv) {
   ADD_GRIDS(ADD_LNB, false, 2) ADD_GRIDS(ADD_LNB, false, 4) ADD_GRIDS(ADD_LNB, false, 8) ADD_GRIDS(ADD_LNB, true, 2) ADD_GRIDS(ADD_LNB, true, 8)
   ADD_GRIDS(ADD_SM, false, 1) ADD_GRIDS(ADD_SM, false, 2) ADD_GRIDS(ADD_SM, false, 4)
   ADD_GRIDS(ADD_SM, true, 1) ADD_GRIDS(ADD_SM, true, 2)
+#endif
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (auto& v : vs) for (int i = 0; i < 10; i++) v.run(in[i % NBUF], out[i % NBUF], st);
   CK(hipStreamSynchronize(st));
