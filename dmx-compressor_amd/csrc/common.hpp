@@ -313,7 +313,7 @@ typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 
 // PACED LOAD ISSUE (round 5).  N x 8 idle issue cycles of this wave between two of its tile loads.  A wave that issues its 16 loads
 // back to back fills the CU's address queue with ITS tile before the next wave gets a slot; paced, the waves of a CU interleave load
-// by load.  Measured on 4096 x 4096 bf16 (tools/tune_pace, tools/scratch -> profiles/r05_tune_pace.txt): a trivial op on deep flat tiles
+// by load.  Measured on 4096 x 4096 bf16 (tools/tune_pace, tools/tune_issue, tools/tune_bfp_pace -> profiles/r05_tune_pace.txt): a trivial op on deep flat tiles
 // 128 x 16 12.7 -> 10.8 us, 256 x 16 11.7 -> 10.9, 512 x 16 11.4 -> 10.9 (the plateau the hot BFP kernel sits on: pacing does
 // nothing for it); rows 8 KiB apart (lastdim_kernel, x * s) 12.4 -> 11.2 -- but ops with ~50+ VALU per vector LOSE (x / s 11.9 -> 14.1,
 // INT8 per channel 12.3 -> 12.9: their arithmetic waits for data that now arrives later), and the optimum is not smooth in N.  Hence an op
