@@ -338,6 +338,43 @@ def fixed_qdq_multi(xs, precision, fraction, clamp, symmetric, rounding, scales,
     return outs
 
 
+@_guarded
+def fixed_float_qdq_multi(xs, precision, fraction, clamp, symmetric, rounding, scales, zero_points, group_size,
+                          fs, man, exp, bias, flush_subnormal, unsigned_abs, rounding_float, seed=0):
+    """(fixed results, float results): `fixed_qdq_multi(xs, ...)` and `float_qdq_multi(fs, ...)` in one launch where the set allows it"""
+    if not xs or not fs:
+        return (fixed_qdq_multi(xs, precision, fraction, clamp, symmetric, rounding, scales, zero_points, group_size, None, seed),
+                float_qdq_multi(fs, man, exp, bias, flush_subnormal, unsigned_abs, rounding_float, None, seed))
+    ins = [_prep(t, "fixed_float_qdq_multi") for t in xs]
+    fins = [_prep(t, "fixed_float_qdq_multi") for t in fs]
+    dt, dev = ins[0].dtype, ins[0].device
+    if any(x.dtype != dt or x.device != dev for x in ins + fins):
+        raise RuntimeError("fixed_float_qdq_multi: all tensors must share one dtype and one device")
+    if len(scales) != len(ins) or len(zero_points) != len(ins):
+        raise RuntimeError("fixed_float_qdq_multi: one scale and one zero_point tensor per weight")
+    outs = [torch.empty_like(x) for x in ins]
+    fouts = [torch.empty_like(x) for x in fins]
+    scs = [s.detach().to(device=dev, dtype=torch.float32).contiguous() for s in scales]
+    zps = [z.detach().to(device=dev, dtype=torch.int64).contiguous() for z in zero_points]
+    gs = group_size or 1
+    descs = (_lib.AffineDesc * len(ins))()
+    for i, (d, x, o, s, z) in enumerate(zip(descs, ins, outs, scs, zps)):
+        outer, C, inner = split3(x.shape, 0) if x.dim() > 0 else (1, 1, 1)
+        need = -(-C // gs) if (group_size or s.numel() != 1) else 1
+        if s.numel() < need or z.numel() < need:
+            raise ValueError(f"fixed_float_qdq_multi: tensor {i} needs {need} scale/zero_point entries, got {s.numel()}/{z.numel()}")
+        if need == 1:
+            outer, C, inner = 1, 1, x.numel()
+        d.in_, d.out, d.scale, d.zero_point, d.outer, d.C, d.inner = x.data_ptr(), o.data_ptr(), s.data_ptr(), z.data_ptr(), outer, C, inner
+    fdescs = (_lib.TensorDesc * len(fins))()
+    for d, x, o in zip(fdescs, fins, fouts):
+        d.in_, d.out, d.outer, d.L, d.inner = x.data_ptr(), o.data_ptr(), 1, x.numel(), 1
+    check(lib().dmxq_fixed_float_qdq_multi(descs, len(ins), precision, fraction, int(clamp), int(symmetric), rounding, gs, fdescs, len(fins), man, exp,
+                                           bias, int(flush_subnormal), int(unsigned_abs), rounding_float, dtype_code(dt), seed & _U64,
+                                           stream_of(ins[0])), "dmxq_fixed_float_qdq_multi")
+    return outs, fouts
+
+
 # ------------------------------------------------------------------------------------------------ sparsity
 def _maybe(t, want, shape, dtype, device):
     return torch.empty(shape, dtype=dtype, device=device) if want else None

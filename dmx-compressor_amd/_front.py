@@ -18,7 +18,7 @@ import torch
 from ._lib import DmxqError, ROUNDING_CODE, require_gpu
 
 __all__ = [
-    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "weight_hypernet_multi", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "unary_cast_table", "lut16_apply", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "float_qdq_multi", "fixed_qdq", "fixed_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "group_minmax_accumulate", "qparams", "channel_maxabs",
+    "bfp_qdq", "block_quantize", "bfp_qdq_multi", "bfp_pack", "bfp_unpack", "weight_hypernet", "weight_hypernet_multi", "input_hypernet", "binary_cast", "rope_cast", "relu_cast", "unary_cast", "unary_cast_table", "lut16_apply", "softmax_cast", "layernorm_cast", "rmsnorm_cast", "sbfp_qdq", "mxfp_qdq", "float_qdq", "float_qdq_multi", "fixed_qdq", "fixed_qdq_multi", "fixed_float_qdq_multi", "nm_mask", "nm_sparsify", "topk_mask", "topk_sparsify", "bernoulli_mask", "group_minmax", "group_minmax_accumulate", "qparams", "channel_maxabs",
     "smoothquant_scale", "scale_channels", "gelu", "silu", "quick_gelu", "exp", "silu_experimental", "rope", "softmax", "layernorm",
     "rmsnorm", "histc",
 ]
@@ -222,6 +222,23 @@ def fixed_qdq_multi(tensors, precision: int, fraction: int, clamp: bool, symmetr
         require_gpu(t, "fixed_qdq_multi")
     return list(_ops.fixed_qdq_multi(tensors, precision, fraction, clamp, symmetric, ROUNDING_CODE[rounding], list(scales),
                                      list(zero_points), group_size or 0, out_dtype, _seed_arg(seed, rounding)))
+
+
+def fixed_float_qdq_multi(tensors, precision: int, fraction: int, clamp: bool, symmetric: bool, scales, zero_points, group_size: Optional[int],
+                          float_tensors, mantissa: int, exponent: int, bias: Optional[int] = None, flush_subnormal: bool = True,
+                          unsigned: bool = False):
+    """`fixed_qdq_multi(tensors, ...)` AND `float_qdq_multi(float_tensors, ...)` (nearest rounding both) in ONE launch where the set allows
+    it (`dmxq_fixed_float_qdq_multi`: a layer's INT8 weight casts and its bias casts); -> (fixed results, float results), bit-identical to
+    the two calls."""
+    tensors, float_tensors = list(tensors), list(float_tensors)
+    for t in tensors + float_tensors:
+        require_gpu(t, "fixed_float_qdq_multi")
+    if bias is None:
+        bias = (1 << (exponent - 1)) - 1
+    a, b = _ops.fixed_float_qdq_multi(tensors, precision, fraction, clamp, symmetric, ROUNDING_CODE["nearest"], list(scales), list(zero_points),
+                                      group_size or 0, float_tensors, mantissa, exponent, bias, bool(flush_subnormal), bool(unsigned),
+                                      ROUNDING_CODE["nearest"], 0)
+    return list(a), list(b)
 
 
 # ---------------------------------------------------------------------------------------------------- sparsity

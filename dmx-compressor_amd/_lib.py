@@ -50,6 +50,7 @@ SIGNATURES = {
     "dmxq_fixed_qdq": [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _u64, _vp],
     "dmxq_fixed_qdq_multi": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _u64, _vp],
     "dmxq_float_qdq_multi": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _u64, _vp],
+    "dmxq_fixed_float_qdq_multi": [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _u64, _vp],
     "dmxq_nm_mask": [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp],
     "dmxq_topk_workspace_bytes": [_i64],
     "dmxq_topk_mask": [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i64, _i64, _vp, _vp],

@@ -118,3 +118,61 @@ extern "C" int dmxq_float_qdq_multi(const dmxq_tensor_desc* tensors, int64_t n_t
   if (a.n > 0) { const int r = flush_multi(a, dtype_in, dtype_out, s); if (r != DMXQ_OK && rc == DMXQ_OK) rc = r; }
   return rc;
 }
+
+// One launch for BOTH parameter casts of a layer (round 5): the affine integer casts of its weights and the float casts of its biases.
+extern "C" int dmxq_fixed_float_qdq_multi(const dmxq_affine_desc* fixed, int64_t n_fixed, int precision, int fraction, int clamp, int symmetric,
+                                          int rounding_fixed, int64_t group_size, const dmxq_tensor_desc* flt, int64_t n_float, int man_bits,
+                                          int exp_bits, int exp_bias, int flush_subnormal, int unsigned_abs, int rounding_float, int dtype,
+                                          uint64_t seed, void* stream) {
+  if (n_fixed < 0 || n_float < 0 || (n_fixed > 0 && !fixed) || (n_float > 0 && !flt) || !valid_dtype(dtype)) return DMXQ_ERR_BAD_ARG;
+  using OPA = FixedOp<kUniform, true>;
+  using OPB = FloatOp<DMXQ_ROUND_NEAREST>;
+  using Args = StreamMulti2Args<OPA, OPB>;
+  const int epl = dtype == DMXQ_F32 ? 4 : 8;
+  bool combined = n_fixed >= 1 && n_float >= 1 && n_fixed <= Args::kMaxA && n_float <= Args::kMaxB && n_fixed + n_float <= Args::kMaxTensors &&
+                  fraction == 0 && clamp && rounding_fixed == DMXQ_ROUND_NEAREST && precision >= 1 && precision <= 22 && group_size >= 1 &&
+                  rounding_float == DMXQ_ROUND_NEAREST && exp_bits >= 1 && exp_bits <= 8 && man_bits >= 0 && man_bits <= 22;
+  for (int64_t i = 0; combined && i < n_fixed; i++) {
+    const dmxq_affine_desc& t = fixed[i];
+    if (t.outer < 0 || t.C < 0 || t.inner < 0) return DMXQ_ERR_BAD_ARG;
+    const int64_t n = t.outer * t.C * t.inner;
+    const bool one_group = t.C <= 1 || group_size >= t.C;
+    combined = n > 0 && t.in && t.out && t.scale && t.zero_point && n % epl == 0 && (one_group || t.inner % epl == 0) && n < ((int64_t)1 << 31) &&
+               aligned16(t.in) && aligned16(t.out);
+  }
+  for (int64_t i = 0; combined && i < n_float; i++) {
+    const dmxq_tensor_desc& t = flt[i];
+    if (t.outer < 0 || t.L < 0 || t.inner < 0) return DMXQ_ERR_BAD_ARG;
+    const int64_t n = t.outer * t.L * t.inner;
+    combined = n > 0 && t.in && t.out && n % epl == 0 && n < ((int64_t)1 << 31) && aligned16(t.in) && aligned16(t.out);
+  }
+  if (combined) {
+    float t_min = (float)(-ldexp(1.0, precision - 1));
+    const float t_max = (float)(-(double)t_min - 1.0);
+    if (symmetric) t_min = (float)((double)t_min + 1.0);
+    const FixedFmt f{0, 1, DMXQ_ROUND_NEAREST, t_min, t_max, 0ull};
+    const FloatFmt ff{man_bits, exp_bits, exp_bias, flush_subnormal ? 1 : 0, unsigned_abs ? 1 : 0, DMXQ_ROUND_NEAREST, seed};
+    const OPB opb{ff, make_float_fast(ff.man, ff.exp_bits, ff.bias), make_flush_fast(ff.man, ff.exp_bits, ff.bias, ff.flush && !ff.unsigned_abs)};
+    Args a;
+    a.nA = (int)n_fixed;
+    a.nB = (int)n_float;
+    for (int64_t i = 0; i < n_fixed; i++) {
+      const dmxq_affine_desc& t = fixed[i];
+      const int64_t n = t.outer * t.C * t.inner;
+      const bool one_group = t.C <= 1 || group_size >= t.C;
+      const ChannelMap cm = one_group ? make_channel_map(1, n, 1, n) : make_channel_map(t.C, t.inner, group_size, n);
+      a.a[i] = StreamMultiDesc<OPA>{t.in, t.out, n / epl, 0, OPA{f, cm, t.scale, t.zero_point}};
+    }
+    for (int64_t i = 0; i < n_float; i++) a.b[i] = StreamMultiDesc<OPB>{flt[i].in, flt[i].out, flt[i].outer * flt[i].L * flt[i].inner / epl, 0, opb};
+    int r = DMXQ_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DMXQ_F32) r = launch_stream_multi2<DMXQ_F32, DMXQ_F32, OPA, OPB>(a, s);
+    else if (dtype == DMXQ_BF16) r = launch_stream_multi2<DMXQ_BF16, DMXQ_BF16, OPA, OPB>(a, s);
+    else r = launch_stream_multi2<DMXQ_F16, DMXQ_F16, OPA, OPB>(a, s);
+    if (r != DMXQ_ERR_UNSUPPORTED) return r;
+  }
+  // everything else: the two multi-tensor calls, which give every tensor they cannot batch a launch of its own
+  const int r1 = dmxq_fixed_qdq_multi(fixed, n_fixed, dtype, dtype, precision, fraction, clamp, symmetric, rounding_fixed, group_size, seed, stream);
+  if (r1 != DMXQ_OK) return r1;
+  return dmxq_float_qdq_multi(flt, n_float, dtype, dtype, man_bits, exp_bits, exp_bias, flush_subnormal, unsigned_abs, rounding_float, seed, stream);
+}

@@ -71,10 +71,10 @@ template <class OP> struct OpRawHooks<OP, std::void_t<decltype(OP::kRawHooks)>> 
 // IVB = input bytes per lane-vector: 16, or 8 for aligned 16-bit -> float32 launches -- the lane then owns 4 elements and its results
 // are ONE 16-byte store, every store instruction of a wave covering whole lines (with 16-byte loads they are two 16-byte stores 32 bytes
 // apart: half-written lines per instruction, ~40 % of the bandwidth; bfp_rows.hpp, lastdim.hpp).
-template <int IVB, bool UNAL>
+template <int IVB, bool UNAL, bool NTL = true>
 __device__ __forceinline__ u32x4 stream_load(const char* p, uint32_t off) {
-  if constexpr (IVB == 16) return load_raw16<true, uint32_t, UNAL>(p, off);
-  const u32x2 t = __builtin_nontemporal_load((const u32x2*)(p + off));
+  if constexpr (IVB == 16) return load_raw16<NTL, uint32_t, UNAL>(p, off);
+  const u32x2 t = NTL ? __builtin_nontemporal_load((const u32x2*)(p + off)) : *(const u32x2*)(p + off);
   return u32x4{t.x, t.y, 0u, 0u};
 }
 template <int DTI, int EPL>
@@ -91,7 +91,7 @@ __device__ __forceinline__ void stream_widen(const u32x4& raw, float (&x)[EPL]) 
 }
 // ONE tile (THREADS x UNROLL lane-vectors) of a flat tensor of n_vec vectors; `tile` is the tile index inside that tensor.  Shared by the
 // single-tensor kernel below and the multi-tensor kernel (stream_multi_kernel: many small tensors of one op in one launch).
-template <int DTI, int DTO, int UNROLL, int THREADS, class OP, bool UNAL, int IVB, int PACE, bool NTS = true>
+template <int DTI, int DTO, int UNROLL, int THREADS, class OP, bool UNAL, int IVB, int PACE, bool NTS = true, bool NTL = true>
 __device__ __forceinline__ void stream_tile(const void* __restrict__ in, void* __restrict__ out, int64_t n_vec, int64_t tile, const OP& op) {
   constexpr int EPL = IVB / Elem<DTI>::bytes;
   constexpr int OVB = EPL * Elem<DTO>::bytes;
@@ -109,7 +109,7 @@ __device__ __forceinline__ void stream_tile(const void* __restrict__ in, void* _
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < UNROLL; u++) {
-        raw[u] = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
+        raw[u] = stream_load<IVB, UNAL, NTL>(src + u * (THREADS * IVB), lane_in);
         if (u + 1 < UNROLL) pace_issue<PACE>();
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -161,7 +161,7 @@ __device__ __forceinline__ void stream_tile(const void* __restrict__ in, void* _
 #pragma unroll 1
           for (int u = 0; u < UNROLL; u++) {
             if ((redo >> u) & 1u) {
-              const u32x4 r1 = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
+              const u32x4 r1 = stream_load<IVB, UNAL, NTL>(src + u * (THREADS * IVB), lane_in);
               float x[EPL], y[EPL];
               stream_widen<DTI, EPL>(r1, x);
               tile_apply_exact(op, x, y, (v0 + (int64_t)u * THREADS) * EPL, prep_of(u));
@@ -204,7 +204,7 @@ __device__ __forceinline__ void stream_tile(const void* __restrict__ in, void* _
     for (int u = 0; u < UNROLL; u++) {
       const int64_t vi = v0 + (int64_t)u * THREADS;
       if (vi < n_vec) {
-        u32x4 raw = stream_load<IVB, UNAL>(src + u * (THREADS * IVB), lane_in);
+        u32x4 raw = stream_load<IVB, UNAL, NTL>(src + u * (THREADS * IVB), lane_in);
         float x[EPL], y[EPL];
         if constexpr (OpRawHooks<OP>::value) op.raw_in(raw);
         stream_widen<DTI, EPL>(raw, x);
@@ -340,8 +340,9 @@ template <class OP> struct StreamMultiArgs {
 // trips (the tile table, then its descriptor) before its first data load: ~1 us on a 10 us launch.  Larger sets finish the scan in the
 // argument block.
 constexpr int kStreamMultiPre = 10;
-// NTS: non-temporal stores.  Off for sets of up to 32 MiB: their results are consumed at once (a layer's quantised weights by its GEMMs)
-// and fit the Infinity Cache -- opt-125m layer, one hipGraph of the forward: 188.5 -> 185.1 us with plain stores in this kernel.
+// NTS: non-temporal loads AND stores.  Off for sets of up to 32 MiB: their results are consumed at once (a layer's quantised weights by its
+// GEMMs), their inputs are read again by the next forward, and both fit the Infinity Cache -- opt-125m layer, one hipGraph of the forward:
+// 188.5 -> 185.1 us with plain stores, -> 182.0 us with plain loads too.
 template <int DTI, int DTO, int UNROLL, int THREADS, class OP, bool NTS>
 __global__ __launch_bounds__(THREADS) void stream_multi_kernel(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3, uint32_t e4, uint32_t e5,
                                                               uint32_t e6, uint32_t e7, uint32_t e8, uint32_t e9, int n,
@@ -352,7 +353,73 @@ __global__ __launch_bounds__(THREADS) void stream_multi_kernel(uint32_t e0, uint
     for (int i = kStreamMultiPre + 1; i < n; i++) k = ((uint32_t)a.d[i].tile0 <= gt) ? i : k;
   }
   const StreamMultiDesc<OP>& d = a.d[k];
-  stream_tile<DTI, DTO, UNROLL, THREADS, OP, false, 16, 0, NTS>(d.in, d.out, d.n_vec, (int64_t)gt - d.tile0, d.op);
+  stream_tile<DTI, DTO, UNROLL, THREADS, OP, false, 16, 0, NTS, NTS>(d.in, d.out, d.n_vec, (int64_t)gt - d.tile0, d.op);
+}
+
+// TWO ops in one launch (round 5): the tensors of OPA first, then those of OPB -- a layer's INT8 weight casts and its float bias casts, which
+// were two launches.  Small sets only (at most 21 tensors, fewer than 65,536 tiles): the 20 first-tile boundaries travel as 16-bit halves of
+// ten preloaded scalar arguments, the eleventh is the number of OPA tensors -- no memory access before the descriptor fetch.
+template <class OPA, class OPB> struct StreamMulti2Args {
+  static constexpr int kMaxA = 12, kMaxB = 12, kMaxTensors = 21;
+  int nA, nB;
+  StreamMultiDesc<OPA> a[kMaxA];
+  StreamMultiDesc<OPB> b[kMaxB];
+};
+__device__ __forceinline__ int multi2_index(uint32_t gt, uint32_t e) { return ((e & 0xFFFFu) <= gt) + ((e >> 16) <= gt); }
+// (OPB's tiles are at most as deep as ITS own geometry allows: a FloatOp body at 16 vectors per lane spills, and a kernel with scratch
+//  pays for it on every wave -- the first build of this kernel ran the opt-125m layer 80 us slower)
+template <int DTI, int DTO, int UNROLL, int UNROLLB, int THREADS, class OPA, class OPB, bool NTS>
+__global__ __launch_bounds__(THREADS) void stream_multi2_kernel(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3, uint32_t e4, uint32_t e5,
+                                                               uint32_t e6, uint32_t e7, uint32_t e8, uint32_t e9, int nA,
+                                                               const StreamMulti2Args<OPA, OPB> a) {
+  const uint32_t gt = blockIdx.x;
+  const int k = multi2_index(gt, e0) + multi2_index(gt, e1) + multi2_index(gt, e2) + multi2_index(gt, e3) + multi2_index(gt, e4) +
+                multi2_index(gt, e5) + multi2_index(gt, e6) + multi2_index(gt, e7) + multi2_index(gt, e8) + multi2_index(gt, e9);
+  if (k < nA) {
+    const StreamMultiDesc<OPA>& d = a.a[k];
+    stream_tile<DTI, DTO, UNROLL, THREADS, OPA, false, 16, 0, NTS, NTS>(d.in, d.out, d.n_vec, (int64_t)gt - d.tile0, d.op);
+  } else {
+    const StreamMultiDesc<OPB>& d = a.b[k - nA];
+    stream_tile<DTI, DTO, UNROLLB, THREADS, OPB, false, 16, 0, NTS, NTS>(d.in, d.out, d.n_vec, (int64_t)gt - d.tile0, d.op);
+  }
+}
+// DMXQ_ERR_UNSUPPORTED: the set does not fit this form (the caller launches the two ops separately)
+template <int DTI, int DTO, class OPA, class OPB>
+static int launch_stream_multi2(StreamMulti2Args<OPA, OPB>& a, hipStream_t s) {
+  using A = StreamMulti2Args<OPA, OPB>;
+  if (a.nA < 1 || a.nB < 1 || a.nA > A::kMaxA || a.nB > A::kMaxB || a.nA + a.nB > A::kMaxTensors) return DMXQ_ERR_UNSUPPORTED;
+  constexpr int TT = OpTileThreads<OPA>::value, TU = OpTileUnroll<OPA>::value;   // (same-size dtype pairs only: no widening outputs)
+  int64_t total = 0;
+  for (int i = 0; i < a.nA; i++) total += a.a[i].n_vec;
+  for (int i = 0; i < a.nB; i++) total += a.b[i].n_vec;
+  if (total > ((int64_t)1 << 21)) return DMXQ_ERR_UNSUPPORTED;   // (beyond 32 MiB: two launches cost nothing there)
+#define DMXQ_STREAM_MULTI2(T_, U_)                                                                                    \
+  do {                                                                                                                \
+    int64_t tiles = 0;                                                                                                \
+    uint32_t first[A::kMaxTensors + 1];                                                                               \
+    int n = 0;                                                                                                        \
+    for (int i = 0; i < a.nA; i++) { a.a[i].tile0 = tiles; first[n++] = (uint32_t)tiles; tiles += (a.a[i].n_vec + (int64_t)(T_) * (U_) - 1) / ((int64_t)(T_) * (U_)); } \
+    constexpr int UB = (U_) < 4 ? (U_) : 4;   /* (OPB: shallow tiles, see the kernel) */                                   \
+    for (int i = 0; i < a.nB; i++) { a.b[i].tile0 = tiles; first[n++] = (uint32_t)tiles; tiles += (a.b[i].n_vec + (int64_t)(T_) * UB - 1) / ((int64_t)(T_) * UB); } \
+    if (tiles > 0xFFFF) return DMXQ_ERR_UNSUPPORTED;                                                                  \
+    uint32_t e[10];                                                                                                   \
+    for (int i = 0; i < 10; i++) {                                                                                    \
+      const uint32_t lo = 2 * i + 1 < n ? first[2 * i + 1] : 0xFFFFu, hi = 2 * i + 2 < n ? first[2 * i + 2] : 0xFFFFu;  \
+      e[i] = lo | (hi << 16);                                                                                         \
+    }                                                                                                                 \
+    DMXQ_LAUNCH((stream_multi2_kernel<DTI, DTO, U_, UB, T_, OPA, OPB, false>), dim3((unsigned)tiles), dim3(T_), 0, s, e[0], e[1], e[2], e[3], \
+                e[4], e[5], e[6], e[7], e[8], e[9], a.nA, a);                                                         \
+  } while (0)
+  if (total <= ((int64_t)1 << 17)) {
+    DMXQ_STREAM_MULTI2(256, 1);
+  } else if constexpr (Elem<DTI>::bytes == 2) {
+    DMXQ_STREAM_MULTI2(256, 4);   // (16-bit: the two bodies together spill at 128 x 16 -- 3.4 KiB of scratch per lane; build.py NO_SCRATCH guards the rest)
+  } else {
+    if (total <= ((int64_t)5 << 18)) DMXQ_STREAM_MULTI2(256, 4);
+    else DMXQ_STREAM_MULTI2(TT, TU);
+  }
+#undef DMXQ_STREAM_MULTI2
+  return launch_status();
 }
 
 // Host side of one launch: a.d[i].{in, out, n_vec, op} filled for i < a.n (n_vec > 0, whole vectors, aligned); fills tile0 and launches.

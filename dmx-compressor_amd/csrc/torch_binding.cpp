@@ -373,6 +373,49 @@ std::vector<Tensor> float_qdq_multi_meta(at::TensorList xs, int64_t, int64_t, in
   return outs;
 }
 
+std::tuple<std::vector<Tensor>, std::vector<Tensor>> fixed_float_qdq_multi(at::TensorList xs, int64_t precision, int64_t fraction, bool clamp, bool symmetric,
+                                                                           int64_t rounding, at::TensorList scales, at::TensorList zero_points, int64_t group_size,
+                                                                           at::TensorList fs, int64_t man, int64_t exp, int64_t bias, bool flush, bool unsigned_abs,
+                                                                           int64_t rounding_float, int64_t seed) {
+  std::vector<Tensor> outs, ins, scs, zps, fouts, fins;
+  TORCH_CHECK(!xs.empty() && !fs.empty(), "fixed_float_qdq_multi: both tensor lists must be non-empty (use the single-op multi calls otherwise)");
+  TORCH_CHECK(scales.size() == xs.size() && zero_points.size() == xs.size(), "fixed_float_qdq_multi: one scale and one zero_point tensor per input");
+  std::vector<dmxq_affine_desc> d(xs.size());
+  std::vector<dmxq_tensor_desc> fd(fs.size());
+  for (size_t i = 0; i < xs.size(); i++) {
+    ins.push_back(prep(xs[i], "fixed_float_qdq_multi"));
+    TORCH_CHECK(ins[i].scalar_type() == ins[0].scalar_type() && ins[i].device() == ins[0].device(), "fixed_float_qdq_multi: all tensors must share one dtype and one device");
+    outs.push_back(empty_like_shape(ins[i], c10::nullopt));
+    scs.push_back(scales[i].detach().to(ins[i].device(), at::kFloat).contiguous());
+    zps.push_back(zero_points[i].detach().to(ins[i].device(), at::kLong).contiguous());
+    const int64_t gs = std::max<int64_t>(group_size, 1);
+    Split3 s = ins[i].dim() > 0 ? split3(ins[i], 0) : Split3{1, 1, 1};
+    const int64_t need = (group_size > 0 || scs[i].numel() != 1) ? (s.L + gs - 1) / gs : 1;
+    TORCH_CHECK_VALUE(scs[i].numel() >= need && zps[i].numel() >= need, "fixed_float_qdq_multi: tensor ", i, " needs ", need, " scale/zero_point entries, got ",
+                      scs[i].numel(), "/", zps[i].numel());
+    if (need == 1) s = Split3{1, 1, ins[i].numel()};
+    d[i] = dmxq_affine_desc{ins[i].data_ptr(), outs[i].data_ptr(), (const float*)scs[i].data_ptr(), (const int64_t*)zps[i].data_ptr(), s.outer, s.L, s.inner};
+  }
+  for (size_t i = 0; i < fs.size(); i++) {
+    fins.push_back(prep(fs[i], "fixed_float_qdq_multi"));
+    TORCH_CHECK(fins[i].scalar_type() == ins[0].scalar_type() && fins[i].device() == ins[0].device(), "fixed_float_qdq_multi: all tensors must share one dtype and one device");
+    fouts.push_back(empty_like_shape(fins[i], c10::nullopt));
+    fd[i] = dmxq_tensor_desc{fins[i].data_ptr(), fouts[i].data_ptr(), 1, fins[i].numel(), 1};
+  }
+  Launch l(ins[0]);
+  check(dmxq_fixed_float_qdq_multi(d.data(), (int64_t)d.size(), (int)precision, (int)fraction, clamp, symmetric, (int)rounding, std::max<int64_t>(group_size, 1),
+                                   fd.data(), (int64_t)fd.size(), (int)man, (int)exp, (int)bias, flush, unsigned_abs, (int)rounding_float,
+                                   dt_code(ins[0].scalar_type()), (uint64_t)seed, l.stream), "dmxq_fixed_float_qdq_multi");
+  return {outs, fouts};
+}
+std::tuple<std::vector<Tensor>, std::vector<Tensor>> fixed_float_qdq_multi_meta(at::TensorList xs, int64_t, int64_t, bool, bool, int64_t, at::TensorList, at::TensorList,
+                                                                                int64_t, at::TensorList fs, int64_t, int64_t, int64_t, bool, bool, int64_t, int64_t) {
+  std::vector<Tensor> outs, fouts;
+  for (const Tensor& x : xs) outs.push_back(empty_like_shape(x, c10::nullopt));
+  for (const Tensor& x : fs) fouts.push_back(empty_like_shape(x, c10::nullopt));
+  return {outs, fouts};
+}
+
 Tensor fixed_qdq(const Tensor& x, int64_t precision, int64_t fraction, bool clamp, bool symmetric, int64_t rounding,
                  const OptTensor& scale, const OptTensor& zero_point, c10::optional<int64_t> ch_axis,
                  c10::optional<int64_t> group_size, OptDtype out_dtype, int64_t seed) {
@@ -797,6 +840,7 @@ TORCH_LIBRARY(dmxq, m) {
   m.def("fixed_qdq(Tensor x, int precision, int fraction, bool clamp, bool symmetric, int rounding, Tensor? scale, Tensor? zero_point, int? ch_axis, int? group_size, ScalarType? out_dtype=None, int seed=0) -> Tensor");
   m.def("fixed_qdq_nograd(Tensor x, int precision, int fraction, bool clamp, bool symmetric, int rounding, Tensor? scale, Tensor? zero_point, int? ch_axis, int? group_size, ScalarType? out_dtype=None, int seed=0) -> Tensor");  // the same kernel without the Python STE autograd wrapper (2.5 us per call)
   m.def("float_qdq_multi(Tensor[] xs, int man, int exp, int bias, bool flush_subnormal, bool unsigned_abs=False, int rounding=2, ScalarType? out_dtype=None, int seed=0) -> Tensor[]");
+  m.def("fixed_float_qdq_multi(Tensor[] xs, int precision, int fraction, bool clamp, bool symmetric, int rounding, Tensor[] scales, Tensor[] zero_points, int group_size, Tensor[] fs, int man, int exp, int bias, bool flush_subnormal, bool unsigned_abs, int rounding_float, int seed=0) -> (Tensor[], Tensor[])");
   m.def("fixed_qdq_multi(Tensor[] xs, int precision, int fraction, bool clamp, bool symmetric, int rounding, Tensor[] scales, Tensor[] zero_points, int group_size, ScalarType? out_dtype=None, int seed=0) -> Tensor[]");
   m.def("nm_mask(Tensor score, Tensor? x, int K, int M, int block_dim, bool want_mask, bool want_y, ScalarType? mask_dtype=None, ScalarType? y_dtype=None) -> (Tensor, Tensor)");
   m.def("topk_mask(Tensor score, Tensor? x, int n_zero, bool want_mask, bool want_y, ScalarType? mask_dtype=None, ScalarType? y_dtype=None) -> (Tensor, Tensor)");
@@ -824,7 +868,7 @@ TORCH_LIBRARY(dmxq, m) {
 #define DMXQ_META(m, name) m.impl(#name, &name##_meta)
 #define DMXQ_FOR_ALL(X, m) \
   X(m, bfp_qdq); X(m, block_quantize); X(m, bfp_qdq_multi); X(m, weight_hypernet_multi); X(m, bfp_pack); X(m, bfp_unpack); X(m, weight_hypernet); X(m, input_hypernet); X(m, binary_cast); X(m, relu_cast); X(m, sbfp_qdq); X(m, mxfp_qdq);   \
-  X(m, float_qdq); X(m, float_qdq_multi); X(m, fixed_qdq); X(m, fixed_qdq_multi); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
+  X(m, float_qdq); X(m, float_qdq_multi); X(m, fixed_qdq); X(m, fixed_qdq_multi); X(m, fixed_float_qdq_multi); X(m, nm_mask); X(m, topk_mask); X(m, bernoulli_mask); X(m, group_minmax); X(m, qparams); \
   X(m, histc); X(m, channel_maxabs); X(m, smoothquant_scale); X(m, scale_channels); X(m, unary); X(m, rope); X(m, rope_cast); X(m, softmax); X(m, norm); \
   X(m, unary_cast); X(m, unary_cast_table); X(m, lut16_apply); X(m, softmax_cast); X(m, norm_cast); X(m, group_minmax_accumulate)
 

@@ -1597,13 +1597,35 @@ class LiveWeightBatch:
                 biases = _bias_batches(live)
                 if not self.replan and not torch.is_grad_enabled():
                     self._plan = (mods, groups, hyper, biases)
+            def stamp_bias(m, o):
+                m.__dict__["_live_bias"] = (o, m.bias._version, m.bias.data_ptr())
+
+            # ONE launch for the INT8 weight casts AND the bias casts when the layer has one group of each, same dtype and device
+            # (`dmxq_fixed_float_qdq_multi`: opt-125m's six weights + six biases; 2.3 us of a 185 us forward)
+            fixed_keys = [k for k, ms in groups.items() if k[0] == "fixed" and len(ms) >= 2 and k[7] == "nearest"]
+            bias_keys = [k for k, ms in biases.items() if len(ms) >= 2]
+            done_fixed = done_bias = None
+            if len(fixed_keys) == 1 and len(bias_keys) == 1 and fixed_keys[0][1:3] == bias_keys[0][0:2]:
+                fk, bk = fixed_keys[0], bias_keys[0]
+                ms, bs = groups[fk], biases[bk]
+                _, _, _, precision, fraction, clamp, symmetric, _, gs = fk
+                if fraction == 0 and clamp and len(ms) <= 12 and len(bs) <= 12 and len(ms) + len(bs) <= 21:
+                    wo, bo = ops.fixed_float_qdq_multi([m.weight.detach() for m in ms], precision, fraction, clamp, symmetric,
+                                                       [m.weight_cast.scale for m in ms], [m.weight_cast.zero_point for m in ms], gs,
+                                                       [m.bias.detach() for m in bs], bk[2], bk[3], bk[4], bk[5], bk[6])
+                    for m, o in zip(ms, wo):
+                        m.__dict__["_live_weight"] = (o, m.weight._version, m.weight.data_ptr(), m.weight.dtype)
+                    for m, o in zip(bs, bo):
+                        stamp_bias(m, o)
+                    done_fixed, done_bias = fk, bk
             # the bias casts of the same modules (a plain FloatingPoint format): one launch per group instead of one per module
-            for (_, _, man, exp, ebias, flush, unsigned), ms in biases.items():
-                if len(ms) < 2:
+            for key, ms in biases.items():
+                if len(ms) < 2 or key == done_bias:
                     continue
+                (_, _, man, exp, ebias, flush, unsigned) = key
                 outs = ops.float_qdq_multi([m.bias.detach() for m in ms], man, exp, ebias, flush, unsigned)
                 for m, o in zip(ms, outs):
-                    m.__dict__["_live_bias"] = (o, m.bias._version, m.bias.data_ptr())
+                    stamp_bias(m, o)
 
             def stamp(m, o, natural=None):
                 m.__dict__["_live_weight"] = (o, m.weight._version, m.weight.data_ptr(), natural or m.weight.dtype)
@@ -1619,7 +1641,7 @@ class LiveWeightBatch:
                     for (m, sc, _), o in zip(items, outs):
                         stamp(m, o, torch.promote_types(m.weight.dtype, sc.dtype) if (M and sc is not None) else m.weight.dtype)
             for key, ms in groups.items():
-                if len(ms) < 2:
+                if len(ms) < 2 or key == done_fixed:
                     continue
                 ws = [m.weight.detach() for m in ms]
                 if key[0] == "bfp":

@@ -146,6 +146,15 @@ typedef struct { const void* in; void* out; const float* scale; const int64_t* z
 int dmxq_fixed_qdq_multi(const dmxq_affine_desc* tensors, int64_t n_tensors, int dtype_in, int dtype_out, int precision,
                          int fraction, int clamp, int symmetric, int rounding, int64_t group_size, uint64_t seed, void* stream);
 
+/* dmxq_fixed_qdq_multi AND dmxq_float_qdq_multi in ONE launch (round 5): a layer's affine integer weight casts and its float bias casts
+ * (modeling/nn/core.py:178-203: `_weight` and `_bias` of every module, every forward while nothing is folded), one dtype in and out for all.
+ * Exactly the results of the two calls.  Combined: at most 12 + 12 tensors (21 in all), 32 MiB in all, every tensor batchable by its own
+ * multi call's rules, nearest rounding on both sides; any other set is run as those two calls. */
+int dmxq_fixed_float_qdq_multi(const dmxq_affine_desc* fixed, int64_t n_fixed, int precision, int fraction, int clamp, int symmetric,
+                               int rounding_fixed, int64_t group_size, const dmxq_tensor_desc* flt, int64_t n_float, int man_bits,
+                               int exp_bits, int exp_bias, int flush_subnormal, int unsigned_abs, int rounding_float, int dtype,
+                               uint64_t seed, void* stream);
+
 /* N:M structured-sparsity mask ("BTOPK{K:M,dim}") and its application.
  * Replaces: sparse.py:163-180 BlockTopK.forward (argsort + scatter) and sparse.py:300 `x * mask`.
  * Groups are M consecutive indices along L (stride inner); L % M == 0 required (sparse.py:166-168).

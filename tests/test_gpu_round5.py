@@ -390,3 +390,35 @@ def test_live_weight_batch_also_batches_the_bias_casts(dmx, cuda):
         assert all(bits_equal(l.__dict__["_live_bias"][0], b) == 0 and bits_equal(b, l.bias) != 0 for l, b in zip(model.layers, ref3))
         batch.remove()
         assert not any("_live_bias" in l.__dict__ for l in model.layers)
+
+
+def test_fixed_and_float_casts_of_a_layer_in_one_launch(dmx, cuda, oracle):
+    """`dmxq_fixed_float_qdq_multi` (round 5): a layer's INT8-per-row-group weight casts and its float bias casts in ONE launch == the two
+    multi-tensor calls == one call per tensor, bit for bit, float32 and bf16; sets the combined form does not take (13 weights; a ragged
+    bias) fall back to the two calls with the same results; LiveWeightBatch uses it for an opt-125m style layer."""
+    for dtype in (F32, BF16):
+        shapes = [(768, 768)] * 4 + [(3072, 768), (768, 3072)]
+        ws = [(make("normal", s, seed=1600 + i) * 0.05).to(dtype).to(cuda) for i, s in enumerate(shapes)]
+        scs, zps = [], []
+        for w in ws:
+            mn, mx = oracle.group_minmax(w.cpu().float(), 0, 128)
+            sc, zp = oracle.qparams(mn, mx, 8, True, True)
+            scs.append(sc.to(cuda)); zps.append(zp.to(cuda))
+        bs = [(make("normal", (s[0],), seed=1650 + i) * 0.02).to(dtype).to(cuda) for i, s in enumerate(shapes)]
+        wo, bo = dmx.ops.fixed_float_qdq_multi(ws, 8, 0, True, True, scs, zps, 128, bs, 10, 5, 15, True)
+        want_w = dmx.ops.fixed_qdq_multi(ws, 8, 0, True, True, scs, zps, group_size=128)
+        want_b = dmx.ops.float_qdq_multi(bs, 10, 5, 15, True)
+        for i in range(len(ws)):
+            assert bits_equal(wo[i], want_w[i]) == 0 and bits_equal(bo[i], want_b[i]) == 0, (dtype, i)
+            assert bits_equal(wo[i], dmx.ops.fixed_qdq(ws[i], 8, 0, True, True, scale=scs[i], zero_point=zps[i], ch_axis=0, group_size=128)) == 0
+            assert bits_equal(bo[i], dmx.ops.float_qdq(bs[i], 10, 5, 15, True)) == 0
+        want = oracle.fixed_point_affine_cast(ws[4].cpu().float(), 8, 0, True, True, scs[4].cpu(), zps[4].cpu(), ch_axis=0, group_size=128).to(dtype)
+        assert bits_equal(wo[4], want) == 0
+        assert mismatches_nan_aware(bo[4], oracle.float_quantize(bs[4].cpu().float(), 10, 5, 15, True).to(dtype)) == 0
+        # 13 weights: more than the combined form takes -> the two calls; a bias of 771 elements (not whole vectors) likewise
+        w13, s13, z13 = (ws + ws + ws[:1]), (scs + scs + scs[:1]), (zps + zps + zps[:1])
+        wo2, bo2 = dmx.ops.fixed_float_qdq_multi(w13, 8, 0, True, True, s13, z13, 128, bs, 10, 5, 15, True)
+        assert all(bits_equal(a, want_w[i % 6]) == 0 for i, a in enumerate(wo2)) and all(bits_equal(a, b) == 0 for a, b in zip(bo2, want_b))
+        ragged = bs[:3] + [(make("normal", (771,), seed=1700) * 0.02).to(dtype).to(cuda)]
+        wo3, bo3 = dmx.ops.fixed_float_qdq_multi(ws, 8, 0, True, True, scs, zps, 128, ragged, 10, 5, 15, True)
+        assert all(bits_equal(a, b) == 0 for a, b in zip(wo3, want_w)) and bits_equal(bo3[3], dmx.ops.float_qdq(ragged[3], 10, 5, 15, True)) == 0
