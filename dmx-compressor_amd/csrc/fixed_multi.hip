@@ -125,6 +125,21 @@ extern "C" int dmxq_fixed_float_qdq_multi(const dmxq_affine_desc* fixed, int64_t
                                           int exp_bits, int exp_bias, int flush_subnormal, int unsigned_abs, int rounding_float, int dtype,
                                           uint64_t seed, void* stream) {
   if (n_fixed < 0 || n_float < 0 || (n_fixed > 0 && !fixed) || (n_float > 0 && !flt) || !valid_dtype(dtype)) return DMXQ_ERR_BAD_ARG;
+  // every argument error of EITHER list before the first launch (the two fallback calls validate their own list only)
+  if (!valid_rounding(rounding_fixed) || !valid_rounding(rounding_float) || precision < 1 || group_size < 1 || exp_bits < 1 || exp_bits > 8 ||
+      man_bits < 0)
+    return DMXQ_ERR_BAD_ARG;
+  if (man_bits > 22) return DMXQ_ERR_UNSUPPORTED;
+  for (int64_t i = 0; i < n_fixed; i++) {
+    const dmxq_affine_desc& t = fixed[i];
+    if (t.outer < 0 || t.C < 0 || t.inner < 0 || (t.scale == nullptr) != (t.zero_point == nullptr)) return DMXQ_ERR_BAD_ARG;
+    if (t.outer * t.C * t.inner > 0 && (!t.in || !t.out)) return DMXQ_ERR_BAD_ARG;
+  }
+  for (int64_t i = 0; i < n_float; i++) {
+    const dmxq_tensor_desc& t = flt[i];
+    if (t.outer < 0 || t.L < 0 || t.inner < 0) return DMXQ_ERR_BAD_ARG;
+    if (t.outer * t.L * t.inner > 0 && (!t.in || !t.out)) return DMXQ_ERR_BAD_ARG;
+  }
   using OPA = FixedOp<kUniform, true>;
   using OPB = FloatOp<DMXQ_ROUND_NEAREST>;
   using Args = StreamMulti2Args<OPA, OPB>;

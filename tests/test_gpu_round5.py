@@ -422,3 +422,22 @@ def test_fixed_and_float_casts_of_a_layer_in_one_launch(dmx, cuda, oracle):
         ragged = bs[:3] + [(make("normal", (771,), seed=1700) * 0.02).to(dtype).to(cuda)]
         wo3, bo3 = dmx.ops.fixed_float_qdq_multi(ws, 8, 0, True, True, scs, zps, 128, ragged, 10, 5, 15, True)
         assert all(bits_equal(a, b) == 0 for a, b in zip(wo3, want_w)) and bits_equal(bo3[3], dmx.ops.float_qdq(ragged[3], 10, 5, 15, True)) == 0
+
+
+def test_fixed_float_multi_rejects_bad_arguments_before_any_launch(dmx, cuda):
+    """an argument error in EITHER list of `dmxq_fixed_float_qdq_multi` is reported before the first launch: the weights' outputs stay untouched"""
+    lib, L = dmx._lib, dmx._lib.lib()
+    sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    w = torch.ones(256, 64, device=cuda); wo = torch.full_like(w, 7.0)
+    sc = torch.full((2,), 0.05, device=cuda); zp = torch.zeros(2, dtype=torch.int64, device=cuda)
+    b = torch.ones(64, device=cuda); bo = torch.full_like(b, 7.0)
+    fd = (lib.AffineDesc * 1)(); fd[0].in_, fd[0].out, fd[0].scale, fd[0].zero_point, fd[0].outer, fd[0].C, fd[0].inner = w.data_ptr(), wo.data_ptr(), sc.data_ptr(), zp.data_ptr(), 1, 256, 64
+    td = (lib.TensorDesc * 1)(); td[0].in_, td[0].out, td[0].outer, td[0].L, td[0].inner = b.data_ptr(), bo.data_ptr(), 1, -64, 1   # negative extent
+    assert L.dmxq_fixed_float_qdq_multi(fd, 1, 8, 0, 1, 1, lib.ROUND_NEAREST, 128, td, 1, 10, 5, 15, 1, 0, lib.ROUND_NEAREST, lib.F32, 0, sp) == lib.ERR_BAD_ARG
+    td[0].L = 64
+    assert L.dmxq_fixed_float_qdq_multi(fd, 1, 8, 0, 1, 1, lib.ROUND_NEAREST, 128, td, 1, 10, 9, 15, 1, 0, lib.ROUND_NEAREST, lib.F32, 0, sp) == lib.ERR_BAD_ARG  # 9 exponent bits
+    torch.cuda.synchronize()
+    assert bool((wo == 7.0).all()) and bool((bo == 7.0).all())
+    assert L.dmxq_fixed_float_qdq_multi(fd, 1, 8, 0, 1, 1, lib.ROUND_NEAREST, 128, td, 1, 10, 5, 15, 1, 0, lib.ROUND_NEAREST, lib.F32, 0, sp) == lib.OK
+    torch.cuda.synchronize()
+    assert bits_equal(wo, dmx.ops.fixed_qdq(w, 8, 0, True, True, scale=sc, zero_point=zp, ch_axis=0, group_size=128)) == 0 and bits_equal(bo, dmx.ops.float_qdq(b, 10, 5, 15, True)) == 0
