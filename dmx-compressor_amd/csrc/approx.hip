@@ -678,7 +678,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_block_kernel(const void* _
       for (int i = 0; i < VPL; i++) {
         const int v = i * kThreads + t;
         raw[j][i] = row_load<DT, EPL>(in, base + (int64_t)(v < nv ? v : nv - 1) * EPL);
-        pace_issue<kRowPace>();
+        pace_issue<(CAST && RMS && RPWO == 4) ? 2 : kRowPace>();   // (the RMSNorm module's 26-32 MiB form: see the launcher)
       }
     }
     float x[RPW][VPL][EPL], mean[RPW], rstd[RPW];
@@ -1020,6 +1020,17 @@ static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out,
         DMXQ_LAUNCH((layernorm_block_kernel<D_, E_, V_, RMS, CAST, 0, false, true>),                                \
                     dim3((unsigned)resident_grid(layernorm_block_kernel<D_, E_, V_, RMS, CAST, 0, false, true>, (rows + rpw - 1) / rpw)), \
                     dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps, rb);                                \
+        break;                                                                                                        \
+      }                                                                                                               \
+    }                                                                                                                 \
+    if constexpr (CAST && RMS && (V_) == 2 && (E_) == 8) {                                                            \
+      /* the RMSNorm MODULE on 16-bit rows of 4096 (Llama's hidden size), 26-32 MiB: four rows per workgroup iteration on the persistent  */ \
+      /* grid, 16 idle issue cycles between a lane's loads: 13.5-13.65 -> 12.66 us on 4096 x 4096 bf16 (profiles/r05_tune_rows_pace.txt; */ \
+      /* four rows alone: 12.9-13.2)                                                                                                    */ \
+      if (mid && !rc.bfp_B) {                                                                                         \
+        DMXQ_LAUNCH((layernorm_block_kernel<D_, E_, V_, RMS, CAST, 4>),                                               \
+                    dim3((unsigned)resident_grid(layernorm_block_kernel<D_, E_, V_, RMS, CAST, 4>, (rows + 3) / 4)), dim3(kThreads), 0, s, \
+                    in, out, rows, cols, weight, bias, eps, rc);                                                      \
         break;                                                                                                        \
       }                                                                                                               \
     }                                                                                                                 \
