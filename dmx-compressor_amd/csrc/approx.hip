@@ -516,6 +516,8 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
   // register set, issued at the loop top (profiles/r03_row_prefetch.txt).  What these rows lack at 32 MiB is not queue depth per wave:
   // the same kernel reaches 74 % of the roofline at 128 MiB.  The code path stays (compiled out) as the record of the experiment.
   constexpr bool EARLY = PFO < 0 ? kRowEarlyLoads : PFO != 0;
+  // (the LayerNorm module on 16-bit rows of 768: paced loads, measured with the one-pass grid of the launcher; everything else: the tuner's hook)
+  constexpr int kLnModulePace = (CAST && !RMS && !BFPOUT && VPL == 3 && EPL == 8 && LPR == 32 && RPWO == 0) ? 4 : kRowPace;
   auto load_rows = [&](int64_t r0, RowVec<DT, EPL> (&dst)[RPW][VPL]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
       for (int i = 0; i < VPL; i++) {
         const int v = i * LPR + sl;
         dst[j][i] = row_load<DT, EPL>(in, base + (int64_t)(v < nv ? v : nv - 1) * EPL);
-        pace_issue<kRowPace>();
+        pace_issue<kLnModulePace>();
       }
     }
   };
@@ -1076,6 +1078,15 @@ static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out,
                     dim3(kThreads), 0, s, in, out, rows, cols, weight, bias, eps, rb);                                \
         break;                                                                                                        \
       }                                                                                                               \
+    }                                                                                                                 \
+    if constexpr (CAST && !RMS && (V_) == 3 && (E_) == 8 && (L_) == 32) {                                             \
+      /* the LayerNorm MODULE on 16-bit rows of 768 (opt-125m / Whisper-small hidden size): ONE pass per workgroup instead of the persistent */ \
+      /* grid, with 32 idle issue cycles between a wave's loads (layernorm_wave_kernel kLnModulePace).  Same-lease library A/B, 24000 x 768  */ \
+      /* bf16: 15.26 -> 14.32 us (60.4 -> 64.4 %; pace 2: 14.55; four rows per wave on the persistent grid, pace 0 / 2: 15.50 / 15.53);       */ \
+      /* 32768 / 48000 / 96000 rows: 19.9 -> 19.6, 28.3 -> 26.9, 53.4 -> 51.6 us (profiles/r05_tune_rows_pace.txt)                            */ \
+      DMXQ_LAUNCH((layernorm_wave_kernel<D_, E_, V_, L_, RMS, CAST>), dim3(one_pass_grid((rows + per_wg - 1) / per_wg)), dim3(kThreads), 0, s, \
+                  in, out, rows, cols, weight, bias, eps, rc);                                                        \
+      break;                                                                                                          \
     }                                                                                                                 \
     DMXQ_LAUNCH((layernorm_wave_kernel<D_, E_, V_, L_, RMS, CAST>),                                                 \
                        dim3((unsigned)resident_grid(layernorm_wave_kernel<D_, E_, V_, L_, RMS, CAST>, (rows + per_wg - 1) / per_wg)), \
