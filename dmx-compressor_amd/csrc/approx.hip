@@ -369,7 +369,9 @@ __global__ __launch_bounds__(kThreads) void softmax_wave_kernel(const void* __re
           dst[j][i] = row_load_u<DT, EPL>(in, base + (v < nvf ? (int64_t)v * EPL : cols - EPL));
         } else {
           dst[j][i] = row_load<DT, EPL>(in, base + (int64_t)(v < nvf ? v : nvf - 1) * EPL);
-          pace_issue<kRowPace>();
+          // (the softmax MODULE on 16-bit attention rows of 1281 .. 1536 elements -- Whisper's 1500 --: 16 idle issue cycles between a wave's
+          //  loads, 21.14 -> 20.66 us on [12, 1500, 1500] bf16; pace 4 / 6: 20.77 / 20.95; two rows per wave + pace 2 / 4: 20.61 / 20.62; four: 25.5)
+          pace_issue<(CAST && !BFPOUT && EPL == 4 && VPL == 6 && Elem<DT>::bytes == 2) ? 2 : kRowPace>();
         }
       }
     }
