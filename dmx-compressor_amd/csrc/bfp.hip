@@ -299,8 +299,20 @@ static int launch_multi(const MultiArgs& a, int64_t total_tiles, bool asym, int 
   constexpr int IVB = (Elem<DTO>::bytes > Elem<DTI>::bytes) ? 8 : 16;
   constexpr bool in16 = Elem<DTI>::bytes == 2;
   const bool single = in16 && bfp_single_rounding_ok<DTI>(wl);
-#define DMXQ_MULTI(A_, F_) \
-  DMXQ_LAUNCH((bfp_rows_multi_kernel<DTI, DTO, A_, kMultiUnroll, kMultiThreads, F_, IVB>), dim3((unsigned)total_tiles), dim3(kMultiThreads), 0, s, a)
+  uint32_t e[kMultiPre];
+  int64_t total_vec = 0;
+  for (int i = 0; i < a.n; i++) total_vec += a.d[i].n_vec;
+  for (int i = 0; i < kMultiPre; i++) e[i] = i + 1 < a.n ? (uint32_t)a.d[i + 1].tile0 : 0xFFFFFFFFu;
+  const bool small_set = total_vec * IVB <= ((int64_t)32 << 20);   // (plain stores: the results are consumed at once and fit the Infinity Cache)
+#define DMXQ_MULTI(A_, F_)                                                                                                                    \
+  do {                                                                                                                                        \
+    if (small_set)                                                                                                                            \
+      DMXQ_LAUNCH((bfp_rows_multi_kernel<DTI, DTO, A_, kMultiUnroll, kMultiThreads, F_, IVB, kRowsNtLoad>), dim3((unsigned)total_tiles),       \
+                  dim3(kMultiThreads), 0, s, e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8], e[9], a);                                   \
+    else                                                                                                                                      \
+      DMXQ_LAUNCH((bfp_rows_multi_kernel<DTI, DTO, A_, kMultiUnroll, kMultiThreads, F_, IVB>), dim3((unsigned)total_tiles), dim3(kMultiThreads), \
+                  0, s, e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8], e[9], a);                                                        \
+  } while (0)
   if (single) {
     if constexpr (in16) { if (asym) DMXQ_MULTI(true, 2); else DMXQ_MULTI(false, 2); }
   } else {

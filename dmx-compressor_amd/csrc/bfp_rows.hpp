@@ -344,14 +344,23 @@ constexpr int kMultiThreads = 256, kMultiUnroll = 4;  // 16 KiB (16-bit) tiles: 
 struct MultiDesc { const void* in; void* out; int64_t n_vec; int64_t tile0; /* first tile of this tensor */ };
 struct MultiArgs { MultiDesc d[kMultiMax]; int n; int lpb, wl; };
 
-template <int DTI, int DTO, bool ASYM, int UNROLL, int THREADS, int FAST, int IVB = 16>
-__global__ __launch_bounds__(THREADS) void bfp_rows_multi_kernel(const MultiArgs a) {
-  const int64_t tile = blockIdx.x;
-  int k = 0;
-  for (int i = 1; i < a.n; i++) k = (a.d[i].tile0 <= tile) ? i : k;  // tile0 ascending; n <= 48 scalar compares
+// Round 5 (as stream.hpp stream_multi_kernel): the first tiles of tensors 1 .. 10 arrive as ten SCALAR arguments -- preloaded into SGPRs
+// with the wave -- so that a set of up to 11 tensors is resolved without touching the argument block (scanned from it, a workgroup made two
+// dependent scalar-memory round trips before its first load); larger sets finish the scan in the block.  MODE: non-temporal stores for
+// large sets only -- a layer's quantised weights (<= 32 MiB) are read back by its GEMMs at once and fit the Infinity Cache.
+constexpr int kMultiPre = 10;
+template <int DTI, int DTO, bool ASYM, int UNROLL, int THREADS, int FAST, int IVB = 16, int MODE = kRowsNtLoad | kRowsNtStore>
+__global__ __launch_bounds__(THREADS) void bfp_rows_multi_kernel(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3, uint32_t e4, uint32_t e5,
+                                                                uint32_t e6, uint32_t e7, uint32_t e8, uint32_t e9, const MultiArgs a) {
+  const uint32_t tile = blockIdx.x;
+  int k = (e0 <= tile) + (e1 <= tile) + (e2 <= tile) + (e3 <= tile) + (e4 <= tile) + (e5 <= tile) + (e6 <= tile) + (e7 <= tile) + (e8 <= tile) +
+          (e9 <= tile);
+  if (k == kMultiPre) {
+    for (int i = kMultiPre + 1; i < a.n; i++) k = ((uint32_t)a.d[i].tile0 <= tile) ? i : k;  // tile0 ascending
+  }
   const int lpb = __builtin_amdgcn_readfirstlane(a.lpb);
-  bfp_rows_tile<DTI, DTO, DMXQ_ROUND_NEAREST, ASYM, UNROLL, kRowsNtLoad | kRowsNtStore, THREADS, FAST, UNROLL, IVB>(
-      a.d[k].in, a.d[k].out, a.d[k].n_vec, tile - a.d[k].tile0, lpb, a.wl, DMXQ_ROUND_NEAREST, false, 0ull);
+  bfp_rows_tile<DTI, DTO, DMXQ_ROUND_NEAREST, ASYM, UNROLL, MODE, THREADS, FAST, UNROLL, IVB>(
+      a.d[k].in, a.d[k].out, a.d[k].n_vec, (int64_t)tile - a.d[k].tile0, lpb, a.wl, DMXQ_ROUND_NEAREST, false, 0ull);
 }
 
 }  // namespace dmxq
