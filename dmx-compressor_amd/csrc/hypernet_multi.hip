@@ -23,13 +23,19 @@ struct HnMultiArgs { HnMultiDesc d[kHnMultiMax]; int n, K, lpb, wl, asym; };
 static_assert(sizeof(HnMultiArgs) <= 3072, "kernel arguments stay well under the 4 KiB limit");
 
 template <int DTW, int DTS, int DTO, int M, bool HAS_SCALE, int UN>
-__global__ __launch_bounds__(kThreads) void hypernet_rows_multi_kernel(const HnMultiArgs ma) {
-  const int64_t tile = blockIdx.x;
-  int k = 0;
-  for (int i = 1; i < ma.n; i++) k = (ma.d[i].tile0 <= tile) ? i : k;  // tile0 ascending; <= 32 scalar compares
+__global__ __launch_bounds__(kThreads) void hypernet_rows_multi_kernel(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3, uint32_t e4, uint32_t e5,
+                                                                      uint32_t e6, uint32_t e7, uint32_t e8, uint32_t e9, const HnMultiArgs ma) {
+  // (round 5, as stream.hpp stream_multi_kernel: the first tiles of tensors 1 .. 10 as preloaded scalar arguments -- a layer's seven weights are
+  //  resolved without touching the argument block; larger sets finish the scan in it)
+  const uint32_t tile = blockIdx.x;
+  int k = (e0 <= tile) + (e1 <= tile) + (e2 <= tile) + (e3 <= tile) + (e4 <= tile) + (e5 <= tile) + (e6 <= tile) + (e7 <= tile) + (e8 <= tile) +
+          (e9 <= tile);
+  if (k == 10) {
+    for (int i = 11; i < ma.n; i++) k = ((uint32_t)ma.d[i].tile0 <= tile) ? i : k;  // tile0 ascending
+  }
   const HnMultiDesc& d = ma.d[k];
   const HnArgs a{d.w, d.score, d.scale, d.out, d.n_units, d.L, ma.K, ma.lpb, ma.wl, ma.asym, d.small, d.f_L};
-  const int64_t u0 = (tile - d.tile0) * ((int64_t)kThreads * UN) + threadIdx.x;
+  const int64_t u0 = ((int64_t)tile - d.tile0) * ((int64_t)kThreads * UN) + threadIdx.x;
   if (u0 >= a.n_units) return;  // (whole lane groups of a block leave together: n_units is a multiple of the lanes of a block)
   const bool asym = __builtin_amdgcn_readfirstlane(ma.asym) != 0;
   const int lpb = __builtin_amdgcn_readfirstlane(ma.lpb);
@@ -44,10 +50,16 @@ __global__ __launch_bounds__(kThreads) void hypernet_rows_multi_kernel(const HnM
 
 template <int DTW, int DTS, int DTO>
 static int launch_hn_multi(const HnMultiArgs& a, int64_t tiles, int M, bool has_scale, int units, hipStream_t s) {
+  uint32_t e[10];
+  for (int i = 0; i < 10; i++) e[i] = i + 1 < a.n ? (uint32_t)a.d[i + 1].tile0 : 0xFFFFFFFFu;
 #define DMXQ_HM(M_, S_)                                                                                                                       \
   do {                                                                                                                                        \
-    if (units == kHnUnitsSmall) DMXQ_LAUNCH((hypernet_rows_multi_kernel<DTW, DTS, DTO, M_, S_, kHnUnitsSmall>), dim3((unsigned)tiles), dim3(kThreads), 0, s, a); \
-    else DMXQ_LAUNCH((hypernet_rows_multi_kernel<DTW, DTS, DTO, M_, S_, kHnUnits>), dim3((unsigned)tiles), dim3(kThreads), 0, s, a);        \
+    if (units == kHnUnitsSmall)                                                                                                               \
+      DMXQ_LAUNCH((hypernet_rows_multi_kernel<DTW, DTS, DTO, M_, S_, kHnUnitsSmall>), dim3((unsigned)tiles), dim3(kThreads), 0, s, e[0], e[1], e[2], \
+                  e[3], e[4], e[5], e[6], e[7], e[8], e[9], a);                                                                               \
+    else                                                                                                                                      \
+      DMXQ_LAUNCH((hypernet_rows_multi_kernel<DTW, DTS, DTO, M_, S_, kHnUnits>), dim3((unsigned)tiles), dim3(kThreads), 0, s, e[0], e[1], e[2], e[3], \
+                  e[4], e[5], e[6], e[7], e[8], e[9], a);                                                                                     \
   } while (0)
   if (has_scale) { switch (M) { case 0: DMXQ_HM(0, true); break; case 2: DMXQ_HM(2, true); break; case 4: DMXQ_HM(4, true); break; default: DMXQ_HM(8, true); } }
   else { switch (M) { case 0: DMXQ_HM(0, false); break; case 2: DMXQ_HM(2, false); break; case 4: DMXQ_HM(4, false); break; default: DMXQ_HM(8, false); } }
