@@ -93,7 +93,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 print(" ".join(cmd), flush=True)
             if src in NO_SCRATCH:
                 with open(o + ".remarks", "w") as rf:
-                    subprocess.check_call(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=rf)
+                    rc = subprocess.call(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=rf)
+                # stderr went to the remarks file: show everything in it that is NOT a resource remark (errors, warnings) on the console
+                diag = [l for l in open(o + ".remarks", errors="replace") if "remark:" not in l and l.strip()]
+                if diag:
+                    sys.stderr.write("".join(diag))
+                if rc != 0:
+                    os.remove(o + ".remarks")
+                    raise subprocess.CalledProcessError(rc, cmd)
             else:
                 subprocess.check_call(cmd)
         if src in NO_SCRATCH:   # (every build, also when the object was up to date: the remarks of ITS compilation are kept beside it)

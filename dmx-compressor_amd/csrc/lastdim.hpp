@@ -8,7 +8,7 @@
 //                                                                                           a wave (cross-lane ops are allowed)
 // Optional (round 5), `static constexpr bool kDeferredRedo = true`: the op's straight-line form may not cover every input; then
 //   bool apply_chan_flag(x, p, y, e0)   computes y with the straight-line form and returns true when this lane's row needs
-//   void apply_chan_exact(x, p, y, e0)  instead -- which the kernel runs in ONE cold loop after the store burst, from a fresh load
+//   void apply_chan_exact(x, p, y, e0)  instead -- which the kernel runs in ONE cold loop just before the store burst, from a fresh load
 //                                       (every lane of the wave takes part again: cross-lane ops stay legal), the flagged lanes storing.
 // In place, behind a wave-uniform branch per row, the 16 rows of a lane could not overlap (a branch fences the scheduling of what
 // surrounds it) and the cold blocks sat between the hot ones (stream.hpp has the same finding for its tiles).
@@ -107,6 +107,27 @@ __global__ __launch_bounds__(THREADS) void lastdim_kernel(const void* __restrict
     o[j] = pack_vec<DTO, EPL>(y);
     __builtin_amdgcn_sched_barrier(0);
   }
+  if constexpr (OpDeferredRedo<OP>::value) {
+    // BEFORE the store burst: nothing of this workgroup's rows has been stored yet, so the fresh load sees the ORIGINAL elements when
+    // `out` aliases `in` too (include/dmxq.h allows exact aliasing; round 5 ran this loop after the burst and re-read its own results).
+    // The exact result replaces o[j] through a select chain over compile-time indices (o[] stays in registers).
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo != 0u) != 0ull, 0)) {
+#pragma unroll 1
+      for (int j = 0; j < RPI; j++) {
+        if (__builtin_amdgcn_ballot_w64(((redo >> j) & 1u) != 0u) == 0ull) continue;   // (wave-uniform: every lane of the wave redoes the row)
+        const int64_t r = r0 + (int64_t)j * rpp + sub, rc = r < rows ? r : rows - 1;
+        const u32x4 rw = lastdim_load<IVB>(in, (rc * cv + cbc) * IVB);
+        float x[EPL], y[EPL];
+        widen_row(rw, x);
+        op.apply_chan_exact(x, p, y, r * C + (int64_t)cb * EPL);
+        const OutVec<DTO, EPL> o1 = pack_vec<DTO, EPL>(y);
+        const bool mine = ((redo >> j) & 1u) != 0u;
+#pragma unroll
+        for (int k = 0; k < RPI; k++)
+          if (k == j && mine) o[k] = o1;
+      }
+    }
+  }
   char* dst = (char*)out + r0 * cv * OVB;
   if (whole) {
     if (active) {
@@ -119,20 +140,6 @@ __global__ __launch_bounds__(THREADS) void lastdim_kernel(const void* __restrict
     for (int j = 0; j < RPI; j++) {
       const uint32_t lr = (uint32_t)j * (uint32_t)rpp + (uint32_t)sub;
       if (active && r0 + lr < rows) store_out<DTO, EPL, true>(dst + (lr * (uint32_t)cv + (uint32_t)cb) * (uint32_t)OVB, o[j]);
-    }
-  }
-  if constexpr (OpDeferredRedo<OP>::value) {
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo != 0u) != 0ull, 0)) {
-#pragma unroll 1
-      for (int j = 0; j < RPI; j++) {
-        if (__builtin_amdgcn_ballot_w64(((redo >> j) & 1u) != 0u) == 0ull) continue;   // (wave-uniform: every lane of the wave redoes the row)
-        const int64_t r = r0 + (int64_t)j * rpp + sub, rc = r < rows ? r : rows - 1;
-        const u32x4 rw = lastdim_load<IVB>(in, (rc * cv + cbc) * IVB);
-        float x[EPL], y[EPL];
-        widen_row(rw, x);
-        op.apply_chan_exact(x, p, y, r * C + (int64_t)cb * EPL);
-        if (((redo >> j) & 1u) && active && r < rows) store_out<DTO, EPL, true>((char*)out + (r * cv + cb) * OVB, pack_vec<DTO, EPL>(y));
-      }
     }
   }
 }

@@ -42,7 +42,7 @@ template <class OP> struct OpTilePrep<OP, std::void_t<decltype(OP::kTilePrep)>> 
 // Optional straight-line tile forms: an OP with `static constexpr int kTileVariants = 3` offers, for tiles whose side data came from
 // tile_prepare, `int tile_variant(Prep&) const` (wave-uniform; 0 = the general apply_vec; may complete the Prep, e.g. a reciprocal),
 // `bool apply_vec_tile<V>(x, y, prep)` for V = 1, 2 -- true: this lane's vector needs `apply_vec_exact(x, y, e0, prep)` instead, which
-// the kernel runs in one cold loop after the tile's store burst.  One scalar branch per TILE picks the body, nothing per vector.
+// the kernel runs in one cold loop just before the tile's store burst (in-place safe).  One scalar branch per TILE picks the body, nothing per vector.
 template <class OP, class = void> struct OpTileVariants { static constexpr int value = 1; };
 template <class OP> struct OpTileVariants<OP, std::void_t<decltype(OP::kTileVariants)>> { static constexpr int value = OP::kTileVariants; };
 
@@ -149,13 +149,13 @@ __device__ __forceinline__ void stream_tile(const void* __restrict__ in, void* _
         __builtin_amdgcn_sched_barrier(0);
 #endif
       }
-#pragma unroll
-      for (int u = 0; u < UNROLL; u++) store_out<DTO, EPL, NTS, UNAL>(dst + u * (THREADS * OVB) + lane_out, o[u]);
       if constexpr (V > 0) {
-        // The straight-line forms do not cover every input (Inf / NaN quotients): flagged vectors are redone AFTER the store burst,
-        // from a fresh load, and stored again by the same lane (same-address stores of a lane stay ordered) -- ONE cold loop per
-        // tile.  Redone in place behind a branch per vector, the compiler laid 16 cold blocks of ~250 instructions between the hot
-        // ones: the tile body no longer fitted the instruction cache (INT8 per group, zero point 0: 12.2 us where the form WITH
+        // The straight-line forms do not cover every input (Inf / NaN quotients): flagged vectors are redone BEFORE the store burst,
+        // from a fresh load -- nothing of this tile has been stored yet, so the load sees the ORIGINAL elements when `out` aliases
+        // `in` too (include/dmxq.h: exact aliasing is allowed; round 5 redid them after the burst and read its own results back) --
+        // in ONE cold loop per tile whose result replaces o[u] through a select chain over compile-time indices (o[] stays in
+        // registers).  Redone in place behind a branch per vector, the compiler laid 16 cold blocks of ~250 instructions between the
+        // hot ones: the tile body no longer fitted the instruction cache (INT8 per group, zero point 0: 12.2 us where the form WITH
         // a zero point, whose cold blocks happened to be placed out of line, ran 11.6; tools/tune_stream int8g0 / int8g).
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(redo != 0u) != 0ull, 0)) {
 #pragma unroll 1
@@ -165,11 +165,16 @@ __device__ __forceinline__ void stream_tile(const void* __restrict__ in, void* _
               float x[EPL], y[EPL];
               stream_widen<DTI, EPL>(r1, x);
               tile_apply_exact(op, x, y, (v0 + (int64_t)u * THREADS) * EPL, prep_of(u));
-              store_out<DTO, EPL, NTS, UNAL>(dst + u * (THREADS * OVB) + lane_out, pack_vec<DTO, EPL>(y));
+              const OutVec<DTO, EPL> o1 = pack_vec<DTO, EPL>(y);
+#pragma unroll
+              for (int k = 0; k < UNROLL; k++)
+                if (k == u) o[k] = o1;
             }
           }
         }
       }
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) store_out<DTO, EPL, NTS, UNAL>(dst + u * (THREADS * OVB) + lane_out, o[u]);
     };
     if constexpr (OpTilePrep<OP>::value) {
       // the whole tile shares one set of side data (one quantisation group): fetched once, from a wave-uniform address,

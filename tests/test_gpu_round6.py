@@ -1,0 +1,110 @@
+"""-m gpu, round 6: exact aliasing (out == in) of the kernels with a deferred exact redo, on inputs that TAKE the redo
+(csrc/stream.hpp, csrc/lastdim.hpp redid flagged vectors from a fresh load AFTER the store burst, i.e. from their own
+results when out == in)."""
+import ctypes
+
+import pytest
+import torch
+
+from _data import bits_equal, make, mismatches_nan_aware
+
+pytestmark = pytest.mark.gpu
+BF16, F16, F32 = torch.bfloat16, torch.float16, torch.float32
+vp = ctypes.c_void_p
+
+
+def _specials(x, seed, every=97):
+    """NaN / +-Inf / +-1e38-class values (the largest finite ones of the dtype for fp16) sprinkled over a copy of x: quotients
+    that the reciprocal forms do not cover (Inf / NaN / overflow) land in many different vectors of many tiles"""
+    t = x.clone().reshape(-1)
+    big = 6.0e4 if x.dtype == F16 else 1.0e38
+    vals = torch.tensor([float("nan"), float("inf"), float("-inf"), big, -big, 3.0e38 if x.dtype != F16 else 65504.0], dtype=torch.float32)
+    idx = torch.arange(seed % every, t.numel(), every)
+    t[idx] = vals[torch.arange(idx.numel()) % vals.numel()].to(x.dtype)
+    return t.reshape(x.shape)
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16, F32])
+@pytest.mark.parametrize("shape,ch_axis,gs", [
+    ((64, 1024), None, None),        # per-tensor scale, 256 x 1 tiles
+    ((2048, 1024), None, None),      # 256 x 2 / 256 x 4 tiles
+    ((4096, 4096), 0, 128),          # the op's own deep tiles (INT8 group-128: configs[2]'s cast), one group per tile
+    ((1024, 1024), 0, 64),           # group runs shorter than a deep tile
+    ((512, 768), 0, None),           # per-channel rows (ch_axis = 0): group walker
+    ((512, 4096), -1, None),         # per-channel along the contiguous dim: lastdim_kernel
+])
+def test_fixed_qdq_in_place_with_special_values(dmx, cuda, oracle, dtype, shape, ch_axis, gs):
+    """dmxq_fixed_qdq with out == in must give what it gives out of place, and what the oracle gives, on tensors whose NaN / Inf /
+    huge elements send vectors through the kernels' exact redo"""
+    from dmx_compressor_amd import _lib
+    L = _lib.lib()
+    s = vp(torch.cuda.current_stream().cuda_stream)
+    x = _specials(make("heavy", shape, seed=61, dtype=dtype).clamp(-1e4, 1e4), seed=shape[0])
+    C = 1 if ch_axis is None else shape[ch_axis]
+    n_sc = 1 if ch_axis is None else -(-C // (gs or 1))
+    sc = (make("normal", (n_sc,), seed=62).abs() * 0.05 + 1e-3).float()
+    if n_sc > 3:
+        sc[1] = 1e-30           # a scale outside the reciprocal form's range: the tile takes the general body
+        sc[2] = 3.0e38
+    for zero_points in (torch.zeros(n_sc, dtype=torch.int64), (torch.arange(n_sc) % 7 - 3).to(torch.int64)):
+        sym = bool((zero_points == 0).all())
+        want = oracle.fixed_point_affine_cast(x, 8, 0, True, sym, sc, zero_points, ch_axis=ch_axis, group_size=gs).to(dtype)
+        outer, Cc, inner = (1, 1, x.numel()) if ch_axis is None else _lib.split3(x.shape, ch_axis)
+        t, scd, zpd = x.to(cuda).contiguous(), sc.to(cuda), zero_points.to(cuda)
+        o = torch.empty_like(t)
+        code = _lib.dtype_code(dtype)
+        args = (code, code, outer, Cc, inner, 8, 0, 1, int(sym), 2, vp(scd.data_ptr()), vp(zpd.data_ptr()), gs or 1, 0, s)
+        assert L.dmxq_fixed_qdq(vp(t.data_ptr()), vp(o.data_ptr()), *args) == 0
+        assert mismatches_nan_aware(o, want) == 0, ("out of place", shape, ch_axis, gs, sym)
+        assert int(torch.isnan(o.float()).sum()) > 0      # (the specials really reach the result)
+        assert L.dmxq_fixed_qdq(vp(t.data_ptr()), vp(t.data_ptr()), *args) == 0
+        assert bits_equal(t, o) == 0, ("in place differs from out of place", shape, ch_axis, gs, sym)
+
+
+@pytest.mark.parametrize("rows,L,B", [(512, 4096, 16), (300, 768, 64), (2048, 1024, 16)])
+def test_input_hypernet_in_place_f32_with_special_values(dmx, cuda, rows, L, B):
+    """dmxq_input_hypernet, float32 in == out (the only dtype pair that can alias): rows that fail the fast form (NaN / Inf / huge
+    elements, a tiny and a huge SmoothQuant scale) are redone by the exact form -- from the ORIGINAL elements"""
+    from dmx_compressor_amd import _lib
+    Lb = _lib.lib()
+    s = vp(torch.cuda.current_stream().cuda_stream)
+    x = _specials(make("heavy", (rows, L), seed=71).clamp(-1e6, 1e6), seed=rows, every=211)
+    sq = (make("normal", (L,), seed=72).abs() + 0.05).float()
+    sq[3], sq[17] = 1e-30, 2.0e38
+    t, sqd = x.to(cuda), sq.to(cuda)
+    o = torch.empty_like(t)
+    args = (vp(sqd.data_ptr()),)
+    assert Lb.dmxq_input_hypernet(vp(t.data_ptr()), _lib.F32, vp(sqd.data_ptr()), vp(o.data_ptr()), _lib.F32, rows, L, B, 8, 1, s) == 0
+    # what the fused kernel must equal (include/dmxq.h): the unfused pair, each of which is oracle-pinned elsewhere
+    chain = dmx.ops.bfp_qdq(dmx.ops.scale_channels(t, sqd, -1, True), 8, B)
+    assert mismatches_nan_aware(o, chain) == 0
+    assert Lb.dmxq_input_hypernet(vp(t.data_ptr()), _lib.F32, vp(sqd.data_ptr()), vp(t.data_ptr()), _lib.F32, rows, L, B, 8, 1, s) == 0
+    assert bits_equal(t, o) == 0
+    del args
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_scale_channels_in_place_with_special_values(dmx, cuda, dtype):
+    """dmxq_scale_channels(divide) in place along the contiguous dim and along rows"""
+    from dmx_compressor_amd import _lib
+    L = _lib.lib()
+    s = vp(torch.cuda.current_stream().cuda_stream)
+    x = _specials(make("heavy", (768, 3072), seed=81, dtype=dtype).clamp(-1e6, 1e6), seed=5)
+    for ch_axis in (-1, 0):
+        C = x.shape[ch_axis]
+        sq = (make("normal", (C,), seed=82).abs() + 0.05).float()
+        sq[1], sq[2] = 1e-30, 2.0e38
+        t, sqd = x.to(cuda), sq.to(cuda)
+        o = torch.empty_like(t)
+        outer, Cc, inner = _lib.split3(t.shape, ch_axis)
+        code = _lib.dtype_code(dtype)
+        for divide in (1, 0):
+            t.copy_(x)
+            assert L.dmxq_scale_channels(vp(t.data_ptr()), vp(o.data_ptr()), code, code, outer, Cc, inner, vp(sqd.data_ptr()), divide, s) == 0
+            shp = [1, 1]
+            shp[ch_axis] = C
+            xf, sf = x.float(), sq.reshape(shp)
+            want = (xf / sf if divide else xf * sf).to(dtype)
+            assert mismatches_nan_aware(o, want) == 0, (ch_axis, divide)
+            assert L.dmxq_scale_channels(vp(t.data_ptr()), vp(t.data_ptr()), code, code, outer, Cc, inner, vp(sqd.data_ptr()), divide, s) == 0
+            assert bits_equal(t, o) == 0, (ch_axis, divide)
