@@ -105,6 +105,10 @@ def parse():
     ap.add_argument("--input", choices=["portable", "device"], default="portable",
                     help="c2 inputs: portable = tests/_data.py's counter-based generator on the host (identical bits on every "
                          "machine: outputs are compared with the reference's committed digests); device = torch.randn on the GPU")
+    ap.add_argument("--no-tier2", action="store_true",
+                    help="c2 at N = 1 only: skip the second tier (tools/bench_tier2.py: the config 3 / 4 / 5 kernels and the three configured "
+                         "layers, timed and oracle-checked after the headline measurement; `ops` / `layers` in the JSON line)")
+    ap.add_argument("--tier2-only", default=None, help="comma-separated substrings of second-tier op names / config tags (c3,c4,c5)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks through torch.distributed.run even for --gpus 1 (exercises the self-launch path)")
     return ap.parse_args()
@@ -675,6 +679,20 @@ def main():
         }
         if resident is not None:
             line["cache_resident_value"] = round(resident, 2)
+        if world == 1 and args.workload == "c2" and not args.no_tier2:
+            # the second tier: configs 3 / 4 / 5's kernels and layers, AFTER the headline measurement above, in the
+            # same process and the same driver-observed run; never raises (a failure is recorded in the entry it belongs to)
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("bench_tier2", os.path.join(ROOT, "tools", "bench_tier2.py"))
+                t2 = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(t2)
+                del wl.ins, wl.outs
+                torch.cuda.empty_cache()
+                line.update(t2.run(dev, args.tier2_only.split(",") if args.tier2_only else None,
+                                   log=lambda m: print("[tier2] " + m, file=sys.stderr, flush=True)))
+            except Exception as e:   # noqa: BLE001
+                line["ops"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -1532,60 +1532,110 @@ def fold_weights_and_biases(model: torch.nn.Module) -> torch.nn.Module:
     return model
 
 
+def _live_scopes(root: torch.nn.Module, max_bytes):
+    """The modules a `LiveWeightBatch` hooks: the LARGEST disjoint submodules of `root` that hold at least two weight-bearing DmxModules
+    and at most `max_bytes` of their weights (None: `root` itself, whatever its size).  A scope's weights are quantised together when its
+    forward starts and released when it ends, so `max_bytes` bounds the quantised copies alive at any time: an opt-125m (250 MB) is one
+    scope, a Llama-3-8B (16 GB in bf16) becomes one scope per decoder layer (436 MB), its lm_head (one module) is left to the per-module
+    path.  Containers that are never CALLED (ModuleList / ModuleDict: no forward, their hooks would never fire) are only descended into."""
+    def weights(mod):
+        return [m.weight for m in mod.modules() if isinstance(m, DmxModule) and getattr(m, "weight", None) is not None]
+
+    def walk(mod):
+        ws = weights(mod)
+        if len(ws) < 2:
+            return []
+        callable_ = not isinstance(mod, (torch.nn.ModuleList, torch.nn.ModuleDict))
+        if callable_ and (max_bytes is None or sum(w.numel() * w.element_size() for w in ws) <= max_bytes):
+            return [mod]
+        out = []
+        for c in mod.children():
+            out += walk(c)
+        return out
+
+    return walk(root)
+
+
 class LiveWeightBatch:
     """The weight chains of a (sub)model's DmxModules as a few multi-tensor launches per forward, for weights that are NOT folded --
     the reference re-runs every module's weight hypernet on every forward (modeling/nn/core.py:178-203), one launch chain per weight:
     an opt-125m decoder layer launches six INT8 casts of 0.6-2.4 M elements per forward, each ~4 us of launch for ~1 us of streaming.
 
-        batch = LiveWeightBatch(layer)      # a forward pre-hook on `layer`
-        y = layer(x)                        # pre-hook: ONE launch per group of sibling weights; the modules then pick their result up
-        batch.remove()
+        batch = LiveWeightBatch(model)      # forward hooks on the model's scopes (the model itself when it is small, see below)
+        y = model(x)                        # a scope's pre-hook: ONE launch per group of sibling weights; the modules then pick their
+        batch.remove()                      # result up; the scope's post-hook drops the results again
 
     The bias casts of the same modules (a plain FloatingPoint format, the BASIC rules' bias format) go the same way: one
     `ops.float_qdq_multi` launch per group instead of one launch per module (six per opt-125m decoder layer).
-    The pre-hook plans the groups afresh on every forward (`_weight_batches`: same dtype / device / format / N:M pattern, the rule of
-    `fold_weights_and_biases`), launches `ops.fixed_qdq_multi` / `ops.bfp_qdq_multi` / `ops.weight_hypernet_multi` and leaves each
+    A scope's pre-hook plans the groups afresh on every forward (`_weight_batches`: same dtype / device / format / N:M pattern, the rule
+    of `fold_weights_and_biases`), launches `ops.fixed_qdq_multi` / `ops.bfp_qdq_multi` / `ops.weight_hypernet_multi` and leaves each
     result on its module, stamped with the Parameter's storage and version: `DmxModule.weight_hypernet` returns it for THAT state of
-    the Parameter only (an optimiser step or an assignment in between invalidates it) and only in inference.  Weights stay "live":
-    a changed weight, scale or configuration shows in the next forward.  Results are bit-identical to the per-module path (the
-    multi-tensor entry points are, tests/test_gpu_round2.py / round4.py).  Memory: one quantised copy of every batched weight of
-    `root` at a time -- put the batch on a decoder layer, not on a 70 B model.  `GraphedForward(..., batch_live_weights=True)`
-    installs one for the capture."""
+    the Parameter only (an optimiser step or an assignment in between invalidates it) and only in inference.  The stamps live for the
+    scope's forward ONLY (round 6): a forward hook registered with `always_call=True` pops them when the scope's forward
+    returns or raises, so a later direct call of a submodule, of `m.weight_hypernet(m.weight)` or of `m._weight_ro` -- layer-wise
+    calibration, a recalibrated scale, a new sparsifier score, none of which the stamp can see -- runs the module's own chain, and no
+    quantised copy is held between forwards.  Weights stay "live": a changed weight, scale or configuration shows in the next forward.
+    Results are bit-identical to the per-module path (the multi-tensor entry points are, tests/test_gpu_round2.py / round4.py).
 
-    def __init__(self, root: torch.nn.Module, replan: bool = True):
+    Memory: the quantised copies of ONE scope at a time.  `max_bytes` (default 1 GiB of weights) picks the scopes (`_live_scopes`): the
+    whole of a small model, one decoder layer at a time of a large one.  `GraphedForward(..., batch_live_weights=True)` installs one for
+    the capture and removes it afterwards."""
+
+    def __init__(self, root: torch.nn.Module, replan: bool = True, max_bytes: Optional[int] = 1 << 30):
         """replan: plan the groups afresh on every forward (any reconfiguration shows at once; ~13 us of Python per weight-bearing
         module -- nothing inside a graph capture, 10 % of an EAGER opt-125m layer).  False: plan at the first forward and keep it
         until `refresh()` -- for a configuration that is frozen while the batch is installed."""
-        self.root, self.replan, self._plan = root, replan, None
-        self._handle = root.register_forward_pre_hook(self._prepare)
+        self.root, self.replan = root, replan
+        self._plans, self._stamped = {}, {}
+        self.scopes = _live_scopes(root, max_bytes)
+        self._handles = []
+        for sc in self.scopes:
+            self._handles.append(sc.register_forward_pre_hook(self._prepare))
+            self._handles.append(sc.register_forward_hook(self._release, always_call=True))
+
+    @property
+    def _plan(self):
+        """the kept plan of the first scope (replan = False), None before its first forward"""
+        return self._plans.get(id(self.scopes[0])) if self.scopes else None
 
     def refresh(self):
-        """drop the kept plan (replan = False): the next forward groups the weights again"""
-        self._plan = None
+        """drop the kept plans (replan = False): the next forward groups the weights again"""
+        self._plans.clear()
 
     def remove(self):
-        self._handle.remove()
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+        self._stamped.clear()
         for m in self.root.modules():
             if isinstance(m, DmxModule):
                 m.__dict__.pop("_live_weight", None)
                 m.__dict__.pop("_live_bias", None)
 
+    def _release(self, module, args, output):
+        """the scope's forward is over (returned or raised): its stamps, and the quantised copies they hold, go"""
+        for m in self._stamped.pop(id(module), ()):
+            m.__dict__.pop("_live_weight", None)
+            m.__dict__.pop("_live_bias", None)
+
     def _prepare(self, module, args):
         from . import ops
-        if self.replan or self._plan is None:
-            mods = [m for m in self.root.modules() if isinstance(m, DmxModule) and getattr(m, "weight", None) is not None]
+        plan = self._plans.get(id(module))
+        if self.replan or plan is None:
+            mods = [m for m in module.modules() if isinstance(m, DmxModule) and getattr(m, "weight", None) is not None]
         else:
-            mods = self._plan[0]
+            mods = plan[0]
         for m in mods:
             m.__dict__.pop("_live_weight", None)
             m.__dict__.pop("_live_bias", None)
+        self._stamped[id(module)] = mods
         if torch.compiler.is_compiling():
             return
         if torch.is_grad_enabled() and any(m.weight.requires_grad or (getattr(m, "bias", None) is not None and m.bias.requires_grad) for m in mods):
             mods = [m for m in mods if not (m.weight.requires_grad or (getattr(m, "bias", None) is not None and m.bias.requires_grad))]
             kept = None
         else:
-            kept = self._plan if not self.replan else None
+            kept = plan if not self.replan else None
         if len(mods) < 2:
             return
         with torch.no_grad():
@@ -1596,7 +1646,7 @@ class LiveWeightBatch:
                 groups, hyper = _weight_batches(live)
                 biases = _bias_batches(live)
                 if not self.replan and not torch.is_grad_enabled():
-                    self._plan = (mods, groups, hyper, biases)
+                    self._plans[id(module)] = (mods, groups, hyper, biases)
             def stamp_bias(m, o):
                 m.__dict__["_live_bias"] = (o, m.bias._version, m.bias.data_ptr())
 
@@ -1674,11 +1724,10 @@ class GraphedForward:
     overwritten by the next call -- clone what must outlive it.  Inference only (captured under torch.no_grad); calibration
     (observers, SmoothQuant `calibrating`) and stochastic rounding with an implicit seed must be done before capture."""
 
-    def __init__(self, model: torch.nn.Module, *example_inputs: torch.Tensor, warmup: int = 3, batch_live_weights: bool = True):
+    def __init__(self, model: torch.nn.Module, *example_inputs: torch.Tensor, warmup: int = 3, batch_live_weights: bool = True,
+                 live_batch_max_bytes: Optional[int] = 1 << 30):
         if not example_inputs or not all(isinstance(t, torch.Tensor) and t.is_cuda for t in example_inputs):
             raise ValueError("GraphedForward: tensor inputs on the GPU required")
-        # un-folded weights: the sibling weights' chains as a few multi-tensor launches inside the captured forward (LiveWeightBatch)
-        self.live_batch = LiveWeightBatch(model) if batch_live_weights else None
         # calibration must precede capture: an enabled observer updates its running min / max IN PLACE (dmxq_group_minmax_accumulate) and a
         # calibrating SmoothQuant recomputes its scale -- captured, every replay would repeat that on the static input (ADVICE r3)
         from .cast import CastTo
@@ -1693,13 +1742,23 @@ class GraphedForward:
         dev = self.static_in[0].device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.no_grad(), torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):   # lazily created state (scores, allocator pools, rocBLAS workspaces) before the capture
-                model(*self.static_in)
-            torch.cuda.synchronize(dev)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=side):
-                self.static_out = model(*self.static_in)
+        # un-folded weights: the sibling weights' chains as a few multi-tensor launches inside the captured forward (LiveWeightBatch),
+        # installed AFTER the validation above and for the warm-up and the capture only (round 6): the user's model leaves
+        # this constructor without hooks, whether it returns or raises, and a scope's quantised copies are released when its forward
+        # ends (inside the capture that returns them to the graph's private pool, where the next scope's results reuse them)
+        live_batch = LiveWeightBatch(model, max_bytes=live_batch_max_bytes) if batch_live_weights else None
+        self.live_batch_scopes = len(live_batch.scopes) if live_batch is not None else 0
+        try:
+            with torch.no_grad(), torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):   # lazily created state (scores, allocator pools, rocBLAS workspaces) before the capture
+                    model(*self.static_in)
+                torch.cuda.synchronize(dev)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=side):
+                    self.static_out = model(*self.static_in)
+        finally:
+            if live_batch is not None:
+                live_batch.remove()
         torch.cuda.current_stream(dev).wait_stream(side)
 
     def __call__(self, *inputs: torch.Tensor):

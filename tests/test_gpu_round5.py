@@ -192,17 +192,29 @@ def test_live_weight_batch_equals_the_per_module_path(dmx, cuda, kind):
         want = model(x).clone()
         want_w = [l._weight_ro.clone() for l in model.layers]
         batch = dmx.nn.LiveWeightBatch(model)
+        seen = {}
+        # (the stamps live for the scope's forward only -- round 6 -- so they are looked at from INSIDE it: before the last layer runs)
+        def look(mod, args):
+            seen.update({i: (l.__dict__["_live_weight"][0], l.weight_hypernet(l.weight, dtype), l._weight_ro)
+                         for i, l in enumerate(model.layers) if "_live_weight" in l.__dict__})
+
+        probe = model.layers[-1].register_forward_pre_hook(look)
         got = model(x)
-        assert all("_live_weight" in l.__dict__ for l in model.layers), "every sibling weight should have been batched"
-        for l, w in zip(model.layers, want_w):   # (what Linear._forward asks for: the weight rounded to the input's dtype)
-            assert bits_equal(l.weight_hypernet(l.weight, dtype), w.to(dtype)) == 0
-            assert l._weight_ro.dtype == w.dtype and bits_equal(l._weight_ro, w) == 0
+        probe.remove()
+        assert sorted(seen) == list(range(len(model.layers))), "every sibling weight should have been batched"
+        for i, w in enumerate(want_w):   # (what Linear._forward asks for: the weight rounded to the input's dtype)
+            stamped, asked, ro = seen[i]
+            assert asked is stamped and bits_equal(asked, w.to(dtype)) == 0
+            assert ro.dtype == w.dtype and bits_equal(ro, w) == 0
         assert bits_equal(got, want) == 0
-        # a weight changed in place: the stamp (storage + version) no longer matches before the next forward's batch, and the next
-        # forward re-quantises everything -- the live semantics of the reference
-        model.layers[1].weight.mul_(1.5)     # (in place on the Parameter: a version bump, as an optimiser step makes)
-        stale = model.layers[1].__dict__["_live_weight"][0]
-        fresh = model.layers[1].weight_hypernet(model.layers[1].weight, dtype)   # NOT the stamped result: it belongs to the Parameter's previous version
+        # ... and are gone when it ends: nothing stale for a direct call of a submodule, no quantised copy held between forwards
+        assert not any("_live_weight" in l.__dict__ or "_live_bias" in l.__dict__ for l in model.layers)
+        # a weight changed in place (a version bump, as an optimiser step makes): the next forward re-quantises everything -- the live
+        # semantics of the reference -- and a stamp that belongs to the previous version is refused even inside a forward
+        stale = seen[1][0]
+        model.layers[1].weight.mul_(1.5)
+        model.layers[1].__dict__["_live_weight"] = (stale, model.layers[1].weight._version - 1, model.layers[1].weight.data_ptr(), dtype)
+        fresh = model.layers[1].weight_hypernet(model.layers[1].weight, dtype)   # NOT the stamped result
         assert "_live_weight" not in model.layers[1].__dict__ and bits_equal(fresh.to(dtype), stale) != 0
         batch.remove()
         want2 = model(x).clone()
@@ -210,14 +222,92 @@ def test_live_weight_batch_equals_the_per_module_path(dmx, cuda, kind):
         got2 = model(x)
         assert bits_equal(got2, want2) == 0 and bits_equal(got2, want) != 0
         batch.remove()
-        assert not any("_live_weight" in l.__dict__ for l in model.layers)
+        assert not any("_live_weight" in l.__dict__ for l in model.layers) and not model._forward_pre_hooks and not model._forward_hooks
         kept = dmx.nn.LiveWeightBatch(model, replan=False)     # the plan of the first forward serves the following ones
         assert bits_equal(model(x), want2) == 0 and kept._plan is not None and bits_equal(model(x), want2) == 0
         kept.remove()
         g = dmx.nn.GraphedForward(model, x)
-        assert g.live_batch is not None
+        assert g.live_batch_scopes == 1
+        assert not model._forward_pre_hooks and not model._forward_hooks     # installed for the capture only (round 6)
         assert bits_equal(g(x), want2) == 0
         assert bits_equal(g(x * 0.5), model(x * 0.5)) == 0
+        # a constructor that raises leaves no hook behind either
+        model.layers[0].input_casts.input_cast.enable_observer()
+        with pytest.raises(RuntimeError):
+            dmx.nn.GraphedForward(model, x)
+        model.layers[0].input_casts.input_cast.disable_observer()
+        assert not model._forward_pre_hooks and not model._forward_hooks
+
+
+def test_live_weight_stamps_do_not_outlive_the_forward(dmx, cuda):
+    """a stamp knows the Parameter's storage and version only.  After `root(x)`, a recalibrated scale (updated in place), a
+    new sparsifier score or a reconfigured format must show in ANY later call -- of the root, of a submodule, of `_weight_ro` -- and a
+    forward that raises must not leave stamps behind either.  Scopes: a budget smaller than the model batches layer by layer."""
+    model = _Stack(dmx, [768, 768, 3072, 768], F32).to(cuda).eval()
+    _configure_basic(dmx, model)
+    hp = dmx.nn.DmxModuleQuantizerCalibrationHyperparams(weight=dmx.nn.DmxQuantizerCalibrationHyperparams(
+        observer_cls=dmx.MinMaxObserver, qscheme_to_overload=torch.per_tensor_symmetric, group_size=128, ch_axis=0))
+    for l in model.layers:
+        l.configure(dict(weight_format=dmx.format.INT8))
+        with l.calibrating_quantizers(hp), torch.no_grad():
+            l._weight
+    x = make("normal", (4, 768), seed=1700).to(cuda)
+    with torch.no_grad():
+        batch = dmx.nn.LiveWeightBatch(model)
+        assert batch.scopes == [model]
+        y0 = model(x).clone()
+        l1 = model.layers[1]
+        before = l1._weight_ro.clone()
+        l1.weight_cast.scale.mul_(2.0)          # recalibration updates the buffer in place: the Parameter's version does not move
+        after = l1._weight_ro
+        assert bits_equal(after, before) != 0 and bits_equal(after, l1.weight_cast(l1.weight)) == 0
+        h = model.layers[0](x)
+        direct = l1(h).clone()                  # a direct call of the submodule: its own chain, with the new scale
+        y1 = model(x)
+        assert bits_equal(y1, y0) != 0
+        batch.remove()
+        assert bits_equal(model(x), y1) == 0      # batched forward == per-module forward after the change
+        assert bits_equal(l1(h), direct) == 0
+        # a forward that raises: always_call releases the stamps
+        batch = dmx.nn.LiveWeightBatch(model)
+        def explode(mod, a):
+            raise ValueError("boom")
+
+        boom = model.layers[-1].register_forward_pre_hook(explode)
+        with pytest.raises(ValueError):
+            model(x)
+        boom.remove()
+        assert not any("_live_weight" in l.__dict__ or "_live_bias" in l.__dict__ for l in model.layers)
+        batch.remove()
+
+        # scopes by weight budget: two blocks of two layers each; a budget below the model's weights batches block by block
+        class Blocks(torch.nn.Module):
+            def __init__(self, a, b):
+                super().__init__()
+                self.blocks = torch.nn.ModuleList([torch.nn.Sequential(*a), torch.nn.Sequential(*b)])
+
+            def forward(self, t):
+                for blk in self.blocks:
+                    t = blk(t)
+                return t
+
+        m2 = _Stack(dmx, [768, 768, 768, 768, 768], F32).to(cuda).eval()
+        _configure_basic(dmx, m2)
+        big = Blocks(list(m2.layers[:2]), list(m2.layers[2:]))
+        want = big(x).clone()
+        per_block = 2 * 768 * 768 * 4
+        b2 = dmx.nn.LiveWeightBatch(big, max_bytes=per_block)
+        assert b2.scopes == list(big.blocks)
+        alive = []
+        def look(mod, a):
+            alive.append([("_live_weight" in l.__dict__) for l in m2.layers])
+
+        probe = m2.layers[3].register_forward_pre_hook(look)
+        assert bits_equal(big(x), want) == 0
+        probe.remove()
+        assert alive == [[False, False, True, True]]     # the first block's copies were released before the second block's were made
+        b2.remove()
+        assert dmx.nn.LiveWeightBatch(big, max_bytes=None).scopes == [big]
 
 
 # ------------------------------------------------------------------------------------------------ x / s through the reciprocal
@@ -372,22 +462,33 @@ def test_live_weight_batch_also_batches_the_bias_casts(dmx, cuda):
         want_b = [l.bias_cast(l.bias).clone() for l in model.layers]
         want = model(x).clone()
         batch = dmx.nn.LiveWeightBatch(model)
+        seen = {}
+        # (stamps live for the forward only -- round 6: looked at from inside it, before the last layer runs)
+        def look(mod, args):
+            seen.clear()
+            seen.update({i: (l.__dict__["_live_bias"][0], l._bias_ro) for i, l in enumerate(model.layers) if "_live_bias" in l.__dict__})
+
+        probe = model.layers[-1].register_forward_pre_hook(look)
         got = model(x)
-        assert "_live_bias" not in model.layers[0].__dict__ and all("_live_bias" in l.__dict__ for l in model.layers[1:])
-        for l, b in zip(model.layers, want_b):
+        assert sorted(seen) == [1, 2]
+        for i, b in enumerate(want_b):
+            l = model.layers[i]
+            if i in seen:
+                assert seen[i][1] is seen[i][0] and bits_equal(seen[i][0], b) == 0
             assert bits_equal(l._bias_ro, b) == 0 and bits_equal(b, l.bias) != 0
         assert bits_equal(got, want) == 0
+        assert not any("_live_bias" in l.__dict__ for l in model.layers)
         model.layers[1].bias.add_(0.37)
-        assert bits_equal(model.layers[1]._bias_ro, model.layers[1].bias_cast(model.layers[1].bias)) == 0 and "_live_bias" not in model.layers[1].__dict__
         ref2 = [l.bias_cast(l.bias).clone() for l in model.layers]
         model(x)
-        assert all(bits_equal(l.__dict__["_live_bias"][0], b) == 0 for l, b in zip(model.layers[1:], ref2[1:]))
+        assert sorted(seen) == [1, 2] and all(bits_equal(seen[i][0], ref2[i]) == 0 for i in seen)
         # BFP32_1 on every module (the BASIC configuration): one group of three
         for l in model.layers:
             l.configure(dict(bias_format="BFP[24|8]{1}(SN)"))
         ref3 = [l.bias_cast(l.bias).clone() for l in model.layers]
         model(x)
-        assert all(bits_equal(l.__dict__["_live_bias"][0], b) == 0 and bits_equal(b, l.bias) != 0 for l, b in zip(model.layers, ref3))
+        assert sorted(seen) == [0, 1, 2] and all(bits_equal(seen[i][0], b) == 0 and bits_equal(b, model.layers[i].bias) != 0 for i, b in enumerate(ref3))
+        probe.remove()
         batch.remove()
         assert not any("_live_bias" in l.__dict__ for l in model.layers)
 
