@@ -6,6 +6,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/dmxq.h"
 
@@ -495,9 +497,41 @@ __device__ __forceinline__ T load_uniform_const(const T* p) {
 //     16 for the other symmetric same-dtype builds): between 20 and 36 MiB ONE round of <= 256 workgroups with exactly the depth
 //     that takes -- see below.  Needed the partial last
 //     tile on the same schedule as a full one first (bfp_rows_tile_partial): run vector by vector it made every such plan erratic.
+// Compute units of the device the plans are made for (round 6).  Every size class below was measured on the 256 CUs of an
+// MI355X in SPX mode and is, at bottom, a statement about WORK PER CU ("the whole tensor in one round of <= 2 workgroups per CU"): the
+// classes are therefore kept in units of 1/256 of the chip and scaled by the device's own count -- a partition (CPX: 32 CUs) or another
+// part of the family gets plans with the same per-CU shape instead of plans that silently assume 256 -- and a count other than 256 says
+// so once on stderr, because nothing was MEASURED there.  No device (the GPU-less build container: dmxq_bfp_qdq_describe, argument
+// checks): 256.  DMXQ_PLAN_CUS overrides (tests).
+inline int plan_cus() {
+  static const int cus = [] {
+    if (const char* e = getenv("DMXQ_PLAN_CUS")) {
+      const int v = atoi(e);
+      if (v > 0) return v;
+    }
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      return 256;
+    }
+    if (n != 256)
+      fprintf(stderr, "[dmxq] this device reports %d compute units; the launch plans were tuned on 256 (MI355X, SPX) and are scaled to %d/256 of "
+                      "their size classes -- unmeasured geometry, results are unaffected\n", n, n);
+    return n;
+  }();
+  return cus;
+}
+// a size of THIS device's launch (lane-vectors, bytes) in the units the size classes were measured in: the same work per CU on 256 CUs
+inline int64_t plan_norm(int64_t size_here) {
+  const int cus = plan_cus();
+  return cus == 256 ? size_here : (size_here * 256 + cus - 1) / cus;
+}
+
 struct RowsPlan { int id, threads, unroll; int64_t tiles; };
-inline RowsPlan rows_plan(int64_t n_vec, bool allow_big, int max_depth = 0 /* exact-depth one-round plans up to this many vectors per lane */) {
-  auto mk = [&](int id, int t, int u) { return RowsPlan{id, t, u, (n_vec + (int64_t)t * u - 1) / ((int64_t)t * u)}; };
+inline RowsPlan rows_plan(int64_t n_vec_device, bool allow_big, int max_depth = 0 /* exact-depth one-round plans up to this many vectors per lane */) {
+  auto mk = [&](int id, int t, int u) { return RowsPlan{id, t, u, (n_vec_device + (int64_t)t * u - 1) / ((int64_t)t * u)}; };
+  // the classes below read in the units they were measured in: lane-vectors on 256 CUs
+  const int64_t n_vec = plan_norm(n_vec_device);
   if (n_vec <= ((int64_t)1 << 18)) return mk(0, 512, 1);
   // (round 4: 128 x 2 up to 14 MiB instead of 12 -- 1600 / 1792 rows of 4096 bf16: 58.7 / 61.2 % against 50.3 / 56.1 % for 512 x 4; at 1920
   //  rows 512 x 4 leads 61.0 to 55.9; exactly fitting one-round depths of 5 .. 8 vectors lose to both: tools/tune_bfp -DTUNE_SMALLFIT)
@@ -508,7 +542,7 @@ inline RowsPlan rows_plan(int64_t n_vec, bool allow_big, int max_depth = 0 /* ex
     //  512x16 and ~9.5 on 2560 rows against 7.98 for 128x8: 60 % -> 67-69 % of the roofline at 20-24 MiB)
     if (n_vec <= ((int64_t)5 << 18)) return mk(3, 128, 8);
     if (max_depth >= 11) {
-      // the depth that fills ONE round of 256 workgroups: U = ceil(n_vec / (256 x 512)) for 11 .. 20 (19 / 20: the compact kernel,
+      // the depth that fills ONE round of one workgroup per CU (256 on the MI355X): U = ceil(n_vec / (256 x 512)) for 11 .. 20 (19 / 20: the compact kernel,
       // bfp_rows_compact_kernel); id = 100 + U.  Against 512 x 16
       // below 32 MiB: +4 .. +9 points at 2688 - 3584 rows of 4096 bf16 (192 - 224 of 256 CUs busy there), +1 at 3840; against 512 x 2
       // above: +5 .. +10 at 4100 - 4608 rows (profiles/r04_tune_bfp_oneround.txt, r04_mid_shapes.txt).  19+ vectors spill in

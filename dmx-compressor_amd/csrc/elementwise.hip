@@ -1034,5 +1034,5 @@ extern "C" const char* dmxq_status_string(int status) {
   return "unknown status";
 }
 
-extern "C" int dmxq_abi_version(void) { return 3; }  // 3: + dmxq_weight_hypernet_multi, dmxq_unary_cast_table, dmxq_lut16_apply (additive)
+extern "C" int dmxq_abi_version(void) { return 4; }  // 4: + dmxq_float_qdq_multi, dmxq_fixed_float_qdq_multi (round 5, additive); 3: + dmxq_weight_hypernet_multi, dmxq_unary_cast_table, dmxq_lut16_apply
 #endif  // part 1b

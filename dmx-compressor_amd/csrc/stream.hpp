@@ -271,6 +271,7 @@ static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hip
     // 16-bit -> float32 on aligned tensors: lane-vectors of 4 elements (8 bytes in, 16 out), the geometry rule applied to the OUTPUT bytes
     if (aligned16(in) && aligned16(out)) {
       const int64_t nv = n / 4;
+      const int64_t nvc = plan_norm(nv);   // (size classes: measured on 256 CUs, common.hpp plan_cus)
 #define DMXQ_STREAM8(T_, U_)                                                                                           \
   do {                                                                                                                 \
     int64_t tiles = (nv + (int64_t)(T_) * (U_) - 1) / ((int64_t)(T_) * (U_));                                          \
@@ -278,9 +279,9 @@ static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hip
     if (tiles > (1 << 20)) tiles = 1 << 20;                                                                            \
     DMXQ_LAUNCH((stream_kernel<DTI, DTO, U_, T_, OP, false, 8>), dim3((unsigned)tiles), dim3(T_), 0, s, in, out, n, op); \
   } while (0)
-      if (nv <= ((int64_t)1 << 17)) DMXQ_STREAM8(256, 1);
-      else if (nv <= ((int64_t)3 << 18)) DMXQ_STREAM8(256, 2);
-      else if (nv <= ((int64_t)1 << 21)) DMXQ_STREAM8(256, 4);
+      if (nvc <= ((int64_t)1 << 17)) DMXQ_STREAM8(256, 1);
+      else if (nvc <= ((int64_t)3 << 18)) DMXQ_STREAM8(256, 2);
+      else if (nvc <= ((int64_t)1 << 21)) DMXQ_STREAM8(256, 4);
       else DMXQ_STREAM8(256, 2);
 #undef DMXQ_STREAM8
       return launch_status();
@@ -306,10 +307,11 @@ static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hip
     if (tiles > (1 << 20)) tiles = 1 << 20;                                                                       \
     DMXQ_LAUNCH((stream_kernel<DTI, DTO, U_, T_, OP>), dim3((unsigned)tiles), dim3(T_), 0, s, in, out, n, op); \
   } while (0)
-  if (n_vec <= ((int64_t)1 << 17)) DMXQ_STREAM(256, 1);
-  else if (n_vec <= ((int64_t)3 << 18)) DMXQ_STREAM(256, 2);
-  else if (n_vec <= ((int64_t)5 << 18)) DMXQ_STREAM(256, 4);
-  else if (n_vec <= ((int64_t)1 << 21)) {
+  const int64_t nvc = plan_norm(n_vec);   // (size classes: measured on 256 CUs, common.hpp plan_cus)
+  if (nvc <= ((int64_t)1 << 17)) DMXQ_STREAM(256, 1);
+  else if (nvc <= ((int64_t)3 << 18)) DMXQ_STREAM(256, 2);
+  else if (nvc <= ((int64_t)5 << 18)) DMXQ_STREAM(256, 4);
+  else if (nvc <= ((int64_t)1 << 21)) {
     // the op's own geometry, with the op's own pace between a wave's loads (common.hpp OpLoadPace; 0 for most ops)
 #ifdef DMXQ_EXP_STREAM_PACE
     constexpr int kPace = DMXQ_EXP_STREAM_PACE;
@@ -398,6 +400,7 @@ static int launch_stream_multi2(StreamMulti2Args<OPA, OPB>& a, hipStream_t s) {
   for (int i = 0; i < a.nA; i++) total += a.a[i].n_vec;
   for (int i = 0; i < a.nB; i++) total += a.b[i].n_vec;
   if (total > ((int64_t)1 << 21)) return DMXQ_ERR_UNSUPPORTED;   // (beyond 32 MiB: two launches cost nothing there)
+  const int64_t totalc = plan_norm(total);
 #define DMXQ_STREAM_MULTI2(T_, U_)                                                                                    \
   do {                                                                                                                \
     int64_t tiles = 0;                                                                                                \
@@ -415,12 +418,12 @@ static int launch_stream_multi2(StreamMulti2Args<OPA, OPB>& a, hipStream_t s) {
     DMXQ_LAUNCH((stream_multi2_kernel<DTI, DTO, U_, UB, T_, OPA, OPB, false>), dim3((unsigned)tiles), dim3(T_), 0, s, e[0], e[1], e[2], e[3], \
                 e[4], e[5], e[6], e[7], e[8], e[9], a.nA, a);                                                         \
   } while (0)
-  if (total <= ((int64_t)1 << 17)) {
+  if (totalc <= ((int64_t)1 << 17)) {
     DMXQ_STREAM_MULTI2(256, 1);
   } else if constexpr (Elem<DTI>::bytes == 2) {
     DMXQ_STREAM_MULTI2(256, 4);   // (16-bit: the two bodies together spill at 128 x 16 -- 3.4 KiB of scratch per lane; build.py NO_SCRATCH guards the rest)
   } else {
-    if (total <= ((int64_t)5 << 18)) DMXQ_STREAM_MULTI2(256, 4);
+    if (totalc <= ((int64_t)5 << 18)) DMXQ_STREAM_MULTI2(256, 4);
     else DMXQ_STREAM_MULTI2(TT, TU);
   }
 #undef DMXQ_STREAM_MULTI2
@@ -446,9 +449,10 @@ static int launch_stream_multi(StreamMultiArgs<OP>& a, hipStream_t s) {
     DMXQ_LAUNCH((stream_multi_kernel<DTI, DTO, U_, T_, OP, N_>), dim3((unsigned)tiles), dim3(T_), 0, s, e[0], e[1], e[2], e[3], e[4], e[5], \
                 e[6], e[7], e[8], e[9], a.n, a);                                                                     \
   } while (0)
-  if (total <= ((int64_t)1 << 17)) DMXQ_STREAM_MULTI(256, 1, false);
-  else if (total <= ((int64_t)5 << 18)) DMXQ_STREAM_MULTI(256, 4, false);
-  else if (total <= ((int64_t)1 << 21)) DMXQ_STREAM_MULTI(TT, TU, false);
+  const int64_t totalc = plan_norm(total);
+  if (totalc <= ((int64_t)1 << 17)) DMXQ_STREAM_MULTI(256, 1, false);
+  else if (totalc <= ((int64_t)5 << 18)) DMXQ_STREAM_MULTI(256, 4, false);
+  else if (totalc <= ((int64_t)1 << 21)) DMXQ_STREAM_MULTI(TT, TU, false);
   else DMXQ_STREAM_MULTI(256, 2, true);
 #undef DMXQ_STREAM_MULTI
   return launch_status();

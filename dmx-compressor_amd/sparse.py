@@ -197,7 +197,7 @@ class Sparsify(torch.nn.Module):
 
     def __init__(self, tensor_shape, sparseness="DENSE", backward_mode="STE", score_func=None):
         super().__init__()
-        self.mask, self.plastic = None, False
+        self._mask, self._mask_pending, self.plastic = None, True, False
         self.score = torch.nn.Parameter(torch.rand(tensor_shape), requires_grad=True)   # uniform-random until trained / assigned
         self._set_sparseness(sparseness)
         self._set_backward_mode(backward_mode)
@@ -225,6 +225,24 @@ class Sparsify(torch.nn.Module):
 
     def update_mask(self, score):
         self.mask = self.sparseness.get_mask(score)
+
+    @property
+    def mask(self):
+        """The reference's constructor ends with `update_mask(self.score)` (sparse.py:260-262): a freshly built Sparsify HAS the mask of
+        its initial score before any forward.  Here that first mask is computed when it is first READ, from the score as it is then: the
+        mask kernels run on the GPU only and the constructor's score lives on the host (a constructor-time launch would copy every
+        score of a model to the device and back for a mask most callers never look at; Llama-3-8B: 7 G elements).  A score that sits on
+        the host is masked on the device and the mask returned to the score's device."""
+        if self._mask is None and self._mask_pending:
+            sc = self.score.detach()
+            on = sc if sc.is_cuda else sc.to("cuda")
+            m = self.sparseness.get_mask(on)
+            self._mask, self._mask_pending = (None if m is None else m.to(sc.device)), False
+        return self._mask
+
+    @mask.setter
+    def mask(self, m):
+        self._mask, self._mask_pending = m, False
 
     @property
     def density(self):

@@ -48,7 +48,8 @@ typedef enum {
 } dmxq_status;
 
 const char* dmxq_status_string(int status);
-/* ABI version: bumped on any signature change or addition (3 = round 4: + dmxq_weight_hypernet_multi, dmxq_unary_cast_table, dmxq_lut16_apply; nothing removed or changed). */
+/* ABI version: bumped on any signature change or addition.  4 = round 5: + dmxq_float_qdq_multi, dmxq_fixed_float_qdq_multi; 3 = round 4: + dmxq_weight_hypernet_multi,
+ * dmxq_unary_cast_table, dmxq_lut16_apply.  Nothing was ever removed or changed: a caller built against version n runs on any library >= n. */
 int dmxq_abi_version(void);
 
 /* Block floating point Q->DQ ("BFP[p|8]{B}", MXINT).

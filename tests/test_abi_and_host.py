@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(dmx):
         assert hasattr(L, name), f"libdmxq.so does not export {name}"
     # the ctypes table covers the whole header (minus the two helpers bound separately)
     assert declared - {"dmxq_status_string", "dmxq_abi_version"} == set(dmx._lib.SIGNATURES)
-    assert L.dmxq_abi_version() == 3
+    assert L.dmxq_abi_version() == 4
     assert L.dmxq_status_string(0) == b"ok" and b"bad" in L.dmxq_status_string(1)
 
 

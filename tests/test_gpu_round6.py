@@ -108,3 +108,19 @@ def test_scale_channels_in_place_with_special_values(dmx, cuda, dtype):
             assert mismatches_nan_aware(o, want) == 0, (ch_axis, divide)
             assert L.dmxq_scale_channels(vp(t.data_ptr()), vp(t.data_ptr()), code, code, outer, Cc, inner, vp(sqd.data_ptr()), divide, s) == 0
             assert bits_equal(t, o) == 0, (ch_axis, divide)
+
+
+def test_sparsify_has_the_mask_of_its_initial_score(dmx, cuda, oracle):
+    """sparse.py:260-262: the reference's constructor computes the first mask; the mirror computes it when first read (the kernels run
+    on the GPU only), on the score's own device, and a forward replaces it"""
+    torch.manual_seed(3)
+    sp = dmx.sparse.Sparsify((16, 64), sparseness="BTOPK{2:4,-1}(U)")
+    m = sp.mask
+    assert m is not None and m.device == sp.score.device and bits_equal(m, oracle.nm_mask(sp.score.detach(), 2, 4)) == 0
+    assert sp.mask is m                                   # computed once
+    sp = dmx.sparse.Sparsify((16, 64), sparseness="BTOPK{4:8,-1}(U)").to(cuda)
+    assert bits_equal(sp.mask, oracle.nm_mask(sp.score.detach().cpu(), 4, 8)) == 0
+    x = make("normal", (16, 64), seed=9).to(cuda)
+    y = sp(x)
+    assert bits_equal(y, oracle.sparsify(x.cpu(), sp.score.detach().cpu(), 4, 8)) == 0 and sp.mask is not None
+    assert dmx.sparse.Sparsify((4, 4)).mask is None       # DENSE: nothing to mask
