@@ -14,7 +14,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libdmxq.so")
 TORCH_LIB = os.path.join(HERE, "lib", "dmxq_torch.so")
 # "file.hip" or "file.hip#N": the file compiled with -DDMXQ_EW_PART=N into file_pN.o (elementwise.hip: three objects, approx.hip: two, in parallel)
-SOURCES = ["bfp.hip#1", "approx.hip#3", "approx.hip#5", "approx.hip#1", "approx.hip#2", "approx.hip#4", "elementwise.hip#2", "elementwise.hip#1", "elementwise.hip#3", "bfp_cols.hip#1", "bfp_cols.hip#2", "bfp_cols.hip#3", "bfp.hip#2", "bfp.hip#3", "bfp_urows.hip", "bfp_smallinner.hip", "blockfmt.hip", "bfp_pack.hip", "hypernet.hip", "hypernet_multi.hip", "nm_mask.hip", "topk.hip", "reduce.hip", "unary.hip", "act_cast.hip", "lut16.hip", "fixed_multi.hip", "rope.hip"]
+SOURCES = ["bfp.hip#1", "approx.hip#3", "approx.hip#5", "approx.hip#1", "approx.hip#2", "approx.hip#4", "elementwise.hip#2", "elementwise.hip#1", "elementwise.hip#3", "bfp_cols.hip#1", "bfp_cols.hip#2", "bfp_cols.hip#3", "bfp.hip#2", "bfp.hip#3", "bfp_urows.hip", "bfp_smallinner.hip", "bfp_slab.hip", "blockfmt.hip", "bfp_pack.hip", "hypernet.hip", "hypernet_multi.hip", "nm_mask.hip", "topk.hip", "reduce.hip", "unary.hip", "act_cast.hip", "lut16.hip", "fixed_multi.hip", "rope.hip"]
 # bit-exact fp32: no fast-math, no fma contraction; fp32 denormals stay on (gfx950 default).
 # --offload-compress (round 5): the gfx950 code objects are stored zstd-compressed inside the fat binary and unpacked by the HIP runtime at
 # load: libdmxq.so 88 MB -> 17 MB (what a gpurun snapshot pushes, what a wheel would ship), load time and kernels unchanged

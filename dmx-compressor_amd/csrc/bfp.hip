@@ -195,6 +195,18 @@ static int dispatch_mode(const void* in, void* out, int64_t outer, int64_t L, in
 
 }  // namespace dmxq
 
+// Which strided-block tensors take the LDS slab kernel (bfp_slab.hip) instead of the register-tiled column kernel (bfp_cols.hip).
+// DMXQ_SLAB=0 / 1 overrides (A/B runs): never / whenever the kernel applies.
+static bool slab_preferred(int dtype_in, int64_t L, int64_t inner, int64_t B) {
+  static const int forced = [] { const char* e = getenv("DMXQ_SLAB"); return e ? atoi(e) : -1; }();
+  if (forced >= 0) return forced != 0;
+  (void)dtype_in; (void)L;
+  // rows that are NOT whole 128-byte lines (14 x 14, 28 x 28 maps: the column kernel's row pieces share their first and last line with the
+  // neighbouring piece, 50 % of the roofline) and slabs of at least 16 KiB (smaller tiles are all overhead: [8, 12, 1500, 64] along the
+  // sequence 38 % here, 54 % there).  Whole-line rows stay with the column kernel (56 x 56: 69 %; profiles/r06_slab_ab3.txt).
+  return (inner * 2) % 128 != 0 && B * inner * 2 >= 16 * 1024;
+}
+
 extern "C" int dmxq_float_qdq(const void* in, void* out, int dtype_in, int dtype_out, int64_t n, int man_bits,
                               int exp_bits, int exp_bias, int flush_subnormal, int unsigned_abs, int rounding,
                               uint64_t seed, void* stream);
@@ -208,6 +220,9 @@ extern "C" int dmxq_internal_bfp_cols(const void* in, void* out, int dtype_in, i
 
 extern "C" int dmxq_internal_bfp_smallinner(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L,
                                             int64_t inner, int64_t B, int wl, int rounding, int symmetric, void* stream);
+// bfp_slab.hip (round 6): [B rows x inner] slabs / column tiles through the LDS for feature-map sized inner extents
+extern "C" int dmxq_internal_bfp_slab(const void* in, void* out, int dtype_in, int dtype_out, int64_t outer, int64_t L, int64_t inner,
+                                      int64_t B, int wl, int rounding, int symmetric, void* stream);
 
 // parts 2 / 3: the flat-stream / generic dispatch of the other dtype pairs
 extern "C" int dmxq_internal_bfp_flat_f32(const void* in, void* out, int dtype_out, int64_t outer, int64_t L, int64_t inner, int64_t block_size,
@@ -271,6 +286,10 @@ extern "C" int dmxq_bfp_qdq(const void* in, void* out, int dtype_in, int dtype_o
   if (inner > 1 && inner < 64) {  // a few elements between the members of a block: sub-slabs through the LDS (bfp_smallinner.hip)
     const int rc = dmxq_internal_bfp_smallinner(in, out, dtype_in, dtype_out, outer, L, inner, block_size, precision, rounding, symmetric,
                                                 stream);
+    if (rc != DMXQ_ERR_UNSUPPORTED) return rc;
+  }
+  if (inner >= 64 && slab_preferred(dtype_in, L, inner, block_size)) {
+    const int rc = dmxq_internal_bfp_slab(in, out, dtype_in, dtype_out, outer, L, inner, block_size, precision, rounding, symmetric, stream);
     if (rc != DMXQ_ERR_UNSUPPORTED) return rc;
   }
   if (inner > 1) {
@@ -408,7 +427,9 @@ extern "C" int dmxq_bfp_qdq_describe(int dtype_in, int dtype_out, int64_t outer,
              pl.threads, pl.unroll, (long long)grid);
     return DMXQ_OK;
   }
-  snprintf(buf, (size_t)buf_len, "%s", inner == 1 ? "dmxq::bfp_urows_kernel (ragged / unaligned rows)" : "dmxq::bfp_cols_kernel or bfp_generic_kernel (blocks along a strided dim)");
+  snprintf(buf, (size_t)buf_len, "%s", inner == 1 ? "dmxq::bfp_urows_kernel (ragged / unaligned rows)"
+                                                  : "dmxq::bfp_slab_kernel (rows that are not whole lines, through the LDS), bfp_smallinner_kernel, bfp_cols_kernel or "
+                                                    "bfp_generic_kernel (blocks along a strided dim)");
   return DMXQ_OK;
 }
 #endif  // DMXQ_BP(1)

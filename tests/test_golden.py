@@ -428,14 +428,16 @@ def test_chunked_generator_equals_make():
 
 def test_c2_oracle_reproduces_the_reference_digests(oracle):
     """tests/golden/c2_digests.json (oracle/gen_golden_r4.py): SHA-256 of the reference's CastTo("BFP[8|8]{16}(SN)") output on the
-    counter-generated 4096 x 4096 bf16 tensors.  The oracle must reproduce them (two of the 44 here: seconds, not minutes)."""
+    counter-generated 4096 x 4096 bf16 tensors, 20 rotation slots for each of the eight ranks of the scaling run (round 6; ranks 0 / 1 since
+    round 4).  The oracle must reproduce them (three of the 164 here: seconds, not minutes)."""
     import json
 
     from _data import make_chunked, sha256_bits
 
     g = json.load(open(os.path.join(GOLD, "c2_digests.json")))
-    assert g["format"] == "BFP[8|8]{16}(SN)" and g["shape"] == [4096, 4096] and len(g["slots"]) == 40 and len(g["kinds"]) == 4
-    for key, kind, seed in (("kinds", "normal", 0), ("slots", "heavy", 1007)):
+    assert g["format"] == "BFP[8|8]{16}(SN)" and g["shape"] == [4096, 4096] and len(g["slots"]) == 160 and len(g["kinds"]) == 4
+    assert sorted(int(k) for k in g["slots"]) == [1000 * r + s for r in range(8) for s in range(20)]
+    for key, kind, seed in (("kinds", "normal", 0), ("slots", "heavy", 1007), ("slots", "heavy", 7019)):
         e = g[key][kind if key == "kinds" else str(seed)]
         x = make_chunked(kind, (4096, 4096), seed, torch.bfloat16)
         assert sha256_bits(x) == e["input_sha256"]

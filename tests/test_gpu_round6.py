@@ -124,3 +124,54 @@ def test_sparsify_has_the_mask_of_its_initial_score(dmx, cuda, oracle):
     y = sp(x)
     assert bits_equal(y, oracle.sparsify(x.cpu(), sp.score.detach().cpu(), 4, 8)) == 0 and sp.mask is not None
     assert dmx.sparse.Sparsify((4, 4)).mask is None       # DENSE: nothing to mask
+
+
+# ------------------------------------------------------------------------------------------------ bfp_slab.hip (LDS slabs / column tiles)
+SLAB_CASES = [
+    # shape, block_dim, B                      what it selects in csrc/bfp_slab.hip
+    ((4, 128, 14, 14), 1, 64),               # FLAT: rows of 392 bytes (not whole vectors), one contiguous slab per tile
+    ((2, 192, 14, 14), 1, 128),              # FLAT, 32 rows per lane, ragged last block (192 = 128 + 64)
+    ((3, 100, 14, 14), 1, 64),               # FLAT with a ragged last block of 36 rows
+    ((2, 128, 28, 28), 1, 64),               # SEGMENTED: two column tiles of 392
+    ((2, 64, 56, 56), 1, 64),                # SEGMENTED: eight column tiles
+    ((2, 48, 28, 28), 1, 16),                # B = 16: two lanes per column pair
+    ((2, 40, 28, 28), 1, 8),                 # B = 8: one lane per column pair
+    ((2, 96, 28, 28), 1, 32),
+    ((1, 512, 18, 18), 1, 256),              # B = 256: 64 rows per lane
+    ((2, 3, 224, 224), 1, 64),               # L = 3 < B / 2: one ragged block of three rows, B reduced to 8
+    ((2, 64, 10, 10), 1, 64),                # inner = 100
+    ((2, 64, 15, 15), 1, 64),                # odd inner: NOT the slab kernel (column kernel, unaligned form) -- same results
+    ((2, 12, 200, 64), -2, 64),              # attention operands blocked along the sequence: inner = 64
+    ((8, 1500, 64), -2, 64),                 # ... with a ragged last block (1500 = 23 x 64 + 28)
+]
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("shape,dim,B", SLAB_CASES)
+def test_bfp_slab_kernel_vs_oracle(dmx, cuda, oracle, dtype, shape, dim, B):
+    """blocks along a strided dim through the LDS slab kernel: heavy-tailed data with special blocks (all zero, denormal maximum, Inf,
+    NaN, huge maximum: the literal path), symmetric and asymmetric, two precisions (single / double rounding builds), in place"""
+    x = make("heavy", shape, seed=B + shape[1], dtype=dtype)
+    flat = x.reshape(-1)
+    n = flat.numel()
+    xs = x.clone()
+    view = xs.transpose(dim, -1)
+    view[0, ..., : min(B, view.shape[-1])] = 0.0                    # an all-zero block per column of the first outer index
+    flat = xs.reshape(-1)
+    flat[n // 3] = float("inf")
+    flat[n // 3 + 7] = float("nan")
+    flat[n // 2] = 3.0e38 if dtype == BF16 else 65504.0
+    flat[n // 2 + 1] = -(3.0e38 if dtype == BF16 else 65504.0)
+    flat[5::997] = flat[5::997] * 0 + (1e-40 if dtype == BF16 else 6e-8)     # denormal elements
+    for wl, sym in ((8, True), (8, False), (16, True), (4, False)):
+        want = oracle.bfp_cast(xs, wl, B, dim, sym).to(dtype)
+        got = dmx.ops.bfp_qdq(xs.to(cuda), wl, B, dim, sym)
+        assert mismatches_nan_aware(got, want) == 0, (shape, dim, B, wl, sym)
+    # in place through the C ABI
+    from dmx_compressor_amd import _lib
+    L = _lib.lib()
+    t = xs.to(cuda).contiguous()
+    outer, Ld, inner = _lib.split3(t.shape, dim)
+    code = _lib.dtype_code(dtype)
+    assert L.dmxq_bfp_qdq(vp(t.data_ptr()), vp(t.data_ptr()), code, code, outer, Ld, inner, B, 8, 2, 1, 0, vp(torch.cuda.current_stream().cuda_stream)) == 0
+    assert mismatches_nan_aware(t, oracle.bfp_cast(xs, 8, B, dim, True).to(dtype)) == 0
