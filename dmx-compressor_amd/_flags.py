@@ -10,7 +10,30 @@ Code that pokes a buffer directly must call `refresh_flags()` afterwards; `load_
 """
 
 
-class HostFlags:
+class FastAttr:
+    """nn.Module.__getattr__ -- what every `self.weight_cast`, `self.smoothquant`, `self.scale` costs, because submodules, parameters and
+    buffers live in three dicts outside `__dict__` -- restated for the lookups this package makes ~260 times per forward of a decoder
+    layer (round 6: 70 of 1030 profiled microseconds, profiles/r06_eager_profile_opt125m.txt): the three dicts straight from
+    `__dict__`, submodules first (the commonest miss), the same AttributeError at the end.  Same lookup rule, nothing cached."""
+
+    def __getattr__(self, name):
+        d = self.__dict__
+        try:
+            m = d["_modules"]
+            if name in m:
+                return m[name]
+            m = d["_parameters"]
+            if name in m:
+                return m[name]
+            m = d["_buffers"]
+            if name in m:
+                return m[name]
+        except KeyError:   # (before nn.Module.__init__ ran)
+            pass
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+
+
+class HostFlags(FastAttr):
     _flag_names = ()
     #: zero-dim float buffers mirrored the same way (SmoothQuant's `migration_strength`, `scale_min`: read with `float(...)` in every
     #: calibration / dynamic forward -- a device->host copy and a stream drain each once the module is on the GPU, and not capturable)

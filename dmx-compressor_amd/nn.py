@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from .approximate import Approximate, NoApproximation
 from .cast import CastTo, CastToDict
+from ._flags import FastAttr
 from .format import Same
 from .smoothquant import ActivationWeightSmoothQuant
 from .sparse import Dense, Sparsify
@@ -100,7 +101,7 @@ def _aliases_any(out, inputs, module) -> bool:
     return False
 
 
-class DmxModule(torch.nn.Module):
+class DmxModule(FastAttr, torch.nn.Module):
     """Mixin base: call `_dmx_init()` after the torch module's own __init__ (see the concrete classes)."""
 
     functional_forward = None
@@ -1725,15 +1726,31 @@ class GraphedForward:
     (observers, SmoothQuant `calibrating`) and stochastic rounding with an implicit seed must be done before capture."""
 
     def __init__(self, model: torch.nn.Module, *example_inputs: torch.Tensor, warmup: int = 3, batch_live_weights: bool = True,
-                 live_batch_max_bytes: Optional[int] = 1 << 30):
+                 live_batch_max_bytes: Optional[int] = 1 << 30, calibrating: bool = False):
+        """calibrating: capture a forward whose MinMax observers are ENABLED (round 6).  An observer step is then part of the graph --
+        `dmxq_group_minmax_accumulate` folds the batch's extrema into the running `min_val` / `max_val` IN PLACE, `dmxq_qparams` derives
+        scale and zero point, and they are copied into the cast's persistent buffers: three launches, no host read -- so every replay
+        `g(batch)` is one calibration step on that batch, with the observer state of the same steps run eagerly, bit for bit
+        (numerical/cast.py:179-226, numerical/observer.py:173-193).  The warm-up forwards observe the example input (a running min / max
+        is idempotent under repeats, but it must be a batch the calibration may see).  Only MinMax observers without a process group:
+        a HistogramObserver searches its thresholds on the host, a sharded exchange is a collective.  Default False: an enabled
+        observer in a model that is captured for inference is a mistake and is refused."""
         if not example_inputs or not all(isinstance(t, torch.Tensor) and t.is_cuda for t in example_inputs):
             raise ValueError("GraphedForward: tensor inputs on the GPU required")
-        # calibration must precede capture: an enabled observer updates its running min / max IN PLACE (dmxq_group_minmax_accumulate) and a
-        # calibrating SmoothQuant recomputes its scale -- captured, every replay would repeat that on the static input (ADVICE r3)
+        # calibration must precede an INFERENCE capture: an enabled observer updates its running min / max IN PLACE and a calibrating
+        # SmoothQuant recomputes its scale -- captured, every replay would repeat that on the static input (ADVICE r3)
         from .cast import CastTo
+        from .observer import DummyObserver, MinMaxObserver
         from .smoothquant import ActivationWeightSmoothQuant as SmoothQuant
         for name, mod in model.named_modules():
             if isinstance(mod, CastTo) and mod._flag("observer_enabled"):
+                obs = mod.activation_post_process
+                if calibrating and isinstance(obs, (MinMaxObserver, DummyObserver)) and getattr(obs, "process_group", None) is None:
+                    continue
+                if calibrating:
+                    raise RuntimeError(f"GraphedForward(calibrating=True): the observer of {name or 'the model'} is a {type(obs).__name__}"
+                                       f"{' with a process group' if getattr(obs, 'process_group', None) is not None else ''}; only MinMax "
+                                       "observers without a process group run without the host")
                 raise RuntimeError(f"GraphedForward: the observer of {name or 'the model'} is enabled; finish calibration (disable_observer) before capture")
             if isinstance(mod, SmoothQuant) and (getattr(mod, "calibrating", False) or mod._flag("dynamic")):
                 raise RuntimeError(f"GraphedForward: SmoothQuant of {name or 'the model'} is calibrating / dynamic; capture a frozen scale")

@@ -175,3 +175,53 @@ def test_bfp_slab_kernel_vs_oracle(dmx, cuda, oracle, dtype, shape, dim, B):
     code = _lib.dtype_code(dtype)
     assert L.dmxq_bfp_qdq(vp(t.data_ptr()), vp(t.data_ptr()), code, code, outer, Ld, inner, B, 8, 2, 1, 0, vp(torch.cuda.current_stream().cuda_stream)) == 0
     assert mismatches_nan_aware(t, oracle.bfp_cast(xs, 8, B, dim, True).to(dtype)) == 0
+
+
+# ------------------------------------------------------------------------------------------------ a calibrating forward as a hipGraph
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_graphed_forward_of_a_minmax_calibrating_linear(dmx, cuda, dtype):
+    """GraphedForward(calibrating=True): every replay is one MinMax observer step (numerical/cast.py:179-226) on the batch it was given.
+    After the same batches, the observer state and the qparams of the graphed copy equal the eagerly calibrated copy's bit for bit
+    (input cast: per tensor; weight cast: slabs of 128 rows), and so do the fake-quantised outputs afterwards."""
+    nn = dmx.nn
+
+    def make_linear():
+        m = nn.Linear(768, 3072, bias=True)
+        m.weight.data = (make("normal", (3072, 768), seed=31) * 0.05).to(dtype)
+        m.bias.data = (make("normal", (3072,), seed=32) * 0.02).to(dtype)
+        m = m.to(cuda).eval()
+        m.configure(dict(input_formats=[dmx.format.INT8], weight_format=dmx.format.INT8))
+        return m
+
+    hp = nn.DmxModuleQuantizerCalibrationHyperparams(
+        inputs={"input_cast": nn.DmxQuantizerCalibrationHyperparams(observer_cls=dmx.MinMaxObserver, qscheme_to_overload=torch.per_tensor_affine)},
+        weight=nn.DmxQuantizerCalibrationHyperparams(observer_cls=dmx.MinMaxObserver, qscheme_to_overload=torch.per_tensor_symmetric,
+                                                     group_size=128, ch_axis=0))
+    batches = [(make("heavy", (4, 64, 768), seed=40 + i).clamp(-50, 50) * (1 + i)).to(dtype).to(cuda) for i in range(4)]
+    eager, graphed = make_linear(), make_linear()
+    with torch.no_grad():
+        with eager.calibrating_quantizers(hp):
+            for b in batches:
+                eager(b)
+        with pytest.raises(RuntimeError):
+            graphed.enable_quantizer_calib(True, hp)
+            nn.GraphedForward(graphed, batches[0])                # an enabled observer without calibrating=True: refused
+        g = nn.GraphedForward(graphed, batches[0], calibrating=True, warmup=2)
+        for b in batches:
+            g(b)
+        torch.cuda.synchronize()
+        graphed.enable_quantizer_calib(False, hp)
+    for ce, cg in ((eager.input_casts.input_cast, graphed.input_casts.input_cast), (eager.weight_cast, graphed.weight_cast)):
+        oe, og = ce.activation_post_process, cg.activation_post_process
+        assert oe.min_val.shape == og.min_val.shape
+        assert bits_equal(oe.min_val, og.min_val) == 0 and bits_equal(oe.max_val, og.max_val) == 0
+        assert bits_equal(ce.scale, cg.scale) == 0 and torch.equal(ce.zero_point, cg.zero_point)
+        assert float(oe.max_val.max()) > 0
+    x = batches[1]
+    with torch.no_grad():
+        assert bits_equal(eager(x), graphed(x)) == 0
+        hist = nn.DmxModuleQuantizerCalibrationHyperparams(inputs={"input_cast": nn.DmxQuantizerCalibrationHyperparams(observer_cls=dmx.HistogramObserver)})
+        graphed.enable_quantizer_calib(True, hist)
+        with pytest.raises(RuntimeError, match="HistogramObserver"):
+            nn.GraphedForward(graphed, x, calibrating=True)
+        graphed.enable_quantizer_calib(False, hist)
