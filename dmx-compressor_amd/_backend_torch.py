@@ -10,7 +10,9 @@ import torch
 from . import _lib
 from ._lib import DmxqError
 
-TORCH_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "dmxq_torch.so")
+# DMXQ_TORCH_LIB_PATH: another build of the binding, together with DMXQ_LIB_PATH = the libdmxq it was linked against (an instrumented
+# pair: tools/sanitize/run_sanitizers.sh)
+TORCH_LIB_PATH = os.environ.get("DMXQ_TORCH_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "dmxq_torch.so")
 
 
 def _load():

@@ -21,12 +21,12 @@ if _binding == "ctypes":
     from . import _backend_ctypes as _raw
     BINDING = "ctypes"
 elif _binding == "torch":
-    if os.environ.get("DMXQ_LIB_PATH"):
+    if os.environ.get("DMXQ_LIB_PATH") and not os.environ.get("DMXQ_TORCH_LIB_PATH"):
         # dmxq_torch.so is linked against lib/libdmxq.so (rpath $ORIGIN): the override would only reach the ctypes handle, an A/B
         # run would silently measure the stock build and two copies of the library (each with its own thread_local launch
         # state) would be loaded
         raise ImportError("DMXQ_LIB_PATH (an alternative libdmxq.so) only works with DMXQ_BINDING=ctypes: the torch extension "
-                          "resolves lib/libdmxq.so through its rpath")
+                          "resolves lib/libdmxq.so through its rpath (or name the binding that was linked against it: DMXQ_TORCH_LIB_PATH)")
     from ._backend_torch import RAW as _raw
     BINDING = "torch"
 else:

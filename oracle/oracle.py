@@ -16,13 +16,16 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# ORACLE_LIB_PATH: another build of oracle.c (`make -C oracle asan`: AddressSanitizer + UBSan, tools/sanitize/run_sanitizers.sh)
+_LIB_PATH = os.environ.get("ORACLE_LIB_PATH") or os.path.join(_HERE, "liboracle.so")
 R_UP, R_DOWN, R_NEAREST, R_STOCHASTIC = 0, 1, 2, 3
 ROUNDING = {"up": R_UP, "down": R_DOWN, "nearest": R_NEAREST, "stochastic": R_STOCHASTIC}
 
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "oracle.c")
+    if os.environ.get("ORACLE_LIB_PATH"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     return _LIB_PATH
