@@ -6,7 +6,7 @@
 #   3. libdmxq.so's host code under ASan + UBSan (build_host_asan.py): tests/test_abi_and_host.py and host_driver.py (27 k calls over every
 #      plan boundary and descriptor-array size) through ctypes
 #   4. csrc/torch_binding.cpp under ASan + UBSan: meta kernels and the CPU-tensor refusals of every op class (torch_binding_driver.py)
-set -u
+set -u -o pipefail
 cd "$(dirname "$0")/../.."
 OUT=profiles/r06_sanitizers.txt
 ASANRT=/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so
