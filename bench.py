@@ -145,6 +145,12 @@ def synth(seed, rows, cols, device):
     return (a * torch.exp(2.0 * b)).to(torch.bfloat16)
 
 
+def llama_seeds(t):
+    """(weight seed, score seed) of the t-th weight of bench.py's llama-shard layer copy 0: what oracle/gen_golden_r6.py committed the
+    reference's digests for (tests/golden/llama_shard_digests.json)"""
+    return 7700 + t, 5000 + t
+
+
 def slot_seed(rank, slot):
     """seed of rank `rank`'s rotation slot `slot` (c2): what oracle/gen_golden_r4.py committed the reference's digests for"""
     return 1000 * rank + slot
@@ -292,12 +298,27 @@ class Workload:
             B = 64 if hyper else 16
             self.layers = []
             self.keep = []   # host descriptor arrays of the multi-tensor calls (must outlive the launches that read them)
+            if os.path.join(ROOT, "tests") not in sys.path:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
             for c in range(args.layers):
                 layer = []
                 for t, (nm, rows, cols) in enumerate(LLAMA_LAYER):
                     s, e = parallel.row_shards(rows, world)[rank]
-                    # every rank synthesises the SAME global tensor (seeded by copy/tensor) and keeps its rows, so the
-                    # gathered result can be compared with rank 0's whole-tensor launch
+                    if c == 0 and args.input == "portable":
+                        # layer copy 0 (the one that is checked): every rank generates ITS rows of the global tensor with the counter-based
+                        # generator of tests/_data.py (element = f(seed, linear index)): the same bits on every machine, so each rank's
+                        # shards can be compared with the SHA-256 of what the REFERENCE's Sparsify -> CastTo makes of those rows
+                        # (tests/golden/llama_shard_digests.json, oracle/gen_golden_r6.py) -- round 6
+                        from _data import make_chunked
+                        ws, ss = llama_seeds(t)
+                        w = make_chunked("heavy", (e - s, cols), ws, torch.bfloat16, start=s * cols).to(dev) if e > s else torch.empty(0, cols, dtype=torch.bfloat16, device=dev)
+                        sc = None
+                        if hyper:
+                            sc = (make_chunked("uniform", (e - s, cols), ss, torch.bfloat16, start=s * cols).to(dev) if e > s
+                                  else torch.empty(0, cols, dtype=torch.bfloat16, device=dev))
+                        layer.append((nm, rows, cols, (s, e), w, sc, torch.empty_like(w)))
+                        continue
+                    # (other copies, --input device: every rank synthesises the SAME global tensor on the device and keeps its rows)
                     w_full = synth(77 + 10 * c + t, rows, cols, dev)
                     w = w_full[s:e].clone()
                     sc = None
@@ -391,7 +412,12 @@ class Workload:
                         n_ref += 1
             msg = f"{n}/{n} slots == oracle.bfp_cast (bit-exact)"
             if gold:
-                msg += f"; {n_ref}/{n} slots == SHA-256 of the reference's CastTo output (tests/golden/c2_digests.json)"
+                # every rank asserted its own slots above; what rank 0 reports is the MINIMUM over ranks of the slots that matched the
+                # reference's digests (round 6: digests for the 20 slots of all eight ranks)
+                lo = torch.tensor([float(n_ref)], dtype=torch.float64, device="cpu" if self.args.dist_backend == "gloo" else self.dev)
+                if dist is not None and world > 1:
+                    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                msg += f"; {int(lo[0])}/{n} slots == SHA-256 of the reference's CastTo output (tests/golden/c2_digests.json)"
                 if n_foreign:
                     msg += f" ({n_foreign} inputs differ from the committed input digests on this host)"
             if world > 1:
@@ -405,6 +431,24 @@ class Workload:
             return msg
         hyper = self.args.op in ("hypernet", "hypernet-each")
         B = 64 if hyper else 16
+        # the reference's own output for these rows (tests/golden/llama_shard_digests.json: SHA-256 per eighth of every weight's rows, so
+        # that the shards of N = 1, 2, 4, 8 ranks are unions of digested pieces)
+        gold, n_ref, n_pieces = None, 0, 0
+        gp = os.path.join(ROOT, "tests", "golden", "llama_shard_digests.json")
+        if self.args.input == "portable" and os.path.exists(gp) and world in (1, 2, 4, 8):
+            gold = json.load(open(gp))["tensors"]
+        if gold is not None:
+            key = "hypernet_sha256" if hyper else "bfp_sha256"
+            for nm, rows, cols, (s, e), w, sc, out in self.layers[0]:
+                piece = rows // 8
+                for k in range(s // piece, e // piece):
+                    g = gold[nm]["pieces"][k]
+                    a, b = k * piece - s, (k + 1) * piece - s
+                    n_pieces += 1
+                    if sha256_bits(w[a:b]) != g["w_sha256"] or (hyper and sha256_bits(sc[a:b]) != g["score_sha256"]):
+                        continue    # this host's libm rounded some fp64 log / cos differently: the oracle check below stands
+                    assert sha256_bits(out[a:b]) == g[key], f"rank {rank} {nm} rows [{k * piece}, {(k + 1) * piece}): output differs from the reference's digest"
+                    n_ref += 1
         for nm, rows, cols, (s, e), w, sc, out in self.layers[0]:
             if e > s:   # this rank's shard against the oracle composed like the reference (sparse.py:287-301 -> format.py:304-343)
                 wc = w.cpu()
@@ -423,8 +467,15 @@ class Workload:
                     whole = d.ops.bfp_qdq(full_w, PRECISION, 16)
                 assert torch.equal(whole.view(torch.int16), full_o.view(torch.int16)), f"{nm}: gathered shards differ from whole tensor"
             del full_w, full_o, full_s
-        return (f"7 weights: all_gather of {world} row shards == whole-tensor result on rank 0 (bit-exact); every rank: its shards == "
-                "oracle " + ("sparsify -> bfp_cast" if hyper else "bfp_cast") + " (bit-exact)")
+        msg = (f"7 weights: all_gather of {world} row shards == whole-tensor result on rank 0 (bit-exact); every rank: its shards == "
+               "oracle " + ("sparsify -> bfp_cast" if hyper else "bfp_cast") + " (bit-exact)")
+        if gold is not None:
+            t = torch.tensor([float(n_ref), float(n_pieces)], dtype=torch.float64, device="cpu" if self.args.dist_backend == "gloo" else self.dev)
+            if dist is not None and world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            msg += (f"; {int(t[0])}/{int(t[1])} row pieces (eighths of the 7 weights, all ranks) == SHA-256 of the reference's "
+                    + ("Sparsify -> CastTo" if hyper else "CastTo") + " output (tests/golden/llama_shard_digests.json)")
+        return msg
 
 
 def main():
@@ -591,6 +642,13 @@ def main():
         walls_10x = t10.tolist()
     t = torch.tensor([walls, evs, walls_alt], device=cdev, dtype=torch.float64)
     elems = torch.tensor([float(wl.elems_per_step_rank)], device=cdev, dtype=torch.float64)
+    # every rank's OWN median region and element count, side by side with the max-over-ranks figure (round 6): a straggler shows as a
+    # low per-rank minimum instead of only lowering the total
+    mine = torch.tensor([statistics.median(walls), statistics.median(evs), float(wl.elems_per_step_rank)], device=cdev, dtype=torch.float64)
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)   # per replay: the slowest rank
         dist.all_reduce(elems, op=dist.ReduceOp.SUM)
@@ -662,12 +720,20 @@ def main():
                        "dist_backend": (args.dist_backend + (" (harness-only transport; ranks share GPUs: not a scaling figure)"
                                                              if args.dist_backend == "gloo" else " (RCCL)")) if dist is not None else None,
                        "input": ("tests/_data.py make('heavy', (4096, 4096), seed = 1000 rank + slot, bf16): counter-based, host-generated"
-                                 if args.input == "portable" else "torch.randn on the device") if args.workload != "llama-shard" else "torch.randn on the device",
+                                 if args.input == "portable" else "torch.randn on the device") if args.workload != "llama-shard"
+                                else ("layer copy 0: tests/_data.py make('heavy' | 'uniform', rows of the shard, seed = 7700 + t | 5000 + t, bf16), counter-based, "
+                                      "host-generated; other copies: torch.randn on the device" if args.input == "portable" else "torch.randn on the device"),
                        "timing": "one untimed replay, then R wall-clock regions of exactly K steps (barrier+sync, K steps, sync; "
                                  "max over ranks; median region -> ms_per_step, value) and R HIP-event regions of the same K steps "
                                  "(events on the launch stream, a queued device-side delay in front so that host launch latency is "
                                  "not inside the events; median region -> roofline)",
                        "per_gpu_elements_per_step": wl.elems_per_step_rank,
+                       "per_rank": {"value": [round(float(p[2]) / (float(p[0]) / K) / 1e9, 2) if float(p[2]) > 0 else 0.0 for p in per_rank],
+                                    "value_min": round(min((float(p[2]) / (float(p[0]) / K) / 1e9) for p in per_rank), 2),
+                                    "value_max": round(max((float(p[2]) / (float(p[0]) / K) / 1e9) for p in per_rank), 2),
+                                    "event_us_per_step": [round(float(p[1]) * 1e6 / K, 3) for p in per_rank],
+                                    "note": "each rank's own elements per step / its own median wall-clock region (Gelements/s); `value` is "
+                                            "all ranks' elements / the per-region maximum over ranks"},
                        "check": checked},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                          "frac": round(achieved / PEAK_HBM, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -679,6 +745,14 @@ def main():
         }
         if resident is not None:
             line["cache_resident_value"] = round(resident, 2)
+        try:   # which library this line was measured on (tools/stamp.py: commit recorded in the build container, SHA-256 recomputed here)
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("dmxq_stamp", os.path.join(ROOT, "tools", "stamp.py"))
+            st = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(st)
+            line["build"] = st.current()
+        except Exception as e:   # noqa: BLE001
+            line["build"] = {"error": repr(e)[:120]}
         if world == 1 and args.workload == "c2" and not args.no_tier2:
             # the second tier: configs 3 / 4 / 5's kernels and layers, AFTER the headline measurement above, in the
             # same process and the same driver-observed run; never raises (a failure is recorded in the entry it belongs to)

@@ -25,27 +25,33 @@ def normal(n, seed, start=0):
     return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
 
 
-def make_chunked(kind, shape, seed=0, dtype=torch.float32, workers=None, chunk=1 << 20):
+def make_chunked(kind, shape, seed=0, dtype=torch.float32, workers=None, chunk=1 << 20, start=0):
     """make("normal" | "heavy", ...) computed in index chunks on a thread pool (numpy releases the GIL): the SAME bits
     as make() -- every element is a function of (seed, linear index) -- at a fraction of the time for the 16.8 M-element
-    benchmark tensors (bench.py generates 20 of them per rank; tests/test_abi_and_host.py checks the equality)."""
+    benchmark tensors (bench.py generates 20 of them per rank; tests/test_abi_and_host.py checks the equality).
+    kind "uniform": U(0, 1) (the N:M scores of bench.py's llama-shard workload).  start: the linear index of the first element --
+    a ROW SHARD of a larger tensor is make_chunked(kind, (rows_of_the_shard, cols), seed, start = first_row * cols): every rank of a
+    sharded run generates only its own rows, and the bits are those of the whole tensor's rows (round 6)."""
     import os
     from concurrent.futures import ThreadPoolExecutor
 
-    if kind not in ("normal", "heavy"):
+    if kind not in ("normal", "heavy", "uniform"):
         raise ValueError(kind)
     n = int(np.prod(shape))
     out = torch.empty(n, dtype=dtype)
 
-    def one(start):
-        m = min(chunk, n - start)
-        v = normal(m, seed, start)
-        if kind == "heavy":
-            v = v * np.exp(4.0 * normal(m, seed + 1, start))
+    def one(off):
+        m = min(chunk, n - off)
+        if kind == "uniform":
+            v = uniform(m, seed, start + off)
+        else:
+            v = normal(m, seed, start + off)
+            if kind == "heavy":
+                v = v * np.exp(4.0 * normal(m, seed + 1, start + off))
         t = torch.from_numpy(v.astype(np.float32))
         if dtype == torch.float16:
             t = t.clamp(-65504.0, 65504.0)
-        out[start:start + m] = t.to(dtype)
+        out[off:off + m] = t.to(dtype)
 
     workers = workers or max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
     with ThreadPoolExecutor(workers) as ex:

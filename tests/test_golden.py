@@ -473,3 +473,24 @@ def test_stochastic_bfp_draws_are_unbiased_and_pairwise_uncorrelated(oracle):
     c = torch.corrcoef(d.t())
     off = c - torch.eye(B - 1)
     assert float(off.abs().max()) < 0.02, float(off.abs().max())   # (independent draws: |r| ~ 1 / sqrt(196608) = 0.002)
+
+
+def test_llama_shard_digests_are_reproduced_by_the_oracle(oracle):
+    """tests/golden/llama_shard_digests.json (oracle/gen_golden_r6.py): SHA-256 of the reference's Sparsify(2:4) -> CastTo(BFP16_64) and
+    CastTo(BFP16_16) outputs per eighth of the rows of the seven Llama-3-8B layer weights bench.py's llama-shard workload generates.
+    One piece of one small weight here: generated as a SHARD (start offset), cast by the oracle, compared with the committed digests."""
+    import json
+
+    from _data import make_chunked, sha256_bits
+
+    g = json.load(open(os.path.join(GOLD, "llama_shard_digests.json")))
+    assert sorted(g["tensors"]) == sorted(["q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"])
+    assert all(len(t["pieces"]) == 8 for t in g["tensors"].values())
+    t = g["tensors"]["k_proj"]
+    k, piece, cols = 5, t["rows"] // 8, t["cols"]
+    w = make_chunked("heavy", (piece, cols), t["w_seed"], torch.bfloat16, start=k * piece * cols)
+    sc = make_chunked("uniform", (piece, cols), t["score_seed"], torch.bfloat16, start=k * piece * cols)
+    e = t["pieces"][k]
+    assert e["rows"] == [k * piece, (k + 1) * piece] and sha256_bits(w) == e["w_sha256"] and sha256_bits(sc) == e["score_sha256"]
+    assert sha256_bits(oracle.bfp_cast(oracle.sparsify(w, sc, 2, 4), 8, 64).to(torch.bfloat16)) == e["hypernet_sha256"]
+    assert sha256_bits(oracle.bfp_cast(w, 8, 16).to(torch.bfloat16)) == e["bfp_sha256"]

@@ -55,6 +55,9 @@ def test_bench_two_ranks_share_one_gpu_over_gloo(extra, scaling):
     if not extra:
         assert line["config"]["per_gpu_elements_per_step"] == 4096 * 4096
         assert "4/4 slots == oracle" in line["config"]["check"] and "4/4 slots == SHA-256 of the reference" in line["config"]["check"]
+    else:
+        assert "56/56 row pieces" in line["config"]["check"], line["config"]["check"]
+    assert len(line["config"]["per_rank"]["value"]) == 2
     assert line["value"] > 0
 
 
@@ -73,6 +76,13 @@ def test_bench_eight_ranks_share_one_gpu_over_gloo(extra, scaling):
     if not extra:
         assert line["config"]["per_gpu_elements_per_step"] == 4096 * 4096
         assert "4/4 slots == oracle" in line["config"]["check"]
+        # round 6: the reference's digests exist for the slots of ALL eight ranks; the reported count is the minimum over ranks
+        assert "4/4 slots == SHA-256 of the reference" in line["config"]["check"], line["config"]["check"]
+    else:
+        # ... and for every eighth of the seven weights' rows (tests/golden/llama_shard_digests.json): 7 weights x 8 pieces over the 8 ranks
+        assert "56/56 row pieces" in line["config"]["check"] and "SHA-256 of the reference's Sparsify -> CastTo" in line["config"]["check"], line["config"]["check"]
+    pr = line["config"]["per_rank"]
+    assert len(pr["value"]) == 8 and 0 < pr["value_min"] <= pr["value_max"]
     assert line["value"] > 0
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):   # (kept for profiles/: the line of the rehearsal, labelled by its own dist_backend field)

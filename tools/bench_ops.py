@@ -117,6 +117,15 @@ def main():
         lambda i: L.dmxq_bfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, 512, 512, 9, 64, 8, 2, 1, 0, sp), k, 512 * 512 * 9 * 4)
     run("bfp_qdq bf16 feature map [64,2048,7,7] along channels B=64 (LDS sub-slab kernel)",
         lambda i: L.dmxq_bfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, 64, 2048, 49, 64, 8, 2, 1, 0, sp), k, 64 * 2048 * 49 * 4)
+    # conv activations whose rows are not whole 128-byte lines (round 6: csrc/bfp_slab.hip), each on its own rotating buffers
+    for shp in ((256, 1024, 14, 14), (64, 512, 28, 28)):
+        nel = shp[0] * shp[1] * shp[2] * shp[3]
+        kk = nb(nel * 4)
+        cx = bufs(torch.bfloat16, kk, shape=shp)
+        cy = [torch.empty_like(t) for t in cx]
+        run(f"bfp_qdq bf16 feature map [{shp[0]},{shp[1]},{shp[2]},{shp[3]}] along channels B=64 (LDS slab kernel: rows of {shp[2] * shp[3] * 2} bytes)",
+            lambda i: L.dmxq_bfp_qdq(vp(cx[i].data_ptr()), vp(cy[i].data_ptr()), _lib.BF16, _lib.BF16, shp[0], shp[1], shp[2] * shp[3], 64, 8, 2, 1, 0, sp), kk, nel * 4)
+        del cx, cy
     run("bfp_qdq bf16 rows ragged L=C-8 B=64 (generic path)",
         lambda i: L.dmxq_bfp_qdq(vp(xs[i].data_ptr()), vp(ys[i].data_ptr()), _lib.BF16, _lib.BF16, R, C - 8, 1, 64, 8, 2, 1, 0, sp), k, R * (C - 8) * 4)
     # ---------------------------------------------------------------- float / fixed / scale / gelu

@@ -58,3 +58,5 @@ env $E DMXQ_TORCH_LIB_PATH=$SO/dmxq_torch_asan.so python tools/sanitize/torch_bi
 echo
 if [ $fail = 0 ]; then echo "RESULT: clean (no sanitizer report, every step exited 0)"; else echo "RESULT: FAILURES above"; fi
 } 2>&1 | tee $OUT
+# (the instrumented objects are ~770 MB: a gpurun snapshot must stay under 512 MiB)
+rm -rf tools/sanitize/_out oracle/_asan
