@@ -40,6 +40,50 @@ class _Overloads:
 RAW = _Overloads(_load())
 
 
+# ---------------------------------------------------------------------------------------------------- direct entry points (round 6)
+# `dmxq_torch.so` is also a Python extension module (`PyInit_dmxq_fast`, csrc/torch_binding.cpp): the SAME C++ functions the dispatcher
+# calls, without the dispatcher (~2 us of schema matching, boxing and dispatch per call; profiles/r06_host_overhead.txt).  Eager
+# inference calls take them; while torch.compile / export traces, and for everything that needs autograd, the dispatcher op stays
+# (`*_nograd` are the no-gradient variants the front end picks by itself; the other names have no autograd formula to lose).
+# DMXQ_NO_FAST_CALLS=1 switches them off (A/B runs).
+_FAST_NAMES = {"bfp_qdq_nograd": "bfp_qdq", "float_qdq_nograd": "float_qdq", "fixed_qdq_nograd": "fixed_qdq", "sbfp_qdq_nograd": "sbfp_qdq",
+               "mxfp_qdq_nograd": "mxfp_qdq", "weight_hypernet": "weight_hypernet", "input_hypernet": "input_hypernet", "binary_cast": "binary_cast",
+               "relu_cast": "relu_cast", "scale_channels": "scale_channels", "rope_cast": "rope_cast", "unary_cast": "unary_cast",
+               "lut16_apply": "lut16_apply", "softmax_cast": "softmax_cast", "norm_cast": "norm_cast"}
+FAST = None
+
+
+def _load_fast():
+    import importlib.machinery
+    import importlib.util
+
+    loader = importlib.machinery.ExtensionFileLoader("dmxq_fast", TORCH_LIB_PATH)
+    mod = importlib.util.module_from_spec(importlib.util.spec_from_loader("dmxq_fast", loader))
+    loader.exec_module(mod)
+    return mod
+
+
+def _direct(fast_fn, op):
+    is_compiling = torch.compiler.is_compiling
+
+    def call(*args):
+        return op(*args) if is_compiling() else fast_fn(*args)
+
+    call.__wrapped__ = op
+    return call
+
+
+if not os.environ.get("DMXQ_NO_FAST_CALLS"):
+    try:
+        FAST = _load_fast()
+    except (ImportError, OSError, AttributeError):   # (a binding built without the entry points: the dispatcher serves everything)
+        FAST = None
+    if FAST is not None:
+        for _raw_name, _fast_name in _FAST_NAMES.items():
+            setattr(RAW, _raw_name, _direct(getattr(FAST, _fast_name), getattr(RAW, _raw_name)))
+        del _raw_name, _fast_name
+
+
 # ---------------------------------------------------------------------------------------------------- autograd (STE)
 def _ste_setup(ctx, inputs, output):
     ctx.in_dtype = inputs[0].dtype

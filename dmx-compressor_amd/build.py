@@ -159,7 +159,7 @@ def link_torch_binding(obj: str, force: bool = False, verbose: bool = False) -> 
         _, tlib = _torch_flags()
         cmd = [os.environ.get("CXX", "g++"), "-shared", "-fPIC", "-o", TORCH_LIB, obj, "-L" + os.path.dirname(LIB), "-ldmxq",
                "-Wl,-rpath,$ORIGIN", "-L" + tlib, "-Wl,-rpath," + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip",
-               "-ltorch_hip"]
+               "-ltorch_hip", "-ltorch_python"]   # (torch_python: the pybind casters of the direct entry points, PyInit_dmxq_fast)
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
