@@ -19,7 +19,7 @@ def _run(extra, port, n=2, plain=False):
     launcher = [] if plain else ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
                                  "127.0.0.1", "--master-port", str(port)]
     cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "6", "--warmup", "2",
-                                         "--replays", "3", "--no-cpu-baseline"] + extra
+                                         "--replays", "3", "--no-cpu-baseline", "--no-tier2"] + extra
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1100 if n > 2 else 600)

@@ -225,3 +225,74 @@ def test_graphed_forward_of_a_minmax_calibrating_linear(dmx, cuda, dtype):
         with pytest.raises(RuntimeError, match="HistogramObserver"):
             nn.GraphedForward(graphed, x, calibrating=True)
         graphed.enable_quantizer_calib(False, hist)
+
+
+# ------------------------------------------------------------------------------------------------ dispatcher-free entry points
+def test_direct_entry_points_equal_the_dispatcher_ops(dmx, cuda):
+    """csrc/torch_binding.cpp PyInit_dmxq_fast: the same C++ functions as `torch.ops.dmxq.*` without the dispatcher.  Every routed
+    name gives the dispatcher op's bits, raises what it raises, and steps aside while torch.compile traces."""
+    if dmx.ops.BINDING != "torch":
+        pytest.skip("torch binding only")
+    from dmx_compressor_amd import _backend_torch as B
+    assert B.FAST is not None, "dmxq_torch.so was built without PyInit_dmxq_fast"
+    x = make("heavy", (64, 1536), seed=91, dtype=BF16).clamp(-1e4, 1e4).to(cuda)
+    xf = x.float()
+    sc = (make("normal", (12,), seed=92).abs() * 0.05 + 1e-3).to(cuda)
+    zp = torch.zeros(12, dtype=torch.int64, device=cuda)
+    f16 = [10, 5, 15, 1]
+    w = (make("normal", (1536,), seed=93) * 0.1 + 1).to(BF16).to(cuda)
+    table = B.RAW.unary_cast_table(x, 0, 0.0, f16, f16)
+    cases = {
+        "bfp_qdq_nograd": (x, 8, 64, -1, True, 2, None, 0),
+        "float_qdq_nograd": (x, 10, 5, 15, True, False, 2, None, 0),
+        "fixed_qdq_nograd": (xf, 8, 0, True, True, 2, sc, zp, -1, 128, None, 0),
+        "sbfp_qdq_nograd": (x, 4, 16, 4, 4, 7, True, True, True, -1, None),
+        "mxfp_qdq_nograd": (x, 3, 4, 32, -1, None),
+        "weight_hypernet": (x, 8, 64, True, torch.rand(64, 1536, device=cuda), 2, 4, None, BF16, -1),
+        "input_hypernet": (x, (torch.rand(1536, device=cuda) + 0.5), 8, 64, True),
+        "binary_cast": (x, x.flip(0), 0, f16, f16, f16, 0, 0),
+        "relu_cast": (x, f16, f16, 0, 0),
+        "scale_channels": (x, (torch.rand(1536, device=cuda) + 0.5), -1, True, None),
+        "unary_cast": (x, 0, 0.0, f16, f16),
+        "lut16_apply": (x, table),
+        "softmax_cast": (x, float("-inf"), f16, f16, 0, 0),
+        "norm_cast": (x, 1536, w, w, 1e-5, 0, f16, f16, 0, 0),
+    }
+    assert set(cases) | {"rope_cast"} == set(B._FAST_NAMES)
+    for name, args in cases.items():
+        routed = getattr(B.RAW, name)
+        op = routed.__wrapped__
+        got, want = routed(*args), op(*args)
+        assert got.dtype == want.dtype and mismatches_nan_aware(got, want) == 0, name
+    with pytest.raises(RuntimeError):
+        B.RAW.bfp_qdq_nograd(x.cpu(), 8, 64, -1, True, 2, None, 0)            # no CPU fallback, same error class
+    with pytest.raises(NotImplementedError):
+        B.RAW.input_hypernet(x, torch.ones(7, device=cuda), 8, 64, True)      # not fusable: NotImplementedError as from the dispatcher
+    # torch.compile traces the dispatcher op (meta kernel), not the extension function
+    cast = dmx.CastTo(format="BFP[8|8]{64}(SN)")
+    eager = cast(x)
+    compiled = torch.compile(lambda t: cast(t) + 0, fullgraph=True)
+    assert mismatches_nan_aware(compiled(x), eager + 0) == 0
+
+
+def test_bench_line_carries_the_second_tier_and_the_build_stamp():
+    """`python bench.py` at N = 1 times configs 3 / 4 / 5's kernels after the headline measurement and puts them into the ONE JSON line
+    (`ops`: us / bytes / frac / check per op, each checked against the oracle outside the timed region), with the library's stamp
+    (`build`).  Here with `--tier2-only basic` (one op) and no layers' worth of waiting."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--replays", "3", "--nbuf", "4", "--preheat", "50",
+                        "--no-cpu-baseline", "--tier2-only", "basic"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    op = line["ops"]["basic.float16_activation_cast_bf16"]
+    assert "bit-exact" in op["check"] and 0 < op["frac"] < 1 and op["bytes"] == 4 * 4096 * 4096 and op["us"] > 0
+    assert set(line["layers"]) == {"opt125m", "llama", "whisper"} and all("us_per_forward" in v for v in line["layers"].values())
+    assert line["build"]["libdmxq_sha256"] and "4/4 slots == oracle" in line["config"]["check"]
+    assert line["roofline"]["frac"] > 0 and line["value"] > 0
