@@ -235,6 +235,11 @@ def fixed_float_qdq_multi(tensors, precision: int, fraction: int, clamp: bool, s
         require_gpu(t, "fixed_float_qdq_multi")
     if bias is None:
         bias = (1 << (exponent - 1)) - 1
+    if not tensors or not float_tensors:
+        # one of the sets is empty: exactly the two calls (decided HERE so that both bindings behave alike -- ADVICE r5: the torch
+        # binding refused an empty list where the ctypes one fell back)
+        return (fixed_qdq_multi(tensors, precision, fraction, clamp, symmetric, scales, zero_points, group_size=group_size) if tensors else [],
+                float_qdq_multi(float_tensors, mantissa, exponent, bias, flush_subnormal, unsigned) if float_tensors else [])
     a, b = _ops.fixed_float_qdq_multi(tensors, precision, fraction, clamp, symmetric, ROUNDING_CODE["nearest"], list(scales), list(zero_points),
                                       group_size or 0, float_tensors, mantissa, exponent, bias, bool(flush_subnormal), bool(unsigned),
                                       ROUNDING_CODE["nearest"], 0)

@@ -296,3 +296,18 @@ def test_bench_line_carries_the_second_tier_and_the_build_stamp():
     assert set(line["layers"]) == {"opt125m", "llama", "whisper"} and all("us_per_forward" in v for v in line["layers"].values())
     assert line["build"]["libdmxq_sha256"] and "4/4 slots == oracle" in line["config"]["check"]
     assert line["roofline"]["frac"] > 0 and line["value"] > 0
+
+
+@pytest.mark.parametrize("binding", ["torch", "ctypes"])
+def test_fixed_float_multi_with_an_empty_list_is_the_two_calls_in_both_bindings(dmx, cuda, oracle, binding):
+    """the torch binding refused an empty list where the ctypes one fell back to the single-op calls; the front end decides now"""
+    F = dmx.ops.front(binding)
+    w = (make("normal", (256, 64), seed=3) * 0.05).to(cuda)
+    sc = (w.reshape(2, 128, 64).abs().amax(dim=(1, 2)) / 127.0).contiguous()
+    zp = torch.zeros(2, dtype=torch.int64, device=cuda)
+    b = (make("normal", (64,), seed=4) * 0.02).to(cuda)
+    a, f = F.fixed_float_qdq_multi([w], 8, 0, True, True, [sc], [zp], 128, [], 22, 8, 127, False)
+    assert f == [] and bits_equal(a[0], oracle.fixed_point_affine_cast(w.cpu(), 8, 0, True, True, sc.cpu(), zp.cpu(), ch_axis=0, group_size=128)) == 0
+    a, f = F.fixed_float_qdq_multi([], 8, 0, True, True, [], [], 128, [b], 22, 8, 127, False)
+    assert a == [] and bits_equal(f[0], oracle.float_quantize(b.cpu(), 22, 8, 127, False)) == 0
+    assert F.fixed_float_qdq_multi([], 8, 0, True, True, [], [], 128, [], 22, 8, 127, False) == ([], [])
