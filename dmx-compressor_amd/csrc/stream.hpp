@@ -335,6 +335,12 @@ static int launch_stream(const void* in, void* out, int64_t n, const OP& op, hip
 // launch of its own, so the result is always what one call per tensor gives.  Geometry: launch_stream's size rule applied to the
 // TOTAL of the set.  (The hand-written predecessor of this kernel, fixed_multi_kernel, ran 256 x 4 tiles with a table read and a
 // division per vector: 13.8 us for the 56 MB of an opt-125m layer's six float32 weights, 51 % of the roofline.)
+// (A/B switch: -DDMXQ_EXP_MULTI_NTS=1 builds the small-set launches with non-temporal loads and stores too)
+#ifdef DMXQ_EXP_MULTI_NTS
+constexpr bool kMultiSmallNT = DMXQ_EXP_MULTI_NTS != 0;
+#else
+constexpr bool kMultiSmallNT = false;
+#endif
 template <class OP> struct StreamMultiDesc { const void* in; void* out; int64_t n_vec, tile0; OP op; };
 template <class OP> struct StreamMultiArgs {
   static constexpr int kMax = (int)(3600 / sizeof(StreamMultiDesc<OP>)) < 32 ? (int)(3600 / sizeof(StreamMultiDesc<OP>)) : 32;  // (a 4 KiB argument block)
@@ -415,7 +421,7 @@ static int launch_stream_multi2(StreamMulti2Args<OPA, OPB>& a, hipStream_t s) {
       const uint32_t lo = 2 * i + 1 < n ? first[2 * i + 1] : 0xFFFFu, hi = 2 * i + 2 < n ? first[2 * i + 2] : 0xFFFFu;  \
       e[i] = lo | (hi << 16);                                                                                         \
     }                                                                                                                 \
-    DMXQ_LAUNCH((stream_multi2_kernel<DTI, DTO, U_, UB, T_, OPA, OPB, false>), dim3((unsigned)tiles), dim3(T_), 0, s, e[0], e[1], e[2], e[3], \
+    DMXQ_LAUNCH((stream_multi2_kernel<DTI, DTO, U_, UB, T_, OPA, OPB, kMultiSmallNT>), dim3((unsigned)tiles), dim3(T_), 0, s, e[0], e[1], e[2], e[3], \
                 e[4], e[5], e[6], e[7], e[8], e[9], a.nA, a);                                                         \
   } while (0)
   if (totalc <= ((int64_t)1 << 17)) {
@@ -450,9 +456,9 @@ static int launch_stream_multi(StreamMultiArgs<OP>& a, hipStream_t s) {
                 e[6], e[7], e[8], e[9], a.n, a);                                                                     \
   } while (0)
   const int64_t totalc = plan_norm(total);
-  if (totalc <= ((int64_t)1 << 17)) DMXQ_STREAM_MULTI(256, 1, false);
-  else if (totalc <= ((int64_t)5 << 18)) DMXQ_STREAM_MULTI(256, 4, false);
-  else if (totalc <= ((int64_t)1 << 21)) DMXQ_STREAM_MULTI(TT, TU, false);
+  if (totalc <= ((int64_t)1 << 17)) DMXQ_STREAM_MULTI(256, 1, kMultiSmallNT);
+  else if (totalc <= ((int64_t)5 << 18)) DMXQ_STREAM_MULTI(256, 4, kMultiSmallNT);
+  else if (totalc <= ((int64_t)1 << 21)) DMXQ_STREAM_MULTI(TT, TU, kMultiSmallNT);
   else DMXQ_STREAM_MULTI(256, 2, true);
 #undef DMXQ_STREAM_MULTI
   return launch_status();
