@@ -62,6 +62,13 @@ __device__ __forceinline__ void pack_codes_literal(const float (&x)[EPL], uint32
 // rows of whole power-of-two blocks: a workgroup takes a contiguous tile of kPackThreads x kPackUnroll 16-byte vectors, all of a
 // lane's loads in flight before the first block maximum; the magic-add codes for every lane as straight-line code, the blocks
 // that form does not cover redone behind one cold branch (the structure of bfp_rows.hpp)
+// (idle issue cycles between a lane's loads, common.hpp pace_issue; -DDMXQ_EXP_PACK_PACE=N for A/B builds.  Round 6, same-lease A/B of
+//  0 / 2 / 4 on 4096 x 4096 bf16: see profiles/r06_ab_stragglers.txt)
+#ifdef DMXQ_EXP_PACK_PACE
+constexpr int kPackPace = DMXQ_EXP_PACK_PACE;
+#else
+constexpr int kPackPace = 0;
+#endif
 constexpr int kPackThreads = 256, kPackUnroll = 4;  // (round 3, 4096 x 4096 bf16: 256 x 2 and 256 x 4 12.0 us, 256 x 8 12.8, 256 x 16 and 128 x 16 14.5)
 // VAR bit 0 (16-bit inputs, n_vec even, mant 16-byte aligned): 16-byte code stores -- neighbouring lanes swap the codes of two unroll
 //   slots (one DPP quad_perm each way), so the even lane stores vectors (v, v + 1) of slot 2k and the odd lane those of slot 2k + 1;
@@ -86,6 +93,7 @@ __global__ __launch_bounds__(T) void bfp_pack_rows_kernel(const void* __restrict
     // past the end: the same lane position of the LAST block (whole blocks: n_vec % lpb == 0), so that every lane of a
     // wave takes part in the block maxima with defined data; nothing is stored for it
     raw[u] = load_raw16<true>(in, (v < n_vec ? v : n_vec - lpb + in_blk) * 16);
+    if (u + 1 < U) pace_issue<kPackPace>();
   }
   __builtin_amdgcn_sched_barrier(0);
   uint32_t w[U][EPL / 4];
