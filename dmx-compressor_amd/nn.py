@@ -1789,6 +1789,49 @@ class GraphedForward:
         return self.static_out
 
 
+class GraphedModule:
+    """`GraphedForward` per input SIGNATURE, behind the call syntax of the module (round 6): the eager forward of a configured layer is
+    host-bound (an opt-125m decoder layer: 734 us eager, 176-219 us as a graph), and a serving loop sees a handful
+    of shapes.
+
+        fast = GraphedModule(layer)          # nothing is captured yet
+        y = fast(x)                          # first call with this (shapes, dtypes, devices): warm-up + capture; then ONE replay per call
+        y2 = fast(x_other_batch)             # another signature: its own graph (at most `max_graphs`, least recently used dropped)
+
+    Results are CLONED out of the graph's static buffers by default (`clone_outputs=True`: a caller may keep them across calls; False hands
+    out the static buffers, overwritten by the next call with the same signature).  Inference only, frozen configuration: after
+    `configure()`, calibration or any other change of formats / flags / scales that are BAKED into launches as arguments (formats are;
+    scale and zero-point TENSORS are read at replay time and may change), call `invalidate()` -- the captured launches carry the
+    arguments of their capture.  Non-tensor and keyword arguments are not supported (use `GraphedForward` on a closure)."""
+
+    def __init__(self, model: torch.nn.Module, clone_outputs: bool = True, max_graphs: int = 8, **graphed_forward_kwargs):
+        self.model, self.clone_outputs, self.max_graphs, self._kw = model, clone_outputs, max_graphs, graphed_forward_kwargs
+        self._graphs = OrderedDict()
+
+    def invalidate(self):
+        """drop every captured graph (the next call of each signature captures again)"""
+        self._graphs.clear()
+
+    def __call__(self, *inputs: torch.Tensor):
+        key = tuple((tuple(t.shape), t.dtype, t.device) for t in inputs)
+        g = self._graphs.get(key)
+        if g is None:
+            g = GraphedForward(self.model, *inputs, **self._kw)
+            self._graphs[key] = g
+            while len(self._graphs) > self.max_graphs:
+                self._graphs.popitem(last=False)
+        else:
+            self._graphs.move_to_end(key)
+        out = g(*inputs)
+        if not self.clone_outputs:
+            return out
+        if isinstance(out, torch.Tensor):
+            return out.clone()
+        if isinstance(out, (tuple, list)):
+            return type(out)(o.clone() if isinstance(o, torch.Tensor) else o for o in out)
+        return out
+
+
 def configure_model(model: torch.nn.Module, *rules: DmxConfigRule):
     """DmxModel.configure(None, *rules) for a model already built from these modules (model.py:61-78)"""
     for r in rules:

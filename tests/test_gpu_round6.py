@@ -311,3 +311,37 @@ def test_fixed_float_multi_with_an_empty_list_is_the_two_calls_in_both_bindings(
     a, f = F.fixed_float_qdq_multi([], 8, 0, True, True, [], [], 128, [b], 22, 8, 127, False)
     assert a == [] and bits_equal(f[0], oracle.float_quantize(b.cpu(), 22, 8, 127, False)) == 0
     assert F.fixed_float_qdq_multi([], 8, 0, True, True, [], [], 128, [], 22, 8, 127, False) == ([], [])
+
+
+def test_graphed_module_captures_one_graph_per_input_signature(dmx, cuda):
+    """nn.GraphedModule: the module's call syntax over one hipGraph per (shapes, dtypes): results equal the eager forward bit for bit,
+    a second signature gets its own graph, results are clones (they survive the next call), `invalidate()` re-captures after a
+    reconfiguration, the least recently used graph is dropped beyond `max_graphs`."""
+    nn = dmx.nn
+
+    class Stack(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b, self.act = nn.Linear(256, 512), nn.Linear(512, 256), nn.GELU()
+
+        def forward(self, x):
+            return self.b(self.act(self.a(x)))
+
+    m = Stack().to(cuda).to(BF16).eval()
+    nn.configure_model(m, *dmx.config_rules.BASIC)
+    x1 = make("normal", (8, 64, 256), seed=71, dtype=BF16).to(cuda)
+    x2 = make("normal", (3, 256), seed=72, dtype=BF16).to(cuda)
+    with torch.no_grad():
+        e1, e2 = m(x1).clone(), m(x2).clone()
+        fast = nn.GraphedModule(m, max_graphs=2)
+        y1 = fast(x1)
+        y2 = fast(x2)
+        assert bits_equal(y1, e1) == 0 and bits_equal(y2, e2) == 0 and len(fast._graphs) == 2
+        y1b = fast(x1 * 0.5)
+        assert bits_equal(y1, e1) == 0                      # a clone: not overwritten by the replay
+        assert bits_equal(y1b, m(x1 * 0.5)) == 0
+        fast(make("normal", (5, 256), seed=73, dtype=BF16).to(cuda))
+        assert len(fast._graphs) == 2 and (((3, 256), BF16, x2.device),) not in fast._graphs   # least recently used dropped
+        m.a.configure(dict(weight_format="BFP[8|8]{16}(SN)"))
+        fast.invalidate()
+        assert bits_equal(fast(x1), m(x1)) == 0 and bits_equal(fast(x1), e1) != 0
