@@ -345,3 +345,29 @@ def test_graphed_module_captures_one_graph_per_input_signature(dmx, cuda):
         m.a.configure(dict(weight_format="BFP[8|8]{16}(SN)"))
         fast.invalidate()
         assert bits_equal(fast(x1), m(x1)) == 0 and bits_equal(fast(x1), e1) != 0
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_bfp_slab_random_cases(dmx, cuda, oracle, chunk):
+    """randomised differential cases drawn INSIDE the slab kernel's routing rule (rows that are not whole 128-byte lines, slabs of at
+    least 16 KiB): block sizes, ragged block dims, even inner extents, both 16-bit dtypes, precisions, symmetric / asymmetric"""
+    import random
+    rng = random.Random(6000 + chunk)
+    done = 0
+    while done < 14:
+        B = rng.choice([8, 16, 32, 64, 64, 64, 128, 256])
+        inner = 2 * rng.randrange(32, 620)
+        if (inner * 2) % 128 == 0 or B * inner * 2 < 16 * 1024 or B * ((inner // 2 + 40)) * 4 > 150 * 1024:
+            continue
+        L = rng.choice([B, 2 * B, B + rng.randrange(1, B), 3 * B, max(1, B // 2 + 1), 5])
+        outer = rng.choice([1, 2, 3])
+        if outer * L * inner > 600000:
+            continue
+        dtype = rng.choice([BF16, F16])
+        wl = rng.choice([2, 4, 8, 8, 8, 12, 15, 16, 20])
+        sym = rng.random() < 0.7
+        x = make(rng.choice(["normal", "heavy", "mixed_nd" if not sym else "mixed", "outlier", "ties"]), (outer, L, inner), seed=chunk * 100 + done, dtype=dtype, block=min(B, 64))
+        got = dmx.ops.bfp_qdq(x.to(cuda), wl, B, 1, sym)
+        want = oracle.bfp_cast(x, wl, B, 1, sym).to(dtype)
+        assert mismatches_nan_aware(got, want) == 0, (chunk, done, outer, L, inner, B, dtype, wl, sym)
+        done += 1
