@@ -327,6 +327,11 @@ __device__ __forceinline__ float seg_max(float v) {
 #define DMXQ_EXP_ROW_PACE 0
 #endif
 constexpr int kRowPace = DMXQ_EXP_ROW_PACE;   // common.hpp pace_issue between a wave's row loads (experiment)
+#ifdef DMXQ_EXP_LN32
+constexpr int kLn32OnePass = DMXQ_EXP_LN32;
+#else
+constexpr int kLn32OnePass = 0;
+#endif
 constexpr bool kRowEarlyLoads = false;  // layernorm_wave_kernel: next rows requested before this iteration's stores (measured slower, see there)
 constexpr int rows_per_wave(int vpl, int epl) { return 32 / (vpl * epl) >= 4 ? 4 : (32 / (vpl * epl) >= 2 ? 2 : 1); }
 
@@ -519,7 +524,9 @@ __global__ __launch_bounds__(kThreads) void layernorm_wave_kernel(const void* __
   // the same kernel reaches 74 % of the roofline at 128 MiB.  The code path stays (compiled out) as the record of the experiment.
   constexpr bool EARLY = PFO < 0 ? kRowEarlyLoads : PFO != 0;
   // (the LayerNorm module on 16-bit rows of 768: paced loads, measured with the one-pass grid of the launcher; everything else: the tuner's hook)
-  constexpr int kLnModulePace = (CAST && !RMS && !BFPOUT && VPL == 3 && EPL == 8 && LPR == 32 && RPWO == 0) ? 4 : kRowPace;
+  // (-DDMXQ_EXP_LN32=N, A/B builds: the float32 module on rows of 768 -- 64 lanes x 3 vectors of 4 -- on the one-pass grid too, pace N - 1)
+  constexpr int kLnModulePace = (CAST && !RMS && !BFPOUT && VPL == 3 && EPL == 8 && LPR == 32 && RPWO == 0) ? 4
+                                : ((kLn32OnePass > 0 && CAST && !RMS && !BFPOUT && VPL == 3 && EPL == 4 && LPR == 64 && RPWO == 0) ? kLn32OnePass - 1 : kRowPace);
   auto load_rows = [&](int64_t r0, RowVec<DT, EPL> (&dst)[RPW][VPL]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
@@ -1081,7 +1088,7 @@ static int norm_dispatch(const void* in, void* out, int dtype_in, int dtype_out,
         break;                                                                                                        \
       }                                                                                                               \
     }                                                                                                                 \
-    if constexpr (CAST && !RMS && (V_) == 3 && (E_) == 8 && (L_) == 32) {                                             \
+    if constexpr (CAST && !RMS && (V_) == 3 && (((E_) == 8 && (L_) == 32) || (kLn32OnePass > 0 && (E_) == 4 && (L_) == 64))) {   \
       /* the LayerNorm MODULE on 16-bit rows of 768 (opt-125m / Whisper-small hidden size): ONE pass per workgroup instead of the persistent */ \
       /* grid, with 32 idle issue cycles between a wave's loads (layernorm_wave_kernel kLnModulePace).  Same-lease library A/B, 24000 x 768  */ \
       /* bf16: 15.26 -> 14.32 us (60.4 -> 64.4 %; pace 2: 14.55; four rows per wave on the persistent grid, pace 0 / 2: 15.50 / 15.53);       */ \
