@@ -371,3 +371,36 @@ def test_bfp_slab_random_cases(dmx, cuda, oracle, chunk):
         want = oracle.bfp_cast(x, wl, B, 1, sym).to(dtype)
         assert mismatches_nan_aware(got, want) == 0, (chunk, done, outer, L, inner, B, dtype, wl, sym)
         done += 1
+
+
+def test_plans_scaled_to_another_cu_count_give_the_same_bits(oracle):
+    """common.hpp plan_cus: the size classes are stated for 256 CUs and scaled by the device's count (DMXQ_PLAN_CUS overrides, read once
+    per process).  Planning for 64 or 304 CUs changes tile geometry only: every result stays bit-exact against the oracle, on sizes
+    that cross the plan boundaries (flat rows, per-group affine, multi-tensor sets)."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = textwrap.dedent("""
+        import sys, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests"); sys.path.insert(0, %r + "/oracle")
+        import dmx_compressor_amd as dmx, oracle as O
+        from _data import make, bits_equal
+        dev = torch.device("cuda:0")
+        for rows in (96, 700, 1800, 2600, 3072, 4096, 5000):
+            x = make("heavy", (rows, 1024), seed=rows, dtype=torch.bfloat16)
+            assert bits_equal(dmx.ops.bfp_qdq(x.to(dev), 8, 16), O.bfp_cast(x, 8, 16).to(torch.bfloat16)) == 0, rows
+            xf = x.float().clamp(-50, 50)
+            sc = (torch.rand(-(-rows // 128)) * 0.05 + 0.01); zp = torch.zeros(sc.numel(), dtype=torch.int64)
+            got = dmx.ops.fixed_qdq(xf.to(dev), 8, 0, True, True, scale=sc.to(dev), zero_point=zp.to(dev), ch_axis=0, group_size=128)
+            assert bits_equal(got, O.fixed_point_affine_cast(xf, 8, 0, True, True, sc, zp, ch_axis=0, group_size=128)) == 0, rows
+        ws = [make("normal", (r, 768), seed=r).to(torch.bfloat16) for r in (768, 3072, 768, 128)]
+        outs = dmx.ops.bfp_qdq_multi([w.to(dev) for w in ws], 8, 64)
+        assert all(bits_equal(o, O.bfp_cast(w, 8, 64).to(torch.bfloat16)) == 0 for o, w in zip(outs, ws))
+        print("OK")
+    """ % (root, root, root))
+    for cus in ("64", "304"):
+        env = dict(os.environ, DMXQ_PLAN_CUS=cus)
+        p = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "OK" in p.stdout, (cus, p.stderr[-1500:])
