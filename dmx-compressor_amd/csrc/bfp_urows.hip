@@ -139,17 +139,28 @@ template <int DTI, int DTO, int RND, bool ASYM>
 static int launch_urows(const void* in, void* out, int64_t rows, int64_t L, int64_t B, int wl, int rounding,
                         uint64_t seed, hipStream_t s) {
   constexpr int EPL = 16 / Elem<DTI>::bytes;
-  constexpr int UNROLL = 3;  // 2..4 are within 3 % of each other, 8 is 10 % slower (rows of 1500 / 4088 / 4100)
+  // vectors per lane: 3 (2..4 are within 3 % of each other on rows of 1500 / 4088 / 4100 at 100+ MB, 8 is 10 % slower), and 6 for
+  // tensors of up to 24 MiB of lane-vectors -- the rule of every streaming kernel here, more of a small tensor in flight per
+  // workgroup: [8, 12, 64, 1500] bf16 (Whisper's attention probabilities, 37 MB moved) 9.73 -> 9.03 us, [2048, 1500] 10.4 -> 10.0,
+  // while 18000 x 1500 LOSES 5 % with 6 (same-lease A/B of four builds, profiles/r06_ab_stragglers.txt).  -DDMXQ_EXP_UROWS_UNROLL=N: A/B builds.
+#ifdef DMXQ_EXP_UROWS_UNROLL
+  constexpr int U_BIG = DMXQ_EXP_UROWS_UNROLL, U_SMALL = DMXQ_EXP_UROWS_UNROLL;
+#else
+  constexpr int U_BIG = 3, U_SMALL = 6;
+#endif
   const int lpb = (int)(B / EPL);
   const int64_t nvr = (L + EPL - 1) / EPL, nvrp = (nvr + lpb - 1) / lpb * lpb;
   const int tail = (int)(L - (nvr - 1) * EPL);  // 1..EPL elements in the last vector of a row
   const int back = (tail < EPL && L % B >= EPL && in != out) ? EPL - tail : 0;
-  const int64_t tiles = (rows * nvrp + (int64_t)kThreads * UNROLL - 1) / ((int64_t)kThreads * UNROLL);
+  const bool small = plan_norm(rows * nvrp) <= ((int64_t)3 << 19);
+  const int unroll = small ? U_SMALL : U_BIG;
+  const int64_t tiles = (rows * nvrp + (int64_t)kThreads * unroll - 1) / ((int64_t)kThreads * unroll);
   const int grid = (int)(tiles < (1 << 20) ? tiles : (1 << 20));
   const int fast = (RND == DMXQ_ROUND_NEAREST && wl <= 20) ? (bfp_single_rounding_ok<DTI>(wl) ? 2 : 1) : 0;
-#define DMXQ_UR(F_)                                                                                                \
-  DMXQ_LAUNCH((bfp_urows_kernel<DTI, DTO, RND, ASYM, F_, UNROLL>), dim3(grid), dim3(kThreads), 0, s, in, out, \
+#define DMXQ_UR1(F_, U_)                                                                                           \
+  DMXQ_LAUNCH((bfp_urows_kernel<DTI, DTO, RND, ASYM, F_, U_>), dim3(grid), dim3(kThreads), 0, s, in, out,          \
                      rows, L, (int)nvr, (int)nvrp, tail, back, lpb, wl, rounding, seed)
+#define DMXQ_UR(F_) do { if (small) DMXQ_UR1(F_, U_SMALL); else DMXQ_UR1(F_, U_BIG); } while (0)
   constexpr bool in16 = Elem<DTI>::bytes == 2;
   if constexpr (RND == kRuntimeRounding) {
     DMXQ_UR(0);
@@ -161,6 +172,7 @@ static int launch_urows(const void* in, void* out, int64_t rows, int64_t L, int6
     }
   }
 #undef DMXQ_UR
+#undef DMXQ_UR1
   return launch_status();
 }
 
