@@ -226,13 +226,19 @@ extern "C" int dmxq_internal_bfp_slab(const void* in, void* out, int dtype_in, i
   const int threads = big ? 1024 : 256;
   const int nvl = (int)(((B * inner) / 8 + threads - 1) / threads);   // vectors of a full tile per lane
   if (nvl > 16 || (big && (nvl > 8 || per == 64))) return DMXQ_ERR_UNSUPPORTED;   // (B = 256 at 1024 lanes would spill: 128 VGPRs)
+  // persistent workgroups only where ONE workgroup fits a CU (the 1024-lane form: 54.7 % against 48.2 % with one tile per workgroup on
+  // [64,512,28,28]); with several workgroups per CU their phases overlap by themselves and one tile per workgroup is as fast (14 x 14
+  // maps: 65.6 vs 66.0 %) or faster ([8,32,2048,128] along the sequence, 16 KiB slabs: 76.3 vs 67.7 %) -- profiles/r06_slab_ab4*.txt.
+  // -DDMXQ_SLAB_PERSIST / env DMXQ_SLAB_PERSIST=0|1 force either (A/B runs).
+  static const int forced_persist = [] { const char* e = getenv("DMXQ_SLAB_PERSIST"); return e ? atoi(e) : -1; }();
+  const bool persistent = forced_persist >= 0 ? forced_persist != 0 : big;
   int rc_unsupported = 0;
 #define DMXQ_SL5(K_, T_)                                                                                                            \
   do {                                                                                                                              \
     int per_cu = slab_resident((const void*)(K_), T_, lds);                                                                         \
     if (per_cu < 1) { rc_unsupported = 1; break; }                                                                                  \
     int64_t grid = (int64_t)per_cu * plan_cus();                                                                                    \
-    if (grid > tiles) grid = tiles;                                                                                                 \
+    if (grid > tiles || !persistent) grid = tiles;                                                                                  \
     DMXQ_LAUNCH((K_), dim3((unsigned)grid), dim3(T_), lds, s, a, (uint32_t)tiles);                                                  \
   } while (0)
 #define DMXQ_SL3(D_, A_, F_, P_)                                                                                                    \

@@ -19,7 +19,8 @@ def bench(name, f, byt, iters=100):
     us = a.elapsed_time(b) * 1000 / iters
     print(f"{name:48s} {us:8.2f} us {byt / us / 1e3 / 80:5.1f}%", flush=True)
 for shape, dim, B in (((64, 256, 56, 56), 1, 64), ((64, 512, 28, 28), 1, 64), ((64, 1024, 14, 14), 1, 64), ((256, 1024, 14, 14), 1, 64), ((64, 3, 224, 224), 1, 64),
-                      ((8, 12, 1500, 64), -2, 64), ((8, 32, 2048, 128), -2, 64), ((64, 64, 112, 112), 1, 64)):
+                      ((8, 12, 1500, 64), -2, 64), ((8, 32, 2048, 128), -2, 64), ((64, 64, 112, 112), 1, 64),
+                      ((16, 16, 1024, 256), -2, 64), ((8, 64, 1024, 192), -2, 64), ((8, 32, 2048, 128), -2, 128), ((32, 32, 256, 128), -2, 32)):
     xs = [torch.randn(*shape, device=dev).to(torch.bfloat16) for _ in range(max(2, int(6e8 // (torch.tensor(shape).prod().item() * 2))))]
     i = [0]
     def f():
