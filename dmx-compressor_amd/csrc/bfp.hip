@@ -203,11 +203,10 @@ static bool slab_preferred(int dtype_in, int64_t L, int64_t inner, int64_t B) {
   (void)dtype_in; (void)L;
   // rows that are NOT whole 128-byte lines (14 x 14, 28 x 28 maps: the column kernel's row pieces share their first and last line with the
   // neighbouring piece, 50 % of the roofline) and slabs of at least 16 KiB (smaller tiles are all overhead: [8, 12, 1500, 64] along the
-  // sequence 38 % here, 54 % there).  Whole-line rows: the slab kernel for rows of up to 256 bytes (attention operands blocked along the
-  // sequence, head dim 128: [8, 32, 2048, 128] B = 64 / 128: 76 / 71 % against 73 / 62 %) while a slab is 16-64 KiB; longer whole-line rows
-  // stay with the column kernel (rows of 384 / 512 bytes: 75-76 / 73 % there, 75 / 71 % here; 56 x 56 maps 69 %, and their slabs do not fit).
-  // profiles/r06_slab_ab3 / ab4 / ab6.
-  if ((inner * 2) % 128 == 0) return inner * 2 <= 256 && B * inner * 2 >= 16 * 1024 && B * inner * 2 <= 64 * 1024;
+  // sequence 38 % here, 54 % there).  Whole-line rows stay with the column kernel: on 134 MB of attention operands blocked along the
+  // sequence the slab kernel is ahead for rows of 256 bytes ([8, 32, 2048, 128] B = 64 / 128: 76 / 71 % against 73 / 62 %) and behind for
+  // 384 / 512 bytes, but at the sizes a decoder layer has it is BEHIND ([4, 32, 512, 128]: 7.3 vs 6.3 us inside a graph) and a configured
+  // Llama layer's graph went 617-621 -> 632-634 us with that routing (profiles/r06_slab_ab6*.txt, r06_slab_small_operands.txt).
   return (inner * 2) % 128 != 0 && B * inner * 2 >= 16 * 1024;
 }
 
