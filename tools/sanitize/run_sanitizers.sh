@@ -52,7 +52,7 @@ subprocess.check_call([cc, "-O1", "-g", "-fPIC", "-std=c++17", "-D__HIP_PLATFORM
                        "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-sanitize=vptr", "-shared-libsan", "-fno-omit-frame-pointer",
                        "-mllvm", "-asan-globals=0"] + inc + ["-c", B.CSRC + "/torch_binding.cpp", "-o", out + "/torch_binding_asan.o"])
 subprocess.check_call([cc, "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libsan", "-o", out + "/dmxq_torch_asan.so", out + "/torch_binding_asan.o",
-                       "-L" + out, "-ldmxq_asan", "-Wl,-rpath," + out, "-L" + tlib, "-Wl,-rpath," + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip"])
+                       "-L" + out, "-ldmxq_asan", "-Wl,-rpath," + out, "-L" + tlib, "-Wl,-rpath," + tlib, "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", "-ltorch_python"])
 PY
 env $E DMXQ_TORCH_LIB_PATH=$SO/dmxq_torch_asan.so python tools/sanitize/torch_binding_driver.py 2>&1 | tail -3 || fail=1
 echo

@@ -56,4 +56,23 @@ for dt in (torch.bfloat16, torch.float16, torch.float32):
     both("group_minmax", lambda dev: (t(dev, 256, 64, dtype=dt), 0, 128))
     both("channel_maxabs", lambda dev: (t(dev, 256, 64, dtype=dt), -1))
     both("scale_channels", lambda dev: (t(dev, 256, 64, dtype=dt), t(dev, 64, dtype=torch.float32), -1, True, None))
-print(f"torch binding driver: {n_meta} meta-kernel calls, {n_cpu} CPU-tensor calls refused, on {_backend_torch.TORCH_LIB_PATH}")
+# the dispatcher-free entry points (PyInit_dmxq_fast in the same shared object): argument conversion and the refusal of CPU tensors
+n_fast = 0
+F = _backend_torch.FAST
+assert F is not None, "the instrumented binding has no direct entry points"
+x = torch.randn(4, 64)
+f16 = [10, 5, 15, 1]
+for name, args in (("bfp_qdq", (x, 8, 16)), ("bfp_qdq", (x, 8, 16, -1, True, 2, torch.float32, 0)), ("float_qdq", (x, 10, 5, 15, True)),
+                   ("fixed_qdq", (x, 8, 0, True, True, 2, None, None, None, None)), ("sbfp_qdq", (x, 4, 16, 4, 4, 7, True, True, True)),
+                   ("mxfp_qdq", (x, 3, 4, 32)), ("weight_hypernet", (x, 8, 64, True, None, 0, 0, None)), ("input_hypernet", (x, torch.ones(64), 8, 64, True)),
+                   ("binary_cast", (x, x, 0, f16, f16, f16)), ("relu_cast", (x, f16, f16)), ("scale_channels", (x, torch.ones(64), -1, True)),
+                   ("unary_cast", (x, 0, 0.0, f16, f16)), ("lut16_apply", (x, x)), ("softmax_cast", (x, float("-inf"), f16, f16)),
+                   ("norm_cast", (x, 64, None, None, 1e-5, 0, f16, f16))):
+    try:
+        getattr(F, name)(*args)
+    except (RuntimeError, NotImplementedError, TypeError):
+        n_fast += 1
+    else:
+        raise AssertionError(f"dmxq_fast.{name} accepted CPU tensors")
+print(f"torch binding driver: {n_meta} meta-kernel calls, {n_cpu} CPU-tensor calls refused through the dispatcher, {n_fast} through the direct entry points, "
+      f"on {_backend_torch.TORCH_LIB_PATH}")
