@@ -322,6 +322,9 @@ typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 // trait (`static constexpr int kLoadPace`), default 0, set only where the gain was >= 5 % over a range of N.
 template <class OP, class = void> struct OpLoadPace { static constexpr int value = 0; };
 template <class OP> struct OpLoadPace<OP, decltype((void)OP::kLoadPace)> { static constexpr int value = OP::kLoadPace; };
+// (the op's pace for a launch with 8-byte loads -- 16-bit -> float32 --, where it differs: `static constexpr int kLoadPaceWide`)
+template <class OP, class = void> struct OpLoadPaceWide { static constexpr int value = OpLoadPace<OP>::value; };
+template <class OP> struct OpLoadPaceWide<OP, decltype((void)OP::kLoadPaceWide)> { static constexpr int value = OP::kLoadPaceWide; };
 template <int N>
 __device__ __forceinline__ void pace_issue() {
   if constexpr (N > 0) {

@@ -384,6 +384,10 @@ struct ScaleOp {
   // lastdim_kernel, x * s: 16 idle issue cycles between a lane's row loads (common.hpp OpLoadPace: 4096 x 4096 bf16 12.4 -> 11.2 us,
   // the same for 2 .. 12); x / s carries ~54 VALU per row behind its loads and LOSES with any pace (11.9 -> 13.7+)
   static constexpr int kLoadPace = DIVIDE ? 0 : 2;
+  // ... and for the WIDENING launch (16-bit -> float32: 8-byte loads, lastdim.hpp IVB == 8) of the division too (round 6, same-lease A/B of
+  // three builds, bf16 -> float32 x / s on 4096 x 4096: 19.67 -> 17.50 us with 2, 17.38 with 4 -- 63 -> 70 % -- while the same-width
+  // division LOSES with either: 11.55 -> 13.75 / 14.07 us; profiles/r06_ab_stragglers.txt)
+  static constexpr int kLoadPaceWide = 2;
   __device__ __forceinline__ void apply_one(float x, float& y, int64_t e) const {
     ChanIter it;
     it.start(cm, e);

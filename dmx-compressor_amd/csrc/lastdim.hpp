@@ -173,7 +173,7 @@ static int launch_lastdim_typed(const void* in, void* out, int64_t rows, int64_t
 #ifdef DMXQ_EXP_LD_PACE
   constexpr int kPace = DMXQ_EXP_LD_PACE;
 #else
-  constexpr int kPace = OpLoadPace<OP>::value;   // common.hpp: idle issue cycles between a lane's row loads
+  constexpr int kPace = IVB == 8 ? OpLoadPaceWide<OP>::value : OpLoadPace<OP>::value;   // common.hpp: idle issue cycles between a lane's row loads
 #endif
 #define DMXQ_LDK(R_)                                                                                                          \
   DMXQ_LAUNCH((lastdim_kernel<DTI, DTO, OP, kThreads, R_, IVB, kPace>), dim3((unsigned)pl.gx, (unsigned)pl.strips), dim3(kThreads), 0, s, in, out, rows, C, \
