@@ -22,7 +22,7 @@ def _run(extra, port, n=2, plain=False):
                                          "--replays", "3", "--no-cpu-baseline", "--no-tier2"] + extra
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1100 if n > 2 else 600)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=500 if n > 2 else 300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]     # rank 0 prints ONE JSON line
@@ -61,7 +61,7 @@ def test_bench_two_ranks_share_one_gpu_over_gloo(extra, scaling):
     assert line["value"] > 0
 
 
-@pytest.mark.timeout(1200)
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("extra,scaling", [([], "weak"), (["--workload", "llama-shard", "--op", "hypernet", "--layers", "1"], "strong")])
 def test_bench_eight_ranks_share_one_gpu_over_gloo(extra, scaling):
     """The N = 8 rehearsal (round 5): world = 8 on the lease's one GPU over gloo -- the driver's 8-GPU run must not be the first time
