@@ -11,8 +11,9 @@
 // row: two blocks) and every Q-th row of it; the Q lanes of a pair are neighbours (block maxima through quad DPP permutes).  Row pitch
 // = 32 / Q (mod 32) dwords: the 32 lanes of a half-wave -- 32 / Q column pairs x Q rows -- then fall into 32 different banks for the b32
 // reads and writes.  Slabs up to 64 KiB: workgroups of 256 lanes, several per CU; up to 150 KiB (28 x 28 maps, B = 64: 98 KiB): ONE
-// workgroup of 1024 lanes per CU.  A tile's loads are all in flight at once (NV per lane); workgroups are persistent (the grid is
-// one resident round) and hold the NEXT tile's loads in registers while they work on the current one in the LDS.
+// workgroup of 1024 lanes per CU.  A tile's loads are all in flight at once (NV per lane).  The 256-lane form runs one tile per
+// workgroup; the 1024-lane form is PERSISTENT (the grid is one resident round) and holds the NEXT tile's loads in registers while it
+// works on the current one in the LDS (the launcher's `persistent`: measured both ways, profiles/r06_slab_ab4 / ab6).
 // HBM traffic is one read and one write per element; arithmetic and results are those of every other BFP kernel (bfp_math.hpp).
 // Scope: 16-bit tensors, same dtype in and out, nearest rounding, B = 2^k in [8, 256], even inner; in place allowed (a tile is read
 // completely before it is written, tiles are disjoint).  (A SEGMENTED form -- tiles of B rows x a column range for slabs that do not
