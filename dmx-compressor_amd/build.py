@@ -123,6 +123,33 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+FENCES_LIB = os.path.join(HERE, "lib", "libdmxq_gate_fences.so")
+
+
+def build_gate_fences_variant(verbose: bool = False) -> str:
+    """lib/libdmxq_gate_fences.so: the product's objects with csrc/reduce.hip rebuilt -DDMXQ_GATE_FENCES=1 -- the FORMAL release / acquire
+    form of the reductions' init gate (the default build orders with s_waitcnt + sc1 stores: a hardware argument, include/dmxq.h).
+    Not used by the product; tests/test_gpu_round6.py runs the gate's stress tests against BOTH builds, loading this one
+    through DMXQ_BINDING=ctypes DMXQ_LIB_PATH.  Built by __graft_entry__.build() so that it travels to the GPU box."""
+    src = os.path.join(CSRC, "reduce.hip")
+    base = os.path.join(OBJ, "reduce.o")
+    obj = os.path.join(OBJ, "reduce_gate_fences.obj")   # (not *.o: build() links every *.o of this directory's product list only, but keep it apart anyway)
+    deps = [src, os.path.join(CSRC, "gate_registry.hpp"), os.path.join(CSRC, "common.hpp"), os.path.abspath(__file__)]
+    if _stale(obj, deps):
+        cmd = [_hipcc()] + FLAGS + ["-DDMXQ_GATE_FENCES=1", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    objs = []
+    for spec in SOURCES:
+        s_, _, part = spec.partition("#")
+        o = os.path.join(OBJ, s_.replace(".hip", f"_p{part}.o" if part else ".o"))
+        objs.append(obj if o == base else o)
+    if _stale(FENCES_LIB, objs):
+        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "--offload-compress", "-shared", "-fPIC", "-o", FENCES_LIB] + objs)
+    return FENCES_LIB
+
+
 def _torch_flags():
     import sysconfig
 

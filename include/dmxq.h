@@ -19,7 +19,7 @@
  *     i.e. it relies on gfx950 acknowledging an `sc1` store only once it is visible at the agent coherence point (all eight XCD L2s)
  *     and on atomics never being served from a stale cached line.  That is behaviour of this hardware, not a guarantee of the LLVM
  *     AMDGPU memory model; `-DDMXQ_GATE_FENCES=1` builds the formal release / acquire form (measured slower than the fill launch it
- *     replaces, profiles/r05_gate_ab.txt), and DMXQ_NO_INIT_GATE=1 removes the protocol at run time);
+ *     replaces, profiles/r05_gate_ab.txt; built as lib/libdmxq_gate_fences.so and put through the same stress tests, tests/test_gpu_round6.py), and DMXQ_NO_INIT_GATE=1 removes the protocol at run time);
  *   - caller-allocated outputs (the reference allocates with zeros_like and returns a new tensor,
  *     quant_cuda.cpp:116-139 — the host mirror keeps that ownership contract above this ABI);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are asynchronous;

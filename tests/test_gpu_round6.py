@@ -404,3 +404,21 @@ def test_plans_scaled_to_another_cu_count_give_the_same_bits(oracle):
         env = dict(os.environ, DMXQ_PLAN_CUS=cus)
         p = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "OK" in p.stdout, (cus, p.stderr[-1500:])
+
+
+def test_init_gate_stress_tests_on_the_formal_fence_build_too():
+    """the init gate of the reductions is built two ways -- the default (s_waitcnt + sc1 stores: an argument about this
+    hardware) and -DDMXQ_GATE_FENCES=1 (release / acquire fences of the LLVM AMDGPU memory model).  The takeover, filler-kernel,
+    multi-stream / capture and concurrent-host-thread tests of rounds 4-5 run in the main suite on the default build; here the SAME tests
+    run against lib/libdmxq_gate_fences.so (build.py build_gate_fences_variant), loaded through the ctypes binding."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "dmx-compressor_amd", "lib", "libdmxq_gate_fences.so")
+    assert os.path.exists(lib), "libdmxq_gate_fences.so missing: run __graft_entry__.build()"
+    env = dict(os.environ, DMXQ_BINDING="ctypes", DMXQ_LIB_PATH=lib)
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_round5.py"), os.path.join(root, "tests", "test_gpu_round4.py"),
+                        "-m", "gpu", "-q", "-x", "-k", "init_gate", "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout
